@@ -1,0 +1,210 @@
+/*
+ * np_hip.h — C ABI of the MI355X (gfx950) device back end for NumPower's fp32 hot path.
+ *
+ * This is the drop-in boundary: plain C, raw device pointers, size_t counts, int status.
+ * It replaces the reference's inner (C <-> device back end) interface, i.e.
+ *   - src/gpu_alloc.h:8-15            (vmalloc / vfree / vmemcpy* / vmemcheck / NDArray_VFLOAT)
+ *   - src/ndmath/cuda/cuda_math.h:14-79 (cuda_*_float, cuda_float_*, cuda_sum/prod/min/max_float,
+ *                                        cuda_fill_float, cuda_float_multiply_matrix_vector)
+ *   - the cublasSgemm call in src/ndmath/linalg.c:55-71
+ * Every entry point cites the reference symbol it stands in for.  All paths are relative to
+ * the reference tree (NumPower/numpower @ 2024_08_07).
+ *
+ * Conventions
+ *   - every function returns NP_OK (0) or a negative np_status; np_last_error() returns the
+ *     message of the last failure on the calling thread.
+ *   - pointers are DEVICE pointers unless the parameter name starts with `host`.
+ *   - all arrays are contiguous C-order fp32 (the reference's only dtype on this path,
+ *     src/types.h:5); the ops never look at strides (same contract as arithmetics.c).
+ *   - work is enqueued on the library stream (np_get_stream/np_set_stream) and is asynchronous;
+ *     np_sync(), np_memcpy_d2h() and the host_out reductions are the only blocking calls.
+ *     (The reference synchronises after every launch, cuda_math.cu:1104-1109; results are
+ *     identical, only the blocking point moves to the read-back.)
+ *   - no torch / PHP / Zend types anywhere in this file.
+ */
+#ifndef NUMPOWER_AMD_NP_HIP_H
+#define NUMPOWER_AMD_NP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum np_status {
+    NP_OK = 0,
+    NP_ERR_INVALID = -1,   /* bad argument (null pointer, unknown op, bad shape)          */
+    NP_ERR_ALLOC = -2,     /* "device memory allocation failed" (gpu_alloc.c:15)          */
+    NP_ERR_DEVICE = -3,    /* HIP runtime error (message in np_last_error)                */
+    NP_ERR_NODEVICE = -4   /* "No GPU device available" (numpower.c:525)                  */
+} np_status;
+
+/* ---- runtime ------------------------------------------------------------------------ */
+
+/* Select the device and create the library stream.  Replaces the implicit CUDA context
+ * creation of the reference; np_set_device mirrors NDArray::setDevice -> cudaSetDevice
+ * (numpower.c:615-635). */
+int np_init(int device);
+int np_set_device(int device);
+int np_device_count(int *host_count);
+int np_sync(void);
+const char *np_last_error(void);
+/* Library version string, e.g. "numpower_amd 0.1 gfx950". */
+const char *np_version(void);
+
+/* Stream plumbing: the library launches on one stream.  By default it owns a non-blocking
+ * stream; a caller that already has one (e.g. torch's current stream, passed as the raw
+ * hipStream_t) can hand it in.  Pass NULL to go back to the library-owned stream. */
+int np_set_stream(void *hip_stream);
+void *np_get_stream(void);
+
+/* Event timing on the library stream (used by bench.py; hipEvent based). */
+int np_timer_create(void **timer);
+int np_timer_start(void *timer);
+int np_timer_stop(void *timer);
+int np_timer_elapsed_ms(void *timer, float *host_ms);   /* blocks until stop event done */
+int np_timer_destroy(void *timer);
+
+/* ---- device-buffer layer (replaces src/gpu_alloc.c) ---------------------------------- */
+
+/* vmalloc (gpu_alloc.c:11-17).  size_t instead of the reference's `unsigned int` (4 GiB cap).
+ * Served from a caching sub-allocator (freed blocks are kept per size class and reused, so the
+ * per-op result allocation of arithmetics.c:211-231 does not reach hipMalloc in steady state).
+ * Bumps the live-allocation counter that np_live_allocs() reports. */
+int np_malloc(void **dev_ptr, size_t bytes);
+/* vfree (gpu_alloc.c:30-33). */
+int np_free(void *dev_ptr);
+/* vmemcheck (gpu_alloc.c:36-40): number of live np_malloc blocks (NDARRAY_VCHECK parity). */
+long np_live_allocs(void);
+/* Return all cached (free) blocks to the driver; returns bytes released through *host_bytes. */
+int np_pool_trim(size_t *host_bytes);
+/* Bytes currently held by the pool (live + cached). */
+size_t np_pool_reserved_bytes(void);
+
+/* vmemcpyh2d (gpu_alloc.c:25-27) / the cudaMemcpy H2D of NDArray_ToGPU (ndarray.c:1054). */
+int np_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes);
+/* The cudaMemcpy D2H of NDArray_ToCPU (ndarray.c:1090); blocks until the data is on the host. */
+int np_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes);
+/* vmemcpyd2d (gpu_alloc.c:20-22).  NOTE argument order here is (dst, src). */
+int np_memcpy_d2d(void *dev_dst, const void *dev_src, size_t bytes);
+/* cudaMemset(…, 0, …) of NDArray_Zeros (initializers.c:437-446). */
+int np_memset0(void *dev_ptr, size_t bytes);
+/* cuda_fill_float (cuda_math.cu:829,912). */
+int np_fill(float *dev_ptr, float value, size_t n);
+/* NDArray_VFLOAT / NDArray_VFLOATF_I (gpu_alloc.c:43-54): one float back to the host. */
+int np_read_float(const float *dev_ptr, size_t index, float *host_out);
+
+/* ---- binary elementwise with fused broadcast ------------------------------------------ */
+
+/* Ops of NDArray_{Add,Subtract,Multiply,Divide,Mod,Pow}_Float (arithmetics.c:160-926) and
+ * float_arctan2 (double_math.c:259-261, cuda_float_arctan2 cuda_math.cu:489,1224). */
+typedef enum np_binary_op {
+    NP_ADD = 0, NP_SUBTRACT = 1, NP_MULTIPLY = 2, NP_DIVIDE = 3, NP_MOD = 4, NP_POW = 5,
+    NP_ARCTAN2 = 6,
+    NP_BINARY_OP_COUNT
+} np_binary_op;
+
+/* How an operand maps onto the rows x cols output.  These are exactly the patterns
+ * NDArray_Broadcast materialises (ndarray.c:1196-1291); here they are index arithmetic
+ * inside the kernel, no temporary is written. */
+typedef enum np_operand_kind {
+    NP_FULL = 0,    /* rows*cols elements                                                   */
+    NP_SCALAR = 1,  /* 1 element        (0-d scalar expand, arithmetics.c:169-181)          */
+    NP_ROW = 2,     /* cols elements    (1-D / 1xC -> every row, ndarray.c:1202-1223,1273)  */
+    NP_COL = 3      /* rows elements    (Rx1 -> every column, ndarray.c:1226-1272)          */
+} np_operand_kind;
+
+/* Result-visible CPU-path quirks of the reference that the kernel can reproduce so that GPU
+ * results equal the reference's AVX2 CPU results element for element:
+ *   NP_QUIRK_AVX_BODY  — elements with index < body_end behave like the AVX2 loop body,
+ *                        the rest like the scalar tail:
+ *       multiply: body turns every zero product into -0.0f (fix_negative_zero,
+ *                 arithmetics.c:280-284,403), tail turns -0.0f into +0.0f (:410-412)
+ *       mod:      body is a - floor(a/b)*b (arithmetics.c:794), tail is fmodf (:800)
+ *   body_end is what the loop `for (i = 0; i < numel(a) - 7; i += 8)` covers, see
+ *   np_avx_body_end().  flags = 0 gives plain IEEE multiply / C fmodf for every element
+ *   (what the reference's own CUDA kernels do, cuda_math.cu:617-631). */
+#define NP_QUIRK_AVX_BODY 1u
+
+/* Number of leading elements covered by the reference's 8-wide AVX2 loop when the loop bound
+ * is `numel_a - 7` (arithmetics.c:251): 0 if numel_a < 8, else 8*ceil((numel_a-7)/8). */
+size_t np_avx_body_end(size_t numel_a);
+
+/* out[r*cols + c] = a[...] op b[...];  replaces cuda_{add,subtract,multiply,divide,mod,pow}_float
+ * (cuda_math.cu:1064-1109) + the Zeros/Fill/Broadcast temporaries in front of them. */
+int np_binary(int op, const float *a, int a_kind, const float *b, int b_kind, float *out,
+              size_t rows, size_t cols, unsigned flags, size_t body_end);
+
+/* ---- unary elementwise ------------------------------------------------------------------ */
+
+/* The float_* kernels of src/ndmath/double_math.c:9-265 (order follows double_math.h:7-44). */
+typedef enum np_unary_op {
+    NP_ABS = 0, NP_SQRT, NP_EXP, NP_EXP2, NP_EXPM1, NP_LOG, NP_LOG2, NP_LOG10, NP_LOG1P, NP_LOGB,
+    NP_SIN, NP_COS, NP_TAN, NP_ARCSIN, NP_ARCCOS, NP_ARCTAN, NP_DEGREES, NP_RADIANS,
+    NP_SINH, NP_COSH, NP_TANH, NP_ARCSINH, NP_ARCCOSH, NP_ARCTANH,
+    NP_RINT, NP_FIX, NP_FLOOR, NP_CEIL, NP_TRUNC, NP_SINC, NP_NEGATE, NP_SIGN,
+    NP_CLIP,        /* p0 = min, p1 = max            (float_clip, double_math.c:250-252)    */
+    NP_ROUND,       /* p0 = decimals                 (float_round, double_math.c:254-257)   */
+    NP_RSQRT,       /* 0x5f3759df bit hack + 1 Newton step (float_rsqrt, :111-126)          */
+    NP_POSITIVE, NP_RECIPROCAL,
+    NP_UNARY_OP_COUNT
+} np_unary_op;
+
+/* out[i] = f(in[i]); in == out is allowed.  Replaces NDArrayMathGPU_ElementWise{,1F,2F}
+ * (cuda_math.cu:1532-1558) and the unary kernels behind them, without the preceding
+ * NDArray_Copy (one 8 B/elem pass instead of copy + in-place = 16 B/elem). */
+int np_unary(int op, const float *in, float *out, size_t n, float p0, float p1);
+
+/* ---- reductions -------------------------------------------------------------------------- */
+
+typedef enum np_reduce_op {
+    NP_SUM = 0, NP_PROD = 1, NP_MIN = 2, NP_MAX = 3, NP_MEAN = 4,
+    NP_REDUCE_OP_COUNT
+} np_reduce_op;
+
+/* Full reduction to one host float.  Replaces cuda_sum_float / cuda_prod_float /
+ * cuda_min_float / cuda_max_float (cuda_math.cu:921,934,1032,1016).  Deterministic two-pass
+ * (wave64 shuffle + LDS, then one block over the per-block partials); no float atomics. */
+int np_reduce_all(int op, const float *in, size_t n, float *host_out);
+/* Same, result left on the device (1 float). */
+int np_reduce_all_dev(int op, const float *in, size_t n, float *dev_out);
+
+/* Reduce the middle axis of a contiguous array viewed as outer x axis_len x inner; out has
+ * outer*inner elements.  Replaces the host-side recursion reduce()/_reduce()/apply_reduce()
+ * (ndarray.c:523-578,394-429,358-368), which issues one Add_Float + alloc + D2D copy + free
+ * per slice, by one (or two) kernels.
+ * flags: NP_QUIRK_AVX_BODY with NP_PROD reproduces the sign the reference's repeated
+ * NDArray_Multiply_Float leaves on ZERO results (arithmetics.c:403,410-412): -0.0f for inner
+ * index < np_avx_body_end(inner), +0.0f after it; pass it only when the reduced slices are
+ * at least 1-D (0-d slices take the plain a*b short cut, arithmetics.c:302-316). */
+int np_reduce_axis(int op, const float *in, size_t outer, size_t axis_len, size_t inner,
+                   float *out, unsigned flags);
+/* Scratch the axis reduction may need for its partials, in bytes (0 if none); the library
+ * allocates it from the pool itself — exported so callers can size memory budgets. */
+size_t np_reduce_axis_workspace(size_t outer, size_t axis_len, size_t inner);
+
+/* ---- matmul --------------------------------------------------------------------------------- */
+
+/* C[MxN] = A[MxK] . B[KxN], row-major, alpha = 1, beta = 0, exact fp32 (v_mfma_f32_32x32x2_f32).
+ * Replaces cblas_sgemm(RowMajor,N,N,…) / cublasSgemm in NDArray_FMatmul (linalg.c:44-82). */
+int np_sgemm(size_t M, size_t N, size_t K, const float *A, const float *B, float *C);
+/* batch independent products; matrix b of X starts at X + b*stride_x (strides in elements).
+ * The reference has no batched entry point (linalg.c:239-242 rejects ndim > 2); this is the
+ * loop-of-2-D-calls collapsed into one launch (BASELINE config 5). */
+int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K,
+                             const float *A, size_t stride_a, const float *B, size_t stride_b,
+                             float *C, size_t stride_c);
+/* y[M] = A[MxN] . x[N]; replaces cblas_sgemv / matrixVectorMultiplyFloatKernel
+ * (linalg.c:367-386, cuda_math.cu:228,1417). */
+int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y);
+
+/* Kernel-variant selection for tuning/benchmarks (0 = default heuristic). */
+int np_sgemm_set_variant(int variant);
+int np_elementwise_set_variant(int variant);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NUMPOWER_AMD_NP_HIP_H */

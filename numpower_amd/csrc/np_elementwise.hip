@@ -1,0 +1,536 @@
+// Elementwise kernels of libnp_hip.so: binary ops with fused scalar/row/column broadcast, the
+// unary float_* family, and fill.  HBM-bound streaming kernels: 16 B per lane per access
+// (global_load/store_dwordx4), several independent accesses in flight per lane, grid sized to a
+// few workgroups per CU with a grid-stride loop.  No LDS, no MFMA: nothing here has reuse.
+//
+// Reference behaviour restated (file:line relative to the reference tree):
+//   binary ops      src/ndmath/arithmetics.c:160-926  (+ CUDA kernels cuda_math.cu:593-633)
+//   broadcast       src/ndarray.c:1172-1294           (materialised there, index math here)
+//   unary ops       src/ndmath/double_math.c:9-265    (+ CUDA kernels cuda_math.cu:207-585)
+//   fill            cuda_math.cu:829,912
+#include <math.h>
+
+#include "np_internal.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// scalar op bodies
+// ------------------------------------------------------------------------------------------
+
+// `body` = element lies in the range the reference's AVX2 loop covers (only meaningful when the
+// caller asked for NP_QUIRK_AVX_BODY); QUIRK=false gives plain IEEE / C semantics.
+template <int OP, bool QUIRK>
+__device__ __forceinline__ float binary_apply(float a, float b, bool body) {
+    if constexpr (OP == NP_ADD) return a + b;
+    if constexpr (OP == NP_SUBTRACT) return a - b;
+    if constexpr (OP == NP_DIVIDE) return __fdiv_rn(a, b);
+    if constexpr (OP == NP_MULTIPLY) {
+        float p = a * b;
+        if constexpr (QUIRK) {
+            // arithmetics.c:403 (body: every zero -> -0.0f) / :410-412 (tail: -0.0f -> +0.0f)
+            if (p == 0.0f) p = body ? -0.0f : 0.0f;
+        }
+        return p;
+    }
+    if constexpr (OP == NP_MOD) {
+        if constexpr (QUIRK) {
+            if (body) {
+                // arithmetics.c:794: a - floor(a/b)*b; gcc -march=native contracts the
+                // sub(mul) into one vfnmadd231ps, i.e. a single rounding.
+                float q = floorf(__fdiv_rn(a, b));
+                return __fmaf_rn(-q, b, a);
+            }
+        }
+        return fmodf(a, b);   // arithmetics.c:800, cuda_math.cu:628
+    }
+    if constexpr (OP == NP_POW) return powf(a, b);
+    if constexpr (OP == NP_ARCTAN2) return atan2f(a, b);
+    return 0.0f;
+}
+
+template <int OP>
+__device__ __forceinline__ float unary_apply(float x, float p0, float p1) {
+    if constexpr (OP == NP_ABS) return fabsf(x);
+    if constexpr (OP == NP_SQRT) return __fsqrt_rn(x);
+    if constexpr (OP == NP_EXP) return expf(x);
+    if constexpr (OP == NP_EXP2) return exp2f(x);
+    if constexpr (OP == NP_EXPM1) return expm1f(x);
+    if constexpr (OP == NP_LOG) return logf(x);
+    if constexpr (OP == NP_LOG2) return log2f(x);
+    if constexpr (OP == NP_LOG10) return log10f(x);
+    if constexpr (OP == NP_LOG1P) return log1pf(x);
+    if constexpr (OP == NP_LOGB) return logbf(x);
+    if constexpr (OP == NP_SIN) return sinf(x);
+    if constexpr (OP == NP_COS) return cosf(x);
+    if constexpr (OP == NP_TAN) return tanf(x);
+    if constexpr (OP == NP_ARCSIN) return asinf(x);
+    if constexpr (OP == NP_ARCCOS) return acosf(x);
+    if constexpr (OP == NP_ARCTAN) return atanf(x);
+    // double_math.c:156-162: the constant is built in double from pi ~ 3.1415926535
+    if constexpr (OP == NP_DEGREES) return (float)((double)x * (180.0 / 3.1415926535));
+    if constexpr (OP == NP_RADIANS) return (float)((double)x * (3.1415926535 / 180.0));
+    if constexpr (OP == NP_SINH) return sinhf(x);
+    if constexpr (OP == NP_COSH) return coshf(x);
+    if constexpr (OP == NP_TANH) return tanhf(x);
+    if constexpr (OP == NP_ARCSINH) return asinhf(x);
+    if constexpr (OP == NP_ARCCOSH) return acoshf(x);
+    if constexpr (OP == NP_ARCTANH) return atanhf(x);
+    // double_math.c:200-210: the post-adjust can never fire (rounded - floor is 0 or 1), so
+    // float_rint is rintf: round half to even.
+    if constexpr (OP == NP_RINT) return rintf(x);
+    if constexpr (OP == NP_FIX) return truncf(x);
+    if constexpr (OP == NP_FLOOR) return floorf(x);
+    if constexpr (OP == NP_CEIL) return ceilf(x);
+    if constexpr (OP == NP_TRUNC) return truncf(x);
+    if constexpr (OP == NP_SINC) {
+        // double_math.c:228-235
+        const float pi = 3.1415927f;
+        if (x == 0.0f) x = 1.0e-20f;
+        x = __fmul_rn(pi, x);
+        return __fdiv_rn(sinf(x), x);
+    }
+    if constexpr (OP == NP_NEGATE) return -x;
+    if constexpr (OP == NP_SIGN) return (float)((x > 0.0f) - (x < 0.0f));
+    if constexpr (OP == NP_CLIP) return fminf(p1, fmaxf(x, p0));
+    // double_math.c:254-257 with factor = powf(10, decimals) evaluated on the host (p0)
+    if constexpr (OP == NP_ROUND) return __fdiv_rn(roundf(__fmul_rn(x, p0)), p0);
+    if constexpr (OP == NP_RSQRT) {
+        // double_math.c:111-126; gcc -march=native contracts 1.5 - (x2*y)*y into one fnmadd
+        const float x2 = __fmul_rn(x, 0.5f);
+        unsigned i = __float_as_uint(x);
+        i = 0x5f3759dfu - (i >> 1);
+        float y = __uint_as_float(i);
+        const float t = __fmul_rn(x2, y);
+        const float u = __fmaf_rn(-t, y, 1.5f);
+        return __fmul_rn(y, u);
+    }
+    if constexpr (OP == NP_POSITIVE) return (x < 0.0f) ? -x : x;   // double_math.c:241-244
+    if constexpr (OP == NP_RECIPROCAL) return __fdiv_rn(1.0f, x);
+    return 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// memory helpers
+// ------------------------------------------------------------------------------------------
+
+template <bool NT>
+__device__ __forceinline__ v4f ld4(const float *p) {
+    if constexpr (NT) return __builtin_nontemporal_load((const v4f *)p);
+    return *(const v4f *)p;
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float *p, v4f v) {
+    if constexpr (NT)
+        __builtin_nontemporal_store(v, (v4f *)p);
+    else
+        *(v4f *)p = v;
+}
+
+// Operand fetch for the vector path: `v` is the float4 index into the rows x cols output,
+// cols4 = cols / 4 (the vector path requires cols % 4 == 0 for ROW/COL operands).
+template <int KIND, bool NT, typename I>
+__device__ __forceinline__ v4f fetch4(const float *p, I v, I cols4, float splat) {
+    if constexpr (KIND == NP_FULL) return ld4<NT>(p + (size_t)v * 4);
+    if constexpr (KIND == NP_SCALAR) return v4f{splat, splat, splat, splat};
+    if constexpr (KIND == NP_ROW) return *(const v4f *)(p + (size_t)(v % cols4) * 4);
+    if constexpr (KIND == NP_COL) {
+        const float s = p[(size_t)(v / cols4)];
+        return v4f{s, s, s, s};
+    }
+    return v4f{0, 0, 0, 0};
+}
+
+template <int KIND, typename I>
+__device__ __forceinline__ float fetch1(const float *p, I i, I cols) {
+    if constexpr (KIND == NP_FULL) return p[i];
+    if constexpr (KIND == NP_SCALAR) return p[0];
+    if constexpr (KIND == NP_ROW) return p[i % cols];
+    if constexpr (KIND == NP_COL) return p[i / cols];
+    return 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+
+// Vector path: each lane handles UNROLL float4 per trip, spaced one grid apart so that every
+// wave-level access is a contiguous 1 KiB segment.
+template <int OP, int AK, int BK, bool QUIRK, int UNROLL, bool NT, typename I>
+__global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict__ a,
+                                                         const float *__restrict__ b,
+                                                         float *__restrict__ out, I nvec, I cols4,
+                                                         I tail_start, I n, I body_end) {
+    const I stride = (I)gridDim.x * blockDim.x;
+    const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    float sa = 0.0f, sb = 0.0f;
+    if constexpr (AK == NP_SCALAR) sa = a[0];
+    if constexpr (BK == NP_SCALAR) sb = b[0];
+
+    for (I base = tid; base < nvec; base += stride * UNROLL) {
+        v4f va[UNROLL], vb[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const I v = base + (I)u * stride;
+            if (v < nvec) {
+                va[u] = fetch4<AK, NT, I>(a, v, cols4, sa);
+                vb[u] = fetch4<BK, NT, I>(b, v, cols4, sb);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const I v = base + (I)u * stride;
+            if (v < nvec) {
+                v4f r;
+                const I e = v * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    r[k] = binary_apply<OP, QUIRK>(va[u][k], vb[u][k], (e + k) < body_end);
+                st4<NT>(out + (size_t)v * 4, r);
+            }
+        }
+    }
+    // ragged tail (n % 4 elements), only reachable for FULL/SCALAR operand kinds
+    if (blockIdx.x == 0) {
+        const I i = tail_start + threadIdx.x;
+        if (i < n) {
+            const float x = (AK == NP_SCALAR) ? sa : a[i];
+            const float y = (BK == NP_SCALAR) ? sb : b[i];
+            out[i] = binary_apply<OP, QUIRK>(x, y, i < body_end);
+        }
+    }
+}
+
+// Scalar path: any operand kinds, any shape/alignment.
+template <int OP, bool QUIRK, typename I>
+__global__ __launch_bounds__(256) void binary_scalar_kernel(const float *__restrict__ a, int ak,
+                                                            const float *__restrict__ b, int bk,
+                                                            float *__restrict__ out, I n, I cols,
+                                                            I body_end) {
+    const I stride = (I)gridDim.x * blockDim.x;
+    for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float x, y;
+        switch (ak) {
+            case NP_FULL: x = a[i]; break;
+            case NP_SCALAR: x = a[0]; break;
+            case NP_ROW: x = a[i % cols]; break;
+            default: x = a[i / cols]; break;
+        }
+        switch (bk) {
+            case NP_FULL: y = b[i]; break;
+            case NP_SCALAR: y = b[0]; break;
+            case NP_ROW: y = b[i % cols]; break;
+            default: y = b[i / cols]; break;
+        }
+        out[i] = binary_apply<OP, QUIRK>(x, y, i < body_end);
+    }
+}
+
+template <int OP, int UNROLL, bool NT, typename I>
+__global__ __launch_bounds__(256) void unary_vec_kernel(const float *in, float *out, I nvec,
+                                                        I tail_start, I n, float p0, float p1) {
+    const I stride = (I)gridDim.x * blockDim.x;
+    const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    for (I base = tid; base < nvec; base += stride * UNROLL) {
+        v4f vx[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const I v = base + (I)u * stride;
+            if (v < nvec) vx[u] = ld4<NT>(in + (size_t)v * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const I v = base + (I)u * stride;
+            if (v < nvec) {
+                v4f r;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = unary_apply<OP>(vx[u][k], p0, p1);
+                st4<NT>(out + (size_t)v * 4, r);
+            }
+        }
+    }
+    if (blockIdx.x == 0) {
+        const I i = tail_start + threadIdx.x;
+        if (i < n) out[i] = unary_apply<OP>(in[i], p0, p1);
+    }
+}
+
+template <int OP, typename I>
+__global__ __launch_bounds__(256) void unary_scalar_kernel(const float *in, float *out, I n,
+                                                           float p0, float p1) {
+    const I stride = (I)gridDim.x * blockDim.x;
+    for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = unary_apply<OP>(in[i], p0, p1);
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ out, float value, I n,
+                                                   I head, I nvec) {
+    // head = elements before the first 16-byte boundary, then nvec float4, then the rest
+    const I stride = (I)gridDim.x * blockDim.x;
+    const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    const v4f v{value, value, value, value};
+    for (I i = tid; i < nvec; i += stride) *(v4f *)(out + head + (size_t)i * 4) = v;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) out[threadIdx.x] = value;
+        const I t = head + nvec * 4 + threadIdx.x;
+        if (t < n) out[t] = value;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch configuration
+// ------------------------------------------------------------------------------------------
+
+int g_variant = 0;   // see np_elementwise_set_variant
+
+struct LaunchCfg {
+    int unroll;          // float4 per lane per trip
+    int blocks_per_cu;   // grid = min(needed, CUs * blocks_per_cu)
+    bool nt;             // non-temporal loads/stores
+};
+
+// variant = unroll_code + 10*bpc_code + 100*nt ; 0 = default
+LaunchCfg cfg_from_variant(int variant) {
+    LaunchCfg c{4, 8, true};
+    if (variant <= 0) return c;
+    const int u = variant % 10, b = (variant / 10) % 10, nt = (variant / 100) % 10;
+    if (u == 1) c.unroll = 1;
+    if (u == 2) c.unroll = 2;
+    if (u == 4) c.unroll = 4;
+    if (u == 8) c.unroll = 8;
+    if (b > 0) c.blocks_per_cu = b * 2;   // 1..9 -> 2..18
+    c.nt = (nt != 0);
+    return c;
+}
+
+unsigned grid_for(size_t work_items, int per_thread, int blocks_per_cu) {
+    const size_t threads = (work_items + per_thread - 1) / per_thread;
+    size_t blocks = (threads + 255) / 256;
+    const size_t cap = (size_t)np::num_cus() * blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+// ---- binary dispatch ----
+
+template <int OP, int AK, int BK, bool QUIRK, typename I>
+int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size_t cols,
+                      size_t body_end) {
+    const LaunchCfg c = cfg_from_variant(g_variant);
+    const I nvec = (I)(n / 4), cols4 = (I)(cols / 4), tail = (I)(n / 4 * 4);
+    const unsigned grid = grid_for(n / 4 + 1, c.unroll, c.blocks_per_cu);
+    hipStream_t s = np::stream();
+#define NP_BV(U, NT)                                                                       \
+    binary_vec_kernel<OP, AK, BK, QUIRK, U, NT, I><<<grid, 256, 0, s>>>(a, b, out, nvec,   \
+                                                                         cols4, tail, (I)n, \
+                                                                         (I)body_end)
+    if (c.nt) {
+        switch (c.unroll) {
+            case 1: NP_BV(1, true); break;
+            case 2: NP_BV(2, true); break;
+            case 8: NP_BV(8, true); break;
+            default: NP_BV(4, true); break;
+        }
+    } else {
+        switch (c.unroll) {
+            case 1: NP_BV(1, false); break;
+            case 2: NP_BV(2, false); break;
+            case 8: NP_BV(8, false); break;
+            default: NP_BV(4, false); break;
+        }
+    }
+#undef NP_BV
+    NP_LAUNCH_CHECK("binary_vec_kernel");
+    return NP_OK;
+}
+
+template <int OP, bool QUIRK, typename I>
+int launch_binary_scalar(const float *a, int ak, const float *b, int bk, float *out, size_t n,
+                         size_t cols, size_t body_end) {
+    const unsigned grid = grid_for(n, 4, 16);
+    binary_scalar_kernel<OP, QUIRK, I>
+        <<<grid, 256, 0, np::stream()>>>(a, ak, b, bk, out, (I)n, (I)cols, (I)body_end);
+    NP_LAUNCH_CHECK("binary_scalar_kernel");
+    return NP_OK;
+}
+
+template <int OP, bool QUIRK, typename I>
+int dispatch_binary_kinds(const float *a, int ak, const float *b, int bk, float *out, size_t rows,
+                          size_t cols, size_t body_end) {
+    const size_t n = rows * cols;
+    // vector path: all FULL pointers 16-byte aligned; ROW/COL operands need cols % 4 == 0 so a
+    // float4 never straddles a row (ROW pointers must be aligned too).
+    const bool bcast = (ak == NP_ROW || ak == NP_COL || bk == NP_ROW || bk == NP_COL);
+    bool vec = aligned16(out) && n >= 4;
+    if (ak == NP_FULL || ak == NP_ROW) vec = vec && aligned16(a);
+    if (bk == NP_FULL || bk == NP_ROW) vec = vec && aligned16(b);
+    if (bcast) vec = vec && (cols % 4 == 0);
+    if (vec) {
+#define NP_BK(AK_, BK_)                                                                     \
+    if (ak == AK_ && bk == BK_)                                                             \
+        return launch_binary_vec<OP, AK_, BK_, QUIRK, I>(a, b, out, n, cols, body_end)
+        NP_BK(NP_FULL, NP_FULL);
+        NP_BK(NP_FULL, NP_SCALAR);
+        NP_BK(NP_SCALAR, NP_FULL);
+        NP_BK(NP_FULL, NP_ROW);
+        NP_BK(NP_ROW, NP_FULL);
+        NP_BK(NP_FULL, NP_COL);
+        NP_BK(NP_COL, NP_FULL);
+#undef NP_BK
+    }
+    return launch_binary_scalar<OP, QUIRK, I>(a, ak, b, bk, out, n, cols, body_end);
+}
+
+template <int OP, bool QUIRK>
+int dispatch_binary_index(const float *a, int ak, const float *b, int bk, float *out, size_t rows,
+                          size_t cols, size_t body_end) {
+    const size_t n = rows * cols;
+    if (n < (size_t(1) << 31)) {
+        if (body_end > n) body_end = n;
+        return dispatch_binary_kinds<OP, QUIRK, uint32_t>(a, ak, b, bk, out, rows, cols, body_end);
+    }
+    return dispatch_binary_kinds<OP, QUIRK, uint64_t>(a, ak, b, bk, out, rows, cols, body_end);
+}
+
+template <int OP>
+int dispatch_binary_quirk(const float *a, int ak, const float *b, int bk, float *out, size_t rows,
+                          size_t cols, unsigned flags, size_t body_end) {
+    constexpr bool has_quirk = (OP == NP_MULTIPLY || OP == NP_MOD);
+    if constexpr (has_quirk) {
+        if (flags & NP_QUIRK_AVX_BODY)
+            return dispatch_binary_index<OP, true>(a, ak, b, bk, out, rows, cols, body_end);
+    }
+    return dispatch_binary_index<OP, false>(a, ak, b, bk, out, rows, cols, 0);
+}
+
+// ---- unary dispatch ----
+
+template <int OP, typename I>
+int launch_unary(const float *in, float *out, size_t n, float p0, float p1) {
+    hipStream_t s = np::stream();
+    if (aligned16(in) && aligned16(out) && n >= 4) {
+        const LaunchCfg c = cfg_from_variant(g_variant);
+        const I nvec = (I)(n / 4), tail = (I)(n / 4 * 4);
+        const unsigned grid = grid_for(n / 4 + 1, c.unroll, c.blocks_per_cu);
+#define NP_UV(U, NT) \
+    unary_vec_kernel<OP, U, NT, I><<<grid, 256, 0, s>>>(in, out, nvec, tail, (I)n, p0, p1)
+        if (c.nt) {
+            switch (c.unroll) {
+                case 1: NP_UV(1, true); break;
+                case 2: NP_UV(2, true); break;
+                case 8: NP_UV(8, true); break;
+                default: NP_UV(4, true); break;
+            }
+        } else {
+            switch (c.unroll) {
+                case 1: NP_UV(1, false); break;
+                case 2: NP_UV(2, false); break;
+                case 8: NP_UV(8, false); break;
+                default: NP_UV(4, false); break;
+            }
+        }
+#undef NP_UV
+        NP_LAUNCH_CHECK("unary_vec_kernel");
+        return NP_OK;
+    }
+    const unsigned grid = grid_for(n, 4, 16);
+    unary_scalar_kernel<OP, I><<<grid, 256, 0, s>>>(in, out, (I)n, p0, p1);
+    NP_LAUNCH_CHECK("unary_scalar_kernel");
+    return NP_OK;
+}
+
+template <int OP>
+int dispatch_unary(const float *in, float *out, size_t n, float p0, float p1) {
+    if (n < (size_t(1) << 31)) return launch_unary<OP, uint32_t>(in, out, n, p0, p1);
+    return launch_unary<OP, uint64_t>(in, out, n, p0, p1);
+}
+
+size_t operand_elems(int kind, size_t rows, size_t cols) {
+    switch (kind) {
+        case NP_FULL: return rows * cols;
+        case NP_SCALAR: return 1;
+        case NP_ROW: return cols;
+        default: return rows;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int np_elementwise_set_variant(int variant) {
+    g_variant = variant;
+    return NP_OK;
+}
+
+int np_binary(int op, const float *a, int a_kind, const float *b, int b_kind, float *out,
+              size_t rows, size_t cols, unsigned flags, size_t body_end) {
+    if (op < 0 || op >= NP_BINARY_OP_COUNT)
+        return np::fail(NP_ERR_INVALID, "np_binary: unknown op %d", op);
+    if (a_kind < NP_FULL || a_kind > NP_COL || b_kind < NP_FULL || b_kind > NP_COL)
+        return np::fail(NP_ERR_INVALID, "np_binary: unknown operand kind (%d, %d)", a_kind, b_kind);
+    if (rows == 0 || cols == 0) return NP_OK;
+    if (!a || !b || !out) return np::fail(NP_ERR_INVALID, "np_binary: null pointer");
+    if (int rc = np::ensure_init()) return rc;
+    (void)operand_elems;
+    switch (op) {
+        case NP_ADD: return dispatch_binary_quirk<NP_ADD>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
+        case NP_SUBTRACT: return dispatch_binary_quirk<NP_SUBTRACT>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
+        case NP_MULTIPLY: return dispatch_binary_quirk<NP_MULTIPLY>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
+        case NP_DIVIDE: return dispatch_binary_quirk<NP_DIVIDE>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
+        case NP_MOD: return dispatch_binary_quirk<NP_MOD>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
+        case NP_POW: return dispatch_binary_quirk<NP_POW>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
+        default: return dispatch_binary_quirk<NP_ARCTAN2>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
+    }
+}
+
+int np_unary(int op, const float *in, float *out, size_t n, float p0, float p1) {
+    if (op < 0 || op >= NP_UNARY_OP_COUNT)
+        return np::fail(NP_ERR_INVALID, "np_unary: unknown op %d", op);
+    if (n == 0) return NP_OK;
+    if (!in || !out) return np::fail(NP_ERR_INVALID, "np_unary: null pointer");
+    if (int rc = np::ensure_init()) return rc;
+    // float_round: factor = powf(10, decimals), evaluated once with the host libm (the same
+    // glibc powf the reference calls per element, double_math.c:255).
+    if (op == NP_ROUND) p0 = powf(10.0f, p0);
+#define NP_U(OP_) case OP_: return dispatch_unary<OP_>(in, out, n, p0, p1)
+    switch (op) {
+        NP_U(NP_ABS); NP_U(NP_SQRT); NP_U(NP_EXP); NP_U(NP_EXP2); NP_U(NP_EXPM1); NP_U(NP_LOG);
+        NP_U(NP_LOG2); NP_U(NP_LOG10); NP_U(NP_LOG1P); NP_U(NP_LOGB); NP_U(NP_SIN); NP_U(NP_COS);
+        NP_U(NP_TAN); NP_U(NP_ARCSIN); NP_U(NP_ARCCOS); NP_U(NP_ARCTAN); NP_U(NP_DEGREES);
+        NP_U(NP_RADIANS); NP_U(NP_SINH); NP_U(NP_COSH); NP_U(NP_TANH); NP_U(NP_ARCSINH);
+        NP_U(NP_ARCCOSH); NP_U(NP_ARCTANH); NP_U(NP_RINT); NP_U(NP_FIX); NP_U(NP_FLOOR);
+        NP_U(NP_CEIL); NP_U(NP_TRUNC); NP_U(NP_SINC); NP_U(NP_NEGATE); NP_U(NP_SIGN); NP_U(NP_CLIP);
+        NP_U(NP_ROUND); NP_U(NP_RSQRT); NP_U(NP_POSITIVE); NP_U(NP_RECIPROCAL);
+        default: break;
+    }
+#undef NP_U
+    return np::fail(NP_ERR_INVALID, "np_unary: unknown op %d", op);
+}
+
+int np_fill(float *dev_ptr, float value, size_t n) {
+    if (n == 0) return NP_OK;
+    if (!dev_ptr) return np::fail(NP_ERR_INVALID, "np_fill: null pointer");
+    if (int rc = np::ensure_init()) return rc;
+    // peel to a 16-byte boundary (row views start anywhere)
+    size_t head = ((16 - ((uintptr_t)dev_ptr & 15u)) & 15u) / 4;
+    if (head > n) head = n;
+    const size_t nvec = (n - head) / 4;
+    const unsigned grid = grid_for(nvec + 1, 4, 8);
+    if (n < (size_t(1) << 31))
+        fill_kernel<uint32_t><<<grid, 256, 0, np::stream()>>>(dev_ptr, value, (uint32_t)n,
+                                                              (uint32_t)head, (uint32_t)nvec);
+    else
+        fill_kernel<uint64_t><<<grid, 256, 0, np::stream()>>>(dev_ptr, value, (uint64_t)n,
+                                                              (uint64_t)head, (uint64_t)nvec);
+    NP_LAUNCH_CHECK("fill_kernel");
+    return NP_OK;
+}
+
+}  // extern "C"

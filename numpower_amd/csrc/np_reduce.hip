@@ -1,0 +1,485 @@
+// Reductions of libnp_hip.so: full reductions (sum / prod / min / max / mean) and single-axis
+// reductions over a contiguous array viewed as outer x axis_len x inner.
+//
+// HBM-bound: every input element is read exactly once with 16-byte lane accesses; cross-lane
+// combines use wave64 shuffles (DPP / ds_bpermute), cross-wave combines go through LDS, and
+// cross-workgroup combines are a deterministic second pass over per-workgroup partials (no float
+// atomics: the reference's atomicAdd kernels, cuda_math.cu:777-828, are order-nondeterministic
+// and its prod kernel is wrong).
+//
+// Reference behaviour restated:
+//   NDArray_Sum_Float / NDArray_Float_Prod / NDArray_Mean_Float   src/ndmath/arithmetics.c:36-102
+//   NDArray_Min / NDArray_Max                                      src/ndarray.c:752-772,939-959
+//   reduce() / _reduce() / apply_reduce()                          src/ndarray.c:523-578,394-429,358-368
+// The reference accumulates strictly left to right in fp32; the tree order used here differs in
+// rounding (it is closer to the exact sum).  tests/ pin both against an fp64 accumulation.
+#include <float.h>
+#include <math.h>
+
+#include "np_internal.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int OP>
+__device__ __forceinline__ float r_identity() {
+    if constexpr (OP == NP_SUM || OP == NP_MEAN) return 0.0f;
+    if constexpr (OP == NP_PROD) return 1.0f;
+    if constexpr (OP == NP_MIN) return INFINITY;
+    return -INFINITY;
+}
+
+template <int OP>
+__device__ __forceinline__ float r_combine(float a, float b) {
+    if constexpr (OP == NP_SUM || OP == NP_MEAN) return a + b;
+    if constexpr (OP == NP_PROD) return a * b;
+    // same comparison the reference uses (ndarray.c:764, :951): NaN never replaces
+    if constexpr (OP == NP_MIN) return (b < a) ? b : a;
+    return (b > a) ? b : a;
+}
+
+template <int OP>
+__device__ __forceinline__ float wave_reduce(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = r_combine<OP>(v, __shfl_down(v, off, 64));
+    return v;   // lane 0 holds the wave's result
+}
+
+// Workgroup reduce of one value per thread (256 threads = 4 waves).  Result valid in thread 0.
+template <int OP>
+__device__ __forceinline__ float block_reduce(float v, float *lds4) {
+    v = wave_reduce<OP>(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds4[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = lds4[0];
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 1; w < nw; ++w) v = r_combine<OP>(v, lds4[w]);
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// full reduction
+// ------------------------------------------------------------------------------------------
+
+// pass 1: each workgroup reduces a grid-strided share of the input to one partial.
+// `in` must be 16-byte aligned at in + head; head/tail elements are folded in by block 0.
+template <int OP, typename I>
+__global__ __launch_bounds__(256) void reduce_all_pass1(const float *__restrict__ in,
+                                                        float *__restrict__ partials, I n, I head,
+                                                        I nvec) {
+    __shared__ float lds4[4];
+    const I stride = (I)gridDim.x * blockDim.x;
+    const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    const float id = r_identity<OP>();
+    // 4 independent float4 accumulators = 16 loads-worth of ILP per lane
+    v4f acc0{id, id, id, id}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    const float *base = in + head;
+    I v = tid;
+    for (; v + 3 * stride < nvec; v += 4 * stride) {
+        const v4f x0 = __builtin_nontemporal_load((const v4f *)(base + (size_t)v * 4));
+        const v4f x1 = __builtin_nontemporal_load((const v4f *)(base + (size_t)(v + stride) * 4));
+        const v4f x2 = __builtin_nontemporal_load((const v4f *)(base + (size_t)(v + 2 * stride) * 4));
+        const v4f x3 = __builtin_nontemporal_load((const v4f *)(base + (size_t)(v + 3 * stride) * 4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc0[k] = r_combine<OP>(acc0[k], x0[k]);
+            acc1[k] = r_combine<OP>(acc1[k], x1[k]);
+            acc2[k] = r_combine<OP>(acc2[k], x2[k]);
+            acc3[k] = r_combine<OP>(acc3[k], x3[k]);
+        }
+    }
+    for (; v < nvec; v += stride) {
+        const v4f x0 = *(const v4f *)(base + (size_t)v * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc0[k] = r_combine<OP>(acc0[k], x0[k]);
+    }
+    float r = id;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r = r_combine<OP>(r, r_combine<OP>(r_combine<OP>(acc0[k], acc1[k]),
+                                          r_combine<OP>(acc2[k], acc3[k])));
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) r = r_combine<OP>(r, in[threadIdx.x]);
+        const I t = head + nvec * 4 + threadIdx.x;
+        if (t < n) r = r_combine<OP>(r, in[t]);
+    }
+    r = block_reduce<OP>(r, lds4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// pass 2: one workgroup folds the partials; MEAN divides by the element count at the end
+// (`value / numElements`, arithmetics.c:89, numpower.c:2659).
+template <int OP>
+__global__ __launch_bounds__(256) void reduce_all_pass2(const float *__restrict__ partials, int np,
+                                                        float *__restrict__ out, float count) {
+    __shared__ float lds4[4];
+    float r = r_identity<OP>();
+    for (int i = threadIdx.x; i < np; i += blockDim.x) r = r_combine<OP>(r, partials[i]);
+    r = block_reduce<OP>(r, lds4);
+    if (threadIdx.x == 0) {
+        if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, count);
+        out[0] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// axis reduction, inner >= 4 and inner % 4 == 0: "column" reduce
+// ------------------------------------------------------------------------------------------
+//
+// View: in[outer][axis_len][inner].  A workgroup owns a tile of 64 float4 columns (256 floats of
+// the inner dimension) and one of `splits` contiguous chunks of the axis; its 4 waves walk
+// interleaved rows of the chunk (each wave-level load is one contiguous 1 KiB segment of a row),
+// keep ROWS_IN_FLIGHT independent loads in flight, and combine through LDS at the end.
+// out_partial[outer][splits][inner]; with splits == 1 this is the final result.
+//
+// FINAL applies the epilogue: MEAN -> divide by axis_len; PROD with the AVX-body quirk ->
+// zero results take the sign the reference's repeated Multiply_Float leaves behind
+// (arithmetics.c:403,410-412): -0.0f for inner index < body_end, +0.0f after it.
+template <int OP, bool FINAL, typename I>
+__global__ __launch_bounds__(256) void reduce_axis_cols(const float *__restrict__ in,
+                                                        float *__restrict__ out, I axis_len,
+                                                        I inner4, I splits, float mean_div,
+                                                        int prod_quirk, I body_end) {
+    __shared__ v4f lds[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const I col4 = (I)blockIdx.x * 64 + lane;
+    const I split = blockIdx.y;
+    const I o = blockIdx.z;
+    const I chunk = (axis_len + splits - 1) / splits;
+    const I r0 = split * chunk;
+    I r1 = r0 + chunk;
+    if (r1 > axis_len) r1 = axis_len;
+    const float id = r_identity<OP>();
+    v4f acc0{id, id, id, id}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    if (col4 < inner4) {
+        const size_t row_stride = (size_t)inner4 * 4;
+        const float *p = in + (size_t)o * axis_len * row_stride + (size_t)col4 * 4;
+        I r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            const v4f x0 = __builtin_nontemporal_load((const v4f *)(p + (size_t)r * row_stride));
+            const v4f x1 = __builtin_nontemporal_load((const v4f *)(p + (size_t)(r + 4) * row_stride));
+            const v4f x2 = __builtin_nontemporal_load((const v4f *)(p + (size_t)(r + 8) * row_stride));
+            const v4f x3 = __builtin_nontemporal_load((const v4f *)(p + (size_t)(r + 12) * row_stride));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc0[k] = r_combine<OP>(acc0[k], x0[k]);
+                acc1[k] = r_combine<OP>(acc1[k], x1[k]);
+                acc2[k] = r_combine<OP>(acc2[k], x2[k]);
+                acc3[k] = r_combine<OP>(acc3[k], x3[k]);
+            }
+        }
+        for (; r < r1; r += 4) {
+            const v4f x0 = *(const v4f *)(p + (size_t)r * row_stride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc0[k] = r_combine<OP>(acc0[k], x0[k]);
+        }
+    }
+    v4f acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        acc[k] = r_combine<OP>(r_combine<OP>(acc0[k], acc1[k]), r_combine<OP>(acc2[k], acc3[k]));
+    if (wave > 0) lds[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col4 < inner4) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const v4f t = lds[w][lane];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = r_combine<OP>(acc[k], t[k]);
+        }
+        if constexpr (FINAL) {
+            if constexpr (OP == NP_MEAN) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = __fdiv_rn(acc[k], mean_div);
+            }
+            if constexpr (OP == NP_PROD) {
+                if (prod_quirk) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (acc[k] == 0.0f) acc[k] = (col4 * 4 + k < body_end) ? -0.0f : 0.0f;
+                }
+            }
+        }
+        float *q = out + ((size_t)o * splits + split) * (size_t)inner4 * 4 + (size_t)col4 * 4;
+        *(v4f *)q = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// axis reduction, generic: one thread per output element, sequential over the axis.
+// Used for ragged inner sizes (inner % 4 != 0, misaligned views) and tiny problems.
+// ------------------------------------------------------------------------------------------
+template <int OP, typename I>
+__global__ __launch_bounds__(256) void reduce_axis_generic(const float *__restrict__ in,
+                                                           float *__restrict__ out, I outer,
+                                                           I axis_len, I inner, float mean_div,
+                                                           int prod_quirk, I body_end) {
+    const I total = outer * inner;
+    const I stride = (I)gridDim.x * blockDim.x;
+    for (I idx = (I)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const I o = idx / inner, j = idx % inner;
+        const float *p = in + (size_t)o * axis_len * inner + j;
+        float r = r_identity<OP>();
+        if (axis_len > 0) r = p[0];
+        for (I a = 1; a < axis_len; ++a) r = r_combine<OP>(r, p[(size_t)a * inner]);
+        if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, mean_div);
+        if constexpr (OP == NP_PROD) {
+            if (prod_quirk && r == 0.0f) r = (j < body_end) ? -0.0f : 0.0f;
+        }
+        out[idx] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// axis reduction, inner == 1: "row" reduce.  LPR lanes cooperate on one row (LPR = 64: one wave
+// per row; 256: one workgroup per row), reading the row with coalesced accesses.
+// ------------------------------------------------------------------------------------------
+template <int OP, typename I>
+__global__ __launch_bounds__(256) void reduce_rows_wave(const float *__restrict__ in,
+                                                        float *__restrict__ out, I rows, I len,
+                                                        float mean_div) {
+    const int lane = threadIdx.x & 63;
+    const I row = (I)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *p = in + (size_t)row * len;
+    const float id = r_identity<OP>();
+    float r = id;
+    // peel to 16-byte alignment, then float4
+    I head = (I)(((16 - ((uintptr_t)p & 15u)) & 15u) / 4);
+    if (head > len) head = len;
+    if ((I)lane < head) r = p[lane];
+    const I nvec = (len - head) / 4;
+    v4f acc{id, id, id, id};
+    for (I v = lane; v < nvec; v += 64) {
+        const v4f x = *(const v4f *)(p + head + (size_t)v * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = r_combine<OP>(acc[k], x[k]);
+    }
+    r = r_combine<OP>(r, r_combine<OP>(r_combine<OP>(acc[0], acc[1]), r_combine<OP>(acc[2], acc[3])));
+    const I t = head + nvec * 4 + lane;
+    if (t < len) r = r_combine<OP>(r, p[t]);
+    r = wave_reduce<OP>(r);
+    if (lane == 0) {
+        if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, mean_div);
+        out[row] = r;
+    }
+}
+
+template <int OP, typename I>
+__global__ __launch_bounds__(256) void reduce_rows_block(const float *__restrict__ in,
+                                                         float *__restrict__ out, I rows, I len,
+                                                         float mean_div) {
+    __shared__ float lds4[4];
+    const I row = blockIdx.x;
+    const float *p = in + (size_t)row * len;
+    const float id = r_identity<OP>();
+    float r = id;
+    I head = (I)(((16 - ((uintptr_t)p & 15u)) & 15u) / 4);
+    if (head > len) head = len;
+    if ((I)threadIdx.x < head) r = p[threadIdx.x];
+    const I nvec = (len - head) / 4;
+    v4f acc0{id, id, id, id}, acc1 = acc0;
+    I v = threadIdx.x;
+    for (; v + 256 < nvec; v += 512) {
+        const v4f x0 = __builtin_nontemporal_load((const v4f *)(p + head + (size_t)v * 4));
+        const v4f x1 = __builtin_nontemporal_load((const v4f *)(p + head + (size_t)(v + 256) * 4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc0[k] = r_combine<OP>(acc0[k], x0[k]);
+            acc1[k] = r_combine<OP>(acc1[k], x1[k]);
+        }
+    }
+    for (; v < nvec; v += 256) {
+        const v4f x0 = *(const v4f *)(p + head + (size_t)v * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc0[k] = r_combine<OP>(acc0[k], x0[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r = r_combine<OP>(r, r_combine<OP>(acc0[k], acc1[k]));
+    const I t = head + nvec * 4 + threadIdx.x;
+    if (t < len) r = r_combine<OP>(r, p[t]);
+    r = block_reduce<OP>(r, lds4);
+    if (threadIdx.x == 0) {
+        if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, mean_div);
+        out[row] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <int OP, typename I>
+int launch_reduce_all(const float *in, size_t n, float *dev_out) {
+    hipStream_t s = np::stream();
+    size_t head = ((16 - ((uintptr_t)in & 15u)) & 15u) / 4;
+    if (head > n) head = n;
+    const size_t nvec = (n - head) / 4;
+    // enough workgroups to fill the chip (8 per CU), but never more than one per 4 KiB of input
+    size_t blocks = (nvec + 255) / 256;
+    const size_t cap = (size_t)np::num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    np::Scratch partials;
+    if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
+    reduce_all_pass1<OP, I><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (I)n,
+                                                           (I)head, (I)nvec);
+    NP_LAUNCH_CHECK("reduce_all_pass1");
+    reduce_all_pass2<OP><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, dev_out,
+                                           (float)n);
+    NP_LAUNCH_CHECK("reduce_all_pass2");
+    return NP_OK;
+}
+
+template <int OP>
+int dispatch_reduce_all(const float *in, size_t n, float *dev_out) {
+    if (n < (size_t(1) << 31)) return launch_reduce_all<OP, uint32_t>(in, n, dev_out);
+    return launch_reduce_all<OP, uint64_t>(in, n, dev_out);
+}
+
+// how many chunks to cut the axis into so that the column reduce has >= ~8 workgroups per CU
+size_t choose_splits(size_t outer, size_t axis_len, size_t inner4) {
+    const size_t col_tiles = (inner4 + 63) / 64;
+    const size_t base = col_tiles * outer;
+    const size_t target = (size_t)np::num_cus() * 8;
+    if (base >= target) return 1;
+    size_t s = (target + base - 1) / base;
+    // keep at least 64 rows per chunk so the per-workgroup epilogue stays negligible
+    const size_t max_s = axis_len / 64 > 0 ? axis_len / 64 : 1;
+    if (s > max_s) s = max_s;
+    if (s > 65535) s = 65535;
+    return s < 1 ? 1 : s;
+}
+
+template <int OP, typename I>
+int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t inner, float *out,
+                       unsigned flags) {
+    hipStream_t s = np::stream();
+    const float mean_div = (float)(long)axis_len;   // CreateFromLongScalar, numpower.c:2666
+    const int quirk = (OP == NP_PROD && (flags & NP_QUIRK_AVX_BODY) && axis_len > 1) ? 1 : 0;
+    const size_t body_end = np_avx_body_end(inner);
+
+    if (inner == 1) {
+        // contiguous rows
+        if (axis_len >= 4096) {
+            if (outer > 0x7fffffffu)
+                return np::fail(NP_ERR_INVALID, "np_reduce_axis: too many rows for row reduce");
+            reduce_rows_block<OP, I><<<(unsigned)outer, 256, 0, s>>>(in, out, (I)outer, (I)axis_len,
+                                                                  mean_div);
+            NP_LAUNCH_CHECK("reduce_rows_block");
+            return NP_OK;
+        }
+        if (axis_len >= 32) {
+            const size_t blocks = (outer + 3) / 4;
+            if (blocks > 0x7fffffffu)
+                return np::fail(NP_ERR_INVALID, "np_reduce_axis: too many rows for row reduce");
+            reduce_rows_wave<OP, I><<<(unsigned)blocks, 256, 0, s>>>(in, out, (I)outer, (I)axis_len,
+                                                                  mean_div);
+            NP_LAUNCH_CHECK("reduce_rows_wave");
+            return NP_OK;
+        }
+    } else if (inner % 4 == 0 && aligned16(in) && aligned16(out) && outer <= 65535) {
+        const size_t inner4 = inner / 4;
+        const size_t splits = choose_splits(outer, axis_len, inner4);
+        const dim3 grid((unsigned)((inner4 + 63) / 64), (unsigned)splits, (unsigned)outer);
+        if (splits == 1) {
+            reduce_axis_cols<OP, true, I><<<grid, 256, 0, s>>>(in, out, (I)axis_len, (I)inner4, (I)1,
+                                                            mean_div, quirk, (I)body_end);
+            NP_LAUNCH_CHECK("reduce_axis_cols");
+            return NP_OK;
+        }
+        np::Scratch partials;
+        if (int rc = partials.alloc(outer * splits * inner * sizeof(float))) return rc;
+        reduce_axis_cols<OP, false, I><<<grid, 256, 0, s>>>(in, (float *)partials.ptr, (I)axis_len,
+                                                         (I)inner4, (I)splits, mean_div, 0, (I)0);
+        NP_LAUNCH_CHECK("reduce_axis_cols(pass 1)");
+        // pass 2: the partials are an outer x splits x inner array; MEAN must divide by the real
+        // axis length, not by `splits`.
+        const dim3 grid2((unsigned)((inner4 + 63) / 64), 1, (unsigned)outer);
+        reduce_axis_cols<OP, true, I><<<grid2, 256, 0, s>>>((const float *)partials.ptr, out,
+                                                         (I)splits, (I)inner4, (I)1, mean_div,
+                                                         quirk, (I)body_end);
+        NP_LAUNCH_CHECK("reduce_axis_cols(pass 2)");
+        return NP_OK;
+    }
+    // generic fallback
+    const size_t total = outer * inner;
+    size_t blocks = (total + 255) / 256;
+    const size_t cap = (size_t)np::num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    reduce_axis_generic<OP, I><<<(unsigned)blocks, 256, 0, s>>>(in, out, (I)outer, (I)axis_len,
+                                                             (I)inner, mean_div, quirk,
+                                                             (I)body_end);
+    NP_LAUNCH_CHECK("reduce_axis_generic");
+    return NP_OK;
+}
+
+template <int OP>
+int dispatch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t inner, float *out,
+                         unsigned flags) {
+    const size_t n = outer * axis_len * inner;
+    if (n < (size_t(1) << 31))
+        return launch_reduce_axis<OP, uint32_t>(in, outer, axis_len, inner, out, flags);
+    return launch_reduce_axis<OP, uint64_t>(in, outer, axis_len, inner, out, flags);
+}
+
+}  // namespace
+
+extern "C" {
+
+int np_reduce_all_dev(int op, const float *in, size_t n, float *dev_out) {
+    if (op < 0 || op >= NP_REDUCE_OP_COUNT)
+        return np::fail(NP_ERR_INVALID, "np_reduce_all: unknown op %d", op);
+    if (!dev_out) return np::fail(NP_ERR_INVALID, "np_reduce_all: null output");
+    if (n > 0 && !in) return np::fail(NP_ERR_INVALID, "np_reduce_all: null input");
+    if (int rc = np::ensure_init()) return rc;
+    switch (op) {
+        case NP_SUM: return dispatch_reduce_all<NP_SUM>(in, n, dev_out);
+        case NP_PROD: return dispatch_reduce_all<NP_PROD>(in, n, dev_out);
+        case NP_MIN: return dispatch_reduce_all<NP_MIN>(in, n, dev_out);
+        case NP_MAX: return dispatch_reduce_all<NP_MAX>(in, n, dev_out);
+        default: return dispatch_reduce_all<NP_MEAN>(in, n, dev_out);
+    }
+}
+
+int np_reduce_all(int op, const float *in, size_t n, float *host_out) {
+    if (!host_out) return np::fail(NP_ERR_INVALID, "np_reduce_all: null output");
+    np::Scratch out;
+    if (int rc = out.alloc(sizeof(float))) return rc;
+    if (int rc = np_reduce_all_dev(op, in, n, (float *)out.ptr)) return rc;
+    return np_memcpy_d2h(host_out, out.ptr, sizeof(float));
+}
+
+size_t np_reduce_axis_workspace(size_t outer, size_t axis_len, size_t inner) {
+    if (inner <= 1 || inner % 4 != 0 || outer > 65535) return 0;
+    if (np::ensure_init()) return 0;
+    const size_t splits = choose_splits(outer, axis_len, inner / 4);
+    return splits > 1 ? outer * splits * inner * sizeof(float) : 0;
+}
+
+int np_reduce_axis(int op, const float *in, size_t outer, size_t axis_len, size_t inner,
+                   float *out, unsigned flags) {
+    if (op < 0 || op >= NP_REDUCE_OP_COUNT)
+        return np::fail(NP_ERR_INVALID, "np_reduce_axis: unknown op %d", op);
+    if (outer == 0 || inner == 0) return NP_OK;
+    if (axis_len == 0) return np::fail(NP_ERR_INVALID, "np_reduce_axis: empty axis");
+    if (!in || !out) return np::fail(NP_ERR_INVALID, "np_reduce_axis: null pointer");
+    if (int rc = np::ensure_init()) return rc;
+    switch (op) {
+        case NP_SUM: return dispatch_reduce_axis<NP_SUM>(in, outer, axis_len, inner, out, flags);
+        case NP_PROD: return dispatch_reduce_axis<NP_PROD>(in, outer, axis_len, inner, out, flags);
+        case NP_MIN: return dispatch_reduce_axis<NP_MIN>(in, outer, axis_len, inner, out, flags);
+        case NP_MAX: return dispatch_reduce_axis<NP_MAX>(in, outer, axis_len, inner, out, flags);
+        default: return dispatch_reduce_axis<NP_MEAN>(in, outer, axis_len, inner, out, flags);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+// Runtime + device-buffer layer of libnp_hip.so.
+//
+// Stands in for the reference's src/gpu_alloc.c (vmalloc / vfree / vmemcpy* / vmemcheck /
+// NDArray_VFLOAT, gpu_alloc.c:11-54) and for the implicit CUDA context handling around it.
+// Differences that matter on MI355X:
+//   * sizes are size_t (the reference's `unsigned int` caps a buffer at 4 GiB; one GPU here
+//     has 288 GB of HBM3E);
+//   * allocations come from a caching pool, so the one-result-buffer-per-op pattern of the
+//     reference's L2 (arithmetics.c:211-231) costs a free-list pop instead of hipMalloc;
+//   * everything is ordered on one library stream and asynchronous; the only blocking calls
+//     are np_sync, np_memcpy_d2h, np_read_float and the timers.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "np_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+struct Runtime {
+    std::mutex mu;
+    bool inited = false;
+    int device = 0;
+    int cus = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t cur_stream = nullptr;
+    // caching pool
+    std::map<size_t, std::vector<void *>> free_blocks;   // rounded size -> blocks
+    std::unordered_map<void *, size_t> live;             // ptr -> rounded size
+    size_t reserved = 0;                                 // bytes held (live + cached)
+    long live_count = 0;
+};
+
+Runtime &rt() {
+    static Runtime r;
+    return r;
+}
+
+size_t round_size(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    if (bytes < (size_t(1) << 20)) {
+        size_t s = 256;
+        while (s < bytes) s <<= 1;
+        return s;
+    }
+    const size_t g = size_t(2) << 20;   // 2 MiB granules above 1 MiB
+    return (bytes + g - 1) / g * g;
+}
+
+size_t trim_locked(Runtime &r) {
+    size_t released = 0;
+    for (auto &kv : r.free_blocks) {
+        for (void *p : kv.second) {
+            (void)hipFree(p);
+            released += kv.first;
+        }
+        kv.second.clear();
+    }
+    r.free_blocks.clear();
+    r.reserved -= released;
+    return released;
+}
+
+struct Timer {
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+namespace np {
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+hipStream_t stream() { return rt().cur_stream; }
+int num_cus() { return rt().cus; }
+
+int ensure_init() {
+    if (rt().inited) return NP_OK;
+    return np_init(0);
+}
+
+int Scratch::alloc(size_t bytes) { return np_malloc(&ptr, bytes); }
+Scratch::~Scratch() {
+    if (ptr) np_free(ptr);
+}
+
+}  // namespace np
+
+extern "C" {
+
+const char *np_last_error(void) { return g_err; }
+const char *np_version(void) { return "numpower_amd 0.1 (gfx950 / CDNA4)"; }
+
+int np_device_count(int *host_count) {
+    if (!host_count) return np::fail(NP_ERR_INVALID, "np_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *host_count = 0;
+        return np::fail(NP_ERR_NODEVICE, "No GPU device available (%s)", hipGetErrorString(e));
+    }
+    *host_count = n;
+    return NP_OK;
+}
+
+int np_init(int device) {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> lk(r.mu);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return np::fail(NP_ERR_NODEVICE, "No GPU device available or HIP not enabled");
+    if (device < 0 || device >= n)
+        return np::fail(NP_ERR_INVALID, "np_init: device %d out of range (0..%d)", device, n - 1);
+    NP_HIP_CHECK(hipSetDevice(device));
+    if (r.inited && r.device == device) return NP_OK;
+    if (r.inited) {
+        // moving to another device: drop cached blocks of the old one
+        (void)hipSetDevice(r.device);
+        trim_locked(r);
+        if (r.own_stream) (void)hipStreamDestroy(r.own_stream);
+        r.own_stream = nullptr;
+        NP_HIP_CHECK(hipSetDevice(device));
+    }
+    hipDeviceProp_t prop;
+    NP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    r.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    NP_HIP_CHECK(hipStreamCreateWithFlags(&r.own_stream, hipStreamNonBlocking));
+    r.cur_stream = r.own_stream;
+    r.device = device;
+    r.inited = true;
+    return NP_OK;
+}
+
+int np_set_device(int device) { return np_init(device); }
+
+int np_sync(void) {
+    if (int rc = np::ensure_init()) return rc;
+    NP_HIP_CHECK(hipStreamSynchronize(rt().cur_stream));
+    return NP_OK;
+}
+
+int np_set_stream(void *hip_stream) {
+    if (int rc = np::ensure_init()) return rc;
+    Runtime &r = rt();
+    // drain the stream we are leaving so pool reuse stays ordered
+    NP_HIP_CHECK(hipStreamSynchronize(r.cur_stream));
+    r.cur_stream = hip_stream ? (hipStream_t)hip_stream : r.own_stream;
+    return NP_OK;
+}
+
+void *np_get_stream(void) {
+    if (np::ensure_init()) return nullptr;
+    return (void *)rt().cur_stream;
+}
+
+/* ---- timers ---- */
+
+int np_timer_create(void **timer) {
+    if (!timer) return np::fail(NP_ERR_INVALID, "np_timer_create: null output");
+    if (int rc = np::ensure_init()) return rc;
+    Timer *t = new Timer;
+    NP_HIP_CHECK(hipEventCreate(&t->start));
+    NP_HIP_CHECK(hipEventCreate(&t->stop));
+    *timer = t;
+    return NP_OK;
+}
+int np_timer_start(void *timer) {
+    if (!timer) return np::fail(NP_ERR_INVALID, "np_timer_start: null timer");
+    NP_HIP_CHECK(hipEventRecord(((Timer *)timer)->start, rt().cur_stream));
+    return NP_OK;
+}
+int np_timer_stop(void *timer) {
+    if (!timer) return np::fail(NP_ERR_INVALID, "np_timer_stop: null timer");
+    NP_HIP_CHECK(hipEventRecord(((Timer *)timer)->stop, rt().cur_stream));
+    return NP_OK;
+}
+int np_timer_elapsed_ms(void *timer, float *host_ms) {
+    if (!timer || !host_ms) return np::fail(NP_ERR_INVALID, "np_timer_elapsed_ms: null argument");
+    Timer *t = (Timer *)timer;
+    NP_HIP_CHECK(hipEventSynchronize(t->stop));
+    NP_HIP_CHECK(hipEventElapsedTime(host_ms, t->start, t->stop));
+    return NP_OK;
+}
+int np_timer_destroy(void *timer) {
+    if (!timer) return NP_OK;
+    Timer *t = (Timer *)timer;
+    (void)hipEventDestroy(t->start);
+    (void)hipEventDestroy(t->stop);
+    delete t;
+    return NP_OK;
+}
+
+/* ---- device buffers ---- */
+
+int np_malloc(void **dev_ptr, size_t bytes) {
+    if (!dev_ptr) return np::fail(NP_ERR_INVALID, "np_malloc: null output pointer");
+    *dev_ptr = nullptr;
+    if (int rc = np::ensure_init()) return rc;
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> lk(r.mu);
+    const size_t sz = round_size(bytes);
+    void *p = nullptr;
+    auto it = r.free_blocks.find(sz);
+    if (it != r.free_blocks.end() && !it->second.empty()) {
+        p = it->second.back();
+        it->second.pop_back();
+    } else {
+        hipError_t e = hipMalloc(&p, sz);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            // give cached blocks back to the driver and retry once
+            NP_HIP_CHECK(hipStreamSynchronize(r.cur_stream));
+            trim_locked(r);
+            e = hipMalloc(&p, sz);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return np::fail(NP_ERR_ALLOC, "device memory allocation failed (%zu bytes: %s)",
+                                bytes, hipGetErrorString(e));
+            }
+        }
+        r.reserved += sz;
+    }
+    r.live[p] = sz;
+    r.live_count++;
+    *dev_ptr = p;
+    return NP_OK;
+}
+
+int np_free(void *dev_ptr) {
+    if (!dev_ptr) return NP_OK;
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> lk(r.mu);
+    auto it = r.live.find(dev_ptr);
+    if (it == r.live.end())
+        return np::fail(NP_ERR_INVALID, "np_free: pointer %p was not allocated by np_malloc", dev_ptr);
+    r.free_blocks[it->second].push_back(dev_ptr);
+    r.live.erase(it);
+    r.live_count--;
+    return NP_OK;
+}
+
+long np_live_allocs(void) { return rt().live_count; }
+
+int np_pool_trim(size_t *host_bytes) {
+    if (int rc = np::ensure_init()) return rc;
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> lk(r.mu);
+    NP_HIP_CHECK(hipStreamSynchronize(r.cur_stream));
+    size_t released = trim_locked(r);
+    if (host_bytes) *host_bytes = released;
+    return NP_OK;
+}
+
+size_t np_pool_reserved_bytes(void) { return rt().reserved; }
+
+int np_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes) {
+    if (bytes == 0) return NP_OK;
+    if (!dev_dst || !host_src) return np::fail(NP_ERR_INVALID, "np_memcpy_h2d: null pointer");
+    if (int rc = np::ensure_init()) return rc;
+    // Pageable source: hipMemcpyAsync stages it and returns once the host buffer is reusable,
+    // which is the semantic NDArray_ToGPU needs (ndarray.c:1054-1055).
+    NP_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, rt().cur_stream));
+    NP_HIP_CHECK(hipStreamSynchronize(rt().cur_stream));
+    return NP_OK;
+}
+
+int np_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes) {
+    if (bytes == 0) return NP_OK;
+    if (!host_dst || !dev_src) return np::fail(NP_ERR_INVALID, "np_memcpy_d2h: null pointer");
+    if (int rc = np::ensure_init()) return rc;
+    NP_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, rt().cur_stream));
+    NP_HIP_CHECK(hipStreamSynchronize(rt().cur_stream));
+    return NP_OK;
+}
+
+int np_memcpy_d2d(void *dev_dst, const void *dev_src, size_t bytes) {
+    if (bytes == 0) return NP_OK;
+    if (!dev_dst || !dev_src) return np::fail(NP_ERR_INVALID, "np_memcpy_d2d: null pointer");
+    if (int rc = np::ensure_init()) return rc;
+    NP_HIP_CHECK(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, rt().cur_stream));
+    return NP_OK;
+}
+
+int np_memset0(void *dev_ptr, size_t bytes) {
+    if (bytes == 0) return NP_OK;
+    if (!dev_ptr) return np::fail(NP_ERR_INVALID, "np_memset0: null pointer");
+    if (int rc = np::ensure_init()) return rc;
+    NP_HIP_CHECK(hipMemsetAsync(dev_ptr, 0, bytes, rt().cur_stream));
+    return NP_OK;
+}
+
+int np_read_float(const float *dev_ptr, size_t index, float *host_out) {
+    if (!dev_ptr || !host_out) return np::fail(NP_ERR_INVALID, "np_read_float: null pointer");
+    return np_memcpy_d2h(host_out, dev_ptr + index, sizeof(float));
+}
+
+size_t np_avx_body_end(size_t numel_a) {
+    if (numel_a < 8) return 0;
+    return (numel_a - 7 + 7) / 8 * 8;
+}
+
+}  // extern "C"
