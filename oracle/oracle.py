@@ -1,0 +1,208 @@
+"""ctypes front end of oracle/np_oracle.c — the CPU restatement of the reference's hot path.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under numpower_amd/ imports this module.
+
+The functions take and return numpy float32 arrays; shapes carry the reference's ndim semantics
+(0-d arrays are the reference's 0-d scalars).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "lib" / "libnp_oracle.so"
+
+BINARY = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "mod": 4, "pow": 5, "arctan2": 6}
+UNARY = {name: i for i, name in enumerate([
+    "abs", "sqrt", "exp", "exp2", "expm1", "log", "log2", "log10", "log1p", "logb",
+    "sin", "cos", "tan", "arcsin", "arccos", "arctan", "degrees", "radians",
+    "sinh", "cosh", "tanh", "arcsinh", "arccosh", "arctanh",
+    "rint", "fix", "floor", "ceil", "trunc", "sinc", "negate", "sign",
+    "clip", "round", "rsqrt", "positive", "reciprocal"])}
+REDUCE = {"sum": 0, "prod": 1, "min": 2, "max": 3, "mean": 4}
+
+
+class OracleError(RuntimeError):
+    """The message the reference would pass to zend_throw_error."""
+
+
+_lib = None
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+
+def build():
+    import sys
+    sys.path.insert(0, str(HERE.parent))
+    from numpower_amd.build import build_oracle
+    return build_oracle()
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB.exists():
+        build()
+    lib = C.CDLL(str(LIB))
+    lib.oracle_last_error.restype = C.c_char_p
+    lib.oracle_map.restype = C.c_long
+    lib.oracle_map.argtypes = [C.c_int, _fp, _fp, C.c_long, C.c_float, C.c_float]
+    lib.oracle_binary.restype = C.c_int
+    lib.oracle_binary.argtypes = [C.c_int, _fp, _ip, C.c_int, _fp, _ip, C.c_int,
+                                  C.POINTER(_fp), _ip, _ip]
+    lib.oracle_free.argtypes = [C.c_void_p]
+    for name in ("oracle_sum", "oracle_prod", "oracle_min", "oracle_max", "oracle_mean"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_float
+        fn.argtypes = [_fp, C.c_long]
+    lib.oracle_reduce_axis.restype = C.c_int
+    lib.oracle_reduce_axis.argtypes = [C.c_int, _fp, _ip, C.c_int, C.c_int, _fp]
+    lib.oracle_set_blas.restype = C.c_int
+    lib.oracle_set_blas.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    lib.oracle_blas_kind.restype = C.c_int
+    lib.oracle_matmul.argtypes = [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]
+    lib.oracle_matvec.argtypes = [C.c_int, C.c_int, _fp, _fp, _fp]
+    lib.oracle_matmul_check.restype = C.c_int
+    lib.oracle_matmul_check.argtypes = [_ip, C.c_int, _ip, C.c_int]
+    lib.oracle_broadcast.restype = C.c_int
+    lib.oracle_broadcast.argtypes = [_fp, _ip, C.c_int, _ip, C.c_int, _fp]
+    _lib = lib
+    return lib
+
+
+def _f(a):
+    return np.asarray(a, dtype=np.float32, order="C")   # (ascontiguousarray would promote 0-d to 1-d)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _shape(a):
+    s = (C.c_int * max(a.ndim, 1))(*a.shape)
+    return s
+
+
+def _err():
+    return OracleError(load().oracle_last_error().decode())
+
+
+# ---------------------------------------------------------------------------------------------
+
+def binary(op: str, a, b) -> np.ndarray:
+    """NDArray_{Add,Subtract,Multiply,Divide,Mod,Pow}_Float(a, b) incl. broadcast + AVX quirks."""
+    lib = load()
+    a, b = _f(a), _f(b)
+    out = _fp()
+    oshape = (C.c_int * 32)()
+    ondim = C.c_int()
+    rc = lib.oracle_binary(BINARY[op], _ptr(a), _shape(a), a.ndim, _ptr(b), _shape(b), b.ndim,
+                           C.byref(out), oshape, C.byref(ondim))
+    if rc != 0:
+        raise _err()
+    shape = tuple(oshape[i] for i in range(ondim.value))
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    res = np.ctypeslib.as_array(out, shape=(n,)).copy().reshape(shape)
+    lib.oracle_free(out)
+    return res
+
+
+def unary(op: str, x, p0: float = 0.0, p1: float = 0.0, strict_domain: bool = False) -> np.ndarray:
+    """NDArray_Map / Map1F / Map2F with the float_* kernel `op`."""
+    x = _f(x)
+    out = np.empty_like(x)
+    bad = load().oracle_map(UNARY[op], _ptr(x), _ptr(out), x.size, p0, p1)
+    if bad and strict_domain:
+        raise OracleError("RuntimeError: Invalid argument provided for %s (reference calls exit(1))" % op)
+    return out
+
+
+def reduce_all(op: str, x) -> np.float32:
+    x = _f(x)
+    fn = getattr(load(), "oracle_" + op)
+    return np.float32(fn(_ptr(x), x.size))
+
+
+def reduce_axis(op: str, x, axis: int) -> np.ndarray:
+    """reduce(x, &axis, Add|Multiply) (+ Divide for mean)."""
+    x = _f(x)
+    out = np.empty(x.shape[:axis] + x.shape[axis + 1:], dtype=np.float32) if 0 <= axis < x.ndim \
+        else np.empty((), dtype=np.float32)
+    rc = load().oracle_reduce_axis(REDUCE[op], _ptr(x), _shape(x), x.ndim, axis, _ptr(out))
+    if rc != 0:
+        raise _err()
+    return out
+
+
+def find_openblas():
+    """Locate an OpenBLAS with the CBLAS interface: (path, symbol_prefix) or None.
+    The reference links whatever -lcblas/-lopenblas the host has (config.m4:67-87)."""
+    cands = []
+    for pat, prefix in (("/usr/lib/x86_64-linux-gnu/libopenblas*.so*", ""),
+                        ("/usr/lib64/libopenblas*.so*", ""),
+                        ("/usr/local/lib/python3*/dist-packages/scipy.libs/libscipy_openblas-*.so", "scipy_"),
+                        ("/usr/lib/python3*/site-packages/scipy.libs/libscipy_openblas-*.so", "scipy_")):
+        for p in sorted(glob.glob(pat)):
+            cands.append((p, prefix))
+    try:
+        import scipy
+        base = Path(scipy.__file__).resolve().parent.parent / "scipy.libs"
+        for p in sorted(base.glob("libscipy_openblas-*.so")):
+            cands.append((str(p), "scipy_"))
+    except Exception:
+        pass
+    return cands[0] if cands else None
+
+
+_blas_info = None
+
+
+def use_openblas(threads: int | None = None):
+    """Attach the oracle's matmul to an OpenBLAS found on this host; returns a description."""
+    global _blas_info
+    if _blas_info is not None:
+        return _blas_info
+    found = find_openblas()
+    if not found:
+        _blas_info = {"kind": "builtin-plain-sgemm", "threads": 1}
+        return _blas_info
+    path, prefix = found
+    t = threads or os.cpu_count() or 1
+    if load().oracle_set_blas(path.encode(), prefix.encode(), t) != 0:
+        _blas_info = {"kind": "builtin-plain-sgemm", "threads": 1, "error": _err().args[0]}
+        return _blas_info
+    _blas_info = {"kind": "openblas", "path": path, "threads": t}
+    return _blas_info
+
+
+def matmul(a, b) -> np.ndarray:
+    """NDArray_Matmul for 2-D operands (cblas_sgemm row-major)."""
+    use_openblas()
+    a, b = _f(a), _f(b)
+    if load().oracle_matmul_check(_shape(a), a.ndim, _shape(b), b.ndim) != 0:
+        raise _err()
+    if a.ndim == 0:
+        return binary("multiply", a, b)
+    if a.ndim == 1:
+        # NDArray_Dot -> NDArray_Inner: sum of products (cblas_sdot), not on the GPU hot path
+        return np.float32(np.dot(a.astype(np.float64), b.astype(np.float64)))
+    m, k = a.shape
+    n = b.shape[1]
+    c = np.zeros((m, n), dtype=np.float32)
+    load().oracle_matmul(m, n, k, _ptr(a), _ptr(b), _ptr(c))
+    return c
+
+
+def matvec(a, x) -> np.ndarray:
+    use_openblas()
+    a, x = _f(a), _f(x)
+    y = np.zeros(a.shape[0], dtype=np.float32)
+    load().oracle_matvec(a.shape[0], a.shape[1], _ptr(a), _ptr(x), _ptr(y))
+    return y

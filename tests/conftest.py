@@ -1,0 +1,29 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement of the reference (oracle/np_oracle.c), built on demand."""
+    from oracle import oracle as o
+    o.load()
+    return o
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The device library through ctypes; skips nothing: a missing .so is a hard error."""
+    from numpower_amd import device
+    device.init(int(os.environ.get("NP_TEST_DEVICE", "0")))
+    return device

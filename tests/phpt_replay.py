@@ -1,0 +1,150 @@
+"""Replay the reference's PHPT known-answer vectors (tests/golden/phpt_vectors.json) through a
+back end and render the results exactly as PHP's print_r would, so the text can be compared with
+the --EXPECT-- section byte for byte.
+
+A back end provides the PHP-visible operations of class NDArray for the hot path:
+    array(nested_list) -> handle          NDArray::array
+    scalar(number) -> handle              int/float operand (0-d CPU scalar, numpower.c:93-98)
+    row(handle, i) -> handle              $a[i]  (view of row i)
+    binary(name, x, y) -> handle|float    operators / NDArray_*_Float
+    unary(name, x, p0, p1) -> handle      NDArray::exp ... (Map family)
+    reduce(name, x, axis|None) -> handle|float
+    matmul(x, y) -> handle
+    to_list(handle) -> nested list of Python floats (toArray())
+Scalars (0-d results, full reductions) come back as Python floats (RETURN_NDARRAY,
+numpower.c:137-150).
+"""
+from __future__ import annotations
+
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+
+VECTORS = Path(__file__).resolve().parent / "golden" / "phpt_vectors.json"
+
+OPERATORS = {"+": "add", "-": "subtract", "*": "multiply", "/": "divide", "**": "pow", "%": "mod"}
+REDUCTIONS = {"sum", "prod", "min", "max", "mean"}
+
+
+def load_vectors():
+    return json.loads(VECTORS.read_text())["tests"]
+
+
+# ---- PHP text rendering ---------------------------------------------------------------------
+
+def php_float(v: float) -> str:
+    """PHP's (string)$float with precision=14 (zend_gcvt): what print_r shows for a double."""
+    v = float(v)
+    if math.isnan(v):
+        return "NAN"
+    if math.isinf(v):
+        return "INF" if v > 0 else "-INF"
+    if v == 0.0:
+        return "-0" if math.copysign(1.0, v) < 0 else "0"
+    s = "%.14G" % v
+    if "E" in s:
+        mant, exp = s.split("E")
+        if "." not in mant:
+            mant += ".0"
+        sign = exp[0]
+        digits = exp[1:].lstrip("0") or "0"
+        return "%sE%s%s" % (mant, sign, digits)
+    return s
+
+
+def print_r(value, indent: int = 0) -> str:
+    """PHP print_r() of a float or a nested array of floats."""
+    if not isinstance(value, list):
+        return php_float(value)
+    pad = " " * indent
+    out = "Array\n" + pad + "(\n"
+    for i, v in enumerate(value):
+        out += pad + "    [%d] => " % i
+        out += print_r(v, indent + 8)
+        out += "\n"
+    out += pad + ")\n"
+    return out
+
+
+# ---- replay -----------------------------------------------------------------------------------
+
+def _operand(backend, env, spec):
+    if "var" in spec:
+        h = env[spec["var"]]
+        if "index" in spec:
+            h = backend.row(h, spec["index"])
+        return h
+    lit = spec["lit"]
+    if isinstance(lit, list):
+        return backend.array(lit)
+    return backend.scalar(lit)
+
+
+def replay(backend, test) -> str:
+    """Run one PHPT record through `backend`; returns the text PHP would have printed."""
+    env = {name: backend.array(val) for name, val in test["vars"].items()}
+    text = ""
+    for call in test["calls"]:
+        args = [_operand(backend, env, a) for a in call["args"]]
+        kw = call.get("kwargs", {})
+        if call["kind"] == "operator":
+            res = backend.binary(OPERATORS[call["op"]], args[0], args[1])
+        else:
+            op = call["op"]
+            if op in REDUCTIONS:
+                res = backend.reduce(op, args[0], kw.get("axis"))
+            elif op == "matmul":
+                res = backend.matmul(args[0], args[1])
+            elif op == "square":     # PHP_METHOD(NDArray, square): Multiply_Float(nda, nda), numpower.c:3093
+                res = backend.binary("multiply", args[0], args[0])
+            elif op == "clip":
+                res = backend.unary("clip", args[0], float(kw["min"]), float(kw["max"]))
+            elif op == "round":
+                res = backend.unary("round", args[0], float(kw["precision"]), 0.0)
+            else:
+                res = backend.unary(op, args[0], 0.0, 0.0)
+        if call["to_array"]:
+            text += print_r(backend.to_list(res))
+        else:
+            text += print_r(float(res))
+    return text
+
+
+class OracleBackend:
+    """Back end = the CPU restatement in oracle/ (numpy arrays stand for CPU NDArrays)."""
+
+    def __init__(self):
+        from oracle import oracle
+        self.o = oracle
+
+    def array(self, nested):
+        return np.array(nested, dtype=np.float32)
+
+    def scalar(self, v):
+        return np.array(v, dtype=np.float32)
+
+    def row(self, h, i):
+        return h[i]
+
+    def _ret(self, a):
+        a = np.asarray(a, dtype=np.float32)
+        return float(a) if a.ndim == 0 else a
+
+    def binary(self, name, x, y):
+        return self._ret(self.o.binary(name, x, y))
+
+    def unary(self, name, x, p0, p1):
+        return self._ret(self.o.unary(name, x, p0, p1))
+
+    def reduce(self, name, x, axis):
+        if axis is None:
+            return float(self.o.reduce_all(name, x))
+        return self._ret(self.o.reduce_axis(name, x, int(axis)))
+
+    def matmul(self, x, y):
+        return self._ret(self.o.matmul(x, y))
+
+    def to_list(self, h):
+        return np.asarray(h, dtype=np.float64).tolist()

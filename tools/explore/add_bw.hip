@@ -1,0 +1,71 @@
+// Exploration harness (dev tool): HBM streaming structures for out = a + b on 1e8 floats.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
+
+template<bool NTL> __device__ __forceinline__ v4f ld(const v4f* p){ if constexpr(NTL) return __builtin_nontemporal_load(p); else return *p; }
+template<bool NTS> __device__ __forceinline__ void st(v4f* p, v4f v){ if constexpr(NTS) __builtin_nontemporal_store(v,p); else *p=v; }
+
+// MODE 0: add (2R+1W), 1: copy (1R+1W), 2: read-only (sum into sink), 3: write-only
+// grid-strided, unrolled accesses one grid apart
+template<int U, bool NTL, bool NTS, int MODE, int T>
+__global__ __launch_bounds__(T) void k_grid(const v4f* a, const v4f* b, v4f* o, unsigned nvec, float* sink){
+  unsigned stride = gridDim.x*T; unsigned tid = blockIdx.x*T+threadIdx.x; v4f accs{0,0,0,0};
+  for(unsigned base=tid; base<nvec; base+=stride*U){
+    v4f va[U], vb[U];
+    #pragma unroll
+    for(int u=0;u<U;++u){ unsigned v=base+u*stride; if(v<nvec){ if(MODE!=3) va[u]=ld<NTL>(a+v); if(MODE==0) vb[u]=ld<NTL>(b+v);} }
+    #pragma unroll
+    for(int u=0;u<U;++u){ unsigned v=base+u*stride; if(v<nvec){ if(MODE==0) st<NTS>(o+v, va[u]+vb[u]); else if(MODE==1) st<NTS>(o+v, va[u]); else if(MODE==2) accs+=va[u]; else st<NTS>(o+v, v4f{1,2,3,4}); } }
+  }
+  if(MODE==2 && accs[0]+accs[1]+accs[2]+accs[3]==12345.678f) sink[0]=1;
+}
+// block-contiguous chunks: block handles U*T consecutive float4, loops over chunks grid-strided
+template<int U, bool NTL, bool NTS, int MODE, int T>
+__global__ __launch_bounds__(T) void k_chunk(const v4f* a, const v4f* b, v4f* o, unsigned nvec, float* sink){
+  v4f accs{0,0,0,0};
+  const unsigned chunk = U*T; unsigned nchunks = (nvec + chunk-1)/chunk;
+  for(unsigned c=blockIdx.x; c<nchunks; c+=gridDim.x){
+    unsigned base = c*chunk + threadIdx.x;
+    v4f va[U], vb[U];
+    #pragma unroll
+    for(int u=0;u<U;++u){ unsigned v=base+u*T; if(v<nvec){ if(MODE!=3) va[u]=ld<NTL>(a+v); if(MODE==0) vb[u]=ld<NTL>(b+v);} }
+    #pragma unroll
+    for(int u=0;u<U;++u){ unsigned v=base+u*T; if(v<nvec){ if(MODE==0) st<NTS>(o+v, va[u]+vb[u]); else if(MODE==1) st<NTS>(o+v, va[u]); else if(MODE==2) accs+=va[u]; else st<NTS>(o+v, v4f{1,2,3,4}); } }
+  }
+  if(MODE==2 && accs[0]+accs[1]+accs[2]+accs[3]==12345.678f) sink[0]=1;
+}
+
+float *A,*B,*O,*S; unsigned nvec; hipStream_t st_;
+template<typename F> void bench(const char* name, double bytes, F launch){
+  for(int i=0;i<3;++i) launch(); CK(hipStreamSynchronize(st_));
+  std::vector<float> ts; hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for(int i=0;i<15;++i){ CK(hipEventRecord(e0,st_)); launch(); CK(hipEventRecord(e1,st_)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); ts.push_back(ms);} 
+  std::sort(ts.begin(), ts.end());
+  printf("%-44s med %.4f ms  %.0f GB/s   min %.4f ms %.0f GB/s\n", name, ts[7], bytes/ts[7]/1e6, ts[0], bytes/ts[0]/1e6); fflush(stdout);
+}
+template<int U,bool NTL,bool NTS,int MODE,int T> void run_cfg(int kind, int bpc){
+  double bytes = (MODE==0?12.0:MODE==1?8.0:4.0)*nvec*4;
+  unsigned grid;
+  if(kind==0){ size_t need=((size_t)nvec+ (size_t)U*T-1)/((size_t)U*T); grid = bpc? std::min<size_t>(need,(size_t)256*bpc):need; }
+  else { size_t need=((size_t)nvec+(size_t)U*T-1)/((size_t)U*T); grid = bpc? std::min<size_t>(need,(size_t)256*bpc):need; }
+  char name[128]; snprintf(name,128,"%s mode%d U%d T%d ntl%d nts%d bpc%d grid%u", kind?"chunk":"grid ", MODE,U,T,(int)NTL,(int)NTS,bpc,grid);
+  if(kind==0) bench(name, bytes, [&]{ k_grid<U,NTL,NTS,MODE,T><<<grid,T,0,st_>>>((v4f*)A,(v4f*)B,(v4f*)O,nvec,S); });
+  else bench(name, bytes, [&]{ k_chunk<U,NTL,NTS,MODE,T><<<grid,T,0,st_>>>((v4f*)A,(v4f*)B,(v4f*)O,nvec,S); });
+}
+template<int U,int T,int MODE> void sweep_nt(int kind,int bpc){ run_cfg<U,true,true,MODE,T>(kind,bpc); run_cfg<U,false,false,MODE,T>(kind,bpc); run_cfg<U,true,false,MODE,T>(kind,bpc); run_cfg<U,false,true,MODE,T>(kind,bpc);} 
+int main(){
+  size_t n=100000000; nvec=n/4; CK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  CK(hipMalloc(&A,n*4)); CK(hipMalloc(&B,n*4)); CK(hipMalloc(&O,n*4)); CK(hipMalloc(&S,4));
+  CK(hipMemsetAsync(A,0x3f,n*4,st_)); CK(hipMemsetAsync(B,0x3e,n*4,st_)); CK(hipMemsetAsync(O,0,n*4,st_));
+  // reference rooflines on this box
+  for(int bpc: {0,2,4,8,16}) { run_cfg<4,true,true,1,256>(1,bpc); run_cfg<4,true,true,2,256>(1,bpc); run_cfg<4,true,true,3,256>(1,bpc);} 
+  // add: structure x bpc
+  for(int kind: {0,1}) for(int bpc: {0,1,2,3,4,6,8,16}) { sweep_nt<4,256,0>(kind,bpc); }
+  for(int kind: {0,1}) for(int bpc: {0,1,2,4,8}) { run_cfg<1,true,true,0,256>(kind,bpc); run_cfg<2,true,true,0,256>(kind,bpc); run_cfg<8,true,true,0,256>(kind,bpc); run_cfg<16,true,true,0,256>(kind,bpc);} 
+  for(int kind: {0,1}) for(int bpc: {0,1,2,4}) { run_cfg<2,true,true,0,512>(kind,bpc); run_cfg<4,true,true,0,512>(kind,bpc); run_cfg<2,true,true,0,1024>(kind,bpc); run_cfg<4,true,true,0,1024>(kind,bpc); run_cfg<4,true,true,0,64>(kind,bpc*4); run_cfg<8,true,true,0,128>(kind,bpc*2);} 
+  return 0;
+}
