@@ -112,7 +112,10 @@ typedef enum np_operand_kind {
     NP_FULL = 0,    /* rows*cols elements                                                   */
     NP_SCALAR = 1,  /* 1 element        (0-d scalar expand, arithmetics.c:169-181)          */
     NP_ROW = 2,     /* cols elements    (1-D / 1xC -> every row, ndarray.c:1202-1223,1273)  */
-    NP_COL = 3      /* rows elements    (Rx1 -> every column, ndarray.c:1226-1272)          */
+    NP_COL = 3,     /* rows elements    (Rx1 -> every column, ndarray.c:1226-1272)          */
+    NP_HOST_SCALAR = 4  /* like NP_SCALAR but the pointer is a HOST pointer to one float: the
+                         * `$gpu_array + 2.0` case, where the 0-d operand lives on the CPU
+                         * (arithmetics.c:163 exempts 0-d operands from the device check)      */
 } np_operand_kind;
 
 /* Result-visible CPU-path quirks of the reference that the kernel can reproduce so that GPU

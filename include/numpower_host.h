@@ -1,0 +1,145 @@
+/*
+ * numpower_host.h — host-side mirror of the reference's NDArray L2/L3 interface for the hot path.
+ *
+ * PHP (and its headers) are not available where this was built, so the layer that sits between
+ * the Zend glue (numpower.c) and the device back end is provided as a plain C-callable library
+ * (libnumpower_host.so, written in C++) with the SAME entry-point names, argument meaning,
+ * ownership rules and error messages as the reference's C files, so that numpower.c's
+ * PHP_METHODs can call it unchanged:
+ *
+ *   struct NDArray / NDArrayDescriptor          src/ndarray.h:52-74   (same field order)
+ *   NDArray_Zeros/Empty/EmptyLike/Copy/Fill,
+ *   NDArray_CreateFrom{Double,Float,Long}Scalar  src/initializers.c:379-448,633-790
+ *   NDArray_FREE                                 src/ndarray.c:587-632
+ *   NDArray_ToGPU / NDArray_ToCPU                src/ndarray.c:1037-1093
+ *   NDArray_{Add,Subtract,Multiply,Divide,Mod,Pow}_Float, NDArray_Abs,
+ *   NDArray_Sum_Float / Float_Prod / Mean_Float  src/ndmath/arithmetics.c:36-947
+ *   NDArray_Min / NDArray_Max                    src/ndarray.c:752-772,939-959
+ *   reduce()                                     src/ndarray.c:523-578
+ *   NDArrayMathGPU_ElementWise{,1F,2F,1N}        src/ndmath/cuda/cuda_math.cu:1532-1558
+ *   NDArray_Matmul / NDArray_FMatmul / NDArray_Dot   src/ndmath/linalg.c:44-82,216-245,354-393
+ *
+ * Device work goes through the C ABI of include/np_hip.h; this library contains no kernels and
+ * no CPU arithmetic.  Arrays on NDARRAY_DEVICE_CPU exist only as staging for ->gpu()/->cpu()
+ * and as 0-d scalar operands: an arithmetic call whose array operands live on the CPU fails with
+ * an error (the reference's CPU path — AVX2/OpenBLAS — stays the reference's own code; this
+ * library never computes on the host).
+ *
+ * Errors: where the reference calls zend_throw_error(NULL, msg) and returns NULL, these
+ * functions call the installed error handler with the same message (default: remember it for
+ * numpower_host_last_error()) and return NULL.
+ */
+#ifndef NUMPOWER_AMD_HOST_H
+#define NUMPOWER_AMD_HOST_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDARRAY_DEVICE_CPU 0
+#define NDARRAY_DEVICE_GPU 1
+
+typedef struct NDArrayDescriptor {
+    const char *type;   /* "float32" */
+    int elsize;
+    long numElements;
+} NDArrayDescriptor;
+
+typedef struct NDArray {
+    int uuid;
+    int *strides;       /* bytes */
+    int *dimensions;
+    int ndim;
+    char *data;         /* host pointer (device == CPU) or device pointer (device == GPU) */
+    struct NDArray *base;
+    int flags;
+    NDArrayDescriptor *descriptor;
+    void *iterator;
+    void *php_iterator;
+    int refcount;
+    int device;
+} NDArray;
+
+#define NDArray_FDATA(a) ((float *) ((a)->data))
+#define NDArray_NDIM(a) ((int) ((a)->ndim))
+#define NDArray_SHAPE(a) ((int *) ((a)->dimensions))
+#define NDArray_NUMELEMENTS(a) ((long) ((a)->descriptor->numElements))
+#define NDArray_DEVICE(a) ((int) ((a)->device))
+
+/* ---- errors (zend_throw_error stand-in) ---- */
+typedef void (*numpower_error_handler)(const char *message);
+void numpower_host_set_error_handler(numpower_error_handler handler);   /* NULL = default */
+const char *numpower_host_last_error(void);   /* "" if none since the last clear */
+void numpower_host_clear_error(void);
+
+/* ---- allocation / placement ---- */
+/* shape is copied (the reference takes ownership of an emalloc'd shape; copying keeps the C API
+ * usable from ctypes — the Zend glue frees its own vector). */
+NDArray *NDArray_Zeros(const int *shape, int ndim, const char *type, int device);
+NDArray *NDArray_Empty(const int *shape, int ndim, const char *type, int device);
+NDArray *NDArray_EmptyLike(NDArray *a);
+NDArray *NDArray_Copy(NDArray *a, int device);   /* same-device copy (device must equal a's) */
+NDArray *NDArray_Fill(NDArray *a, float fill_value);
+NDArray *NDArray_CreateFromDoubleScalar(double scalar);
+NDArray *NDArray_CreateFromFloatScalar(float scalar);
+NDArray *NDArray_CreateFromLongScalar(long scalar);
+/* CPU array from a host buffer (stands in for Create_NDArray_FromZval, initializers.c:30-247) */
+NDArray *NDArray_FromHostBuffer(const float *host_data, const int *shape, int ndim);
+/* View of slice `index` along the leading axis: what $a[i] / NDArrayIterator_GET return
+ * (iterators.c:94-111): shares data, base = a, ADDREFs a. */
+NDArray *NDArray_LeadingSlice(NDArray *a, int index);
+void NDArray_FREE(NDArray *array);
+NDArray *NDArray_ToGPU(NDArray *target);
+NDArray *NDArray_ToCPU(NDArray *target);
+float NDArray_GetFloatScalar(NDArray *a);        /* ndarray.c:1302-1310 */
+/* copy numElements floats of a CPU array into host_out (toArray() plumbing) */
+int NDArray_CopyToHostBuffer(NDArray *a, float *host_out);
+/* live device allocations (vmemcheck, gpu_alloc.c:36-40) */
+long NDArray_LiveDeviceAllocations(void);
+
+/* ---- binary elementwise (arithmetics.c:160-926) ---- */
+NDArray *NDArray_Add_Float(NDArray *a, NDArray *b);
+NDArray *NDArray_Subtract_Float(NDArray *a, NDArray *b);
+NDArray *NDArray_Multiply_Float(NDArray *a, NDArray *b);
+NDArray *NDArray_Divide_Float(NDArray *a, NDArray *b);
+NDArray *NDArray_Mod_Float(NDArray *a, NDArray *b);
+NDArray *NDArray_Pow_Float(NDArray *a, NDArray *b);
+int NDArray_IsBroadcastable(const NDArray *array1, const NDArray *array2);   /* ndarray.c:1124-1162 */
+
+/* ---- unary elementwise (cuda_math.cu:1532-1558; op = np_unary_op of np_hip.h) ---- */
+NDArray *NDArrayMathGPU_ElementWise(NDArray *ndarray, int op);
+NDArray *NDArrayMathGPU_ElementWise1F(NDArray *ndarray, int op, float val1);
+NDArray *NDArrayMathGPU_ElementWise2F(NDArray *ndarray, int op, float val1, float val2);
+NDArray *NDArrayMathGPU_ElementWise1N(NDArray *ndarray, int op /* np_binary_op */, NDArray *val1);
+NDArray *NDArray_Abs(NDArray *nda);
+
+/* ---- reductions ---- */
+float NDArray_Sum_Float(NDArray *a);
+float NDArray_Float_Prod(NDArray *a);
+float NDArray_Mean_Float(NDArray *a);
+float NDArray_Min(NDArray *target);
+float NDArray_Max(NDArray *target);
+/* operation must be NDArray_Add_Float or NDArray_Multiply_Float (the two the reference passes,
+ * numpower.c:4637,4742,2661); anything else is an error. */
+NDArray *reduce(NDArray *array, int *axis, NDArray *(*operation)(NDArray *, NDArray *));
+/* min/max along an axis: the reference's single_reduce path is unreachable/broken
+ * (numpower.c:4654 parses one argument; apply_single_reduce writes element 0 only), so these are
+ * additions with NumPy semantics. */
+NDArray *NDArray_MinAxis(NDArray *target, int axis);
+NDArray *NDArray_MaxAxis(NDArray *target, int axis);
+
+/* ---- matmul ---- */
+NDArray *NDArray_Matmul(NDArray *a, NDArray *b);
+NDArray *NDArray_FMatmul(NDArray *a, NDArray *b);
+NDArray *NDArray_Dot(NDArray *nda, NDArray *ndb);
+/* batch x M x K times batch x K x N -> batch x M x N (BASELINE config 5; no reference entry
+ * point: linalg.c:239-242 rejects ndim > 2 with "Stack of matrices not allowed") */
+NDArray *NDArray_BatchedMatmul(NDArray *a, NDArray *b);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NUMPOWER_AMD_HOST_H */

@@ -162,12 +162,14 @@ template <int OP, int AK, int BK, bool QUIRK, int UNROLL, bool NT, typename I>
 __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict__ a,
                                                          const float *__restrict__ b,
                                                          float *__restrict__ out, I nvec, I cols4,
-                                                         I tail_start, I n, I body_end) {
+                                                         I tail_start, I n, I body_end, float ha,
+                                                         float hb) {
     const I stride = (I)gridDim.x * blockDim.x;
     const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    // scalar operands: device pointer, or (null pointer) a value handed over by the host
     float sa = 0.0f, sb = 0.0f;
-    if constexpr (AK == NP_SCALAR) sa = a[0];
-    if constexpr (BK == NP_SCALAR) sb = b[0];
+    if constexpr (AK == NP_SCALAR) sa = a ? a[0] : ha;
+    if constexpr (BK == NP_SCALAR) sb = b ? b[0] : hb;
 
     for (I base = tid; base < nvec; base += stride * UNROLL) {
         v4f va[UNROLL], vb[UNROLL];
@@ -208,19 +210,19 @@ template <int OP, bool QUIRK, typename I>
 __global__ __launch_bounds__(256) void binary_scalar_kernel(const float *__restrict__ a, int ak,
                                                             const float *__restrict__ b, int bk,
                                                             float *__restrict__ out, I n, I cols,
-                                                            I body_end) {
+                                                            I body_end, float ha, float hb) {
     const I stride = (I)gridDim.x * blockDim.x;
     for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float x, y;
         switch (ak) {
             case NP_FULL: x = a[i]; break;
-            case NP_SCALAR: x = a[0]; break;
+            case NP_SCALAR: x = a ? a[0] : ha; break;
             case NP_ROW: x = a[i % cols]; break;
             default: x = a[i / cols]; break;
         }
         switch (bk) {
             case NP_FULL: y = b[i]; break;
-            case NP_SCALAR: y = b[0]; break;
+            case NP_SCALAR: y = b ? b[0] : hb; break;
             case NP_ROW: y = b[i % cols]; break;
             default: y = b[i / cols]; break;
         }
@@ -292,16 +294,21 @@ struct LaunchCfg {
     bool nt;             // non-temporal loads/stores
 };
 
+// Default = what tools/explore/add_bw.hip measured fastest on MI355X for 2R+1W streams of 1e8
+// floats (profiles/r01_add_bw_explore.log): no grid cap — every lane moves UNROLL float4 and
+// retires, ~24k workgroups keep the dispatcher ahead of the memory system — with non-temporal
+// loads and stores.  Capping the grid at a few workgroups per CU and grid-striding was 3-8 %
+// slower; cached (non-nt) accesses 5-10 % slower.
 // variant = unroll_code + 10*bpc_code + 100*nt ; 0 = default
 LaunchCfg cfg_from_variant(int variant) {
-    LaunchCfg c{4, 8, true};
+    LaunchCfg c{4, 0, true};
     if (variant <= 0) return c;
     const int u = variant % 10, b = (variant / 10) % 10, nt = (variant / 100) % 10;
     if (u == 1) c.unroll = 1;
     if (u == 2) c.unroll = 2;
     if (u == 4) c.unroll = 4;
     if (u == 8) c.unroll = 8;
-    if (b > 0) c.blocks_per_cu = b * 2;   // 1..9 -> 2..18
+    c.blocks_per_cu = b * 2;   // 0 = uncapped, 1..9 -> 2..18 workgroups per CU
     c.nt = (nt != 0);
     return c;
 }
@@ -309,8 +316,11 @@ LaunchCfg cfg_from_variant(int variant) {
 unsigned grid_for(size_t work_items, int per_thread, int blocks_per_cu) {
     const size_t threads = (work_items + per_thread - 1) / per_thread;
     size_t blocks = (threads + 255) / 256;
-    const size_t cap = (size_t)np::num_cus() * blocks_per_cu;
-    if (blocks > cap) blocks = cap;
+    if (blocks_per_cu > 0) {
+        const size_t cap = (size_t)np::num_cus() * blocks_per_cu;
+        if (blocks > cap) blocks = cap;
+    }
+    if (blocks > 0x7fffffffu) blocks = 0x7fffffffu;
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
 }
@@ -321,7 +331,7 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 template <int OP, int AK, int BK, bool QUIRK, typename I>
 int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size_t cols,
-                      size_t body_end) {
+                      size_t body_end, float ha, float hb) {
     const LaunchCfg c = cfg_from_variant(g_variant);
     const I nvec = (I)(n / 4), cols4 = (I)(cols / 4), tail = (I)(n / 4 * 4);
     const unsigned grid = grid_for(n / 4 + 1, c.unroll, c.blocks_per_cu);
@@ -329,7 +339,7 @@ int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size
 #define NP_BV(U, NT)                                                                       \
     binary_vec_kernel<OP, AK, BK, QUIRK, U, NT, I><<<grid, 256, 0, s>>>(a, b, out, nvec,   \
                                                                          cols4, tail, (I)n, \
-                                                                         (I)body_end)
+                                                                         (I)body_end, ha, hb)
     if (c.nt) {
         switch (c.unroll) {
             case 1: NP_BV(1, true); break;
@@ -352,17 +362,17 @@ int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size
 
 template <int OP, bool QUIRK, typename I>
 int launch_binary_scalar(const float *a, int ak, const float *b, int bk, float *out, size_t n,
-                         size_t cols, size_t body_end) {
+                         size_t cols, size_t body_end, float ha, float hb) {
     const unsigned grid = grid_for(n, 4, 16);
     binary_scalar_kernel<OP, QUIRK, I>
-        <<<grid, 256, 0, np::stream()>>>(a, ak, b, bk, out, (I)n, (I)cols, (I)body_end);
+        <<<grid, 256, 0, np::stream()>>>(a, ak, b, bk, out, (I)n, (I)cols, (I)body_end, ha, hb);
     NP_LAUNCH_CHECK("binary_scalar_kernel");
     return NP_OK;
 }
 
 template <int OP, bool QUIRK, typename I>
 int dispatch_binary_kinds(const float *a, int ak, const float *b, int bk, float *out, size_t rows,
-                          size_t cols, size_t body_end) {
+                          size_t cols, size_t body_end, float ha, float hb) {
     const size_t n = rows * cols;
     // vector path: all FULL pointers 16-byte aligned; ROW/COL operands need cols % 4 == 0 so a
     // float4 never straddles a row (ROW pointers must be aligned too).
@@ -374,7 +384,7 @@ int dispatch_binary_kinds(const float *a, int ak, const float *b, int bk, float 
     if (vec) {
 #define NP_BK(AK_, BK_)                                                                     \
     if (ak == AK_ && bk == BK_)                                                             \
-        return launch_binary_vec<OP, AK_, BK_, QUIRK, I>(a, b, out, n, cols, body_end)
+        return launch_binary_vec<OP, AK_, BK_, QUIRK, I>(a, b, out, n, cols, body_end, ha, hb)
         NP_BK(NP_FULL, NP_FULL);
         NP_BK(NP_FULL, NP_SCALAR);
         NP_BK(NP_SCALAR, NP_FULL);
@@ -384,29 +394,29 @@ int dispatch_binary_kinds(const float *a, int ak, const float *b, int bk, float 
         NP_BK(NP_COL, NP_FULL);
 #undef NP_BK
     }
-    return launch_binary_scalar<OP, QUIRK, I>(a, ak, b, bk, out, n, cols, body_end);
+    return launch_binary_scalar<OP, QUIRK, I>(a, ak, b, bk, out, n, cols, body_end, ha, hb);
 }
 
 template <int OP, bool QUIRK>
 int dispatch_binary_index(const float *a, int ak, const float *b, int bk, float *out, size_t rows,
-                          size_t cols, size_t body_end) {
+                          size_t cols, size_t body_end, float ha, float hb) {
     const size_t n = rows * cols;
     if (n < (size_t(1) << 31)) {
         if (body_end > n) body_end = n;
-        return dispatch_binary_kinds<OP, QUIRK, uint32_t>(a, ak, b, bk, out, rows, cols, body_end);
+        return dispatch_binary_kinds<OP, QUIRK, uint32_t>(a, ak, b, bk, out, rows, cols, body_end, ha, hb);
     }
-    return dispatch_binary_kinds<OP, QUIRK, uint64_t>(a, ak, b, bk, out, rows, cols, body_end);
+    return dispatch_binary_kinds<OP, QUIRK, uint64_t>(a, ak, b, bk, out, rows, cols, body_end, ha, hb);
 }
 
 template <int OP>
 int dispatch_binary_quirk(const float *a, int ak, const float *b, int bk, float *out, size_t rows,
-                          size_t cols, unsigned flags, size_t body_end) {
+                          size_t cols, unsigned flags, size_t body_end, float ha, float hb) {
     constexpr bool has_quirk = (OP == NP_MULTIPLY || OP == NP_MOD);
     if constexpr (has_quirk) {
         if (flags & NP_QUIRK_AVX_BODY)
-            return dispatch_binary_index<OP, true>(a, ak, b, bk, out, rows, cols, body_end);
+            return dispatch_binary_index<OP, true>(a, ak, b, bk, out, rows, cols, body_end, ha, hb);
     }
-    return dispatch_binary_index<OP, false>(a, ak, b, bk, out, rows, cols, 0);
+    return dispatch_binary_index<OP, false>(a, ak, b, bk, out, rows, cols, 0, ha, hb);
 }
 
 // ---- unary dispatch ----
@@ -473,20 +483,24 @@ int np_binary(int op, const float *a, int a_kind, const float *b, int b_kind, fl
               size_t rows, size_t cols, unsigned flags, size_t body_end) {
     if (op < 0 || op >= NP_BINARY_OP_COUNT)
         return np::fail(NP_ERR_INVALID, "np_binary: unknown op %d", op);
-    if (a_kind < NP_FULL || a_kind > NP_COL || b_kind < NP_FULL || b_kind > NP_COL)
+    if (a_kind < NP_FULL || a_kind > NP_HOST_SCALAR || b_kind < NP_FULL || b_kind > NP_HOST_SCALAR)
         return np::fail(NP_ERR_INVALID, "np_binary: unknown operand kind (%d, %d)", a_kind, b_kind);
     if (rows == 0 || cols == 0) return NP_OK;
     if (!a || !b || !out) return np::fail(NP_ERR_INVALID, "np_binary: null pointer");
     if (int rc = np::ensure_init()) return rc;
     (void)operand_elems;
+    // host scalars travel by value (kernel argument); the kernels see kind SCALAR + null pointer
+    float ha = 0.0f, hb = 0.0f;
+    if (a_kind == NP_HOST_SCALAR) { ha = *a; a = nullptr; a_kind = NP_SCALAR; }
+    if (b_kind == NP_HOST_SCALAR) { hb = *b; b = nullptr; b_kind = NP_SCALAR; }
     switch (op) {
-        case NP_ADD: return dispatch_binary_quirk<NP_ADD>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
-        case NP_SUBTRACT: return dispatch_binary_quirk<NP_SUBTRACT>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
-        case NP_MULTIPLY: return dispatch_binary_quirk<NP_MULTIPLY>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
-        case NP_DIVIDE: return dispatch_binary_quirk<NP_DIVIDE>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
-        case NP_MOD: return dispatch_binary_quirk<NP_MOD>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
-        case NP_POW: return dispatch_binary_quirk<NP_POW>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
-        default: return dispatch_binary_quirk<NP_ARCTAN2>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end);
+        case NP_ADD: return dispatch_binary_quirk<NP_ADD>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_SUBTRACT: return dispatch_binary_quirk<NP_SUBTRACT>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_MULTIPLY: return dispatch_binary_quirk<NP_MULTIPLY>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_DIVIDE: return dispatch_binary_quirk<NP_DIVIDE>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_MOD: return dispatch_binary_quirk<NP_MOD>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_POW: return dispatch_binary_quirk<NP_POW>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        default: return dispatch_binary_quirk<NP_ARCTAN2>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
     }
 }
 

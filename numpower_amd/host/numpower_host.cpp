@@ -1,0 +1,602 @@
+// libnumpower_host.so — host-side mirror of the reference's NDArray L2/L3 entry points for the
+// hot path (include/numpower_host.h).  No kernels and no host arithmetic live here: every op
+// classifies its operands the way the reference does (scalar expand, broadcast pattern, shape
+// and device checks, error messages) and then makes ONE call into the C ABI of np_hip.h.
+//
+// What the reference does around each op and what happens here instead:
+//   scalar operand   Zeros + Fill of a full-size temporary (arithmetics.c:169-181)
+//                    -> operand kind NP_SCALAR / NP_HOST_SCALAR, no temporary
+//   broadcast        NDArray_Broadcast materialises a full-size copy, on the GPU with one
+//                    cudaMemcpy per row or per ELEMENT (ndarray.c:1214-1267)
+//                    -> operand kind NP_ROW / NP_COL, index arithmetic in the kernel
+//   result buffer    vmalloc + cudaDeviceSynchronize per op (arithmetics.c:216-221)
+//                    -> np_malloc from the caching pool, no sync
+//   unary ops        NDArray_Copy then in-place kernel (cuda_math.cu:1532-1537)
+//                    -> one out-of-place kernel
+//   axis reductions  one Add_Float + alloc + D2D copy + free per slice (ndarray.c:394-429)
+//                    -> np_reduce_axis (one or two launches)
+//   matmul           cublasCreate / cublasSgemm / cublasDestroy per call (linalg.c:55-71)
+//                    -> np_sgemm
+#include "numpower_host.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "np_hip.h"
+
+namespace {
+
+const char *const TYPE_FLOAT32 = "float32";   // src/types.h:5
+
+thread_local char g_error[512] = "";
+numpower_error_handler g_handler = nullptr;
+
+// zend_throw_error(NULL, fmt, ...) stand-in
+void throw_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    if (g_handler) g_handler(g_error);
+}
+
+// a failed C-ABI call surfaces its own message
+bool dev_ok(int rc) {
+    if (rc == NP_OK) return true;
+    throw_error("%s", np_last_error());
+    return false;
+}
+
+long shape_numel(const int *shape, int ndim) {
+    long n = 1;   // ndim == 0 -> 1 (Create_NDArray, initializers.c:265-269)
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    return n;
+}
+
+// Generate_Strides (initializers.c:115-135): byte strides, C order
+int *make_strides(const int *shape, int ndim) {
+    int *st = (int *)malloc(sizeof(int) * (ndim > 0 ? ndim : 1));
+    if (ndim > 0) {
+        st[ndim - 1] = (int)sizeof(float);
+        for (int i = ndim - 2; i >= 0; --i) st[i] = shape[i + 1] * st[i + 1];
+    }
+    return st;
+}
+
+// Create_NDArray (initializers.c:255-286) without data
+NDArray *make_header(const int *shape, int ndim, int device) {
+    NDArray *a = (NDArray *)calloc(1, sizeof(NDArray));
+    a->dimensions = (int *)malloc(sizeof(int) * (ndim > 0 ? ndim : 1));
+    if (ndim > 0) memcpy(a->dimensions, shape, sizeof(int) * ndim);
+    a->strides = make_strides(shape, ndim);
+    a->ndim = ndim;
+    a->descriptor = (NDArrayDescriptor *)malloc(sizeof(NDArrayDescriptor));
+    a->descriptor->type = TYPE_FLOAT32;
+    a->descriptor->elsize = (int)sizeof(float);
+    a->descriptor->numElements = shape_numel(shape, ndim);
+    a->refcount = 1;
+    a->device = device;
+    return a;
+}
+
+void free_header(NDArray *a) {
+    free(a->strides);
+    free(a->dimensions);
+    free(a->descriptor);
+    free(a);
+}
+
+// allocate the data buffer of a fresh header on its device
+bool alloc_data(NDArray *a, bool zero) {
+    const size_t bytes = (size_t)NDArray_NUMELEMENTS(a) * sizeof(float);
+    if (a->device == NDARRAY_DEVICE_GPU) {
+        void *p = nullptr;
+        if (!dev_ok(np_malloc(&p, bytes ? bytes : sizeof(float)))) return false;
+        a->data = (char *)p;
+        if (zero && bytes && !dev_ok(np_memset0(p, bytes))) return false;
+    } else {
+        a->data = (char *)(zero ? calloc(bytes ? bytes : sizeof(float), 1)
+                                : malloc(bytes ? bytes : sizeof(float)));
+    }
+    return true;
+}
+
+NDArray *new_array(const int *shape, int ndim, int device, bool zero) {
+    NDArray *a = make_header(shape, ndim, device);
+    if (!alloc_data(a, zero)) {
+        free_header(a);
+        return nullptr;
+    }
+    return a;
+}
+
+bool same_shape(const NDArray *a, const NDArray *b) {
+    if (a->ndim != b->ndim) return false;
+    for (int i = 0; i < a->ndim; ++i)
+        if (a->dimensions[i] != b->dimensions[i]) return false;
+    return true;
+}
+
+bool require_gpu(const NDArray *a, const char *what) {
+    if (a->device == NDARRAY_DEVICE_GPU) return true;
+    throw_error("%s: operand is on the CPU; numpower_amd only computes on the GPU "
+                "(call ->gpu() first, the CPU path is the reference's own)", what);
+    return false;
+}
+
+// How the smaller operand maps onto the larger one (the patterns of NDArray_Broadcast,
+// ndarray.c:1196-1291, with the intended NumPy meaning: the reference's own materialisation
+// leaves memory uninitialised for ndim > 2 destinations and for 1xC sources with C != R).
+// Returns the np_operand_kind or -1 ("Can't broadcast arrays.").
+int broadcast_kind(const NDArray *small, const NDArray *large, size_t *rows, size_t *cols) {
+    const int ln = large->ndim, sn = small->ndim;
+    const long lnum = NDArray_NUMELEMENTS(large);
+    if (!NDArray_IsBroadcastable(small, large)) return -1;
+    if (sn == 1 && ln > 1) {   // ndarray.c:1202-1223
+        *cols = (size_t)large->dimensions[ln - 1];
+        *rows = (size_t)(lnum / (long)*cols);
+        return NP_ROW;
+    }
+    if (sn == 2 && ln == 2) {
+        const int sr = small->dimensions[0], sc = small->dimensions[1];
+        const int lr = large->dimensions[0], lc = large->dimensions[1];
+        *rows = (size_t)lr;
+        *cols = (size_t)lc;
+        if (sr == 1 && sc == 1) return NP_SCALAR;          // ndarray.c:1238-1246
+        if (sr == lr && sc == 1) return NP_COL;            // ndarray.c:1227-1237
+        if (sr == 1 && sc == lc) return NP_ROW;            // ndarray.c:1273-1291
+    }
+    return -1;
+}
+
+typedef NDArray *(*binary_fn)(NDArray *, NDArray *);
+
+// Shared body of NDArray_{Add,Subtract,Multiply,Divide,Mod,Pow}_Float (arithmetics.c:160-926).
+NDArray *binary_op(int op, NDArray *a, NDArray *b) {
+    if (!a || !b) return nullptr;
+    // arithmetics.c:163-166 — 0-d operands are exempt from the device check
+    if (NDArray_DEVICE(a) != NDArray_DEVICE(b) && NDArray_NDIM(a) != 0 && NDArray_NDIM(b) != 0) {
+        throw_error("Device mismatch, both NDArray MUST be in the same device.");
+        return nullptr;
+    }
+    const bool a_scalar = NDArray_NDIM(a) == 0, b_scalar = NDArray_NDIM(b) == 0;
+    // where does the result live?  With a 0-d operand the other one decides.
+    const NDArray *place = a_scalar && !b_scalar ? b : a;
+    if (a_scalar && b_scalar && NDArray_DEVICE(a) != NDARRAY_DEVICE_GPU &&
+        NDArray_DEVICE(b) != NDARRAY_DEVICE_GPU) {
+        throw_error("binary op on two CPU scalars: not a GPU operation");
+        return nullptr;
+    }
+    if (a_scalar && b_scalar && NDArray_DEVICE(a) != NDARRAY_DEVICE_GPU) place = b;
+    if (!require_gpu(place, "binary op")) return nullptr;
+
+    const long na = NDArray_NUMELEMENTS(a), nb = NDArray_NUMELEMENTS(b);
+    int ak = NP_FULL, bk = NP_FULL;
+    size_t rows = 1, cols = 1;
+    const NDArray *shape_of = a;
+    // AVX-body bound of the reference: NDArray_NUMELEMENTS(a) with a = first operand after the
+    // scalar expand but before the broadcast (arithmetics.c:251)
+    size_t loop_numel_a = (size_t)na;
+
+    if (a_scalar || b_scalar) {
+        const NDArray *full = a_scalar ? b : a;   // both scalars: 1 x 1
+        shape_of = full;
+        cols = (size_t)NDArray_NUMELEMENTS(full);
+        if (a_scalar && !b_scalar) {
+            ak = NDArray_DEVICE(a) == NDARRAY_DEVICE_GPU ? NP_SCALAR : NP_HOST_SCALAR;
+            loop_numel_a = (size_t)nb;
+        } else if (b_scalar && !a_scalar) {
+            bk = NDArray_DEVICE(b) == NDARRAY_DEVICE_GPU ? NP_SCALAR : NP_HOST_SCALAR;
+        } else {
+            ak = NDArray_DEVICE(a) == NDARRAY_DEVICE_GPU ? NP_SCALAR : NP_HOST_SCALAR;
+            bk = NDArray_DEVICE(b) == NDARRAY_DEVICE_GPU ? NP_SCALAR : NP_HOST_SCALAR;
+        }
+    } else if (na < nb) {           // arithmetics.c:186-189
+        const int k = broadcast_kind(a, b, &rows, &cols);
+        if (k < 0) {
+            throw_error("Can't broadcast arrays.");
+            return nullptr;
+        }
+        ak = k;
+        shape_of = b;
+    } else if (nb < na) {           // arithmetics.c:190-193
+        const int k = broadcast_kind(b, a, &rows, &cols);
+        if (k < 0) {
+            throw_error("Can't broadcast arrays.");
+            return nullptr;
+        }
+        bk = k;
+    } else {
+        cols = (size_t)na;          // equal element counts: flat elementwise (arithmetics.c:194-197)
+    }
+
+    NDArray *result = new_array(shape_of->dimensions, shape_of->ndim, NDARRAY_DEVICE_GPU, false);
+    if (!result) return nullptr;
+    // 0-d x 0-d multiply/divide take the plain short cut (arithmetics.c:302-316,575-580)
+    const bool quirk_ops = (op == NP_MULTIPLY || op == NP_MOD) && !(a_scalar && b_scalar);
+    const unsigned flags = quirk_ops ? NP_QUIRK_AVX_BODY : 0u;
+    const size_t body_end = quirk_ops ? np_avx_body_end(loop_numel_a) : 0;
+    if (!dev_ok(np_binary(op, NDArray_FDATA(a), ak, NDArray_FDATA(b), bk, NDArray_FDATA(result), rows,
+                          cols, flags, body_end))) {
+        NDArray_FREE(result);
+        return nullptr;
+    }
+    return result;
+}
+
+NDArray *unary_op(NDArray *x, int op, float p0, float p1) {
+    if (!x) return nullptr;
+    if (!require_gpu(x, "elementwise op")) return nullptr;
+    NDArray *out = new_array(x->dimensions, x->ndim, NDARRAY_DEVICE_GPU, false);
+    if (!out) return nullptr;
+    if (!dev_ok(np_unary(op, NDArray_FDATA(x), NDArray_FDATA(out), (size_t)NDArray_NUMELEMENTS(x), p0, p1))) {
+        NDArray_FREE(out);
+        return nullptr;
+    }
+    return out;
+}
+
+float reduce_all(NDArray *a, int op, const char *what) {
+    if (!a || !require_gpu(a, what)) return -1.0f;
+    float v = 0.0f;
+    if (!dev_ok(np_reduce_all(op, NDArray_FDATA(a), (size_t)NDArray_NUMELEMENTS(a), &v))) return -1.0f;
+    return v;
+}
+
+NDArray *reduce_axis(NDArray *array, int axis, int op, bool quirk) {
+    if (!array) return nullptr;
+    if (axis >= NDArray_NDIM(array) || axis < 0) {   // ndarray.c:534-538
+        throw_error("axis %d is out of bounds for array of dimension %d", axis, NDArray_NDIM(array));
+        return nullptr;
+    }
+    if (!require_gpu(array, "axis reduction")) return nullptr;
+    const int nd = NDArray_NDIM(array);
+    int out_shape[128];
+    int j = 0;
+    size_t outer = 1, inner = 1;
+    for (int i = 0; i < nd; ++i) {
+        if (i != axis) out_shape[j++] = array->dimensions[i];
+        if (i < axis) outer *= (size_t)array->dimensions[i];
+        if (i > axis) inner *= (size_t)array->dimensions[i];
+    }
+    NDArray *rtn = new_array(out_shape, nd - 1, NDARRAY_DEVICE_GPU, false);
+    if (!rtn) return nullptr;
+    // slices are (nd - axis - 1)-dimensional; 0-d slices multiply without the zero-sign fix
+    const unsigned flags = (quirk && nd - axis - 1 >= 1) ? NP_QUIRK_AVX_BODY : 0u;
+    if (!dev_ok(np_reduce_axis(op, NDArray_FDATA(array), outer, (size_t)array->dimensions[axis], inner,
+                               NDArray_FDATA(rtn), flags))) {
+        NDArray_FREE(rtn);
+        return nullptr;
+    }
+    return rtn;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* ---- errors ---- */
+void numpower_host_set_error_handler(numpower_error_handler handler) { g_handler = handler; }
+const char *numpower_host_last_error(void) { return g_error; }
+void numpower_host_clear_error(void) { g_error[0] = '\0'; }
+
+/* ---- allocation / placement ---- */
+
+NDArray *NDArray_Zeros(const int *shape, int ndim, const char *type, int device) {
+    (void)type;
+    if (ndim > 0 && !shape) return nullptr;
+    return new_array(shape, ndim, device, true);
+}
+
+NDArray *NDArray_Empty(const int *shape, int ndim, const char *type, int device) {
+    (void)type;
+    if (ndim > 0 && !shape) return nullptr;
+    return new_array(shape, ndim, device, false);
+}
+
+NDArray *NDArray_EmptyLike(NDArray *a) {
+    return new_array(a->dimensions, a->ndim, a->device, false);
+}
+
+NDArray *NDArray_Copy(NDArray *a, int device) {   // initializers.c:742-790
+    if (!a) return nullptr;
+    if (device != a->device) {
+        throw_error("NDArray_Copy: use NDArray_ToGPU / NDArray_ToCPU to change devices");
+        return nullptr;
+    }
+    NDArray *r = new_array(a->dimensions, a->ndim, device, false);
+    if (!r) return nullptr;
+    const size_t bytes = (size_t)NDArray_NUMELEMENTS(a) * sizeof(float);
+    if (device == NDARRAY_DEVICE_GPU) {
+        if (!dev_ok(np_memcpy_d2d(r->data, a->data, bytes))) {
+            NDArray_FREE(r);
+            return nullptr;
+        }
+    } else {
+        memcpy(r->data, a->data, bytes);
+    }
+    return r;
+}
+
+NDArray *NDArray_Fill(NDArray *a, float fill_value) {   // initializers.c:633-648
+    if (!a) return nullptr;
+    const size_t n = (size_t)NDArray_NUMELEMENTS(a);
+    if (a->device == NDARRAY_DEVICE_GPU) {
+        if (!dev_ok(np_fill(NDArray_FDATA(a), fill_value, n))) return nullptr;
+    } else {
+        // plain store loop: placement plumbing, not arithmetic
+        for (size_t i = 0; i < n; ++i) NDArray_FDATA(a)[i] = fill_value;
+    }
+    return a;
+}
+
+NDArray *NDArray_CreateFromFloatScalar(float scalar) {   // initializers.c:693-710
+    NDArray *r = new_array(nullptr, 0, NDARRAY_DEVICE_CPU, false);
+    NDArray_FDATA(r)[0] = scalar;
+    return r;
+}
+NDArray *NDArray_CreateFromDoubleScalar(double scalar) { return NDArray_CreateFromFloatScalar((float)scalar); }
+NDArray *NDArray_CreateFromLongScalar(long scalar) { return NDArray_CreateFromFloatScalar((float)scalar); }
+
+NDArray *NDArray_FromHostBuffer(const float *host_data, const int *shape, int ndim) {
+    if (!host_data) return nullptr;
+    NDArray *r = new_array(shape, ndim, NDARRAY_DEVICE_CPU, false);
+    memcpy(r->data, host_data, (size_t)NDArray_NUMELEMENTS(r) * sizeof(float));
+    return r;
+}
+
+NDArray *NDArray_LeadingSlice(NDArray *a, int index) {   // iterators.c:94-111
+    if (!a || a->ndim < 1) {
+        throw_error("cannot take a slice of a 0-d array");
+        return nullptr;
+    }
+    if (index < 0 || index >= a->dimensions[0]) {
+        throw_error("Index out of bounds");
+        return nullptr;
+    }
+    NDArray *r = make_header(a->dimensions + 1, a->ndim - 1, a->device);
+    r->data = a->data + (size_t)index * (size_t)a->strides[0];
+    r->base = a;
+    a->refcount++;   // NDArray_ADDREF
+    return r;
+}
+
+void NDArray_FREE(NDArray *array) {   // ndarray.c:587-632
+    if (array == nullptr || array->refcount == -1) return;
+    if (array->refcount > 0) array->refcount--;
+    if (array->refcount == 0) {
+        if (array->data != nullptr && array->base == nullptr) {
+            if (array->device == NDARRAY_DEVICE_CPU)
+                free(array->data);
+            else
+                (void)np_free(array->data);   // vfree
+        }
+        if (array->base != nullptr) NDArray_FREE(array->base);
+        array->refcount = -1;
+        free_header(array);
+    }
+}
+
+NDArray *NDArray_ToGPU(NDArray *target) {   // ndarray.c:1037-1068
+    if (!target) return nullptr;
+    int count = 0;
+    if (np_device_count(&count) != NP_OK || count <= 0) {
+        throw_error("No GPU device available or CUDA not enabled");   // numpower.c:525
+        return nullptr;
+    }
+    if (target->device == NDARRAY_DEVICE_GPU) return NDArray_Copy(target, NDARRAY_DEVICE_GPU);
+    NDArray *r = new_array(target->dimensions, target->ndim, NDARRAY_DEVICE_GPU, false);
+    if (!r) return nullptr;
+    if (!dev_ok(np_memcpy_h2d(r->data, target->data, (size_t)NDArray_NUMELEMENTS(target) * sizeof(float)))) {
+        NDArray_FREE(r);
+        return nullptr;
+    }
+    return r;
+}
+
+NDArray *NDArray_ToCPU(NDArray *target) {   // ndarray.c:1075-1093
+    if (!target) return nullptr;
+    if (target->device == NDARRAY_DEVICE_CPU) return NDArray_Copy(target, NDARRAY_DEVICE_CPU);
+    NDArray *r = new_array(target->dimensions, target->ndim, NDARRAY_DEVICE_CPU, false);
+    if (!r) return nullptr;
+    if (!dev_ok(np_memcpy_d2h(r->data, target->data, (size_t)NDArray_NUMELEMENTS(target) * sizeof(float)))) {
+        NDArray_FREE(r);
+        return nullptr;
+    }
+    return r;
+}
+
+float NDArray_GetFloatScalar(NDArray *a) {   // ndarray.c:1302-1310
+    if (a->device == NDARRAY_DEVICE_CPU) return NDArray_FDATA(a)[0];
+    float v = 0.0f;
+    (void)dev_ok(np_read_float(NDArray_FDATA(a), 0, &v));   // NDArray_VFLOAT
+    return v;
+}
+
+int NDArray_CopyToHostBuffer(NDArray *a, float *host_out) {
+    if (!a || !host_out) return -1;
+    if (a->device != NDARRAY_DEVICE_CPU) {   // numpower.c:466
+        throw_error("NDArray must be on CPU RAM before it can be converted to a PHP array.");
+        return -1;
+    }
+    memcpy(host_out, a->data, (size_t)NDArray_NUMELEMENTS(a) * sizeof(float));
+    return 0;
+}
+
+long NDArray_LiveDeviceAllocations(void) { return np_live_allocs(); }
+
+/* ---- binary ---- */
+NDArray *NDArray_Add_Float(NDArray *a, NDArray *b) { return binary_op(NP_ADD, a, b); }
+NDArray *NDArray_Subtract_Float(NDArray *a, NDArray *b) { return binary_op(NP_SUBTRACT, a, b); }
+NDArray *NDArray_Multiply_Float(NDArray *a, NDArray *b) { return binary_op(NP_MULTIPLY, a, b); }
+NDArray *NDArray_Divide_Float(NDArray *a, NDArray *b) { return binary_op(NP_DIVIDE, a, b); }
+NDArray *NDArray_Mod_Float(NDArray *a, NDArray *b) { return binary_op(NP_MOD, a, b); }
+NDArray *NDArray_Pow_Float(NDArray *a, NDArray *b) { return binary_op(NP_POW, a, b); }
+
+int NDArray_IsBroadcastable(const NDArray *array1, const NDArray *array2) {   // ndarray.c:1124-1162
+    const int n1 = array1->ndim, n2 = array2->ndim;
+    if (n1 == 1 && n2 > 1) return array1->dimensions[0] == array2->dimensions[n2 - 1];
+    if (n1 > 1 && n2 == 1) return array2->dimensions[0] == array1->dimensions[n1 - 1];
+    const int maxd = n1 > n2 ? n1 : n2;
+    for (int i = 0; i < maxd; ++i) {
+        const int s1 = i < n1 ? array1->dimensions[i] : 1;
+        const int s2 = i < n2 ? array2->dimensions[i] : 1;
+        if (s1 != s2 && s1 != 1 && s2 != 1) return 0;
+    }
+    return 1;
+}
+
+/* ---- unary ---- */
+NDArray *NDArrayMathGPU_ElementWise(NDArray *ndarray, int op) { return unary_op(ndarray, op, 0.0f, 0.0f); }
+NDArray *NDArrayMathGPU_ElementWise1F(NDArray *ndarray, int op, float val1) { return unary_op(ndarray, op, val1, 0.0f); }
+NDArray *NDArrayMathGPU_ElementWise2F(NDArray *ndarray, int op, float val1, float val2) {
+    return unary_op(ndarray, op, val1, val2);
+}
+NDArray *NDArrayMathGPU_ElementWise1N(NDArray *ndarray, int op, NDArray *val1) {
+    // cuda_float_arctan2(n, x, y): x[i] = atan2f(x[i], y[i]) over numel(x) (cuda_math.cu:489,1224)
+    if (!ndarray || !val1) return nullptr;
+    if (!require_gpu(ndarray, "elementwise op") || !require_gpu(val1, "elementwise op")) return nullptr;
+    if (NDArray_NUMELEMENTS(val1) < NDArray_NUMELEMENTS(ndarray)) {
+        throw_error("Incompatible shapes");
+        return nullptr;
+    }
+    NDArray *out = new_array(ndarray->dimensions, ndarray->ndim, NDARRAY_DEVICE_GPU, false);
+    if (!out) return nullptr;
+    if (!dev_ok(np_binary(op, NDArray_FDATA(ndarray), NP_FULL, NDArray_FDATA(val1), NP_FULL, NDArray_FDATA(out), 1,
+                          (size_t)NDArray_NUMELEMENTS(ndarray), 0, 0))) {
+        NDArray_FREE(out);
+        return nullptr;
+    }
+    return out;
+}
+NDArray *NDArray_Abs(NDArray *nda) { return unary_op(nda, NP_ABS, 0.0f, 0.0f); }   // arithmetics.c:934-947
+
+/* ---- reductions ---- */
+float NDArray_Sum_Float(NDArray *a) { return reduce_all(a, NP_SUM, "sum"); }
+float NDArray_Float_Prod(NDArray *a) { return reduce_all(a, NP_PROD, "prod"); }
+float NDArray_Mean_Float(NDArray *a) { return reduce_all(a, NP_MEAN, "mean"); }
+float NDArray_Min(NDArray *target) { return reduce_all(target, NP_MIN, "min"); }
+float NDArray_Max(NDArray *target) { return reduce_all(target, NP_MAX, "max"); }
+
+NDArray *reduce(NDArray *array, int *axis, NDArray *(*operation)(NDArray *, NDArray *)) {
+    const int ax = axis ? *axis : 0;   // ndarray.c:528-532
+    if (operation == NDArray_Add_Float) return reduce_axis(array, ax, NP_SUM, false);
+    if (operation == NDArray_Multiply_Float) return reduce_axis(array, ax, NP_PROD, true);
+    throw_error("reduce: unsupported operation (only NDArray_Add_Float / NDArray_Multiply_Float)");
+    return nullptr;
+}
+NDArray *NDArray_MinAxis(NDArray *target, int axis) { return reduce_axis(target, axis, NP_MIN, false); }
+NDArray *NDArray_MaxAxis(NDArray *target, int axis) { return reduce_axis(target, axis, NP_MAX, false); }
+
+/* ---- matmul ---- */
+NDArray *NDArray_FMatmul(NDArray *a, NDArray *b) {   // linalg.c:44-82
+    if (!require_gpu(a, "matmul")) return nullptr;
+    int shape[2] = {a->dimensions[0], b->dimensions[1]};
+    NDArray *result = new_array(shape, 2, NDARRAY_DEVICE_GPU, false);
+    if (!result) return nullptr;
+    if (!dev_ok(np_sgemm((size_t)a->dimensions[0], (size_t)b->dimensions[1], (size_t)a->dimensions[1],
+                         NDArray_FDATA(a), NDArray_FDATA(b), NDArray_FDATA(result)))) {
+        NDArray_FREE(result);
+        return nullptr;
+    }
+    return result;
+}
+
+NDArray *NDArray_Matmul(NDArray *a, NDArray *b) {   // linalg.c:216-245
+    if (!a || !b) return nullptr;
+    if (NDArray_DEVICE(a) != NDArray_DEVICE(b)) {
+        throw_error("Device mismatch, both NDArray MUST be in the same device.");
+        return nullptr;
+    }
+    if (NDArray_NDIM(a) != NDArray_NDIM(b)) {
+        throw_error("Arrays must have the same shape. Broadcasting not implemented.");
+        return nullptr;
+    }
+    if (NDArray_NDIM(a) == 0 && NDArray_NDIM(b) == 0) return NDArray_Multiply_Float(a, b);
+    if (NDArray_NDIM(a) == 1 && NDArray_NDIM(b) == 1) return NDArray_Dot(a, b);
+    if (a->dimensions[a->ndim - 1] != b->dimensions[b->ndim - 2]) {
+        throw_error("Shape mismatch for matmul. cols(a) != rows(b)");
+        return nullptr;
+    }
+    if (NDArray_NDIM(a) > 2 && NDArray_NDIM(b) > 2) {
+        throw_error("Stack of matrices not allowed");
+        return nullptr;
+    }
+    return NDArray_FMatmul(a, b);
+}
+
+NDArray *NDArray_Dot(NDArray *nda, NDArray *ndb) {   // linalg.c:354-393
+    if (!nda || !ndb) return nullptr;
+    if (NDArray_DEVICE(nda) != NDArray_DEVICE(ndb)) {
+        throw_error("Device mismatch, both NDArray MUST be in the same device.");
+        return nullptr;
+    }
+    if (NDArray_NDIM(nda) == 1 && NDArray_NDIM(ndb) == 1) {
+        // NDArray_Inner (linalg.c:310-352): sum(a * b) = a 1 x n times n-vector product
+        if (!require_gpu(nda, "dot")) return nullptr;
+        if (nda->dimensions[0] != ndb->dimensions[0]) {
+            throw_error("Shape mismatch for dot");
+            return nullptr;
+        }
+        NDArray *rtn = new_array(nullptr, 0, NDARRAY_DEVICE_GPU, false);
+        if (!rtn) return nullptr;
+        if (!dev_ok(np_sgemv(1, (size_t)nda->dimensions[0], NDArray_FDATA(nda), NDArray_FDATA(ndb), NDArray_FDATA(rtn)))) {
+            NDArray_FREE(rtn);
+            return nullptr;
+        }
+        return rtn;
+    }
+    if (NDArray_NDIM(nda) == 2 && NDArray_NDIM(ndb) == 2) return NDArray_Matmul(nda, ndb);
+    if (NDArray_NDIM(nda) == 0 || NDArray_NDIM(ndb) == 0) return NDArray_Multiply_Float(nda, ndb);
+    if (NDArray_NDIM(nda) > 0 && NDArray_NDIM(ndb) == 1) {   // linalg.c:367-386
+        if (!require_gpu(nda, "dot")) return nullptr;
+        const int nd = nda->ndim;
+        const size_t cols = (size_t)nda->dimensions[nd - 1];
+        if ((size_t)ndb->dimensions[0] != cols) {
+            throw_error("Shape mismatch for dot");
+            return nullptr;
+        }
+        const size_t rows = (size_t)(NDArray_NUMELEMENTS(nda) / (long)cols);
+        NDArray *rtn = new_array(nda->dimensions, nd - 1, NDARRAY_DEVICE_GPU, false);
+        if (!rtn) return nullptr;
+        if (!dev_ok(np_sgemv(rows, cols, NDArray_FDATA(nda), NDArray_FDATA(ndb), NDArray_FDATA(rtn)))) {
+            NDArray_FREE(rtn);
+            return nullptr;
+        }
+        return rtn;
+    }
+    throw_error("Not implemented");   // linalg.c:387-390
+    return nullptr;
+}
+
+NDArray *NDArray_BatchedMatmul(NDArray *a, NDArray *b) {
+    if (!a || !b) return nullptr;
+    if (NDArray_DEVICE(a) != NDArray_DEVICE(b)) {
+        throw_error("Device mismatch, both NDArray MUST be in the same device.");
+        return nullptr;
+    }
+    if (NDArray_NDIM(a) != 3 || NDArray_NDIM(b) != 3 || a->dimensions[0] != b->dimensions[0]) {
+        throw_error("Arrays must have the same shape. Broadcasting not implemented.");
+        return nullptr;
+    }
+    if (a->dimensions[2] != b->dimensions[1]) {
+        throw_error("Shape mismatch for matmul. cols(a) != rows(b)");
+        return nullptr;
+    }
+    if (!require_gpu(a, "matmul")) return nullptr;
+    const size_t batch = (size_t)a->dimensions[0], M = (size_t)a->dimensions[1], K = (size_t)a->dimensions[2],
+                 N = (size_t)b->dimensions[2];
+    int shape[3] = {(int)batch, (int)M, (int)N};
+    NDArray *result = new_array(shape, 3, NDARRAY_DEVICE_GPU, false);
+    if (!result) return nullptr;
+    if (!dev_ok(np_sgemm_strided_batched(batch, M, N, K, NDArray_FDATA(a), M * K, NDArray_FDATA(b), K * N,
+                                         NDArray_FDATA(result), M * N))) {
+        NDArray_FREE(result);
+        return nullptr;
+    }
+    return result;
+}
+
+}  // extern "C"

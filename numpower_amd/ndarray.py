@@ -1,0 +1,373 @@
+"""Python stand-in for the PHP `NDArray` class surface on the hot path.
+
+PHP is not available where this was built, so the Zend glue (numpower.c) cannot be compiled;
+this module plays its role for tests and benchmarks: it marshals Python values the way
+ZVAL_TO_NDARRAY does (numpower.c:89-117), calls the SAME host entry points the PHP_METHODs call
+(libnumpower_host.so: NDArray_Add_Float, reduce, NDArray_Matmul, NDArray_ToGPU ...), frees
+temporaries like CHECK_INPUT_AND_FREE (numpower.c:119-135) and converts results like
+RETURN_NDARRAY (numpower.c:137-150: ndim > 0 -> NDArray object, ndim == 0 -> float).
+
+    a = NDArray.array([[1, 2], [3, 4]]).gpu()
+    c = (a + 2) * a[0]
+    NDArray.sum(c, axis=0).cpu().toArray()
+
+All arithmetic runs in the HIP library.  Operating on CPU-resident arrays raises `Error` (the
+reference's CPU path is not re-implemented here and nothing falls back to numpy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib
+from ._lib import BINARY_OPS, UNARY_OPS
+
+CPU, GPU = 0, 1
+
+
+class Error(RuntimeError):
+    """PHP `Error` thrown by zend_throw_error in the reference."""
+
+
+class _CNDArrayDescriptor(C.Structure):
+    _fields_ = [("type", C.c_char_p), ("elsize", C.c_int), ("numElements", C.c_long)]
+
+
+class _CNDArray(C.Structure):
+    pass
+
+
+_CNDArray._fields_ = [
+    ("uuid", C.c_int), ("strides", C.POINTER(C.c_int)), ("dimensions", C.POINTER(C.c_int)),
+    ("ndim", C.c_int), ("data", C.c_void_p), ("base", C.POINTER(_CNDArray)), ("flags", C.c_int),
+    ("descriptor", C.POINTER(_CNDArrayDescriptor)), ("iterator", C.c_void_p),
+    ("php_iterator", C.c_void_p), ("refcount", C.c_int), ("device", C.c_int)]
+
+_P = C.POINTER(_CNDArray)
+_host = None
+
+
+def host_lib_path() -> Path:
+    return _lib.LIBDIR / "libnumpower_host.so"
+
+
+def _load_host():
+    global _host
+    if _host is not None:
+        return _host
+    _lib.load()   # libnp_hip.so first (RTLD_GLOBAL)
+    path = host_lib_path()
+    if not path.exists():
+        raise Error(f"{path} is missing: run `python -m numpower_amd.build` (no CPU fallback)")
+    h = C.CDLL(str(path))
+    ip = C.POINTER(C.c_int)
+    fp = C.POINTER(C.c_float)
+    sig = {
+        "numpower_host_last_error": (C.c_char_p, []),
+        "numpower_host_clear_error": (None, []),
+        "NDArray_Zeros": (_P, [ip, C.c_int, C.c_char_p, C.c_int]),
+        "NDArray_Empty": (_P, [ip, C.c_int, C.c_char_p, C.c_int]),
+        "NDArray_Copy": (_P, [_P, C.c_int]),
+        "NDArray_Fill": (_P, [_P, C.c_float]),
+        "NDArray_CreateFromDoubleScalar": (_P, [C.c_double]),
+        "NDArray_CreateFromLongScalar": (_P, [C.c_long]),
+        "NDArray_FromHostBuffer": (_P, [fp, ip, C.c_int]),
+        "NDArray_LeadingSlice": (_P, [_P, C.c_int]),
+        "NDArray_FREE": (None, [_P]),
+        "NDArray_ToGPU": (_P, [_P]),
+        "NDArray_ToCPU": (_P, [_P]),
+        "NDArray_GetFloatScalar": (C.c_float, [_P]),
+        "NDArray_CopyToHostBuffer": (C.c_int, [_P, fp]),
+        "NDArray_LiveDeviceAllocations": (C.c_long, []),
+        "NDArray_IsBroadcastable": (C.c_int, [_P, _P]),
+        "NDArrayMathGPU_ElementWise": (_P, [_P, C.c_int]),
+        "NDArrayMathGPU_ElementWise1F": (_P, [_P, C.c_int, C.c_float]),
+        "NDArrayMathGPU_ElementWise2F": (_P, [_P, C.c_int, C.c_float, C.c_float]),
+        "NDArrayMathGPU_ElementWise1N": (_P, [_P, C.c_int, _P]),
+        "NDArray_Abs": (_P, [_P]),
+        "NDArray_Sum_Float": (C.c_float, [_P]),
+        "NDArray_Float_Prod": (C.c_float, [_P]),
+        "NDArray_Mean_Float": (C.c_float, [_P]),
+        "NDArray_Min": (C.c_float, [_P]),
+        "NDArray_Max": (C.c_float, [_P]),
+        "NDArray_MinAxis": (_P, [_P, C.c_int]),
+        "NDArray_MaxAxis": (_P, [_P, C.c_int]),
+        "NDArray_Matmul": (_P, [_P, _P]),
+        "NDArray_Dot": (_P, [_P, _P]),
+        "NDArray_BatchedMatmul": (_P, [_P, _P]),
+    }
+    for name in ("Add", "Subtract", "Multiply", "Divide", "Mod", "Pow"):
+        sig[f"NDArray_{name}_Float"] = (_P, [_P, _P])
+    for name, (res, args) in sig.items():
+        fn = getattr(h, name)
+        fn.restype = res
+        fn.argtypes = args
+    # reduce(array, int *axis, operation): the operation is passed as the address of the
+    # library's own NDArray_Add_Float / NDArray_Multiply_Float, exactly as numpower.c does.
+    h.reduce.restype = _P
+    h.reduce.argtypes = [_P, C.POINTER(C.c_int), C.c_void_p]
+    _host = h
+    return h
+
+
+def _raise_pending(h, what="call"):
+    msg = h.numpower_host_last_error()
+    text = msg.decode() if msg else ""
+    h.numpower_host_clear_error()
+    raise Error(text or f"{what} failed")
+
+
+_BINARY_FN = {"add": "NDArray_Add_Float", "subtract": "NDArray_Subtract_Float",
+              "multiply": "NDArray_Multiply_Float", "divide": "NDArray_Divide_Float",
+              "mod": "NDArray_Mod_Float", "pow": "NDArray_Pow_Float"}
+
+# PHP method name -> np_unary_op for the plain NDArrayMathGPU_ElementWise family
+# (method table numpower.c:5136-5174)
+_UNARY_METHODS = [n for n in UNARY_OPS if n not in ("clip", "round")]
+
+
+class NDArray:
+    """Handle on a C `NDArray*` owned by libnumpower_host.so (PHP objects hold a uuid into
+    MAIN_MEM_STACK instead, buffer.c:91-120; the ownership rules are the same: the object's
+    destructor calls NDArray_FREE, views keep their base alive through the refcount)."""
+
+    __slots__ = ("_p", "_h")
+
+    def __init__(self, ptr):
+        self._h = _load_host()
+        if not ptr:
+            _raise_pending(self._h)
+        self._p = ptr
+
+    def __del__(self):
+        try:
+            if self._p:
+                self._h.NDArray_FREE(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+    # ---- marshalling (ZVAL_TO_NDARRAY, numpower.c:89-117) ---------------------------------
+    @staticmethod
+    def _coerce(value):
+        """-> (NDArray, is_temporary)"""
+        if isinstance(value, NDArray):
+            return value, False
+        h = _load_host()
+        if isinstance(value, bool):
+            raise Error("argument must be an array, long, double, gdimage or ndarray.")
+        if isinstance(value, int):
+            return NDArray(h.NDArray_CreateFromLongScalar(value)), True
+        if isinstance(value, float):
+            return NDArray(h.NDArray_CreateFromDoubleScalar(value)), True
+        if isinstance(value, (list, tuple, np.ndarray)):
+            return NDArray.array(value), True
+        raise Error("argument must be an array, long, double, gdimage or ndarray.")
+
+    @staticmethod
+    def _wrap(ptr):
+        """RETURN_NDARRAY (numpower.c:137-150)."""
+        h = _load_host()
+        if not ptr:
+            _raise_pending(h)
+        if ptr.contents.ndim > 0:
+            return NDArray(ptr)
+        v = h.NDArray_GetFloatScalar(ptr)
+        h.NDArray_FREE(ptr)
+        return float(v)
+
+    # ---- construction -----------------------------------------------------------------------
+    @staticmethod
+    def array(values) -> "NDArray":
+        """NDArray::array — CPU array from a nested list (fp32)."""
+        a = np.asarray(values, dtype=np.float32, order="C")
+        h = _load_host()
+        shape = (C.c_int * max(a.ndim, 1))(*a.shape)
+        return NDArray(h.NDArray_FromHostBuffer(a.ctypes.data_as(C.POINTER(C.c_float)), shape, a.ndim))
+
+    @staticmethod
+    def zeros(shape, device=CPU) -> "NDArray":
+        h = _load_host()
+        s = (C.c_int * max(len(shape), 1))(*shape)
+        return NDArray(h.NDArray_Zeros(s, len(shape), b"float32", device))
+
+    # ---- placement ---------------------------------------------------------------------------
+    def gpu(self) -> "NDArray":
+        """$a->gpu(): always a new array (NDArray_ToGPU, ndarray.c:1037-1068)."""
+        return NDArray(self._h.NDArray_ToGPU(self._p))
+
+    def cpu(self) -> "NDArray":
+        return NDArray(self._h.NDArray_ToCPU(self._p))
+
+    def isGPU(self) -> bool:
+        return self._p.contents.device == GPU
+
+    # ---- introspection -------------------------------------------------------------------------
+    def shape(self):
+        c = self._p.contents
+        return [c.dimensions[i] for i in range(c.ndim)]
+
+    def size(self) -> int:
+        return int(self._p.contents.descriptor.contents.numElements)
+
+    def ndim(self) -> int:
+        return int(self._p.contents.ndim)
+
+    def toArray(self):
+        """toArray(): nested list of floats; throws for GPU arrays (numpower.c:456-477)."""
+        return self.numpy().astype(np.float64).tolist()
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape(), dtype=np.float32)
+        if self._h.NDArray_CopyToHostBuffer(self._p, out.ctypes.data_as(C.POINTER(C.c_float))) != 0:
+            _raise_pending(self._h)
+        return out
+
+    def fill(self, value: float) -> "NDArray":
+        if not self._h.NDArray_Fill(self._p, value):
+            _raise_pending(self._h)
+        return self
+
+    def __getitem__(self, index: int) -> "NDArray":
+        """$a[i]: view of slice i of the leading axis."""
+        return NDArray._wrap(self._h.NDArray_LeadingSlice(self._p, int(index)))
+
+    def __len__(self):
+        return self.shape()[0]
+
+    # ---- binary ops ------------------------------------------------------------------------------
+    @staticmethod
+    def _binary(name, a, b):
+        h = _load_host()
+        x, _tx = NDArray._coerce(a)
+        y, _ty = NDArray._coerce(b)
+        return NDArray._wrap(getattr(h, _BINARY_FN[name])(x._p, y._p))
+
+    add = staticmethod(lambda a, b: NDArray._binary("add", a, b))
+    subtract = staticmethod(lambda a, b: NDArray._binary("subtract", a, b))
+    multiply = staticmethod(lambda a, b: NDArray._binary("multiply", a, b))
+    divide = staticmethod(lambda a, b: NDArray._binary("divide", a, b))
+    mod = staticmethod(lambda a, b: NDArray._binary("mod", a, b))
+    pow = staticmethod(lambda a, b: NDArray._binary("pow", a, b))
+
+    def __add__(self, o): return NDArray._binary("add", self, o)
+    def __radd__(self, o): return NDArray._binary("add", o, self)
+    def __sub__(self, o): return NDArray._binary("subtract", self, o)
+    def __rsub__(self, o): return NDArray._binary("subtract", o, self)
+    def __mul__(self, o): return NDArray._binary("multiply", self, o)
+    def __rmul__(self, o): return NDArray._binary("multiply", o, self)
+    def __truediv__(self, o): return NDArray._binary("divide", self, o)
+    def __rtruediv__(self, o): return NDArray._binary("divide", o, self)
+    def __mod__(self, o): return NDArray._binary("mod", self, o)
+    def __pow__(self, o): return NDArray._binary("pow", self, o)
+
+    @staticmethod
+    def square(a):   # PHP_METHOD(NDArray, square): Multiply_Float(nda, nda), numpower.c:3093
+        x, _ = NDArray._coerce(a)
+        return NDArray._binary("multiply", x, x)
+
+    @staticmethod
+    def arctan2(x, y):
+        h = _load_host()
+        a, _ = NDArray._coerce(x)
+        b, _ = NDArray._coerce(y)
+        return NDArray._wrap(h.NDArrayMathGPU_ElementWise1N(a._p, BINARY_OPS["arctan2"], b._p))
+
+    # ---- unary ops ---------------------------------------------------------------------------------
+    @staticmethod
+    def _unary(name, a):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(h.NDArrayMathGPU_ElementWise(x._p, UNARY_OPS[name]))
+
+    @staticmethod
+    def clip(a, min, max):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(h.NDArrayMathGPU_ElementWise2F(x._p, UNARY_OPS["clip"], float(min), float(max)))
+
+    @staticmethod
+    def round(a, precision=0):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(h.NDArrayMathGPU_ElementWise1F(x._p, UNARY_OPS["round"], float(precision)))
+
+    # ---- reductions -----------------------------------------------------------------------------------
+    @staticmethod
+    def _reduce(op, a, axis):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        if axis is None:
+            fn = {"sum": h.NDArray_Sum_Float, "prod": h.NDArray_Float_Prod, "min": h.NDArray_Min,
+                  "max": h.NDArray_Max}[op]
+            h.numpower_host_clear_error()
+            v = fn(x._p)
+            if h.numpower_host_last_error():
+                _raise_pending(h)
+            return float(v)
+        ax = C.c_int(int(axis))
+        if op == "sum":    # numpower.c:4637
+            return NDArray._wrap(h.reduce(x._p, C.byref(ax), C.cast(h.NDArray_Add_Float, C.c_void_p)))
+        if op == "prod":   # numpower.c:4742
+            return NDArray._wrap(h.reduce(x._p, C.byref(ax), C.cast(h.NDArray_Multiply_Float, C.c_void_p)))
+        if op == "min":
+            return NDArray._wrap(h.NDArray_MinAxis(x._p, int(axis)))
+        return NDArray._wrap(h.NDArray_MaxAxis(x._p, int(axis)))
+
+    sum = staticmethod(lambda a, axis=None: NDArray._reduce("sum", a, axis))
+    prod = staticmethod(lambda a, axis=None: NDArray._reduce("prod", a, axis))
+    min = staticmethod(lambda a, axis=None: NDArray._reduce("min", a, axis))
+    max = staticmethod(lambda a, axis=None: NDArray._reduce("max", a, axis))
+
+    @staticmethod
+    def mean(a, axis=None):
+        """PHP_METHOD(NDArray, mean) (numpower.c:2642-2688)."""
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        if axis is None:
+            # NDArray_Sum_Float(nda) / NDArray_NUMELEMENTS(nda): float / long in C
+            s = NDArray._reduce("sum", x, None)
+            return float(np.float32(s) / np.float32(x.size()))
+        total = NDArray._reduce("sum", x, axis)
+        count = NDArray(h.NDArray_CreateFromLongScalar(x.shape()[int(axis)]))
+        if isinstance(total, float):   # 1-D input: 0-d sum
+            return float(np.float32(total) / np.float32(x.shape()[int(axis)]))
+        return NDArray._binary("divide", total, count)
+
+    # ---- linear algebra -----------------------------------------------------------------------------------
+    @staticmethod
+    def matmul(a, b):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        y, _ = NDArray._coerce(b)
+        return NDArray._wrap(h.NDArray_Matmul(x._p, y._p))
+
+    @staticmethod
+    def dot(a, b):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        y, _ = NDArray._coerce(b)
+        return NDArray._wrap(h.NDArray_Dot(x._p, y._p))
+
+    @staticmethod
+    def batched_matmul(a, b):
+        h = _load_host()
+        return NDArray._wrap(h.NDArray_BatchedMatmul(a._p, b._p))
+
+    @staticmethod
+    def live_device_allocations() -> int:
+        return int(_load_host().NDArray_LiveDeviceAllocations())
+
+
+def _install_unary_methods():
+    for name in _UNARY_METHODS:
+        if hasattr(NDArray, name):
+            continue
+        setattr(NDArray, name, staticmethod(lambda a, _n=name: NDArray._unary(_n, a)))
+
+
+_install_unary_methods()
+# `abs` goes through NDArray_Abs in the reference (arithmetics.c:934-947); same kernel
+nd = NDArray

@@ -112,6 +112,44 @@ def replay(backend, test) -> str:
     return text
 
 
+class GpuBackend:
+    """Back end = the product path: numpower_amd.ndarray.NDArray (host library -> C ABI -> HIP
+    kernels).  Every array operand is moved to the GPU first, exactly what a PHP script does with
+    ->gpu(); results come back with ->cpu()->toArray()."""
+
+    def __init__(self):
+        from numpower_amd.ndarray import NDArray
+        self.nd = NDArray
+
+    def array(self, nested):
+        return self.nd.array(nested).gpu()
+
+    def scalar(self, v):
+        return v   # int/float operands stay host scalars (ZVAL_TO_NDARRAY, numpower.c:93-98)
+
+    def row(self, h, i):
+        return h[i]
+
+    def binary(self, name, x, y):
+        return self.nd._binary(name, x, y)
+
+    def unary(self, name, x, p0, p1):
+        if name == "clip":
+            return self.nd.clip(x, p0, p1)
+        if name == "round":
+            return self.nd.round(x, p0)
+        return self.nd._unary(name, x)
+
+    def reduce(self, name, x, axis):
+        return self.nd._reduce(name, x, axis)
+
+    def matmul(self, x, y):
+        return self.nd.matmul(x, y)
+
+    def to_list(self, h):
+        return h.cpu().toArray()
+
+
 class OracleBackend:
     """Back end = the CPU restatement in oracle/ (numpy arrays stand for CPU NDArrays)."""
 

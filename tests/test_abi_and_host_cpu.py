@@ -1,0 +1,104 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/np_hip.h declares, the ctypes prototypes cover all of them, and the host layer's
+argument checking / marshalling works without a GPU (no compute calls here)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared(header: Path, pattern: str):
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+    return sorted(set(re.findall(pattern, text)))
+
+
+def test_np_hip_exports_every_declared_symbol():
+    from numpower_amd import _lib
+    lib = _lib.load()
+    names = _declared(ROOT / "include" / "np_hip.h", r"\b(np_\w+)\s*\(")
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), "libnp_hip.so does not export %s" % n
+        assert n in _lib.PROTOTYPES, "numpower_amd/_lib.py has no prototype for %s" % n
+    assert set(_lib.PROTOTYPES) <= set(names)
+
+
+def test_host_library_exports_every_declared_symbol():
+    from numpower_amd import ndarray
+    h = ndarray._load_host()
+    names = _declared(ROOT / "include" / "numpower_host.h",
+                      r"\b(NDArray\w+|reduce|numpower_host_\w+)\s*\(")
+    names = [n for n in names if not n.startswith("NDArray_FDATA") and n not in (
+        "NDArray_NDIM", "NDArray_SHAPE", "NDArray_NUMELEMENTS", "NDArray_DEVICE")]
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(h, n), "libnumpower_host.so does not export %s" % n
+
+
+def test_enum_values_match_header():
+    """The Python-side op tables are positional; pin them against the header's enums."""
+    from numpower_amd import _lib
+    text = (ROOT / "include" / "np_hip.h").read_text()
+    m = re.search(r"typedef enum np_unary_op \{(.*?)\} np_unary_op;", text, re.S)
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+    names = [t.split("=")[0].strip() for t in body.split(",") if t.strip()]
+    names = [n for n in names if n != "NP_UNARY_OP_COUNT"]
+    assert [n[3:].lower() for n in names] == list(_lib.UNARY_OPS)
+    from oracle import oracle
+    assert list(oracle.UNARY) == list(_lib.UNARY_OPS)
+    assert oracle.BINARY == _lib.BINARY_OPS and oracle.REDUCE == _lib.REDUCE_OPS
+
+
+def test_avx_body_end_helper():
+    from numpower_amd import _lib
+    lib = _lib.load()
+    for n in range(0, 70):
+        i = 0
+        while i < n - 7:   # the reference's loop header, arithmetics.c:251
+            i += 8
+        assert lib.np_avx_body_end(n) == i
+
+
+def test_no_device_is_a_loud_error():
+    """Without a GPU every device entry point fails with the reference's message; nothing falls
+    back to the host."""
+    from numpower_amd import _lib
+    lib = _lib.load()
+    n = C.c_int()
+    if lib.np_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    p = C.c_void_p()
+    assert lib.np_malloc(C.byref(p), 1024) != 0
+    assert b"No GPU device available" in lib.np_last_error()
+    from numpower_amd.ndarray import Error, NDArray
+    with pytest.raises(Error, match="No GPU device available or CUDA not enabled"):
+        NDArray.array([[1, 2], [3, 4]]).gpu()
+    with pytest.raises(Error, match="only computes on the GPU"):
+        NDArray.array([[1, 2], [3, 4]]) + 2
+
+
+def test_host_marshalling_on_cpu():
+    from numpower_amd.ndarray import NDArray
+    a = NDArray.array([[1, 2, 3], [4, 5, 6]])
+    assert a.shape() == [2, 3] and a.size() == 6 and a.ndim() == 2 and not a.isGPU()
+    assert a.toArray() == [[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]
+    assert a[1].toArray() == [4.0, 5.0, 6.0]
+    assert a[1][2] == 6.0          # 0-d view -> float (RETURN_NDARRAY)
+    row = a[0]
+    del a                           # the view holds its base (NDArray_ADDREF)
+    assert row.toArray() == [1.0, 2.0, 3.0]
+    z = NDArray.zeros([2, 2])
+    z.fill(7.0)
+    assert z.toArray() == [[7.0, 7.0], [7.0, 7.0]]
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under numpower_amd/ may reference it."""
+    banned = re.compile(r"import\s+oracle|from\s+oracle|libnp_oracle|np_oracle|oracle_\w+\s*\(|oracle/")
+    for path in (ROOT / "numpower_amd").rglob("*"):
+        if path.suffix in (".py", ".hip", ".cpp", ".h") and path.name != "build.py":
+            assert not banned.search(path.read_text()), "%s references the oracle" % path

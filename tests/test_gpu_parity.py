@@ -1,0 +1,414 @@
+"""GPU parity tests: the HIP path (through the C ABI / host library) against the oracle.
+
+Bar (BASELINE.json north_star): bit-exact where the arithmetic is exact (add, subtract, multiply,
+divide, mod incl. the reference's AVX-body quirks, rounding ops, sqrt, rsqrt bit hack, clip ...),
+<= 1e-5 relative for transcendentals / reductions / GEMM.  Reductions and GEMM are additionally
+checked against an fp64 accumulation, because the reference's sequential fp32 sums themselves
+drift from the exact result at large N.
+"""
+import numpy as np
+import pytest
+
+from numpower_amd import synth
+from tests.phpt_replay import GpuBackend, load_vectors, replay
+
+pytestmark = pytest.mark.gpu
+
+# ops whose result must equal the oracle bit for bit
+EXACT_UNARY = ["abs", "sqrt", "rint", "fix", "floor", "ceil", "trunc", "negate", "sign", "rsqrt",
+               "positive", "reciprocal", "degrees", "radians", "logb"]
+# libm-class functions: glibc (oracle) and the device libm (ocml) are both ~1 ulp accurate but
+# not bit-identical; tolerance = 1e-5 relative (north_star) with an absolute floor for results
+# that cross zero.
+TRANSCENDENTAL_UNARY = ["exp", "exp2", "expm1", "log", "log2", "log10", "log1p", "sin", "cos", "tan",
+                        "arcsin", "arccos", "arctan", "sinh", "cosh", "tanh", "arcsinh", "arccosh",
+                        "arctanh", "sinc"]
+REL_TOL = 1e-5
+
+DOMAIN = {  # input ranges inside each function's domain
+    "log": (1e-3, 1e3), "log2": (1e-3, 1e3), "log10": (1e-3, 1e3), "log1p": (-0.99, 1e3),
+    "logb": (1e-3, 1e3), "sqrt": (0.0, 1e3), "rsqrt": (1e-3, 1e3), "arcsin": (-1.0, 1.0),
+    "arccos": (-1.0, 1.0), "arccosh": (1.0, 1e3), "arctanh": (-0.999, 0.999), "exp": (-10, 10),
+    "exp2": (-10, 10), "expm1": (-10, 10), "sinh": (-10, 10), "cosh": (-10, 10),
+    "reciprocal": (0.1, 100.0),
+}
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_equal(got, ref, what):
+    got = np.asarray(got, dtype=np.float32)
+    ref = np.asarray(ref, dtype=np.float32)
+    assert got.shape == ref.shape, what
+    both_nan = np.isnan(got) & np.isnan(ref)
+    diff = (bits(got) != bits(ref)) & ~both_nan
+    assert not diff.any(), "%s: %d of %d elements differ, first at %s: got %r ref %r" % (
+        what, int(diff.sum()), diff.size, np.argwhere(diff)[0].tolist(),
+        got[tuple(np.argwhere(diff)[0])], ref[tuple(np.argwhere(diff)[0])])
+
+
+def assert_close(got, ref, what, rel=REL_TOL, abs_floor=1e-6):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, what
+    finite = np.isfinite(ref)
+    assert (np.isfinite(got) == finite).all(), what + ": non-finite pattern differs"
+    err = np.abs(got[finite] - ref[finite])
+    bound = rel * np.abs(ref[finite]) + abs_floor * rel
+    bad = err > bound
+    assert not bad.any(), "%s: max rel err %.3g" % (what, float((err / np.maximum(np.abs(ref[finite]), 1e-30)).max()))
+
+
+# ---------------------------------------------------------------------------------------------
+# 1. the reference's own KATs through the GPU path
+# ---------------------------------------------------------------------------------------------
+
+TESTS = load_vectors()
+_TEXT_EXACT = {"add", "subtract", "multiply", "divide", "mod", "abs", "clip", "sign", "sqrt", "square",
+               "ceil", "fix", "floor", "rint", "round", "trunc", "prod", "sum", "max", "min", "matmul",
+               "degrees", "radians", "logb"}
+
+
+def _numbers(text):
+    import re
+    toks = re.findall(r"=> (-?[\w.+-]+)$", text, flags=re.M)
+    return toks
+
+
+@pytest.mark.parametrize("test", TESTS, ids=[t["source"].split("/")[-1] for t in TESTS])
+def test_phpt_kat_on_gpu(test, hip):
+    got = replay(GpuBackend(), test).rstrip()
+    want = test["expect"].rstrip()
+    op = test["title"].split("::")[-1].strip().lower()
+    if got == want:
+        return
+    assert op not in _TEXT_EXACT, "exact op %s: GPU text differs from the reference's EXPECT" % op
+    # transcendental: same structure, numbers within 1e-5 relative
+    g, w = _numbers(got), _numbers(want)
+    assert len(g) == len(w) and len(g) > 0
+    for a, b in zip(g, w):
+        if a == b:
+            continue
+        fa, fb = float(a.replace("NAN", "nan")), float(b.replace("NAN", "nan"))
+        assert abs(fa - fb) <= REL_TOL * abs(fb) + 1e-12, (op, a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# 2. binary ops vs the oracle, all operand shapes, incl. the AVX-body quirks
+# ---------------------------------------------------------------------------------------------
+
+SHAPES = [(1000, 1000), (257, 1001), (3, 5), (64, 4096), (1, 7), (9, 1)]
+
+
+def _pair(shape, seed, lo=-4.0, hi=4.0):
+    a = synth.uniform(shape, seed, lo, hi)
+    b = synth.uniform(shape, seed + 1, lo, hi)
+    # plant exact zeros, negative zeros and negative operands so the multiply/mod quirks fire
+    flat_a, flat_b = a.reshape(-1), b.reshape(-1)
+    flat_a[::7] = 0.0
+    flat_a[3::11] = -0.0
+    flat_b[5::13] = np.float32(-2.5)
+    flat_b[flat_b == 0] = np.float32(1.0)
+    return a, b
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("op", ["add", "subtract", "multiply", "divide", "mod"])
+def test_binary_exact_same_shape(op, shape, hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    a, b = _pair(shape, 100 + len(shape) + shape[0])
+    got = NDArray._binary(op, NDArray.array(a).gpu(), NDArray.array(b).gpu()).cpu().numpy()
+    assert_bit_equal(got, oracle.binary(op, a, b), "%s %s" % (op, shape))
+
+
+@pytest.mark.parametrize("shape", [(1000, 1000), (257, 1001), (12, 4), (5, 3)])
+@pytest.mark.parametrize("op", ["add", "subtract", "multiply", "divide", "mod"])
+def test_binary_exact_broadcast(op, shape, hip, oracle):
+    """scalar / row vector / column / 1xC operands on either side (ndarray.c:1196-1291)."""
+    from numpower_amd.ndarray import NDArray
+    a, b = _pair(shape, 7)
+    r, c = shape
+    ga = NDArray.array(a).gpu()
+    row = b[0].copy()
+    col = b[:, :1].copy()
+    cases = {
+        "arr,scalar": (ga, 2.5, a, np.float32(2.5)),
+        "scalar,arr": (-1.5, ga, np.float32(-1.5), a),
+        "arr,row": (ga, NDArray.array(row).gpu(), a, row),
+        "row,arr": (NDArray.array(row).gpu(), ga, row, a),
+        "arr,col": (ga, NDArray.array(col).gpu(), a, col),
+        "col,arr": (NDArray.array(col).gpu(), ga, col, a),
+    }
+    for name, (x, y, ox, oy) in cases.items():
+        got = NDArray._binary(op, x, y).cpu().numpy()
+        assert_bit_equal(got, oracle.binary(op, ox, oy), "%s %s %s" % (op, shape, name))
+    if r == c:   # the reference's 1xC -> RxC branch only fills the result when C == R
+        one_by_c = b[:1].copy()
+        got = NDArray._binary(op, ga, NDArray.array(one_by_c).gpu()).cpu().numpy()
+        assert_bit_equal(got, oracle.binary(op, a, one_by_c), "%s %s arr,1xC" % (op, shape))
+
+
+def test_binary_view_operand(hip, oracle):
+    """$a + $a[1]: the row operand is a view into the same buffer (unaligned for odd widths)."""
+    from numpower_amd.ndarray import NDArray
+    for shape in [(6, 1001), (6, 1000)]:
+        a, _ = _pair(shape, 3)
+        ga = NDArray.array(a).gpu()
+        got = (ga * ga[1]).cpu().numpy()
+        assert_bit_equal(got, oracle.binary("multiply", a, a[1]), "view %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [(1000, 1000), (33, 65)])
+def test_pow_and_arctan2(shape, hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    base = synth.uniform(shape, 11, 0.1, 4.0)
+    ex = synth.uniform(shape, 12, -3.0, 3.0)
+    got = NDArray.pow(NDArray.array(base).gpu(), NDArray.array(ex).gpu()).cpu().numpy()
+    assert_close(got, oracle.binary("pow", base, ex), "pow")
+    y = synth.uniform(shape, 13, -3.0, 3.0)
+    got = NDArray.arctan2(NDArray.array(ex).gpu(), NDArray.array(y).gpu()).cpu().numpy()
+    assert_close(got, oracle.binary("arctan2", ex, y), "arctan2")
+
+
+def test_binary_errors(hip):
+    from numpower_amd.ndarray import Error, NDArray
+    a = NDArray.array(np.ones((4, 6), np.float32)).gpu()
+    b = NDArray.array(np.ones((5,), np.float32)).gpu()
+    with pytest.raises(Error, match="Can't broadcast arrays."):
+        a + b
+    with pytest.raises(Error, match="Device mismatch, both NDArray MUST be in the same device."):
+        a + NDArray.array(np.ones((4, 6), np.float32))
+
+
+# ---------------------------------------------------------------------------------------------
+# 3. unary ops vs the oracle
+# ---------------------------------------------------------------------------------------------
+
+def _unary_input(op, shape=(1000, 1003)):
+    lo, hi = DOMAIN.get(op, (-10.0, 10.0))
+    x = synth.uniform(shape, 40 + len(op), lo, hi)
+    flat = x.reshape(-1)
+    if op not in DOMAIN or op in ("sqrt",):
+        flat[::97] = 0.0
+    if op in ("rint", "round", "fix", "floor", "ceil", "trunc"):
+        flat[1::5] = np.float32(0.5) + np.arange(flat[1::5].size, dtype=np.float32) - 100
+    return x
+
+
+@pytest.mark.parametrize("op", EXACT_UNARY)
+def test_unary_exact(op, hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    x = _unary_input(op)
+    got = NDArray._unary(op, NDArray.array(x).gpu()).cpu().numpy()
+    assert_bit_equal(got, oracle.unary(op, x), op)
+
+
+@pytest.mark.parametrize("op", TRANSCENDENTAL_UNARY)
+def test_unary_transcendental(op, hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    x = _unary_input(op)
+    got = NDArray._unary(op, NDArray.array(x).gpu()).cpu().numpy()
+    assert_close(got, oracle.unary(op, x), op)
+
+
+def test_clip_and_round_exact(hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    x = _unary_input("round")
+    gx = NDArray.array(x).gpu()
+    assert_bit_equal(NDArray.clip(gx, -1.5, 2.25).cpu().numpy(), oracle.unary("clip", x, -1.5, 2.25), "clip")
+    for d in (0, 1, 2, 3, -1):
+        assert_bit_equal(NDArray.round(gx, d).cpu().numpy(), oracle.unary("round", x, d), "round %d" % d)
+
+
+def test_unary_special_values(hip, oracle):
+    """NaN / inf / -0 / out-of-domain inputs (sqrt(-x) -> NAN as tests/math/028 expects)."""
+    from numpower_amd.ndarray import NDArray
+    x = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-40, -1e-40, 3.4e38, 0.5, -0.5, 2.5, -2.5],
+                 dtype=np.float32)
+    gx = NDArray.array(x).gpu()
+    for op in ["abs", "sqrt", "negate", "sign", "positive", "floor", "ceil", "trunc", "fix", "rint", "reciprocal"]:
+        assert_bit_equal(NDArray._unary(op, gx).cpu().numpy(), oracle.unary(op, x), op + " specials")
+
+
+# ---------------------------------------------------------------------------------------------
+# 4. reductions
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(1000, 1000), (257, 1001), (7,), (3, 5, 64), (1, 1)])
+def test_full_reductions(shape, hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform(shape, 21, 0.0, 1.0)
+    gx = NDArray.array(x).gpu()
+    exact = x.astype(np.float64)
+    for op, ref64 in [("sum", exact.sum()), ("min", exact.min()), ("max", exact.max())]:
+        got = NDArray._reduce(op, gx, None)
+        ref = float(oracle.reduce_all(op, x))
+        if op in ("min", "max"):
+            assert got == ref
+        else:
+            # both within tolerance of the fp64 sum; the oracle's sequential order is the looser one
+            assert abs(got - ref64) <= REL_TOL * abs(ref64)
+            assert abs(got - ref) <= 2e-5 * abs(ref64) + abs(ref - ref64)
+    p = synth.uniform(shape, 22, 0.9, 1.1)
+    got = NDArray.prod(NDArray.array(p).gpu())
+    ref64 = float(np.prod(p.astype(np.float64)))
+    assert abs(got - ref64) <= 1e-4 * abs(ref64)
+    m = NDArray.mean(gx)
+    assert abs(m - exact.mean()) <= REL_TOL * abs(exact.mean())
+
+
+@pytest.mark.parametrize("shape,axis", [((1000, 1000), 0), ((1000, 1000), 1), ((257, 1001), 0), ((257, 1001), 1),
+                                        ((7, 300, 64), 0), ((7, 300, 64), 1), ((7, 300, 64), 2), ((5, 8), 0),
+                                        ((4096, 5000), 1), ((40, 33), 1), ((16, 8, 4, 12), 2)])
+def test_axis_sum_and_mean(shape, axis, hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform(shape, 31, 0.0, 1.0)
+    gx = NDArray.array(x).gpu()
+    ref64 = x.astype(np.float64).sum(axis)
+    got = NDArray.sum(gx, axis)
+    got = got.cpu().numpy() if not isinstance(got, float) else np.float32(got)
+    assert_close(got, ref64, "sum axis %d of %s vs fp64" % (axis, shape))
+    ref = oracle.reduce_axis("sum", x, axis)
+    # oracle (sequential fp32, like the reference) within its own drift of the same fp64 truth
+    assert np.abs(ref - ref64).max() <= 1e-4 * np.abs(ref64).max()
+    gm = NDArray.mean(gx, axis)
+    gm = gm.cpu().numpy() if not isinstance(gm, float) else np.float32(gm)
+    assert_close(gm, x.astype(np.float64).mean(axis), "mean axis %d" % axis)
+
+
+def test_axis_sum_small_is_bit_exact(hip, oracle):
+    """For KAT-sized inputs (<= 2 slices) the order of additions is forced, so the GPU result
+    equals the reference's sequential sum bit for bit."""
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform((2, 1000), 5, -100, 100)
+    assert_bit_equal(NDArray.sum(NDArray.array(x).gpu(), 0).cpu().numpy(), oracle.reduce_axis("sum", x, 0), "2-row sum")
+
+
+@pytest.mark.parametrize("shape,axis", [((6, 1000), 0), ((6, 1001), 0), ((300, 20), 1), ((4, 5, 16), 1)])
+def test_axis_prod_zero_sign_quirk(shape, axis, hip, oracle):
+    """reduce(Multiply_Float): zero results carry the sign the reference's AVX body / scalar tail
+    leave behind (arithmetics.c:403,410-412); checked bit-exact on inputs whose products are
+    exactly representable."""
+    from numpower_amd.ndarray import NDArray
+    rng = np.random.default_rng(3)
+    x = rng.choice(np.array([0.0, -0.0, 1.0, -1.0, 2.0, -2.0, 0.5], dtype=np.float32), size=shape)
+    got = NDArray.prod(NDArray.array(x).gpu(), axis).cpu().numpy()
+    assert_bit_equal(got, oracle.reduce_axis("prod", x, axis), "prod axis %d of %s" % (axis, shape))
+
+
+def test_axis_min_max(hip):
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform((300, 257), 8, -5, 5)
+    gx = NDArray.array(x).gpu()
+    for axis in (0, 1):
+        assert_bit_equal(NDArray.max(gx, axis).cpu().numpy(), x.max(axis), "max axis")
+        assert_bit_equal(NDArray.min(gx, axis).cpu().numpy(), x.min(axis), "min axis")
+
+
+def test_axis_errors(hip):
+    from numpower_amd.ndarray import Error, NDArray
+    gx = NDArray.array(np.ones((3, 4), np.float32)).gpu()
+    with pytest.raises(Error, match="axis 2 is out of bounds for array of dimension 2"):
+        NDArray.sum(gx, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# 5. matmul
+# ---------------------------------------------------------------------------------------------
+
+def _gemm_check(got, A, B, what):
+    ref64 = A.astype(np.float64) @ B.astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    err = np.abs(got.astype(np.float64) - ref64) / np.maximum(scale, 1e-30)
+    assert err.max() <= 1e-6, "%s: max normalised err %.3g" % (what, err.max())
+    return ref64
+
+
+@pytest.mark.parametrize("mnk", [(2, 2, 2), (2, 1, 2), (64, 64, 64), (128, 128, 128), (100, 90, 70),
+                                 (257, 129, 65), (1000, 1000, 1000), (1024, 512, 2048), (1, 1000, 1)])
+def test_matmul_vs_oracle_and_fp64(mnk, hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    m, n, k = mnk
+    A = synth.uniform((m, k), 3, -1, 1)
+    B = synth.uniform((k, n), 4, -1, 1)
+    got = NDArray.matmul(NDArray.array(A).gpu(), NDArray.array(B).gpu()).cpu().numpy()
+    ref64 = _gemm_check(got, A, B, "matmul %s" % (mnk,))
+    ref = oracle.matmul(A, B)   # OpenBLAS, the reference's CPU back end
+    # 1e-5 relative to the reference, measured against the magnitude of the row.column products
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    assert (np.abs(got - ref) / np.maximum(scale, 1e-30)).max() <= REL_TOL
+    assert (np.abs(ref - ref64) / np.maximum(scale, 1e-30)).max() <= REL_TOL
+
+
+def test_matmul_transpose_detecting(hip):
+    """A = I with an asymmetric B catches swapped operands / transposed C writes."""
+    from numpower_amd.ndarray import NDArray
+    n = 160
+    B = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 251) - 100
+    got = NDArray.matmul(NDArray.array(np.eye(n, dtype=np.float32)).gpu(), NDArray.array(B).gpu()).cpu().numpy()
+    assert_bit_equal(got, B, "I.B")
+    got = NDArray.matmul(NDArray.array(B).gpu(), NDArray.array(np.eye(n, dtype=np.float32)).gpu()).cpu().numpy()
+    assert_bit_equal(got, B, "B.I")
+
+
+def test_matmul_errors_and_dot(hip, oracle):
+    from numpower_amd.ndarray import Error, NDArray
+    a = NDArray.array(np.ones((3, 4), np.float32)).gpu()
+    with pytest.raises(Error, match=r"Shape mismatch for matmul. cols\(a\) != rows\(b\)"):
+        NDArray.matmul(a, NDArray.array(np.ones((3, 4), np.float32)).gpu())
+    with pytest.raises(Error, match="Stack of matrices not allowed"):
+        t = NDArray.array(np.ones((2, 3, 3), np.float32)).gpu()
+        NDArray.matmul(t, t)
+    with pytest.raises(Error, match="Arrays must have the same shape. Broadcasting not implemented."):
+        NDArray.matmul(a, NDArray.array(np.ones((4,), np.float32)).gpu())
+    A = synth.uniform((300, 1000), 1, -1, 1)
+    x = synth.uniform((1000,), 2, -1, 1)
+    got = NDArray.dot(NDArray.array(A).gpu(), NDArray.array(x).gpu()).cpu().numpy()
+    ref = oracle.matvec(A, x)
+    scale = np.abs(A).astype(np.float64) @ np.abs(x).astype(np.float64)
+    assert (np.abs(got - ref) / scale).max() <= REL_TOL
+
+
+def test_batched_matmul(hip):
+    from numpower_amd.ndarray import NDArray
+    A = synth.uniform((5, 130, 70), 12, -1, 1)
+    B = synth.uniform((5, 70, 200), 13, -1, 1)
+    got = NDArray.batched_matmul(NDArray.array(A).gpu(), NDArray.array(B).gpu()).cpu().numpy()
+    for i in range(5):
+        _gemm_check(got[i], A[i], B[i], "batch %d" % i)
+
+
+# ---------------------------------------------------------------------------------------------
+# 6. device-buffer layer
+# ---------------------------------------------------------------------------------------------
+
+def test_placement_roundtrip_and_leak_counter(hip):
+    from numpower_amd.ndarray import Error, NDArray
+    before = NDArray.live_device_allocations()
+    x = synth.uniform((123, 457), 9, -1, 1)
+    g = NDArray.array(x).gpu()
+    assert g.isGPU() and g.shape() == [123, 457]
+    assert_bit_equal(g.cpu().numpy(), x, "gpu()/cpu() round trip")
+    g2 = g.gpu()   # already on the GPU: a copy (ndarray.c:1043-1045)
+    assert_bit_equal(g2.cpu().numpy(), x, "gpu() of a GPU array copies")
+    with pytest.raises(Error, match="NDArray must be on CPU RAM before it can be converted to a PHP array."):
+        g.toArray()
+    row = g[5]
+    assert_bit_equal(row.cpu().numpy(), x[5], "row view")
+    del g, g2
+    assert_bit_equal(row.cpu().numpy(), x[5], "view keeps its base alive")
+    del row
+    assert NDArray.live_device_allocations() == before   # vmemcheck parity (gpu_alloc.c:36-40)
+
+
+def test_fill_and_zeros(hip):
+    from numpower_amd.ndarray import GPU, NDArray
+    z = NDArray.zeros([37, 19], GPU)
+    assert not z.cpu().numpy().any()
+    z.fill(2.5)
+    assert (z.cpu().numpy() == np.float32(2.5)).all()
+    z[3].fill(-1.0)   # unaligned view
+    h = z.cpu().numpy()
+    assert (h[3] == -1.0).all() and (h[2] == 2.5).all() and (h[4] == 2.5).all()
