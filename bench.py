@@ -1,0 +1,345 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X hot path (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-extras]
+
+A "step" is one pass of the hot path over one batch of synthetic input: one nd::matmul of two
+4096 x 4096 fp32 matrices (BASELINE config 2, the configuration the metric is quoted on).
+Inputs are resident in HBM before the timed region.  K steps are launched back to back between
+a barrier + device sync on both sides; `value` = all ranks' FLOPs / max-over-ranks wall time.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank multiplies its own
+independent matrices — the path shards over independent arrays with no data-path collective
+("weak" scaling); BASELINE config 5 (batched matmul sharded over the ranks + one RCCL
+all-gather) is measured separately and reported under "extras".
+
+The JSON line also carries
+  roofline      achieved vs peak for the dominant kernel (fp32 MFMA GEMM), from HIP events
+                recorded on the kernel's own stream around the timed launches
+  cpu_baseline  the oracle (CPU restatement of the reference: cblas_sgemm from the OpenBLAS found
+                on this host) timed on a bounded sample of the same workload
+  extras        the second half of the metric (elementwise add on 1e8 floats, GB/s) and the other
+                BASELINE configs (exp/log, broadcast, axis-0 sum), each with its HBM roofline
+                fraction and CPU baseline, plus a parity verdict against the oracle.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from numpower_amd import device as D          # noqa: E402
+from numpower_amd import synth                 # noqa: E402
+from numpower_amd._lib import Timer, load      # noqa: E402
+
+METRIC = "GFLOP/s nd::matmul 4096² fp32; GB/s elementwise add 10^8 fp32 @1 MI355X"
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBPS = 8000.0          # HBM3E spec; ~6.3 TB/s is what a float4 copy reaches
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class Dist:
+    """torch.distributed plumbing (only imported when N > 1)."""
+
+    def __init__(self, n):
+        self.n = n
+        self.rank = 0
+        self.torch = None
+        if n > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            self.rank = int(os.environ.get("RANK", "0"))
+            self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            D.init(self.local_rank)
+            # run our kernels on torch's current stream so that RCCL and torch see one order
+            from numpower_amd._lib import check
+            check(load().np_set_stream(torch.cuda.current_stream().cuda_stream))
+        else:
+            D.init(0)
+
+    def barrier_sync(self):
+        if self.n > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+        D.sync()
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.n == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.n > 1:
+            self.dist.destroy_process_group()
+
+
+def timed(dist: Dist, fn, steps: int, warmup: int):
+    """-> (wall seconds max over ranks, HIP-event ms on this rank's stream) for `steps` calls."""
+    for _ in range(warmup):
+        fn()
+    dist.barrier_sync()
+    ev = Timer()
+    t0 = time.perf_counter()
+    ev.start()
+    for _ in range(steps):
+        fn()
+    ev.stop()
+    dist.barrier_sync()
+    wall = time.perf_counter() - t0
+    return dist.max_over_ranks(wall), ev.elapsed_ms()
+
+
+def cpu_time(fn, budget_s=8.0, max_iters=5):
+    """Median time of a CPU callable over a bounded number of runs."""
+    fn()   # warm (page in, thread pool)
+    ts = []
+    t_start = time.perf_counter()
+    while len(ts) < max_iters and (time.perf_counter() - t_start < budget_s or not ts):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), len(ts)
+
+
+# ---------------------------------------------------------------------------------------------
+
+def bench_matmul(dist: Dist, steps, warmup, do_cpu):
+    n = 4096
+    seed = 3 + 100 * dist.rank
+    A = synth.uniform((n, n), seed, -1.0, 1.0)
+    B = synth.uniform((n, n), seed + 1, -1.0, 1.0)
+    dA, dB, dC = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B), D.DeviceArray((n, n))
+    wall, ev_ms = timed(dist, lambda: D.sgemm(dA, dB, out=dC), steps, warmup)
+    flop = 2.0 * n ** 3
+    # parity: sampled rows against an fp64 product (1e-5 relative to |A|.|B|)
+    rows = [0, 1, 1234, 4095]
+    got = dC.to_host()[rows].astype(np.float64)
+    ref = A[rows].astype(np.float64) @ B.astype(np.float64)
+    scale = np.abs(A[rows]).astype(np.float64) @ np.abs(B).astype(np.float64)
+    err = float((np.abs(got - ref) / scale).max())
+    out = {
+        "wall_s": wall, "event_ms": ev_ms, "flop_per_step": flop,
+        "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6),
+    }
+    if do_cpu:
+        from oracle import oracle
+        info = oracle.use_openblas()
+        Cc = np.empty((n, n), dtype=np.float32)
+        t, iters = cpu_time(lambda: Cc.__setitem__(slice(None), oracle.matmul(A, B)), budget_s=10.0, max_iters=3)
+        out["cpu"] = {"value": flop / t / 1e9, "unit": "GFLOP/s", "cores": info.get("threads", 1),
+                      "kind": "port",
+                      "sample": "%d x full 4096^2 sgemm via %s" % (iters, info.get("kind")),
+                      "blas": info}
+        cerr = float((np.abs(Cc[rows].astype(np.float64) - ref) / scale).max())
+        out["gpu_vs_cpu_max_norm_err"] = float((np.abs(got - Cc[rows]) / scale).max())
+        out["cpu_vs_fp64_max_norm_err"] = cerr
+    for d in (dA, dB, dC):
+        d.free()
+    return out
+
+
+def hbm_case(name, bytes_per_launch, launch, steps, warmup, dist):
+    wall, ev_ms = timed(dist, launch, steps, warmup)
+    per_launch_ms = ev_ms / steps
+    gbps = bytes_per_launch / per_launch_ms / 1e6
+    return {"name": name, "ms_per_launch": per_launch_ms, "GBps": gbps,
+            "algorithmic_bytes": bytes_per_launch,
+            "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": gbps / PEAK_HBM_GBPS, "traffic": None}}
+
+
+def bench_extras(dist: Dist, steps, warmup):
+    """The HBM-bound configs (C3a/b/c, C4) at BASELINE.json's sizes, N = 1 only."""
+    from oracle import oracle
+    ex = {}
+    N = 100_000_000
+    a = synth.uniform((N,), 5, 0.0, 1.0)
+    b = synth.uniform((N,), 6, 0.0, 1.0)
+    da, db, do = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b), D.DeviceArray((N,))
+    r = hbm_case("add 1e8 fp32 (C3a)", 12.0 * N, lambda: D.binary("add", da, "full", db, "full", 1, N, out=do),
+                 steps, warmup, dist)
+    got = do.to_host()
+    t, it = cpu_time(lambda: oracle.binary("add", a, b), budget_s=6.0, max_iters=3)
+    ref = oracle.binary("add", a, b)
+    r["parity_ok"] = bool((got.view(np.uint32) == ref.view(np.uint32)).all())
+    r["cpu_baseline"] = {"value": 12.0 * N / t / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+                         "sample": "%d x full 1e8-element NDArray_Add_Float restatement (AVX2, 1 thread)" % it}
+    ex["add_1e8"] = r
+    del ref, got
+
+    for op, seed, lo, hi in (("exp", 7, -10.0, 10.0), ("log", 8, 1e-3, 1e3)):
+        x = synth.uniform((N,), seed, lo, hi)
+        check_n = 4_000_000
+        dx = D.DeviceArray.from_host(x)
+        r = hbm_case("%s 1e8 fp32 (C3b)" % op, 8.0 * N, lambda: D.unary(op, dx, out=do), steps, warmup, dist)
+        got = do.to_host()[:check_n].astype(np.float64)
+        t, it = cpu_time(lambda: oracle.unary(op, x[:20_000_000]), budget_s=5.0, max_iters=2)
+        ref = oracle.unary(op, x[:check_n]).astype(np.float64)
+        rel = float((np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)).max())
+        r["parity_max_rel_err"] = rel
+        r["parity_ok"] = bool(rel <= 1e-5)
+        r["cpu_baseline"] = {"value": 8.0 * 20_000_000 / t / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+                             "sample": "%d x 2e7-element NDArray_Map(float_%s) restatement (libm, 1 thread)" % (it, op)}
+        ex["%s_1e8" % op] = r
+        dx.free()
+        del x
+
+    # C3c: broadcast forms on 25000 x 4000, no materialised temporary: 8 B/elem + the vector
+    R, Cc = 25000, 4000
+    row = synth.uniform((Cc,), 9, 0.0, 1.0)
+    col = synth.uniform((R,), 10, 0.0, 1.0)
+    drow, dcol = D.DeviceArray.from_host(row), D.DeviceArray.from_host(col)
+    r = hbm_case("X + row, 25000x4000 (C3c)", 8.0 * N + 4.0 * Cc,
+                 lambda: D.binary("add", da, "full", drow, "row", R, Cc, out=do), steps, warmup, dist)
+    got = do.to_host().reshape(R, Cc)
+    r["parity_ok"] = bool((got == (a.reshape(R, Cc) + row[None, :])).all())
+    ex["add_row_broadcast"] = r
+    r = hbm_case("X + col, 25000x4000 (C3c)", 8.0 * N + 4.0 * R,
+                 lambda: D.binary("add", da, "full", dcol, "col", R, Cc, out=do), steps, warmup, dist)
+    got = do.to_host().reshape(R, Cc)
+    r["parity_ok"] = bool((got == (a.reshape(R, Cc) + col[:, None])).all())
+    ex["add_col_broadcast"] = r
+    for d in (da, db, do, drow, dcol):
+        d.free()
+    del a, b, got
+
+    # C4: sum(axis 0) of 65536 x 4096
+    rows, cols = 65536, 4096
+    X = synth.uniform((rows, cols), 11, 0.0, 1.0)
+    dX, dout = D.DeviceArray.from_host(X), D.DeviceArray((cols,))
+    r = hbm_case("sum(axis 0) 65536x4096 (C4)", 4.0 * rows * cols + 4.0 * cols,
+                 lambda: D.reduce_axis("sum", dX, 0, out=dout), steps, warmup, dist)
+    got = dout.to_host().astype(np.float64)
+    ref64 = X.sum(axis=0, dtype=np.float64)
+    rel = float((np.abs(got - ref64) / ref64).max())
+    r["parity_max_rel_err_vs_fp64"] = rel
+    r["parity_ok"] = bool(rel <= 1e-5)
+    sub = X[:8192]
+    t, it = cpu_time(lambda: oracle.reduce_axis("sum", sub, 0), budget_s=5.0, max_iters=3)
+    ref_seq = oracle.reduce_axis("sum", sub, 0).astype(np.float64)
+    r["reference_order_rel_err_vs_fp64_8192rows"] = float(
+        (np.abs(ref_seq - sub.sum(axis=0, dtype=np.float64)) / sub.sum(axis=0, dtype=np.float64)).max())
+    r["cpu_baseline"] = {"value": 4.0 * sub.size / t / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+                         "sample": "%d x reduce(axis 0) restatement on the first 8192 rows" % it}
+    ex["sum_axis0"] = r
+    dX.free()
+    dout.free()
+    return ex
+
+
+def bench_config5(dist: Dist, steps, warmup):
+    """BASELINE config 5: 512 x (1024 x 1024) batched matmul, batch sharded over the ranks in
+    contiguous slabs, one RCCL all-gather of the result slabs (strong scaling; compute-only and
+    gathered throughput)."""
+    torch = dist.torch
+    total, n = 512, 1024
+    per = total // dist.n
+    lo = dist.rank * per
+    dev = torch.device("cuda", dist.local_rank)
+    # inputs of this rank's slab, generated per matrix so every rank holds exactly its own
+    A = torch.empty((per, n, n), dtype=torch.float32, device=dev)
+    B = torch.empty((per, n, n), dtype=torch.float32, device=dev)
+    for i in range(per):
+        A[i].copy_(torch.from_numpy(synth.uniform((n, n), 12_000 + lo + i, -1.0, 1.0)))
+        B[i].copy_(torch.from_numpy(synth.uniform((n, n), 13_000 + lo + i, -1.0, 1.0)))
+    Cfull = torch.empty((total, n, n), dtype=torch.float32, device=dev)
+    mine = Cfull[lo:lo + per]
+    lib = load()
+    from numpower_amd._lib import check
+
+    def compute():
+        check(lib.np_sgemm_strided_batched(per, n, n, n, A.data_ptr(), n * n, B.data_ptr(), n * n,
+                                           mine.data_ptr(), n * n))
+
+    def compute_and_gather():
+        compute()
+        dist.dist.all_gather_into_tensor(Cfull.view(-1), mine.reshape(-1))
+
+    flop = 2.0 * total * n ** 3
+    wall_c, _ = timed(dist, compute, steps, warmup)
+    wall_g, _ = timed(dist, compute_and_gather, steps, warmup)
+    # parity: one matrix of a peer's slab, after the gather, against fp64
+    peer = (dist.rank + 1) % dist.n
+    j = peer * per
+    Ah = synth.uniform((n, n), 12_000 + j, -1.0, 1.0).astype(np.float64)
+    Bh = synth.uniform((n, n), 13_000 + j, -1.0, 1.0).astype(np.float64)
+    err = float((np.abs(Cfull[j].cpu().numpy().astype(np.float64) - Ah @ Bh) / (np.abs(Ah) @ np.abs(Bh))).max())
+    return {"workload": "512 x (1024x1024) fp32 batched matmul, %d slab(s) of %d" % (dist.n, per),
+            "scaling": "strong", "compute_only_GFLOPs": flop * steps / wall_c / 1e9,
+            "gathered_GFLOPs": flop * steps / wall_g / 1e9, "allgather_bytes_per_rank": per * n * n * 4,
+            "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-extras", action="store_true", help="headline only")
+    args = ap.parse_args()
+
+    dist = Dist(args.gpus)
+    rank0 = dist.rank == 0
+    mm = bench_matmul(dist, args.steps, args.warmup, do_cpu=rank0 and args.gpus == 1)
+    flop = mm["flop_per_step"]
+    value = flop * args.steps * args.gpus / mm["wall_s"] / 1e9            # GFLOP/s, whole job
+    kernel_tflops = flop / (mm["event_ms"] / args.steps) / 1e9             # this rank's kernel
+    result = {
+        "metric": METRIC, "value": value, "unit": "GFLOP/s", "n_gpus": args.gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": mm["wall_s"] / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "nd::matmul 4096x4096 . 4096x4096 fp32 (BASELINE config 2), "
+                               "one independent product per step per GPU",
+                   "parallelism": "replicas x%d (independent arrays, no collective)" % args.gpus},
+        "roofline": {"bound": "mfma", "achieved": kernel_tflops, "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": kernel_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "kernel": "sgemm_kernel<128,128,16> (v_mfma_f32_32x32x2_f32)",
+                     "algorithmic_flop_per_launch": flop},
+        "parity": {"matmul_max_norm_err_vs_fp64": mm["parity_max_norm_err_vs_fp64"], "ok": mm["parity_ok"]},
+    }
+    if "cpu" in mm:
+        result["cpu_baseline"] = mm["cpu"]
+        result["parity"]["gpu_vs_cpu_reference_max_norm_err"] = mm["gpu_vs_cpu_max_norm_err"]
+    extras = {}
+    if not args.no_extras:
+        if args.gpus == 1:
+            try:
+                extras = bench_extras(dist, max(10, args.steps // 2), args.warmup)
+                add = extras["add_1e8"]
+                result["secondary"] = {"metric": "GB/s elementwise add 10^8 fp32", "value": add["GBps"],
+                                       "unit": "GB/s", "roofline": add["roofline"],
+                                       "cpu_baseline": add["cpu_baseline"], "parity_ok": add["parity_ok"]}
+            except Exception as e:   # extras must never take the headline down
+                extras = {"error": repr(e)}
+        else:
+            try:
+                extras = {"config5_batched_matmul_allgather": bench_config5(dist, max(3, args.steps // 10), 2)}
+            except Exception as e:
+                extras = {"error": repr(e)}
+    if extras:
+        result["extras"] = extras
+    if rank0:
+        print(json.dumps(result), flush=True)
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()

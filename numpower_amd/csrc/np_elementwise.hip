@@ -12,6 +12,13 @@
 
 #include "np_internal.h"
 
+// Bit-level parity with the reference's CPU results needs every multiply, add and divide rounded
+// on its own: no implicit FMA contraction anywhere in this file (the two places where the
+// reference's build DOES fuse — mod's AVX body and the rsqrt Newton step — say so with an
+// explicit __fmaf_rn).  `/` and sqrtf are IEEE-correct under hipcc's defaults; the __f*_rn
+// helpers are plain operators in this ROCm, kept only as documentation of intent.
+#pragma clang fp contract(off)
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -54,7 +61,9 @@ __device__ __forceinline__ float binary_apply(float a, float b, bool body) {
 template <int OP>
 __device__ __forceinline__ float unary_apply(float x, float p0, float p1) {
     if constexpr (OP == NP_ABS) return fabsf(x);
-    if constexpr (OP == NP_SQRT) return __fsqrt_rn(x);
+    // sqrtf is correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt;
+    // __fsqrt_rn is NOT (it lowers to the native approximation unless OCML_BASIC_ROUNDED_OPERATIONS)
+    if constexpr (OP == NP_SQRT) return sqrtf(x);
     if constexpr (OP == NP_EXP) return expf(x);
     if constexpr (OP == NP_EXP2) return exp2f(x);
     if constexpr (OP == NP_EXPM1) return expm1f(x);

@@ -1,0 +1,96 @@
+"""Multi-GPU extension of the hot path: batch-parallel sharding.
+
+The reference has nothing multi-GPU (NDArray::setDevice only, numpower.c:615-635).  Every hot-path
+op is independent per array, so ranks normally run as replicas with no communication at all.  The
+one sharded case (BASELINE config 5) is a batched matmul: batch b of B goes to rank b // (B / N)
+— contiguous slabs, so each rank's share is ONE strided-batched GEMM launch — and, when a
+replicated result is wanted, the result slabs are combined with ONE all-gather (RCCL over xGMI:
+every peer's slab arrives over its own link).  No other collective exists on the path.
+
+One process per GPU, torch.distributed as plumbing (backend "nccl" = RCCL on ROCm, "gloo" in the
+CPU tests).  The compute is injected as a callable so that this module has no kernel code and the
+CPU tests can drive the partition + gather logic without a GPU.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Slab:
+    """Contiguous share [start, stop) of a batch owned by one rank."""
+    rank: int
+    start: int
+    stop: int
+
+    @property
+    def size(self) -> int:
+        return self.stop - self.start
+
+
+def slab_for(batch: int, world_size: int, rank: int) -> Slab:
+    """Contiguous, balanced partition: the first batch % world ranks get one extra matrix."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    base, extra = divmod(batch, world_size)
+    start = rank * base + min(rank, extra)
+    return Slab(rank, start, start + base + (1 if rank < extra else 0))
+
+
+def all_slabs(batch: int, world_size: int):
+    return [slab_for(batch, world_size, r) for r in range(world_size)]
+
+
+def sharded_batched_matmul(a_slab, b_slab, batch: int, compute, dist=None, gather: bool = True):
+    """Batched matmul with the batch sharded over the ranks of `dist`'s default group.
+
+    a_slab / b_slab : this rank's slab of the operands, torch tensors [slab, M, K] / [slab, K, N]
+                      on the rank's device
+    compute(a, b, out): writes the slab product into `out` [slab, M, N] (the HIP strided-batched
+                      GEMM on GPU ranks)
+    gather=True     : returns the replicated [batch, M, N] result (one all-gather);
+    gather=False    : returns this rank's [slab, M, N] result only (no collective at all).
+    """
+    import torch
+
+    if dist is None:
+        import torch.distributed as dist   # noqa: F811
+    world, rank = dist.get_world_size(), dist.get_rank()
+    slab = slab_for(batch, world, rank)
+    if a_slab.shape[0] != slab.size or b_slab.shape[0] != slab.size:
+        raise ValueError("rank %d expects a slab of %d matrices, got %d" % (rank, slab.size, a_slab.shape[0]))
+    m, n = a_slab.shape[1], b_slab.shape[2]
+    if not gather:
+        out = torch.empty((slab.size, m, n), dtype=a_slab.dtype, device=a_slab.device)
+        compute(a_slab, b_slab, out)
+        return out
+    full = torch.empty((batch, m, n), dtype=a_slab.dtype, device=a_slab.device)
+    mine = full[slab.start:slab.stop]
+    compute(a_slab, b_slab, mine)   # written in place: the gather needs no staging copy
+    if world == 1:
+        return full
+    if batch % world == 0:
+        # equal slabs: a single in-place all-gather into the result tensor
+        dist.all_gather_into_tensor(full.view(-1), mine.reshape(-1))
+    else:
+        # ragged slabs: pad every contribution to the largest slab so that it is still ONE
+        # equal-count all-gather, then drop the padding
+        slabs = all_slabs(batch, world)
+        pad = max(s.size for s in slabs)
+        send = torch.zeros((pad, m, n), dtype=full.dtype, device=full.device)
+        send[:slab.size].copy_(mine)
+        recv = torch.empty((world, pad, m, n), dtype=full.dtype, device=full.device)
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+        for s in slabs:
+            if s.rank != rank:
+                full[s.start:s.stop].copy_(recv[s.rank, :s.size])
+    return full
+
+
+def hip_compute(a, b, out):
+    """compute() for GPU ranks: one np_sgemm_strided_batched launch on torch's current stream."""
+    from ._lib import check, load
+    s, m, k = a.shape
+    n = b.shape[2]
+    check(load().np_sgemm_strided_batched(s, m, n, k, a.data_ptr(), m * k, b.data_ptr(), k * n,
+                                          out.data_ptr(), m * n))

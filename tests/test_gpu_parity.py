@@ -251,10 +251,12 @@ def test_full_reductions(shape, hip, oracle):
             # both within tolerance of the fp64 sum; the oracle's sequential order is the looser one
             assert abs(got - ref64) <= REL_TOL * abs(ref64)
             assert abs(got - ref) <= 2e-5 * abs(ref64) + abs(ref - ref64)
-    p = synth.uniform(shape, 22, 0.9, 1.1)
+    w = min(0.1, 1.0 / np.sqrt(x.size))   # keeps the product of x.size factors inside fp32 range
+    p = synth.uniform(shape, 22, 1.0 - w, 1.0 + w)
     got = NDArray.prod(NDArray.array(p).gpu())
     ref64 = float(np.prod(p.astype(np.float64)))
     assert abs(got - ref64) <= 1e-4 * abs(ref64)
+    assert abs(float(oracle.reduce_all("prod", p)) - ref64) <= 1e-3 * abs(ref64)
     m = NDArray.mean(gx)
     assert abs(m - exact.mean()) <= REL_TOL * abs(exact.mean())
 

@@ -1,0 +1,87 @@
+"""N > 1 path on CPU: world_size-2 (and 3, ragged) gloo runs of the batch-sharding logic in
+numpower_amd/parallel.py.  The compute callable is a plain torch.bmm here (test stand-in: the HIP
+kernel itself is covered by the -m gpu tests); what is under test is the slab partition, the
+in-place all-gather and the ragged padding path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from numpower_amd import parallel, synth
+
+
+def test_slab_partition_is_contiguous_and_balanced():
+    for batch in (512, 7, 1, 10):
+        for world in (1, 2, 3, 4, 8):
+            slabs = parallel.all_slabs(batch, world)
+            assert slabs[0].start == 0 and slabs[-1].stop == batch
+            for a, b in zip(slabs, slabs[1:]):
+                assert a.stop == b.start
+            sizes = [s.size for s in slabs]
+            assert max(sizes) - min(sizes) <= 1
+    assert parallel.slab_for(512, 8, 3) == parallel.Slab(3, 192, 256)   # batch b -> rank b // 64
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, batch, gather, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, k, n = 6, 5, 4
+        slab = parallel.slab_for(batch, world, rank)
+        a = torch.stack([torch.from_numpy(synth.uniform((m, k), 100 + i, -1, 1)) for i in range(slab.start, slab.stop)]) \
+            if slab.size else torch.empty((0, m, k))
+        b = torch.stack([torch.from_numpy(synth.uniform((k, n), 200 + i, -1, 1)) for i in range(slab.start, slab.stop)]) \
+            if slab.size else torch.empty((0, k, n))
+
+        def compute(x, y, out):
+            torch.bmm(x, y, out=out)
+
+        res = parallel.sharded_batched_matmul(a, b, batch, compute, dist=dist, gather=gather)
+        q.put((rank, res.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, batch, gather):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, gather, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+def _expected(batch):
+    return np.stack([synth.uniform((6, 5), 100 + i, -1, 1) @ synth.uniform((5, 4), 200 + i, -1, 1)
+                     for i in range(batch)])
+
+
+@pytest.mark.parametrize("world,batch", [(2, 8), (2, 7), (3, 8)])
+def test_sharded_batched_matmul_gathered(world, batch):
+    out = _run(world, batch, gather=True)
+    want = _expected(batch)
+    for rank in range(world):
+        np.testing.assert_allclose(out[rank], want, rtol=1e-6, atol=1e-6)
+
+
+def test_sharded_batched_matmul_left_sharded():
+    out = _run(2, 8, gather=False)
+    want = _expected(8)
+    np.testing.assert_allclose(out[0], want[:4], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(out[1], want[4:], rtol=1e-6, atol=1e-6)
