@@ -1,0 +1,31 @@
+"""Profiling driver (dev tool): launches each headline kernel a few times at BASELINE sizes so
+that rocprofv3 (--kernel-trace --stats, or --pmc passes) sees clean per-kernel dispatches.
+Usage: python tools/prof_kernels.py [iters]"""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+from numpower_amd import device as D, synth
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+D.init(0)
+n = 4096
+A = D.DeviceArray.from_host(synth.uniform((n, n), 3, -1, 1)); B = D.DeviceArray.from_host(synth.uniform((n, n), 4, -1, 1)); Cm = D.DeviceArray((n, n))
+for _ in range(iters): D.sgemm(A, B, out=Cm)
+D.sync()
+N = 100_000_000
+a = D.DeviceArray.from_host(synth.uniform((N,), 5)); b = D.DeviceArray.from_host(synth.uniform((N,), 6)); o = D.DeviceArray((N,))
+for _ in range(iters): D.binary("add", a, "full", b, "full", 1, N, out=o)
+for _ in range(iters): D.unary("exp", a, out=o)
+for _ in range(iters): D.unary("log", b, out=o)
+row = D.DeviceArray.from_host(synth.uniform((4000,), 9)); col = D.DeviceArray.from_host(synth.uniform((25000,), 10))
+for _ in range(iters): D.binary("add", a, "full", row, "row", 25000, 4000, out=o)
+for _ in range(iters): D.binary("add", a, "full", col, "col", 25000, 4000, out=o)
+for _ in range(iters): D.reduce_all("sum", a)
+D.sync()
+a.free(); b.free(); o.free()
+X = D.DeviceArray((65536, 4096)); D.fill(X, 0.5); out = D.DeviceArray((4096,)); out1 = D.DeviceArray((65536,))
+for _ in range(iters): D.reduce_axis("sum", X, 0, out=out)
+for _ in range(iters): D.reduce_axis("sum", X, 1, out=out1)
+D.sync()
+print("done")
