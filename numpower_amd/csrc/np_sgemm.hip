@@ -18,6 +18,8 @@
 //   Bs[buf][k][n]  row-major as in memory; a B fragment is one ds_read_b32 per lane, 32
 //                  consecutive floats per half-wave (conflict-free).
 // Row-major A.B needs no transposes on either operand with this mapping.
+#include <type_traits>
+
 #include "np_internal.h"
 
 namespace {
@@ -33,7 +35,31 @@ struct GemmArgs {
     size_t stride_a, stride_b, stride_c;   // batch strides (elements)
     unsigned tiles_m, tiles_n;
     unsigned swizzle;                       // 0 = row-major tile order, else XCD-aware grouping
+    unsigned long long *probe;              // optional per-workgroup timing record (debug), else null
 };
+
+// Debug instrumentation: per workgroup {shader-clock start, end, 100 MHz wall start, end, XCC id}.
+// Used by tools/gemm_probe.py to separate "cycles lost to stalls" from "clock lowered by DVFS".
+__device__ __forceinline__ void probe_begin(const GemmArgs &g, unsigned long long &c0,
+                                            unsigned long long &w0) {
+    if (g.probe) {
+        c0 = __builtin_readcyclecounter();
+        w0 = wall_clock64();
+    }
+}
+__device__ __forceinline__ void probe_end(const GemmArgs &g, unsigned long long c0,
+                                          unsigned long long w0) {
+    if (g.probe && threadIdx.x == 0) {
+        unsigned long long *p = g.probe + 8 * ((size_t)blockIdx.z * gridDim.x + blockIdx.x);
+        p[0] = c0;
+        p[1] = __builtin_readcyclecounter();
+        p[2] = w0;
+        p[3] = wall_clock64();
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p[4] = xcc;
+    }
+}
 
 // Tile id -> (tile_m, tile_n).  Workgroup b is placed on XCD b % 8 (observed dispatch order);
 // with `swizzle` each XCD gets a contiguous run of tiles, and runs are walked in GROUP-row
@@ -83,6 +109,8 @@ __global__ __launch_bounds__(256, MINW) void sgemm_kernel(GemmArgs g) {
     unsigned tile_m, tile_n;
     tile_coords(g, blockIdx.x, tile_m, tile_n);
     const unsigned m0 = tile_m * BM, n0 = tile_n * BN;
+    unsigned long long probe_c0 = 0, probe_w0 = 0;
+    probe_begin(g, probe_c0, probe_w0);
 
     const float *A = g.A + (size_t)blockIdx.z * g.stride_a;
     const float *B = g.B + (size_t)blockIdx.z * g.stride_b;
@@ -196,6 +224,384 @@ __global__ __launch_bounds__(256, MINW) void sgemm_kernel(GemmArgs g) {
                 const unsigned col = n0 + wn0 + j * 32 + li;
                 if (!EDGE || (row < g.M && col < g.N)) C[(size_t)row * g.ldc + col] = acc[i][j][r];
             }
+    probe_end(g, probe_c0, probe_w0);
+}
+
+// Software-pipelined variant (the default for large problems).
+//
+// Why: with the simple kernel above the 4 co-resident waves of a SIMD convoy — each wave's
+// non-MFMA tail (vmcnt wait, ds_write, barrier, first ds_read latency ≈ 300 cycles per K-tile)
+// lines up with the others', and rocprof shows the matrix pipe busy only 83 % of the kernel
+// (profiles/r01/pmc_summary.txt: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM cycles)).
+// Here every wave keeps its own MFMA stream fed:
+//   * 3 LDS buffers, ONE barrier per K-tile placed in the MIDDLE of the tile: tile t+1 is written
+//     to LDS after the first half of tile t's MFMAs have been issued and is published by that
+//     barrier; the second half of tile t's MFMAs run behind it.  (Buffer (t+1)%3 was last read
+//     for tile t-2, which every wave finished before arriving at the previous barrier.)
+//   * A/B fragments are double-buffered in registers: the ds_reads for the next 8-deep k group
+//     are issued before the current group's 16 MFMAs, so no MFMA waits on an LDS round trip.
+//   * global loads for tile t+2 are issued right after tile t+1's registers were stored.
+// BK is fixed at 16 = two k groups = the two halves.
+// MODE bit 0: spread the staging work between the MFMAs.  Bits 1-4 are timing ablations used by
+// tools/gemm_ab.py only (they produce WRONG results): 2 = no barrier, 4 = no global loads,
+// 8 = no LDS stores, 16 = no fragment reads inside the K loop.
+template <int BM, int BN, bool VEC, bool EDGE, int MODE>
+__global__ __launch_bounds__(256, 2) void sgemm_pipe_kernel(GemmArgs g) {
+    constexpr int BK = 16;
+    constexpr bool SPREAD = MODE & 1, NO_BAR = MODE & 2, NO_GLD = MODE & 4, NO_STS = MODE & 8, NO_FRAG = MODE & 16;
+    constexpr int LDA_S = BK + 4, LDB_S = BN;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_V4 = BM * BK / 4 / 256, B_V4 = BK * BN / 4 / 256;
+    constexpr int A_SZ = BM * LDA_S, B_SZ = BK * LDB_S;
+
+    __shared__ __attribute__((aligned(16))) float smem[3 * (A_SZ + B_SZ)];
+    float *const As = smem;
+    float *const Bs = smem + 3 * A_SZ;
+
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63, wave = tid >> 6;
+    const unsigned li = lane & 31, lh = lane >> 5;
+    const unsigned wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+    unsigned tile_m, tile_n;
+    tile_coords(g, blockIdx.x, tile_m, tile_n);
+    const unsigned m0 = tile_m * BM, n0 = tile_n * BN;
+    unsigned long long probe_c0 = 0, probe_w0 = 0;
+    probe_begin(g, probe_c0, probe_w0);
+
+    const float *A = g.A + (size_t)blockIdx.z * g.stride_a;
+    const float *B = g.B + (size_t)blockIdx.z * g.stride_b;
+    float *C = g.C + (size_t)blockIdx.z * g.stride_c;
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    v4f ra[A_V4], rb[B_V4];
+
+    auto load_global = [&](unsigned kt) {
+        const unsigned k0 = kt * BK;
+#pragma unroll
+        for (int r = 0; r < A_V4; ++r) {
+            const unsigned f = tid + 256 * r;
+            const unsigned row = f / (BK / 4), c4 = f % (BK / 4);
+            const unsigned gm = m0 + row, gk = k0 + c4 * 4;
+            if constexpr (VEC) {
+                if (!EDGE || (gm < g.M && gk < g.K))
+                    ra[r] = *(const v4f *)(A + (size_t)gm * g.lda + gk);
+                else
+                    ra[r] = v4f{0, 0, 0, 0};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    ra[r][e] = (gm < g.M && gk + e < g.K) ? A[(size_t)gm * g.lda + gk + e] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < B_V4; ++r) {
+            const unsigned f = tid + 256 * r;
+            const unsigned row = f / (BN / 4), c4 = f % (BN / 4);
+            const unsigned gk = k0 + row, gn = n0 + c4 * 4;
+            if constexpr (VEC) {
+                if (!EDGE || (gk < g.K && gn < g.N))
+                    rb[r] = *(const v4f *)(B + (size_t)gk * g.ldb + gn);
+                else
+                    rb[r] = v4f{0, 0, 0, 0};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    rb[r][e] = (gk < g.K && gn + e < g.N) ? B[(size_t)gk * g.ldb + gn + e] : 0.0f;
+            }
+        }
+    };
+
+    auto store_lds = [&](unsigned buf) {
+        float *as = As + buf * A_SZ;
+        float *bs = Bs + buf * B_SZ;
+#pragma unroll
+        for (int r = 0; r < A_V4; ++r) {
+            const unsigned f = tid + 256 * r;
+            const unsigned row = f / (BK / 4), c4 = f % (BK / 4);
+            *(v4f *)&as[row * LDA_S + c4 * 4] = ra[r];
+        }
+#pragma unroll
+        for (int r = 0; r < B_V4; ++r) {
+            const unsigned f = tid + 256 * r;
+            const unsigned row = f / (BN / 4), c4 = f % (BN / 4);
+            *(v4f *)&bs[row * LDB_S + c4 * 4] = rb[r];
+        }
+    };
+
+    // register fragments of one 8-deep k group: a4[i] = 4 consecutive k of this lane's row,
+    // bv[s][j] = B[kb + 4*half + s][col]
+    struct Frag {
+        v4f a4[TM];
+        float bv[4][TN];
+    };
+    auto read_frag = [&](Frag &f, unsigned buf, int kg) {
+        const float *as = As + buf * A_SZ + (wm0 + li) * LDA_S + 4 * lh + kg * 8;
+        const float *bs = Bs + buf * B_SZ + (4 * lh + kg * 8) * LDB_S + wn0 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a4[i] = *(const v4f *)(as + i * 32 * LDA_S);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f.bv[s][j] = bs[s * LDB_S + j * 32];
+    };
+    auto mfma_steps = [&](const Frag &f, int s0, int s1) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a4[i][s], f.bv[s][j], acc[i][j], 0, 0, 0);
+    };
+
+    const unsigned nk = (g.K + BK - 1) / BK;
+    Frag f0, f1;
+    load_global(0);
+    store_lds(0);
+    if (nk > 1) load_global(1);
+    __syncthreads();
+    read_frag(f0, 0, 0);
+
+    unsigned cur = 0;
+    for (unsigned kt = 0; kt < nk; ++kt) {
+        const unsigned nxt = (cur == 2) ? 0 : cur + 1;
+        const bool more = (kt + 1 < nk);
+        // first half: k group 0 (fragments already in f0); fetch group 1 underneath
+        if (!NO_FRAG) read_frag(f1, cur, 1);
+        if constexpr (SPREAD) {
+            // staging work spread between the MFMAs so that it issues in their shadow
+            mfma_steps(f0, 0, 2);
+            if (more && !NO_STS) store_lds(nxt);  // tile kt+1 -> LDS (its loads were issued a tile ago)
+            mfma_steps(f0, 2, 3);
+            if (kt + 2 < nk && !NO_GLD) load_global(kt + 2);   // in flight during the next ~32 MFMAs
+            mfma_steps(f0, 3, 4);
+        } else {
+            mfma_steps(f0, 0, 4);
+            if (more) {
+                if (!NO_STS) store_lds(nxt);
+                if (kt + 2 < nk && !NO_GLD) load_global(kt + 2);
+            }
+        }
+        if (!NO_BAR) __syncthreads();             // publishes tile kt+1
+        // second half: k group 1; fetch group 0 of the next tile underneath
+        if (more && !NO_FRAG) read_frag(f0, nxt, 0);
+        mfma_steps(NO_FRAG ? f0 : f1, 0, 4);
+        cur = nxt;
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const unsigned col = n0 + wn0 + j * 32 + li;
+                if (!EDGE || (row < g.M && col < g.N)) C[(size_t)row * g.ldc + col] = acc[i][j][r];
+            }
+    probe_end(g, probe_c0, probe_w0);
+}
+
+// LDS-DMA variant for fully aligned problems (M % 256 == 0, N % 128 == 0, K % 16 == 0): the
+// large-matrix default.
+//
+// Why (ablation of the kernel above, tools/gemm_ab.py, profiles/r01/gemm_ablation.log): with
+// everything but the MFMAs removed the loop runs 152 TFLOP/s; the register->LDS stores of the
+// staged tiles alone cost 7 %, the fragment reads 4 %, global loads and the barrier ~0.  So:
+//   * global -> LDS goes by global_load_lds_dwordx4 (no staging VGPRs, no ds_write at all).  The
+//     DMA writes lane-linear 16-byte slots, so the A tile is [256 rows][4 slots of 4 k] unpadded
+//     and the bank-conflict fix moves to the SOURCE address: LDS slot p of row r holds k-chunk
+//     p ^ ((r >> 2) & 3); fragment reads apply the same XOR (conflict-free ds_read_b128: a
+//     16-lane group covers 16 distinct 16-byte slots of the 256-byte bank row).
+//   * the wave tile grows to 128 x 64 (4 x 2 MFMA blocks, 128 accumulator VGPRs): every B
+//     fragment register now feeds 4 MFMAs, halving the ds_read_b32 traffic per MFMA.
+//   * 256 x 128 workgroup tile, 4 waves, 3 LDS buffers (72 KiB) -> 2 workgroups per CU; 4096^2
+//     is exactly one resident round of 512 workgroups.
+// Pipeline per K-tile (one barrier, in the middle, as in sgemm_pipe_kernel): fragments of k-group
+// 1 are fetched under the MFMAs of group 0; the barrier publishes tile t+1 (its DMAs were issued
+// a full tile earlier; hipcc's vmcnt(0) in front of the barrier is then already satisfied);
+// right after it the DMAs of tile t+2 go into the buffer tile t-1 just vacated.
+__global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 128, BK = 16;
+    constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
+    constexpr int A_SZ = BM * BK, B_SZ = BK * BN;   // floats per buffer: 4096 + 2048
+
+    __shared__ __attribute__((aligned(16))) float smem[3 * (A_SZ + B_SZ)];
+    float *const As = smem;
+    float *const Bs = smem + 3 * A_SZ;
+
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned li = lane & 31, lh = lane >> 5;
+    const unsigned wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+    unsigned tile_m, tile_n;
+    tile_coords(g, blockIdx.x, tile_m, tile_n);
+    const unsigned m0 = tile_m * BM, n0 = tile_n * BN;
+    unsigned long long probe_c0 = 0, probe_w0 = 0;
+    probe_begin(g, probe_c0, probe_w0);
+
+    const float *A = g.A + (size_t)blockIdx.z * g.stride_a;
+    const float *B = g.B + (size_t)blockIdx.z * g.stride_b;
+    float *C = g.C + (size_t)blockIdx.z * g.stride_c;
+
+    // DMA source pointers of this lane for K-tile 0 (advanced by BK / BK rows per tile).
+    // A: the wave moves 4 chunks of 16 rows x 64 B; lane = (row_in_chunk, slot); slot p of row r
+    //    fetches k-chunk p ^ ((r >> 2) & 3).
+    // B: the wave moves 2 chunks of 2 k-rows x 512 B, straight row-major.
+    const float *a_src[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned r = (wave * 4 + c) * 16 + (lane >> 2);
+        const unsigned q = (lane & 3) ^ ((r >> 2) & 3);
+        a_src[c] = A + (size_t)(m0 + r) * g.lda + q * 4;
+    }
+    const float *b_src[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const unsigned krow = (wave * 2 + c) * 2 + (lane >> 5);
+        b_src[c] = B + (size_t)krow * g.ldb + n0 + (lane & 31) * 4;
+    }
+    const size_t b_step = (size_t)BK * g.ldb;
+
+    auto dma_tile = [&](unsigned buf) {
+        float *as = As + buf * A_SZ + wave * 1024;   // 4 chunks x 256 floats per wave
+        float *bs = Bs + buf * B_SZ + wave * 512;    // 2 chunks x 256 floats per wave
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)a_src[c],
+                                             (__attribute__((address_space(3))) void *)(as + c * 256), 16, 0, 0);
+            a_src[c] += BK;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)b_src[c],
+                                             (__attribute__((address_space(3))) void *)(bs + c * 256), 16, 0, 0);
+            b_src[c] += b_step;
+        }
+    };
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    struct Frag {
+        v4f a4[TM];
+        float bv[4][TN];
+    };
+    // per-lane LDS offsets (floats): row (wm0 + i*32 + li), physical slot (kg*2 + lh) ^ sw
+    const unsigned sw = (li >> 2) & 3;
+    const unsigned a_off0 = (wm0 + li) * BK + ((lh ^ sw) * 4);          // k group 0
+    const unsigned a_off1 = (wm0 + li) * BK + (((2 + lh) ^ sw) * 4);    // k group 1
+    const unsigned b_off = (4 * lh) * BN + wn0 + li;
+    auto read_frag = [&](Frag &f, unsigned buf, int kg) {
+        const float *as = As + buf * A_SZ + (kg ? a_off1 : a_off0);
+        const float *bs = Bs + buf * B_SZ + b_off + kg * 8 * BN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a4[i] = *(const v4f *)(as + i * 32 * BK);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f.bv[s][j] = bs[s * BN + j * 32];
+    };
+    auto mfma_group = [&](const Frag &f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a4[i][s], f.bv[s][j], acc[i][j], 0, 0, 0);
+    };
+
+    const unsigned nk = g.K / BK;
+    Frag f0, f1;
+    dma_tile(0);
+    if (nk > 1) dma_tile(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_frag(f0, 0, 0);
+
+    // One K-tile.  DMA / NEXT are compile-time so that the steady-state iteration is a single
+    // basic block per half and the issue-order hints below can interleave across it.
+    unsigned cur = 0;
+    auto k_tile = [&](auto dma_c, auto next_c) {
+        constexpr bool DMA = decltype(dma_c)::value, NEXT = decltype(next_c)::value;
+        const unsigned nxt = (cur == 2) ? 0 : cur + 1;
+        const unsigned nn = (nxt == 2) ? 0 : nxt + 1;
+        // first half: MFMAs of k group 0; the 8 LDS reads of group 1 go out one behind each of the
+        // first 8 MFMAs (in the shadow of a running MFMA instead of as one burst)
+        read_frag(f1, cur, 1);
+        mfma_group(f0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+        // keep the wait + barrier BEHIND the 32 MFMAs (hipcc would hoist them to the top of the
+        // tile: register-only MFMAs are not ordered by a "memory" clobber)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NEXT) {
+            // tile kt+1 (DMA issued one tile ago) must have landed for every wave before anyone
+            // reads it; the same barrier tells everyone that tile kt-1's buffer is free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // second half: MFMAs of k group 1 with 6 LDS-DMA issues (tile kt+2 -> the buffer tile kt-1
+        // vacated) and the 8 LDS reads of the next tile's group 0, each behind its own MFMA
+        if constexpr (DMA) dma_tile(nn);
+        if constexpr (NEXT) read_frag(f0, nxt, 0);
+        mfma_group(f1);
+        if constexpr (DMA) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (global_load_lds)
+            }
+        }
+        if constexpr (NEXT) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    unsigned kt = 0;
+    for (; kt + 2 < nk; ++kt) k_tile(T{}, T{});
+    if (kt + 1 < nk) k_tile(F{}, T{});
+    k_tile(F{}, F{});
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const unsigned col = n0 + wn0 + j * 32 + li;
+                C[(size_t)row * g.ldc + col] = acc[i][j][r];
+            }
+    probe_end(g, probe_c0, probe_w0);
 }
 
 // y = A x, one wave per row (rows are contiguous: float4 loads, wave64 shuffle reduce).
@@ -227,6 +633,7 @@ __global__ __launch_bounds__(256) void sgemv_kernel(const float *__restrict__ A,
 }
 
 int g_variant = 0;
+unsigned long long *g_probe = nullptr;
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
@@ -247,6 +654,23 @@ int launch_sgemm_tile(GemmArgs g, unsigned batch, bool vec) {
     return NP_OK;
 }
 
+template <int BM, int BN, int MODE>
+int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    const bool edge = (g.M % BM) || (g.N % BN) || (g.K % 16);
+    const dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
+    hipStream_t s = np::stream();
+    if (vec && !edge)
+        sgemm_pipe_kernel<BM, BN, true, false, MODE><<<grid, 256, 0, s>>>(g);
+    else if (vec)
+        sgemm_pipe_kernel<BM, BN, true, true, MODE><<<grid, 256, 0, s>>>(g);
+    else
+        sgemm_pipe_kernel<BM, BN, false, true, MODE><<<grid, 256, 0, s>>>(g);
+    NP_LAUNCH_CHECK("sgemm_pipe_kernel");
+    return NP_OK;
+}
+
 int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, size_t sa,
                  const float *B, size_t sb, float *C, size_t sc) {
     if (M > 0x7fffffffu || N > 0x7fffffffu || K > 0x7fffffffu || batch > 65535)
@@ -257,9 +681,21 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
     g.lda = (unsigned)K; g.ldb = (unsigned)N; g.ldc = (unsigned)N;
     g.stride_a = sa; g.stride_b = sb; g.stride_c = sc;
     g.tiles_m = g.tiles_n = 0;
+    g.probe = g_probe;
     const bool vec = (K % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(B) &&
                      (sa % 4 == 0) && (sb % 4 == 0);
     // variant = tile_code + 10 * swizzle_group ; 0 = default
+    if (g_variant >= 1000) {   // timing ablations of the pipelined kernel (wrong results!)
+        switch (g_variant - 1000) {
+            case 3: return launch_sgemm_pipe<128, 128, 1 + 2>(g, (unsigned)batch, vec);
+            case 5: return launch_sgemm_pipe<128, 128, 1 + 4>(g, (unsigned)batch, vec);
+            case 9: return launch_sgemm_pipe<128, 128, 1 + 8>(g, (unsigned)batch, vec);
+            case 17: return launch_sgemm_pipe<128, 128, 1 + 16>(g, (unsigned)batch, vec);
+            case 15: return launch_sgemm_pipe<128, 128, 1 + 2 + 4 + 8>(g, (unsigned)batch, vec);
+            case 31: return launch_sgemm_pipe<128, 128, 1 + 2 + 4 + 8 + 16>(g, (unsigned)batch, vec);
+            default: break;
+        }
+    }
     const int tile = g_variant % 10;
     g.swizzle = (unsigned)(g_variant / 10);
     switch (tile) {
@@ -267,19 +703,46 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
         case 2: return launch_sgemm_tile<128, 128, 32, 2>(g, (unsigned)batch, vec);
         case 3: return launch_sgemm_tile<128, 128, 16, 2>(g, (unsigned)batch, vec);
         case 4: return launch_sgemm_tile<64, 64, 16, 4>(g, (unsigned)batch, vec);
+        case 5: return launch_sgemm_pipe<128, 128, 0>(g, (unsigned)batch, vec);
+        case 6: return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
+        case 7:
+            if (vec && M % 256 == 0 && N % 128 == 0 && K % 16 == 0) {
+                g.tiles_m = g.M / 256;
+                g.tiles_n = g.N / 128;
+                sgemm_dma_kernel<<<dim3(g.tiles_m * g.tiles_n, 1, (unsigned)batch), 256, 0, np::stream()>>>(g);
+                NP_LAUNCH_CHECK("sgemm_dma_kernel");
+                return NP_OK;
+            }
+            return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
         default: break;
     }
-    // heuristic: small outputs get 64x64 tiles so that more than a handful of CUs have work
+    // Default choice, measured on MI355X at 4096^3 (profiles/r01/gemm_ab.log): LDS-DMA kernel
+    // 145 TFLOP/s, register-staged pipelined 128x128 kernel 135, simple 128x128 kernel 132-135.
+    //   1. fully aligned and enough 256x128 tiles to give every CU one  -> sgemm_dma_kernel
+    //   2. enough 128x128 tiles                                          -> sgemm_pipe_kernel
+    //   3. otherwise 64x64 tiles so that more than a handful of CUs have work
+    const size_t cus = (size_t)np::num_cus();
+    if (vec && M % 256 == 0 && N % 128 == 0 && K % 16 == 0 && (M / 256) * (N / 128) * batch >= cus) {
+        g.tiles_m = g.M / 256;
+        g.tiles_n = g.N / 128;
+        sgemm_dma_kernel<<<dim3(g.tiles_m * g.tiles_n, 1, (unsigned)batch), 256, 0, np::stream()>>>(g);
+        NP_LAUNCH_CHECK("sgemm_dma_kernel");
+        return NP_OK;
+    }
     const size_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128) * batch;
-    if (big_tiles < (size_t)np::num_cus() && (M > 64 || N > 64))
-        return launch_sgemm_tile<64, 64, 16, 4>(g, (unsigned)batch, vec);
-    if (M <= 64 && N <= 64) return launch_sgemm_tile<64, 64, 16, 4>(g, (unsigned)batch, vec);
-    return launch_sgemm_tile<128, 128, 16, 4>(g, (unsigned)batch, vec);
+    if (big_tiles >= cus) return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
+    return launch_sgemm_tile<64, 64, 16, 4>(g, (unsigned)batch, vec);
 }
 
 }  // namespace
 
 extern "C" {
+
+// debug: device buffer of 8 x u64 per workgroup, filled by the next np_sgemm launches (null = off)
+int np_debug_sgemm_probe(void *dev_buf) {
+    g_probe = (unsigned long long *)dev_buf;
+    return NP_OK;
+}
 
 int np_sgemm_set_variant(int variant) {
     g_variant = variant;
