@@ -311,7 +311,7 @@ def main():
                    "parallelism": "replicas x%d (independent arrays, no collective)" % args.gpus},
         "roofline": {"bound": "mfma", "achieved": kernel_tflops, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": kernel_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                     "kernel": "sgemm_kernel<128,128,16> (v_mfma_f32_32x32x2_f32)",
+                     "kernel": "sgemm_dma_kernel 256x128x16 (v_mfma_f32_32x32x2_f32, LDS-DMA staging)",
                      "algorithmic_flop_per_launch": flop},
         "parity": {"matmul_max_norm_err_vs_fp64": mm["parity_max_norm_err_vs_fp64"], "ok": mm["parity_ok"]},
     }

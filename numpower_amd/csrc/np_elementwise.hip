@@ -303,14 +303,15 @@ struct LaunchCfg {
     bool nt;             // non-temporal loads/stores
 };
 
-// Default = what tools/explore/add_bw.hip measured fastest on MI355X for 2R+1W streams of 1e8
-// floats (profiles/r01_add_bw_explore.log): no grid cap — every lane moves UNROLL float4 and
-// retires, ~24k workgroups keep the dispatcher ahead of the memory system — with non-temporal
-// loads and stores.  Capping the grid at a few workgroups per CU and grid-striding was 3-8 %
-// slower; cached (non-nt) accesses 5-10 % slower.
+// Default = what was measured fastest on MI355X for 1e8-float streams (tools/explore/add_bw.hip,
+// tools/ew_ab.py; profiles/r01/add_bw_explore.log, profiles/r01/ew_ab.log): no grid cap — every
+// lane moves UNROLL = 2 float4 and retires, ~49k workgroups keep the dispatcher ahead of the
+// memory system — with non-temporal loads and stores.  Capping the grid at a few workgroups per
+// CU and grid-striding was 3-8 % slower, cached (non-nt) accesses 5-10 % slower, UNROLL 1/4/8
+// 1-8 % slower than 2 on random data (add 6.28, exp 6.60, add+row 6.47 TB/s at UNROLL 2).
 // variant = unroll_code + 10*bpc_code + 100*nt ; 0 = default
 LaunchCfg cfg_from_variant(int variant) {
-    LaunchCfg c{4, 0, true};
+    LaunchCfg c{2, 0, true};
     if (variant <= 0) return c;
     const int u = variant % 10, b = (variant / 10) % 10, nt = (variant / 100) % 10;
     if (u == 1) c.unroll = 1;

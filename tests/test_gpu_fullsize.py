@@ -1,0 +1,139 @@
+"""GPU parity at BASELINE.json's full sizes (configs 2-5), through properties that do not need the
+oracle to chew through the whole input:
+
+  C3a add 1e8          bit-exact against IEEE fp32 addition (= the reference's AVX2 add) + linearity
+  C3b exp / log 1e8    sampled against the oracle, exp(log(x)) round trip on the full array
+  C3c broadcast        bit-exact, row and column forms on 25000 x 4000
+  C4  sum(axis 0)      65536 x 4096 against an fp64 accumulation, checksum-of-checksums vs sum()
+  C2  matmul 4096^2    sampled rows against fp64, associativity-free identities (A.I, scaling)
+  C5  batched matmul   64 x (1024 x 1024) slab (one rank's share of 512) against per-matrix np_sgemm
+"""
+import numpy as np
+import pytest
+
+from numpower_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N8 = 100_000_000
+
+
+def _u32(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_add_1e8_bit_exact_and_linear(hip):
+    D = hip
+    a = synth.uniform((N8,), 5, 0.0, 1.0)
+    b = synth.uniform((N8,), 6, 0.0, 1.0)
+    da, db = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b)
+    out = D.binary("add", da, "full", db, "full", 1, N8)
+    got = out.to_host()
+    assert (_u32(got) == _u32(a + b)).all()          # numpy fp32 add is IEEE, like _mm256_add_ps
+    # (a + b) - b == a wherever the addition was exact; checked through the kernel itself
+    back = D.binary("subtract", out, "full", db, "full", 1, N8).to_host()
+    exact = (got.astype(np.float64) == a.astype(np.float64) + b.astype(np.float64))
+    assert (back[exact] == a[exact]).all()
+    # scalar and tail handling at a size that is not a multiple of 4
+    n = N8 - 3
+    v = D.binary("multiply", da.view(0, (n,)), "full", D.DeviceArray.from_host(np.float32([2.0])), "scalar", 1, n).to_host()
+    assert (_u32(v) == _u32(a[:n] * np.float32(2.0))).all()
+    for d in (da, db, out):
+        d.free()
+
+
+def test_exp_log_1e8(hip, oracle):
+    D = hip
+    x = synth.uniform((N8,), 8, 1e-3, 1e3)
+    dx = D.DeviceArray.from_host(x)
+    dl = D.unary("log", dx)
+    got = dl.to_host()
+    idx = np.concatenate([np.arange(0, 200_000), np.arange(N8 - 200_000, N8), np.arange(0, N8, 997)])
+    ref = oracle.unary("log", x[idx]).astype(np.float64)
+    assert (np.abs(got[idx] - ref) <= 1e-5 * np.abs(ref) + 1e-11).all()
+    back = D.unary("exp", dl).to_host().astype(np.float64)
+    assert (np.abs(back - x) <= 5e-6 * np.abs(x) * (1.0 + np.abs(np.log(x.astype(np.float64))))).all()
+    for d in (dx, dl):
+        d.free()
+
+
+def test_broadcast_25000x4000_bit_exact(hip):
+    D = hip
+    R, C = 25000, 4000
+    X = synth.uniform((R, C), 5, 0.0, 1.0)
+    row = synth.uniform((C,), 9, 0.0, 1.0)
+    col = synth.uniform((R,), 10, 0.0, 1.0)
+    dX = D.DeviceArray.from_host(X)
+    got = D.binary("add", dX, "full", D.DeviceArray.from_host(row), "row", R, C).to_host()
+    assert (_u32(got) == _u32(X + row[None, :])).all()
+    got = D.binary("divide", D.DeviceArray.from_host(col), "col", dX, "full", R, C).to_host()
+    with np.errstate(divide="ignore"):
+        assert (_u32(got) == _u32(col[:, None] / X)).all()
+    dX.free()
+
+
+def test_sum_axis0_65536x4096(hip):
+    D = hip
+    rows, cols = 65536, 4096
+    X = synth.uniform((rows, cols), 11, 0.0, 1.0)
+    dX = D.DeviceArray.from_host(X)
+    got = D.reduce_axis("sum", dX, 0).to_host().astype(np.float64)
+    ref = X.sum(axis=0, dtype=np.float64)
+    assert (np.abs(got - ref) <= 1e-5 * ref).all()
+    # checksum of checksums: sum over the column sums == sum over the row sums == sum of everything
+    r1 = D.reduce_axis("sum", dX, 1).to_host().astype(np.float64)
+    total = float(ref.sum())
+    assert abs(got.sum() - total) <= 1e-6 * total
+    assert abs(r1.sum() - total) <= 1e-6 * total
+    assert abs(D.reduce_all("sum", dX) - total) <= 1e-5 * total
+    assert D.reduce_all("max", dX) == float(X.max()) and D.reduce_all("min", dX) == float(X.min())
+    mean = D.reduce_axis("mean", dX, 0).to_host().astype(np.float64)
+    assert (np.abs(mean - ref / rows) <= 1e-5 * ref / rows).all()
+    dX.free()
+
+
+def test_matmul_4096(hip, oracle):
+    D = hip
+    n = 4096
+    A = synth.uniform((n, n), 3, -1.0, 1.0)
+    B = synth.uniform((n, n), 4, -1.0, 1.0)
+    dA, dB = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B)
+    C = D.sgemm(dA, dB).to_host()
+    rows = np.array([0, 1, 31, 32, 255, 256, 1234, 2047, 2048, 4095])
+    ref = A[rows].astype(np.float64) @ B.astype(np.float64)
+    scale = np.abs(A[rows]).astype(np.float64) @ np.abs(B).astype(np.float64)
+    assert (np.abs(C[rows] - ref) <= 1e-6 * scale).all()
+    cols = np.array([0, 63, 64, 127, 128, 4095])
+    refc = A.astype(np.float64) @ B[:, cols].astype(np.float64)
+    scalec = np.abs(A).astype(np.float64) @ np.abs(B[:, cols]).astype(np.float64)
+    assert (np.abs(C[:, cols] - refc) <= 1e-6 * scalec).all()
+    # the reference's CPU back end (OpenBLAS) on the same inputs, all elements
+    Cref = oracle.matmul(A, B)
+    norm = np.sqrt(n) * 1.0   # |row| . |col| magnitude for U(-1,1) operands ~ n/3; loose global bound
+    assert np.abs(C - Cref).max() <= 1e-5 * (n / 3.0)
+    # exact identities: A . I == A bit for bit, (2A) . B == 2 (A . B) bit for bit
+    I = np.eye(n, dtype=np.float32)
+    assert (_u32(D.sgemm(dA, D.DeviceArray.from_host(I)).to_host()) == _u32(A)).all()
+    C2 = D.sgemm(D.DeviceArray.from_host(A * np.float32(2.0)), dB).to_host()
+    assert (_u32(C2) == _u32(C * np.float32(2.0))).all()
+    del norm
+
+
+def test_batched_matmul_slab_64x1024(hip):
+    """One rank's share of BASELINE config 5 (512 / 8 = 64 matrices): the strided-batched launch and
+    independent 2-D np_sgemm calls on the same matrices (a different tile shape is chosen for a
+    single 1024^2 product) both match the fp64 product."""
+    D = hip
+    bsz, n = 64, 1024
+    A = synth.uniform((bsz, n, n), 12, -1.0, 1.0)
+    B = synth.uniform((bsz, n, n), 13, -1.0, 1.0)
+    dA, dB = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B)
+    Cb = D.sgemm_batched(dA, dB).to_host()
+    for i in (0, 1, 31, 63):
+        Ci = D.sgemm(dA.view(i * n * n, (n, n)), dB.view(i * n * n, (n, n))).to_host()
+        ref = A[i].astype(np.float64) @ B[i].astype(np.float64)
+        scale = np.abs(A[i]).astype(np.float64) @ np.abs(B[i]).astype(np.float64)
+        assert (np.abs(Cb[i] - ref) <= 1e-6 * scale).all()
+        assert (np.abs(Ci - ref) <= 1e-6 * scale).all()
+    dA.free()
+    dB.free()

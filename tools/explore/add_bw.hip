@@ -57,7 +57,31 @@ template<int U,bool NTL,bool NTS,int MODE,int T> void run_cfg(int kind, int bpc)
   else bench(name, bytes, [&]{ k_chunk<U,NTL,NTS,MODE,T><<<grid,T,0,st_>>>((v4f*)A,(v4f*)B,(v4f*)O,nvec,S); });
 }
 template<int U,int T,int MODE> void sweep_nt(int kind,int bpc){ run_cfg<U,true,true,MODE,T>(kind,bpc); run_cfg<U,false,false,MODE,T>(kind,bpc); run_cfg<U,true,false,MODE,T>(kind,bpc); run_cfg<U,false,true,MODE,T>(kind,bpc);} 
-int main(){
+__global__ void k_rand(float* p, size_t n, unsigned seed){ size_t i = blockIdx.x*(size_t)blockDim.x+threadIdx.x; size_t st=(size_t)gridDim.x*blockDim.x; for(; i<n; i+=st){ unsigned long long z = (i + 0x9E3779B97F4A7C15ull*(seed+1)); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31; p[i] = (float)(z >> 40) * (1.0f/16777216.0f); } }
+template<int U,bool NTL,bool NTS,int T> void run_off(size_t offb, size_t offo){
+  double bytes = 12.0*nvec*4; size_t need=((size_t)nvec+(size_t)U*T-1)/((size_t)U*T); unsigned grid=need;
+  char name[128]; snprintf(name,128,"offset U%d T%d offB=%zuB offO=%zuB", U,T,offb,offo);
+  bench(name, bytes, [&]{ k_grid<U,NTL,NTS,0,T><<<grid,T,0,st_>>>((v4f*)A,(v4f*)((char*)B+offb),(v4f*)((char*)O+offo),nvec,S); });
+}
+int main(int argc, char** argv){ if(argc>2){
+  size_t n=100000000; nvec=n/4; CK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  CK(hipMalloc(&A,n*4+(8<<20))); CK(hipMalloc(&B,n*4+(8<<20))); CK(hipMalloc(&O,n*4+(8<<20))); CK(hipMalloc(&S,4));
+  printf("A=%p B=%p O=%p\n",A,B,O);
+  k_rand<<<2048,256,0,st_>>>(A,n,1); k_rand<<<2048,256,0,st_>>>(B,n+1000000,2); CK(hipStreamSynchronize(st_));
+  for(int rep=0; rep<2; ++rep){
+    for(size_t off: {(size_t)0,(size_t)256,(size_t)1024,(size_t)4096,(size_t)16384,(size_t)65536,(size_t)262144,(size_t)1048576,(size_t)(1048576+4096+256)}) run_off<2,true,true,256>(off, 2*off);
+  }
+  return 0; }
+  if(argc>1){
+  size_t n=100000000; nvec=n/4; CK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  CK(hipMalloc(&A,n*4)); CK(hipMalloc(&B,n*4)); CK(hipMalloc(&O,n*4)); CK(hipMalloc(&S,4));
+  k_rand<<<2048,256,0,st_>>>(A,n,1); k_rand<<<2048,256,0,st_>>>(B,n,2); CK(hipStreamSynchronize(st_));
+  for(int rep=0; rep<3; ++rep){
+    run_cfg<4,true,true,0,64>(0,0); run_cfg<4,true,true,0,256>(0,0); run_cfg<1,true,true,0,256>(1,0); run_cfg<4,true,true,0,128>(0,0);
+    run_cfg<8,true,true,0,64>(0,0); run_cfg<2,true,true,0,64>(0,0); run_cfg<2,true,true,0,128>(0,0); run_cfg<2,true,true,0,256>(0,0); run_cfg<1,true,true,0,64>(0,0);
+    run_cfg<4,true,true,0,1024>(0,0); run_cfg<1,true,true,0,1024>(0,0); run_cfg<4,true,true,1,256>(0,0); run_cfg<4,true,true,2,256>(0,0);
+  }
+  return 0; }
   size_t n=100000000; nvec=n/4; CK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   CK(hipMalloc(&A,n*4)); CK(hipMalloc(&B,n*4)); CK(hipMalloc(&O,n*4)); CK(hipMalloc(&S,4));
   CK(hipMemsetAsync(A,0x3f,n*4,st_)); CK(hipMemsetAsync(B,0x3e,n*4,st_)); CK(hipMemsetAsync(O,0,n*4,st_));
