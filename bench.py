@@ -50,19 +50,25 @@ def log(*a):
 
 
 class Dist:
-    """torch.distributed plumbing (only imported when N > 1)."""
+    """torch.distributed plumbing (only imported when N > 1, or when NP_BENCH_FORCE_DIST=1 asks for
+    the same code path on one GPU: world size 1, RCCL initialised, kernels on torch's stream)."""
 
     def __init__(self, n):
         self.n = n
         self.rank = 0
+        self.local_rank = 0
         self.torch = None
-        if n > 1:
+        self.use_torch = n > 1 or os.environ.get("NP_BENCH_FORCE_DIST") == "1"
+        if self.use_torch:
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
             self.rank = int(os.environ.get("RANK", "0"))
             self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", str(n))
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(self.local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
@@ -74,20 +80,20 @@ class Dist:
             D.init(0)
 
     def barrier_sync(self):
-        if self.n > 1:
+        if self.use_torch:
             self.dist.barrier()
             self.torch.cuda.synchronize()
         D.sync()
 
     def max_over_ranks(self, x: float) -> float:
-        if self.n == 1:
+        if not self.use_torch:
             return x
         t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def close(self):
-        if self.n > 1:
+        if self.use_torch:
             self.dist.destroy_process_group()
 
 
@@ -320,7 +326,7 @@ def main():
         result["parity"]["gpu_vs_cpu_reference_max_norm_err"] = mm["gpu_vs_cpu_max_norm_err"]
     extras = {}
     if not args.no_extras:
-        if args.gpus == 1:
+        if not dist.use_torch:
             try:
                 extras = bench_extras(dist, max(10, args.steps // 2), args.warmup)
                 add = extras["add_1e8"]

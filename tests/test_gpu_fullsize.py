@@ -28,15 +28,15 @@ def test_add_1e8_bit_exact_and_linear(hip):
     b = synth.uniform((N8,), 6, 0.0, 1.0)
     da, db = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b)
     out = D.binary("add", da, "full", db, "full", 1, N8)
-    got = out.to_host()
+    got = out.to_host().reshape(-1)
     assert (_u32(got) == _u32(a + b)).all()          # numpy fp32 add is IEEE, like _mm256_add_ps
     # (a + b) - b == a wherever the addition was exact; checked through the kernel itself
-    back = D.binary("subtract", out, "full", db, "full", 1, N8).to_host()
+    back = D.binary("subtract", out, "full", db, "full", 1, N8).to_host().reshape(-1)
     exact = (got.astype(np.float64) == a.astype(np.float64) + b.astype(np.float64))
     assert (back[exact] == a[exact]).all()
     # scalar and tail handling at a size that is not a multiple of 4
     n = N8 - 3
-    v = D.binary("multiply", da.view(0, (n,)), "full", D.DeviceArray.from_host(np.float32([2.0])), "scalar", 1, n).to_host()
+    v = D.binary("multiply", da.view(0, (n,)), "full", D.DeviceArray.from_host(np.float32([2.0])), "scalar", 1, n).to_host().reshape(-1)
     assert (_u32(v) == _u32(a[:n] * np.float32(2.0))).all()
     for d in (da, db, out):
         d.free()
