@@ -13,6 +13,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_libraries():
+    """The .so files are git-ignored build artefacts; (re)build whatever is missing or stale
+    (hipcc cross-compiles for gfx950 without a GPU)."""
+    from numpower_amd import build
+    build.build_all()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU restatement of the reference (oracle/np_oracle.c), built on demand."""
