@@ -190,6 +190,11 @@ def bench_extras(dist: Dist, steps, warmup):
                          "sample": "%d x full 1e8-element NDArray_Add_Float restatement (AVX2, 1 thread)" % it}
     ex["add_1e8"] = r
     del ref, got
+    # comparison elementwise (same kernel template, 12 B/elem)
+    r = hbm_case("greater 1e8 fp32 (logic.c, §8f)", 12.0 * N,
+                 lambda: D.binary("greater", da, "full", db, "full", 1, N, out=do), steps, warmup, dist)
+    r["parity_ok"] = bool((do.to_host().reshape(-1) == (a > b).astype(np.float32)).all())
+    ex["greater_1e8"] = r
 
     for op, seed, lo, hi in (("exp", 7, -10.0, 10.0), ("log", 8, 1e-3, 1e3)):
         x = synth.uniform((N,), seed, lo, hi)

@@ -102,6 +102,13 @@ int np_read_float(const float *dev_ptr, size_t index, float *host_out);
 typedef enum np_binary_op {
     NP_ADD = 0, NP_SUBTRACT = 1, NP_MULTIPLY = 2, NP_DIVIDE = 3, NP_MOD = 4, NP_POW = 5,
     NP_ARCTAN2 = 6,
+    /* comparison ops of src/logic.c:67-670: 1.0f where true, 0.0f elsewhere.
+     * Ordered compares (NaN -> 0).  EQUAL / NOT_EQUAL: the reference's AVX2 body compares exactly
+     * (_CMP_EQ_OQ / _CMP_NEQ_OQ, logic.c:541,642), its scalar tail and its CUDA kernels use
+     * |a-b| <= 1e-7 (logic.c:552,655, cuda_math.cu:243); NP_QUIRK_AVX_BODY selects the CPU
+     * body/tail split, flags = 0 the tolerance form everywhere. */
+    NP_EQUAL = 7, NP_NOT_EQUAL = 8, NP_GREATER = 9, NP_GREATER_EQUAL = 10, NP_LESS = 11,
+    NP_LESS_EQUAL = 12,
     NP_BINARY_OP_COUNT
 } np_binary_op;
 
@@ -172,6 +179,14 @@ typedef enum np_reduce_op {
 int np_reduce_all(int op, const float *in, size_t n, float *host_out);
 /* Same, result left on the device (1 float). */
 int np_reduce_all_dev(int op, const float *in, size_t n, float *dev_out);
+
+/* NDArray_All (logic.c:25-58): *host_out = 1 if every element is non-zero, else 0.
+ * flags = NP_QUIRK_AVX_BODY reproduces what the reference's CPU code actually computes: its AVX2
+ * body tests `movemask != 0x0F` on an 8-lane mask (logic.c:36-39), i.e. a full 8-element block
+ * passes only if elements 0-3 are non-zero (and not NaN) and elements 4-7 ARE zero or NaN; the
+ * scalar tail (`== 0.0`) is the only part that means "all non-zero".  flags = 0 gives the
+ * intended meaning for every element. */
+int np_all(const float *in, size_t n, unsigned flags, int *host_out);
 
 /* Reduce the middle axis of a contiguous array viewed as outer x axis_len x inner; out has
  * outer*inner elements.  Replaces the host-side recursion reduce()/_reduce()/apply_reduce()

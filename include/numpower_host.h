@@ -108,6 +108,15 @@ NDArray *NDArray_Mod_Float(NDArray *a, NDArray *b);
 NDArray *NDArray_Pow_Float(NDArray *a, NDArray *b);
 int NDArray_IsBroadcastable(const NDArray *array1, const NDArray *array2);   /* ndarray.c:1124-1162 */
 
+/* ---- comparisons (src/logic.c:25-670): 1.0f / 0.0f masks ---- */
+NDArray *NDArray_Equal(NDArray *nda, NDArray *ndb);
+NDArray *NDArray_NotEqual(NDArray *nda, NDArray *ndb);
+NDArray *NDArray_Greater(NDArray *nda, NDArray *ndb);
+NDArray *NDArray_GreaterEqual(NDArray *nda, NDArray *ndb);
+NDArray *NDArray_Less(NDArray *nda, NDArray *ndb);
+NDArray *NDArray_LessEqual(NDArray *nda, NDArray *ndb);
+float NDArray_All(NDArray *a);   /* 1 / 0, reproduces the reference's CPU result (logic.c:25-58) */
+
 /* ---- unary elementwise (cuda_math.cu:1532-1558; op = np_unary_op of np_hip.h) ---- */
 NDArray *NDArrayMathGPU_ElementWise(NDArray *ndarray, int op);
 NDArray *NDArrayMathGPU_ElementWise1F(NDArray *ndarray, int op, float val1);

@@ -14,7 +14,8 @@ LIBDIR = Path(__file__).resolve().parent / "lib"
 # enums of include/np_hip.h -----------------------------------------------------------------
 NP_OK = 0
 BINARY_OPS = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "mod": 4, "pow": 5,
-              "arctan2": 6}
+              "arctan2": 6, "equal": 7, "not_equal": 8, "greater": 9, "greater_equal": 10,
+              "less": 11, "less_equal": 12}
 NP_FULL, NP_SCALAR, NP_ROW, NP_COL = 0, 1, 2, 3
 NP_QUIRK_AVX_BODY = 1
 UNARY_OPS = {name: i for i, name in enumerate([
@@ -60,6 +61,7 @@ PROTOTYPES = {
     "np_unary": (C.c_int, [C.c_int, _f32p, _f32p, C.c_size_t, C.c_float, C.c_float]),
     "np_reduce_all": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.POINTER(C.c_float)]),
     "np_reduce_all_dev": (C.c_int, [C.c_int, _f32p, C.c_size_t, _f32p]),
+    "np_all": (C.c_int, [_f32p, C.c_size_t, C.c_uint, C.POINTER(C.c_int)]),
     "np_reduce_axis": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p,
                                  C.c_uint]),
     "np_reduce_axis_workspace": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_size_t]),

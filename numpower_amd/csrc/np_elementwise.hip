@@ -55,6 +55,21 @@ __device__ __forceinline__ float binary_apply(float a, float b, bool body) {
     }
     if constexpr (OP == NP_POW) return powf(a, b);
     if constexpr (OP == NP_ARCTAN2) return atan2f(a, b);
+    // comparisons (src/logic.c:67-670): ordered, 1.0f / 0.0f
+    if constexpr (OP == NP_GREATER) return (a > b) ? 1.0f : 0.0f;
+    if constexpr (OP == NP_GREATER_EQUAL) return (a >= b) ? 1.0f : 0.0f;
+    if constexpr (OP == NP_LESS) return (a < b) ? 1.0f : 0.0f;
+    if constexpr (OP == NP_LESS_EQUAL) return (a <= b) ? 1.0f : 0.0f;
+    if constexpr (OP == NP_EQUAL) {
+        // AVX2 body: _CMP_EQ_OQ (logic.c:541); tail and CUDA kernel: |a-b| <= 1e-7 (logic.c:552)
+        if (QUIRK && body) return (a == b) ? 1.0f : 0.0f;
+        return (fabsf(a - b) <= 0.0000001f) ? 1.0f : 0.0f;
+    }
+    if constexpr (OP == NP_NOT_EQUAL) {
+        // AVX2 body: _CMP_NEQ_OQ, ordered: NaN -> 0 (logic.c:642); tail: !(|a-b| <= 1e-7) (logic.c:655)
+        if (QUIRK && body) return (a < b || a > b) ? 1.0f : 0.0f;
+        return (fabsf(a - b) <= 0.0000001f) ? 0.0f : 1.0f;
+    }
     return 0.0f;
 }
 
@@ -421,7 +436,7 @@ int dispatch_binary_index(const float *a, int ak, const float *b, int bk, float 
 template <int OP>
 int dispatch_binary_quirk(const float *a, int ak, const float *b, int bk, float *out, size_t rows,
                           size_t cols, unsigned flags, size_t body_end, float ha, float hb) {
-    constexpr bool has_quirk = (OP == NP_MULTIPLY || OP == NP_MOD);
+    constexpr bool has_quirk = (OP == NP_MULTIPLY || OP == NP_MOD || OP == NP_EQUAL || OP == NP_NOT_EQUAL);
     if constexpr (has_quirk) {
         if (flags & NP_QUIRK_AVX_BODY)
             return dispatch_binary_index<OP, true>(a, ak, b, bk, out, rows, cols, body_end, ha, hb);
@@ -510,6 +525,12 @@ int np_binary(int op, const float *a, int a_kind, const float *b, int b_kind, fl
         case NP_DIVIDE: return dispatch_binary_quirk<NP_DIVIDE>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         case NP_MOD: return dispatch_binary_quirk<NP_MOD>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         case NP_POW: return dispatch_binary_quirk<NP_POW>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_EQUAL: return dispatch_binary_quirk<NP_EQUAL>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_NOT_EQUAL: return dispatch_binary_quirk<NP_NOT_EQUAL>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_GREATER: return dispatch_binary_quirk<NP_GREATER>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_GREATER_EQUAL: return dispatch_binary_quirk<NP_GREATER_EQUAL>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_LESS: return dispatch_binary_quirk<NP_LESS>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_LESS_EQUAL: return dispatch_binary_quirk<NP_LESS_EQUAL>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         default: return dispatch_binary_quirk<NP_ARCTAN2>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
     }
 }

@@ -127,6 +127,41 @@ __global__ __launch_bounds__(256) void reduce_all_pass2(const float *__restrict_
     }
 }
 
+// NDArray_All (logic.c:25-58) as a min-reduction over a per-element verdict (1 = passes).
+// QUIRK: index < body_end follows the reference's AVX2 body, which tests `movemask != 0x0F` on an
+// 8-lane mask: lanes 0-3 of every 8-block must be non-zero and non-NaN (_CMP_NEQ_OQ true) and
+// lanes 4-7 must NOT be (zero or NaN); the rest follows the scalar tail (x == 0.0 fails).
+template <bool QUIRK, typename I>
+__device__ __forceinline__ float all_verdict(float x, I index, I body_end) {
+    if (QUIRK && index < body_end) {
+        const bool neq_oq = (x < 0.0f) || (x > 0.0f);
+        return (((index & 7) < 4) == neq_oq) ? 1.0f : 0.0f;
+    }
+    return (x == 0.0f) ? 0.0f : 1.0f;
+}
+
+template <bool QUIRK, typename I>
+__global__ __launch_bounds__(256) void all_pass1(const float *__restrict__ in,
+                                                 float *__restrict__ partials, I n, I head, I nvec,
+                                                 I body_end) {
+    __shared__ float lds4[4];
+    const I stride = (I)gridDim.x * blockDim.x;
+    float r = 1.0f;
+    const float *base = in + head;
+    for (I v = (I)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+        const v4f x = __builtin_nontemporal_load((const v4f *)(base + (size_t)v * 4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r = fminf(r, all_verdict<QUIRK, I>(x[k], head + v * 4 + k, body_end));
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) r = fminf(r, all_verdict<QUIRK, I>(in[threadIdx.x], (I)threadIdx.x, body_end));
+        const I t = head + nvec * 4 + threadIdx.x;
+        if (t < n) r = fminf(r, all_verdict<QUIRK, I>(in[t], t, body_end));
+    }
+    r = block_reduce<NP_MIN>(r, lds4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
 // ------------------------------------------------------------------------------------------
 // axis reduction, inner >= 4 and inner % 4 == 0: "column" reduce
 // ------------------------------------------------------------------------------------------
@@ -456,6 +491,40 @@ int np_reduce_all(int op, const float *in, size_t n, float *host_out) {
     if (int rc = out.alloc(sizeof(float))) return rc;
     if (int rc = np_reduce_all_dev(op, in, n, (float *)out.ptr)) return rc;
     return np_memcpy_d2h(host_out, out.ptr, sizeof(float));
+}
+
+int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
+    if (!host_out) return np::fail(NP_ERR_INVALID, "np_all: null output");
+    *host_out = 1;
+    if (n == 0) return NP_OK;
+    if (!in) return np::fail(NP_ERR_INVALID, "np_all: null input");
+    if (n >= (size_t(1) << 31)) return np::fail(NP_ERR_INVALID, "np_all: array too large");
+    if (int rc = np::ensure_init()) return rc;
+    hipStream_t s = np::stream();
+    size_t head = ((16 - ((uintptr_t)in & 15u)) & 15u) / 4;
+    if (head > n) head = n;
+    const size_t nvec = (n - head) / 4;
+    size_t blocks = (nvec + 255) / 256;
+    const size_t cap = (size_t)np::num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    np::Scratch partials, out;
+    if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
+    if (int rc = out.alloc(sizeof(float))) return rc;
+    const uint32_t body_end = (uint32_t)np_avx_body_end(n);
+    if (flags & NP_QUIRK_AVX_BODY)
+        all_pass1<true, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n,
+                                                                   (uint32_t)head, (uint32_t)nvec, body_end);
+    else
+        all_pass1<false, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n,
+                                                                    (uint32_t)head, (uint32_t)nvec, 0u);
+    NP_LAUNCH_CHECK("all_pass1");
+    reduce_all_pass2<NP_MIN><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, (float *)out.ptr, 1.0f);
+    NP_LAUNCH_CHECK("reduce_all_pass2");
+    float v = 0.0f;
+    if (int rc = np_memcpy_d2h(&v, out.ptr, sizeof(float))) return rc;
+    *host_out = (v != 0.0f) ? 1 : 0;
+    return NP_OK;
 }
 
 size_t np_reduce_axis_workspace(size_t outer, size_t axis_len, size_t inner) {

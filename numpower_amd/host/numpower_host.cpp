@@ -153,12 +153,16 @@ int broadcast_kind(const NDArray *small, const NDArray *large, size_t *rows, siz
 
 typedef NDArray *(*binary_fn)(NDArray *, NDArray *);
 
-// Shared body of NDArray_{Add,Subtract,Multiply,Divide,Mod,Pow}_Float (arithmetics.c:160-926).
+// Shared body of NDArray_{Add,Subtract,Multiply,Divide,Mod,Pow}_Float (arithmetics.c:160-926)
+// and of the comparison family NDArray_{Equal,NotEqual,Greater,GreaterEqual,Less,LessEqual}
+// (logic.c:67-670), which repeats the same scalar-expand + broadcast skeleton.
 NDArray *binary_op(int op, NDArray *a, NDArray *b) {
     if (!a || !b) return nullptr;
-    // arithmetics.c:163-166 — 0-d operands are exempt from the device check
+    const bool compare = op >= NP_EQUAL && op <= NP_LESS_EQUAL;
+    // arithmetics.c:163-166 / logic.c:70-73 — 0-d operands are exempt from the device check
     if (NDArray_DEVICE(a) != NDArray_DEVICE(b) && NDArray_NDIM(a) != 0 && NDArray_NDIM(b) != 0) {
-        throw_error("Device mismatch, both NDArray MUST be in the same device.");
+        throw_error(compare ? "Devices mismatch in `equal` function"
+                            : "Device mismatch, both NDArray MUST be in the same device.");
         return nullptr;
     }
     const bool a_scalar = NDArray_NDIM(a) == 0, b_scalar = NDArray_NDIM(b) == 0;
@@ -215,8 +219,12 @@ NDArray *binary_op(int op, NDArray *a, NDArray *b) {
     NDArray *result = new_array(shape_of->dimensions, shape_of->ndim, NDARRAY_DEVICE_GPU, false);
     if (!result) return nullptr;
     // 0-d x 0-d multiply/divide take the plain short cut (arithmetics.c:302-316,575-580)
-    const bool quirk_ops = (op == NP_MULTIPLY || op == NP_MOD) && !(a_scalar && b_scalar);
+    const bool quirk_ops = ((op == NP_MULTIPLY || op == NP_MOD) && !(a_scalar && b_scalar)) ||
+                           op == NP_EQUAL || op == NP_NOT_EQUAL;
     const unsigned flags = quirk_ops ? NP_QUIRK_AVX_BODY : 0u;
+    // AVX-body bound: NotEqual loops over the broadcast operand (logic.c:636), everything else over
+    // the first operand before the broadcast (arithmetics.c:251, logic.c:535)
+    if (op == NP_NOT_EQUAL) loop_numel_a = rows * cols;
     const size_t body_end = quirk_ops ? np_avx_body_end(loop_numel_a) : 0;
     if (!dev_ok(np_binary(op, NDArray_FDATA(a), ak, NDArray_FDATA(b), bk, NDArray_FDATA(result), rows,
                           cols, flags, body_end))) {
@@ -434,6 +442,21 @@ NDArray *NDArray_Multiply_Float(NDArray *a, NDArray *b) { return binary_op(NP_MU
 NDArray *NDArray_Divide_Float(NDArray *a, NDArray *b) { return binary_op(NP_DIVIDE, a, b); }
 NDArray *NDArray_Mod_Float(NDArray *a, NDArray *b) { return binary_op(NP_MOD, a, b); }
 NDArray *NDArray_Pow_Float(NDArray *a, NDArray *b) { return binary_op(NP_POW, a, b); }
+
+/* ---- comparisons (logic.c:67-670) ---- */
+NDArray *NDArray_Equal(NDArray *nda, NDArray *ndb) { return binary_op(NP_EQUAL, nda, ndb); }
+NDArray *NDArray_NotEqual(NDArray *nda, NDArray *ndb) { return binary_op(NP_NOT_EQUAL, nda, ndb); }
+NDArray *NDArray_Greater(NDArray *nda, NDArray *ndb) { return binary_op(NP_GREATER, nda, ndb); }
+NDArray *NDArray_GreaterEqual(NDArray *nda, NDArray *ndb) { return binary_op(NP_GREATER_EQUAL, nda, ndb); }
+NDArray *NDArray_Less(NDArray *nda, NDArray *ndb) { return binary_op(NP_LESS, nda, ndb); }
+NDArray *NDArray_LessEqual(NDArray *nda, NDArray *ndb) { return binary_op(NP_LESS_EQUAL, nda, ndb); }
+
+float NDArray_All(NDArray *a) {   // logic.c:25-58
+    if (!a || !require_gpu(a, "all")) return -1.0f;
+    int v = 0;
+    if (!dev_ok(np_all(NDArray_FDATA(a), (size_t)NDArray_NUMELEMENTS(a), NP_QUIRK_AVX_BODY, &v))) return -1.0f;
+    return (float)v;
+}
 
 int NDArray_IsBroadcastable(const NDArray *array1, const NDArray *array2) {   // ndarray.c:1124-1162
     const int n1 = array1->ndim, n2 = array2->ndim;

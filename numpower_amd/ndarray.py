@@ -100,6 +100,9 @@ def _load_host():
     }
     for name in ("Add", "Subtract", "Multiply", "Divide", "Mod", "Pow"):
         sig[f"NDArray_{name}_Float"] = (_P, [_P, _P])
+    for name in ("Equal", "NotEqual", "Greater", "GreaterEqual", "Less", "LessEqual"):
+        sig[f"NDArray_{name}"] = (_P, [_P, _P])
+    sig["NDArray_All"] = (C.c_float, [_P])
     for name, (res, args) in sig.items():
         fn = getattr(h, name)
         fn.restype = res
@@ -121,7 +124,11 @@ def _raise_pending(h, what="call"):
 
 _BINARY_FN = {"add": "NDArray_Add_Float", "subtract": "NDArray_Subtract_Float",
               "multiply": "NDArray_Multiply_Float", "divide": "NDArray_Divide_Float",
-              "mod": "NDArray_Mod_Float", "pow": "NDArray_Pow_Float"}
+              "mod": "NDArray_Mod_Float", "pow": "NDArray_Pow_Float",
+              # comparison family (src/logic.c), PHP methods equal / not_equal / greater / ...
+              "equal": "NDArray_Equal", "not_equal": "NDArray_NotEqual", "greater": "NDArray_Greater",
+              "greater_equal": "NDArray_GreaterEqual", "less": "NDArray_Less",
+              "less_equal": "NDArray_LessEqual"}
 
 # PHP method name -> np_unary_op for the plain NDArrayMathGPU_ElementWise family
 # (method table numpower.c:5136-5174)
@@ -251,6 +258,23 @@ class NDArray:
     divide = staticmethod(lambda a, b: NDArray._binary("divide", a, b))
     mod = staticmethod(lambda a, b: NDArray._binary("mod", a, b))
     pow = staticmethod(lambda a, b: NDArray._binary("pow", a, b))
+    equal = staticmethod(lambda a, b: NDArray._binary("equal", a, b))
+    not_equal = staticmethod(lambda a, b: NDArray._binary("not_equal", a, b))
+    greater = staticmethod(lambda a, b: NDArray._binary("greater", a, b))
+    greater_equal = staticmethod(lambda a, b: NDArray._binary("greater_equal", a, b))
+    less = staticmethod(lambda a, b: NDArray._binary("less", a, b))
+    less_equal = staticmethod(lambda a, b: NDArray._binary("less_equal", a, b))
+
+    @staticmethod
+    def all(a) -> int:
+        """PHP_METHOD(NDArray, all) without axis: RETURN_LONG(NDArray_All(nda)) (numpower.c:1330)."""
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        h.numpower_host_clear_error()
+        v = h.NDArray_All(x._p)
+        if h.numpower_host_last_error():
+            _raise_pending(h)
+        return int(v)
 
     def __add__(self, o): return NDArray._binary("add", self, o)
     def __radd__(self, o): return NDArray._binary("add", o, self)

@@ -12,6 +12,7 @@
  *   full reductions    src/ndmath/arithmetics.c:36-102, src/ndarray.c:752-772,939-959
  *   axis reductions    src/ndarray.c:358-368,394-429,523-578 (+ mean: numpower.c:2660-2670)
  *   matmul / dot       src/ndmath/linalg.c:44-82,216-245,354-393 (cblas_sgemm / cblas_sgemv)
+ *   comparisons, all   src/logic.c:25-670
  *
  * Parity pinning.  The reference itself cannot be compiled in this image: every file on the path
  * includes <php.h> / <Zend/zend_types.h> (e.g. arithmetics.c:1-3, ndarray.h:9) and PHP's headers
@@ -42,7 +43,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { O_ADD = 0, O_SUBTRACT, O_MULTIPLY, O_DIVIDE, O_MOD, O_POW, O_ARCTAN2 };
+enum { O_ADD = 0, O_SUBTRACT, O_MULTIPLY, O_DIVIDE, O_MOD, O_POW, O_ARCTAN2,
+       /* comparisons, src/logic.c:67-670 */
+       O_EQUAL, O_NOT_EQUAL, O_GREATER, O_GREATER_EQUAL, O_LESS, O_LESS_EQUAL };
 
 enum {
     U_ABS = 0, U_SQRT, U_EXP, U_EXP2, U_EXPM1, U_LOG, U_LOG2, U_LOG10, U_LOG1P, U_LOGB,
@@ -255,11 +258,19 @@ static void binary_loop(int op, const float *a, const float *b, float *r, long n
             __m256 v1 = _mm256_loadu_ps(&a[i]);
             __m256 v2 = _mm256_loadu_ps(&b[i]);
             __m256 o;
+            const __m256 ones = _mm256_set1_ps(1.0f);
             switch (op) {
                 case O_ADD: o = _mm256_add_ps(v1, v2); break;
                 case O_SUBTRACT: o = _mm256_sub_ps(v1, v2); break;
                 case O_MULTIPLY: o = fix_negative_zero(_mm256_mul_ps(v1, v2)); break;
                 case O_DIVIDE: o = _mm256_div_ps(v1, v2); break;
+                /* comparisons: mask AND 1.0f / blend(0, 1, mask) (logic.c:134-138, 234-237, 339, 440, 541, 642) */
+                case O_EQUAL: o = _mm256_and_ps(_mm256_cmp_ps(v1, v2, _CMP_EQ_OQ), ones); break;
+                case O_NOT_EQUAL: o = _mm256_and_ps(_mm256_cmp_ps(v1, v2, _CMP_NEQ_OQ), ones); break;
+                case O_GREATER: o = _mm256_and_ps(_mm256_cmp_ps(v1, v2, _CMP_GT_OQ), ones); break;
+                case O_GREATER_EQUAL: o = _mm256_and_ps(_mm256_cmp_ps(v1, v2, _CMP_GE_OS), ones); break;
+                case O_LESS: o = _mm256_and_ps(_mm256_cmp_ps(v1, v2, _CMP_LT_OQ), ones); break;
+                case O_LESS_EQUAL: o = _mm256_and_ps(_mm256_cmp_ps(v1, v2, _CMP_LE_OQ), ones); break;
                 default:   /* O_MOD, arithmetics.c:794 */
                     o = _mm256_sub_ps(v1, _mm256_mul_ps(_mm256_floor_ps(_mm256_div_ps(v1, v2)), v2));
                     break;
@@ -278,6 +289,13 @@ static void binary_loop(int op, const float *a, const float *b, float *r, long n
             case O_DIVIDE: r[i] = a[i] / b[i]; break;
             case O_MOD: r[i] = fmodf(a[i], b[i]); break;
             case O_POW: r[i] = powf(a[i], b[i]); break;
+            /* scalar tails of the comparisons: logic.c:146, 245, 350, 451, 552, 655 */
+            case O_EQUAL: r[i] = (fabsf(a[i] - b[i]) <= 0.0000001f) ? 1.0f : 0.0f; break;
+            case O_NOT_EQUAL: r[i] = (fabsf(a[i] - b[i]) <= 0.0000001f) ? 0.0f : 1.0f; break;
+            case O_GREATER: r[i] = a[i] > b[i] ? 1.0f : 0.0f; break;
+            case O_GREATER_EQUAL: r[i] = a[i] >= b[i] ? 1.0f : 0.0f; break;
+            case O_LESS: r[i] = a[i] < b[i] ? 1.0f : 0.0f; break;
+            case O_LESS_EQUAL: r[i] = a[i] <= b[i] ? 1.0f : 0.0f; break;
             default: r[i] = atan2f(a[i], b[i]); break;   /* float_arctan2 via Map1ND, ndarray.c:716 */
         }
     }
@@ -337,8 +355,14 @@ int oracle_binary(int op, const float *a, const int *as, int an, const float *b,
     long n = numel(rs, rn);
     float *r = (float *) malloc(sizeof(float) * (n > 0 ? n : 1));
     /* loop bound of the AVX body is NDArray_NUMELEMENTS(a) with `a` = the (possibly scalar-
-     * expanded, NOT broadcast) first operand (:251) */
-    binary_loop(op, a_broad, b_broad, r, n, na);
+     * expanded, NOT broadcast) first operand (:251; same in Less/Equal, logic.c:228,535);
+     * Greater/LessEqual/GreaterEqual/NotEqual loop over the broadcast operand (logic.c:128,333,434,636).
+     * NOTE Less/Equal also INDEX the un-broadcast operands (logic.c:230-231,537-538), which reads
+     * past the smaller buffer when one operand was broadcast: undefined in the reference; the
+     * restatement uses the broadcast data there. */
+    long bound = na;
+    if (op == O_GREATER || op == O_LESS_EQUAL || op == O_GREATER_EQUAL || op == O_NOT_EQUAL) bound = n;
+    binary_loop(op, a_broad, b_broad, r, n, bound);
     for (int i = 0; i < rn; i++) out_shape[i] = rs[i];
     *out_ndim = rn;
     *out = r;
@@ -374,6 +398,21 @@ float oracle_max(const float *a, long n) {      /* NDArray_Max, ndarray.c:939-95
         if (a[i] > m) m = a[i];
     return m;
 }
+/* NDArray_All (logic.c:25-58), including the body's `mask != 0x0F` test on an 8-lane mask */
+float oracle_all(const float *array, long n) {
+    long i;
+    __m256 zero = _mm256_set1_ps(0.0f);
+    for (i = 0; i < n - 7; i += 8) {
+        __m256 elements = _mm256_loadu_ps(&array[i]);
+        __m256 comparison = _mm256_cmp_ps(elements, zero, _CMP_NEQ_OQ);
+        int mask = _mm256_movemask_ps(comparison);
+        if (mask != 0x0F) return 0;
+    }
+    for (; i < n; i++)
+        if (array[i] == 0.0) return 0;
+    return 1;
+}
+
 /* NDArray::mean without axis: NDArray_Sum_Float(nda) / NDArray_NUMELEMENTS(nda) (numpower.c:2659) */
 float oracle_mean(const float *a, long n) { return oracle_sum(a, n) / n; }
 

@@ -18,7 +18,8 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 LIB = HERE / "lib" / "libnp_oracle.so"
 
-BINARY = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "mod": 4, "pow": 5, "arctan2": 6}
+BINARY = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "mod": 4, "pow": 5, "arctan2": 6,
+          "equal": 7, "not_equal": 8, "greater": 9, "greater_equal": 10, "less": 11, "less_equal": 12}
 UNARY = {name: i for i, name in enumerate([
     "abs", "sqrt", "exp", "exp2", "expm1", "log", "log2", "log10", "log1p", "logb",
     "sin", "cos", "tan", "arcsin", "arccos", "arctan", "degrees", "radians",
@@ -58,7 +59,7 @@ def load():
     lib.oracle_binary.argtypes = [C.c_int, _fp, _ip, C.c_int, _fp, _ip, C.c_int,
                                   C.POINTER(_fp), _ip, _ip]
     lib.oracle_free.argtypes = [C.c_void_p]
-    for name in ("oracle_sum", "oracle_prod", "oracle_min", "oracle_max", "oracle_mean"):
+    for name in ("oracle_sum", "oracle_prod", "oracle_min", "oracle_max", "oracle_mean", "oracle_all"):
         fn = getattr(lib, name)
         fn.restype = C.c_float
         fn.argtypes = [_fp, C.c_long]

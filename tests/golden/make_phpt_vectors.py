@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn the reference's hot-path known-answer tests into a data fixture.
 
-Reads  /root/reference/tests/math/002..044-*.phpt and tests/linalg/001-ndarray-matmul.phpt
+Reads  /root/reference/tests/math/002..044-*.phpt, tests/linalg/001-ndarray-matmul.phpt and
+tests/logic/001,003..008-*.phpt
 (only available in the build container) and writes tests/golden/phpt_vectors.json with, per file:
 the input arrays, the sequence of calls (operator / static method, operands, keyword arguments)
 and the expected print_r text of the --EXPECT-- section.  The PHP script text itself is NOT
@@ -20,6 +21,8 @@ REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
 OUT = Path(__file__).resolve().parent / "phpt_vectors.json"
 
 FILES = sorted((REF / "tests" / "math").glob("*.phpt")) + [REF / "tests" / "linalg" / "001-ndarray-matmul.phpt"]
+# SURVEY.md §8f row 1 (comparison / logic elementwise); 002-ndarray-allclose is CPU-only in the reference
+FILES += [f for f in sorted((REF / "tests" / "logic").glob("*.phpt")) if "allclose" not in f.name]
 
 ASSIGN = re.compile(r"^\$(\w+) = \\NDArray::array\((.*)\);$")
 PRINT = re.compile(r"^print_r\((.*)\);$")

@@ -26,6 +26,7 @@ VECTORS = Path(__file__).resolve().parent / "golden" / "phpt_vectors.json"
 
 OPERATORS = {"+": "add", "-": "subtract", "*": "multiply", "/": "divide", "**": "pow", "%": "mod"}
 REDUCTIONS = {"sum", "prod", "min", "max", "mean"}
+COMPARISONS = {"equal", "not_equal", "greater", "greater_equal", "less", "less_equal"}
 
 
 def load_vectors():
@@ -97,6 +98,10 @@ def replay(backend, test) -> str:
                 res = backend.reduce(op, args[0], kw.get("axis"))
             elif op == "matmul":
                 res = backend.matmul(args[0], args[1])
+            elif op in COMPARISONS:
+                res = backend.binary(op, args[0], args[1])
+            elif op == "all":
+                res = backend.all(args[0])
             elif op == "square":     # PHP_METHOD(NDArray, square): Multiply_Float(nda, nda), numpower.c:3093
                 res = backend.binary("multiply", args[0], args[0])
             elif op == "clip":
@@ -146,6 +151,9 @@ class GpuBackend:
     def matmul(self, x, y):
         return self.nd.matmul(x, y)
 
+    def all(self, x):
+        return self.nd.all(x)
+
     def to_list(self, h):
         return h.cpu().toArray()
 
@@ -183,6 +191,9 @@ class OracleBackend:
 
     def matmul(self, x, y):
         return self._ret(self.o.matmul(x, y))
+
+    def all(self, x):
+        return float(self.o.reduce_all("all", x))
 
     def to_list(self, h):
         return np.asarray(h, dtype=np.float64).tolist()
