@@ -180,6 +180,15 @@ int np_reduce_all(int op, const float *in, size_t n, float *host_out);
 /* Same, result left on the device (1 float). */
 int np_reduce_all_dev(int op, const float *in, size_t n, float *dev_out);
 
+/* Statistics (src/ndmath/statistics.c:88-154).  The reference composes these
+ * from Sum / Subtract / Abs / Pow with a full-size temporary per step (32 B/elem for variance);
+ * here: mean, then ONE fused pass over (x - mean)^2 (8 B/elem in total).
+ *   variance = m2 / n (NDArray_Variance), std = sqrtf(m2 / n) (NDArray_Std). */
+int np_moments(const float *in, size_t n, float *host_mean, float *host_m2);
+/* NDArray_Average with weights (statistics.c:131-154): sum(a*w) and sum(w), the product fused
+ * into the reduction (no a*w temporary). */
+int np_weighted_sums(const float *a, const float *w, size_t n, float *host_sum_aw, float *host_sum_w);
+
 /* NDArray_All (logic.c:25-58): *host_out = 1 if every element is non-zero, else 0.
  * flags = NP_QUIRK_AVX_BODY reproduces what the reference's CPU code actually computes: its AVX2
  * body tests `movemask != 0x0F` on an 8-lane mask (logic.c:36-39), i.e. a full 8-element block

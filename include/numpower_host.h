@@ -117,6 +117,11 @@ NDArray *NDArray_Less(NDArray *nda, NDArray *ndb);
 NDArray *NDArray_LessEqual(NDArray *nda, NDArray *ndb);
 float NDArray_All(NDArray *a);   /* 1 / 0, reproduces the reference's CPU result (logic.c:25-58) */
 
+/* ---- statistics (src/ndmath/statistics.c:88-154): 0-d CPU scalar results ---- */
+NDArray *NDArray_Variance(NDArray *a);
+NDArray *NDArray_Std(NDArray *a);
+NDArray *NDArray_Average(NDArray *a, NDArray *weights /* may be NULL */);
+
 /* ---- unary elementwise (cuda_math.cu:1532-1558; op = np_unary_op of np_hip.h) ---- */
 NDArray *NDArrayMathGPU_ElementWise(NDArray *ndarray, int op);
 NDArray *NDArrayMathGPU_ElementWise1F(NDArray *ndarray, int op, float val1);

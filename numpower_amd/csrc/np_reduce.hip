@@ -127,6 +127,79 @@ __global__ __launch_bounds__(256) void reduce_all_pass2(const float *__restrict_
     }
 }
 
+// Fused sum-reductions over a transformed input (src/ndmath/statistics.c):
+//   XFORM 1: (x - p0)^2      second pass of variance / std (p0 = mean)
+//   XFORM 2: x * y           weighted sum of NDArray_Average
+// Same streaming structure as reduce_all_pass1 (float4 nt loads, wave shuffle + LDS, one partial
+// per workgroup); requires 16-byte aligned inputs (callers fall back to XFORM via scalar head/tail).
+template <int XFORM, typename I>
+__global__ __launch_bounds__(256) void reduce_xform_pass1(const float *__restrict__ in,
+                                                          const float *__restrict__ in2,
+                                                          float *__restrict__ partials, I n, I nvec,
+                                                          float p0) {
+    __shared__ float lds4[4];
+    const I stride = (I)gridDim.x * blockDim.x;
+    const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    v4f acc0{0, 0, 0, 0}, acc1 = acc0;
+    auto xf = [&](float x, float y) -> float {
+        if constexpr (XFORM == 1) {
+            const float d = x - p0;
+            return d * d;
+        } else {
+            return x * y;
+        }
+    };
+    I v = tid;
+    for (; v + stride < nvec; v += 2 * stride) {
+        const v4f x0 = __builtin_nontemporal_load((const v4f *)(in + (size_t)v * 4));
+        const v4f x1 = __builtin_nontemporal_load((const v4f *)(in + (size_t)(v + stride) * 4));
+        v4f y0{0, 0, 0, 0}, y1 = y0;
+        if constexpr (XFORM == 2) {
+            y0 = __builtin_nontemporal_load((const v4f *)(in2 + (size_t)v * 4));
+            y1 = __builtin_nontemporal_load((const v4f *)(in2 + (size_t)(v + stride) * 4));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc0[k] += xf(x0[k], y0[k]);
+            acc1[k] += xf(x1[k], y1[k]);
+        }
+    }
+    for (; v < nvec; v += stride) {
+        const v4f x0 = *(const v4f *)(in + (size_t)v * 4);
+        v4f y0{0, 0, 0, 0};
+        if constexpr (XFORM == 2) y0 = *(const v4f *)(in2 + (size_t)v * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc0[k] += xf(x0[k], y0[k]);
+    }
+    float r = (acc0[0] + acc1[0]) + (acc0[1] + acc1[1]) + ((acc0[2] + acc1[2]) + (acc0[3] + acc1[3]));
+    if (blockIdx.x == 0) {
+        const I t = nvec * 4 + threadIdx.x;   // ragged tail (n % 4 elements)
+        if (t < n) r += xf(in[t], XFORM == 2 ? in2[t] : 0.0f);
+    }
+    r = block_reduce<NP_SUM>(r, lds4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// generic (misaligned views): one thread per element stride, scalar loads
+template <int XFORM, typename I>
+__global__ __launch_bounds__(256) void reduce_xform_scalar(const float *__restrict__ in,
+                                                           const float *__restrict__ in2,
+                                                           float *__restrict__ partials, I n, float p0) {
+    __shared__ float lds4[4];
+    const I stride = (I)gridDim.x * blockDim.x;
+    float r = 0.0f;
+    for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if constexpr (XFORM == 1) {
+            const float d = in[i] - p0;
+            r += d * d;
+        } else {
+            r += in[i] * in2[i];
+        }
+    }
+    r = block_reduce<NP_SUM>(r, lds4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
 // NDArray_All (logic.c:25-58) as a min-reduction over a per-element verdict (1 = passes).
 // QUIRK: index < body_end follows the reference's AVX2 body, which tests `movemask != 0x0F` on an
 // 8-lane mask: lanes 0-3 of every 8-block must be non-zero and non-NaN (_CMP_NEQ_OQ true) and
@@ -491,6 +564,60 @@ int np_reduce_all(int op, const float *in, size_t n, float *host_out) {
     if (int rc = out.alloc(sizeof(float))) return rc;
     if (int rc = np_reduce_all_dev(op, in, n, (float *)out.ptr)) return rc;
     return np_memcpy_d2h(host_out, out.ptr, sizeof(float));
+}
+
+}  // extern "C" (the template below cannot have C linkage)
+
+// sum over XFORM(in[, in2]) -> one device float
+template <int XFORM>
+static int xform_sum(const float *in, const float *in2, size_t n, float p0, float *dev_out) {
+    if (n >= (size_t(1) << 31)) return np::fail(NP_ERR_INVALID, "statistics: array too large");
+    hipStream_t s = np::stream();
+    const bool vec = aligned16(in) && (XFORM != 2 || aligned16(in2));
+    const size_t nvec = n / 4;
+    size_t blocks = ((vec ? nvec : n / 4) + 255) / 256;
+    const size_t cap = (size_t)np::num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    np::Scratch partials;
+    if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
+    if (vec)
+        reduce_xform_pass1<XFORM, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, in2, (float *)partials.ptr,
+                                                                         (uint32_t)n, (uint32_t)nvec, p0);
+    else
+        reduce_xform_scalar<XFORM, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, in2, (float *)partials.ptr,
+                                                                          (uint32_t)n, p0);
+    NP_LAUNCH_CHECK("reduce_xform");
+    reduce_all_pass2<NP_SUM><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, dev_out, 1.0f);
+    NP_LAUNCH_CHECK("reduce_all_pass2");
+    return NP_OK;
+}
+
+extern "C" {
+
+int np_moments(const float *in, size_t n, float *host_mean, float *host_m2) {
+    if (!host_mean || !host_m2) return np::fail(NP_ERR_INVALID, "np_moments: null output");
+    if (n == 0 || !in) return np::fail(NP_ERR_INVALID, "np_moments: empty input");
+    if (int rc = np::ensure_init()) return rc;
+    float sum = 0.0f;
+    if (int rc = np_reduce_all(NP_SUM, in, n, &sum)) return rc;
+    const float mean = sum / (float)n;   // NDArray_Sum_Float(a) / NDArray_NUMELEMENTS(a), statistics.c:95,119
+    np::Scratch out;
+    if (int rc = out.alloc(sizeof(float))) return rc;
+    if (int rc = xform_sum<1>(in, nullptr, n, mean, (float *)out.ptr)) return rc;
+    *host_mean = mean;
+    return np_memcpy_d2h(host_m2, out.ptr, sizeof(float));
+}
+
+int np_weighted_sums(const float *a, const float *w, size_t n, float *host_sum_aw, float *host_sum_w) {
+    if (!host_sum_aw || !host_sum_w) return np::fail(NP_ERR_INVALID, "np_weighted_sums: null output");
+    if (n == 0 || !a || !w) return np::fail(NP_ERR_INVALID, "np_weighted_sums: empty input");
+    if (int rc = np::ensure_init()) return rc;
+    np::Scratch out;
+    if (int rc = out.alloc(sizeof(float))) return rc;
+    if (int rc = xform_sum<2>(a, w, n, 0.0f, (float *)out.ptr)) return rc;
+    if (int rc = np_memcpy_d2h(host_sum_aw, out.ptr, sizeof(float))) return rc;
+    return np_reduce_all(NP_SUM, w, n, host_sum_w);
 }
 
 int np_all(const float *in, size_t n, unsigned flags, int *host_out) {

@@ -19,6 +19,7 @@
 //                    -> np_sgemm
 #include "numpower_host.h"
 
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -450,6 +451,41 @@ NDArray *NDArray_Greater(NDArray *nda, NDArray *ndb) { return binary_op(NP_GREAT
 NDArray *NDArray_GreaterEqual(NDArray *nda, NDArray *ndb) { return binary_op(NP_GREATER_EQUAL, nda, ndb); }
 NDArray *NDArray_Less(NDArray *nda, NDArray *ndb) { return binary_op(NP_LESS, nda, ndb); }
 NDArray *NDArray_LessEqual(NDArray *nda, NDArray *ndb) { return binary_op(NP_LESS_EQUAL, nda, ndb); }
+
+/* ---- statistics (statistics.c:88-154): 0-d CPU scalars, like NDArray_CreateFromFloatScalar ---- */
+NDArray *NDArray_Variance(NDArray *a) {   // statistics.c:117-130
+    if (!a || !require_gpu(a, "variance")) return nullptr;
+    float mean = 0.0f, m2 = 0.0f;
+    if (!dev_ok(np_moments(NDArray_FDATA(a), (size_t)NDArray_NUMELEMENTS(a), &mean, &m2))) return nullptr;
+    return NDArray_CreateFromFloatScalar(m2 / NDArray_NUMELEMENTS(a));
+}
+
+NDArray *NDArray_Std(NDArray *a) {   // statistics.c:88-108 (the reference rejects GPU arrays here)
+    if (!a || !require_gpu(a, "std")) return nullptr;
+    float mean = 0.0f, m2 = 0.0f;
+    if (!dev_ok(np_moments(NDArray_FDATA(a), (size_t)NDArray_NUMELEMENTS(a), &mean, &m2))) return nullptr;
+    return NDArray_CreateFromFloatScalar(sqrtf(m2 / (float)(NDArray_NUMELEMENTS(a))));
+}
+
+NDArray *NDArray_Average(NDArray *a, NDArray *weights) {   // statistics.c:131-154
+    if (!a || !require_gpu(a, "average")) return nullptr;
+    if (weights == nullptr) {
+        float s = reduce_all(a, NP_SUM, "average");
+        return NDArray_CreateFromFloatScalar(s / NDArray_NUMELEMENTS(a));
+    }
+    if (NDArray_DEVICE(a) != NDArray_DEVICE(weights)) {
+        throw_error("All NDArrays used in a operation must be on the same device.");
+        return nullptr;
+    }
+    if (NDArray_NUMELEMENTS(a) != NDArray_NUMELEMENTS(weights)) {
+        throw_error("Can't broadcast arrays.");
+        return nullptr;
+    }
+    float s_aw = 0.0f, s_w = 0.0f;
+    if (!dev_ok(np_weighted_sums(NDArray_FDATA(a), NDArray_FDATA(weights), (size_t)NDArray_NUMELEMENTS(a), &s_aw, &s_w)))
+        return nullptr;
+    return NDArray_CreateFromFloatScalar(s_aw / s_w);
+}
 
 float NDArray_All(NDArray *a) {   // logic.c:25-58
     if (!a || !require_gpu(a, "all")) return -1.0f;

@@ -103,6 +103,9 @@ def _load_host():
     for name in ("Equal", "NotEqual", "Greater", "GreaterEqual", "Less", "LessEqual"):
         sig[f"NDArray_{name}"] = (_P, [_P, _P])
     sig["NDArray_All"] = (C.c_float, [_P])
+    sig["NDArray_Variance"] = (_P, [_P])
+    sig["NDArray_Std"] = (_P, [_P])
+    sig["NDArray_Average"] = (_P, [_P, _P])
     for name, (res, args) in sig.items():
         fn = getattr(h, name)
         fn.restype = res
@@ -359,6 +362,28 @@ class NDArray:
         if isinstance(total, float):   # 1-D input: 0-d sum
             return float(np.float32(total) / np.float32(x.shape()[int(axis)]))
         return NDArray._binary("divide", total, count)
+
+    # ---- statistics (PHP_METHOD variance / std / average, numpower.c:2743-2900) ----
+    @staticmethod
+    def variance(a):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(h.NDArray_Variance(x._p))
+
+    @staticmethod
+    def std(a):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(h.NDArray_Std(x._p))
+
+    @staticmethod
+    def average(a, weights=None):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        if weights is None:
+            return NDArray._wrap(h.NDArray_Average(x._p, None))
+        w, _ = NDArray._coerce(weights)
+        return NDArray._wrap(h.NDArray_Average(x._p, w._p))
 
     # ---- linear algebra -----------------------------------------------------------------------------------
     @staticmethod

@@ -398,6 +398,32 @@ float oracle_max(const float *a, long n) {      /* NDArray_Max, ndarray.c:939-95
         if (a[i] > m) m = a[i];
     return m;
 }
+/* NDArray_Variance (statistics.c:117-130): mean, Subtract, Abs, Pow(…, 2), Sum / n — every step
+ * a full pass with fp32 rounding, restated in the same order. */
+float oracle_variance(const float *a, long n) {
+    float mean = oracle_sum(a, n) / n;
+    float value = 0;
+    for (long i = 0; i < n; i++) value += powf(fabsf(a[i] - mean), 2.0f);
+    return value / n;
+}
+/* NDArray_Std (statistics.c:88-108) */
+float oracle_std(const float *a, long n) {
+    float mean = oracle_sum(a, n) / n;
+    float sum = 0.0f;
+    for (long i = 0; i < n; i++) sum += powf(a[i] - mean, 2);
+    return sqrtf(sum / (float) n);
+}
+/* NDArray_Average with weights (statistics.c:145-151): Multiply_Float then two Sum_Float */
+float oracle_average_weighted(const float *a, const float *w, long n) {
+    float s_w = oracle_sum(w, n);
+    float s_aw = 0;
+    for (long i = 0; i < n; i++) {
+        float p = a[i] * w[i];   /* the -0.0 fix of Multiply_Float does not change a sum */
+        s_aw += p;
+    }
+    return s_aw / s_w;
+}
+
 /* NDArray_All (logic.c:25-58), including the body's `mask != 0x0F` test on an 8-lane mask */
 float oracle_all(const float *array, long n) {
     long i;

@@ -59,7 +59,10 @@ def load():
     lib.oracle_binary.argtypes = [C.c_int, _fp, _ip, C.c_int, _fp, _ip, C.c_int,
                                   C.POINTER(_fp), _ip, _ip]
     lib.oracle_free.argtypes = [C.c_void_p]
-    for name in ("oracle_sum", "oracle_prod", "oracle_min", "oracle_max", "oracle_mean", "oracle_all"):
+    lib.oracle_average_weighted.restype = C.c_float
+    lib.oracle_average_weighted.argtypes = [_fp, _fp, C.c_long]
+    for name in ("oracle_sum", "oracle_prod", "oracle_min", "oracle_max", "oracle_mean", "oracle_all",
+                 "oracle_variance", "oracle_std"):
         fn = getattr(lib, name)
         fn.restype = C.c_float
         fn.argtypes = [_fp, C.c_long]
@@ -129,6 +132,11 @@ def reduce_all(op: str, x) -> np.float32:
     x = _f(x)
     fn = getattr(load(), "oracle_" + op)
     return np.float32(fn(_ptr(x), x.size))
+
+
+def average_weighted(a, w) -> np.float32:
+    a, w = _f(a), _f(w)
+    return np.float32(load().oracle_average_weighted(_ptr(a), _ptr(w), a.size))
 
 
 def reduce_axis(op: str, x, axis: int) -> np.ndarray:

@@ -137,3 +137,26 @@ def test_batched_matmul_slab_64x1024(hip):
         assert (np.abs(Ci - ref) <= 1e-6 * scale).all()
     dA.free()
     dB.free()
+
+
+def test_elementwise_beyond_2p31_elements(hip):
+    """The reference's `int` element counts and `unsigned int` byte sizes stop at 2^31 elements /
+    4 GiB (gpu_alloc.c:11, cuda_math.cu:1104); this back end is size_t end to end.  8.6 GB per
+    operand, filled and checked on the device side (64-bit index kernels)."""
+    D = hip
+    n = (1 << 31) + 20
+    a, b = D.DeviceArray((n,)), D.DeviceArray((n,))
+    D.fill(a, 1.5)
+    D.fill(b, 2.25)
+    D.fill(a.view(n - 3, (3,)), -4.0)                      # a ragged tail that differs
+    out = D.binary("add", a, "full", b, "full", 1, n)
+    assert (out.view(0, (1000,)).to_host() == np.float32(3.75)).all()
+    assert (out.view((1 << 31) - 8, (16,)).to_host() == np.float32(3.75)).all()   # across the 2^31 line
+    assert out.view(n - 4, (4,)).to_host().tolist() == [3.75, -1.75, -1.75, -1.75]
+    total = D.reduce_all("sum", out)
+    want = 3.75 * (n - 3) - 1.75 * 3
+    assert abs(total - want) <= 1e-5 * want
+    ex = D.unary("negate", out)
+    assert ex.view(n - 2, (2,)).to_host().tolist() == [1.75, 1.75]
+    for d in (a, b, out, ex):
+        d.free()

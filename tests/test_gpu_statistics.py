@@ -1,0 +1,65 @@
+"""SURVEY.md §8(f) row 2 on the GPU: variance / std / average (src/ndmath/statistics.c:88-154) as
+fused reductions, against the oracle's step-by-step restatement and an fp64 computation.  Bar:
+1e-5 relative (the reference's own chain of fp32 passes is looser than that at large N, so the
+oracle is compared with the looser of the two)."""
+import numpy as np
+import pytest
+
+from numpower_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(1000, 1000), (257, 1001), (7,), (3, 5, 64), (2, 2)])
+def test_variance_std_average(shape, hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform(shape, 61, -3.0, 5.0)
+    w = synth.uniform(shape, 62, 0.1, 2.0)
+    gx, gw = NDArray.array(x).gpu(), NDArray.array(w).gpu()
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    var = NDArray.variance(gx)
+    std = NDArray.std(gx)
+    avg = NDArray.average(gx)
+    wavg = NDArray.average(gx, gw)
+    assert isinstance(var, float) and isinstance(std, float)        # 0-d results come back as floats
+    assert abs(var - x64.var()) <= 1e-5 * x64.var()
+    assert abs(std - x64.std()) <= 1e-5 * x64.std()
+    assert abs(avg - x64.mean()) <= 1e-5 * np.abs(x64).mean()
+    ref_w = (x64 * w64).sum() / w64.sum()
+    assert abs(wavg - ref_w) <= 1e-5 * (np.abs(x64) * w64).sum() / w64.sum()
+    # the oracle (reference order, fp32 pass by pass) agrees within its own drift
+    slack = 3e-5 if x.size > 100000 else 1e-5
+    assert abs(float(oracle.reduce_all("variance", x)) - x64.var()) <= slack * x64.var()
+    assert abs(float(oracle.reduce_all("std", x)) - x64.std()) <= slack * x64.std()
+    assert abs(float(oracle.average_weighted(x, w)) - ref_w) <= slack * (np.abs(x64) * w64).sum() / w64.sum()
+    assert abs(var - float(oracle.reduce_all("variance", x))) <= 2 * slack * x64.var()
+
+
+def test_statistics_on_view_and_errors(hip):
+    from numpower_amd.ndarray import Error, NDArray
+    x = synth.uniform((6, 1001), 3, -1.0, 1.0)
+    g = NDArray.array(x).gpu()
+    row = g[1]                       # 4-byte aligned view: scalar fallback kernels
+    r64 = x[1].astype(np.float64)
+    assert abs(NDArray.variance(row) - r64.var()) <= 1e-5 * r64.var()
+    assert abs(NDArray.average(row, g[2]) - (r64 * x[2]).sum() / x[2].astype(np.float64).sum()) <= 1e-4
+    with pytest.raises(Error, match="All NDArrays used in a operation must be on the same device."):
+        NDArray.average(g, NDArray.array(x))
+    with pytest.raises(Error, match="only computes on the GPU"):
+        NDArray.variance(NDArray.array(x))
+
+
+def test_moments_1e8(hip):
+    """BASELINE-size input: mean and variance of 1e8 uniform values against their closed forms."""
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    D = hip
+    n = 100_000_000
+    x = synth.uniform((n,), 5, 0.0, 1.0)
+    d = D.DeviceArray.from_host(x)
+    mean, m2 = C.c_float(), C.c_float()
+    check(load().np_moments(d.ptr, n, C.byref(mean), C.byref(m2)))
+    x64 = x.astype(np.float64)
+    assert abs(mean.value - x64.mean()) <= 1e-5 * x64.mean()
+    assert abs(m2.value / n - x64.var()) <= 1e-5 * x64.var()
+    d.free()
