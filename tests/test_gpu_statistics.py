@@ -27,8 +27,10 @@ def test_variance_std_average(shape, hip, oracle):
     assert abs(avg - x64.mean()) <= 1e-5 * np.abs(x64).mean()
     ref_w = (x64 * w64).sum() / w64.sum()
     assert abs(wavg - ref_w) <= 1e-5 * (np.abs(x64) * w64).sum() / w64.sum()
-    # the oracle (reference order, fp32 pass by pass) agrees within its own drift
-    slack = 3e-5 if x.size > 100000 else 1e-5
+    # the oracle (reference order: one sequential fp32 accumulator per pass) agrees within its own
+    # drift, which is large at 1e6 elements (3.7e-4 on the variance: the running sum reaches 5e6
+    # where an ulp is 0.5) — the GPU result above is held to 1e-5 of the fp64 value regardless
+    slack = 1e-3 if x.size > 100000 else 1e-5
     assert abs(float(oracle.reduce_all("variance", x)) - x64.var()) <= slack * x64.var()
     assert abs(float(oracle.reduce_all("std", x)) - x64.std()) <= slack * x64.std()
     assert abs(float(oracle.average_weighted(x, w)) - ref_w) <= slack * (np.abs(x64) * w64).sum() / w64.sum()
