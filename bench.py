@@ -251,8 +251,15 @@ def bench_extras(dist: Dist, steps, warmup):
     r["cpu_baseline"] = {"value": 4.0 * sub.size / t / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
                          "sample": "%d x reduce(axis 0) restatement on the first 8192 rows" % it}
     ex["sum_axis0"] = r
-    dX.free()
     dout.free()
+    # device transpose of the same 65536 x 4096 array, 8 B/elem
+    dT = D.DeviceArray((cols, rows))
+    r = hbm_case("transpose 65536x4096 (manipulation.c, §8f)", 8.0 * rows * cols,
+                 lambda: D.transpose2d(dX, out=dT), steps, warmup, dist)
+    r["parity_ok"] = bool((dT.to_host()[:, :4096] == X[:4096].T).all())
+    ex["transpose_65536x4096"] = r
+    dT.free()
+    dX.free()
     return ex
 
 

@@ -226,6 +226,17 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K,
  * (linalg.c:367-386, cuda_math.cu:228,1417). */
 int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y);
 
+/* ---- layout ---------------------------------------------------------- */
+
+/* out[b][c][r] = in[b][r][c] for batch matrices of rows x cols (contiguous); in != out.
+ * Replaces cuda_float_transpose / transposeCoalesced (cuda_math.cu:136-150,1288-1294: fixed 16x16
+ * grid, only correct up to 256 x 256) with a 64 x 64 LDS-tiled transpose, any size. */
+int np_transpose2d(const float *in, float *out, size_t batch, size_t rows, size_t cols);
+/* General axis permutation into a new contiguous buffer: out.shape[i] = shape[perm[i]]
+ * (NDArray_Transpose + NDArray_ToContiguous, manipulation.c:68-130,381-421).  ndim <= 8;
+ * shape/perm are host arrays.  Errors: "axes don't match array", "repeated axis in transpose". */
+int np_permute(const float *in, float *out, int ndim, const int *host_shape, const int *host_perm);
+
 /* Kernel-variant selection for tuning/benchmarks (0 = default heuristic). */
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);

@@ -117,6 +117,14 @@ NDArray *NDArray_Less(NDArray *nda, NDArray *ndb);
 NDArray *NDArray_LessEqual(NDArray *nda, NDArray *ndb);
 float NDArray_All(NDArray *a);   /* 1 / 0, reproduces the reference's CPU result (logic.c:25-58) */
 
+/* ---- layout (src/manipulation.c:68-130) ---- */
+typedef struct NDArray_Dims {   /* src/ndarray.h:40-43 */
+    int *ptr;
+    int len;
+} NDArray_Dims;
+/* New contiguous array with the axes permuted (NULL = reverse all axes). */
+NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute);
+
 /* ---- statistics (src/ndmath/statistics.c:88-154): 0-d CPU scalar results ---- */
 NDArray *NDArray_Variance(NDArray *a);
 NDArray *NDArray_Std(NDArray *a);

@@ -72,6 +72,8 @@ PROTOTYPES = {
                                            _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p,
                                            C.c_size_t]),
     "np_sgemv": (C.c_int, [C.c_size_t, C.c_size_t, _f32p, _f32p, _f32p]),
+    "np_transpose2d": (C.c_int, [_f32p, _f32p, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "np_permute": (C.c_int, [_f32p, _f32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "np_sgemm_set_variant": (C.c_int, [C.c_int]),
     "np_elementwise_set_variant": (C.c_int, [C.c_int]),
 }

@@ -133,6 +133,14 @@ def sgemv(a: DeviceArray, x: DeviceArray, out: DeviceArray | None = None):
     return out
 
 
+def transpose2d(x: DeviceArray, out: DeviceArray | None = None):
+    rows, cols = x.shape
+    if out is None:
+        out = DeviceArray((cols, rows))
+    check(load().np_transpose2d(x.ptr, out.ptr, 1, rows, cols))
+    return out
+
+
 def fill(x: DeviceArray, value: float):
     check(load().np_fill(x.ptr, value, x.size))
     return x

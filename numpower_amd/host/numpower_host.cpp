@@ -452,6 +452,51 @@ NDArray *NDArray_GreaterEqual(NDArray *nda, NDArray *ndb) { return binary_op(NP_
 NDArray *NDArray_Less(NDArray *nda, NDArray *ndb) { return binary_op(NP_LESS, nda, ndb); }
 NDArray *NDArray_LessEqual(NDArray *nda, NDArray *ndb) { return binary_op(NP_LESS_EQUAL, nda, ndb); }
 
+/* ---- layout (manipulation.c:68-130) ---- */
+NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute) {
+    if (!a) return nullptr;
+    const int n = NDArray_NDIM(a);
+    int permutation[128];
+    if (n > 128) {
+        throw_error("axes don't match array");
+        return nullptr;
+    }
+    if (permute == nullptr) {
+        for (int i = 0; i < n; ++i) permutation[i] = n - 1 - i;   // manipulation.c:75-80
+    } else {
+        if (permute->len != n) {
+            throw_error("axes don't match array");                 // manipulation.c:84-87
+            return nullptr;
+        }
+        int reverse[128];
+        for (int i = 0; i < n; ++i) reverse[i] = -1;
+        for (int i = 0; i < n; ++i) {
+            int axis = permute->ptr[i];
+            if (axis < 0) axis += n;                               // check_and_adjust_axis
+            if (axis < 0 || axis >= n) {
+                throw_error("axes don't match array");
+                return nullptr;
+            }
+            if (reverse[axis] != -1) {
+                throw_error("repeated axis in transpose");         // manipulation.c:97-100
+                return nullptr;
+            }
+            reverse[axis] = i;
+            permutation[i] = axis;
+        }
+    }
+    if (!require_gpu(a, "transpose")) return nullptr;
+    int out_shape[128];
+    for (int i = 0; i < n; ++i) out_shape[i] = a->dimensions[permutation[i]];
+    NDArray *ret = new_array(out_shape, n, NDARRAY_DEVICE_GPU, false);
+    if (!ret) return nullptr;
+    if (!dev_ok(np_permute(NDArray_FDATA(a), NDArray_FDATA(ret), n, a->dimensions, permutation))) {
+        NDArray_FREE(ret);
+        return nullptr;
+    }
+    return ret;
+}
+
 /* ---- statistics (statistics.c:88-154): 0-d CPU scalars, like NDArray_CreateFromFloatScalar ---- */
 NDArray *NDArray_Variance(NDArray *a) {   // statistics.c:117-130
     if (!a || !require_gpu(a, "variance")) return nullptr;

@@ -49,6 +49,10 @@ _P = C.POINTER(_CNDArray)
 _host = None
 
 
+class _CDims(C.Structure):   # NDArray_Dims, src/ndarray.h:40-43
+    _fields_ = [("ptr", C.POINTER(C.c_int)), ("len", C.c_int)]
+
+
 def host_lib_path() -> Path:
     return _lib.LIBDIR / "libnumpower_host.so"
 
@@ -103,6 +107,7 @@ def _load_host():
     for name in ("Equal", "NotEqual", "Greater", "GreaterEqual", "Less", "LessEqual"):
         sig[f"NDArray_{name}"] = (_P, [_P, _P])
     sig["NDArray_All"] = (C.c_float, [_P])
+    sig["NDArray_Transpose"] = (_P, [_P, C.POINTER(_CDims)])
     sig["NDArray_Variance"] = (_P, [_P])
     sig["NDArray_Std"] = (_P, [_P])
     sig["NDArray_Average"] = (_P, [_P, _P])
@@ -362,6 +367,17 @@ class NDArray:
         if isinstance(total, float):   # 1-D input: 0-d sum
             return float(np.float32(total) / np.float32(x.shape()[int(axis)]))
         return NDArray._binary("divide", total, count)
+
+    # ---- layout (PHP_METHOD transpose, numpower.c:1404-1450) ----
+    @staticmethod
+    def transpose(a, axes=None):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        if axes is None:
+            return NDArray._wrap(h.NDArray_Transpose(x._p, None))
+        arr = (C.c_int * max(len(axes), 1))(*[int(v) for v in axes])
+        dims = _CDims(arr, len(axes))
+        return NDArray._wrap(h.NDArray_Transpose(x._p, C.byref(dims)))
 
     # ---- statistics (PHP_METHOD variance / std / average, numpower.c:2743-2900) ----
     @staticmethod

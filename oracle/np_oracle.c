@@ -398,6 +398,43 @@ float oracle_max(const float *a, long n) {      /* NDArray_Max, ndarray.c:939-95
         if (a[i] > m) m = a[i];
     return m;
 }
+/* NDArray_Transpose (manipulation.c:68-130): permute shape and byte strides of a copy, then
+ * NDArray_ToContiguous walks the permuted view element by element (manipulation.c:381-421).
+ * perm == NULL reverses the axes.  Returns 0, or -1 with the reference's message. */
+int oracle_transpose(const float *in, const int *shape, int ndim, const int *perm, float *out, int *out_shape) {
+    int p[32], seen[32];
+    long in_stride[32];
+    if (ndim > 32) return fail("axes don't match array");
+    for (int i = 0; i < ndim; i++) seen[i] = 0;
+    for (int i = 0; i < ndim; i++) {
+        int axis = perm ? perm[i] : ndim - 1 - i;
+        if (axis < 0) axis += ndim;
+        if (axis < 0 || axis >= ndim) return fail("axes don't match array");
+        if (seen[axis]) return fail("repeated axis in transpose");
+        seen[axis] = 1;
+        p[i] = axis;
+    }
+    long s = 1;
+    for (int i = ndim - 1; i >= 0; i--) {
+        in_stride[i] = s;
+        s *= shape[i];
+    }
+    long n = s;
+    for (int i = 0; i < ndim; i++) out_shape[i] = shape[p[i]];
+    int idx[32];
+    for (int i = 0; i < ndim; i++) idx[i] = 0;
+    for (long o = 0; o < n; o++) {
+        long off = 0;
+        for (int i = 0; i < ndim; i++) off += idx[i] * in_stride[p[i]];
+        out[o] = in[off];
+        for (int i = ndim - 1; i >= 0; i--) {   /* odometer over the output index */
+            if (++idx[i] < out_shape[i]) break;
+            idx[i] = 0;
+        }
+    }
+    return 0;
+}
+
 /* NDArray_Variance (statistics.c:117-130): mean, Subtract, Abs, Pow(…, 2), Sum / n — every step
  * a full pass with fp32 rounding, restated in the same order. */
 float oracle_variance(const float *a, long n) {

@@ -134,6 +134,22 @@ def reduce_all(op: str, x) -> np.float32:
     return np.float32(fn(_ptr(x), x.size))
 
 
+def transpose(x, axes=None) -> np.ndarray:
+    """NDArray_Transpose + NDArray_ToContiguous."""
+    lib = load()
+    lib.oracle_transpose.restype = C.c_int
+    lib.oracle_transpose.argtypes = [_fp, _ip, C.c_int, _ip, _fp, _ip]
+    x = _f(x)
+    out = np.empty(x.size, dtype=np.float32)
+    oshape = (C.c_int * max(x.ndim, 1))()
+    perm = None if axes is None else (C.c_int * max(len(axes), 1))(*[int(a) for a in axes])
+    if axes is not None and len(axes) != x.ndim:
+        raise OracleError("axes don't match array")
+    if lib.oracle_transpose(_ptr(x), _shape(x), x.ndim, perm, _ptr(out), oshape) != 0:
+        raise _err()
+    return out.reshape(tuple(oshape[i] for i in range(x.ndim)))
+
+
 def average_weighted(a, w) -> np.float32:
     a, w = _f(a), _f(w)
     return np.float32(load().oracle_average_weighted(_ptr(a), _ptr(w), a.size))

@@ -23,6 +23,8 @@ OUT = Path(__file__).resolve().parent / "phpt_vectors.json"
 FILES = sorted((REF / "tests" / "math").glob("*.phpt")) + [REF / "tests" / "linalg" / "001-ndarray-matmul.phpt"]
 # SURVEY.md §8f row 1 (comparison / logic elementwise); 002-ndarray-allclose is CPU-only in the reference
 FILES += [f for f in sorted((REF / "tests" / "logic").glob("*.phpt")) if "allclose" not in f.name]
+# §8f row 3 (layout ops on device)
+FILES += [REF / "tests" / "manipulation" / "001-ndarray-transpose.phpt"]
 
 ASSIGN = re.compile(r"^\$(\w+) = \\NDArray::array\((.*)\);$")
 PRINT = re.compile(r"^print_r\((.*)\);$")
@@ -72,6 +74,9 @@ def parse_file(path):
         line = line.strip()
         if not line:
             continue
+        if line == r"use \NDArray as nd;":      # class alias used by the manipulation tests
+            continue
+        line = re.sub(r"(?<![\\\w])nd::", r"\\NDArray::", line)
         a = ASSIGN.match(line)
         if a:
             rec["vars"][a.group(1)] = ast.literal_eval(a.group(2))

@@ -102,6 +102,8 @@ def replay(backend, test) -> str:
                 res = backend.binary(op, args[0], args[1])
             elif op == "all":
                 res = backend.all(args[0])
+            elif op == "transpose":
+                res = backend.transpose(args[0])
             elif op == "square":     # PHP_METHOD(NDArray, square): Multiply_Float(nda, nda), numpower.c:3093
                 res = backend.binary("multiply", args[0], args[0])
             elif op == "clip":
@@ -154,6 +156,9 @@ class GpuBackend:
     def all(self, x):
         return self.nd.all(x)
 
+    def transpose(self, x):
+        return self.nd.transpose(x)
+
     def to_list(self, h):
         return h.cpu().toArray()
 
@@ -194,6 +199,9 @@ class OracleBackend:
 
     def all(self, x):
         return float(self.o.reduce_all("all", x))
+
+    def transpose(self, x):
+        return self._ret(self.o.transpose(x))
 
     def to_list(self, h):
         return np.asarray(h, dtype=np.float64).tolist()
