@@ -49,6 +49,19 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic():
+    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in their own
+    runs, gfx950 correction applied — see the _note inside the file) and committed under profiles/;
+    the newest round's file wins.  {} when none is there: `traffic` is then null."""
+    files = sorted((ROOT / "profiles").glob("r*/pmc_traffic.json"))
+    if not files:
+        return {}, None
+    try:
+        return json.loads(files[-1].read_text()), str(files[-1].relative_to(ROOT))
+    except Exception:
+        return {}, None
+
+
 class Dist:
     """torch.distributed plumbing (only imported when N > 1, or when NP_BENCH_FORCE_DIST=1 asks for
     the same code path on one GPU: world size 1, RCCL initialised, kernels on torch's stream)."""
@@ -73,9 +86,14 @@ class Dist:
             torch.cuda.set_device(self.local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             D.init(self.local_rank)
-            # run our kernels on torch's current stream so that RCCL and torch see one order
+            # run our kernels on torch's current stream so that RCCL and torch see one order.  The
+            # legacy default stream has handle 0, which np_set_stream reads as "library-owned
+            # stream", so make a real stream current first.
             from numpower_amd._lib import check
-            check(load().np_set_stream(torch.cuda.current_stream().cuda_stream))
+            self.stream = torch.cuda.Stream(device=self.local_rank)
+            torch.cuda.set_stream(self.stream)
+            assert self.stream.cuda_stream != 0
+            check(load().np_set_stream(self.stream.cuda_stream))
         else:
             D.init(0)
 
@@ -352,6 +370,16 @@ def main():
                 extras = {"config5_batched_matmul_allgather": bench_config5(dist, max(3, args.steps // 10), 2)}
             except Exception as e:
                 extras = {"error": repr(e)}
+    # HBM traffic per launch from the committed PMC passes (profiles/rNN/pmc_traffic.json)
+    traffic, src = pmc_traffic()
+    if traffic:
+        result["roofline"]["traffic"] = traffic.get("sgemm_dma_kernel", {}).get("hbm_bytes")
+        result["roofline"]["traffic_source"] = src
+        for key, entry in extras.items():
+            if isinstance(entry, dict) and key in traffic and "roofline" in entry:
+                entry["roofline"]["traffic"] = traffic[key].get("hbm_bytes")
+        if "secondary" in result and "add_1e8" in traffic:
+            result["secondary"]["roofline"]["traffic"] = traffic["add_1e8"].get("hbm_bytes")
     if extras:
         result["extras"] = extras
     if rank0:

@@ -88,9 +88,24 @@ def sharded_batched_matmul(a_slab, b_slab, batch: int, compute, dist=None, gathe
 
 
 def hip_compute(a, b, out):
-    """compute() for GPU ranks: one np_sgemm_strided_batched launch on torch's current stream."""
+    """compute() for GPU ranks: one np_sgemm_strided_batched launch, ordered with torch's work.
+
+    If torch's current stream is a real stream the library is switched onto it (RCCL then sees the
+    GEMM in stream order).  The legacy default stream has handle 0, which np_set_stream reads as
+    "library-owned stream": in that case the GEMM runs on the library stream between two explicit
+    synchronisations."""
+    import torch
+
     from ._lib import check, load
+    lib = load()
     s, m, k = a.shape
     n = b.shape[2]
-    check(load().np_sgemm_strided_batched(s, m, n, k, a.data_ptr(), m * k, b.data_ptr(), k * n,
-                                          out.data_ptr(), m * n))
+    handle = torch.cuda.current_stream(a.device).cuda_stream
+    if handle:
+        check(lib.np_set_stream(handle))
+    else:
+        torch.cuda.synchronize(a.device)      # inputs produced on the null stream are complete
+    check(lib.np_sgemm_strided_batched(s, m, n, k, a.data_ptr(), m * k, b.data_ptr(), k * n,
+                                       out.data_ptr(), m * n))
+    if not handle:
+        check(lib.np_sync())                  # result complete before the collective is enqueued
