@@ -62,6 +62,27 @@ def pmc_traffic():
         return {}, None
 
 
+class _stdout_to_devnull:
+    """Temporarily point fd 1 at /dev/null and flush C stdio into it (library banners)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._libc = C.CDLL(None)
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        self._null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self._null, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        os.close(self._null)
+        return False
+
+
 class Dist:
     """torch.distributed plumbing (only imported when N > 1, or when NP_BENCH_FORCE_DIST=1 asks for
     the same code path on one GPU: world size 1, RCCL initialised, kernels on torch's stream)."""
@@ -84,7 +105,13 @@ class Dist:
             os.environ.setdefault("WORLD_SIZE", str(n))
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(self.local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            # RCCL prints a version banner through C stdio on stdout when the communicator comes up;
+            # stdout must carry exactly one JSON line, so the banner is flushed into /dev/null.
+            with _stdout_to_devnull():
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                warm = torch.zeros(1, device="cuda")
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
             D.init(self.local_rank)
             # run our kernels on torch's current stream so that RCCL and torch see one order.  The
             # legacy default stream has handle 0, which np_set_stream reads as "library-owned
@@ -112,7 +139,8 @@ class Dist:
 
     def close(self):
         if self.use_torch:
-            self.dist.destroy_process_group()
+            with _stdout_to_devnull():
+                self.dist.destroy_process_group()
 
 
 def timed(dist: Dist, fn, steps: int, warmup: int):
@@ -385,6 +413,10 @@ def main():
     if rank0:
         print(json.dumps(result), flush=True)
     dist.close()
+    # nothing but the JSON line may reach stdout: whatever a library still holds in C stdio buffers
+    # (RCCL's banner) is sent to /dev/null at exit
+    sys.stdout.flush()
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
 
 if __name__ == "__main__":
