@@ -26,6 +26,11 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+// float4 that is only dword-aligned: rows of a matrix whose leading dimension is not a multiple
+// of 4 (K = 4097, N = 1001 ...).  gfx950 global loads handle it (hipcc emits global_load_dwordx4).
+struct __attribute__((packed, aligned(4))) U4 {
+    v4f v;
+};
 
 struct GemmArgs {
     const float *A, *B;
@@ -139,9 +144,13 @@ __global__ __launch_bounds__(256, MINW) void sgemm_kernel(GemmArgs g) {
                 else
                     ra[r] = v4f{0, 0, 0, 0};
             } else {
+                if (gm < g.M && gk + 3 < g.K) {
+                    ra[r] = ((const U4 *)(A + (size_t)gm * g.lda + gk))->v;   // dword-aligned dwordx4
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    ra[r][e] = (gm < g.M && gk + e < g.K) ? A[(size_t)gm * g.lda + gk + e] : 0.0f;
+                    for (int e = 0; e < 4; ++e)
+                        ra[r][e] = (gm < g.M && gk + e < g.K) ? A[(size_t)gm * g.lda + gk + e] : 0.0f;
+                }
             }
         }
 #pragma unroll
@@ -155,9 +164,13 @@ __global__ __launch_bounds__(256, MINW) void sgemm_kernel(GemmArgs g) {
                 else
                     rb[r] = v4f{0, 0, 0, 0};
             } else {
+                if (gk < g.K && gn + 3 < g.N) {
+                    rb[r] = ((const U4 *)(B + (size_t)gk * g.ldb + gn))->v;
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    rb[r][e] = (gk < g.K && gn + e < g.N) ? B[(size_t)gk * g.ldb + gn + e] : 0.0f;
+                    for (int e = 0; e < 4; ++e)
+                        rb[r][e] = (gk < g.K && gn + e < g.N) ? B[(size_t)gk * g.ldb + gn + e] : 0.0f;
+                }
             }
         }
     };
@@ -297,9 +310,13 @@ __global__ __launch_bounds__(256, 2) void sgemm_pipe_kernel(GemmArgs g) {
                 else
                     ra[r] = v4f{0, 0, 0, 0};
             } else {
+                if (gm < g.M && gk + 3 < g.K) {
+                    ra[r] = ((const U4 *)(A + (size_t)gm * g.lda + gk))->v;   // dword-aligned dwordx4
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    ra[r][e] = (gm < g.M && gk + e < g.K) ? A[(size_t)gm * g.lda + gk + e] : 0.0f;
+                    for (int e = 0; e < 4; ++e)
+                        ra[r][e] = (gm < g.M && gk + e < g.K) ? A[(size_t)gm * g.lda + gk + e] : 0.0f;
+                }
             }
         }
 #pragma unroll
@@ -313,9 +330,13 @@ __global__ __launch_bounds__(256, 2) void sgemm_pipe_kernel(GemmArgs g) {
                 else
                     rb[r] = v4f{0, 0, 0, 0};
             } else {
+                if (gk < g.K && gn + 3 < g.N) {
+                    rb[r] = ((const U4 *)(B + (size_t)gk * g.ldb + gn))->v;
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    rb[r][e] = (gk < g.K && gn + e < g.N) ? B[(size_t)gk * g.ldb + gn + e] : 0.0f;
+                    for (int e = 0; e < 4; ++e)
+                        rb[r][e] = (gk < g.K && gn + e < g.N) ? B[(size_t)gk * g.ldb + gn + e] : 0.0f;
+                }
             }
         }
     };
@@ -716,21 +737,31 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
             return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
         default: break;
     }
-    // Default choice, measured on MI355X at 4096^3 (profiles/r01/gemm_ab.log): LDS-DMA kernel
-    // 145 TFLOP/s, register-staged pipelined 128x128 kernel 135, simple 128x128 kernel 132-135.
-    //   1. fully aligned and enough 256x128 tiles to give every CU one  -> sgemm_dma_kernel
-    //   2. enough 128x128 tiles                                          -> sgemm_pipe_kernel
-    //   3. otherwise 64x64 tiles so that more than a handful of CUs have work
-    const size_t cus = (size_t)np::num_cus();
-    if (vec && M % 256 == 0 && N % 128 == 0 && K % 16 == 0 && (M / 256) * (N / 128) * batch >= cus) {
+    // Default choice: a cost model calibrated on MI355X (profiles/r01/gemm_ab.log, gemm_sweep.log).
+    // Every CU works through ceil(tiles / CUs) tiles, a tile costs its area divided by the
+    // kernel's measured MFMA efficiency at 4096^3:
+    //   sgemm_dma_kernel 256x128 (fully aligned shapes only)   0.93   (145 TFLOP/s)
+    //   sgemm_kernel     128x128                               0.85   (132-135)
+    //   sgemm_kernel      64x64                                0.71   (110)
+    // The model reproduces the measured ranking at n = 1024 ... 8192 (e.g. 3072^3: 64x64 tiles =
+    // 9 per CU beat 288 DMA tiles = 2 per CU on 32 CUs and 1 on the rest: 110 vs 81 TFLOP/s).
+    const double cus = (double)np::num_cus();
+    auto cost = [&](size_t bm, size_t bn, double eff) {
+        const double tiles = (double)(((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch);
+        return ceil(tiles / cus) * (double)(bm * bn) / eff;
+    };
+    const bool dma_ok = vec && M % 256 == 0 && N % 128 == 0 && K % 16 == 0;
+    const double c_dma = dma_ok ? cost(256, 128, 0.93) : 1e300;
+    const double c_128 = cost(128, 128, 0.85);
+    const double c_64 = cost(64, 64, 0.71);
+    if (c_dma <= c_128 && c_dma <= c_64) {
         g.tiles_m = g.M / 256;
         g.tiles_n = g.N / 128;
         sgemm_dma_kernel<<<dim3(g.tiles_m * g.tiles_n, 1, (unsigned)batch), 256, 0, np::stream()>>>(g);
         NP_LAUNCH_CHECK("sgemm_dma_kernel");
         return NP_OK;
     }
-    const size_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128) * batch;
-    if (big_tiles >= cus) return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
+    if (c_128 <= c_64) return launch_sgemm_tile<128, 128, 16, 4>(g, (unsigned)batch, vec);
     return launch_sgemm_tile<64, 64, 16, 4>(g, (unsigned)batch, vec);
 }
 
