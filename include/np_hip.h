@@ -240,6 +240,7 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
 /* Kernel-variant selection for tuning/benchmarks (0 = default heuristic). */
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);
+int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128 */
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "np_permute": (C.c_int, [_f32p, _f32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "np_sgemm_set_variant": (C.c_int, [C.c_int]),
     "np_elementwise_set_variant": (C.c_int, [C.c_int]),
+    "np_layout_set_variant": (C.c_int, [C.c_int]),
 }
 
 
