@@ -236,6 +236,16 @@ def bench_extras(dist: Dist, steps, warmup):
                          "sample": "%d x full 1e8-element NDArray_Add_Float restatement (AVX2, 1 thread)" % it}
     ex["add_1e8"] = r
     del ref, got
+    # end to end through the boundary's placement calls, once: gpu() x2 -> add -> cpu() on pageable
+    # host buffers (NDArray_ToGPU / NDArray_ToCPU); PCIe-bound, reported beside the kernel number
+    from numpower_amd.ndarray import NDArray
+    ha, hb = NDArray.array(a), NDArray.array(b)
+    t0 = time.perf_counter()
+    res = (ha.gpu() + hb.gpu()).cpu()
+    e2e = time.perf_counter() - t0
+    r["end_to_end_gpu_add_cpu"] = {"seconds": e2e, "GBps_over_pcie": 12.0 * N / e2e / 1e9,
+                                   "note": "2 x H2D 0.4 GB + kernel + D2H 0.4 GB, pageable memory"}
+    del ha, hb, res
     # comparison elementwise (same kernel template, 12 B/elem)
     r = hbm_case("greater 1e8 fp32 (logic.c, §8f)", 12.0 * N,
                  lambda: D.binary("greater", da, "full", db, "full", 1, N, out=do), steps, warmup, dist)

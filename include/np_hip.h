@@ -189,6 +189,13 @@ int np_moments(const float *in, size_t n, float *host_mean, float *host_m2);
  * into the reduction (no a*w temporary). */
 int np_weighted_sums(const float *a, const float *w, size_t n, float *host_sum_aw, float *host_sum_w);
 
+/* argmax (is_max != 0) / argmin along the middle axis of outer x axis_len x inner; out receives
+ * outer*inner indices AS FLOATS, like the reference (float_argmax / float_argmin,
+ * src/ndmath/calculation.c:9-72: first occurrence wins; argmax: a NaN in position 0 is maximal,
+ * later NaNs are never selected; argmin: the first NaN wins).  The reference rejects GPU arrays
+ * ("GPU not supported.", calculation.c:75-78). */
+int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, size_t inner, float *out);
+
 /* NDArray_All (logic.c:25-58): *host_out = 1 if every element is non-zero, else 0.
  * flags = NP_QUIRK_AVX_BODY reproduces what the reference's CPU code actually computes: its AVX2
  * body tests `movemask != 0x0F` on an 8-lane mask (logic.c:36-39), i.e. a full 8-element block

@@ -125,6 +125,13 @@ typedef struct NDArray_Dims {   /* src/ndarray.h:40-43 */
 /* New contiguous array with the axes permuted (NULL = reverse all axes). */
 NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute);
 
+/* ---- argmax / argmin (src/ndmath/calculation.c:73-194) ----
+ * axis = 128 (NDARRAY_MAX_DIMS) reduces the flattened array; indices are returned as floats. */
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+NDArray *NDArray_ArgMinMaxCommon(NDArray *op, int axis, bool keepdims, bool is_argmax);
+
 /* ---- statistics (src/ndmath/statistics.c:88-154): 0-d CPU scalar results ---- */
 NDArray *NDArray_Variance(NDArray *a);
 NDArray *NDArray_Std(NDArray *a);

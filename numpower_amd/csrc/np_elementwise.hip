@@ -1,7 +1,8 @@
 // Elementwise kernels of libnp_hip.so: binary ops with fused scalar/row/column broadcast, the
 // unary float_* family, and fill.  HBM-bound streaming kernels: 16 B per lane per access
-// (global_load/store_dwordx4), several independent accesses in flight per lane, grid sized to a
-// few workgroups per CU with a grid-stride loop.  No LDS, no MFMA: nothing here has reuse.
+// (global_load/store_dwordx4), UNROLL independent accesses in flight per lane, an uncapped grid
+// (every lane moves UNROLL float4 and retires), non-temporal loads and stores.  No LDS, no MFMA:
+// nothing here has reuse.
 //
 // Reference behaviour restated (file:line relative to the reference tree):
 //   binary ops      src/ndmath/arithmetics.c:160-926  (+ CUDA kernels cuda_math.cu:593-633)
@@ -165,15 +166,6 @@ __device__ __forceinline__ v4f fetch4(const float *p, I v, I cols4, float splat)
         return v4f{s, s, s, s};
     }
     return v4f{0, 0, 0, 0};
-}
-
-template <int KIND, typename I>
-__device__ __forceinline__ float fetch1(const float *p, I i, I cols) {
-    if constexpr (KIND == NP_FULL) return p[i];
-    if constexpr (KIND == NP_SCALAR) return p[0];
-    if constexpr (KIND == NP_ROW) return p[i % cols];
-    if constexpr (KIND == NP_COL) return p[i / cols];
-    return 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -486,15 +478,6 @@ int dispatch_unary(const float *in, float *out, size_t n, float p0, float p1) {
     return launch_unary<OP, uint64_t>(in, out, n, p0, p1);
 }
 
-size_t operand_elems(int kind, size_t rows, size_t cols) {
-    switch (kind) {
-        case NP_FULL: return rows * cols;
-        case NP_SCALAR: return 1;
-        case NP_ROW: return cols;
-        default: return rows;
-    }
-}
-
 }  // namespace
 
 extern "C" {
@@ -513,7 +496,6 @@ int np_binary(int op, const float *a, int a_kind, const float *b, int b_kind, fl
     if (rows == 0 || cols == 0) return NP_OK;
     if (!a || !b || !out) return np::fail(NP_ERR_INVALID, "np_binary: null pointer");
     if (int rc = np::ensure_init()) return rc;
-    (void)operand_elems;
     // host scalars travel by value (kernel argument); the kernels see kind SCALAR + null pointer
     float ha = 0.0f, hb = 0.0f;
     if (a_kind == NP_HOST_SCALAR) { ha = *a; a = nullptr; a_kind = NP_SCALAR; }

@@ -200,6 +200,135 @@ __global__ __launch_bounds__(256) void reduce_xform_scalar(const float *__restri
     if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }
 
+// ------------------------------------------------------------------------------------------
+// argmax / argmin (src/ndmath/calculation.c:9-72): index-carrying reductions
+// ------------------------------------------------------------------------------------------
+//
+// float_argmax: first index of the maximum; a NaN in element 0 wins outright, later NaNs are never
+// selected (`*ip > mp` is false for NaN).  float_argmin: `!(mp <= *ip)` — the first NaN anywhere
+// wins (and stops the scan), otherwise the first index of the minimum.  `better(a, b)` below says
+// whether candidate a must replace b when a comes from a LATER index range (ties keep the earlier).
+struct ArgPair {
+    float v;
+    unsigned i;   // index along the reduced axis
+};
+
+template <bool IS_MAX>
+__device__ __forceinline__ float arg_key(float x, unsigned index) {
+    if constexpr (IS_MAX) {
+        // NaN at position 0 is maximal; NaN elsewhere can never win
+        if (x != x) return (index == 0) ? INFINITY : -INFINITY;
+        return x;
+    }
+    return x;
+}
+
+// true if (vb, ib) should replace (va, ia); both are valid candidates
+template <bool IS_MAX>
+__device__ __forceinline__ bool arg_replace(float va, unsigned ia, float vb, unsigned ib) {
+    if constexpr (IS_MAX) {
+        if (vb > va) return true;
+        return (vb == va) && (ib < ia);
+    } else {
+        const bool na = va != va, nb = vb != vb;
+        if (na || nb) {
+            if (na && nb) return ib < ia;
+            return nb;               // a NaN beats every number (first NaN wins)
+        }
+        if (vb < va) return true;
+        return (vb == va) && (ib < ia);
+    }
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ ArgPair arg_combine(ArgPair a, ArgPair b) {
+    return arg_replace<IS_MAX>(a.v, a.i, b.v, b.i) ? b : a;
+}
+
+// One workgroup per (row, chunk): rows are contiguous (inner == 1).  partial index = row*chunks+chunk.
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void argreduce_rows_kernel(const float *__restrict__ in, float *__restrict__ pv,
+                                                             unsigned *__restrict__ pi, unsigned len,
+                                                             unsigned chunks) {
+    __shared__ float sv[4];
+    __shared__ unsigned si[4];
+    const unsigned row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const unsigned per = (len + chunks - 1) / chunks;
+    const unsigned lo = chunk * per;
+    unsigned hi = lo + per;
+    if (hi > len) hi = len;
+    const float *p = in + (size_t)row * len;
+    ArgPair best{IS_MAX ? -INFINITY : INFINITY, 0xffffffffu};
+    bool have = false;
+    for (unsigned i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const ArgPair c{arg_key<IS_MAX>(p[i], i), i};
+        if (!have) {
+            best = c;
+            have = true;
+        } else {
+            best = arg_combine<IS_MAX>(best, c);
+        }
+    }
+    // lanes without a candidate carry index 0xffffffff and a neutral value: they lose every tie
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ArgPair o;
+        o.v = __shfl_down(best.v, off, 64);
+        o.i = __shfl_down(best.i, off, 64);
+        if (o.i != 0xffffffffu) best = (best.i == 0xffffffffu) ? o : arg_combine<IS_MAX>(best, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sv[wave] = best.v;
+        si[wave] = best.i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ArgPair r{sv[0], si[0]};
+        for (int w = 1; w < 4; ++w) {
+            const ArgPair o{sv[w], si[w]};
+            if (o.i != 0xffffffffu) r = (r.i == 0xffffffffu) ? o : arg_combine<IS_MAX>(r, o);
+        }
+        pv[blockIdx.x] = r.v;
+        pi[blockIdx.x] = r.i;
+    }
+}
+
+// fold the per-chunk partials of each row (chunks are in index order) and write the float index
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void argreduce_fold_kernel(const float *__restrict__ pv,
+                                                             const unsigned *__restrict__ pi,
+                                                             float *__restrict__ out, unsigned rows,
+                                                             unsigned chunks) {
+    const unsigned row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    ArgPair r{pv[(size_t)row * chunks], pi[(size_t)row * chunks]};
+    for (unsigned c = 1; c < chunks; ++c) {
+        const ArgPair o{pv[(size_t)row * chunks + c], pi[(size_t)row * chunks + c]};
+        if (o.i != 0xffffffffu) r = (r.i == 0xffffffffu) ? o : arg_combine<IS_MAX>(r, o);
+    }
+    out[row] = (float)r.i;
+}
+
+// generic: one thread per output element, sequential over the axis exactly like the reference loop
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void argreduce_generic_kernel(const float *__restrict__ in,
+                                                                float *__restrict__ out, size_t outer,
+                                                                unsigned axis_len, size_t inner) {
+    const size_t total = outer * inner;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const size_t o = idx / inner, j = idx % inner;
+        const float *p = in + o * axis_len * inner + j;
+        ArgPair best{arg_key<IS_MAX>(p[0], 0), 0};
+        for (unsigned a = 1; a < axis_len; ++a) {
+            const ArgPair c{arg_key<IS_MAX>(p[(size_t)a * inner], a), a};
+            best = arg_combine<IS_MAX>(best, c);
+        }
+        out[idx] = (float)best.i;
+    }
+}
+
 // NDArray_All (logic.c:25-58) as a min-reduction over a per-element verdict (1 = passes).
 // QUIRK: index < body_end follows the reference's AVX2 body, which tests `movemask != 0x0F` on an
 // 8-lane mask: lanes 0-3 of every 8-block must be non-zero and non-NaN (_CMP_NEQ_OQ true) and
@@ -594,6 +723,52 @@ static int xform_sum(const float *in, const float *in2, size_t n, float p0, floa
 }
 
 extern "C" {
+
+int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, size_t inner, float *out) {
+    if (outer == 0 || inner == 0) return NP_OK;
+    if (axis_len == 0) return np::fail(NP_ERR_INVALID, "attempt to get %s of an empty sequence", is_max ? "argmax" : "argmin");
+    if (!in || !out) return np::fail(NP_ERR_INVALID, "np_argreduce: null pointer");
+    if (axis_len > 0xfffffffeull) return np::fail(NP_ERR_INVALID, "np_argreduce: axis too long");
+    if (int rc = np::ensure_init()) return rc;
+    hipStream_t s = np::stream();
+    if (inner == 1) {
+        // contiguous rows: (row, chunk) workgroups + a fold over the chunks of each row
+        const size_t target = (size_t)np::num_cus() * 8;
+        size_t chunks = 1;
+        if (outer < target) {
+            chunks = (target + outer - 1) / outer;
+            const size_t max_chunks = (axis_len + 1023) / 1024;   // >= 1024 elements per chunk
+            if (chunks > max_chunks) chunks = max_chunks;
+        }
+        if (outer * chunks > 0x7fffffffull) return np::fail(NP_ERR_INVALID, "np_argreduce: too many rows");
+        np::Scratch pv, pi;
+        if (int rc = pv.alloc(outer * chunks * sizeof(float))) return rc;
+        if (int rc = pi.alloc(outer * chunks * sizeof(unsigned))) return rc;
+        const unsigned grid = (unsigned)(outer * chunks);
+        if (is_max)
+            argreduce_rows_kernel<true><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)chunks);
+        else
+            argreduce_rows_kernel<false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)chunks);
+        NP_LAUNCH_CHECK("argreduce_rows_kernel");
+        const unsigned fgrid = (unsigned)((outer + 255) / 256);
+        if (is_max)
+            argreduce_fold_kernel<true><<<fgrid, 256, 0, s>>>((const float *)pv.ptr, (const unsigned *)pi.ptr, out, (unsigned)outer, (unsigned)chunks);
+        else
+            argreduce_fold_kernel<false><<<fgrid, 256, 0, s>>>((const float *)pv.ptr, (const unsigned *)pi.ptr, out, (unsigned)outer, (unsigned)chunks);
+        NP_LAUNCH_CHECK("argreduce_fold_kernel");
+        return NP_OK;
+    }
+    const size_t total = outer * inner;
+    size_t blocks = (total + 255) / 256;
+    const size_t cap = (size_t)np::num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (is_max)
+        argreduce_generic_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(in, out, outer, (unsigned)axis_len, inner);
+    else
+        argreduce_generic_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(in, out, outer, (unsigned)axis_len, inner);
+    NP_LAUNCH_CHECK("argreduce_generic_kernel");
+    return NP_OK;
+}
 
 int np_moments(const float *in, size_t n, float *host_mean, float *host_m2) {
     if (!host_mean || !host_m2) return np::fail(NP_ERR_INVALID, "np_moments: null output");

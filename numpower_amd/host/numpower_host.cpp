@@ -497,6 +497,53 @@ NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute) {
     return ret;
 }
 
+/* ---- argmax / argmin (calculation.c:73-194) ---- */
+// axis == NDARRAY_MAX_DIMS (128) means "flattened" (numpower.c:2588-2590); the reference moves the
+// axis last with a Transpose copy and walks rows — here the (outer, axis, inner) view is reduced
+// in place, no copy.
+NDArray *NDArray_ArgMinMaxCommon(NDArray *op, int axis, bool keepdims, bool is_argmax) {
+    if (!op) return nullptr;
+    if (!require_gpu(op, is_argmax ? "argmax" : "argmin")) return nullptr;
+    const int nd = NDArray_NDIM(op);
+    const bool flat = (axis == 128) || nd == 0;
+    if (!flat) {
+        if (axis < 0) axis += nd;
+        if (axis < 0 || axis >= nd) {
+            throw_error("Invalid axis parameter");
+            return nullptr;
+        }
+    }
+    size_t outer = 1, inner = 1, len = 1;
+    int out_shape[128];
+    int out_nd = 0;
+    if (flat) {
+        len = (size_t)NDArray_NUMELEMENTS(op);
+        if (keepdims)
+            for (int i = 0; i < nd; ++i) out_shape[out_nd++] = 1;
+    } else {
+        len = (size_t)op->dimensions[axis];
+        for (int i = 0; i < nd; ++i) {
+            if (i < axis) outer *= (size_t)op->dimensions[i];
+            if (i > axis) inner *= (size_t)op->dimensions[i];
+            if (i != axis)
+                out_shape[out_nd++] = op->dimensions[i];
+            else if (keepdims)
+                out_shape[out_nd++] = 1;
+        }
+    }
+    if (len == 0) {
+        throw_error("attempt to get %s of an empty sequence", is_argmax ? "argmax" : "argmin");
+        return nullptr;
+    }
+    NDArray *rp = new_array(out_shape, out_nd, NDARRAY_DEVICE_GPU, false);
+    if (!rp) return nullptr;
+    if (!dev_ok(np_argreduce(is_argmax ? 1 : 0, NDArray_FDATA(op), outer, len, inner, NDArray_FDATA(rp)))) {
+        NDArray_FREE(rp);
+        return nullptr;
+    }
+    return rp;
+}
+
 /* ---- statistics (statistics.c:88-154): 0-d CPU scalars, like NDArray_CreateFromFloatScalar ---- */
 NDArray *NDArray_Variance(NDArray *a) {   // statistics.c:117-130
     if (!a || !require_gpu(a, "variance")) return nullptr;

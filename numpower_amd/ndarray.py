@@ -108,6 +108,7 @@ def _load_host():
         sig[f"NDArray_{name}"] = (_P, [_P, _P])
     sig["NDArray_All"] = (C.c_float, [_P])
     sig["NDArray_Transpose"] = (_P, [_P, C.POINTER(_CDims)])
+    sig["NDArray_ArgMinMaxCommon"] = (_P, [_P, C.c_int, C.c_bool, C.c_bool])
     sig["NDArray_Variance"] = (_P, [_P])
     sig["NDArray_Std"] = (_P, [_P])
     sig["NDArray_Average"] = (_P, [_P, _P])
@@ -215,6 +216,11 @@ class NDArray:
 
     def cpu(self) -> "NDArray":
         return NDArray(self._h.NDArray_ToCPU(self._p))
+
+    @staticmethod
+    def setDevice(device_id: int) -> None:
+        """NDArray::setDevice -> cudaSetDevice in the reference (numpower.c:615-635)."""
+        _lib.check(_lib.load().np_set_device(int(device_id)))
 
     def isGPU(self) -> bool:
         return self._p.contents.device == GPU
@@ -378,6 +384,17 @@ class NDArray:
         arr = (C.c_int * max(len(axes), 1))(*[int(v) for v in axes])
         dims = _CDims(arr, len(axes))
         return NDArray._wrap(h.NDArray_Transpose(x._p, C.byref(dims)))
+
+    # ---- argmax / argmin (PHP_METHOD argmax / argmin, numpower.c:2570-2630) ----
+    @staticmethod
+    def _arg(a, axis, keepdims, is_max):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        ax = 128 if axis is None else int(axis)   # ZEND_NUM_ARGS() == 1 -> axis = 128 (flattened)
+        return NDArray._wrap(h.NDArray_ArgMinMaxCommon(x._p, ax, bool(keepdims), bool(is_max)))
+
+    argmax = staticmethod(lambda a, axis=None, keepdims=False: NDArray._arg(a, axis, keepdims, True))
+    argmin = staticmethod(lambda a, axis=None, keepdims=False: NDArray._arg(a, axis, keepdims, False))
 
     # ---- statistics (PHP_METHOD variance / std / average, numpower.c:2743-2900) ----
     @staticmethod

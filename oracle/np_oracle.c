@@ -398,6 +398,29 @@ float oracle_max(const float *a, long n) {      /* NDArray_Max, ndarray.c:939-95
         if (a[i] > m) m = a[i];
     return m;
 }
+/* float_argmax / float_argmin (calculation.c:9-72) applied along the middle axis of an
+ * outer x len x inner view (NDArray_ArgMinMaxCommon moves the axis last with a transposed copy and
+ * walks contiguous rows, calculation.c:97-181 — same element order per row). */
+void oracle_argreduce(int is_max, const float *in, long outer, long len, long inner, float *out) {
+    for (long o = 0; o < outer; o++)
+        for (long j = 0; j < inner; j++) {
+            const float *ip = in + o * len * inner + j;
+            float mp = *ip;
+            float ind = 0;
+            if (!isnan(mp)) {
+                for (long i = 1; i < len; i++) {
+                    const float v = ip[i * inner];
+                    if (is_max ? (v > mp) : !(mp <= v)) {
+                        mp = v;
+                        ind = (float) i;
+                        if (isnan(mp)) break;
+                    }
+                }
+            }
+            out[o * inner + j] = ind;
+        }
+}
+
 /* NDArray_Transpose (manipulation.c:68-130): permute shape and byte strides of a copy, then
  * NDArray_ToContiguous walks the permuted view element by element (manipulation.c:381-421).
  * perm == NULL reverses the axes.  Returns 0, or -1 with the reference's message. */

@@ -134,6 +134,24 @@ def reduce_all(op: str, x) -> np.float32:
     return np.float32(fn(_ptr(x), x.size))
 
 
+def argreduce(x, axis=None, is_max=True) -> np.ndarray:
+    """NDArray_ArgMinMaxCommon: float indices; axis None = flattened (axis 128 in the reference)."""
+    lib = load()
+    lib.oracle_argreduce.argtypes = [C.c_int, _fp, C.c_long, C.c_long, C.c_long, _fp]
+    lib.oracle_argreduce.restype = None
+    x = _f(x)
+    if axis is None:
+        outer, length, inner, oshape = 1, x.size, 1, ()
+    else:
+        axis = axis % x.ndim
+        outer = int(np.prod(x.shape[:axis], dtype=np.int64))
+        inner = int(np.prod(x.shape[axis + 1:], dtype=np.int64))
+        length, oshape = x.shape[axis], x.shape[:axis] + x.shape[axis + 1:]
+    out = np.empty(outer * inner, dtype=np.float32)
+    lib.oracle_argreduce(1 if is_max else 0, _ptr(x), outer, length, inner, _ptr(out))
+    return out.reshape(oshape)
+
+
 def transpose(x, axes=None) -> np.ndarray:
     """NDArray_Transpose + NDArray_ToContiguous."""
     lib = load()

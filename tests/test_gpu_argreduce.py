@@ -1,0 +1,84 @@
+"""SURVEY.md §8(f) row 2 (second half) on the GPU: argmax / argmin (src/ndmath/calculation.c:9-194),
+exact index parity with the oracle's restatement of float_argmax / float_argmin, including ties
+(first occurrence) and the two functions' different NaN rules."""
+import numpy as np
+import pytest
+
+from numpower_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(7,), (1000,), (1000, 1000), (257, 1001), (3, 5, 64), (100003,)])
+@pytest.mark.parametrize("is_max", [True, False])
+def test_arg_flat_and_axes(shape, is_max, hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform(shape, 81, -5.0, 5.0)
+    flat = x.reshape(-1)
+    flat[::37] = flat[3]                      # ties: the first occurrence must win
+    g = NDArray.array(x).gpu()
+    fn = NDArray.argmax if is_max else NDArray.argmin
+    got = fn(g)
+    assert isinstance(got, float)
+    assert got == float(oracle.argreduce(x, None, is_max))
+    assert got == float(np.argmax(flat) if is_max else np.argmin(flat))
+    for axis in range(len(shape)):
+        got = fn(g, axis)
+        got = got.cpu().numpy() if not isinstance(got, float) else np.float32(got)
+        want = oracle.argreduce(x, axis, is_max)
+        assert got.shape == want.shape
+        assert (got == want).all()
+        assert (got == (np.argmax(x, axis) if is_max else np.argmin(x, axis))).all()
+    if len(shape) == 2:
+        kd = fn(g, 1, True)
+        assert kd.shape() == [shape[0], 1]
+
+
+def test_arg_nan_rules(hip, oracle):
+    from numpower_amd.ndarray import NDArray
+    nan = np.nan
+    cases = [np.array([nan, 1, 5, 2], np.float32),       # argmax: NaN first is maximal -> 0
+             np.array([1, nan, 5, 2], np.float32),       # argmax skips later NaNs -> 2; argmin -> 1
+             np.array([1, 5, nan, nan, -7], np.float32), # argmin: first NaN wins -> 2
+             np.array([-np.inf, nan, 3], np.float32),
+             np.array([np.inf, 2, np.inf], np.float32),
+             np.array([nan, nan], np.float32)]
+    big = synth.uniform((50000,), 5, -1, 1)
+    big[40000] = nan
+    big[123] = 7.0
+    cases.append(big)
+    for x in cases:
+        g = NDArray.array(x).gpu()
+        assert NDArray.argmax(g) == float(oracle.argreduce(x, None, True)), x[:8]
+        assert NDArray.argmin(g) == float(oracle.argreduce(x, None, False)), x[:8]
+    m = np.stack([cases[1], cases[0]])
+    g = NDArray.array(m).gpu()
+    assert (NDArray.argmax(g, 1).cpu().numpy() == oracle.argreduce(m, 1, True)).all()
+    assert (NDArray.argmin(g, 0).cpu().numpy() == oracle.argreduce(m, 0, False)).all()
+
+
+def test_arg_errors(hip):
+    from numpower_amd.ndarray import Error, NDArray
+    g = NDArray.array(np.ones((3, 4), np.float32)).gpu()
+    with pytest.raises(Error, match="Invalid axis parameter"):
+        NDArray.argmax(g, 5)
+    with pytest.raises(Error, match="only computes on the GPU"):
+        NDArray.argmax(NDArray.array(np.ones((3, 4), np.float32)))
+
+
+def test_argmax_1e8(hip):
+    D = hip
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    n = 100_000_000
+    x = synth.uniform((n,), 9, 0.0, 1.0)
+    x[77_777_777] = 2.0
+    x[12_345] = -1.0
+    d = D.DeviceArray.from_host(x)
+    out = D.DeviceArray((1,))
+    check(load().np_argreduce(1, d.ptr, 1, n, 1, out.ptr))
+    assert out.to_host()[0] == np.float32(77_777_777)
+    check(load().np_argreduce(0, d.ptr, 1, n, 1, out.ptr))
+    assert out.to_host()[0] == np.float32(12_345)
+    d.free()
+    del C
