@@ -251,6 +251,33 @@ def bench_extras(dist: Dist, steps, warmup):
                  lambda: D.binary("greater", da, "full", db, "full", 1, N, out=do), steps, warmup, dist)
     r["parity_ok"] = bool((do.to_host().reshape(-1) == (a > b).astype(np.float32)).all())
     ex["greater_1e8"] = r
+    # exp(a) * b + 2 as ONE fused kernel (12 B/elem) vs three launches
+    from numpower_amd._lib import BINARY_OPS, UNARY_OPS, FusedOp, check
+    prog = (FusedOp * 3)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0),
+                         FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 1, N // 8 * 8),
+                         FusedOp(1, BINARY_OPS["add"], 2, 0, 0, 0, 0, 0))
+    two = C.c_float(2.0)
+    ptrs = (C.c_void_p * 3)(da.ptr, db.ptr, C.cast(C.pointer(two), C.c_void_p))
+    kinds = (C.c_int * 3)(0, 0, 4)
+    lib = load()
+    r = hbm_case("exp(a)*b+2 fused, 1e8 (§8f row 4)", 12.0 * N,
+                 lambda: check(lib.np_fused_chain(ptrs, kinds, 3, prog, 3, do.ptr, N)), steps, warmup, dist)
+    fused_out = do.to_host().reshape(-1)
+    tmp, tmp2 = D.DeviceArray((N,)), D.DeviceArray((N,))
+    stwo = D.DeviceArray.from_host(np.float32([2.0]))
+
+    def unfused():   # what three PHP-level ops cost: three launches, two temporaries
+        D.unary("exp", da, out=tmp)
+        D.binary("multiply", tmp, "full", db, "full", 1, N, quirk_numel_a=N, out=tmp2)
+        D.binary("add", tmp2, "full", stwo, "scalar", 1, N, out=tmp)
+
+    _, ev_ms = timed(dist, unfused, steps, warmup)
+    r["unfused_ms_per_chain"] = ev_ms / steps
+    r["speedup_vs_unfused"] = (ev_ms / steps) / r["ms_per_launch"]
+    r["parity_ok"] = bool((fused_out.view(np.uint32) == tmp.to_host().reshape(-1).view(np.uint32)).all())
+    ex["fused_chain_1e8"] = r
+    tmp.free()
+    tmp2.free()
 
     for op, seed, lo, hi in (("exp", 7, -10.0, 10.0), ("log", 8, 1e-3, 1e3)):
         x = synth.uniform((N,), seed, lo, hi)

@@ -166,6 +166,31 @@ typedef enum np_unary_op {
  * NDArray_Copy (one 8 B/elem pass instead of copy + in-place = 16 B/elem). */
 int np_unary(int op, const float *in, float *out, size_t n, float p0, float p1);
 
+/* ---- fused elementwise chains --------------------------------------- */
+
+/* One pass over HBM for a whole chain of elementwise ops:
+ *     acc = inputs[0];  for each op:  acc = f(acc)            (NP_FUSED_UNARY,  op = np_unary_op)
+ *                                     acc = acc (op) in[k]    (NP_FUSED_BINARY, op = np_binary_op,
+ *                                     acc = in[k] (op) acc     operand = k, swap = 0 / 1)
+ *     out[i] = acc
+ * e.g. nd::exp($a) * $b + 2 costs 12 B/elem instead of 8 + 12 + 8 = 28 B/elem and two temporaries
+ * (one allocation + one full round trip per PHP-level op in the reference, numpower.c:193-229).
+ * Every step runs the same arithmetic as np_unary / np_binary, so the result is bit-identical to
+ * the unfused sequence; flags/body_end have the meaning they have in np_binary.  Inputs are NP_FULL
+ * arrays of n elements or NP_HOST_SCALAR values; at most 6 inputs and 12 ops per chain. */
+typedef enum np_fused_kind { NP_FUSED_UNARY = 0, NP_FUSED_BINARY = 1 } np_fused_kind;
+typedef struct np_fused_op {
+    int kind;      /* np_fused_kind */
+    int op;        /* np_unary_op or np_binary_op */
+    int operand;   /* binary: index into inputs[] of the other operand */
+    int swap;      /* binary: 0 = acc (op) operand, 1 = operand (op) acc */
+    float p0, p1;  /* unary parameters (clip min/max, round decimals) */
+    unsigned flags;     /* NP_QUIRK_AVX_BODY or 0 */
+    size_t body_end;    /* see np_binary */
+} np_fused_op;
+int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inputs,
+                   const np_fused_op *ops, int n_ops, float *out, size_t n);
+
 /* ---- reductions -------------------------------------------------------------------------- */
 
 typedef enum np_reduce_op {

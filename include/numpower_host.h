@@ -125,6 +125,13 @@ typedef struct NDArray_Dims {   /* src/ndarray.h:40-43 */
 /* New contiguous array with the axes permuted (NULL = reverse all axes). */
 NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute);
 
+/* ---- fused elementwise chains ----
+ * Evaluates acc = inputs[0]; acc = op_k(acc [, inputs[operand_k]]) ... in one kernel; `ops` uses
+ * np_fused_op of np_hip.h (flags/body_end are filled in here).  Bit-identical to calling the
+ * stand-alone entry points one after the other. */
+#include "np_hip.h"
+NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops);
+
 /* ---- argmax / argmin (src/ndmath/calculation.c:73-194) ----
  * axis = 128 (NDARRAY_MAX_DIMS) reduces the flattened array; indices are returned as floats. */
 #ifndef __cplusplus

@@ -28,6 +28,14 @@ REDUCE_OPS = {"sum": 0, "prod": 1, "min": 2, "max": 3, "mean": 4}
 
 _f32p = C.c_void_p   # device pointers travel as integers
 
+NP_FUSED_UNARY, NP_FUSED_BINARY = 0, 1
+
+
+class FusedOp(C.Structure):
+    """np_fused_op of include/np_hip.h."""
+    _fields_ = [("kind", C.c_int), ("op", C.c_int), ("operand", C.c_int), ("swap", C.c_int),
+                ("p0", C.c_float), ("p1", C.c_float), ("flags", C.c_uint), ("body_end", C.c_size_t)]
+
 # name -> (restype, argtypes).  Every symbol include/np_hip.h declares is listed here; the CPU
 # test-suite checks that the built library exports each of them.
 PROTOTYPES = {
@@ -59,6 +67,8 @@ PROTOTYPES = {
     "np_binary": (C.c_int, [C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_size_t,
                             C.c_size_t, C.c_uint, C.c_size_t]),
     "np_unary": (C.c_int, [C.c_int, _f32p, _f32p, C.c_size_t, C.c_float, C.c_float]),
+    "np_fused_chain": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(FusedOp),
+                                 C.c_int, _f32p, C.c_size_t]),
     "np_reduce_all": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.POINTER(C.c_float)]),
     "np_reduce_all_dev": (C.c_int, [C.c_int, _f32p, C.c_size_t, _f32p]),
     "np_all": (C.c_int, [_f32p, C.c_size_t, C.c_uint, C.POINTER(C.c_int)]),

@@ -357,21 +357,12 @@ int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size
     binary_vec_kernel<OP, AK, BK, QUIRK, U, NT, I><<<grid, 256, 0, s>>>(a, b, out, nvec,   \
                                                                          cols4, tail, (I)n, \
                                                                          (I)body_end, ha, hb)
-    if (c.nt) {
-        switch (c.unroll) {
-            case 1: NP_BV(1, true); break;
-            case 2: NP_BV(2, true); break;
-            case 8: NP_BV(8, true); break;
-            default: NP_BV(4, true); break;
-        }
-    } else {
-        switch (c.unroll) {
-            case 1: NP_BV(1, false); break;
-            case 2: NP_BV(2, false); break;
-            case 8: NP_BV(8, false); break;
-            default: NP_BV(4, false); break;
-        }
-    }
+    // only the measured-useful variants are instantiated (the full unroll x nt sweep lives in
+    // tools/explore/add_bw.hip): UNROLL 2 (default) and 4, non-temporal
+    if (c.unroll == 4)
+        NP_BV(4, true);
+    else
+        NP_BV(2, true);
 #undef NP_BV
     NP_LAUNCH_CHECK("binary_vec_kernel");
     return NP_OK;
@@ -447,21 +438,10 @@ int launch_unary(const float *in, float *out, size_t n, float p0, float p1) {
         const unsigned grid = grid_for(n / 4 + 1, c.unroll, c.blocks_per_cu);
 #define NP_UV(U, NT) \
     unary_vec_kernel<OP, U, NT, I><<<grid, 256, 0, s>>>(in, out, nvec, tail, (I)n, p0, p1)
-        if (c.nt) {
-            switch (c.unroll) {
-                case 1: NP_UV(1, true); break;
-                case 2: NP_UV(2, true); break;
-                case 8: NP_UV(8, true); break;
-                default: NP_UV(4, true); break;
-            }
-        } else {
-            switch (c.unroll) {
-                case 1: NP_UV(1, false); break;
-                case 2: NP_UV(2, false); break;
-                case 8: NP_UV(8, false); break;
-                default: NP_UV(4, false); break;
-            }
-        }
+        if (c.unroll == 4)
+            NP_UV(4, true);
+        else
+            NP_UV(2, true);
 #undef NP_UV
         NP_LAUNCH_CHECK("unary_vec_kernel");
         return NP_OK;
@@ -478,9 +458,167 @@ int dispatch_unary(const float *in, float *out, size_t n, float p0, float p1) {
     return launch_unary<OP, uint64_t>(in, out, n, p0, p1);
 }
 
+// ------------------------------------------------------------------------------------------
+// fused elementwise chains
+// ------------------------------------------------------------------------------------------
+//
+// acc = in[0]; for each op: acc = f(acc) | acc (op) in[k] | in[k] (op) acc; out = acc — ONE pass
+// over HBM for a whole expression like exp(a) * b + 2 instead of one pass (and one temporary) per
+// PHP-level op.  Every step goes through the same binary_apply / unary_apply bodies as the
+// stand-alone kernels (contraction is off in this file), so a fused chain is bit-identical to the
+// unfused sequence.  Inputs are full arrays of n elements or host scalars.
+constexpr int FUSED_MAX_OPS = 12;
+constexpr int FUSED_MAX_IN = 6;
+
+struct FusedArgs {
+    int n_ops, n_in;
+    const float *in[FUSED_MAX_IN];   // null -> scalar[i]
+    float scalar[FUSED_MAX_IN];
+    np_fused_op ops[FUSED_MAX_OPS];
+};
+
+__device__ __forceinline__ float unary_dispatch(int op, float x, float p0, float p1) {
+#define NP_UD(OP_) case OP_: return unary_apply<OP_>(x, p0, p1)
+    switch (op) {
+        NP_UD(NP_ABS); NP_UD(NP_SQRT); NP_UD(NP_EXP); NP_UD(NP_EXP2); NP_UD(NP_EXPM1); NP_UD(NP_LOG);
+        NP_UD(NP_LOG2); NP_UD(NP_LOG10); NP_UD(NP_LOG1P); NP_UD(NP_LOGB); NP_UD(NP_SIN); NP_UD(NP_COS);
+        NP_UD(NP_TAN); NP_UD(NP_ARCSIN); NP_UD(NP_ARCCOS); NP_UD(NP_ARCTAN); NP_UD(NP_DEGREES);
+        NP_UD(NP_RADIANS); NP_UD(NP_SINH); NP_UD(NP_COSH); NP_UD(NP_TANH); NP_UD(NP_ARCSINH);
+        NP_UD(NP_ARCCOSH); NP_UD(NP_ARCTANH); NP_UD(NP_RINT); NP_UD(NP_FIX); NP_UD(NP_FLOOR);
+        NP_UD(NP_CEIL); NP_UD(NP_TRUNC); NP_UD(NP_SINC); NP_UD(NP_NEGATE); NP_UD(NP_SIGN); NP_UD(NP_CLIP);
+        NP_UD(NP_ROUND); NP_UD(NP_RSQRT); NP_UD(NP_POSITIVE); NP_UD(NP_RECIPROCAL);
+        default: return x;
+    }
+#undef NP_UD
+}
+
+__device__ __forceinline__ float binary_dispatch(int op, float a, float b, bool quirk, bool body) {
+#define NP_BD(OP_) case OP_: return quirk ? binary_apply<OP_, true>(a, b, body) : binary_apply<OP_, false>(a, b, body)
+    switch (op) {
+        NP_BD(NP_ADD); NP_BD(NP_SUBTRACT); NP_BD(NP_MULTIPLY); NP_BD(NP_DIVIDE); NP_BD(NP_MOD); NP_BD(NP_POW);
+        NP_BD(NP_ARCTAN2); NP_BD(NP_EQUAL); NP_BD(NP_NOT_EQUAL); NP_BD(NP_GREATER); NP_BD(NP_GREATER_EQUAL);
+        NP_BD(NP_LESS); NP_BD(NP_LESS_EQUAL);
+        default: return a;
+    }
+#undef NP_BD
+}
+
+template <bool VEC, typename I>
+__global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs f, float *__restrict__ out, I n) {
+    const I nvec = VEC ? n / 4 : 0;
+    const I stride = (I)gridDim.x * blockDim.x;
+    const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    auto run = [&](const float *r, I index) -> float {
+        float acc = r[0];
+        for (int k = 0; k < f.n_ops; ++k) {
+            const np_fused_op &o = f.ops[k];
+            if (o.kind == NP_FUSED_UNARY) {
+                acc = unary_dispatch(o.op, acc, o.p0, o.p1);
+            } else {
+                // select instead of r[o.operand]: a runtime-indexed register array would be
+                // demoted to scratch memory
+                float other = r[0];
+#pragma unroll
+                for (int i = 1; i < FUSED_MAX_IN; ++i) other = (o.operand == i) ? r[i] : other;
+                const bool body = (size_t)index < o.body_end;
+                acc = o.swap ? binary_dispatch(o.op, other, acc, o.flags & NP_QUIRK_AVX_BODY, body)
+                             : binary_dispatch(o.op, acc, other, o.flags & NP_QUIRK_AVX_BODY, body);
+            }
+        }
+        return acc;
+    };
+    for (I v = tid; v < nvec; v += stride) {
+        v4f x[FUSED_MAX_IN];
+#pragma unroll
+        for (int i = 0; i < FUSED_MAX_IN; ++i) {
+            if (i < f.n_in) {
+                if (f.in[i])
+                    x[i] = __builtin_nontemporal_load((const v4f *)(f.in[i] + (size_t)v * 4));
+                else
+                    x[i] = v4f{f.scalar[i], f.scalar[i], f.scalar[i], f.scalar[i]};
+            }
+        }
+        v4f res;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float r[FUSED_MAX_IN];
+#pragma unroll
+            for (int i = 0; i < FUSED_MAX_IN; ++i) r[i] = (i < f.n_in) ? x[i][e] : 0.0f;
+            res[e] = run(r, v * 4 + e);
+        }
+        __builtin_nontemporal_store(res, (v4f *)(out + (size_t)v * 4));
+    }
+    // scalar path: everything when !VEC, the ragged tail otherwise
+    for (I i = nvec * 4 + tid; i < n; i += stride) {
+        float r[FUSED_MAX_IN];
+#pragma unroll
+        for (int k = 0; k < FUSED_MAX_IN; ++k) r[k] = (k < f.n_in) ? (f.in[k] ? f.in[k][i] : f.scalar[k]) : 0.0f;
+        out[i] = run(r, i);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inputs,
+                   const np_fused_op *ops, int n_ops, float *out, size_t n) {
+    if (n_inputs < 1 || n_inputs > FUSED_MAX_IN)
+        return np::fail(NP_ERR_INVALID, "np_fused_chain: 1..%d inputs supported", FUSED_MAX_IN);
+    if (n_ops < 0 || n_ops > FUSED_MAX_OPS)
+        return np::fail(NP_ERR_INVALID, "np_fused_chain: at most %d ops per chain", FUSED_MAX_OPS);
+    if (!inputs || !input_kinds || (n_ops > 0 && !ops) || !out)
+        return np::fail(NP_ERR_INVALID, "np_fused_chain: null pointer");
+    if (n == 0) return NP_OK;
+    if (int rc = np::ensure_init()) return rc;
+    FusedArgs f;
+    f.n_ops = n_ops;
+    f.n_in = n_inputs;
+    bool vec = aligned16(out);
+    for (int i = 0; i < FUSED_MAX_IN; ++i) {
+        f.in[i] = nullptr;
+        f.scalar[i] = 0.0f;
+    }
+    for (int i = 0; i < n_inputs; ++i) {
+        if (!inputs[i]) return np::fail(NP_ERR_INVALID, "np_fused_chain: null input %d", i);
+        if (input_kinds[i] == NP_HOST_SCALAR) {
+            f.scalar[i] = *inputs[i];
+        } else if (input_kinds[i] == NP_FULL) {
+            f.in[i] = inputs[i];
+            vec = vec && aligned16(inputs[i]);
+        } else {
+            return np::fail(NP_ERR_INVALID, "np_fused_chain: inputs must be NP_FULL or NP_HOST_SCALAR");
+        }
+    }
+    for (int k = 0; k < n_ops; ++k) {
+        const np_fused_op &o = ops[k];
+        if (o.kind == NP_FUSED_UNARY) {
+            if (o.op < 0 || o.op >= NP_UNARY_OP_COUNT) return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown unary op %d", o.op);
+        } else if (o.kind == NP_FUSED_BINARY) {
+            if (o.op < 0 || o.op >= NP_BINARY_OP_COUNT) return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown binary op %d", o.op);
+            if (o.operand < 0 || o.operand >= n_inputs) return np::fail(NP_ERR_INVALID, "np_fused_chain: operand index out of range");
+        } else {
+            return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown op kind %d", o.kind);
+        }
+        f.ops[k] = o;
+        if (o.kind == NP_FUSED_UNARY && o.op == NP_ROUND) f.ops[k].p0 = powf(10.0f, o.p0);   // as np_unary
+    }
+    const unsigned grid = grid_for(n / 4 + 1, 1, 0);
+    hipStream_t s = np::stream();
+    if (n < (size_t(1) << 31)) {
+        if (vec)
+            fused_chain_kernel<true, uint32_t><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);
+        else
+            fused_chain_kernel<false, uint32_t><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);
+    } else {
+        if (vec)
+            fused_chain_kernel<true, uint64_t><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);
+        else
+            fused_chain_kernel<false, uint64_t><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);
+    }
+    NP_LAUNCH_CHECK("fused_chain_kernel");
+    return NP_OK;
+}
 
 int np_elementwise_set_variant(int variant) {
     g_variant = variant;

@@ -497,6 +497,66 @@ NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute) {
     return ret;
 }
 
+/* ---- fused elementwise chains ---- */
+// What a Zend glue would flush when a lazily built expression reaches toArray()/cpu()/a reduction:
+// inputs[0] is the GPU array the chain starts from, the other inputs are GPU arrays with the same
+// number of elements or 0-d CPU scalars.  Quirk flags are set exactly as the stand-alone
+// NDArray_*_Float / comparison entry points set them, so the fused result is bit-identical.
+NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops) {
+    if (!inputs || n_inputs < 1 || !inputs[0]) return nullptr;
+    NDArray *first = inputs[0];
+    if (NDArray_NDIM(first) == 0) {
+        throw_error("fused chain must start from an array");
+        return nullptr;
+    }
+    if (!require_gpu(first, "fused elementwise chain")) return nullptr;
+    const long n = NDArray_NUMELEMENTS(first);
+    const float *ptrs[16];
+    int kinds[16];
+    if (n_inputs > 16 || n_ops > 64) {
+        throw_error("fused chain too long");
+        return nullptr;
+    }
+    for (int i = 0; i < n_inputs; ++i) {
+        NDArray *x = inputs[i];
+        if (!x) return nullptr;
+        if (NDArray_NDIM(x) == 0 && NDArray_DEVICE(x) == NDARRAY_DEVICE_CPU) {
+            kinds[i] = NP_HOST_SCALAR;
+        } else {
+            if (NDArray_DEVICE(x) != NDARRAY_DEVICE_GPU) {
+                throw_error("Device mismatch, both NDArray MUST be in the same device.");
+                return nullptr;
+            }
+            if (NDArray_NUMELEMENTS(x) != n) {
+                throw_error("Can't broadcast arrays.");
+                return nullptr;
+            }
+            kinds[i] = NP_FULL;
+        }
+        ptrs[i] = NDArray_FDATA(x);
+    }
+    np_fused_op prog[64];
+    for (int k = 0; k < n_ops; ++k) {
+        prog[k] = ops[k];
+        prog[k].flags = 0;
+        prog[k].body_end = 0;
+        if (ops[k].kind == NP_FUSED_BINARY) {
+            const int op = ops[k].op;
+            if (op == NP_MULTIPLY || op == NP_MOD || op == NP_EQUAL || op == NP_NOT_EQUAL) {
+                prog[k].flags = NP_QUIRK_AVX_BODY;
+                prog[k].body_end = np_avx_body_end((size_t)n);   // both operands have n elements here
+            }
+        }
+    }
+    NDArray *result = new_array(first->dimensions, first->ndim, NDARRAY_DEVICE_GPU, false);
+    if (!result) return nullptr;
+    if (!dev_ok(np_fused_chain(ptrs, kinds, n_inputs, prog, n_ops, NDArray_FDATA(result), (size_t)n))) {
+        NDArray_FREE(result);
+        return nullptr;
+    }
+    return result;
+}
+
 /* ---- argmax / argmin (calculation.c:73-194) ---- */
 // axis == NDARRAY_MAX_DIMS (128) means "flattened" (numpower.c:2588-2590); the reference moves the
 // axis last with a Transpose copy and walks rows — here the (outer, axis, inner) view is reduced

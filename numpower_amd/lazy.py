@@ -1,0 +1,103 @@
+"""Caller-side fusion of elementwise chains.
+
+In the reference every PHP-level op — `nd::exp($a)`, `* $b`, `+ 2` — allocates a result and makes
+a full round trip through memory (ndarray_do_operation_ex, numpower.c:193-229).  `Lazy` is what a
+Zend glue would keep behind an `NDArray` object instead: the chain of pending elementwise ops,
+flushed as ONE kernel (NDArray_FusedChain -> np_fused_chain) when a value is needed.
+
+    y = (a.lazy().exp() * b + 2.0).eval()        # one pass over HBM, bit-identical to
+    y = (NDArray.exp(a) * b) + 2.0               # three passes and two temporaries
+
+Chains are linear: acc = f_k(... f_1(a)); binary steps take another GPU array of the same size or
+a Python number.  Anything else (row/column broadcast, reductions, matmul) is evaluated eagerly by
+NDArray as before.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _lib
+from ._lib import BINARY_OPS, NP_FUSED_BINARY, NP_FUSED_UNARY, UNARY_OPS, FusedOp
+from .ndarray import Error, NDArray, _load_host, _P
+
+MAX_OPS = 12
+MAX_INPUTS = 6
+
+
+class Lazy:
+    def __init__(self, first: NDArray):
+        if not isinstance(first, NDArray):
+            raise Error("Lazy chains start from an NDArray")
+        self.inputs = [first]
+        self.ops = []
+
+    # ---- building -----------------------------------------------------------------------------
+    def _flush_if_full(self, extra_inputs=0):
+        if len(self.ops) >= MAX_OPS or len(self.inputs) + extra_inputs > MAX_INPUTS:
+            done = self.eval()
+            self.inputs, self.ops = [done], []
+
+    def _unary(self, name, p0=0.0, p1=0.0):
+        self._flush_if_full()
+        self.ops.append(FusedOp(NP_FUSED_UNARY, UNARY_OPS[name], 0, 0, float(p0), float(p1), 0, 0))
+        return self
+
+    def _binary(self, name, other, swap):
+        if isinstance(other, Lazy):
+            other = other.eval()
+        self._flush_if_full(1)
+        if isinstance(other, NDArray):
+            operand = None
+            for i, x in enumerate(self.inputs):      # reuse an input that is already bound
+                if x is other:
+                    operand = i
+            if operand is None:
+                self.inputs.append(other)
+                operand = len(self.inputs) - 1
+        elif isinstance(other, (int, float)) and not isinstance(other, bool):
+            scalar, _ = NDArray._coerce(other)        # 0-d CPU scalar, as ZVAL_TO_NDARRAY makes it
+            self.inputs.append(scalar)
+            operand = len(self.inputs) - 1
+        else:
+            raise Error("argument must be an array, long, double, gdimage or ndarray.")
+        self.ops.append(FusedOp(NP_FUSED_BINARY, BINARY_OPS[name], operand, 1 if swap else 0, 0.0, 0.0, 0, 0))
+        return self
+
+    def __add__(self, o): return self._binary("add", o, False)
+    def __radd__(self, o): return self._binary("add", o, True)
+    def __sub__(self, o): return self._binary("subtract", o, False)
+    def __rsub__(self, o): return self._binary("subtract", o, True)
+    def __mul__(self, o): return self._binary("multiply", o, False)
+    def __rmul__(self, o): return self._binary("multiply", o, True)
+    def __truediv__(self, o): return self._binary("divide", o, False)
+    def __rtruediv__(self, o): return self._binary("divide", o, True)
+    def __mod__(self, o): return self._binary("mod", o, False)
+    def __pow__(self, o): return self._binary("pow", o, False)
+
+    def clip(self, min, max): return self._unary("clip", min, max)
+    def round(self, precision=0): return self._unary("round", precision)
+
+    def __getattr__(self, name):
+        if name in UNARY_OPS:
+            return lambda: self._unary(name)
+        if name in BINARY_OPS:
+            return lambda other: self._binary(name, other, False)
+        raise AttributeError(name)
+
+    # ---- flushing -------------------------------------------------------------------------------
+    def eval(self) -> NDArray:
+        """Run the pending chain as one kernel and return the resulting GPU array."""
+        h = _load_host()
+        h.NDArray_FusedChain.restype = _P
+        h.NDArray_FusedChain.argtypes = [C.POINTER(_P), C.c_int, C.POINTER(FusedOp), C.c_int]
+        arr = (_P * len(self.inputs))(*[x._p for x in self.inputs])
+        ops = (FusedOp * max(len(self.ops), 1))(*self.ops)
+        return NDArray._wrap(h.NDArray_FusedChain(arr, len(self.inputs), ops, len(self.ops)))
+
+
+def lazy(a: NDArray) -> Lazy:
+    return Lazy(a)
+
+
+NDArray.lazy = lambda self: Lazy(self)   # $a->lazy() in the PHP surface this stands in for
+del _lib

@@ -1,0 +1,76 @@
+"""SURVEY.md §8(f) row 4 on the GPU: fused elementwise chains are bit-identical to the same ops
+issued one by one through the stand-alone entry points (and therefore to the oracle wherever those
+are), for every op kind incl. the quirk-carrying ones, at aligned, ragged and view shapes."""
+import numpy as np
+import pytest
+
+from numpower_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(x):
+    return np.asarray(x, dtype=np.float32).view(np.uint32)
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and ((_bits(a) == _bits(b)) | (np.isnan(a) & np.isnan(b))).all()
+
+
+@pytest.mark.parametrize("shape", [(1000, 1000), (257, 1001), (3, 5), (64, 4096)])
+def test_fused_equals_unfused(shape, hip):
+    from numpower_amd.lazy import Lazy   # noqa: F401  (installs NDArray.lazy)
+    from numpower_amd.ndarray import NDArray
+    a = synth.uniform(shape, 91, -2.0, 2.0)
+    b = synth.uniform(shape, 92, 0.5, 2.0)
+    c = synth.uniform(shape, 93, -1.0, 1.0)
+    a.reshape(-1)[::7] = 0.0          # zero products: multiply's -0.0 / +0.0 quirk must survive fusion
+    ga, gb, gc = NDArray.array(a).gpu(), NDArray.array(b).gpu(), NDArray.array(c).gpu()
+
+    fused = (ga.lazy().exp() * gb + 2.0).eval()
+    plain = (NDArray.exp(ga) * gb) + 2.0
+    assert _same(fused.cpu().numpy(), plain.cpu().numpy())
+
+    fused = ((ga.lazy() * gc) % gb).abs().sqrt().eval()
+    plain = NDArray.sqrt(NDArray.abs((ga * gc) % gb))
+    assert _same(fused.cpu().numpy(), plain.cpu().numpy())
+
+    fused = (1.5 - ga.lazy()).clip(-1.0, 2.0).round(2).eval()
+    plain = NDArray.round(NDArray.clip(1.5 - ga, -1.0, 2.0), 2)
+    assert _same(fused.cpu().numpy(), plain.cpu().numpy())
+
+    fused = (ga.lazy().equal(gc) + ga.lazy().greater(gb).eval()).eval()
+    plain = NDArray.equal(ga, gc) + NDArray.greater(ga, gb)
+    assert _same(fused.cpu().numpy(), plain.cpu().numpy())
+
+    # the same array bound twice is loaded once
+    lz = ga.lazy() * ga + ga
+    assert len(lz.inputs) == 1
+    assert _same(lz.eval().cpu().numpy(), ((ga * ga) + ga).cpu().numpy())
+
+
+def test_long_chain_splits_and_views(hip):
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform((6, 1001), 3, 0.5, 1.5)
+    g = NDArray.array(x).gpu()
+    row, other = g[1], g[2]                      # 4-byte aligned views: scalar path of the kernel
+    lz = row.lazy()
+    plain = row
+    for k in range(20):                          # longer than one chain: flushes in between
+        lz = (lz * other + 0.25).sqrt()
+        plain = NDArray.sqrt(plain * other + 0.25)
+    assert _same(lz.eval().cpu().numpy(), plain.cpu().numpy())
+
+
+def test_fused_errors(hip):
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    from numpower_amd.ndarray import Error, NDArray
+    a = NDArray.array(np.ones((4, 6), np.float32)).gpu()
+    with pytest.raises(Error, match="Can't broadcast arrays."):
+        (a.lazy() + NDArray.array(np.ones((6,), np.float32)).gpu()).eval()
+    with pytest.raises(Error, match="Device mismatch"):
+        (a.lazy() + NDArray.array(np.ones((4, 6), np.float32))).eval()
+    with pytest.raises(Error, match="only computes on the GPU"):
+        NDArray.array(np.ones((4, 6), np.float32)).lazy().exp().eval()
