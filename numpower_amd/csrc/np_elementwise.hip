@@ -470,15 +470,61 @@ int dispatch_unary(const float *in, float *out, size_t n, float p0, float p1) {
 constexpr int FUSED_MAX_OPS = 12;
 constexpr int FUSED_MAX_IN = 6;
 
-struct FusedArgs {
-    int n_ops, n_in;
-    const float *in[FUSED_MAX_IN];   // null -> scalar[i]
-    float scalar[FUSED_MAX_IN];
-    np_fused_op ops[FUSED_MAX_OPS];
+// What the kernel interprets (built on the host from np_fused_op): operands are resolved to
+// pointers / values up front so a step costs one uniform load of its descriptor.
+enum { FUSED_SRC_SCALAR = 0, FUSED_SRC_STREAM = 1, FUSED_SRC_INPUT0 = 2 };
+struct FusedStep {
+    int kind, op, swap, quirk;
+    float p0, p1, scalar;
+    int src_kind;
+    const float *prefetch;   // array whose load is started when this step consumes its streamed operand
+    size_t body_end;
 };
+struct FusedArgs {
+    int n_ops;
+    float scalar0;
+    const float *in0;              // null -> scalar0
+    const float *first_prefetch;   // first streamed operand of the chain (null: none)
+    FusedStep ops[FUSED_MAX_OPS];
+};
+// The kernel indexes ops[] with a run-time k.  On a by-value kernel parameter that makes the compiler
+// copy the whole struct to scratch (private memory) first; reading it through the kernarg segment
+// pointer (constant address space) keeps every descriptor fetch a scalar load.
+typedef const __attribute__((address_space(4))) FusedArgs *FusedArgsK;
 
-__device__ __forceinline__ float unary_dispatch(int op, float x, float p0, float p1) {
-#define NP_UD(OP_) case OP_: return unary_apply<OP_>(x, p0, p1)
+constexpr bool binary_has_quirk(int op) {
+    return op == NP_MULTIPLY || op == NP_MOD || op == NP_EQUAL || op == NP_NOT_EQUAL;
+}
+
+// One op applied to all N elements a thread holds: the op switch below runs once per op per
+// thread-trip (uniform, scalar branch), not once per element.
+template <int OP, int N>
+__device__ __forceinline__ void unary_all(float (&acc)[N], float p0, float p1) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = unary_apply<OP>(acc[e], p0, p1);
+}
+
+template <int OP, int N>
+__device__ __forceinline__ void binary_all(float (&acc)[N], const float (&oth)[N], bool swap, bool quirk,
+                                           const bool (&body)[N]) {
+    if (binary_has_quirk(OP) && quirk) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float x = swap ? oth[e] : acc[e], y = swap ? acc[e] : oth[e];
+            acc[e] = binary_apply<OP, binary_has_quirk(OP)>(x, y, body[e]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float x = swap ? oth[e] : acc[e], y = swap ? acc[e] : oth[e];
+            acc[e] = binary_apply<OP, false>(x, y, false);
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void unary_dispatch(int op, float (&acc)[N], float p0, float p1) {
+#define NP_UD(OP_) case OP_: unary_all<OP_, N>(acc, p0, p1); break
     switch (op) {
         NP_UD(NP_ABS); NP_UD(NP_SQRT); NP_UD(NP_EXP); NP_UD(NP_EXP2); NP_UD(NP_EXPM1); NP_UD(NP_LOG);
         NP_UD(NP_LOG2); NP_UD(NP_LOG10); NP_UD(NP_LOG1P); NP_UD(NP_LOGB); NP_UD(NP_SIN); NP_UD(NP_COS);
@@ -487,73 +533,123 @@ __device__ __forceinline__ float unary_dispatch(int op, float x, float p0, float
         NP_UD(NP_ARCCOSH); NP_UD(NP_ARCTANH); NP_UD(NP_RINT); NP_UD(NP_FIX); NP_UD(NP_FLOOR);
         NP_UD(NP_CEIL); NP_UD(NP_TRUNC); NP_UD(NP_SINC); NP_UD(NP_NEGATE); NP_UD(NP_SIGN); NP_UD(NP_CLIP);
         NP_UD(NP_ROUND); NP_UD(NP_RSQRT); NP_UD(NP_POSITIVE); NP_UD(NP_RECIPROCAL);
-        default: return x;
+        default: break;
     }
 #undef NP_UD
 }
 
-__device__ __forceinline__ float binary_dispatch(int op, float a, float b, bool quirk, bool body) {
-#define NP_BD(OP_) case OP_: return quirk ? binary_apply<OP_, true>(a, b, body) : binary_apply<OP_, false>(a, b, body)
+template <int N>
+__device__ __forceinline__ void binary_dispatch(int op, float (&acc)[N], const float (&oth)[N], bool swap,
+                                                bool quirk, const bool (&body)[N]) {
+#define NP_BD(OP_) case OP_: binary_all<OP_, N>(acc, oth, swap, quirk, body); break
     switch (op) {
         NP_BD(NP_ADD); NP_BD(NP_SUBTRACT); NP_BD(NP_MULTIPLY); NP_BD(NP_DIVIDE); NP_BD(NP_MOD); NP_BD(NP_POW);
         NP_BD(NP_ARCTAN2); NP_BD(NP_EQUAL); NP_BD(NP_NOT_EQUAL); NP_BD(NP_GREATER); NP_BD(NP_GREATER_EQUAL);
         NP_BD(NP_LESS); NP_BD(NP_LESS_EQUAL);
-        default: return a;
+        default: break;
     }
 #undef NP_BD
 }
 
-template <bool VEC, typename I>
-__global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs f, float *__restrict__ out, I n) {
-    const I nvec = VEC ? n / 4 : 0;
+// U slots of G contiguous elements per thread (G = 4: one float4 per slot), N = U*G values held in
+// registers.  Slot v of a span starts at element elem0 + v*G.  Operand arrays are streamed: the
+// load of the next array operand is issued as soon as the previous one has been consumed, so it is
+// in flight while the steps in between compute; with input 0 that keeps two loads outstanding per
+// thread without holding every input in registers (which cost occupancy: 6 inputs x 8 values).
+template <int U, int G, typename I>
+__device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p, const I (&first)[U],
+                                            const bool (&live)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if constexpr (G == 4) {
+            v4f t = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+            if (live[u]) t = __builtin_nontemporal_load((const v4f *)(p + (size_t)first[u]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[u * 4 + e] = t[e];
+        } else {
+            dst[u] = live[u] ? __builtin_nontemporal_load(p + (size_t)first[u]) : 0.0f;
+        }
+    }
+}
+
+template <int U, int G, typename I>
+__device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out, I elem0, I nslots, I tid,
+                                           I stride) {
+    constexpr int N = U * G;
+    const int n_ops = f->n_ops;
+    const float *in0 = f->in0, *first_prefetch = f->first_prefetch;
+    const float scalar0 = f->scalar0;
+    for (I base = 0; base < nslots; base += stride * U) {
+        I first[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const I v = base + (I)u * stride + tid;   // coalesced per u
+            live[u] = v < nslots;
+            first[u] = elem0 + v * G;
+        }
+        float x0[N], acc[N], nxt[N];
+        if (in0) {
+            fused_fetch<U, G, I>(x0, in0, first, live);
+        } else {
+#pragma unroll
+            for (int e = 0; e < N; ++e) x0[e] = scalar0;
+        }
+        if (first_prefetch) {
+            fused_fetch<U, G, I>(nxt, first_prefetch, first, live);
+        } else {
+#pragma unroll
+            for (int e = 0; e < N; ++e) nxt[e] = 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] = x0[e];
+        for (int k = 0; k < n_ops; ++k) {
+            struct {
+                int kind, op, swap, quirk, src_kind;
+                float p0, p1, scalar;
+                const float *prefetch;
+                size_t body_end;
+            } o = {f->ops[k].kind, f->ops[k].op, f->ops[k].swap, f->ops[k].quirk, f->ops[k].src_kind,
+                   f->ops[k].p0, f->ops[k].p1, f->ops[k].scalar, f->ops[k].prefetch, f->ops[k].body_end};
+            if (o.kind == NP_FUSED_UNARY) {
+                unary_dispatch<N>(o.op, acc, o.p0, o.p1);
+                continue;
+            }
+            float oth[N];
+            bool body[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                oth[e] = (o.src_kind == FUSED_SRC_STREAM) ? nxt[e] : (o.src_kind == FUSED_SRC_INPUT0) ? x0[e] : o.scalar;
+                // body_end is a multiple of 8 and float4 slots start at multiples of 4: one flag per slot
+                body[e] = (size_t)first[e / G] < o.body_end;
+            }
+            if (o.src_kind == FUSED_SRC_STREAM && o.prefetch) fused_fetch<U, G, I>(nxt, o.prefetch, first, live);
+            binary_dispatch<N>(o.op, acc, oth, o.swap != 0, o.quirk != 0, body);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            if constexpr (G == 4)
+                __builtin_nontemporal_store(v4f{acc[u * 4], acc[u * 4 + 1], acc[u * 4 + 2], acc[u * 4 + 3]},
+                                            (v4f *)(out + (size_t)first[u]));
+            else
+                out[first[u]] = acc[u];
+        }
+    }
+}
+
+template <bool VEC, int U, typename I>
+__global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, float *__restrict__ out, I n) {
+    (void)by_value;   // first kernel argument: lives at offset 0 of the kernarg segment
+    FusedArgsK f = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
     const I stride = (I)gridDim.x * blockDim.x;
     const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
-    auto run = [&](const float *r, I index) -> float {
-        float acc = r[0];
-        for (int k = 0; k < f.n_ops; ++k) {
-            const np_fused_op &o = f.ops[k];
-            if (o.kind == NP_FUSED_UNARY) {
-                acc = unary_dispatch(o.op, acc, o.p0, o.p1);
-            } else {
-                // select instead of r[o.operand]: a runtime-indexed register array would be
-                // demoted to scratch memory
-                float other = r[0];
-#pragma unroll
-                for (int i = 1; i < FUSED_MAX_IN; ++i) other = (o.operand == i) ? r[i] : other;
-                const bool body = (size_t)index < o.body_end;
-                acc = o.swap ? binary_dispatch(o.op, other, acc, o.flags & NP_QUIRK_AVX_BODY, body)
-                             : binary_dispatch(o.op, acc, other, o.flags & NP_QUIRK_AVX_BODY, body);
-            }
-        }
-        return acc;
-    };
-    for (I v = tid; v < nvec; v += stride) {
-        v4f x[FUSED_MAX_IN];
-#pragma unroll
-        for (int i = 0; i < FUSED_MAX_IN; ++i) {
-            if (i < f.n_in) {
-                if (f.in[i])
-                    x[i] = __builtin_nontemporal_load((const v4f *)(f.in[i] + (size_t)v * 4));
-                else
-                    x[i] = v4f{f.scalar[i], f.scalar[i], f.scalar[i], f.scalar[i]};
-            }
-        }
-        v4f res;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float r[FUSED_MAX_IN];
-#pragma unroll
-            for (int i = 0; i < FUSED_MAX_IN; ++i) r[i] = (i < f.n_in) ? x[i][e] : 0.0f;
-            res[e] = run(r, v * 4 + e);
-        }
-        __builtin_nontemporal_store(res, (v4f *)(out + (size_t)v * 4));
-    }
-    // scalar path: everything when !VEC, the ragged tail otherwise
-    for (I i = nvec * 4 + tid; i < n; i += stride) {
-        float r[FUSED_MAX_IN];
-#pragma unroll
-        for (int k = 0; k < FUSED_MAX_IN; ++k) r[k] = (k < f.n_in) ? (f.in[k] ? f.in[k][i] : f.scalar[k]) : 0.0f;
-        out[i] = run(r, i);
+    if constexpr (VEC) {
+        const I nvec = n / 4;
+        fused_span<U, 4, I>(f, out, (I)0, nvec, tid, stride);
+        fused_span<1, 1, I>(f, out, nvec * 4, n - nvec * 4, tid, stride);   // ragged tail (< 4 elements)
+    } else {
+        fused_span<U, 1, I>(f, out, (I)0, n, tid, stride);   // 4-byte aligned views
     }
 }
 
@@ -573,49 +669,75 @@ int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inp
     if (int rc = np::ensure_init()) return rc;
     FusedArgs f;
     f.n_ops = n_ops;
-    f.n_in = n_inputs;
     bool vec = aligned16(out);
-    for (int i = 0; i < FUSED_MAX_IN; ++i) {
-        f.in[i] = nullptr;
-        f.scalar[i] = 0.0f;
-    }
     for (int i = 0; i < n_inputs; ++i) {
         if (!inputs[i]) return np::fail(NP_ERR_INVALID, "np_fused_chain: null input %d", i);
-        if (input_kinds[i] == NP_HOST_SCALAR) {
-            f.scalar[i] = *inputs[i];
-        } else if (input_kinds[i] == NP_FULL) {
-            f.in[i] = inputs[i];
+        if (input_kinds[i] == NP_FULL)
             vec = vec && aligned16(inputs[i]);
-        } else {
+        else if (input_kinds[i] != NP_HOST_SCALAR)
             return np::fail(NP_ERR_INVALID, "np_fused_chain: inputs must be NP_FULL or NP_HOST_SCALAR");
-        }
     }
+    f.in0 = input_kinds[0] == NP_FULL ? inputs[0] : nullptr;
+    f.scalar0 = input_kinds[0] == NP_FULL ? 0.0f : *inputs[0];
+    f.first_prefetch = nullptr;
+    FusedStep *last_stream = nullptr;
     for (int k = 0; k < n_ops; ++k) {
         const np_fused_op &o = ops[k];
+        FusedStep &d = f.ops[k];
+        d = FusedStep{};
+        d.kind = o.kind;
+        d.op = o.op;
+        d.p0 = o.p0;
+        d.p1 = o.p1;
         if (o.kind == NP_FUSED_UNARY) {
             if (o.op < 0 || o.op >= NP_UNARY_OP_COUNT) return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown unary op %d", o.op);
+            if (o.op == NP_ROUND) d.p0 = powf(10.0f, o.p0);   // as np_unary
         } else if (o.kind == NP_FUSED_BINARY) {
             if (o.op < 0 || o.op >= NP_BINARY_OP_COUNT) return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown binary op %d", o.op);
             if (o.operand < 0 || o.operand >= n_inputs) return np::fail(NP_ERR_INVALID, "np_fused_chain: operand index out of range");
+            d.swap = o.swap;
+            d.quirk = (o.flags & NP_QUIRK_AVX_BODY) ? 1 : 0;
+            d.body_end = o.body_end;
+            if (input_kinds[o.operand] == NP_HOST_SCALAR) {
+                d.src_kind = FUSED_SRC_SCALAR;
+                d.scalar = *inputs[o.operand];
+            } else if (inputs[o.operand] == inputs[0]) {
+                d.src_kind = FUSED_SRC_INPUT0;   // already in registers
+            } else {
+                d.src_kind = FUSED_SRC_STREAM;
+                if (last_stream)
+                    last_stream->prefetch = inputs[o.operand];
+                else
+                    f.first_prefetch = inputs[o.operand];
+                last_stream = &d;
+            }
         } else {
             return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown op kind %d", o.kind);
         }
-        f.ops[k] = o;
-        if (o.kind == NP_FUSED_UNARY && o.op == NP_ROUND) f.ops[k].p0 = powf(10.0f, o.p0);   // as np_unary
     }
-    const unsigned grid = grid_for(n / 4 + 1, 1, 0);
+    // float4 slots per thread-trip (NP_FUSED_U) and grid cap (NP_FUSED_BPC): tuning knobs for
+    // tools/fused_ab.py; the defaults are the measured best
+    static const int fu = getenv("NP_FUSED_U") ? atoi(getenv("NP_FUSED_U")) : 2;
+    static const int bpc = getenv("NP_FUSED_BPC") ? atoi(getenv("NP_FUSED_BPC")) : 0;
     hipStream_t s = np::stream();
-    if (n < (size_t(1) << 31)) {
-        if (vec)
-            fused_chain_kernel<true, uint32_t><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);
-        else
-            fused_chain_kernel<false, uint32_t><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);
-    } else {
-        if (vec)
-            fused_chain_kernel<true, uint64_t><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);
-        else
-            fused_chain_kernel<false, uint64_t><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);
-    }
+    const bool small = n < (size_t(1) << 31);
+#define NP_FC(VEC_, U_)                                                                          \
+    do {                                                                                         \
+        const unsigned grid = grid_for(VEC_ ? n / 4 + 1 : n, U_, bpc);                           \
+        if (small)                                                                               \
+            fused_chain_kernel<VEC_, U_, uint32_t><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);    \
+        else                                                                                     \
+            fused_chain_kernel<VEC_, U_, uint64_t><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);    \
+    } while (0)
+    if (!vec)
+        NP_FC(false, 2);
+    else if (fu == 1)
+        NP_FC(true, 1);
+    else if (fu == 4)
+        NP_FC(true, 4);
+    else
+        NP_FC(true, 2);
+#undef NP_FC
     NP_LAUNCH_CHECK("fused_chain_kernel");
     return NP_OK;
 }

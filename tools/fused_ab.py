@@ -1,0 +1,64 @@
+"""A/B of the fused-chain kernel's knobs (NP_FUSED_U, NP_FUSED_BPC are read once per process, so
+each configuration runs in its own subprocess).  Usage: python tools/fused_ab.py"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def one(chain):
+    from numpower_amd import _lib
+    from numpower_amd._lib import BINARY_OPS, UNARY_OPS, FusedOp
+    lib = _lib.load()
+    _lib.check(lib.np_init(0))
+    n = 100_000_000
+    bufs = [_lib.DeviceBuffer(4 * n) for _ in range(4)]
+    for i, b in enumerate(bufs[:3]):
+        _lib.check(lib.np_fill(b.ptr, 0.5 + i, n))
+    two = C.c_float(2.0)
+    if chain == "exp_mul_add":
+        inputs = [bufs[0].ptr, bufs[1].ptr, C.addressof(two)]
+        kinds = [0, 0, 4]
+        ops = [FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0), FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 1, n // 8 * 8),
+               FusedOp(1, BINARY_OPS["add"], 2, 0, 0, 0, 0, 0)]
+        nbytes = 12 * n
+    elif chain == "fma3":       # a*b+c : 3 arrays in, 1 out
+        inputs = [bufs[0].ptr, bufs[1].ptr, bufs[2].ptr]
+        kinds = [0, 0, 0]
+        ops = [FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 1, n // 8 * 8), FusedOp(1, BINARY_OPS["add"], 2, 0, 0, 0, 0, 0)]
+        nbytes = 16 * n
+    else:                        # long unary chain: 1 in 1 out, 6 ops
+        inputs = [bufs[0].ptr]
+        kinds = [0]
+        ops = [FusedOp(0, UNARY_OPS[u], 0, 0, 0, 0, 0, 0) for u in ("exp", "log1p", "sqrt", "tanh", "abs", "sin")]
+        nbytes = 8 * n
+    arr = (C.c_void_p * len(inputs))(*inputs)
+    k = (C.c_int * len(kinds))(*kinds)
+    o = (FusedOp * len(ops))(*ops)
+    t = _lib.Timer()
+    for _ in range(5):
+        _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, n))
+    t.start()
+    reps = 30
+    for _ in range(reps):
+        _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, n))
+    t.stop()
+    _lib.check(lib.np_sync())
+    ms = t.elapsed_ms() / reps
+    print(json.dumps({"chain": chain, "U": os.environ.get("NP_FUSED_U"), "BPC": os.environ.get("NP_FUSED_BPC"),
+                      "ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1)}))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        one(sys.argv[1])
+    else:
+        for chain in ("exp_mul_add", "fma3", "unary6"):
+            for u in ("1", "2", "4"):
+                for bpc in ("0", "8", "16"):
+                    env = dict(os.environ, NP_FUSED_U=u, NP_FUSED_BPC=bpc)
+                    subprocess.run([sys.executable, __file__, chain], env=env, check=False)
