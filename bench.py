@@ -261,7 +261,7 @@ def bench_extras(dist: Dist, steps, warmup):
     kinds = (C.c_int * 3)(0, 0, 4)
     lib = load()
     r = hbm_case("exp(a)*b+2 fused, 1e8 (§8f row 4)", 12.0 * N,
-                 lambda: check(lib.np_fused_chain(ptrs, kinds, 3, prog, 3, do.ptr, N)), steps, warmup, dist)
+                 lambda: check(lib.np_fused_chain(ptrs, kinds, 3, prog, 3, do.ptr, 1, N)), steps, warmup, dist)
     fused_out = do.to_host().reshape(-1)
     tmp, tmp2 = D.DeviceArray((N,)), D.DeviceArray((N,))
     stwo = D.DeviceArray.from_host(np.float32([2.0]))
@@ -311,6 +311,29 @@ def bench_extras(dist: Dist, steps, warmup):
     got = do.to_host().reshape(R, Cc)
     r["parity_ok"] = bool((got == (a.reshape(R, Cc) + col[:, None])).all())
     ex["add_col_broadcast"] = r
+    # C3c as BASELINE.json words it — "exp/log with broadcast": exp(X) + r in ONE pass (8 B/elem)
+    # through the fused chain, against the two launches (16 B/elem + a temporary) the op-by-op API costs
+    prog2 = (FusedOp * 2)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0),
+                          FusedOp(1, BINARY_OPS["add"], 1, 0, 0, 0, 0, 0))
+    tmp = D.DeviceArray((N,))
+    for label, dvec, kind, nvec in (("row", drow, 2, Cc), ("col", dcol, 3, R)):
+        ptrs2 = (C.c_void_p * 2)(da.ptr, dvec.ptr)
+        kinds2 = (C.c_int * 2)(0, kind)
+        r = hbm_case("exp(X) + %s fused, 25000x4000 (C3c)" % label, 8.0 * N + 4.0 * nvec,
+                     lambda: check(lib.np_fused_chain(ptrs2, kinds2, 2, prog2, 2, do.ptr, R, Cc)),
+                     steps, warmup, dist)
+        fused_out = do.to_host().reshape(-1)
+
+        def two_launches():
+            D.unary("exp", da, out=tmp)
+            D.binary("add", tmp, "full", dvec, label, R, Cc, out=do)
+
+        _, ev_ms = timed(dist, two_launches, steps, warmup)
+        r["unfused_ms_per_chain"] = ev_ms / steps
+        r["speedup_vs_unfused"] = (ev_ms / steps) / r["ms_per_launch"]
+        r["parity_ok"] = bool((fused_out.view(np.uint32) == do.to_host().reshape(-1).view(np.uint32)).all())
+        ex["exp_plus_%s_fused" % label] = r
+    tmp.free()
     for d in (da, db, do, drow, dcol):
         d.free()
     del a, b, got

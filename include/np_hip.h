@@ -176,8 +176,11 @@ int np_unary(int op, const float *in, float *out, size_t n, float p0, float p1);
  * e.g. nd::exp($a) * $b + 2 costs 12 B/elem instead of 8 + 12 + 8 = 28 B/elem and two temporaries
  * (one allocation + one full round trip per PHP-level op in the reference, numpower.c:193-229).
  * Every step runs the same arithmetic as np_unary / np_binary, so the result is bit-identical to
- * the unfused sequence; flags/body_end have the meaning they have in np_binary.  Inputs are NP_FULL
- * arrays of n elements or NP_HOST_SCALAR values; at most 6 inputs and 12 ops per chain. */
+ * the unfused sequence; flags/body_end have the meaning they have in np_binary.  The result is
+ * rows x cols; inputs[0] is NP_FULL (rows*cols elements) or NP_HOST_SCALAR, the other inputs have
+ * any np_operand_kind: NP_FULL, NP_ROW (cols floats, added to every row), NP_COL (rows floats, one
+ * per row), NP_SCALAR (device 0-d) or NP_HOST_SCALAR — the broadcast cases of ndarray.c:1196-1291
+ * resolved by index arithmetic in the kernel, as in np_binary.  At most 6 inputs and 12 ops. */
 typedef enum np_fused_kind { NP_FUSED_UNARY = 0, NP_FUSED_BINARY = 1 } np_fused_kind;
 typedef struct np_fused_op {
     int kind;      /* np_fused_kind */
@@ -189,7 +192,7 @@ typedef struct np_fused_op {
     size_t body_end;    /* see np_binary */
 } np_fused_op;
 int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inputs,
-                   const np_fused_op *ops, int n_ops, float *out, size_t n);
+                   const np_fused_op *ops, int n_ops, float *out, size_t rows, size_t cols);
 
 /* ---- reductions -------------------------------------------------------------------------- */
 

@@ -473,18 +473,25 @@ constexpr int FUSED_MAX_IN = 6;
 // What the kernel interprets (built on the host from np_fused_op): operands are resolved to
 // pointers / values up front so a step costs one uniform load of its descriptor.
 enum { FUSED_SRC_SCALAR = 0, FUSED_SRC_STREAM = 1, FUSED_SRC_INPUT0 = 2 };
+// how a streamed operand is indexed by the flat element index e of the rows x cols result
+enum { FUSED_IDX_FULL = 0, FUSED_IDX_ROW = 1 /* e % cols */, FUSED_IDX_COL = 2 /* e / cols */, FUSED_IDX_ZERO = 3 };
 struct FusedStep {
     int kind, op, swap, quirk;
     float p0, p1, scalar;
     int src_kind;
     const float *prefetch;   // array whose load is started when this step consumes its streamed operand
     size_t body_end;
+    int prefetch_idx;        // FUSED_IDX_* of `prefetch`
+    int pad;
 };
 struct FusedArgs {
     int n_ops;
     float scalar0;
     const float *in0;              // null -> scalar0
     const float *first_prefetch;   // first streamed operand of the chain (null: none)
+    size_t cols;                   // row length of the result; 0 when no operand is broadcast
+    int first_prefetch_idx;
+    int pad;
     FusedStep ops[FUSED_MAX_OPS];
 };
 // The kernel indexes ops[] with a run-time k.  On a by-value kernel parameter that makes the compiler
@@ -522,9 +529,29 @@ __device__ __forceinline__ void binary_all(float (&acc)[N], const float (&oth)[N
     }
 }
 
-template <int N>
+// Register allocation is static: a kernel that CAN run powf or tanf on 8 elements is allocated for
+// them even when the chain is exp -> multiply -> add, and pays in occupancy.  So there are two
+// interpreters: LIGHT knows only the ops whose bodies are a handful of instructions (the common
+// arithmetic chains), the full one knows everything; np_fused_chain picks per chain.
+constexpr bool fused_light_unary(int op) {
+    switch (op) {
+        case NP_ABS: case NP_SQRT: case NP_EXP: case NP_EXP2: case NP_LOG: case NP_LOG2: case NP_LOG10:
+        case NP_DEGREES: case NP_RADIANS: case NP_RINT: case NP_FIX: case NP_FLOOR: case NP_CEIL:
+        case NP_TRUNC: case NP_NEGATE: case NP_SIGN: case NP_CLIP: case NP_ROUND: case NP_RSQRT:
+        case NP_POSITIVE: case NP_RECIPROCAL:
+            return true;
+        default:
+            return false;
+    }
+}
+constexpr bool fused_light_binary(int op) { return op != NP_MOD && op != NP_POW && op != NP_ARCTAN2; }
+
+template <int N, bool LIGHT>
 __device__ __forceinline__ void unary_dispatch(int op, float (&acc)[N], float p0, float p1) {
-#define NP_UD(OP_) case OP_: unary_all<OP_, N>(acc, p0, p1); break
+#define NP_UD(OP_)                                                                     \
+    case OP_:                                                                          \
+        if constexpr (!LIGHT || fused_light_unary(OP_)) unary_all<OP_, N>(acc, p0, p1); \
+        break
     switch (op) {
         NP_UD(NP_ABS); NP_UD(NP_SQRT); NP_UD(NP_EXP); NP_UD(NP_EXP2); NP_UD(NP_EXPM1); NP_UD(NP_LOG);
         NP_UD(NP_LOG2); NP_UD(NP_LOG10); NP_UD(NP_LOG1P); NP_UD(NP_LOGB); NP_UD(NP_SIN); NP_UD(NP_COS);
@@ -538,10 +565,13 @@ __device__ __forceinline__ void unary_dispatch(int op, float (&acc)[N], float p0
 #undef NP_UD
 }
 
-template <int N>
+template <int N, bool LIGHT>
 __device__ __forceinline__ void binary_dispatch(int op, float (&acc)[N], const float (&oth)[N], bool swap,
                                                 bool quirk, const bool (&body)[N]) {
-#define NP_BD(OP_) case OP_: binary_all<OP_, N>(acc, oth, swap, quirk, body); break
+#define NP_BD(OP_)                                                                                        \
+    case OP_:                                                                                             \
+        if constexpr (!LIGHT || fused_light_binary(OP_)) binary_all<OP_, N>(acc, oth, swap, quirk, body); \
+        break
     switch (op) {
         NP_BD(NP_ADD); NP_BD(NP_SUBTRACT); NP_BD(NP_MULTIPLY); NP_BD(NP_DIVIDE); NP_BD(NP_MOD); NP_BD(NP_POW);
         NP_BD(NP_ARCTAN2); NP_BD(NP_EQUAL); NP_BD(NP_NOT_EQUAL); NP_BD(NP_GREATER); NP_BD(NP_GREATER_EQUAL);
@@ -557,46 +587,77 @@ __device__ __forceinline__ void binary_dispatch(int op, float (&acc)[N], const f
 // in flight while the steps in between compute; with input 0 that keeps two loads outstanding per
 // thread without holding every input in registers (which cost occupancy: 6 inputs x 8 values).
 template <int U, int G, typename I>
-__device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p, const I (&first)[U],
-                                            const bool (&live)[U]) {
+__device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p, int idx, const I (&first)[U],
+                                            const I (&row)[U], const I (&col)[U], const bool (&live)[U]) {
+    if (idx == FUSED_IDX_FULL) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        if constexpr (G == 4) {
-            v4f t = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-            if (live[u]) t = __builtin_nontemporal_load((const v4f *)(p + (size_t)first[u]));
+        for (int u = 0; u < U; ++u) {
+            if constexpr (G == 4) {
+                v4f t = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                if (live[u]) t = __builtin_nontemporal_load((const v4f *)(p + (size_t)first[u]));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[u * 4 + e] = t[e];
-        } else {
-            dst[u] = live[u] ? __builtin_nontemporal_load(p + (size_t)first[u]) : 0.0f;
+                for (int e = 0; e < 4; ++e) dst[u * 4 + e] = t[e];
+            } else {
+                dst[u] = live[u] ? __builtin_nontemporal_load(p + (size_t)first[u]) : 0.0f;
+            }
+        }
+    } else if (idx == FUSED_IDX_ROW) {
+        // one row of `cols` floats, re-read by every result row: cache-resident, plain loads.  The
+        // float4 path is only taken when cols % 4 == 0 (a slot never straddles two rows).
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (G == 4) {
+                v4f t = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                if (live[u]) t = *(const v4f *)(p + (size_t)col[u]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[u * 4 + e] = t[e];
+            } else {
+                dst[u] = live[u] ? p[(size_t)col[u]] : 0.0f;
+            }
+        }
+    } else {
+        // one value per result row (column operand) or one value in all (0-d device scalar)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float t = live[u] ? p[idx == FUSED_IDX_COL ? (size_t)row[u] : (size_t)0] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < G; ++e) dst[u * G + e] = t;
         }
     }
 }
 
-template <int U, int G, typename I>
+template <int U, int G, bool LIGHT, typename I>
 __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out, I elem0, I nslots, I tid,
                                            I stride) {
     constexpr int N = U * G;
     const int n_ops = f->n_ops;
     const float *in0 = f->in0, *first_prefetch = f->first_prefetch;
     const float scalar0 = f->scalar0;
+    const int first_prefetch_idx = f->first_prefetch_idx;
+    const I cols = (I)f->cols;
     for (I base = 0; base < nslots; base += stride * U) {
-        I first[U];
+        I first[U], row[U], col[U];
         bool live[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const I v = base + (I)u * stride + tid;   // coalesced per u
             live[u] = v < nslots;
             first[u] = elem0 + v * G;
+            row[u] = col[u] = 0;
+            if (cols) {   // uniform: only chains with a broadcast operand pay for the division
+                row[u] = first[u] / cols;
+                col[u] = first[u] - row[u] * cols;
+            }
         }
         float x0[N], acc[N], nxt[N];
         if (in0) {
-            fused_fetch<U, G, I>(x0, in0, first, live);
+            fused_fetch<U, G, I>(x0, in0, FUSED_IDX_FULL, first, row, col, live);
         } else {
 #pragma unroll
             for (int e = 0; e < N; ++e) x0[e] = scalar0;
         }
         if (first_prefetch) {
-            fused_fetch<U, G, I>(nxt, first_prefetch, first, live);
+            fused_fetch<U, G, I>(nxt, first_prefetch, first_prefetch_idx, first, row, col, live);
         } else {
 #pragma unroll
             for (int e = 0; e < N; ++e) nxt[e] = 0.0f;
@@ -605,14 +666,15 @@ __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out
         for (int e = 0; e < N; ++e) acc[e] = x0[e];
         for (int k = 0; k < n_ops; ++k) {
             struct {
-                int kind, op, swap, quirk, src_kind;
+                int kind, op, swap, quirk, src_kind, prefetch_idx;
                 float p0, p1, scalar;
                 const float *prefetch;
                 size_t body_end;
             } o = {f->ops[k].kind, f->ops[k].op, f->ops[k].swap, f->ops[k].quirk, f->ops[k].src_kind,
-                   f->ops[k].p0, f->ops[k].p1, f->ops[k].scalar, f->ops[k].prefetch, f->ops[k].body_end};
+                   f->ops[k].prefetch_idx, f->ops[k].p0, f->ops[k].p1, f->ops[k].scalar, f->ops[k].prefetch,
+                   f->ops[k].body_end};
             if (o.kind == NP_FUSED_UNARY) {
-                unary_dispatch<N>(o.op, acc, o.p0, o.p1);
+                unary_dispatch<N, LIGHT>(o.op, acc, o.p0, o.p1);
                 continue;
             }
             float oth[N];
@@ -623,8 +685,9 @@ __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out
                 // body_end is a multiple of 8 and float4 slots start at multiples of 4: one flag per slot
                 body[e] = (size_t)first[e / G] < o.body_end;
             }
-            if (o.src_kind == FUSED_SRC_STREAM && o.prefetch) fused_fetch<U, G, I>(nxt, o.prefetch, first, live);
-            binary_dispatch<N>(o.op, acc, oth, o.swap != 0, o.quirk != 0, body);
+            if (o.src_kind == FUSED_SRC_STREAM && o.prefetch)
+                fused_fetch<U, G, I>(nxt, o.prefetch, o.prefetch_idx, first, row, col, live);
+            binary_dispatch<N, LIGHT>(o.op, acc, oth, o.swap != 0, o.quirk != 0, body);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -638,7 +701,7 @@ __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out
     }
 }
 
-template <bool VEC, int U, typename I>
+template <bool VEC, int U, bool LIGHT, typename I>
 __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, float *__restrict__ out, I n) {
     (void)by_value;   // first kernel argument: lives at offset 0 of the kernarg segment
     FusedArgsK f = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
@@ -646,10 +709,10 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, fl
     const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
     if constexpr (VEC) {
         const I nvec = n / 4;
-        fused_span<U, 4, I>(f, out, (I)0, nvec, tid, stride);
-        fused_span<1, 1, I>(f, out, nvec * 4, n - nvec * 4, tid, stride);   // ragged tail (< 4 elements)
+        fused_span<U, 4, LIGHT, I>(f, out, (I)0, nvec, tid, stride);
+        fused_span<1, 1, LIGHT, I>(f, out, nvec * 4, n - nvec * 4, tid, stride);   // ragged tail (< 4 elements)
     } else {
-        fused_span<U, 1, I>(f, out, (I)0, n, tid, stride);   // 4-byte aligned views
+        fused_span<U, 1, LIGHT, I>(f, out, (I)0, n, tid, stride);   // 4-byte aligned views
     }
 }
 
@@ -658,7 +721,8 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, fl
 extern "C" {
 
 int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inputs,
-                   const np_fused_op *ops, int n_ops, float *out, size_t n) {
+                   const np_fused_op *ops, int n_ops, float *out, size_t rows, size_t cols) {
+    const size_t n = rows * cols;
     if (n_inputs < 1 || n_inputs > FUSED_MAX_IN)
         return np::fail(NP_ERR_INVALID, "np_fused_chain: 1..%d inputs supported", FUSED_MAX_IN);
     if (n_ops < 0 || n_ops > FUSED_MAX_OPS)
@@ -670,17 +734,28 @@ int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inp
     FusedArgs f;
     f.n_ops = n_ops;
     bool vec = aligned16(out);
+    bool broadcast = false;
     for (int i = 0; i < n_inputs; ++i) {
         if (!inputs[i]) return np::fail(NP_ERR_INVALID, "np_fused_chain: null input %d", i);
-        if (input_kinds[i] == NP_FULL)
-            vec = vec && aligned16(inputs[i]);
-        else if (input_kinds[i] != NP_HOST_SCALAR)
-            return np::fail(NP_ERR_INVALID, "np_fused_chain: inputs must be NP_FULL or NP_HOST_SCALAR");
+        switch (input_kinds[i]) {
+            case NP_FULL: vec = vec && aligned16(inputs[i]); break;
+            case NP_ROW: vec = vec && aligned16(inputs[i]) && cols % 4 == 0; broadcast = true; break;
+            case NP_COL: vec = vec && cols % 4 == 0; broadcast = true; break;
+            case NP_SCALAR:
+            case NP_HOST_SCALAR: break;
+            default: return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown operand kind %d", input_kinds[i]);
+        }
     }
+    if (input_kinds[0] != NP_FULL && input_kinds[0] != NP_HOST_SCALAR)
+        return np::fail(NP_ERR_INVALID, "np_fused_chain: input 0 must be NP_FULL or NP_HOST_SCALAR");
     f.in0 = input_kinds[0] == NP_FULL ? inputs[0] : nullptr;
     f.scalar0 = input_kinds[0] == NP_FULL ? 0.0f : *inputs[0];
     f.first_prefetch = nullptr;
+    f.first_prefetch_idx = FUSED_IDX_FULL;
+    f.cols = broadcast ? cols : 0;
+    f.pad = 0;
     FusedStep *last_stream = nullptr;
+    bool light = true;
     for (int k = 0; k < n_ops; ++k) {
         const np_fused_op &o = ops[k];
         FusedStep &d = f.ops[k];
@@ -692,51 +767,61 @@ int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inp
         if (o.kind == NP_FUSED_UNARY) {
             if (o.op < 0 || o.op >= NP_UNARY_OP_COUNT) return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown unary op %d", o.op);
             if (o.op == NP_ROUND) d.p0 = powf(10.0f, o.p0);   // as np_unary
+            light = light && fused_light_unary(o.op);
         } else if (o.kind == NP_FUSED_BINARY) {
             if (o.op < 0 || o.op >= NP_BINARY_OP_COUNT) return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown binary op %d", o.op);
             if (o.operand < 0 || o.operand >= n_inputs) return np::fail(NP_ERR_INVALID, "np_fused_chain: operand index out of range");
+            light = light && fused_light_binary(o.op);
             d.swap = o.swap;
             d.quirk = (o.flags & NP_QUIRK_AVX_BODY) ? 1 : 0;
             d.body_end = o.body_end;
             if (input_kinds[o.operand] == NP_HOST_SCALAR) {
                 d.src_kind = FUSED_SRC_SCALAR;
                 d.scalar = *inputs[o.operand];
-            } else if (inputs[o.operand] == inputs[0]) {
+            } else if (inputs[o.operand] == inputs[0] && input_kinds[o.operand] == NP_FULL && f.in0) {
                 d.src_kind = FUSED_SRC_INPUT0;   // already in registers
             } else {
                 d.src_kind = FUSED_SRC_STREAM;
-                if (last_stream)
+                const int kind = input_kinds[o.operand];
+                const int idx = kind == NP_FULL ? FUSED_IDX_FULL : kind == NP_ROW ? FUSED_IDX_ROW
+                              : kind == NP_COL ? FUSED_IDX_COL : FUSED_IDX_ZERO;
+                if (last_stream) {
                     last_stream->prefetch = inputs[o.operand];
-                else
+                    last_stream->prefetch_idx = idx;
+                } else {
                     f.first_prefetch = inputs[o.operand];
+                    f.first_prefetch_idx = idx;
+                }
                 last_stream = &d;
             }
         } else {
             return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown op kind %d", o.kind);
         }
     }
-    // float4 slots per thread-trip (NP_FUSED_U) and grid cap (NP_FUSED_BPC): tuning knobs for
-    // tools/fused_ab.py; the defaults are the measured best
-    static const int fu = getenv("NP_FUSED_U") ? atoi(getenv("NP_FUSED_U")) : 2;
-    static const int bpc = getenv("NP_FUSED_BPC") ? atoi(getenv("NP_FUSED_BPC")) : 0;
+    // float4 slots per thread-trip: measured (tools/fused_ab.py, profiles/r01/fused_ab.log) — the
+    // LIGHT interpreter is best at 1 slot (49 VGPRs, 8 waves/SIMD), the full one at 2.
+    // NP_FUSED_U / NP_FUSED_FULL override for that A/B.
+    static const int fu_env = getenv("NP_FUSED_U") ? atoi(getenv("NP_FUSED_U")) : 0;
+    static const bool force_full = getenv("NP_FUSED_FULL") != nullptr;
     hipStream_t s = np::stream();
     const bool small = n < (size_t(1) << 31);
-#define NP_FC(VEC_, U_)                                                                          \
-    do {                                                                                         \
-        const unsigned grid = grid_for(VEC_ ? n / 4 + 1 : n, U_, bpc);                           \
-        if (small)                                                                               \
-            fused_chain_kernel<VEC_, U_, uint32_t><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);    \
-        else                                                                                     \
-            fused_chain_kernel<VEC_, U_, uint64_t><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);    \
+#define NP_FC(VEC_, U_, LIGHT_)                                                                          \
+    do {                                                                                                 \
+        const unsigned grid = grid_for(VEC_ ? n / 4 + 1 : n, U_, 0);                                     \
+        if (small)                                                                                       \
+            fused_chain_kernel<VEC_, U_, LIGHT_, uint32_t><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);    \
+        else                                                                                             \
+            fused_chain_kernel<VEC_, U_, LIGHT_, uint64_t><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);    \
     } while (0)
-    if (!vec)
-        NP_FC(false, 2);
-    else if (fu == 1)
-        NP_FC(true, 1);
-    else if (fu == 4)
-        NP_FC(true, 4);
-    else
-        NP_FC(true, 2);
+    if (force_full) light = false;
+    const int fu = fu_env ? fu_env : (light ? 1 : 2);
+    if (!vec) {
+        if (light) NP_FC(false, 2, true); else NP_FC(false, 2, false);
+    } else if (fu == 1) {
+        if (light) NP_FC(true, 1, true); else NP_FC(true, 1, false);
+    } else {
+        if (light) NP_FC(true, 2, true); else NP_FC(true, 2, false);
+    }
 #undef NP_FC
     NP_LAUNCH_CHECK("fused_chain_kernel");
     return NP_OK;

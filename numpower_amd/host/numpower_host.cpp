@@ -499,9 +499,11 @@ NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute) {
 
 /* ---- fused elementwise chains ---- */
 // What a Zend glue would flush when a lazily built expression reaches toArray()/cpu()/a reduction:
-// inputs[0] is the GPU array the chain starts from, the other inputs are GPU arrays with the same
-// number of elements or 0-d CPU scalars.  Quirk flags are set exactly as the stand-alone
-// NDArray_*_Float / comparison entry points set them, so the fused result is bit-identical.
+// inputs[0] is the GPU array the chain starts from (it fixes the result shape); the other inputs
+// are GPU arrays of the same element count, smaller GPU arrays that broadcast onto it (row vector,
+// column, 0-d: the cases of NDArray_Broadcast, ndarray.c:1196-1291) or 0-d CPU scalars.  Quirk
+// flags and AVX-body bounds are set exactly as binary_op() above sets them for the stand-alone
+// NDArray_*_Float / comparison entry points, so the fused result is bit-identical.
 NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops) {
     if (!inputs || n_inputs < 1 || !inputs[0]) return nullptr;
     NDArray *first = inputs[0];
@@ -517,6 +519,8 @@ NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *o
         throw_error("fused chain too long");
         return nullptr;
     }
+    size_t rows = 1, cols = (size_t)n;
+    bool have_2d = false;
     for (int i = 0; i < n_inputs; ++i) {
         NDArray *x = inputs[i];
         if (!x) return nullptr;
@@ -527,14 +531,30 @@ NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *o
                 throw_error("Device mismatch, both NDArray MUST be in the same device.");
                 return nullptr;
             }
-            if (NDArray_NUMELEMENTS(x) != n) {
+            if (NDArray_NDIM(x) == 0) {
+                kinds[i] = NP_SCALAR;
+            } else if (NDArray_NUMELEMENTS(x) == n) {
+                kinds[i] = NP_FULL;          // equal element counts: flat elementwise (arithmetics.c:194-197)
+            } else if (NDArray_NUMELEMENTS(x) < n) {
+                size_t r = 1, c = 1;
+                const int k = broadcast_kind(x, first, &r, &c);
+                if (k < 0 || (have_2d && (r != rows || c != cols))) {
+                    throw_error("Can't broadcast arrays.");
+                    return nullptr;
+                }
+                kinds[i] = k;
+                rows = r;
+                cols = c;
+                have_2d = true;
+            } else {
+                // the accumulator itself would have to grow: not a fused case
                 throw_error("Can't broadcast arrays.");
                 return nullptr;
             }
-            kinds[i] = NP_FULL;
         }
         ptrs[i] = NDArray_FDATA(x);
     }
+    if (kinds[0] != NP_FULL) return nullptr;
     np_fused_op prog[64];
     for (int k = 0; k < n_ops; ++k) {
         prog[k] = ops[k];
@@ -542,15 +562,26 @@ NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *o
         prog[k].body_end = 0;
         if (ops[k].kind == NP_FUSED_BINARY) {
             const int op = ops[k].op;
+            if (ops[k].operand < 0 || ops[k].operand >= n_inputs) {
+                throw_error("fused chain: operand index out of range");
+                return nullptr;
+            }
             if (op == NP_MULTIPLY || op == NP_MOD || op == NP_EQUAL || op == NP_NOT_EQUAL) {
+                // AVX-body bound: element count of the FIRST operand after the scalar expand but
+                // before the broadcast (arithmetics.c:251, logic.c:535); NotEqual loops over the
+                // broadcast operand (logic.c:636)
+                const NDArray *other = inputs[ops[k].operand];
+                size_t loop_numel_a = (size_t)n;
+                if (ops[k].swap && NDArray_NDIM(other) != 0 && op != NP_NOT_EQUAL)
+                    loop_numel_a = (size_t)NDArray_NUMELEMENTS(other);
                 prog[k].flags = NP_QUIRK_AVX_BODY;
-                prog[k].body_end = np_avx_body_end((size_t)n);   // both operands have n elements here
+                prog[k].body_end = np_avx_body_end(loop_numel_a);
             }
         }
     }
     NDArray *result = new_array(first->dimensions, first->ndim, NDARRAY_DEVICE_GPU, false);
     if (!result) return nullptr;
-    if (!dev_ok(np_fused_chain(ptrs, kinds, n_inputs, prog, n_ops, NDArray_FDATA(result), (size_t)n))) {
+    if (!dev_ok(np_fused_chain(ptrs, kinds, n_inputs, prog, n_ops, NDArray_FDATA(result), rows, cols))) {
         NDArray_FREE(result);
         return nullptr;
     }

@@ -8,9 +8,9 @@ flushed as ONE kernel (NDArray_FusedChain -> np_fused_chain) when a value is nee
     y = (a.lazy().exp() * b + 2.0).eval()        # one pass over HBM, bit-identical to
     y = (NDArray.exp(a) * b) + 2.0               # three passes and two temporaries
 
-Chains are linear: acc = f_k(... f_1(a)); binary steps take another GPU array of the same size or
-a Python number.  Anything else (row/column broadcast, reductions, matmul) is evaluated eagerly by
-NDArray as before.
+Chains are linear: acc = f_k(... f_1(a)); binary steps take another GPU array of the same size, a
+smaller GPU array that broadcasts onto the chain's shape (row vector, column, 0-d) or a Python
+number.  Anything else (reductions, matmul) is evaluated eagerly by NDArray as before.
 """
 from __future__ import annotations
 
@@ -72,7 +72,9 @@ class Lazy:
     def __truediv__(self, o): return self._binary("divide", o, False)
     def __rtruediv__(self, o): return self._binary("divide", o, True)
     def __mod__(self, o): return self._binary("mod", o, False)
+    def __rmod__(self, o): return self._binary("mod", o, True)
     def __pow__(self, o): return self._binary("pow", o, False)
+    def __rpow__(self, o): return self._binary("pow", o, True)
 
     def clip(self, min, max): return self._unary("clip", min, max)
     def round(self, precision=0): return self._unary("round", precision)
@@ -100,4 +102,20 @@ def lazy(a: NDArray) -> Lazy:
 
 
 NDArray.lazy = lambda self: Lazy(self)   # $a->lazy() in the PHP surface this stands in for
+
+
+def _defer_to_lazy(name):
+    """`$array (op) $lazy`: let the pending chain absorb the op (Lazy.__r<op>__) instead of
+    NDArray's eager operator trying to coerce a Lazy."""
+    eager = getattr(NDArray, name)
+
+    def op(self, o):
+        if isinstance(o, Lazy):
+            return NotImplemented
+        return eager(self, o)
+    setattr(NDArray, name, op)
+
+
+for _n in ("__add__", "__sub__", "__mul__", "__truediv__", "__mod__", "__pow__"):
+    _defer_to_lazy(_n)
 del _lib

@@ -50,6 +50,45 @@ def test_fused_equals_unfused(shape, hip):
     assert _same(lz.eval().cpu().numpy(), ((ga * ga) + ga).cpu().numpy())
 
 
+@pytest.mark.parametrize("shape", [(250, 400), (33, 1001), (7, 3)])
+def test_fused_broadcast_operands(shape, hip):
+    """Row / column / 0-d device operands inside a chain (ndarray.c:1196-1291 resolved in-kernel):
+    bit-identical to the op-by-op path, incl. the AVX-body bound that depends on WHICH side the
+    small operand is on (arithmetics.c:251)."""
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    from numpower_amd.ndarray import NDArray
+    R, Cc = shape
+    x = synth.uniform(shape, 21, -2.0, 2.0)
+    x.reshape(-1)[::5] = 0.0
+    row = synth.uniform((Cc,), 22, -1.0, 1.0)
+    col = synth.uniform((R, 1), 23, 0.5, 1.5)
+    row1 = synth.uniform((1, Cc), 24, -1.0, 1.0)
+    row[::3] = 0.0
+    gx, grow, gcol, grow1 = (NDArray.array(v).gpu() for v in (x, row, col, row1))
+
+    fused = (gx.lazy().exp() + grow).eval()
+    assert _same(fused.cpu().numpy(), (NDArray.exp(gx) + grow).cpu().numpy())
+    fused = (gx.lazy().exp() + gcol).eval()
+    assert _same(fused.cpu().numpy(), (NDArray.exp(gx) + gcol).cpu().numpy())
+
+    # quirk-carrying ops with the small operand on either side
+    fused = ((gx.lazy() * grow) % gcol).eval()
+    assert _same(fused.cpu().numpy(), ((gx * grow) % gcol).cpu().numpy())
+    fused = (grow * gx.lazy()).eval()
+    assert _same(fused.cpu().numpy(), (grow * gx).cpu().numpy())
+    fused = (gcol % gx.lazy().abs() + grow1).eval()
+    assert _same(fused.cpu().numpy(), ((gcol % NDArray.abs(gx)) + grow1).cpu().numpy())
+    fused = gx.lazy().equal(grow1).eval()
+    assert _same(fused.cpu().numpy(), NDArray.equal(gx, grow1).cpu().numpy())
+    fused = gx.lazy().not_equal(gcol).eval()
+    assert _same(fused.cpu().numpy(), NDArray.not_equal(gx, gcol).cpu().numpy())
+
+    # numpy meaning as an independent check
+    got = (gx.lazy().exp() + grow).eval().cpu().numpy()
+    want = np.exp(x.astype(np.float64)) + row[None, :]
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
 def test_long_chain_splits_and_views(hip):
     from numpower_amd.lazy import Lazy   # noqa: F401
     from numpower_amd.ndarray import NDArray
@@ -69,7 +108,9 @@ def test_fused_errors(hip):
     from numpower_amd.ndarray import Error, NDArray
     a = NDArray.array(np.ones((4, 6), np.float32)).gpu()
     with pytest.raises(Error, match="Can't broadcast arrays."):
-        (a.lazy() + NDArray.array(np.ones((6,), np.float32)).gpu()).eval()
+        (a.lazy() + NDArray.array(np.ones((5,), np.float32)).gpu()).eval()
+    with pytest.raises(Error, match="Can't broadcast arrays."):   # the accumulator would have to grow
+        (NDArray.array(np.ones((6,), np.float32)).gpu().lazy() + a).eval()
     with pytest.raises(Error, match="Device mismatch"):
         (a.lazy() + NDArray.array(np.ones((4, 6), np.float32))).eval()
     with pytest.raises(Error, match="only computes on the GPU"):

@@ -1,4 +1,4 @@
-"""A/B of the fused-chain kernel's knobs (NP_FUSED_U, NP_FUSED_BPC are read once per process, so
+"""A/B of the fused-chain kernel's knobs (NP_FUSED_U, NP_FUSED_FULL are read once per process, so
 each configuration runs in its own subprocess).  Usage: python tools/fused_ab.py"""
 import ctypes as C
 import json
@@ -17,8 +17,11 @@ def one(chain):
     _lib.check(lib.np_init(0))
     n = 100_000_000
     bufs = [_lib.DeviceBuffer(4 * n) for _ in range(4)]
-    for i, b in enumerate(bufs[:3]):
-        _lib.check(lib.np_fill(b.ptr, 0.5 + i, n))
+    import numpy as np
+    from numpower_amd import synth
+    for i, b in enumerate(bufs[:3]):          # random data: constant fills read ~4 % faster
+        h = synth.uniform((n,), 40 + i, 0.25, 1.75)
+        _lib.check(lib.np_memcpy_h2d(b.ptr, h.ctypes.data, 4 * n))
     two = C.c_float(2.0)
     if chain == "exp_mul_add":
         inputs = [bufs[0].ptr, bufs[1].ptr, C.addressof(two)]
@@ -41,15 +44,15 @@ def one(chain):
     o = (FusedOp * len(ops))(*ops)
     t = _lib.Timer()
     for _ in range(5):
-        _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, n))
+        _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, 1, n))
     t.start()
     reps = 30
     for _ in range(reps):
-        _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, n))
+        _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, 1, n))
     t.stop()
     _lib.check(lib.np_sync())
     ms = t.elapsed_ms() / reps
-    print(json.dumps({"chain": chain, "U": os.environ.get("NP_FUSED_U"), "BPC": os.environ.get("NP_FUSED_BPC"),
+    print(json.dumps({"chain": chain, "U": os.environ.get("NP_FUSED_U"), "FULL": os.environ.get("NP_FUSED_FULL"),
                       "ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1)}))
 
 
@@ -58,7 +61,9 @@ if __name__ == "__main__":
         one(sys.argv[1])
     else:
         for chain in ("exp_mul_add", "fma3", "unary6"):
-            for u in ("1", "2", "4"):
-                for bpc in ("0", "8", "16"):
-                    env = dict(os.environ, NP_FUSED_U=u, NP_FUSED_BPC=bpc)
+            for u in ("1", "2"):
+                for full in (None, "1"):
+                    env = dict(os.environ, NP_FUSED_U=u)
+                    if full:
+                        env["NP_FUSED_FULL"] = full
                     subprocess.run([sys.executable, __file__, chain], env=env, check=False)
