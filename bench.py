@@ -251,6 +251,16 @@ def bench_extras(dist: Dist, steps, warmup):
                  lambda: D.binary("greater", da, "full", db, "full", 1, N, out=do), steps, warmup, dist)
     r["parity_ok"] = bool((do.to_host().reshape(-1) == (a > b).astype(np.float32)).all())
     ex["greater_1e8"] = r
+    # §8(f) row 1: NDArray_ArrayEqual / AllClose as one streaming reduction, 8 B/elem, result on the host
+    flag = C.c_int(0)
+    lib0 = load()
+    from numpower_amd._lib import check as _check
+    r = hbm_case("allclose(a, a') 1e8 fp32 (logic.c:719-772, §8f)", 8.0 * N,
+                 lambda: _check(lib0.np_count_mismatch(1, da.ptr, db.ptr, N, 1e-5, 1e-8, C.byref(flag))),
+                 steps, warmup, dist)
+    r["parity_ok"] = bool(flag.value == 1)      # a, b are independent uniforms: not close
+    r["note"] = "includes the 4-byte D2H of the verdict per call"
+    ex["allclose_1e8"] = r
     # exp(a) * b + 2 as ONE fused kernel (12 B/elem) vs three launches
     from numpower_amd._lib import BINARY_OPS, UNARY_OPS, FusedOp, check
     prog = (FusedOp * 3)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0),

@@ -232,6 +232,18 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
  * intended meaning for every element. */
 int np_all(const float *in, size_t n, unsigned flags, int *host_out);
 
+/* Two-array predicates reduced to one flag (one streaming pass, 8 B/elem, no mask temporary):
+ *   NP_MISMATCH_EXACT     *host_any = 1 if a[i] != b[i] for some i     compare_ndarrays, logic.c:686-690
+ *                         (NaN != NaN counts, as in the reference's C loop; its CUDA path,
+ *                         cuda_equal_float, is a launch + D2H of a flag per call)
+ *   NP_MISMATCH_ALLCLOSE  *host_any = 1 if |a[i]-b[i]| > atol + rtol*|b[i]| for some i
+ *                         float_allclose, logic.c:719-738 (a NaN on either side compares false,
+ *                         i.e. "close", exactly as the reference's expression does; the reference
+ *                         rejects GPU arrays: "`allclose` is not compatible with GPU operations.") */
+typedef enum np_mismatch_mode { NP_MISMATCH_EXACT = 0, NP_MISMATCH_ALLCLOSE = 1 } np_mismatch_mode;
+int np_count_mismatch(int mode, const float *a, const float *b, size_t n, float rtol, float atol,
+                      int *host_any);
+
 /* Reduce the middle axis of a contiguous array viewed as outer x axis_len x inner; out has
  * outer*inner elements.  Replaces the host-side recursion reduce()/_reduce()/apply_reduce()
  * (ndarray.c:523-578,394-429,358-368), which issues one Add_Float + alloc + D2D copy + free
@@ -271,6 +283,12 @@ int np_transpose2d(const float *in, float *out, size_t batch, size_t rows, size_
  * (NDArray_Transpose + NDArray_ToContiguous, manipulation.c:68-130,381-421).  ndim <= 8;
  * shape/perm are host arrays.  Errors: "axes don't match array", "repeated axis in transpose". */
 int np_permute(const float *in, float *out, int ndim, const int *host_shape, const int *host_perm);
+/* Gather a strided view into a contiguous buffer: out[i0]...[ik] = in[sum i_d * strides[d]]
+ * (strides in ELEMENTS, may be negative or zero).  One launch instead of NDArray_ToContiguous's
+ * one 4-byte D2D memcpy per element (manipulation.c:381-421); also what NDArray_Diagonal
+ * (indexing.c:21-48: one memcpy per diagonal element) and multi-index NDArray_Slice
+ * (manipulation.c:193-283) reduce to. */
+int np_strided_copy(const float *in, float *out, int ndim, const int *host_shape, const long long *host_strides);
 
 /* Kernel-variant selection for tuning/benchmarks (0 = default heuristic). */
 int np_sgemm_set_variant(int variant);

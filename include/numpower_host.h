@@ -125,6 +125,30 @@ typedef struct NDArray_Dims {   /* src/ndarray.h:40-43 */
 /* New contiguous array with the axes permuted (NULL = reverse all axes). */
 NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute);
 
+/* ---- views, layout and equality around the path ----
+ * NDArray_ArrayEqual   logic.c:703-716      1 / 0 (0 on shape mismatch)
+ * NDArray_AllClose     logic.c:750-772      1 / 0, -1 + error on shape / device mismatch (the
+ *                                           reference rejects GPU arrays; here it is one reduction)
+ * NDArray_ToContiguous manipulation.c:381-421   strided view -> new contiguous array, one launch
+ * NDArray_Diagonal     indexing.c:21-48     (`offset` is ignored, as in the reference)
+ * NDArray_Trace        linalg.c:758-767     0-d CPU scalar
+ * NDArray_Reshape      manipulation.c:138-162   view sharing data (ADDREFs target)
+ * NDArray_Flatten      manipulation.c:169-184   1-D copy
+ * NDArray_ExpandDim    manipulation.c:453-513   axis: 0-d or 1-D CPU array
+ * NDArray_ConcatenateFlat / NDArray_Append  manipulation.c:293-374 (axis must be -1)
+ * NDArray_Slice        manipulation.c:193-283   indexes[i] = CPU array [start(,stop(,step))] */
+int NDArray_ArrayEqual(NDArray *a, NDArray *b);
+int NDArray_AllClose(NDArray *a, NDArray *b, float rtol, float atol);
+NDArray *NDArray_ToContiguous(NDArray *a);
+NDArray *NDArray_Diagonal(NDArray *target, int offset);
+NDArray *NDArray_Trace(NDArray *a);
+NDArray *NDArray_Reshape(NDArray *target, int *new_shape, int ndim);
+NDArray *NDArray_Flatten(NDArray *target);
+NDArray *NDArray_ExpandDim(NDArray *a, NDArray *axis);
+NDArray *NDArray_ConcatenateFlat(NDArray **arrays, int num_arrays);
+NDArray *NDArray_Append(NDArray **arrays, int axis, int num_arrays);
+NDArray *NDArray_Slice(NDArray *array, NDArray **indexes, int num_indices);
+
 /* ---- fused elementwise chains ----
  * Evaluates acc = inputs[0]; acc = op_k(acc [, inputs[operand_k]]) ... in one kernel; `ops` uses
  * np_fused_op of np_hip.h (flags/body_end are filled in here).  Bit-identical to calling the

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "np_reduce_all": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.POINTER(C.c_float)]),
     "np_reduce_all_dev": (C.c_int, [C.c_int, _f32p, C.c_size_t, _f32p]),
     "np_all": (C.c_int, [_f32p, C.c_size_t, C.c_uint, C.POINTER(C.c_int)]),
+    "np_count_mismatch": (C.c_int, [C.c_int, _f32p, _f32p, C.c_size_t, C.c_float, C.c_float, C.POINTER(C.c_int)]),
     "np_argreduce": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p]),
     "np_moments": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "np_weighted_sums": (C.c_int, [_f32p, _f32p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -85,6 +86,7 @@ PROTOTYPES = {
     "np_sgemv": (C.c_int, [C.c_size_t, C.c_size_t, _f32p, _f32p, _f32p]),
     "np_transpose2d": (C.c_int, [_f32p, _f32p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "np_permute": (C.c_int, [_f32p, _f32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "np_strided_copy": (C.c_int, [_f32p, _f32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "np_sgemm_set_variant": (C.c_int, [C.c_int]),
     "np_elementwise_set_variant": (C.c_int, [C.c_int]),
     "np_layout_set_variant": (C.c_int, [C.c_int]),

@@ -212,4 +212,43 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
     return NP_OK;
 }
 
+int np_strided_copy(const float *in, float *out, int ndim, const int *host_shape, const long long *host_strides) {
+    if (ndim < 0 || ndim > MAX_ND) return np::fail(NP_ERR_INVALID, "np_strided_copy: ndim %d not in 0..%d", ndim, MAX_ND);
+    if (ndim > 0 && (!host_shape || !host_strides)) return np::fail(NP_ERR_INVALID, "np_strided_copy: null shape/strides");
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (host_shape[i] < 0) return np::fail(NP_ERR_INVALID, "np_strided_copy: negative dimension");
+        n *= (size_t)host_shape[i];
+    }
+    if (n == 0) return NP_OK;
+    if (!in || !out) return np::fail(NP_ERR_INVALID, "np_strided_copy: null pointer");
+    if (int rc = np::ensure_init()) return rc;
+    bool contiguous = true;
+    size_t expect = 1;
+    for (int i = ndim - 1; i >= 0; --i) {
+        if (host_shape[i] != 1 && host_strides[i] != (long long)expect) contiguous = false;
+        expect *= (size_t)host_shape[i];
+    }
+    if (contiguous) return np_memcpy_d2d(out, in, n * sizeof(float));
+    PermuteArgs a;
+    a.ndim = (unsigned)ndim;
+    for (int i = 0; i < MAX_ND; ++i) {
+        a.out_shape[i] = 1;
+        a.in_stride[i] = 0;
+    }
+    for (int i = 0; i < ndim; ++i) {
+        a.out_shape[i] = (unsigned)host_shape[i];
+        a.in_stride[i] = (size_t)host_strides[i];   // negative strides wrap modulo 2^64, as pointer arithmetic does
+    }
+    size_t blocks = (n + 255) / 256;
+    const size_t cap = (size_t)np::num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (n < (size_t(1) << 31))
+        permute_gather_kernel<uint32_t><<<(unsigned)blocks, 256, 0, np::stream()>>>(in, out, (uint32_t)n, a);
+    else
+        permute_gather_kernel<uint64_t><<<(unsigned)blocks, 256, 0, np::stream()>>>(in, out, (uint64_t)n, a);
+    NP_LAUNCH_CHECK("permute_gather_kernel");
+    return NP_OK;
+}
+
 }  // extern "C"

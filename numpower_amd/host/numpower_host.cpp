@@ -30,6 +30,7 @@
 namespace {
 
 const char *const TYPE_FLOAT32 = "float32";   // src/types.h:5
+constexpr int NP_MAX_ND_HOST = 8;   // np_permute / np_strided_copy handle up to 8 axes
 
 thread_local char g_error[512] = "";
 numpower_error_handler g_handler = nullptr;
@@ -495,6 +496,311 @@ NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute) {
         return nullptr;
     }
     return ret;
+}
+
+/* ---- views, layout and equality around the path ---- */
+namespace {
+
+// NDArray_FromNDArrayBase (initializers.c): header over someone else's buffer
+NDArray *make_view(NDArray *base, char *data, const int *shape, int ndim) {
+    NDArray *r = make_header(shape, ndim, base->device);
+    r->data = data;
+    r->base = base;
+    base->refcount++;   // NDArray_ADDREF
+    return r;
+}
+
+bool is_c_contiguous(const NDArray *a) {
+    int expect = (int)sizeof(float);
+    for (int i = a->ndim - 1; i >= 0; --i) {
+        if (a->dimensions[i] != 1 && a->strides[i] != expect) return false;
+        expect *= a->dimensions[i];
+    }
+    return true;
+}
+
+// gather `shape` elements starting at `data` with byte strides into a fresh contiguous GPU array
+NDArray *gather_to_new(const NDArray *like, const char *data, const int *shape, const int *byte_strides, int ndim) {
+    NDArray *r = new_array(shape, ndim, NDARRAY_DEVICE_GPU, false);
+    if (!r) return nullptr;
+    long long st[NP_MAX_ND_HOST];
+    for (int i = 0; i < ndim; ++i) st[i] = (long long)byte_strides[i] / (long long)sizeof(float);
+    (void)like;
+    if (!dev_ok(np_strided_copy((const float *)data, NDArray_FDATA(r), ndim, shape, st))) {
+        NDArray_FREE(r);
+        return nullptr;
+    }
+    return r;
+}
+
+}  // namespace
+
+int NDArray_ArrayEqual(NDArray *a, NDArray *b) {   // logic.c:703-716
+    if (!a || !b) return 0;
+    if (!same_shape(a, b)) return 0;
+    if (!require_gpu(a, "array_equal") || !require_gpu(b, "array_equal")) return 0;
+    int any = 0;
+    if (!dev_ok(np_count_mismatch(NP_MISMATCH_EXACT, NDArray_FDATA(a), NDArray_FDATA(b),
+                                  (size_t)NDArray_NUMELEMENTS(a), 0.0f, 0.0f, &any)))
+        return 0;
+    return any ? 0 : 1;
+}
+
+int NDArray_AllClose(NDArray *a, NDArray *b, float rtol, float atol) {   // logic.c:750-772
+    if (!a || !b) return -1;
+    if (!same_shape(a, b)) {
+        throw_error("Shape mismatch");
+        return -1;
+    }
+    if (NDArray_DEVICE(a) != NDArray_DEVICE(b)) {
+        throw_error("NDArray::allclose() requires both arrays to be on the same device (CPU or GPU).");
+        return -1;
+    }
+    // the reference stops here for GPU arrays ("`allclose` is not compatible with GPU operations.")
+    if (!require_gpu(a, "allclose")) return -1;
+    int any = 0;
+    if (!dev_ok(np_count_mismatch(NP_MISMATCH_ALLCLOSE, NDArray_FDATA(a), NDArray_FDATA(b),
+                                  (size_t)NDArray_NUMELEMENTS(a), rtol, atol, &any)))
+        return -1;
+    return any ? 0 : 1;
+}
+
+NDArray *NDArray_ToContiguous(NDArray *a) {   // manipulation.c:381-421
+    if (!a) return nullptr;
+    if (!require_gpu(a, "ToContiguous")) return nullptr;
+    if (a->ndim > NP_MAX_ND_HOST) {
+        throw_error("ToContiguous: more than %d dimensions", NP_MAX_ND_HOST);
+        return nullptr;
+    }
+    return gather_to_new(a, a->data, a->dimensions, a->strides, a->ndim);
+}
+
+// The reference ignores `offset` and takes shape[last] elements (indexing.c:29-33), which walks off
+// the buffer when rows < cols; min(rows, cols) is the same wherever the reference is defined.
+NDArray *NDArray_Diagonal(NDArray *target, int offset) {   // indexing.c:21-48
+    (void)offset;
+    if (!target) return nullptr;
+    if (NDArray_NDIM(target) != 2) {
+        throw_error("NDArray_Diagonal: Array must be 2-d.");
+        return nullptr;
+    }
+    if (!require_gpu(target, "diagonal")) return nullptr;
+    const int rows = target->dimensions[0], cols = target->dimensions[1];
+    const int shape[1] = {rows < cols ? rows : cols};
+    const int stride[1] = {target->strides[0] + target->strides[1]};
+    return gather_to_new(target, target->data, shape, stride, 1);
+}
+
+NDArray *NDArray_Trace(NDArray *a) {   // linalg.c:758-767
+    NDArray *diagonal = NDArray_Diagonal(a, 0);
+    if (!diagonal) return nullptr;
+    numpower_host_clear_error();
+    const float result = NDArray_Sum_Float(diagonal);
+    NDArray_FREE(diagonal);
+    if (g_error[0]) return nullptr;
+    return NDArray_CreateFromFloatScalar(result);
+}
+
+NDArray *NDArray_Reshape(NDArray *target, int *new_shape, int ndim) {   // manipulation.c:138-162
+    if (!target) return nullptr;
+    if (new_shape == nullptr) {
+        throw_error("new shape cannot be null.");
+        return nullptr;
+    }
+    long total = 1;
+    for (int i = 0; i < ndim; ++i) total *= new_shape[i];
+    if (total != NDArray_NUMELEMENTS(target)) {
+        throw_error("incompatible shape in reshape call.");
+        return nullptr;
+    }
+    return make_view(target, target->data, new_shape, ndim);   // shares data, ADDREFs target
+}
+
+NDArray *NDArray_Flatten(NDArray *target) {   // manipulation.c:169-184: always a copy
+    if (!target) return nullptr;
+    NDArray *rtn = NDArray_Copy(target, NDArray_DEVICE(target));
+    if (!rtn) return nullptr;
+    const int n = (int)NDArray_NUMELEMENTS(target);
+    rtn->ndim = 1;
+    rtn->dimensions[0] = n;
+    rtn->strides[0] = (int)sizeof(float);
+    return rtn;
+}
+
+NDArray *NDArray_ExpandDim(NDArray *a, NDArray *axis) {   // manipulation.c:453-513
+    if (!a || !axis) return nullptr;
+    if (NDArray_DEVICE(axis) != NDARRAY_DEVICE_CPU) {
+        throw_error("expand_dims: axis must be a CPU scalar or vector");
+        return nullptr;
+    }
+    if (NDArray_NDIM(axis) > 1) {
+        throw_error("axis must be either a scalar or a vector. Found matrix with %d dimensions.", NDArray_NDIM(axis));
+        return nullptr;
+    }
+    const int n_axis = (int)NDArray_NUMELEMENTS(axis);
+    const int out_ndim = n_axis + NDArray_NDIM(a);
+    if (out_ndim > NP_MAX_ND_HOST) {
+        throw_error("expand_dims: more than %d dimensions", NP_MAX_ND_HOST);
+        return nullptr;
+    }
+    int norm[NP_MAX_ND_HOST];
+    for (int i = 0; i < n_axis; ++i) {
+        int ax = (int)NDArray_FDATA(axis)[i];
+        if (ax < -out_ndim || ax >= out_ndim) {   // check_and_adjust_axis, manipulation.c:41-54
+            throw_error("invalid axis or axes provided.");
+            return nullptr;
+        }
+        if (ax < 0) ax += out_ndim;
+        norm[i] = ax;
+    }
+    int out_shape[NP_MAX_ND_HOST];
+    int it = 0;
+    for (int ax = 0; ax < out_ndim; ++ax) {
+        bool found = false;
+        for (int i = 0; i < n_axis; ++i) found = found || norm[i] == ax;
+        if (found) {
+            out_shape[ax] = 1;
+        } else {
+            // repeated axes leave fewer slots than a has dimensions; the reference then reads past
+            // a's shape — report it instead
+            if (it >= NDArray_NDIM(a)) {
+                throw_error("invalid axis or axes provided.");
+                return nullptr;
+            }
+            out_shape[ax] = a->dimensions[it++];
+        }
+    }
+    return NDArray_Reshape(a, out_shape, out_ndim);
+}
+
+NDArray *NDArray_ConcatenateFlat(NDArray **arrays, int num_arrays) {   // manipulation.c:293-361
+    if (num_arrays <= 0 || !arrays) {
+        throw_error("need at least one array to concatenate");
+        return nullptr;
+    }
+    long total = 0;
+    for (int i = 0; i < num_arrays; ++i) {
+        if (!arrays[i]) return nullptr;
+        total += NDArray_NUMELEMENTS(arrays[i]);
+        if (total > 0x7fffffffL) {
+            throw_error("total number of elements too large to concatenate");
+            return nullptr;
+        }
+    }
+    if (!require_gpu(arrays[0], "append")) return nullptr;
+    const int shape[1] = {(int)total};
+    NDArray *ret = new_array(shape, 1, NDARRAY_DEVICE_GPU, false);
+    if (!ret) return nullptr;
+    char *dst = ret->data;
+    for (int i = 0; i < num_arrays; ++i) {
+        const size_t bytes = (size_t)NDArray_NUMELEMENTS(arrays[i]) * sizeof(float);
+        // 0-d operands are host scalars (manipulation.c:344-347); everything else must be on the GPU
+        int rc;
+        if (NDArray_DEVICE(arrays[i]) == NDARRAY_DEVICE_GPU) {
+            rc = np_memcpy_d2d(dst, arrays[i]->data, bytes);
+        } else if (NDArray_NDIM(arrays[i]) == 0) {
+            rc = np_memcpy_h2d(dst, arrays[i]->data, bytes);
+        } else {
+            throw_error("Device mismatch, both NDArray MUST be in the same device.");
+            NDArray_FREE(ret);
+            return nullptr;
+        }
+        if (!dev_ok(rc)) {
+            NDArray_FREE(ret);
+            return nullptr;
+        }
+        dst += bytes;
+    }
+    return ret;
+}
+
+NDArray *NDArray_Append(NDArray **arrays, int axis, int num_arrays) {   // manipulation.c:368-374
+    if (axis == -1) return NDArray_ConcatenateFlat(arrays, num_arrays);
+    return nullptr;
+}
+
+// NDArray_Slice (manipulation.c:193-283): indexes[i] is a small CPU array [start], [start, stop] or
+// [start, stop, step] for axis i (Slice_GetIndices, indexing.c:59-108).  One-element indexes select
+// and drop the axis.  The reference returns a strided VIEW for a single index and a gathered copy
+// for several; because every hot-path op reads `numElements` contiguous floats from `data`
+// (SURVEY.md §8a), a strided view would be misread by the next op — here the result is a view only
+// when it is contiguous, otherwise ONE np_strided_copy launch.
+NDArray *NDArray_Slice(NDArray *array, NDArray **indexes, int num_indices) {
+    if (!array || !indexes) return nullptr;
+    if (num_indices > NDArray_NDIM(array)) {
+        throw_error("too many indices for array.");
+        return nullptr;
+    }
+    const int nd = NDArray_NDIM(array);
+    if (nd > NP_MAX_ND_HOST) {
+        throw_error("slice: more than %d dimensions", NP_MAX_ND_HOST);
+        return nullptr;
+    }
+    int new_shape[NP_MAX_ND_HOST], new_strides[NP_MAX_ND_HOST];
+    int out_nd = 0;
+    char *data_ptr = array->data;
+    for (int i = 0; i < nd; ++i) {
+        const int length = array->dimensions[i];
+        if (i >= num_indices) {   // untouched trailing axes
+            new_shape[out_nd] = length;
+            new_strides[out_nd++] = array->strides[i];
+            continue;
+        }
+        NDArray *ix = indexes[i];
+        if (!ix || NDArray_DEVICE(ix) != NDARRAY_DEVICE_CPU) {
+            throw_error("Slicing error");
+            return nullptr;
+        }
+        const long cnt = NDArray_NUMELEMENTS(ix);
+        const bool has_start = cnt >= 1, has_stop = cnt >= 2, has_step = cnt == 3;
+        int step = has_step ? (int)NDArray_FDATA(ix)[2] : 1;
+        if (step == 0) {
+            throw_error("slice step cannot be zero");
+            return nullptr;
+        }
+        int start, stop, n_steps;
+        if (!has_start) {
+            start = step < 0 ? length - 1 : 0;
+        } else {
+            start = (int)NDArray_FDATA(ix)[0];
+            if (start < 0) start += length;
+            if (start < 0) start = step < 0 ? -1 : 0;
+            if (start >= length) start = step < 0 ? length - 1 : length;
+        }
+        if (!has_stop) {
+            stop = step < 0 ? -1 : length;
+        } else {
+            stop = (int)NDArray_FDATA(ix)[1];
+            if (stop < 0) stop += length;
+            if (stop < 0) stop = -1;
+            if (stop > length) stop = length;
+        }
+        if ((step < 0 && stop >= start) || (step > 0 && start >= stop))
+            n_steps = 0;
+        else if (step < 0)
+            n_steps = (stop - start + 1) / step + 1;
+        else
+            n_steps = (stop - start - 1) / step + 1;
+        if (n_steps <= 0) {   // manipulation.c:231-235
+            n_steps = 0;
+            step = 1;
+            start = 0;
+        }
+        data_ptr += (long)array->strides[i] * start;
+        if (cnt == 1) continue;   // integer index: axis dropped
+        new_shape[out_nd] = n_steps;
+        new_strides[out_nd++] = array->strides[i] * step;
+    }
+    // contiguous result -> view; otherwise gather
+    int expect = (int)sizeof(float);
+    bool contiguous = true;
+    for (int i = out_nd - 1; i >= 0; --i) {
+        if (new_shape[i] != 1 && new_strides[i] != expect) contiguous = false;
+        expect *= new_shape[i];
+    }
+    if (contiguous || shape_numel(new_shape, out_nd) == 0) return make_view(array, data_ptr, new_shape, out_nd);
+    if (!require_gpu(array, "slice")) return nullptr;
+    return gather_to_new(array, data_ptr, new_shape, new_strides, out_nd);
 }
 
 /* ---- fused elementwise chains ---- */

@@ -112,6 +112,16 @@ def _load_host():
     sig["NDArray_Variance"] = (_P, [_P])
     sig["NDArray_Std"] = (_P, [_P])
     sig["NDArray_Average"] = (_P, [_P, _P])
+    sig["NDArray_ArrayEqual"] = (C.c_int, [_P, _P])
+    sig["NDArray_AllClose"] = (C.c_int, [_P, _P, C.c_float, C.c_float])
+    sig["NDArray_ToContiguous"] = (_P, [_P])
+    sig["NDArray_Diagonal"] = (_P, [_P, C.c_int])
+    sig["NDArray_Trace"] = (_P, [_P])
+    sig["NDArray_Reshape"] = (_P, [_P, ip, C.c_int])
+    sig["NDArray_Flatten"] = (_P, [_P])
+    sig["NDArray_ExpandDim"] = (_P, [_P, _P])
+    sig["NDArray_Append"] = (_P, [C.POINTER(_P), C.c_int, C.c_int])
+    sig["NDArray_Slice"] = (_P, [_P, C.POINTER(_P), C.c_int])
     for name, (res, args) in sig.items():
         fn = getattr(h, name)
         fn.restype = res
@@ -384,6 +394,79 @@ class NDArray:
         arr = (C.c_int * max(len(axes), 1))(*[int(v) for v in axes])
         dims = _CDims(arr, len(axes))
         return NDArray._wrap(h.NDArray_Transpose(x._p, C.byref(dims)))
+
+    # ---- views / layout / equality around the path ----
+    @staticmethod
+    def reshape(a, shape):   # PHP_METHOD reshape, numpower.c:644: a view sharing the buffer
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        arr = (C.c_int * max(len(shape), 1))(*[int(v) for v in shape])
+        return NDArray._wrap(h.NDArray_Reshape(x._p, arr, len(shape)))
+
+    @staticmethod
+    def flatten(a):          # numpower.c:1584
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(h.NDArray_Flatten(x._p))
+
+    @staticmethod
+    def expand_dims(a, axis):   # numpower.c:3563: axis int or list of ints
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        ax, _ = NDArray._coerce(axis)
+        return NDArray._wrap(h.NDArray_ExpandDim(x._p, ax._p))
+
+    @staticmethod
+    def append(a, b):        # numpower.c:3908: flat concatenation (axis = -1)
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        y, _ = NDArray._coerce(b)
+        arr = (_P * 2)(x._p, y._p)
+        return NDArray._wrap(h.NDArray_Append(arr, -1, 2))
+
+    @staticmethod
+    def diagonal(a):         # numpower.c:1179
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(h.NDArray_Diagonal(x._p, 0))
+
+    @staticmethod
+    def trace(a):            # numpower.c:4067
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(h.NDArray_Trace(x._p))
+
+    @staticmethod
+    def array_equal(a, b) -> bool:   # the `==` handler of the PHP object, numpower.c:175-186
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        y, _ = NDArray._coerce(b)
+        h.numpower_host_clear_error()
+        r = h.NDArray_ArrayEqual(x._p, y._p)
+        if h.numpower_host_last_error():
+            _raise_pending(h)
+        return bool(r)
+
+    @staticmethod
+    def allclose(a, b, rtol=1e-05, atol=1e-08) -> bool:   # numpower.c:1358-1391
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        y, _ = NDArray._coerce(b)
+        if x is y:
+            return True
+        r = h.NDArray_AllClose(x._p, y._p, float(rtol), float(atol))
+        if r == -1:
+            _raise_pending(h)
+        return bool(r)
+
+    def slice(self, *indices):   # PHP_METHOD slice, numpower.c:4773: each index [start(,stop(,step))]
+        h = _load_host()
+        idx = [NDArray._coerce(list(i) if isinstance(i, (list, tuple)) else [i])[0] for i in indices]
+        arr = (_P * max(len(idx), 1))(*[i._p for i in idx])
+        return NDArray._wrap(h.NDArray_Slice(self._p, arr, len(idx)))
+
+    def contiguous(self):        # NDArray_ToContiguous
+        return NDArray._wrap(_load_host().NDArray_ToContiguous(self._p))
 
     # ---- argmax / argmin (PHP_METHOD argmax / argmin, numpower.c:2570-2630) ----
     @staticmethod

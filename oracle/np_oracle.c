@@ -499,6 +499,29 @@ float oracle_all(const float *array, long n) {
     return 1;
 }
 
+/* compare_ndarrays (logic.c:678-693), CPU branch: 1 unless some a[i] != b[i] (NaN != NaN) */
+int oracle_array_equal(const float *a, const float *b, long n) {
+    int same = 1;
+    for (long i = 0; i < n; i++)
+        if (a[i] != b[i]) same = 0;
+    return same;
+}
+
+/* float_allclose (logic.c:719-738) with the element index the loop means: the reference computes
+ * index = i*sizeof(float) + i*strides[0]/sizeof(float) (= 5i for a contiguous vector), i.e. it
+ * reads past the buffer for every i > 0 — its own KAT (tests/logic/002) only survives because the
+ * first element already decides / the PHP method short-cuts identical handles.  Restated per
+ * element i; the tolerance is one fused multiply-add, as gcc -march=native contracts
+ * `atol + rtol * fabsf(b)`. */
+int oracle_allclose(const float *a, const float *b, long n, float rtol, float atol) {
+    for (long i = 0; i < n; i++) {
+        float diff = fabsf(a[i] - b[i]);
+        float tolerance = fmaf(rtol, fabsf(b[i]), atol);
+        if (diff > tolerance) return 0;
+    }
+    return 1;
+}
+
 /* NDArray::mean without axis: NDArray_Sum_Float(nda) / NDArray_NUMELEMENTS(nda) (numpower.c:2659) */
 float oracle_mean(const float *a, long n) { return oracle_sum(a, n) / n; }
 

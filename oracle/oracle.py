@@ -168,6 +168,148 @@ def transpose(x, axes=None) -> np.ndarray:
     return out.reshape(tuple(oshape[i] for i in range(x.ndim)))
 
 
+def array_equal(a, b) -> int:
+    """NDArray_ArrayEqual (logic.c:703-716)."""
+    a, b = _f(a), _f(b)
+    if a.shape != b.shape:
+        return 0
+    lib = load()
+    lib.oracle_array_equal.restype = C.c_int
+    lib.oracle_array_equal.argtypes = [_fp, _fp, C.c_long]
+    return int(lib.oracle_array_equal(_ptr(a), _ptr(b), a.size))
+
+
+def allclose(a, b, rtol: float = 1e-05, atol: float = 1e-08) -> int:
+    """NDArray_AllClose (logic.c:750-772) / float_allclose, per-element meaning (see np_oracle.c)."""
+    a, b = _f(a), _f(b)
+    if a.shape != b.shape:
+        raise OracleError("Shape mismatch")
+    lib = load()
+    lib.oracle_allclose.restype = C.c_int
+    lib.oracle_allclose.argtypes = [_fp, _fp, C.c_long, C.c_float, C.c_float]
+    return int(lib.oracle_allclose(_ptr(a), _ptr(b), a.size, rtol, atol))
+
+
+# ---- views / layout: index bookkeeping only (bit-exact by construction), numpy restatements ----
+
+def reshape(x, shape) -> np.ndarray:
+    """NDArray_Reshape (manipulation.c:138-162): same buffer, new shape."""
+    x = _f(x)
+    total = 1
+    for v in shape:
+        total *= int(v)
+    if total != x.size:
+        raise OracleError("incompatible shape in reshape call.")
+    return x.reshape(tuple(int(v) for v in shape))
+
+
+def flatten(x) -> np.ndarray:
+    """NDArray_Flatten (manipulation.c:169-184): 1-D copy (a 0-d input becomes [x])."""
+    return _f(x).reshape(-1).copy()
+
+
+def expand_dims(x, axis) -> np.ndarray:
+    """NDArray_ExpandDim (manipulation.c:453-513): axes normalised against the OUTPUT rank
+    (check_and_adjust_axis, manipulation.c:41-54), remaining slots take x's dimensions in order."""
+    x = _f(x)
+    axes = [int(a) for a in (axis if isinstance(axis, (list, tuple)) else [axis])]
+    out_ndim = len(axes) + x.ndim
+    norm = []
+    for a in axes:
+        if a < -out_ndim or a >= out_ndim:
+            raise OracleError("invalid axis or axes provided.")
+        norm.append(a + out_ndim if a < 0 else a)
+    shape, it = [], 0
+    for ax in range(out_ndim):
+        if ax in norm:
+            shape.append(1)
+        else:
+            if it >= x.ndim:
+                raise OracleError("invalid axis or axes provided.")
+            shape.append(x.shape[it])
+            it += 1
+    return reshape(x, shape)
+
+
+def append(a, b) -> np.ndarray:
+    """NDArray_Append(axis = -1) -> NDArray_ConcatenateFlat (manipulation.c:293-374)."""
+    return np.concatenate([_f(a).reshape(-1), _f(b).reshape(-1)])
+
+
+def diagonal(x) -> np.ndarray:
+    """NDArray_Diagonal (indexing.c:21-48): element i at byte offset i*(strides[0]+strides[1]);
+    the reference takes shape[1] of them (reads past the buffer when rows < cols) — min(rows, cols)
+    is the same wherever that is defined."""
+    x = _f(x)
+    if x.ndim != 2:
+        raise OracleError("NDArray_Diagonal: Array must be 2-d.")
+    n = min(x.shape)
+    flat = x.reshape(-1)
+    return flat[np.arange(n) * (x.shape[1] + 1)].copy()
+
+
+def trace(x) -> np.float32:
+    """NDArray_Trace (linalg.c:758-767): NDArray_Sum_Float of the diagonal."""
+    return reduce_all("sum", diagonal(x))
+
+
+def slice_indices(length: int, index):
+    """Slice_GetIndices (indexing.c:59-108) -> (start, step, count)."""
+    index = [int(v) for v in index]
+    step = index[2] if len(index) == 3 else 1
+    if step == 0:
+        raise OracleError("slice step cannot be zero")
+    if len(index) >= 1:
+        start = index[0]
+        if start < 0:
+            start += length
+        if start < 0:
+            start = -1 if step < 0 else 0
+        if start >= length:
+            start = length - 1 if step < 0 else length
+    else:
+        start = length - 1 if step < 0 else 0
+    if len(index) >= 2:
+        stop = index[1]
+        if stop < 0:
+            stop += length
+        if stop < 0:
+            stop = -1
+        if stop > length:
+            stop = length
+    else:
+        stop = -1 if step < 0 else length
+    if (step < 0 and stop >= start) or (step > 0 and start >= stop):
+        count = 0
+    elif step < 0:
+        count = int((stop - start + 1) / step) + 1     # C integer division truncates
+    else:
+        count = int((stop - start - 1) / step) + 1
+    if count <= 0:
+        count, step, start = 0, 1, 0
+    return start, step, count
+
+
+def slice_(x, *indices) -> np.ndarray:
+    """NDArray_Slice (manipulation.c:193-283) + NDArray_ToContiguous: one-element indexes pick and
+    drop the axis, [start, stop(, step)] select a range."""
+    x = _f(x)
+    if len(indices) > x.ndim:
+        raise OracleError("too many indices for array.")
+    sel = []
+    for i, index in enumerate(indices):
+        index = list(index) if isinstance(index, (list, tuple)) else [index]
+        start, step, count = slice_indices(x.shape[i], index)
+        if len(index) == 1:
+            sel.append(start)
+        else:
+            sel.append(start + step * np.arange(count))
+    out = x
+    for axis in range(len(sel) - 1, -1, -1):       # last axis first so earlier axes keep their position
+        out = np.take(out, sel[axis], axis=axis)
+    return np.ascontiguousarray(out, dtype=np.float32)
+
+
 def average_weighted(a, w) -> np.float32:
     a, w = _f(a), _f(w)
     return np.float32(load().oracle_average_weighted(_ptr(a), _ptr(w), a.size))

@@ -22,12 +22,13 @@ OUT = Path(__file__).resolve().parent / "phpt_vectors.json"
 
 FILES = sorted((REF / "tests" / "math").glob("*.phpt")) + [REF / "tests" / "linalg" / "001-ndarray-matmul.phpt"]
 # SURVEY.md §8f row 1 (comparison / logic elementwise); 002-ndarray-allclose is CPU-only in the reference
-FILES += [f for f in sorted((REF / "tests" / "logic").glob("*.phpt")) if "allclose" not in f.name]
+FILES += [f for f in sorted((REF / "tests" / "logic").glob("*.phpt")) if "allclose" not in f.name]   # allclose: below
 # §8f row 3 (layout ops on device)
-FILES += [REF / "tests" / "manipulation" / "001-ndarray-transpose.phpt"]
+FILES += sorted((REF / "tests" / "manipulation").glob("*.phpt"))
+FILES += [REF / "tests" / "linalg" / "003-ndarray-trace.phpt", REF / "tests" / "logic" / "002-ndarray-allclose.phpt"]
 
 ASSIGN = re.compile(r"^\$(\w+) = \\NDArray::array\((.*)\);$")
-PRINT = re.compile(r"^print_r\((.*)\);$")
+PRINT = re.compile(r"^(print_r|var_dump)\((.*)\);$")
 OPER = re.compile(r"^\((.+?) (\+|-|\*\*|\*|/|%) (.+)\)->toArray\(\)$")
 CALL = re.compile(r"^\\NDArray::(\w+)\((.*)\)$")
 
@@ -51,6 +52,9 @@ def split_args(s):
 
 
 def operand(tok):
+    c = CALL.match(tok)
+    if c:                                   # nested static call, e.g. reshape(reshape($b, [2, 2]), [1, 4])
+        return {"call": static_call(c)}
     m = re.fullmatch(r"\$(\w+)(?:\[(\d+)\])?", tok)
     if m:
         d = {"var": m.group(1)}
@@ -60,6 +64,17 @@ def operand(tok):
     if not re.fullmatch(r"[\[\]\d\s,.\-]+", tok):
         raise ValueError("unsupported operand: %r" % tok)
     return {"lit": ast.literal_eval(tok)}   # PHP short array syntax of numbers == Python literal
+
+
+def static_call(c):
+    args, kwargs = [], {}
+    for tok in split_args(c.group(2)):
+        kw = re.fullmatch(r"(\w+): (-?[\d.]+)", tok)
+        if kw:
+            kwargs[kw.group(1)] = ast.literal_eval(kw.group(2))
+        else:
+            args.append(operand(tok))
+    return {"kind": "static", "op": c.group(1), "args": args, "kwargs": kwargs}
 
 
 def parse_file(path):
@@ -84,7 +99,8 @@ def parse_file(path):
         p = PRINT.match(line)
         if not p:
             raise ValueError("%s: unsupported statement %r" % (path.name, line))
-        expr = p.group(1)
+        expr = p.group(2)
+        printer = p.group(1)
         o = OPER.match(expr)
         if o:
             rec["calls"].append({"kind": "operator", "op": o.group(2),
@@ -97,15 +113,11 @@ def parse_file(path):
         c = CALL.match(expr)
         if not c:
             raise ValueError("%s: unsupported expression %r" % (path.name, expr))
-        args, kwargs = [], {}
-        for tok in split_args(c.group(2)):
-            kw = re.fullmatch(r"(\w+): (-?[\d.]+)", tok)
-            if kw:
-                kwargs[kw.group(1)] = ast.literal_eval(kw.group(2))
-            else:
-                args.append(operand(tok))
-        rec["calls"].append({"kind": "static", "op": c.group(1), "args": args, "kwargs": kwargs,
-                             "to_array": to_array})
+        call = static_call(c)
+        call["to_array"] = to_array
+        if printer == "var_dump":
+            call["printer"] = "var_dump"
+        rec["calls"].append(call)
     return rec
 
 

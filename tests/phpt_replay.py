@@ -72,6 +72,8 @@ def print_r(value, indent: int = 0) -> str:
 # ---- replay -----------------------------------------------------------------------------------
 
 def _operand(backend, env, spec):
+    if "call" in spec:                      # nested static call
+        return _call(backend, env, spec["call"])
     if "var" in spec:
         h = env[spec["var"]]
         if "index" in spec:
@@ -83,36 +85,50 @@ def _operand(backend, env, spec):
     return backend.scalar(lit)
 
 
+LAYOUT_OPS = {"reshape", "flatten", "expand_dims", "append", "trace", "allclose"}
+
+
+def _call(backend, env, call):
+    op = call["op"]
+    kw = call.get("kwargs", {})
+    if call["kind"] == "operator":
+        args = [_operand(backend, env, a) for a in call["args"]]
+        return backend.binary(OPERATORS[op], args[0], args[1])
+    if op in ("reshape", "expand_dims"):    # second argument is a shape / axis list, not an array
+        return getattr(backend, op)(_operand(backend, env, call["args"][0]), call["args"][1]["lit"])
+    args = [_operand(backend, env, a) for a in call["args"]]
+    if op in REDUCTIONS:
+        return backend.reduce(op, args[0], kw.get("axis"))
+    if op == "matmul":
+        return backend.matmul(args[0], args[1])
+    if op in COMPARISONS:
+        return backend.binary(op, args[0], args[1])
+    if op == "all":
+        return backend.all(args[0])
+    if op == "transpose":
+        return backend.transpose(args[0])
+    if op in ("flatten", "trace"):
+        return getattr(backend, op)(args[0])
+    if op in ("append", "allclose"):
+        return getattr(backend, op)(args[0], args[1])
+    if op == "square":     # PHP_METHOD(NDArray, square): Multiply_Float(nda, nda), numpower.c:3093
+        return backend.binary("multiply", args[0], args[0])
+    if op == "clip":
+        return backend.unary("clip", args[0], float(kw["min"]), float(kw["max"]))
+    if op == "round":
+        return backend.unary("round", args[0], float(kw["precision"]), 0.0)
+    return backend.unary(op, args[0], 0.0, 0.0)
+
+
 def replay(backend, test) -> str:
     """Run one PHPT record through `backend`; returns the text PHP would have printed."""
     env = {name: backend.array(val) for name, val in test["vars"].items()}
     text = ""
     for call in test["calls"]:
-        args = [_operand(backend, env, a) for a in call["args"]]
-        kw = call.get("kwargs", {})
-        if call["kind"] == "operator":
-            res = backend.binary(OPERATORS[call["op"]], args[0], args[1])
-        else:
-            op = call["op"]
-            if op in REDUCTIONS:
-                res = backend.reduce(op, args[0], kw.get("axis"))
-            elif op == "matmul":
-                res = backend.matmul(args[0], args[1])
-            elif op in COMPARISONS:
-                res = backend.binary(op, args[0], args[1])
-            elif op == "all":
-                res = backend.all(args[0])
-            elif op == "transpose":
-                res = backend.transpose(args[0])
-            elif op == "square":     # PHP_METHOD(NDArray, square): Multiply_Float(nda, nda), numpower.c:3093
-                res = backend.binary("multiply", args[0], args[0])
-            elif op == "clip":
-                res = backend.unary("clip", args[0], float(kw["min"]), float(kw["max"]))
-            elif op == "round":
-                res = backend.unary("round", args[0], float(kw["precision"]), 0.0)
-            else:
-                res = backend.unary(op, args[0], 0.0, 0.0)
-        if call["to_array"]:
+        res = _call(backend, env, call)
+        if call.get("printer") == "var_dump":
+            text += "bool(%s)\n" % ("true" if res else "false")
+        elif call["to_array"]:
             text += print_r(backend.to_list(res))
         else:
             text += print_r(float(res))
@@ -159,8 +175,26 @@ class GpuBackend:
     def transpose(self, x):
         return self.nd.transpose(x)
 
+    def reshape(self, x, shape):
+        return self.nd.reshape(x, shape)
+
+    def flatten(self, x):
+        return self.nd.flatten(x)
+
+    def expand_dims(self, x, axis):
+        return self.nd.expand_dims(x, axis)
+
+    def append(self, x, y):
+        return self.nd.append(x, y)
+
+    def trace(self, x):
+        return self.nd.trace(x)
+
+    def allclose(self, x, y):
+        return self.nd.allclose(x, y)
+
     def to_list(self, h):
-        return h.cpu().toArray()
+        return (h.cpu() if h.isGPU() else h).toArray()
 
 
 class OracleBackend:
@@ -202,6 +236,24 @@ class OracleBackend:
 
     def transpose(self, x):
         return self._ret(self.o.transpose(x))
+
+    def reshape(self, x, shape):
+        return self.o.reshape(x, shape)
+
+    def flatten(self, x):
+        return self.o.flatten(x)
+
+    def expand_dims(self, x, axis):
+        return self.o.expand_dims(x, axis)
+
+    def append(self, x, y):
+        return self.o.append(x, y)
+
+    def trace(self, x):
+        return float(self.o.trace(x))
+
+    def allclose(self, x, y):
+        return True if x is y else bool(self.o.allclose(x, y))   # identical handles: numpower.c:1372-1375
 
     def to_list(self, h):
         return np.asarray(h, dtype=np.float64).tolist()
