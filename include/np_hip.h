@@ -272,6 +272,9 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K,
 /* y[M] = A[MxN] . x[N]; replaces cblas_sgemv / matrixVectorMultiplyFloatKernel
  * (linalg.c:367-386, cuda_math.cu:228,1417). */
 int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y);
+/* out[M x N] = a (M) outer b (N), row-major: NDArray_Outer (linalg.c:724-751; cblas_sger on a zeroed
+ * matrix / cuda_calculate_outer_product), i.e. out[i][j] = 0 + a[i]*b[j] (zero products are +0.0). */
+int np_outer(const float *a, size_t M, const float *b, size_t N, float *out);
 
 /* ---- layout ---------------------------------------------------------- */
 
@@ -290,7 +293,8 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
  * (manipulation.c:193-283) reduce to. */
 int np_strided_copy(const float *in, float *out, int ndim, const int *host_shape, const long long *host_strides);
 
-/* Kernel-variant selection for tuning/benchmarks (0 = default heuristic). */
+/* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 / -2 switch the
+ * split-K path for small-result, long-K products off / on). */
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);
 int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128 */

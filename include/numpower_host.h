@@ -194,6 +194,7 @@ NDArray *NDArray_MaxAxis(NDArray *target, int axis);
 NDArray *NDArray_Matmul(NDArray *a, NDArray *b);
 NDArray *NDArray_FMatmul(NDArray *a, NDArray *b);
 NDArray *NDArray_Dot(NDArray *nda, NDArray *ndb);
+NDArray *NDArray_Outer(NDArray *a, NDArray *b);   /* linalg.c:724-751 */
 /* batch x M x K times batch x K x N -> batch x M x N (BASELINE config 5; no reference entry
  * point: linalg.c:239-242 rejects ndim > 2 with "Stack of matrices not allowed") */
 NDArray *NDArray_BatchedMatmul(NDArray *a, NDArray *b);

@@ -84,6 +84,7 @@ PROTOTYPES = {
                                            _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p,
                                            C.c_size_t]),
     "np_sgemv": (C.c_int, [C.c_size_t, C.c_size_t, _f32p, _f32p, _f32p]),
+    "np_outer": (C.c_int, [_f32p, C.c_size_t, _f32p, C.c_size_t, _f32p]),
     "np_transpose2d": (C.c_int, [_f32p, _f32p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "np_permute": (C.c_int, [_f32p, _f32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "np_strided_copy": (C.c_int, [_f32p, _f32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),

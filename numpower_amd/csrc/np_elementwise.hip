@@ -302,6 +302,33 @@ __global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ out, floa
 // launch configuration
 // ------------------------------------------------------------------------------------------
 
+// out[i][j] = 0 + a[i] * b[j]: cblas_sger on a zeroed matrix (linalg.c:741-742) — the "0 +" matters
+// only for the sign of zero products (-0 + +0 = +0).  Write-bound: 4 B/elem.
+template <bool VEC, typename I>
+__global__ __launch_bounds__(256) void outer_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                    float *__restrict__ out, I rows, I cols) {
+    const I stride = (I)gridDim.x * blockDim.x;
+    const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (VEC) {
+        const I cols4 = cols / 4, nvec = rows * cols4;
+        for (I v = tid; v < nvec; v += stride) {
+            const I i = v / cols4, j4 = v - i * cols4;
+            const float x = a[i];
+            const v4f y = *(const v4f *)(b + (size_t)j4 * 4);
+            v4f r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = __fmaf_rn(x, y[k], 0.0f);
+            __builtin_nontemporal_store(r, (v4f *)(out + (size_t)v * 4));
+        }
+    } else {
+        const I n = rows * cols;
+        for (I e = tid; e < n; e += stride) {
+            const I i = e / cols;
+            out[e] = __fmaf_rn(a[i], b[e - i * cols], 0.0f);
+        }
+    }
+}
+
 int g_variant = 0;   // see np_elementwise_set_variant
 
 struct LaunchCfg {
@@ -884,6 +911,29 @@ int np_unary(int op, const float *in, float *out, size_t n, float p0, float p1) 
     }
 #undef NP_U
     return np::fail(NP_ERR_INVALID, "np_unary: unknown op %d", op);
+}
+
+int np_outer(const float *a, size_t m, const float *b, size_t n, float *out) {
+    if (m == 0 || n == 0) return NP_OK;
+    if (!a || !b || !out) return np::fail(NP_ERR_INVALID, "np_outer: null pointer");
+    if (int rc = np::ensure_init()) return rc;
+    const size_t total = m * n;
+    const bool vec = n % 4 == 0 && aligned16(b) && aligned16(out);
+    const unsigned grid = grid_for(vec ? total / 4 : total, vec ? 2 : 4, 0);
+    hipStream_t s = np::stream();
+    if (total < (size_t(1) << 31)) {
+        if (vec)
+            outer_kernel<true, uint32_t><<<grid, 256, 0, s>>>(a, b, out, (uint32_t)m, (uint32_t)n);
+        else
+            outer_kernel<false, uint32_t><<<grid, 256, 0, s>>>(a, b, out, (uint32_t)m, (uint32_t)n);
+    } else {
+        if (vec)
+            outer_kernel<true, uint64_t><<<grid, 256, 0, s>>>(a, b, out, (uint64_t)m, (uint64_t)n);
+        else
+            outer_kernel<false, uint64_t><<<grid, 256, 0, s>>>(a, b, out, (uint64_t)m, (uint64_t)n);
+    }
+    NP_LAUNCH_CHECK("outer_kernel");
+    return NP_OK;
 }
 
 int np_fill(float *dev_ptr, float value, size_t n) {

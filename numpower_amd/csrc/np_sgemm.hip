@@ -692,18 +692,19 @@ int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
     return NP_OK;
 }
 
-int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, size_t sa,
+// C[b] (M x N, row stride N) = A[b] (M x K, row stride lda) * B[b] (K x N, row stride N)
+int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, size_t lda, size_t sa,
                  const float *B, size_t sb, float *C, size_t sc) {
-    if (M > 0x7fffffffu || N > 0x7fffffffu || K > 0x7fffffffu || batch > 65535)
+    if (M > 0x7fffffffu || N > 0x7fffffffu || K > 0x7fffffffu || lda > 0x7fffffffu || batch > 65535)
         return np::fail(NP_ERR_INVALID, "np_sgemm: dimension too large");
     GemmArgs g;
     g.A = A; g.B = B; g.C = C;
     g.M = (unsigned)M; g.N = (unsigned)N; g.K = (unsigned)K;
-    g.lda = (unsigned)K; g.ldb = (unsigned)N; g.ldc = (unsigned)N;
+    g.lda = (unsigned)lda; g.ldb = (unsigned)N; g.ldc = (unsigned)N;
     g.stride_a = sa; g.stride_b = sb; g.stride_c = sc;
     g.tiles_m = g.tiles_n = 0;
     g.probe = g_probe;
-    const bool vec = (K % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(B) &&
+    const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(B) &&
                      (sa % 4 == 0) && (sb % 4 == 0);
     // variant = tile_code + 10 * swizzle_group ; 0 = default
     if (g_variant >= 1000) {   // timing ablations of the pipelined kernel (wrong results!)
@@ -765,6 +766,38 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
     return launch_sgemm_tile<64, 64, 16, 4>(g, (unsigned)batch, vec);
 }
 
+bool g_splitk = true;   // np_sgemm_set_variant(-1) turns it off (A/B in tools/gemm_sweep.py)
+
+// Split-K for products with a small result and a long inner dimension (X^T X of a tall-skinny X,
+// 100 x 100 x 100000): the M x N tiles alone cannot fill 256 CUs (4 workgroups at 64 x 64), so K is
+// cut into S chunks that run as the batch dimension of the same kernels — chunk s reads
+// A[:, s*Kc:(s+1)*Kc] (row stride K) and B[s*Kc:(s+1)*Kc, :] and writes its partial product to
+// W[s] — and one deterministic np_reduce_axis(sum over s) pass writes C.  No new device code, no
+// atomics: the result does not depend on scheduling.
+// Returns 1 if it handled the product, 0 if the shape does not qualify, < 0 on error.
+int try_splitk(size_t M, size_t N, size_t K, const float *A, const float *B, float *C) {
+    if (!g_splitk || g_variant != 0 || K < 1024) return 0;
+    const size_t cus = (size_t)np::num_cus();
+    const size_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
+    if (t64 * 2 > cus) return 0;
+    size_t S = 2 * cus / t64;
+    if (S > K / 256) S = K / 256;
+    if (S < 2) return 0;
+    const size_t Kc = ((K + S - 1) / S + 15) / 16 * 16;
+    const size_t full = K / Kc, rem = K - full * Kc;
+    S = full + (rem ? 1 : 0);
+    if (S < 2 || S > 65535) return 0;
+    np::Scratch w;
+    if (int rc = w.alloc(S * M * N * sizeof(float))) return rc < 0 ? rc : -1;
+    float *W = (float *)w.ptr;
+    if (int rc = launch_sgemm(full, M, N, Kc, A, K, Kc, B, Kc * N, W, M * N)) return rc < 0 ? rc : -1;
+    if (rem)
+        if (int rc = launch_sgemm(1, M, N, rem, A + full * Kc, K, 0, B + full * Kc * N, 0, W + full * M * N, 0))
+            return rc < 0 ? rc : -1;
+    if (int rc = np_reduce_axis(NP_SUM, W, 1, S, M * N, C, 0)) return rc < 0 ? rc : -1;
+    return 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -776,6 +809,10 @@ int np_debug_sgemm_probe(void *dev_buf) {
 }
 
 int np_sgemm_set_variant(int variant) {
+    if (variant < 0) {   // -1: no split-K, -2: split-K back on (default)
+        g_splitk = variant != -1;
+        return NP_OK;
+    }
     g_variant = variant;
     return NP_OK;
 }
@@ -797,7 +834,12 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K, const f
         return NP_OK;
     }
     if (!A || !B) return np::fail(NP_ERR_INVALID, "np_sgemm: null input");
-    return launch_sgemm(batch, M, N, K, A, stride_a, B, stride_b, C, stride_c);
+    if (batch == 1) {
+        const int handled = try_splitk(M, N, K, A, B, C);
+        if (handled < 0) return handled;
+        if (handled) return NP_OK;
+    }
+    return launch_sgemm(batch, M, N, K, A, K, stride_a, B, stride_b, C, stride_c);
 }
 
 int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y) {

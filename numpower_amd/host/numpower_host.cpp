@@ -1119,6 +1119,27 @@ NDArray *NDArray_Dot(NDArray *nda, NDArray *ndb) {   // linalg.c:354-393
     return nullptr;
 }
 
+NDArray *NDArray_Outer(NDArray *a, NDArray *b) {   // linalg.c:724-751
+    if (!a || !b) return nullptr;
+    if (NDArray_NDIM(a) != 1 || NDArray_NDIM(b) != 1) {
+        throw_error("Invalid operation: NDArray::outer() requires both arrays to be 1-dimensional vectors.");
+        return nullptr;
+    }
+    if (NDArray_DEVICE(a) != NDArray_DEVICE(b)) {
+        throw_error("NDArray::outer() requires both arrays to be on the same device (CPU or GPU).");
+        return nullptr;
+    }
+    if (!require_gpu(a, "outer")) return nullptr;
+    const int shape[2] = {(int)NDArray_NUMELEMENTS(a), (int)NDArray_NUMELEMENTS(b)};
+    NDArray *rtn = new_array(shape, 2, NDARRAY_DEVICE_GPU, false);   // every element is written: no Zeros pass
+    if (!rtn) return nullptr;
+    if (!dev_ok(np_outer(NDArray_FDATA(a), (size_t)shape[0], NDArray_FDATA(b), (size_t)shape[1], NDArray_FDATA(rtn)))) {
+        NDArray_FREE(rtn);
+        return nullptr;
+    }
+    return rtn;
+}
+
 NDArray *NDArray_BatchedMatmul(NDArray *a, NDArray *b) {
     if (!a || !b) return nullptr;
     if (NDArray_DEVICE(a) != NDArray_DEVICE(b)) {

@@ -100,6 +100,7 @@ def _load_host():
         "NDArray_MaxAxis": (_P, [_P, C.c_int]),
         "NDArray_Matmul": (_P, [_P, _P]),
         "NDArray_Dot": (_P, [_P, _P]),
+        "NDArray_Outer": (_P, [_P, _P]),
         "NDArray_BatchedMatmul": (_P, [_P, _P]),
     }
     for name in ("Add", "Subtract", "Multiply", "Divide", "Mod", "Pow"):
@@ -515,6 +516,13 @@ class NDArray:
         x, _ = NDArray._coerce(a)
         y, _ = NDArray._coerce(b)
         return NDArray._wrap(h.NDArray_Dot(x._p, y._p))
+
+    @staticmethod
+    def outer(a, b):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        y, _ = NDArray._coerce(b)
+        return NDArray._wrap(h.NDArray_Outer(x._p, y._p))
 
     @staticmethod
     def batched_matmul(a, b):

@@ -385,6 +385,15 @@ def matmul(a, b) -> np.ndarray:
     return c
 
 
+def outer(a, b) -> np.ndarray:
+    """NDArray_Outer (linalg.c:724-751): cblas_sger(alpha = 1) into a zeroed matrix, i.e.
+    out[i][j] = 0 + a[i]*b[j] — one exact product, one rounding, whatever BLAS computes it."""
+    a, b = _f(a), _f(b)
+    if a.ndim != 1 or b.ndim != 1:
+        raise OracleError("Invalid operation: NDArray::outer() requires both arrays to be 1-dimensional vectors.")
+    return (a[:, None] * b[None, :] + np.float32(0.0)).astype(np.float32)
+
+
 def matvec(a, x) -> np.ndarray:
     use_openblas()
     a, x = _f(a), _f(x)

@@ -420,3 +420,29 @@ def test_fill_and_zeros(hip):
     z[3].fill(-1.0)   # unaligned view
     h = z.cpu().numpy()
     assert (h[3] == -1.0).all() and (h[2] == 2.5).all() and (h[4] == 2.5).all()
+
+
+@pytest.mark.parametrize("mnk", [(100, 100, 100000), (64, 64, 4096), (37, 5, 30011), (128, 96, 2050), (1, 1, 500000)])
+def test_matmul_splitk_small_result_long_k(mnk, hip, oracle):
+    """Small M x N with a long K runs as split-K (chunks of K as the batch dimension + one
+    deterministic reduce, np_sgemm.hip try_splitk): same 1e-5 bar vs fp64 as every other product,
+    bit-identical from run to run, and within accumulation-order noise of the plain kernel."""
+    from numpower_amd import _lib
+    from numpower_amd import device as D
+    m, n, k = mnk
+    a = synth.uniform((m, k), 31, -1.0, 1.0)
+    b = synth.uniform((k, n), 32, -1.0, 1.0)
+    da, db = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b)
+    got = D.sgemm(da, db).to_host()
+    again = D.sgemm(da, db).to_host()
+    assert (got.view(np.uint32) == again.view(np.uint32)).all()
+    ref64 = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(got - ref64) / scale).max() <= 1e-5
+    _lib.check(_lib.load().np_sgemm_set_variant(-1))
+    try:
+        plain = D.sgemm(da, db).to_host()
+    finally:
+        _lib.check(_lib.load().np_sgemm_set_variant(-2))
+    assert (np.abs(plain - ref64) / scale).max() <= 1e-5
+    assert (np.abs(plain.astype(np.float64) - got) / scale).max() <= 2e-6

@@ -209,3 +209,24 @@ def test_strided_copy_abi(hip):
     assert _bits_equal(gather(7, (300, 4), (500, 0)), np.repeat(x[:, 7:8], 4, axis=1))
     assert _bits_equal(gather(0, (150, 250), (1000, 2)), x[::2, ::2])
     assert _bits_equal(gather(0, (300, 500), (500, 1)), x)                         # contiguous -> memcpy path
+
+
+@pytest.mark.parametrize("mn", [(1, 1), (3, 5), (257, 1001), (1024, 4096), (4001, 8)])
+def test_outer(mn, hip, oracle):
+    """NDArray_Outer (linalg.c:724-751): bit-exact vs the restated sger-on-zeros, incl. +0.0 for
+    zero products of either sign."""
+    nd = _nd()
+    m, n = mn
+    a = synth.uniform((m,), 71, -2.0, 2.0)
+    b = synth.uniform((n,), 72, -2.0, 2.0)
+    a[::3] = 0.0
+    b[::4] = -0.0
+    got = nd.outer(nd.array(a).gpu(), nd.array(b).gpu())
+    want = oracle.outer(a, b)
+    assert got.shape() == [m, n] and _bits_equal(got.cpu().numpy(), want)
+    assert not np.signbit(want[want == 0.0]).any()
+    from numpower_amd.ndarray import Error
+    with pytest.raises(Error, match="1-dimensional vectors"):
+        nd.outer(nd.array(np.ones((2, 2), np.float32)).gpu(), nd.array(b).gpu())
+    with pytest.raises(Error, match="same device"):
+        nd.outer(nd.array(a).gpu(), nd.array(b))
