@@ -36,6 +36,7 @@ struct GemmArgs {
     const float *A, *B;
     float *C;
     unsigned M, N, K;
+    unsigned K_last;                        // != 0: inner length of the LAST batch entry (split-K remainder chunk)
     unsigned lda, ldb, ldc;
     size_t stride_a, stride_b, stride_c;   // batch strides (elements)
     unsigned tiles_m, tiles_n;
@@ -94,6 +95,7 @@ __device__ __forceinline__ void tile_coords(const GemmArgs &g, unsigned bid, uns
 // EDGE: tile may stick out of the matrix -> bounds-checked loads (zero fill) and stores
 template <int BM, int BN, int BK, int MINW, bool VEC, bool EDGE>
 __global__ __launch_bounds__(256, MINW) void sgemm_kernel(GemmArgs g) {
+    if (g.K_last && blockIdx.z + 1 == gridDim.z) g.K = g.K_last;   // uniform: split-K remainder chunk
     constexpr int LDA_S = BK + 4;               // padded A row (floats)
     constexpr int LDB_S = BN;                   // B row (floats)
     constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(256, MINW) void sgemm_kernel(GemmArgs g) {
 // 8 = no LDS stores, 16 = no fragment reads inside the K loop.
 template <int BM, int BN, bool VEC, bool EDGE, int MODE>
 __global__ __launch_bounds__(256, 2) void sgemm_pipe_kernel(GemmArgs g) {
+    if (g.K_last && blockIdx.z + 1 == gridDim.z) g.K = g.K_last;   // uniform: split-K remainder chunk
     constexpr int BK = 16;
     constexpr bool SPREAD = MODE & 1, NO_BAR = MODE & 2, NO_GLD = MODE & 4, NO_STS = MODE & 8, NO_FRAG = MODE & 16;
     constexpr int LDA_S = BK + 4, LDB_S = BN;
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_pipe_kernel(GemmArgs g) {
 // a full tile earlier; hipcc's vmcnt(0) in front of the barrier is then already satisfied);
 // right after it the DMAs of tile t+2 go into the buffer tile t-1 just vacated.
 __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
+    if (g.K_last && blockIdx.z + 1 == gridDim.z) g.K = g.K_last;   // uniform: split-K remainder chunk
     constexpr int BM = 256, BN = 128, BK = 16;
     constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
     constexpr int A_SZ = BM * BK, B_SZ = BK * BN;   // floats per buffer: 4096 + 2048
@@ -662,7 +666,7 @@ template <int BM, int BN, int BK, int MINW>
 int launch_sgemm_tile(GemmArgs g, unsigned batch, bool vec) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const bool edge = (g.M % BM) || (g.N % BN) || (g.K % BK);
+    const bool edge = (g.M % BM) || (g.N % BN) || (g.K % BK) || (g.K_last % BK);
     const dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
     hipStream_t s = np::stream();
     if (vec && !edge)
@@ -679,7 +683,7 @@ template <int BM, int BN, int MODE>
 int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    const bool edge = (g.M % BM) || (g.N % BN) || (g.K % 16);
+    const bool edge = (g.M % BM) || (g.N % BN) || (g.K % 16) || (g.K_last % 16);
     const dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
     hipStream_t s = np::stream();
     if (vec && !edge)
@@ -692,6 +696,127 @@ int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
     return NP_OK;
 }
 
+// ---- default kernel choice -------------------------------------------------------------------
+// Three tile configurations, efficiencies measured at 4096^3 on MI355X (profiles/r01/gemm_ab.log):
+//   0: sgemm_dma_kernel 256x128 (fully aligned shapes only)   0.93   (145 TFLOP/s)
+//   1: sgemm_kernel     128x128                               0.85   (132-135)
+//   2: sgemm_kernel      64x64                                0.71   (110)
+struct TileCfg { unsigned bm, bn; double eff; };
+constexpr TileCfg kCfg[3] = {{256, 128, 0.93}, {128, 128, 0.85}, {64, 64, 0.71}};
+
+int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
+    if (cfg == 0) {
+        g.tiles_m = g.M / 256;
+        g.tiles_n = g.N / 128;
+        sgemm_dma_kernel<<<dim3(g.tiles_m * g.tiles_n, 1, batch), 256, 0, np::stream()>>>(g);
+        NP_LAUNCH_CHECK("sgemm_dma_kernel");
+        return NP_OK;
+    }
+    if (cfg == 1) return launch_sgemm_tile<128, 128, 16, 4>(g, batch, vec);
+    return launch_sgemm_tile<64, 64, 16, 4>(g, batch, vec);
+}
+
+bool g_splitk = true;   // np_sgemm_set_variant(-1) turns the K-splitting plans off (A/B in tools/)
+
+// A plan = tile configuration + how many trailing tile-ROWS of C are computed split-K.
+//   tail_rows == 0        : one launch, every workgroup walks the whole K (the classic grid)
+//   0 < tail_rows < all   : the leading rows fill whole waves of the machine; the rows that would
+//                           have formed a mostly-empty last wave are cut into S chunks of K so they
+//                           fill the CUs too (3072^3: 288 tiles on 256 CUs = 2 waves, the second
+//                           12 % full -> 240 tiles + 48 tiles x 5 chunks)
+//   tail_rows == all      : the whole product is split-K (few tiles, long K: X^T X of a tall X)
+// Split parts run as the BATCH dimension of the same kernels (chunk s reads A[:, s*Kc:(s+1)*Kc]
+// with row stride K and B[s*Kc:(s+1)*Kc, :], writes its partial to W[s]); one deterministic
+// np_reduce_axis(sum over s) pass writes C.  No new device code, no atomics: the result never
+// depends on scheduling.  Times are modelled in seconds: a work unit of k inner steps costs
+// 2*bm*bn*k / (eff * peak per CU) + a fixed prologue/epilogue, the reduce costs its HBM traffic.
+struct Plan { int cfg; unsigned tail_rows, S; size_t Kc; double t; };
+
+Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok) {
+    const double cus = (double)np::num_cus();
+    const double cu_flops = 157.3e12 / 256.0, unit_fixed = 1.5e-6, launch = 3e-6, hbm = 4e12;
+    Plan best{2, 0, 1, K, 1e300};
+    for (int c = 0; c < 3; ++c) {
+        if (c == 0 && !dma_ok) continue;
+        const TileCfg &T = kCfg[c];
+        const size_t tm = (M + T.bm - 1) / T.bm, tn = (N + T.bn - 1) / T.bn;
+        auto unit = [&](size_t k) { return 2.0 * T.bm * T.bn * (double)k / (T.eff * cu_flops) + unit_fixed; };
+        const double whole = ceil((double)(tm * tn * batch) / cus) * unit(K);
+        if (whole < best.t) best = Plan{c, 0, 1, K, whole};
+        if (!g_splitk || batch != 1 || K < 512) continue;
+        // candidate tails: up to one machine-wave worth of tile rows, or everything
+        size_t max_tail = (size_t)(cus / (double)tn) + 1;
+        if (max_tail > tm) max_tail = tm;
+        for (size_t pass = 0; pass <= max_tail; ++pass) {
+            const size_t r = pass == 0 ? tm : pass;          // pass 0 = split everything
+            if (pass != 0 && r == tm) continue;
+            const size_t lead_rows = tm - r;
+            const size_t m2 = M - lead_rows * T.bm;         // matrix rows in the split part
+            const size_t max_s = r == tm ? 128 : 8;
+            for (size_t S = 2; S <= max_s; S = S < 8 ? S + 1 : S * 2) {
+                const size_t Kc = ((K + S - 1) / S + 15) / 16 * 16;
+                if (Kc < 128) break;
+                const size_t chunks = (K + Kc - 1) / Kc;
+                if (chunks < 2) continue;
+                double t = ceil((double)(lead_rows * tn) / cus) * unit(K);
+                t += ceil((double)(r * tn * chunks) / cus) * unit(Kc);
+                t += (double)((chunks + 1) * m2 * N * sizeof(float)) / hbm + launch;
+                if (lead_rows) t += launch;
+                if (t < best.t) best = Plan{c, (unsigned)r, (unsigned)chunks, Kc, t};
+            }
+        }
+    }
+    return best;
+}
+
+int launch_planned(GemmArgs g, size_t batch, bool vec) {
+    const size_t M = g.M, N = g.N, K = g.K;
+    const bool dma_ok = vec && M % 256 == 0 && N % 128 == 0 && K % 16 == 0;
+    Plan p = plan_sgemm(M, N, K, batch, dma_ok);
+    // tools/gemm_plan_sweep.py: NP_SGEMM_PLAN="cfg,tail_rows,S" forces a plan, NP_SGEMM_PLAN_DEBUG prints the choice
+    static const char *forced = getenv("NP_SGEMM_PLAN");
+    static const bool debug = getenv("NP_SGEMM_PLAN_DEBUG") != nullptr;
+    if (forced && batch == 1) {
+        int c = 2, r = 0, S = 1;
+        if (sscanf(forced, "%d,%d,%d", &c, &r, &S) == 3 && c >= 0 && c < 3 && (c != 0 || dma_ok)) {
+            const size_t tm = (M + kCfg[c].bm - 1) / kCfg[c].bm;
+            if (r < 0 || (size_t)r > tm) r = (int)tm;
+            p = Plan{c, (unsigned)r, (unsigned)S, K, 0.0};
+            if (r > 0 && S >= 2) p.Kc = ((K + S - 1) / S + 15) / 16 * 16; else p.tail_rows = 0;
+        }
+    }
+    if (debug)
+        fprintf(stderr, "[np_sgemm] %zux%zux%zu batch %zu -> cfg %d tail_rows %u S %u Kc %zu model %.1f us\n", M, N, K,
+                batch, p.cfg, p.tail_rows, p.S, p.Kc, p.t * 1e6);
+    if (p.tail_rows == 0) return launch_cfg(p.cfg, g, (unsigned)batch, vec);
+    const TileCfg &T = kCfg[p.cfg];
+    const size_t tm = (M + T.bm - 1) / T.bm;
+    const size_t m1 = (tm - p.tail_rows) * T.bm, m2 = M - m1;
+    if (m1) {   // leading rows: whole-K workgroups
+        GemmArgs lead = g;
+        lead.M = (unsigned)m1;
+        if (int rc = launch_cfg(p.cfg, lead, 1, vec)) return rc;
+    }
+    const size_t full = K / p.Kc, rem = K - full * p.Kc, chunks = full + (rem ? 1 : 0);
+    np::Scratch w;
+    if (int rc = w.alloc(chunks * m2 * N * sizeof(float))) return rc;
+    float *W = (float *)w.ptr;
+    GemmArgs part = g;
+    part.A = g.A + m1 * g.lda;
+    part.M = (unsigned)m2;
+    part.K = (unsigned)p.Kc;
+    part.C = W;
+    part.stride_a = p.Kc;
+    part.stride_b = p.Kc * N;
+    part.stride_c = m2 * N;
+    // chunks start at multiples of 16 floats: alignment of the bases is unchanged.  The remainder
+    // chunk rides in the same launch as the last batch entry (K_last): as a launch of its own it
+    // would cost a whole extra work-unit time on a mostly idle machine.
+    part.K_last = (unsigned)rem;
+    if (int rc = launch_cfg(p.cfg, part, (unsigned)chunks, vec && rem % 4 == 0)) return rc;
+    return np_reduce_axis(NP_SUM, W, 1, chunks, m2 * N, g.C + m1 * N, 0);
+}
+
 // C[b] (M x N, row stride N) = A[b] (M x K, row stride lda) * B[b] (K x N, row stride N)
 int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, size_t lda, size_t sa,
                  const float *B, size_t sb, float *C, size_t sc) {
@@ -699,7 +824,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
         return np::fail(NP_ERR_INVALID, "np_sgemm: dimension too large");
     GemmArgs g;
     g.A = A; g.B = B; g.C = C;
-    g.M = (unsigned)M; g.N = (unsigned)N; g.K = (unsigned)K;
+    g.M = (unsigned)M; g.N = (unsigned)N; g.K = (unsigned)K; g.K_last = 0;
     g.lda = (unsigned)lda; g.ldb = (unsigned)N; g.ldc = (unsigned)N;
     g.stride_a = sa; g.stride_b = sb; g.stride_c = sc;
     g.tiles_m = g.tiles_n = 0;
@@ -738,64 +863,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
             return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
         default: break;
     }
-    // Default choice: a cost model calibrated on MI355X (profiles/r01/gemm_ab.log, gemm_sweep.log).
-    // Every CU works through ceil(tiles / CUs) tiles, a tile costs its area divided by the
-    // kernel's measured MFMA efficiency at 4096^3:
-    //   sgemm_dma_kernel 256x128 (fully aligned shapes only)   0.93   (145 TFLOP/s)
-    //   sgemm_kernel     128x128                               0.85   (132-135)
-    //   sgemm_kernel      64x64                                0.71   (110)
-    // The model reproduces the measured ranking at n = 1024 ... 8192 (e.g. 3072^3: 64x64 tiles =
-    // 9 per CU beat 288 DMA tiles = 2 per CU on 32 CUs and 1 on the rest: 110 vs 81 TFLOP/s).
-    const double cus = (double)np::num_cus();
-    auto cost = [&](size_t bm, size_t bn, double eff) {
-        const double tiles = (double)(((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch);
-        return ceil(tiles / cus) * (double)(bm * bn) / eff;
-    };
-    const bool dma_ok = vec && M % 256 == 0 && N % 128 == 0 && K % 16 == 0;
-    const double c_dma = dma_ok ? cost(256, 128, 0.93) : 1e300;
-    const double c_128 = cost(128, 128, 0.85);
-    const double c_64 = cost(64, 64, 0.71);
-    if (c_dma <= c_128 && c_dma <= c_64) {
-        g.tiles_m = g.M / 256;
-        g.tiles_n = g.N / 128;
-        sgemm_dma_kernel<<<dim3(g.tiles_m * g.tiles_n, 1, (unsigned)batch), 256, 0, np::stream()>>>(g);
-        NP_LAUNCH_CHECK("sgemm_dma_kernel");
-        return NP_OK;
-    }
-    if (c_128 <= c_64) return launch_sgemm_tile<128, 128, 16, 4>(g, (unsigned)batch, vec);
-    return launch_sgemm_tile<64, 64, 16, 4>(g, (unsigned)batch, vec);
-}
-
-bool g_splitk = true;   // np_sgemm_set_variant(-1) turns it off (A/B in tools/gemm_sweep.py)
-
-// Split-K for products with a small result and a long inner dimension (X^T X of a tall-skinny X,
-// 100 x 100 x 100000): the M x N tiles alone cannot fill 256 CUs (4 workgroups at 64 x 64), so K is
-// cut into S chunks that run as the batch dimension of the same kernels — chunk s reads
-// A[:, s*Kc:(s+1)*Kc] (row stride K) and B[s*Kc:(s+1)*Kc, :] and writes its partial product to
-// W[s] — and one deterministic np_reduce_axis(sum over s) pass writes C.  No new device code, no
-// atomics: the result does not depend on scheduling.
-// Returns 1 if it handled the product, 0 if the shape does not qualify, < 0 on error.
-int try_splitk(size_t M, size_t N, size_t K, const float *A, const float *B, float *C) {
-    if (!g_splitk || g_variant != 0 || K < 1024) return 0;
-    const size_t cus = (size_t)np::num_cus();
-    const size_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
-    if (t64 * 2 > cus) return 0;
-    size_t S = 2 * cus / t64;
-    if (S > K / 256) S = K / 256;
-    if (S < 2) return 0;
-    const size_t Kc = ((K + S - 1) / S + 15) / 16 * 16;
-    const size_t full = K / Kc, rem = K - full * Kc;
-    S = full + (rem ? 1 : 0);
-    if (S < 2 || S > 65535) return 0;
-    np::Scratch w;
-    if (int rc = w.alloc(S * M * N * sizeof(float))) return rc < 0 ? rc : -1;
-    float *W = (float *)w.ptr;
-    if (int rc = launch_sgemm(full, M, N, Kc, A, K, Kc, B, Kc * N, W, M * N)) return rc < 0 ? rc : -1;
-    if (rem)
-        if (int rc = launch_sgemm(1, M, N, rem, A + full * Kc, K, 0, B + full * Kc * N, 0, W + full * M * N, 0))
-            return rc < 0 ? rc : -1;
-    if (int rc = np_reduce_axis(NP_SUM, W, 1, S, M * N, C, 0)) return rc < 0 ? rc : -1;
-    return 1;
+    return launch_planned(g, batch, vec);
 }
 
 }  // namespace
@@ -834,11 +902,6 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K, const f
         return NP_OK;
     }
     if (!A || !B) return np::fail(NP_ERR_INVALID, "np_sgemm: null input");
-    if (batch == 1) {
-        const int handled = try_splitk(M, N, K, A, B, C);
-        if (handled < 0) return handled;
-        if (handled) return NP_OK;
-    }
     return launch_sgemm(batch, M, N, K, A, K, stride_a, B, stride_b, C, stride_c);
 }
 

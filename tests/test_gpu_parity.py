@@ -422,7 +422,12 @@ def test_fill_and_zeros(hip):
     assert (h[3] == -1.0).all() and (h[2] == 2.5).all() and (h[4] == 2.5).all()
 
 
-@pytest.mark.parametrize("mnk", [(100, 100, 100000), (64, 64, 4096), (37, 5, 30011), (128, 96, 2050), (1, 1, 500000)])
+@pytest.mark.parametrize("mnk", [(100, 100, 100000), (64, 64, 4096), (37, 5, 30011), (128, 96, 2050), (1, 1, 500000),
+                                 # planner cases (plan_sgemm): everything split on the 256x128 LDS-DMA tiles,
+                                 # with a remainder chunk riding as the last batch entry (K_last) ...
+                                 (1280, 1280, 8192), (1536, 1536, 1536),
+                                 # ... and a split-K TAIL: 9 x 29 = 261 tiles on 256 CUs
+                                 (2304, 3712, 1040), (520, 3000, 4100)])
 def test_matmul_splitk_small_result_long_k(mnk, hip, oracle):
     """Small M x N with a long K runs as split-K (chunks of K as the batch dimension + one
     deterministic reduce, np_sgemm.hip try_splitk): same 1e-5 bar vs fp64 as every other product,
