@@ -286,6 +286,16 @@ def bench_extras(dist: Dist, steps, warmup):
     r["speedup_vs_unfused"] = (ev_ms / steps) / r["ms_per_launch"]
     r["parity_ok"] = bool((fused_out.view(np.uint32) == tmp.to_host().reshape(-1).view(np.uint32)).all())
     ex["fused_chain_1e8"] = r
+    # ... and with the reduction fused in as well: sum(exp(a) * b + 2) reads 8 B/elem, nothing written
+    out = C.c_float(0.0)
+    r = hbm_case("sum(exp(a)*b+2) fused, 1e8 (§8f row 4)", 8.0 * N,
+                 lambda: check(lib.np_fused_chain_reduce(ptrs, kinds, 3, prog, 3, 0, 1, N, C.byref(out))),
+                 steps, warmup, dist)
+    want = float(tmp.to_host().reshape(-1).astype(np.float64).sum())
+    r["parity_rel_err_vs_fp64"] = abs(out.value - want) / abs(want)
+    r["parity_ok"] = bool(r["parity_rel_err_vs_fp64"] <= 1e-5)
+    r["note"] = "includes the 4-byte D2H of the result per call"
+    ex["fused_chain_sum_1e8"] = r
     tmp.free()
     tmp2.free()
 

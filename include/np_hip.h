@@ -193,6 +193,13 @@ typedef struct np_fused_op {
 } np_fused_op;
 int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inputs,
                    const np_fused_op *ops, int n_ops, float *out, size_t rows, size_t cols);
+/* The same chain with a full reduction (np_reduce_op) as its last step: the chain value never goes
+ * to memory — sum(exp(a) * b) reads 8 B/elem instead of writing 4 and reading 4 more.  Per-workgroup
+ * partials + the deterministic second pass of np_reduce_all; NP_MEAN divides the sum by rows*cols
+ * as NDArray::mean does (numpower.c:2659). */
+int np_fused_chain_reduce(const float *const *inputs, const int *input_kinds, int n_inputs,
+                          const np_fused_op *ops, int n_ops, int reduce_op, size_t rows, size_t cols,
+                          float *host_out);
 
 /* ---- reductions -------------------------------------------------------------------------- */
 

@@ -155,6 +155,9 @@ NDArray *NDArray_Slice(NDArray *array, NDArray **indexes, int num_indices);
  * stand-alone entry points one after the other. */
 #include "np_hip.h"
 NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops);
+/* ... ending in a full reduction (np_reduce_op: sum / prod / min / max / mean) of the chain value,
+ * which is never written to memory.  Returns NaN and raises on error. */
+float NDArray_FusedChainReduce(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops, int reduce_op);
 
 /* ---- argmax / argmin (src/ndmath/calculation.c:73-194) ----
  * axis = 128 (NDARRAY_MAX_DIMS) reduces the flattened array; indices are returned as floats. */

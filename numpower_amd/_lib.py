@@ -69,6 +69,8 @@ PROTOTYPES = {
     "np_unary": (C.c_int, [C.c_int, _f32p, _f32p, C.c_size_t, C.c_float, C.c_float]),
     "np_fused_chain": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(FusedOp),
                                  C.c_int, _f32p, C.c_size_t, C.c_size_t]),
+    "np_fused_chain_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(FusedOp),
+                                        C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]),
     "np_reduce_all": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.POINTER(C.c_float)]),
     "np_reduce_all_dev": (C.c_int, [C.c_int, _f32p, C.c_size_t, _f32p]),
     "np_all": (C.c_int, [_f32p, C.c_size_t, C.c_uint, C.POINTER(C.c_int)]),

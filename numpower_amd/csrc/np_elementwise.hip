@@ -518,7 +518,7 @@ struct FusedArgs {
     const float *first_prefetch;   // first streamed operand of the chain (null: none)
     size_t cols;                   // row length of the result; 0 when no operand is broadcast
     int first_prefetch_idx;
-    int pad;
+    int sink;                      // -1: store the chain value; NP_SUM / NP_PROD / NP_MIN / NP_MAX: reduce it
     FusedStep ops[FUSED_MAX_OPS];
 };
 // The kernel indexes ops[] with a run-time k.  On a by-value kernel parameter that makes the compiler
@@ -655,8 +655,9 @@ __device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p,
 
 template <int U, int G, bool LIGHT, typename I>
 __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out, I elem0, I nslots, I tid,
-                                           I stride) {
+                                           I stride, float &racc) {
     constexpr int N = U * G;
+    const int sink = f->sink;
     const int n_ops = f->n_ops;
     const float *in0 = f->in0, *first_prefetch = f->first_prefetch;
     const float scalar0 = f->scalar0;
@@ -716,6 +717,18 @@ __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out
                 fused_fetch<U, G, I>(nxt, o.prefetch, o.prefetch_idx, first, row, col, live);
             binary_dispatch<N, LIGHT>(o.op, acc, oth, o.swap != 0, o.quirk != 0, body);
         }
+        if (sink >= 0) {
+            // reduction at the end of the chain: the value never goes to memory (uniform branch;
+            // same combine rules as np_reduce_all: NaN never replaces in min / max)
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                if (!live[e / G]) continue;
+                const float v = acc[e];
+                racc = sink == NP_SUM ? racc + v : sink == NP_PROD ? racc * v
+                     : sink == NP_MIN ? ((v < racc) ? v : racc) : ((v > racc) ? v : racc);
+            }
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!live[u]) continue;
@@ -734,12 +747,23 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, fl
     FusedArgsK f = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
     const I stride = (I)gridDim.x * blockDim.x;
     const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sink = f->sink;
+    float racc = sink == NP_SUM ? 0.0f : sink == NP_PROD ? 1.0f : sink == NP_MIN ? INFINITY : -INFINITY;
     if constexpr (VEC) {
         const I nvec = n / 4;
-        fused_span<U, 4, LIGHT, I>(f, out, (I)0, nvec, tid, stride);
-        fused_span<1, 1, LIGHT, I>(f, out, nvec * 4, n - nvec * 4, tid, stride);   // ragged tail (< 4 elements)
+        fused_span<U, 4, LIGHT, I>(f, out, (I)0, nvec, tid, stride, racc);
+        fused_span<1, 1, LIGHT, I>(f, out, nvec * 4, n - nvec * 4, tid, stride, racc);   // ragged tail (< 4 elements)
     } else {
-        fused_span<U, 1, LIGHT, I>(f, out, (I)0, n, tid, stride);   // 4-byte aligned views
+        fused_span<U, 1, LIGHT, I>(f, out, (I)0, n, tid, stride, racc);   // 4-byte aligned views
+    }
+    if (sink >= 0) {   // one partial per workgroup; np_reduce_all_dev folds them (deterministic)
+        __shared__ float lds4[4];
+        float r;
+        if (sink == NP_SUM) r = np::dev::block_reduce<NP_SUM>(racc, lds4);
+        else if (sink == NP_PROD) r = np::dev::block_reduce<NP_PROD>(racc, lds4);
+        else if (sink == NP_MIN) r = np::dev::block_reduce<NP_MIN>(racc, lds4);
+        else r = np::dev::block_reduce<NP_MAX>(racc, lds4);
+        if (threadIdx.x == 0) out[blockIdx.x] = r;
     }
 }
 
@@ -747,8 +771,11 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, fl
 
 extern "C" {
 
-int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inputs,
-                   const np_fused_op *ops, int n_ops, float *out, size_t rows, size_t cols) {
+}  // extern "C"
+
+// sink < 0: out receives rows*cols values; else out is a device float receiving the reduction
+static int fused_chain_impl(const float *const *inputs, const int *input_kinds, int n_inputs,
+                            const np_fused_op *ops, int n_ops, float *out, size_t rows, size_t cols, int sink) {
     const size_t n = rows * cols;
     if (n_inputs < 1 || n_inputs > FUSED_MAX_IN)
         return np::fail(NP_ERR_INVALID, "np_fused_chain: 1..%d inputs supported", FUSED_MAX_IN);
@@ -760,7 +787,7 @@ int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inp
     if (int rc = np::ensure_init()) return rc;
     FusedArgs f;
     f.n_ops = n_ops;
-    bool vec = aligned16(out);
+    bool vec = sink >= 0 || aligned16(out);   // a reduction has no output buffer to align
     bool broadcast = false;
     for (int i = 0; i < n_inputs; ++i) {
         if (!inputs[i]) return np::fail(NP_ERR_INVALID, "np_fused_chain: null input %d", i);
@@ -780,7 +807,20 @@ int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inp
     f.first_prefetch = nullptr;
     f.first_prefetch_idx = FUSED_IDX_FULL;
     f.cols = broadcast ? cols : 0;
-    f.pad = 0;
+    f.sink = sink;
+    np::Scratch partials;
+    float *result = out;
+    unsigned reduce_blocks = 0;
+    if (sink >= 0) {
+        if (n >= (size_t(1) << 31)) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: array too large");
+        // grid-stride loop over a capped grid: one workgroup-reduce + partial per block, so few,
+        // long-lived blocks (NP_FUSED_RBPC blocks per CU for tools/fused_ab.py)
+        static const int rbpc = getenv("NP_FUSED_RBPC") ? atoi(getenv("NP_FUSED_RBPC")) : 16;
+        const size_t want = (n / 4 + 255) / 256 + 1, cap = (size_t)np::num_cus() * (size_t)rbpc;
+        reduce_blocks = (unsigned)(want < cap ? want : cap);
+        if (int rc = partials.alloc(reduce_blocks * sizeof(float))) return rc;
+        out = (float *)partials.ptr;
+    }
     FusedStep *last_stream = nullptr;
     bool light = true;
     for (int k = 0; k < n_ops; ++k) {
@@ -834,7 +874,7 @@ int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inp
     const bool small = n < (size_t(1) << 31);
 #define NP_FC(VEC_, U_, LIGHT_)                                                                          \
     do {                                                                                                 \
-        const unsigned grid = grid_for(VEC_ ? n / 4 + 1 : n, U_, 0);                                     \
+        const unsigned grid = reduce_blocks ? reduce_blocks : grid_for(VEC_ ? n / 4 + 1 : n, U_, 0);     \
         if (small)                                                                                       \
             fused_chain_kernel<VEC_, U_, LIGHT_, uint32_t><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);    \
         else                                                                                             \
@@ -851,6 +891,34 @@ int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inp
     }
 #undef NP_FC
     NP_LAUNCH_CHECK("fused_chain_kernel");
+    if (sink >= 0) return np_reduce_all_dev(sink, (const float *)partials.ptr, reduce_blocks, result);
+    return NP_OK;
+}
+
+extern "C" {
+
+int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inputs,
+                   const np_fused_op *ops, int n_ops, float *out, size_t rows, size_t cols) {
+    return fused_chain_impl(inputs, input_kinds, n_inputs, ops, n_ops, out, rows, cols, -1);
+}
+
+int np_fused_chain_reduce(const float *const *inputs, const int *input_kinds, int n_inputs,
+                          const np_fused_op *ops, int n_ops, int reduce_op, size_t rows, size_t cols,
+                          float *host_out) {
+    if (!host_out) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: null output");
+    if (reduce_op != NP_SUM && reduce_op != NP_PROD && reduce_op != NP_MIN && reduce_op != NP_MAX &&
+        reduce_op != NP_MEAN)
+        return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: unknown reduction %d", reduce_op);
+    if (rows * cols == 0) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: empty input");
+    if (int rc = np::ensure_init()) return rc;
+    np::Scratch dev;
+    if (int rc = dev.alloc(sizeof(float))) return rc;
+    const int sink = reduce_op == NP_MEAN ? NP_SUM : reduce_op;
+    if (int rc = fused_chain_impl(inputs, input_kinds, n_inputs, ops, n_ops, (float *)dev.ptr, rows, cols, sink))
+        return rc;
+    float v = 0.0f;
+    if (int rc = np_memcpy_d2h(&v, dev.ptr, sizeof(float))) return rc;
+    *host_out = reduce_op == NP_MEAN ? v / (float)(rows * cols) : v;
     return NP_OK;
 }
 

@@ -22,44 +22,7 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int OP>
-__device__ __forceinline__ float r_identity() {
-    if constexpr (OP == NP_SUM || OP == NP_MEAN) return 0.0f;
-    if constexpr (OP == NP_PROD) return 1.0f;
-    if constexpr (OP == NP_MIN) return INFINITY;
-    return -INFINITY;
-}
-
-template <int OP>
-__device__ __forceinline__ float r_combine(float a, float b) {
-    if constexpr (OP == NP_SUM || OP == NP_MEAN) return a + b;
-    if constexpr (OP == NP_PROD) return a * b;
-    // same comparison the reference uses (ndarray.c:764, :951): NaN never replaces
-    if constexpr (OP == NP_MIN) return (b < a) ? b : a;
-    return (b > a) ? b : a;
-}
-
-template <int OP>
-__device__ __forceinline__ float wave_reduce(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = r_combine<OP>(v, __shfl_down(v, off, 64));
-    return v;   // lane 0 holds the wave's result
-}
-
-// Workgroup reduce of one value per thread (256 threads = 4 waves).  Result valid in thread 0.
-template <int OP>
-__device__ __forceinline__ float block_reduce(float v, float *lds4) {
-    v = wave_reduce<OP>(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) lds4[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        v = lds4[0];
-        const int nw = (blockDim.x + 63) >> 6;
-        for (int w = 1; w < nw; ++w) v = r_combine<OP>(v, lds4[w]);
-    }
-    return v;
-}
+using namespace np::dev;   // r_identity / r_combine / wave_reduce / block_reduce (np_internal.h)
 
 // ------------------------------------------------------------------------------------------
 // full reduction

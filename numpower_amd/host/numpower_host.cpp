@@ -810,32 +810,41 @@ NDArray *NDArray_Slice(NDArray *array, NDArray **indexes, int num_indices) {
 // column, 0-d: the cases of NDArray_Broadcast, ndarray.c:1196-1291) or 0-d CPU scalars.  Quirk
 // flags and AVX-body bounds are set exactly as binary_op() above sets them for the stand-alone
 // NDArray_*_Float / comparison entry points, so the fused result is bit-identical.
-NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops) {
-    if (!inputs || n_inputs < 1 || !inputs[0]) return nullptr;
+namespace {
+struct ChainCall {
+    const float *ptrs[16];
+    int kinds[16];
+    np_fused_op prog[64];
+    size_t rows, cols;
+};
+
+// operand classification + quirk flags shared by NDArray_FusedChain / NDArray_FusedChainReduce
+bool prepare_chain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops, ChainCall &c) {
+    if (!inputs || n_inputs < 1 || !inputs[0]) return false;
     NDArray *first = inputs[0];
     if (NDArray_NDIM(first) == 0) {
         throw_error("fused chain must start from an array");
-        return nullptr;
+        return false;
     }
-    if (!require_gpu(first, "fused elementwise chain")) return nullptr;
+    if (!require_gpu(first, "fused elementwise chain")) return false;
     const long n = NDArray_NUMELEMENTS(first);
-    const float *ptrs[16];
-    int kinds[16];
+    const float **ptrs = c.ptrs;
+    int *kinds = c.kinds;
     if (n_inputs > 16 || n_ops > 64) {
         throw_error("fused chain too long");
-        return nullptr;
+        return false;
     }
     size_t rows = 1, cols = (size_t)n;
     bool have_2d = false;
     for (int i = 0; i < n_inputs; ++i) {
         NDArray *x = inputs[i];
-        if (!x) return nullptr;
+        if (!x) return false;
         if (NDArray_NDIM(x) == 0 && NDArray_DEVICE(x) == NDARRAY_DEVICE_CPU) {
             kinds[i] = NP_HOST_SCALAR;
         } else {
             if (NDArray_DEVICE(x) != NDARRAY_DEVICE_GPU) {
                 throw_error("Device mismatch, both NDArray MUST be in the same device.");
-                return nullptr;
+                return false;
             }
             if (NDArray_NDIM(x) == 0) {
                 kinds[i] = NP_SCALAR;
@@ -846,7 +855,7 @@ NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *o
                 const int k = broadcast_kind(x, first, &r, &c);
                 if (k < 0 || (have_2d && (r != rows || c != cols))) {
                     throw_error("Can't broadcast arrays.");
-                    return nullptr;
+                    return false;
                 }
                 kinds[i] = k;
                 rows = r;
@@ -855,13 +864,13 @@ NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *o
             } else {
                 // the accumulator itself would have to grow: not a fused case
                 throw_error("Can't broadcast arrays.");
-                return nullptr;
+                return false;
             }
         }
         ptrs[i] = NDArray_FDATA(x);
     }
-    if (kinds[0] != NP_FULL) return nullptr;
-    np_fused_op prog[64];
+    if (kinds[0] != NP_FULL) return false;
+    np_fused_op *prog = c.prog;
     for (int k = 0; k < n_ops; ++k) {
         prog[k] = ops[k];
         prog[k].flags = 0;
@@ -870,7 +879,7 @@ NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *o
             const int op = ops[k].op;
             if (ops[k].operand < 0 || ops[k].operand >= n_inputs) {
                 throw_error("fused chain: operand index out of range");
-                return nullptr;
+                return false;
             }
             if (op == NP_MULTIPLY || op == NP_MOD || op == NP_EQUAL || op == NP_NOT_EQUAL) {
                 // AVX-body bound: element count of the FIRST operand after the scalar expand but
@@ -885,13 +894,33 @@ NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *o
             }
         }
     }
+    c.rows = rows;
+    c.cols = cols;
+    return true;
+}
+}  // namespace
+
+NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops) {
+    ChainCall c;
+    if (!prepare_chain(inputs, n_inputs, ops, n_ops, c)) return nullptr;
+    NDArray *first = inputs[0];
     NDArray *result = new_array(first->dimensions, first->ndim, NDARRAY_DEVICE_GPU, false);
     if (!result) return nullptr;
-    if (!dev_ok(np_fused_chain(ptrs, kinds, n_inputs, prog, n_ops, NDArray_FDATA(result), rows, cols))) {
+    if (!dev_ok(np_fused_chain(c.ptrs, c.kinds, n_inputs, c.prog, n_ops, NDArray_FDATA(result), c.rows, c.cols))) {
         NDArray_FREE(result);
         return nullptr;
     }
     return result;
+}
+
+// ... and with a full reduction as the chain's last step (sum / prod / min / max / mean of an
+// expression without materialising it): returns the value, NaN + error on failure.
+float NDArray_FusedChainReduce(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops, int reduce_op) {
+    ChainCall c;
+    if (!prepare_chain(inputs, n_inputs, ops, n_ops, c)) return NAN;
+    float v = NAN;
+    if (!dev_ok(np_fused_chain_reduce(c.ptrs, c.kinds, n_inputs, c.prog, n_ops, reduce_op, c.rows, c.cols, &v))) return NAN;
+    return v;
 }
 
 /* ---- argmax / argmin (calculation.c:73-194) ---- */

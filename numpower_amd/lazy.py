@@ -97,6 +97,29 @@ class Lazy:
         return NDArray._wrap(h.NDArray_FusedChain(arr, len(self.inputs), ops, len(self.ops)))
 
 
+def _reduce_method(name):
+    def method(self) -> float:
+        """Flush the chain INTO a full reduction: the expression's values are never stored."""
+        from ._lib import REDUCE_OPS
+        h = _load_host()
+        h.NDArray_FusedChainReduce.restype = C.c_float
+        h.NDArray_FusedChainReduce.argtypes = [C.POINTER(_P), C.c_int, C.POINTER(FusedOp), C.c_int, C.c_int]
+        arr = (_P * len(self.inputs))(*[x._p for x in self.inputs])
+        ops = (FusedOp * max(len(self.ops), 1))(*self.ops)
+        h.numpower_host_clear_error()
+        v = h.NDArray_FusedChainReduce(arr, len(self.inputs), ops, len(self.ops), REDUCE_OPS[name])
+        msg = h.numpower_host_last_error()
+        if msg:
+            h.numpower_host_clear_error()
+            raise Error(msg.decode())
+        return float(v)
+    return method
+
+
+for _r in ("sum", "prod", "min", "max", "mean"):
+    setattr(Lazy, _r, _reduce_method(_r))
+
+
 def lazy(a: NDArray) -> Lazy:
     return Lazy(a)
 

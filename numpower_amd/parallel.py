@@ -41,32 +41,27 @@ def all_slabs(batch: int, world_size: int):
     return [slab_for(batch, world_size, r) for r in range(world_size)]
 
 
-def sharded_batched_matmul(a_slab, b_slab, batch: int, compute, dist=None, gather: bool = True):
-    """Batched matmul with the batch sharded over the ranks of `dist`'s default group.
-
-    a_slab / b_slab : this rank's slab of the operands, torch tensors [slab, M, K] / [slab, K, N]
-                      on the rank's device
-    compute(a, b, out): writes the slab product into `out` [slab, M, N] (the HIP strided-batched
-                      GEMM on GPU ranks)
-    gather=True     : returns the replicated [batch, M, N] result (one all-gather);
-    gather=False    : returns this rank's [slab, M, N] result only (no collective at all).
-    """
+def _sharded(slabs_in, batch: int, item_shape, compute, dist, gather: bool):
+    """Shared body: every rank computes its contiguous slab of `batch` independent items straight
+    into its window of the result; gather=True adds the ONE all-gather of the path."""
     import torch
 
     if dist is None:
         import torch.distributed as dist   # noqa: F811
     world, rank = dist.get_world_size(), dist.get_rank()
     slab = slab_for(batch, world, rank)
-    if a_slab.shape[0] != slab.size or b_slab.shape[0] != slab.size:
-        raise ValueError("rank %d expects a slab of %d matrices, got %d" % (rank, slab.size, a_slab.shape[0]))
-    m, n = a_slab.shape[1], b_slab.shape[2]
+    first = slabs_in[0]
+    for x in slabs_in:
+        if x.shape[0] != slab.size:
+            raise ValueError("rank %d expects a slab of %d items, got %d" % (rank, slab.size, x.shape[0]))
+    item_shape = tuple(int(v) for v in item_shape)
     if not gather:
-        out = torch.empty((slab.size, m, n), dtype=a_slab.dtype, device=a_slab.device)
-        compute(a_slab, b_slab, out)
+        out = torch.empty((slab.size,) + item_shape, dtype=first.dtype, device=first.device)
+        compute(*slabs_in, out)
         return out
-    full = torch.empty((batch, m, n), dtype=a_slab.dtype, device=a_slab.device)
+    full = torch.empty((batch,) + item_shape, dtype=first.dtype, device=first.device)
     mine = full[slab.start:slab.stop]
-    compute(a_slab, b_slab, mine)   # written in place: the gather needs no staging copy
+    compute(*slabs_in, mine)   # written in place: the gather needs no staging copy
     if world == 1:
         return full
     if batch % world == 0:
@@ -77,14 +72,62 @@ def sharded_batched_matmul(a_slab, b_slab, batch: int, compute, dist=None, gathe
         # equal-count all-gather, then drop the padding
         slabs = all_slabs(batch, world)
         pad = max(s.size for s in slabs)
-        send = torch.zeros((pad, m, n), dtype=full.dtype, device=full.device)
+        send = torch.zeros((pad,) + item_shape, dtype=full.dtype, device=full.device)
         send[:slab.size].copy_(mine)
-        recv = torch.empty((world, pad, m, n), dtype=full.dtype, device=full.device)
+        recv = torch.empty((world, pad) + item_shape, dtype=full.dtype, device=full.device)
         dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
         for s in slabs:
             if s.rank != rank:
                 full[s.start:s.stop].copy_(recv[s.rank, :s.size])
     return full
+
+
+def sharded_batched_matmul(a_slab, b_slab, batch: int, compute, dist=None, gather: bool = True):
+    """Batched matmul with the batch sharded over the ranks of `dist`'s default group.
+
+    a_slab / b_slab : this rank's slab of the operands, torch tensors [slab, M, K] / [slab, K, N]
+                      on the rank's device
+    compute(a, b, out): writes the slab product into `out` [slab, M, N] (the HIP strided-batched
+                      GEMM on GPU ranks)
+    gather=True     : returns the replicated [batch, M, N] result (one all-gather);
+    gather=False    : returns this rank's [slab, M, N] result only (no collective at all).
+    """
+    return _sharded([a_slab, b_slab], batch, (a_slab.shape[1], b_slab.shape[2]), compute, dist, gather)
+
+
+def sharded_elementwise(slabs, batch: int, compute, dist=None, gather: bool = False):
+    """Per-slice elementwise work with the leading axis sharded (BASELINE north_star: "per-slice
+    elementwise"): `slabs` are this rank's [slab, ...] shares of one or more equally shaped
+    operands, compute(*slabs, out) writes the slab result.  Elementwise results are normally left
+    sharded (gather=False: no collective on the path at all); gather=True replicates them with the
+    same single all-gather as the batched matmul."""
+    return _sharded(list(slabs), batch, tuple(slabs[0].shape[1:]), compute, dist, gather)
+
+
+def hip_elementwise(op: str):
+    """compute() for GPU ranks: one np_binary (two operands) or np_unary (one operand) launch over
+    the whole slab, ordered with torch's work like hip_compute."""
+    def compute(*args):
+        import torch
+
+        from ._lib import BINARY_OPS, NP_FULL, UNARY_OPS, check, load
+        lib = load()
+        *ins, out = args
+        n = out.numel()
+        handle = torch.cuda.current_stream(out.device).cuda_stream
+        if handle:
+            check(lib.np_set_stream(handle))
+        else:
+            torch.cuda.synchronize(out.device)
+        if len(ins) == 2:
+            quirk = op in ("multiply", "mod", "equal", "not_equal")   # as NDArray_*_Float sets them
+            check(lib.np_binary(BINARY_OPS[op], ins[0].data_ptr(), NP_FULL, ins[1].data_ptr(), NP_FULL,
+                                out.data_ptr(), 1, n, 1 if quirk else 0, lib.np_avx_body_end(n) if quirk else 0))
+        else:
+            check(lib.np_unary(UNARY_OPS[op], ins[0].data_ptr(), out.data_ptr(), n, 0.0, 0.0))
+        if not handle:
+            check(lib.np_sync())
+    return compute
 
 
 def hip_compute(a, b, out):

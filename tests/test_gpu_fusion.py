@@ -115,3 +115,34 @@ def test_fused_errors(hip):
         (a.lazy() + NDArray.array(np.ones((4, 6), np.float32))).eval()
     with pytest.raises(Error, match="only computes on the GPU"):
         NDArray.array(np.ones((4, 6), np.float32)).lazy().exp().eval()
+
+
+@pytest.mark.parametrize("shape", [(1000, 1000), (257, 1001), (3, 5), (1,)])
+def test_chain_ending_in_a_reduction(shape, hip):
+    """sum / prod / min / max / mean of an expression without materialising it
+    (np_fused_chain_reduce): min / max are exact; sum / mean within 1e-5 of an fp64 accumulation of
+    the SAME fp32 chain values (the reference's own order is sequential fp32); deterministic."""
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    from numpower_amd.ndarray import NDArray
+    a = synth.uniform(shape, 94, -2.0, 2.0)
+    b = synth.uniform(shape, 95, 0.5, 2.0)
+    ga, gb = NDArray.array(a).gpu(), NDArray.array(b).gpu()
+    vals = (NDArray.exp(ga) * gb + 2.0).cpu().numpy()          # the chain's fp32 values, op by op
+    chain = lambda: ga.lazy().exp() * gb + 2.0                 # noqa: E731
+    assert chain().max() == float(vals.max()) and chain().min() == float(vals.min())
+    s = chain().sum()
+    assert s == chain().sum()
+    want = float(vals.astype(np.float64).sum())
+    assert abs(s - want) <= 1e-5 * abs(want)
+    assert abs(chain().mean() - want / vals.size) <= 1e-5 * abs(want / vals.size)
+    # a chain of length 0 is a plain reduction
+    assert abs(ga.lazy().sum() - float(a.astype(np.float64).sum())) <= 1e-5 * np.abs(a).sum()
+    # prod over a short vector; broadcast operand in a reduced chain
+    if vals.size <= 15:
+        p = (ga.lazy() * 1.0).prod()
+        assert abs(p - float(np.prod(a.astype(np.float64)))) <= 1e-5 * abs(float(np.prod(a.astype(np.float64))))
+    if len(shape) == 2:
+        row = synth.uniform((shape[1],), 96, -1.0, 1.0)
+        got = (ga.lazy() * NDArray.array(row).gpu()).sum()
+        want = float((a * row[None, :]).astype(np.float64).sum())
+        assert abs(got - want) <= 1e-5 * np.abs(a * row[None, :]).sum()

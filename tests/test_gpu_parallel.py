@@ -39,6 +39,13 @@ def test_sharded_batched_matmul_world1_rccl(hip):
                 torch.cuda.synchronize()
             for got in (full.cpu().numpy(), mine.cpu().numpy()):
                 assert (np.abs(got - ref) <= 1e-6 * scale).all()
+            # per-slice elementwise on the same plumbing: HIP np_binary / np_unary over the slab
+            with ctx:
+                prod = parallel.sharded_elementwise([a, a], batch, parallel.hip_elementwise("multiply"), dist=dist)
+                ex = parallel.sharded_elementwise([a], batch, parallel.hip_elementwise("exp"), dist=dist, gather=True)
+                torch.cuda.synchronize()
+            assert np.array_equal(prod.cpu().numpy(), A * A)
+            assert np.allclose(ex.cpu().numpy(), np.exp(A.astype(np.float64)), rtol=1e-6)
     finally:
         dist.destroy_process_group()
         from numpower_amd._lib import check, load

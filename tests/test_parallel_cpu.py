@@ -32,11 +32,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, batch, gather, q):
+def _worker(rank, world, port, batch, gather, q, kind="matmul"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if kind == "elementwise":      # per-slice elementwise: slices of the leading axis are sharded
+            slab = parallel.slab_for(batch, world, rank)
+            mk = lambda seed: torch.stack([torch.from_numpy(synth.uniform((3, 5), seed + i, -1, 1))   # noqa: E731
+                                           for i in range(slab.start, slab.stop)]) if slab.size else torch.empty((0, 3, 5))
+            x, y = mk(300), mk(400)
+            res = parallel.sharded_elementwise([x, y], batch, lambda a, b, out: torch.add(a, b, out=out),
+                                               dist=dist, gather=gather)
+            q.put((rank, res.numpy()))
+            return
         m, k, n = 6, 5, 4
         slab = parallel.slab_for(batch, world, rank)
         a = torch.stack([torch.from_numpy(synth.uniform((m, k), 100 + i, -1, 1)) for i in range(slab.start, slab.stop)]) \
@@ -53,11 +62,11 @@ def _worker(rank, world, port, batch, gather, q):
         dist.destroy_process_group()
 
 
-def _run(world, batch, gather):
+def _run(world, batch, gather, kind="matmul"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, gather, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, gather, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     out = dict(q.get(timeout=120) for _ in range(world))
@@ -85,3 +94,18 @@ def test_sharded_batched_matmul_left_sharded():
     want = _expected(8)
     np.testing.assert_allclose(out[0], want[:4], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(out[1], want[4:], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("world,batch,gather", [(2, 8, False), (2, 7, True), (3, 8, True)])
+def test_sharded_elementwise(world, batch, gather):
+    """north_star's "per-slice elementwise": left sharded there is no collective at all; gathered
+    it is the same single all-gather (ragged slabs included)."""
+    out = _run(world, batch, gather, kind="elementwise")
+    want = np.stack([synth.uniform((3, 5), 300 + i, -1, 1) + synth.uniform((3, 5), 400 + i, -1, 1)
+                     for i in range(batch)])
+    for rank in range(world):
+        if gather:
+            np.testing.assert_array_equal(out[rank], want)
+        else:
+            slab = parallel.slab_for(batch, world, rank)
+            np.testing.assert_array_equal(out[rank], want[slab.start:slab.stop])

@@ -23,13 +23,13 @@ def one(chain):
         h = synth.uniform((n,), 40 + i, 0.25, 1.75)
         _lib.check(lib.np_memcpy_h2d(b.ptr, h.ctypes.data, 4 * n))
     two = C.c_float(2.0)
-    if chain == "exp_mul_add":
+    if chain in ("exp_mul_add", "exp_mul_add_sum"):
         inputs = [bufs[0].ptr, bufs[1].ptr, C.addressof(two)]
         kinds = [0, 0, 4]
         ops = [FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0), FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 1, n // 8 * 8),
                FusedOp(1, BINARY_OPS["add"], 2, 0, 0, 0, 0, 0)]
         nbytes = 12 * n
-    elif chain == "fma3":       # a*b+c : 3 arrays in, 1 out
+    elif chain in ("fma3", "fma3_sum"):       # a*b+c : 3 arrays in, 1 out
         inputs = [bufs[0].ptr, bufs[1].ptr, bufs[2].ptr]
         kinds = [0, 0, 0]
         ops = [FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 1, n // 8 * 8), FusedOp(1, BINARY_OPS["add"], 2, 0, 0, 0, 0, 0)]
@@ -39,20 +39,30 @@ def one(chain):
         kinds = [0]
         ops = [FusedOp(0, UNARY_OPS[u], 0, 0, 0, 0, 0, 0) for u in ("exp", "log1p", "sqrt", "tanh", "abs", "sin")]
         nbytes = 8 * n
+    reduce = chain.endswith("_sum")
+    if reduce:
+        nbytes -= 4 * n
     arr = (C.c_void_p * len(inputs))(*inputs)
     k = (C.c_int * len(kinds))(*kinds)
     o = (FusedOp * len(ops))(*ops)
     t = _lib.Timer()
+    res = C.c_float(0.0)
+
+    def launch():
+        if reduce:
+            _lib.check(lib.np_fused_chain_reduce(arr, k, len(inputs), o, len(ops), 0, 1, n, C.byref(res)))
+        else:
+            _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, 1, n))
     for _ in range(5):
-        _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, 1, n))
+        launch()
     t.start()
     reps = 30
     for _ in range(reps):
-        _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, 1, n))
+        launch()
     t.stop()
     _lib.check(lib.np_sync())
     ms = t.elapsed_ms() / reps
-    print(json.dumps({"chain": chain, "U": os.environ.get("NP_FUSED_U"), "FULL": os.environ.get("NP_FUSED_FULL"),
+    print(json.dumps({"chain": chain, "U": os.environ.get("NP_FUSED_U"), "FULL": os.environ.get("NP_FUSED_FULL"), "RBPC": os.environ.get("NP_FUSED_RBPC"),
                       "ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1)}))
 
 
@@ -60,6 +70,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         one(sys.argv[1])
     else:
+        if os.environ.get("FUSED_AB_REDUCE"):
+            for chain in ("exp_mul_add_sum", "fma3_sum"):
+                for u in ("1", "2"):
+                    for rbpc in ("4", "8", "16", "32", "64"):
+                        env = dict(os.environ, NP_FUSED_U=u, NP_FUSED_RBPC=rbpc)
+                        subprocess.run([sys.executable, __file__, chain], env=env, check=False)
+            sys.exit(0)
         for chain in ("exp_mul_add", "fma3", "unary6"):
             for u in ("1", "2"):
                 for full in (None, "1"):
