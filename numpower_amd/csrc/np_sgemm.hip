@@ -454,6 +454,12 @@ __global__ __launch_bounds__(256, 2) void sgemm_pipe_kernel(GemmArgs g) {
 // 1 are fetched under the MFMAs of group 0; the barrier publishes tile t+1 (its DMAs were issued
 // a full tile earlier; hipcc's vmcnt(0) in front of the barrier is then already satisfied);
 // right after it the DMAs of tile t+2 go into the buffer tile t-1 just vacated.
+//
+// EDGE = the tile may stick out of C (M % 256 or N % 128 != 0; K % 16 == 0 and float4-aligned rows
+// are still required).  Out-of-range A rows and B columns are fetched from CLAMPED addresses (row
+// M-1, columns N-4..N-1): whatever lands in those LDS slots only ever reaches C rows >= M or
+// columns >= N, which the guarded epilogue does not store — no zero fill, no extra work in the loop.
+template <bool EDGE>
 __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     if (g.K_last && blockIdx.z + 1 == gridDim.z) g.K = g.K_last;   // uniform: split-K remainder chunk
     constexpr int BM = 256, BN = 128, BK = 16;
@@ -488,13 +494,17 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     for (int c = 0; c < 4; ++c) {
         const unsigned r = (wave * 4 + c) * 16 + (lane >> 2);
         const unsigned q = (lane & 3) ^ ((r >> 2) & 3);
-        a_src[c] = A + (size_t)(m0 + r) * g.lda + q * 4;
+        unsigned grow = m0 + r;
+        if (EDGE && grow >= g.M) grow = g.M - 1;
+        a_src[c] = A + (size_t)grow * g.lda + q * 4;
     }
     const float *b_src[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const unsigned krow = (wave * 2 + c) * 2 + (lane >> 5);
-        b_src[c] = B + (size_t)krow * g.ldb + n0 + (lane & 31) * 4;
+        unsigned gcol = n0 + (lane & 31) * 4;
+        if (EDGE && gcol + 4 > g.N) gcol = g.N - 4;
+        b_src[c] = B + (size_t)krow * g.ldb + gcol;
     }
     const size_t b_step = (size_t)BK * g.ldb;
 
@@ -624,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const unsigned row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const unsigned col = n0 + wn0 + j * 32 + li;
-                C[(size_t)row * g.ldc + col] = acc[i][j][r];
+                if (!EDGE || (row < g.M && col < g.N)) C[(size_t)row * g.ldc + col] = acc[i][j][r];
             }
     probe_end(g, probe_c0, probe_w0);
 }
@@ -698,7 +708,7 @@ int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
 
 // ---- default kernel choice -------------------------------------------------------------------
 // Three tile configurations, efficiencies measured at 4096^3 on MI355X (profiles/r01/gemm_ab.log):
-//   0: sgemm_dma_kernel 256x128 (fully aligned shapes only)   0.93   (145 TFLOP/s)
+//   0: sgemm_dma_kernel 256x128 (K % 16 == 0, float4 rows)      0.93   (145 TFLOP/s)
 //   1: sgemm_kernel     128x128                               0.85   (132-135)
 //   2: sgemm_kernel      64x64                                0.71   (110)
 struct TileCfg { unsigned bm, bn; double eff; };
@@ -706,9 +716,13 @@ constexpr TileCfg kCfg[3] = {{256, 128, 0.93}, {128, 128, 0.85}, {64, 64, 0.71}}
 
 int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
     if (cfg == 0) {
-        g.tiles_m = g.M / 256;
-        g.tiles_n = g.N / 128;
-        sgemm_dma_kernel<<<dim3(g.tiles_m * g.tiles_n, 1, batch), 256, 0, np::stream()>>>(g);
+        g.tiles_m = (g.M + 255) / 256;
+        g.tiles_n = (g.N + 127) / 128;
+        const dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
+        if (g.M % 256 || g.N % 128)
+            sgemm_dma_kernel<true><<<grid, 256, 0, np::stream()>>>(g);
+        else
+            sgemm_dma_kernel<false><<<grid, 256, 0, np::stream()>>>(g);
         NP_LAUNCH_CHECK("sgemm_dma_kernel");
         return NP_OK;
     }
@@ -771,7 +785,7 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok) {
 
 int launch_planned(GemmArgs g, size_t batch, bool vec) {
     const size_t M = g.M, N = g.N, K = g.K;
-    const bool dma_ok = vec && M % 256 == 0 && N % 128 == 0 && K % 16 == 0;
+    const bool dma_ok = vec && K % 16 == 0 && N >= 4;   // M, N edges: sgemm_dma_kernel<EDGE>
     Plan p = plan_sgemm(M, N, K, batch, dma_ok);
     // tools/gemm_plan_sweep.py: NP_SGEMM_PLAN="cfg,tail_rows,S" forces a plan, NP_SGEMM_PLAN_DEBUG prints the choice
     static const char *forced = getenv("NP_SGEMM_PLAN");
@@ -853,13 +867,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
         case 5: return launch_sgemm_pipe<128, 128, 0>(g, (unsigned)batch, vec);
         case 6: return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
         case 7:
-            if (vec && M % 256 == 0 && N % 128 == 0 && K % 16 == 0) {
-                g.tiles_m = g.M / 256;
-                g.tiles_n = g.N / 128;
-                sgemm_dma_kernel<<<dim3(g.tiles_m * g.tiles_n, 1, (unsigned)batch), 256, 0, np::stream()>>>(g);
-                NP_LAUNCH_CHECK("sgemm_dma_kernel");
-                return NP_OK;
-            }
+            if (vec && K % 16 == 0 && N >= 4) return launch_cfg(0, g, (unsigned)batch, vec);
             return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
         default: break;
     }

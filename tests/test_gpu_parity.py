@@ -335,7 +335,10 @@ def _gemm_check(got, A, B, what):
 
 
 @pytest.mark.parametrize("mnk", [(2, 2, 2), (2, 1, 2), (64, 64, 64), (128, 128, 128), (100, 90, 70),
-                                 (257, 129, 65), (1000, 1000, 1000), (1024, 512, 2048), (1, 1000, 1)])
+                                 (257, 129, 65), (1000, 1000, 1000), (1024, 512, 2048), (1, 1000, 1),
+                                 # LDS-DMA kernel with M / N edges (clamped source rows / columns)
+                                 (2000, 2004, 2000), (1000, 1000, 1008), (300, 516, 2048), (257, 4, 4096),
+                                 (3, 132, 64)])
 def test_matmul_vs_oracle_and_fp64(mnk, hip, oracle):
     from numpower_amd.ndarray import NDArray
     m, n, k = mnk
@@ -451,3 +454,33 @@ def test_matmul_splitk_small_result_long_k(mnk, hip, oracle):
         _lib.check(_lib.load().np_sgemm_set_variant(-2))
     assert (np.abs(plain - ref64) / scale).max() <= 1e-5
     assert (np.abs(plain.astype(np.float64) - got) / scale).max() <= 2e-6
+
+
+@pytest.mark.parametrize("mnk", [(2000, 2004, 2000), (300, 516, 2048), (257, 4, 4096), (3, 132, 64), (255, 127, 16),
+                                 (513, 260, 1024), (4000, 4000, 496)])
+def test_matmul_dma_edge_kernel(mnk, hip):
+    """sgemm_dma_kernel<EDGE> forced (variant 7): M / N not multiples of the 256 x 128 tile — source
+    rows / columns are clamped, the garbage only reaches rows >= M / columns >= N that the guarded
+    epilogue never stores.  Checked against fp64 AND bit-for-bit against the 128 x 128 kernel's
+    neighbours: nothing outside C may be written (a canary frame around the output)."""
+    from numpower_amd import _lib
+    from numpower_amd import device as D
+    lib = _lib.load()
+    m, n, k = mnk
+    a = synth.uniform((m, k), 33, -1.0, 1.0)
+    b = synth.uniform((k, n), 34, -1.0, 1.0)
+    da, db = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b)
+    pad = 4096                                             # floats of canary before and after C
+    frame = D.DeviceArray((m * n + 2 * pad,))
+    D.fill(frame, -777.0)
+    _lib.check(lib.np_sgemm_set_variant(7))
+    try:
+        _lib.check(lib.np_sgemm(m, n, k, da.ptr, db.ptr, frame.ptr + 4 * pad))
+    finally:
+        _lib.check(lib.np_sgemm_set_variant(0))
+    host = frame.to_host().reshape(-1)
+    assert (host[:pad] == -777.0).all() and (host[pad + m * n:] == -777.0).all()
+    got = host[pad:pad + m * n].reshape(m, n)
+    ref64 = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(got - ref64) / scale).max() <= 1e-6
