@@ -1,0 +1,110 @@
+"""Edge cases of the hot path on the GPU: empty and one-element arrays, 0-d operands on either
+side, K = 0 products, and arrays past 2^31 elements (the reference's vmalloc(unsigned int),
+gpu_alloc.c:11, stops at 4 GiB per buffer; the C ABI is size_t throughout and the kernels switch to
+64-bit indices)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from numpower_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _nd():
+    from numpower_amd.ndarray import NDArray
+    return NDArray
+
+
+def test_empty_arrays_flow_through(hip):
+    nd = _nd()
+    e = nd.array(np.zeros((0,), np.float32)).gpu()
+    e2 = nd.array(np.zeros((0, 5), np.float32)).gpu()
+    assert (e + e).shape() == [0] and (e * 2.0).shape() == [0]
+    assert nd.exp(e).shape() == [0] and nd.abs(e2).shape() == [0, 5]
+    assert (e2 + e2).cpu().numpy().shape == (0, 5)
+    assert nd.sum(e) == 0.0                       # empty sum; the loop of NDArray_Sum_Float never runs
+    assert nd.prod(e) == 1.0
+    assert nd.transpose(e2).shape() == [5, 0]
+    assert nd.flatten(e2).shape() == [0]
+    assert nd.array_equal(e, nd.array(np.zeros((0,), np.float32)).gpu()) is True
+    # (0 x 5) . (5 x 3) -> 0 x 3; (3 x 0) . (0 x 4) -> zeros (beta = 0 with an empty inner dimension)
+    z = nd.matmul(e2, nd.array(np.ones((5, 3), np.float32)).gpu())
+    assert z.shape() == [0, 3]
+    k0 = nd.matmul(nd.array(np.zeros((3, 0), np.float32)).gpu(), nd.array(np.zeros((0, 4), np.float32)).gpu())
+    assert (k0.cpu().numpy() == np.zeros((3, 4), np.float32)).all()
+
+
+def test_one_element_and_scalar_operands(hip, oracle):
+    nd = _nd()
+    one = nd.array(np.float32([[-0.0]])).gpu()
+    # 1 x 1 array (op) host scalar, both orders; multiply keeps the reference's zero-sign rule for
+    # a one-element (tail-only) loop: -0.0 products become +0.0 (arithmetics.c:410-412)
+    got = (one * 3.0).cpu().numpy()
+    want = oracle.binary("multiply", np.float32([[-0.0]]), np.float32(3.0))
+    assert got.view(np.uint32).tolist() == want.view(np.uint32).tolist()
+    got = (3.0 * one).cpu().numpy()
+    want = oracle.binary("multiply", np.float32(3.0), np.float32([[-0.0]]))
+    assert got.view(np.uint32).tolist() == want.view(np.uint32).tolist()
+    x = nd.array(np.float32([2.5])).gpu()
+    assert nd.sum(x) == 2.5 and nd.max(x) == 2.5 and nd.min(x) == 2.5 and nd.mean(x) == 2.5
+    assert (10.0 - x).cpu().numpy().tolist() == [7.5]
+    assert (x ** 2).cpu().numpy().tolist() == [6.25]
+    assert nd.matmul(nd.array(np.float32([[3.0]])).gpu(), nd.array(np.float32([[4.0]])).gpu()).cpu().numpy().tolist() == [[12.0]]
+    assert nd.argmax(x) == 0.0
+
+
+def test_ragged_lengths_around_the_vector_width(hip, oracle):
+    """Every length 1..40 and a few around 2^k: float4 body, scalar tail, AVX-body bound."""
+    nd = _nd()
+    for n in list(range(1, 41)) + [255, 256, 257, 1023, 1025, 4099]:
+        a = synth.uniform((n,), 80 + n, -2.0, 2.0)
+        b = synth.uniform((n,), 180 + n, 0.5, 2.0)
+        a[::3] = 0.0
+        ga, gb = nd.array(a).gpu(), nd.array(b).gpu()
+        for op in ("add", "multiply", "mod", "equal"):
+            got = nd._binary(op, ga, gb).cpu().numpy()
+            want = oracle.binary(op, a, b)
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), (op, n)
+        assert (nd.floor(ga).cpu().numpy() == np.floor(a)).all()
+        s = nd.sum(ga)
+        assert abs(s - float(a.astype(np.float64).sum())) <= 1e-5 * max(1.0, np.abs(a).sum())
+
+
+def test_past_2_to_31_elements(hip):
+    """fill / unary / binary / fused chain on 2^31 + 4100 elements (8.6 GB per buffer): values are
+    probed on both sides of the 2^31 boundary and at the very end (64-bit index kernels)."""
+    from numpower_amd import _lib
+    from numpower_amd._lib import BINARY_OPS, UNARY_OPS, FusedOp
+    lib = _lib.load()
+    n = (1 << 31) + 4100
+    a, b, out = (_lib.DeviceBuffer(4 * n) for _ in range(3))
+    _lib.check(lib.np_fill(a.ptr, 1.5, n))
+    _lib.check(lib.np_fill(b.ptr, 2.0, n))
+    # make the far end distinguishable: b[n-1] = 10
+    ten = np.float32([10.0])
+    _lib.check(lib.np_memcpy_h2d(b.ptr + 4 * (n - 1), ten.ctypes.data, 4))
+
+    def probe(buf, index):
+        v = C.c_float()
+        _lib.check(lib.np_read_float(buf.ptr, index, C.byref(v)))
+        return v.value
+
+    probes = [0, 12345, (1 << 31) - 1, 1 << 31, (1 << 31) + 4096, n - 2, n - 1]
+    _lib.check(lib.np_binary(BINARY_OPS["add"], a.ptr, 0, b.ptr, 0, out.ptr, 1, n, 0, 0))
+    assert [probe(out, i) for i in probes] == [3.5] * 6 + [11.5]
+    _lib.check(lib.np_unary(UNARY_OPS["negate"], b.ptr, out.ptr, n, 0.0, 0.0))
+    assert [probe(out, i) for i in probes] == [-2.0] * 6 + [-10.0]
+    ops = (FusedOp * 2)(FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 1, n // 8 * 8),
+                        FusedOp(0, UNARY_OPS["sqrt"], 0, 0, 0, 0, 0, 0))
+    ptrs = (C.c_void_p * 2)(a.ptr, b.ptr)
+    kinds = (C.c_int * 2)(0, 0)
+    _lib.check(lib.np_fused_chain(ptrs, kinds, 2, ops, 2, out.ptr, 1, n))
+    want = float(np.sqrt(np.float32(3.0)))
+    assert [probe(out, i) for i in probes[:-1]] == [want] * 6
+    assert probe(out, n - 1) == float(np.sqrt(np.float32(15.0)))
+    for buf in (a, b, out):
+        buf.free()
+    freed = C.c_size_t()
+    _lib.check(lib.np_pool_trim(C.byref(freed)))        # hand the 26 GB back to the driver
