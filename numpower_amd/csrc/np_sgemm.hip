@@ -711,8 +711,12 @@ int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
 //   0: sgemm_dma_kernel 256x128 (K % 16 == 0, float4 rows)      0.93   (145 TFLOP/s)
 //   1: sgemm_kernel     128x128                               0.85   (132-135)
 //   2: sgemm_kernel      64x64                                0.71   (110)
-struct TileCfg { unsigned bm, bn; double eff; };
-constexpr TileCfg kCfg[3] = {{256, 128, 0.93}, {128, 128, 0.85}, {64, 64, 0.71}};
+// eff = MFMA efficiency with several workgroups resident per CU (>= 2 waves of tiles: one
+// workgroup's barriers and LDS traffic hide under another's MFMAs), eff1 = with a single workgroup
+// per CU (one wave of tiles or less): 2000^3 on 128x128 tiles is exactly 256 tiles and runs at 0.64,
+// not 0.85 (profiles/r01/gemm_plan_sweep.log).
+struct TileCfg { unsigned bm, bn; double eff, eff1; };
+constexpr TileCfg kCfg[3] = {{256, 128, 0.93, 0.89}, {128, 128, 0.85, 0.64}, {64, 64, 0.71, 0.52}};
 
 int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
     if (cfg == 0) {
@@ -754,8 +758,15 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok) {
         if (c == 0 && !dma_ok) continue;
         const TileCfg &T = kCfg[c];
         const size_t tm = (M + T.bm - 1) / T.bm, tn = (N + T.bn - 1) / T.bn;
-        auto unit = [&](size_t k) { return 2.0 * T.bm * T.bn * (double)k / (T.eff * cu_flops) + unit_fixed; };
-        const double whole = ceil((double)(tm * tn * batch) / cus) * unit(K);
+        // time of `units` work units of k inner steps each
+        auto span = [&](double units, size_t k) {
+            if (units <= 0) return 0.0;
+            const double waves = units / cus;
+            const double blend = waves <= 1.0 ? 0.0 : waves >= 2.0 ? 1.0 : waves - 1.0;
+            const double eff = T.eff1 + (T.eff - T.eff1) * blend;
+            return ceil(waves) * (2.0 * T.bm * T.bn * (double)k / (eff * cu_flops) + unit_fixed);
+        };
+        const double whole = span((double)(tm * tn * batch), K);
         if (whole < best.t) best = Plan{c, 0, 1, K, whole};
         if (!g_splitk || batch != 1 || K < 512) continue;
         // candidate tails: up to one machine-wave worth of tile rows, or everything
@@ -772,8 +783,8 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok) {
                 if (Kc < 128) break;
                 const size_t chunks = (K + Kc - 1) / Kc;
                 if (chunks < 2) continue;
-                double t = ceil((double)(lead_rows * tn) / cus) * unit(K);
-                t += ceil((double)(r * tn * chunks) / cus) * unit(Kc);
+                double t = span((double)(lead_rows * tn), K);
+                t += span((double)(r * tn * chunks), Kc);
                 t += (double)((chunks + 1) * m2 * N * sizeof(float)) / hbm + launch;
                 if (lead_rows) t += launch;
                 if (t < best.t) best = Plan{c, (unsigned)r, (unsigned)chunks, Kc, t};
