@@ -300,8 +300,8 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
  * (manipulation.c:193-283) reduce to. */
 int np_strided_copy(const float *in, float *out, int ndim, const int *host_shape, const long long *host_strides);
 
-/* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 / -2 switch the
- * split-K path for small-result, long-K products off / on). */
+/* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 = whole-K plans only,
+ * -2 = default planner again, -3 = default planner + always pad unaligned operands). */
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);
 int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128 */

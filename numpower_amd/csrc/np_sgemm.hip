@@ -20,6 +20,8 @@
 // Row-major A.B needs no transposes on either operand with this mapping.
 #include <type_traits>
 
+#include <algorithm>
+
 #include "np_internal.h"
 
 namespace {
@@ -37,6 +39,7 @@ struct GemmArgs {
     float *C;
     unsigned M, N, K;
     unsigned K_last;                        // != 0: inner length of the LAST batch entry (split-K remainder chunk)
+    unsigned n_store;                       // != 0: C has only this many columns (B was padded to N, see pad_operands)
     unsigned lda, ldb, ldc;
     size_t stride_a, stride_b, stride_c;   // batch strides (elements)
     unsigned tiles_m, tiles_n;
@@ -634,9 +637,31 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const unsigned row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const unsigned col = n0 + wn0 + j * 32 + li;
-                if (!EDGE || (row < g.M && col < g.N)) C[(size_t)row * g.ldc + col] = acc[i][j][r];
+                if (!EDGE || (row < g.M && col < (g.n_store ? g.n_store : g.N)))
+                    C[(size_t)row * g.ldc + col] = acc[i][j][r];
             }
     probe_end(g, probe_c0, probe_w0);
+}
+
+// Zero-padded copy of a row-major matrix: out (rows_out x ld_out, ld_out % 4 == 0, 16-byte aligned)
+// = in (rows_in x cols_in, row stride ld_in) in the top-left corner, zeros elsewhere.
+__global__ __launch_bounds__(256) void pad_copy_kernel(const float *__restrict__ in, unsigned ld_in,
+                                                       unsigned rows_in, unsigned cols_in,
+                                                       float *__restrict__ out, unsigned ld_out,
+                                                       unsigned rows_out) {
+    const unsigned c4n = ld_out / 4;
+    const size_t total = (size_t)rows_out * c4n;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
+        const unsigned r = (unsigned)(v / c4n), c = (unsigned)(v - (size_t)r * c4n) * 4;
+        v4f x{0.0f, 0.0f, 0.0f, 0.0f};
+        if (r < rows_in) {
+            const float *src = in + (size_t)r * ld_in + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < cols_in) x[e] = src[e];
+        }
+        *(v4f *)(out + (size_t)r * ld_out + c) = x;
+    }
 }
 
 // y = A x, one wave per row (rows are contiguous: float4 loads, wave64 shuffle reduce).
@@ -723,7 +748,7 @@ int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
         g.tiles_m = (g.M + 255) / 256;
         g.tiles_n = (g.N + 127) / 128;
         const dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
-        if (g.M % 256 || g.N % 128)
+        if (g.M % 256 || g.N % 128 || g.n_store)
             sgemm_dma_kernel<true><<<grid, 256, 0, np::stream()>>>(g);
         else
             sgemm_dma_kernel<false><<<grid, 256, 0, np::stream()>>>(g);
@@ -734,6 +759,7 @@ int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
     return launch_sgemm_tile<64, 64, 16, 4>(g, batch, vec);
 }
 
+bool g_force_pad = false;   // np_sgemm_set_variant(-3): always take launch_padded when it applies (tests)
 bool g_splitk = true;   // np_sgemm_set_variant(-1) turns the K-splitting plans off (A/B in tools/)
 
 // A plan = tile configuration + how many trailing tile-ROWS of C are computed split-K.
@@ -750,12 +776,13 @@ bool g_splitk = true;   // np_sgemm_set_variant(-1) turns the K-splitting plans 
 // 2*bm*bn*k / (eff * peak per CU) + a fixed prologue/epilogue, the reduce costs its HBM traffic.
 struct Plan { int cfg; unsigned tail_rows, S; size_t Kc; double t; };
 
-Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok) {
+Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool only_dma = false, bool vec = true) {
     const double cus = (double)np::num_cus();
     const double cu_flops = 157.3e12 / 256.0, unit_fixed = 1.5e-6, launch = 3e-6, hbm = 4e12;
     Plan best{2, 0, 1, K, 1e300};
     for (int c = 0; c < 3; ++c) {
         if (c == 0 && !dma_ok) continue;
+        if (c != 0 && only_dma) continue;
         const TileCfg &T = kCfg[c];
         const size_t tm = (M + T.bm - 1) / T.bm, tn = (N + T.bn - 1) / T.bn;
         // time of `units` work units of k inner steps each
@@ -763,7 +790,8 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok) {
             if (units <= 0) return 0.0;
             const double waves = units / cus;
             const double blend = waves <= 1.0 ? 0.0 : waves >= 2.0 ? 1.0 : waves - 1.0;
-            const double eff = T.eff1 + (T.eff - T.eff1) * blend;
+            // the register-staged kernels lose ~1/4 when rows are not float4-loadable (4097^3: 97 vs 132)
+            const double eff = (T.eff1 + (T.eff - T.eff1) * blend) * (vec || c == 0 ? 1.0 : 0.78);
             return ceil(waves) * (2.0 * T.bm * T.bn * (double)k / (eff * cu_flops) + unit_fixed);
         };
         const double whole = span((double)(tm * tn * batch), K);
@@ -794,13 +822,59 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok) {
     return best;
 }
 
+int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec);
+
+// Operands the LDS-DMA kernel cannot take as they are — K % 16 != 0, rows that are not 16-byte
+// aligned (K % 4 or N % 4 != 0), odd base addresses — are copied once into zero-padded, aligned
+// workspaces: A' (M x K'), B' (K' x N'), K' = K rounded up to 16, N' = N rounded up to 4.  The
+// zeros contribute nothing, C is written in place with its real row length (n_store), and the
+// copies cost O(M K + K N) bytes against O(M N K) flops: 4097^3 pays ~70 us of copies to run at the
+// DMA kernel's rate instead of the scalar-load fallback's (97 -> 130+ TFLOP/s).  Taken only when
+// the model says the copies pay (large products).
+int launch_padded(const GemmArgs &g, const Plan &p, size_t Kp, size_t Np) {
+    np::Scratch wa, wb;
+    if (int rc = wa.alloc((size_t)g.M * Kp * sizeof(float))) return rc;
+    if (int rc = wb.alloc(Kp * Np * sizeof(float))) return rc;
+    hipStream_t s = np::stream();
+    const unsigned cap = (unsigned)np::num_cus() * 16;
+    auto blocks = [&](size_t items) { return (unsigned)std::min<size_t>((items + 255) / 256, cap); };
+    pad_copy_kernel<<<blocks((size_t)g.M * Kp / 4), 256, 0, s>>>(g.A, g.lda, g.M, g.K, (float *)wa.ptr, (unsigned)Kp, g.M);
+    NP_LAUNCH_CHECK("pad_copy_kernel");
+    pad_copy_kernel<<<blocks(Kp * Np / 4), 256, 0, s>>>(g.B, g.ldb, g.K, g.N, (float *)wb.ptr, (unsigned)Np, (unsigned)Kp);
+    NP_LAUNCH_CHECK("pad_copy_kernel");
+    GemmArgs q = g;
+    q.A = (const float *)wa.ptr;
+    q.B = (const float *)wb.ptr;
+    q.K = (unsigned)Kp;
+    q.lda = (unsigned)Kp;
+    q.ldb = (unsigned)Np;
+    q.n_store = g.N;          // C keeps its real row length (ldc = N)
+    q.N = (unsigned)Np;
+    return launch_plan(p, q, 1, true);
+}
+
 int launch_planned(GemmArgs g, size_t batch, bool vec) {
     const size_t M = g.M, N = g.N, K = g.K;
     const bool dma_ok = vec && K % 16 == 0 && N >= 4;   // M, N edges: sgemm_dma_kernel<EDGE>
-    Plan p = plan_sgemm(M, N, K, batch, dma_ok);
+    Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec);
+    static const bool debug = getenv("NP_SGEMM_PLAN_DEBUG") != nullptr;
+    if (!dma_ok && batch == 1 && g_splitk && N >= 1) {
+        const size_t Kp = (K + 15) / 16 * 16, Np = (N + 3) / 4 * 4;
+        Plan pp = plan_sgemm(M, Np, Kp, 1, true, true);
+        // two pad launches: read + write of both operands
+        pp.t += 2.0 * (double)((M * Kp + Kp * Np) * sizeof(float)) / 4e12 + 2 * 3e-6;
+        if (debug)
+            fprintf(stderr, "[np_sgemm] %zux%zux%zu pad candidate: cfg %d tail_rows %u S %u model %.1f us vs unpadded cfg %d tail %u S %u %.1f us\n",
+                    M, N, K, pp.cfg, pp.tail_rows, pp.S, pp.t * 1e6, p.cfg, p.tail_rows, p.S, p.t * 1e6);
+        if (pp.t < p.t || g_force_pad) {
+            if (debug)
+                fprintf(stderr, "[np_sgemm] %zux%zux%zu -> padded to K %zu N %zu: cfg %d tail_rows %u S %u model %.1f us (unpadded %.1f)\n",
+                        M, N, K, Kp, Np, pp.cfg, pp.tail_rows, pp.S, pp.t * 1e6, p.t * 1e6);
+            return launch_padded(g, pp, Kp, Np);
+        }
+    }
     // tools/gemm_plan_sweep.py: NP_SGEMM_PLAN="cfg,tail_rows,S" forces a plan, NP_SGEMM_PLAN_DEBUG prints the choice
     static const char *forced = getenv("NP_SGEMM_PLAN");
-    static const bool debug = getenv("NP_SGEMM_PLAN_DEBUG") != nullptr;
     if (forced && batch == 1) {
         int c = 2, r = 0, S = 1;
         if (sscanf(forced, "%d,%d,%d", &c, &r, &S) == 3 && c >= 0 && c < 3 && (c != 0 || dma_ok)) {
@@ -813,6 +887,11 @@ int launch_planned(GemmArgs g, size_t batch, bool vec) {
     if (debug)
         fprintf(stderr, "[np_sgemm] %zux%zux%zu batch %zu -> cfg %d tail_rows %u S %u Kc %zu model %.1f us\n", M, N, K,
                 batch, p.cfg, p.tail_rows, p.S, p.Kc, p.t * 1e6);
+    return launch_plan(p, g, batch, vec);
+}
+
+int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec) {
+    const size_t M = g.M, N = g.n_store ? g.n_store : g.N, K = g.K;   // N: row length of C and of the partials
     if (p.tail_rows == 0) return launch_cfg(p.cfg, g, (unsigned)batch, vec);
     const TileCfg &T = kCfg[p.cfg];
     const size_t tm = (M + T.bm - 1) / T.bm;
@@ -832,7 +911,7 @@ int launch_planned(GemmArgs g, size_t batch, bool vec) {
     part.K = (unsigned)p.Kc;
     part.C = W;
     part.stride_a = p.Kc;
-    part.stride_b = p.Kc * N;
+    part.stride_b = p.Kc * g.ldb;
     part.stride_c = m2 * N;
     // chunks start at multiples of 16 floats: alignment of the bases is unchanged.  The remainder
     // chunk rides in the same launch as the last batch entry (K_last): as a launch of its own it
@@ -849,7 +928,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
         return np::fail(NP_ERR_INVALID, "np_sgemm: dimension too large");
     GemmArgs g;
     g.A = A; g.B = B; g.C = C;
-    g.M = (unsigned)M; g.N = (unsigned)N; g.K = (unsigned)K; g.K_last = 0;
+    g.M = (unsigned)M; g.N = (unsigned)N; g.K = (unsigned)K; g.K_last = 0; g.n_store = 0;
     g.lda = (unsigned)lda; g.ldb = (unsigned)N; g.ldc = (unsigned)N;
     g.stride_a = sa; g.stride_b = sb; g.stride_c = sc;
     g.tiles_m = g.tiles_n = 0;
@@ -896,8 +975,9 @@ int np_debug_sgemm_probe(void *dev_buf) {
 }
 
 int np_sgemm_set_variant(int variant) {
-    if (variant < 0) {   // -1: no split-K, -2: split-K back on (default)
+    if (variant < 0) {   // -1: whole-K plans only, -2: default planner, -3: default + forced operand padding
         g_splitk = variant != -1;
+        g_force_pad = variant == -3;
         return NP_OK;
     }
     g_variant = variant;

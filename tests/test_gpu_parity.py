@@ -484,3 +484,39 @@ def test_matmul_dma_edge_kernel(mnk, hip):
     ref64 = a.astype(np.float64) @ b.astype(np.float64)
     scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
     assert (np.abs(got - ref64) / scale).max() <= 1e-6
+
+
+@pytest.mark.parametrize("mnk", [(2049, 2051, 2053), (1000, 1000, 3001), (1537, 1538, 1540), (4097, 130, 4097),
+                                 (2100, 2102, 1001), (5, 3, 7), (300, 1, 100)])
+def test_matmul_padded_operands(mnk, hip):
+    """K % 16 != 0 / rows that are not 16-byte aligned: large products copy A and B once into
+    zero-padded aligned workspaces and run the LDS-DMA kernel (launch_padded, np_sgemm.hip); C is
+    written in place with its real row length.  fp64 bar + canary frame around C, and the same
+    product with the path off (variant -1: whole-K plans on the original operands) agrees."""
+    from numpower_amd import _lib
+    from numpower_amd import device as D
+    lib = _lib.load()
+    m, n, k = mnk
+    a = synth.uniform((m, k), 35, -1.0, 1.0)
+    b = synth.uniform((k, n), 36, -1.0, 1.0)
+    da, db = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b)
+    pad = 4096
+    frame = D.DeviceArray((m * n + 2 * pad,))
+    D.fill(frame, -777.0)
+    _lib.check(lib.np_sgemm_set_variant(-3))          # take the padded path whatever the model says
+    try:
+        _lib.check(lib.np_sgemm(m, n, k, da.ptr, db.ptr, frame.ptr + 4 * pad))
+    finally:
+        _lib.check(lib.np_sgemm_set_variant(-2))
+    host = frame.to_host().reshape(-1)
+    assert (host[:pad] == -777.0).all() and (host[pad + m * n:] == -777.0).all()
+    got = host[pad:pad + m * n].reshape(m, n)
+    ref64 = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(got - ref64) / scale).max() <= 1e-6
+    _lib.check(lib.np_sgemm_set_variant(-1))
+    try:
+        plain = D.sgemm(da, db).to_host()
+    finally:
+        _lib.check(lib.np_sgemm_set_variant(-2))
+    assert (np.abs(plain.astype(np.float64) - got) / scale).max() <= 2e-6
