@@ -748,6 +748,10 @@ int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
         g.tiles_m = (g.M + 255) / 256;
         g.tiles_n = (g.N + 127) / 128;
         const dim3 grid(g.tiles_m * g.tiles_n, 1, batch);
+        // XCD-aware tile order, bands of 4 tile rows: time-neutral at 4096^3 (the matrices sit in the
+        // 256 MiB Infinity Cache) but the workgroups of one XCD share panels in its L2, L2->fabric
+        // reads 944 -> 691 MB per launch (tools/gemm_swizzle_pmc.py, profiles/r01/gemm_swizzle_pmc.log)
+        if (g_variant == 0 && g.tiles_m >= 8) g.swizzle = 4;
         if (g.M % 256 || g.N % 128 || g.n_store)
             sgemm_dma_kernel<true><<<grid, 256, 0, np::stream()>>>(g);
         else

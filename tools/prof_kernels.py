@@ -22,10 +22,21 @@ row = D.DeviceArray.from_host(synth.uniform((4000,), 9)); col = D.DeviceArray.fr
 for _ in range(iters): D.binary("add", a, "full", row, "row", 25000, 4000, out=o)
 for _ in range(iters): D.binary("add", a, "full", col, "col", 25000, 4000, out=o)
 for _ in range(iters): D.reduce_all("sum", a)
+# fused chain exp(a)*b+2
+import ctypes as C
+from numpower_amd._lib import BINARY_OPS, UNARY_OPS, FusedOp, check, load
+lib = load()
+prog = (FusedOp * 3)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0), FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 1, N // 8 * 8),
+                     FusedOp(1, BINARY_OPS["add"], 2, 0, 0, 0, 0, 0))
+two = C.c_float(2.0)
+ptrs = (C.c_void_p * 3)(a.ptr, b.ptr, C.cast(C.pointer(two), C.c_void_p)); kinds = (C.c_int * 3)(0, 0, 4)
+for _ in range(iters): check(lib.np_fused_chain(ptrs, kinds, 3, prog, 3, o.ptr, 1, N))
 D.sync()
 a.free(); b.free(); o.free()
 X = D.DeviceArray((65536, 4096)); D.fill(X, 0.5); out = D.DeviceArray((4096,)); out1 = D.DeviceArray((65536,))
 for _ in range(iters): D.reduce_axis("sum", X, 0, out=out)
 for _ in range(iters): D.reduce_axis("sum", X, 1, out=out1)
+XT = D.DeviceArray((4096, 65536))
+for _ in range(iters): check(lib.np_transpose2d(X.ptr, XT.ptr, 1, 65536, 4096))
 D.sync()
 print("done")
