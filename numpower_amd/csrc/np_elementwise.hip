@@ -519,12 +519,21 @@ struct FusedArgs {
     size_t cols;                   // row length of the result; 0 when no operand is broadcast
     int first_prefetch_idx;
     int sink;                      // -1: store the chain value; NP_SUM / NP_PROD / NP_MIN / NP_MAX: reduce it
+    unsigned div_m, div_s1, div_s2;   // e / cols for 32-bit e without a division (see fast_div)
     FusedStep ops[FUSED_MAX_OPS];
 };
 // The kernel indexes ops[] with a run-time k.  On a by-value kernel parameter that makes the compiler
 // copy the whole struct to scratch (private memory) first; reading it through the kernarg segment
 // pointer (constant address space) keeps every descriptor fetch a scalar load.
 typedef const __attribute__((address_space(4))) FusedArgs *FusedArgsK;
+
+// Division of a 32-bit index by the (run-time, per-launch constant) row length as multiply-high +
+// shifts (Granlund-Montgomery round-up method): a plain u32 division is ~40 VALU instructions, which
+// is what made exp(X) + row VALU-bound.  q = (t + ((n - t) >> s1)) >> s2 with t = umulhi(m, n).
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned m, unsigned s1, unsigned s2) {
+    const unsigned t = __umulhi(m, n);
+    return (t + ((n - t) >> s1)) >> s2;
+}
 
 constexpr bool binary_has_quirk(int op) {
     return op == NP_MULTIPLY || op == NP_MOD || op == NP_EQUAL || op == NP_NOT_EQUAL;
@@ -663,6 +672,7 @@ __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out
     const float scalar0 = f->scalar0;
     const int first_prefetch_idx = f->first_prefetch_idx;
     const I cols = (I)f->cols;
+    const unsigned div_m = f->div_m, div_s1 = f->div_s1, div_s2 = f->div_s2;
     for (I base = 0; base < nslots; base += stride * U) {
         I first[U], row[U], col[U];
         bool live[U];
@@ -672,8 +682,11 @@ __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out
             live[u] = v < nslots;
             first[u] = elem0 + v * G;
             row[u] = col[u] = 0;
-            if (cols) {   // uniform: only chains with a broadcast operand pay for the division
-                row[u] = first[u] / cols;
+            if (cols) {   // uniform: only chains with a broadcast operand need (row, col)
+                if constexpr (sizeof(I) == 4)
+                    row[u] = (I)fast_div((unsigned)first[u], div_m, div_s1, div_s2);
+                else
+                    row[u] = first[u] / cols;
                 col[u] = first[u] - row[u] * cols;
             }
         }
@@ -808,6 +821,14 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     f.first_prefetch_idx = FUSED_IDX_FULL;
     f.cols = broadcast ? cols : 0;
     f.sink = sink;
+    f.div_m = f.div_s1 = f.div_s2 = 0;   // cols == 1: q = n
+    if (broadcast && cols > 1 && cols <= 0xffffffffull) {
+        unsigned l = 0;
+        while ((1ull << l) < cols) ++l;
+        f.div_m = (unsigned)((((1ull << 32) * ((1ull << l) - cols)) / cols) + 1);
+        f.div_s1 = 1;
+        f.div_s2 = l - 1;
+    }
     np::Scratch partials;
     float *result = out;
     unsigned reduce_blocks = 0;

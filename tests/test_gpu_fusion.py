@@ -146,3 +146,18 @@ def test_chain_ending_in_a_reduction(shape, hip):
         got = (ga.lazy() * NDArray.array(row).gpu()).sum()
         want = float((a * row[None, :]).astype(np.float64).sum())
         assert abs(got - want) <= 1e-5 * np.abs(a * row[None, :]).sum()
+
+
+@pytest.mark.parametrize("cols", [1, 2, 3, 4, 7, 8, 12, 100, 1000, 4000, 4096, 65536, 99991])
+def test_fused_broadcast_index_arithmetic(cols, hip):
+    """The fused kernel derives (row, col) of an element with a multiply-high division (fast_div):
+    every row length class — 1, powers of two, odd, prime, > 2^16 — against the op-by-op path."""
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    from numpower_amd.ndarray import NDArray
+    rows = max(2, min(2000, 3_000_000 // cols))
+    x = synth.uniform((rows, cols), 97, -1.0, 1.0)
+    r = synth.uniform((cols,), 98, -1.0, 1.0)
+    c = synth.uniform((rows, 1), 99, -1.0, 1.0)
+    gx, gr, gc = NDArray.array(x).gpu(), NDArray.array(r).gpu(), NDArray.array(c).gpu()
+    got = (gx.lazy() + gr - gc).eval().cpu().numpy()
+    assert np.array_equal(got, (x + r[None, :]) - c)
