@@ -74,6 +74,77 @@ __device__ __forceinline__ float binary_apply(float a, float b, bool body) {
     return 0.0f;
 }
 
+// log1p and the hyperbolic family: the device library's versions are 3-4x too slow to stay under
+// the HBM roofline (tools/op_sweep.py: log1pf 2.5, sinhf 2.3, asinhf 1.9 TB/s against 6.4 for expf).
+// These are a handful of VALU instructions around expf / logf / sqrtf, accurate to a few ulp over
+// the whole fp32 range (tests/test_gpu_parity.py::test_fast_hyperbolic_accuracy holds them to 2e-6
+// relative against fp64 and to the 1e-5 bar against the oracle's glibc), with glibc's results at
+// +-0, +-inf, NaN and the domain edges.
+// BOUNDED: the caller guarantees 0 <= x < 2^30, so (1+x)-1 is 0 or lies in [2^-24, 2^30] and
+// v_rcp_f32 (1 ulp, no denormal/overflow corner) can replace the IEEE division.
+template <bool BOUNDED = false>
+__device__ __forceinline__ float fast_log1p(float x) {
+    // log(1+x) * x / ((1+x) - 1): the quotient cancels the rounding error of 1+x (Kahan)
+    const float u = 1.0f + x;
+    const float d = u - 1.0f;
+    const float q = BOUNDED ? x * __builtin_amdgcn_rcpf(d) : x / d;
+    float r = (d == 0.0f) ? x : logf(u) * q;   // tiny x (and -0.0) return x itself
+    if (u == INFINITY) r = INFINITY;
+    return r;   // x = -1 -> -inf, x < -1 -> NaN (logf of a negative), NaN -> NaN
+}
+
+__device__ __forceinline__ float fast_sinh(float x) {
+    const float a = fabsf(x);
+    float r;
+    if (a < 0.5f) {          // odd Taylor polynomial: e^a - e^-a would cancel
+        const float a2 = a * a;
+        r = a + a * a2 * (1.0f / 6 + a2 * (1.0f / 120 + a2 * (1.0f / 5040 + a2 * (1.0f / 362880))));
+    } else if (a < 88.0f) {
+        const float e = expf(a);
+        r = 0.5f * e - 0.5f / e;
+    } else {                 // e^a overflows before sinh does (89.416): e^(a/2) * e^(a/2) / 2
+        const float h = expf(0.5f * a);
+        r = (0.5f * h) * h;
+    }
+    return copysignf(r, x);
+}
+
+__device__ __forceinline__ float fast_cosh(float x) {
+    const float a = fabsf(x);
+    if (a < 88.0f) {
+        const float e = expf(a);
+        return 0.5f * e + 0.5f / e;
+    }
+    const float h = expf(0.5f * a);
+    return (0.5f * h) * h;
+}
+
+__device__ __forceinline__ float fast_asinh(float x) {
+    const float a = fabsf(x);
+    float r;
+    if (a > 268435456.0f) {  // 2^28: sqrt(a^2 + 1) == a in fp32 (and a^2 overflows later): log(2a)
+        r = logf(a) + 0.69314718f;
+    } else {                 // log1p(a + a^2 / (1 + sqrt(a^2 + 1))): no cancellation for small a
+        const float a2 = a * a;
+        // the denominator lies in [2, 2^28]: v_rcp_f32 (1 ulp) instead of a full IEEE division
+        r = fast_log1p<true>(a + a2 * __builtin_amdgcn_rcpf(1.0f + sqrtf(a2 + 1.0f)));
+    }
+    return copysignf(r, x);
+}
+
+__device__ __forceinline__ float fast_acosh(float x) {
+    if (x < 1.0f) return NAN;
+    if (x > 268435456.0f) return logf(x) + 0.69314718f;
+    const float t = x - 1.0f;   // exact
+    return fast_log1p<true>(t + sqrtf(2.0f * t + t * t));
+}
+
+__device__ __forceinline__ float fast_atanh(float x) {
+    const float a = fabsf(x);
+    // |x| = 1 -> 2/0 = inf -> inf; |x| > 1 -> log1p of something < -1 -> NaN
+    return copysignf(0.5f * fast_log1p<false>((2.0f * a) / (1.0f - a)), x);
+}
+
 template <int OP>
 __device__ __forceinline__ float unary_apply(float x, float p0, float p1) {
     if constexpr (OP == NP_ABS) return fabsf(x);
@@ -86,7 +157,7 @@ __device__ __forceinline__ float unary_apply(float x, float p0, float p1) {
     if constexpr (OP == NP_LOG) return logf(x);
     if constexpr (OP == NP_LOG2) return log2f(x);
     if constexpr (OP == NP_LOG10) return log10f(x);
-    if constexpr (OP == NP_LOG1P) return log1pf(x);
+    if constexpr (OP == NP_LOG1P) return fast_log1p<false>(x);
     if constexpr (OP == NP_LOGB) return logbf(x);
     if constexpr (OP == NP_SIN) return sinf(x);
     if constexpr (OP == NP_COS) return cosf(x);
@@ -97,12 +168,12 @@ __device__ __forceinline__ float unary_apply(float x, float p0, float p1) {
     // double_math.c:156-162: the constant is built in double from pi ~ 3.1415926535
     if constexpr (OP == NP_DEGREES) return (float)((double)x * (180.0 / 3.1415926535));
     if constexpr (OP == NP_RADIANS) return (float)((double)x * (3.1415926535 / 180.0));
-    if constexpr (OP == NP_SINH) return sinhf(x);
-    if constexpr (OP == NP_COSH) return coshf(x);
+    if constexpr (OP == NP_SINH) return fast_sinh(x);
+    if constexpr (OP == NP_COSH) return fast_cosh(x);
     if constexpr (OP == NP_TANH) return tanhf(x);
-    if constexpr (OP == NP_ARCSINH) return asinhf(x);
-    if constexpr (OP == NP_ARCCOSH) return acoshf(x);
-    if constexpr (OP == NP_ARCTANH) return atanhf(x);
+    if constexpr (OP == NP_ARCSINH) return fast_asinh(x);
+    if constexpr (OP == NP_ARCCOSH) return fast_acosh(x);
+    if constexpr (OP == NP_ARCTANH) return fast_atanh(x);
     // double_math.c:200-210: the post-adjust can never fire (rounded - floor is 0 or 1), so
     // float_rint is rintf: round half to even.
     if constexpr (OP == NP_RINT) return rintf(x);

@@ -520,3 +520,59 @@ def test_matmul_padded_operands(mnk, hip):
     finally:
         _lib.check(lib.np_sgemm_set_variant(-2))
     assert (np.abs(plain.astype(np.float64) - got) / scale).max() <= 2e-6
+
+
+def _log_sweep(lo, hi, n, seed):
+    """n values log-uniform in [lo, hi]."""
+    u = synth.uniform((n,), seed, 0.0, 1.0).astype(np.float64)
+    return np.exp(np.log(lo) + u * (np.log(hi) - np.log(lo))).astype(np.float32)
+
+
+@pytest.mark.parametrize("op", ["log1p", "sinh", "cosh", "arcsinh", "arccosh", "arctanh"])
+def test_fast_hyperbolic_accuracy(op, hip, oracle):
+    """log1p and the hyperbolic family are hand-written around expf / logf / sqrtf (the device
+    library's versions are VALU-bound at a third of the HBM roofline): whole-range accuracy against
+    fp64 (a few ulp: 2e-6 relative) and against the oracle's glibc (the 1e-5 bar), and glibc's
+    results at the special values."""
+    from numpower_amd.ndarray import NDArray
+    f64 = {"log1p": np.log1p, "sinh": np.sinh, "cosh": np.cosh, "arcsinh": np.arcsinh, "arccosh": np.arccosh,
+           "arctanh": np.arctanh}[op]
+    n = 200_000
+    if op == "log1p":
+        parts = [_log_sweep(1e-38, 1e-6, n, 1), _log_sweep(1e-6, 1.0, n, 2), _log_sweep(1.0, 3e38, n, 3),
+                 -_log_sweep(1e-38, 1e-3, n, 4), -_log_sweep(1e-3, 0.999999, n, 5)]
+    elif op in ("sinh", "cosh"):
+        pos = [_log_sweep(1e-38, 1e-3, n, 1), _log_sweep(1e-3, 0.5, n, 2), _log_sweep(0.5, 88.0, n, 3),
+               synth.uniform((n,), 4, 88.0, 89.4), synth.uniform((n,), 5, 0.49, 0.51)]
+        parts = pos + [-p for p in pos]
+    elif op == "arcsinh":
+        pos = [_log_sweep(1e-38, 1e-3, n, 1), _log_sweep(1e-3, 10.0, n, 2), _log_sweep(10.0, 3e8, n, 3),
+               _log_sweep(2e8, 3e38, n, 4)]
+        parts = pos + [-p for p in pos]
+    elif op == "arccosh":
+        parts = [np.float32(1.0) + _log_sweep(1e-7, 1.0, n, 1), _log_sweep(2.0, 3e8, n, 2), _log_sweep(2e8, 3e38, n, 3)]
+    else:
+        pos = [_log_sweep(1e-38, 1e-3, n, 1), _log_sweep(1e-3, 0.9, n, 2), np.float32(1.0) - _log_sweep(6e-8, 0.1, n, 3)]
+        parts = pos + [-p for p in pos]
+    x = np.concatenate(parts).astype(np.float32)
+    got = NDArray._unary(op, NDArray.array(x).gpu()).cpu().numpy().astype(np.float64)
+    with np.errstate(all="ignore"):
+        want = f64(x.astype(np.float64))
+    finite = np.isfinite(want) & (np.abs(want) < 3.4e38)
+    rel = np.abs(got[finite] - want[finite]) / np.maximum(np.abs(want[finite]), 1e-300)
+    assert rel.max() <= 2e-6, "%s: max rel err vs fp64 %.3g at x = %r" % (op, rel.max(), x[finite][rel.argmax()])
+    ref = oracle.unary(op, x).astype(np.float64)
+    ok = np.isfinite(ref)
+    rel = np.abs(got[ok] - ref[ok]) / np.maximum(np.abs(ref[ok]), 1e-300)
+    assert rel.max() <= 1e-5
+    assert (np.isinf(ref) == np.isinf(got)).all()          # overflow to inf happens at the same inputs
+    # special values: exactly glibc's answers (sign of zero included; NaN where glibc says NaN)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 0.5, -0.5, 2.0, -2.0, 89.5, -89.5,
+                   3.4e38, -3.4e38, 0.99999994, -0.99999994, 1.0000001], dtype=np.float32)
+    g = NDArray._unary(op, NDArray.array(sp).gpu()).cpu().numpy()
+    r = oracle.unary(op, sp)
+    assert (np.isnan(g) == np.isnan(r)).all(), (op, sp[np.isnan(g) != np.isnan(r)])
+    m = ~np.isnan(r)
+    assert (np.isinf(g[m]) == np.isinf(r[m])).all() and (np.signbit(g[m]) == np.signbit(r[m])).all()
+    fin = m & np.isfinite(r)
+    assert np.allclose(g[fin], r[fin], rtol=1e-5, atol=0.0)
