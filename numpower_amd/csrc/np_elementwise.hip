@@ -651,6 +651,8 @@ constexpr bool fused_light_unary(int op) {
             return false;
     }
 }
+// (adding the hand-written log1p / hyperbolic ops here cost the exp -> multiply -> add chain 3-5 %,
+// adding expm1 / tanh / arc* 10 %: the set stays minimal)
 constexpr bool fused_light_binary(int op) { return op != NP_MOD && op != NP_POW && op != NP_ARCTAN2; }
 
 template <int N, bool LIGHT>
