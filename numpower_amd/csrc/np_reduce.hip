@@ -422,24 +422,87 @@ __global__ __launch_bounds__(256) void reduce_axis_cols(const float *__restrict_
 // axis reduction, generic: one thread per output element, sequential over the axis.
 // Used for ragged inner sizes (inner % 4 != 0, misaligned views) and tiny problems.
 // ------------------------------------------------------------------------------------------
+// The axis may be cut into `chunks` pieces of `chunk_len` rows (out[outer][chunks][inner], a later
+// pass folds the chunks): with few outputs and a long axis that is what puts enough threads on the
+// machine.  The epilogue (MEAN division, PROD zero sign) runs only when chunks == 1.
 template <int OP, typename I>
 __global__ __launch_bounds__(256) void reduce_axis_generic(const float *__restrict__ in,
                                                            float *__restrict__ out, I outer,
                                                            I axis_len, I inner, float mean_div,
-                                                           int prod_quirk, I body_end) {
-    const I total = outer * inner;
+                                                           int prod_quirk, I body_end, I chunks,
+                                                           I chunk_len) {
+    const I total = outer * chunks * inner;
     const I stride = (I)gridDim.x * blockDim.x;
     for (I idx = (I)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const I o = idx / inner, j = idx % inner;
+        const I oc = idx / inner, j = idx - oc * inner;
+        const I o = oc / chunks, c = oc - o * chunks;
+        const I a0 = c * chunk_len;
+        I a1 = a0 + chunk_len;
+        if (a1 > axis_len) a1 = axis_len;
         const float *p = in + (size_t)o * axis_len * inner + j;
         float r = r_identity<OP>();
-        if (axis_len > 0) r = p[0];
-        for (I a = 1; a < axis_len; ++a) r = r_combine<OP>(r, p[(size_t)a * inner]);
-        if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, mean_div);
-        if constexpr (OP == NP_PROD) {
-            if (prod_quirk && r == 0.0f) r = (j < body_end) ? -0.0f : 0.0f;
+        I a = a0;
+        if (a < a1) r = p[(size_t)a++ * inner];
+        // 4 independent loads in flight per thread
+        float r1 = r_identity<OP>(), r2 = r1, r3 = r1;
+        for (; a + 3 < a1; a += 4) {
+            const float x0 = p[(size_t)a * inner], x1 = p[(size_t)(a + 1) * inner];
+            const float x2 = p[(size_t)(a + 2) * inner], x3 = p[(size_t)(a + 3) * inner];
+            r = r_combine<OP>(r, x0);
+            r1 = r_combine<OP>(r1, x1);
+            r2 = r_combine<OP>(r2, x2);
+            r3 = r_combine<OP>(r3, x3);
+        }
+        for (; a < a1; ++a) r = r_combine<OP>(r, p[(size_t)a * inner]);
+        r = r_combine<OP>(r_combine<OP>(r, r1), r_combine<OP>(r2, r3));
+        if (chunks == 1) {
+            if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, mean_div);
+            if constexpr (OP == NP_PROD) {
+                if (prod_quirk && r == 0.0f) r = (j < body_end) ? -0.0f : 0.0f;
+            }
         }
         out[idx] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// axis reduction, small inner (2..64 columns: column sums of an N x 3 point cloud): the generic
+// kernel would give each of the few columns ONE thread.  Here a workgroup reads its slab of rows as
+// flat memory (coalesced dword loads); with T = (256 / inner) * inner active threads and a stride
+// of T the column of a thread never changes (t % inner), so it accumulates in a register; LDS folds
+// the T / inner partials of each column.  out[outer][blocks][inner].
+// ------------------------------------------------------------------------------------------
+template <int OP, typename I>
+__global__ __launch_bounds__(256) void reduce_small_inner(const float *__restrict__ in,
+                                                          float *__restrict__ out, I axis_len,
+                                                          I inner, I rows_per_block) {
+    __shared__ float lds[256];
+    const unsigned T = (256u / (unsigned)inner) * (unsigned)inner;
+    const I o = blockIdx.y, b = blockIdx.x;
+    const I r0 = b * rows_per_block;
+    I r1 = r0 + rows_per_block;
+    if (r1 > axis_len) r1 = axis_len;
+    const size_t cnt = (size_t)(r1 - r0) * inner;
+    const float *p = in + ((size_t)o * axis_len + r0) * inner;
+    const float id = r_identity<OP>();
+    float a0 = id, a1 = id, a2 = id, a3 = id;
+    if (threadIdx.x < T) {
+        size_t e = threadIdx.x;
+        for (; e + 3 * (size_t)T < cnt; e += 4 * (size_t)T) {
+            const float x0 = p[e], x1 = p[e + T], x2 = p[e + 2 * (size_t)T], x3 = p[e + 3 * (size_t)T];
+            a0 = r_combine<OP>(a0, x0);
+            a1 = r_combine<OP>(a1, x1);
+            a2 = r_combine<OP>(a2, x2);
+            a3 = r_combine<OP>(a3, x3);
+        }
+        for (; e < cnt; e += T) a0 = r_combine<OP>(a0, p[e]);
+    }
+    lds[threadIdx.x] = r_combine<OP>(r_combine<OP>(a0, a1), r_combine<OP>(a2, a3));
+    __syncthreads();
+    if (threadIdx.x < (unsigned)inner) {
+        float r = lds[threadIdx.x];
+        for (unsigned k = threadIdx.x + (unsigned)inner; k < T; k += (unsigned)inner) r = r_combine<OP>(r, lds[k]);
+        out[((size_t)o * gridDim.x + b) * inner + threadIdx.x] = r;
     }
 }
 
@@ -450,7 +513,7 @@ __global__ __launch_bounds__(256) void reduce_axis_generic(const float *__restri
 template <int OP, typename I>
 __global__ __launch_bounds__(256) void reduce_rows_wave(const float *__restrict__ in,
                                                         float *__restrict__ out, I rows, I len,
-                                                        float mean_div) {
+                                                        float mean_div, int prod_quirk) {
     const int lane = threadIdx.x & 63;
     const I row = (I)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -474,17 +537,26 @@ __global__ __launch_bounds__(256) void reduce_rows_wave(const float *__restrict_
     r = wave_reduce<OP>(r);
     if (lane == 0) {
         if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, mean_div);
+        // inner == 1: the reference multiplies one-element slices, i.e. always in the scalar tail,
+        // which turns a zero product of either sign into +0.0 (arithmetics.c:410-412)
+        if constexpr (OP == NP_PROD) {
+            if (prod_quirk && r == 0.0f) r = 0.0f;
+        }
         out[row] = r;
     }
 }
 
+// blockIdx.y = chunk of the row (chunks > 1: few rows, long rows — out[row][chunk], a later pass
+// folds the chunks; the MEAN division then happens there).
 template <int OP, typename I>
 __global__ __launch_bounds__(256) void reduce_rows_block(const float *__restrict__ in,
-                                                         float *__restrict__ out, I rows, I len,
-                                                         float mean_div) {
+                                                         float *__restrict__ out, I rows, I row_len,
+                                                         float mean_div, I chunk_len, int prod_quirk) {
     __shared__ float lds4[4];
-    const I row = blockIdx.x;
-    const float *p = in + (size_t)row * len;
+    const I row = blockIdx.x, chunk = blockIdx.y;
+    const I c0 = chunk * chunk_len;
+    const I len = (row_len - c0 < chunk_len) ? row_len - c0 : chunk_len;
+    const float *p = in + (size_t)row * row_len + c0;
     const float id = r_identity<OP>();
     float r = id;
     I head = (I)(((16 - ((uintptr_t)p & 15u)) & 15u) / 4);
@@ -514,7 +586,10 @@ __global__ __launch_bounds__(256) void reduce_rows_block(const float *__restrict
     r = block_reduce<OP>(r, lds4);
     if (threadIdx.x == 0) {
         if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, mean_div);
-        out[row] = r;
+        if constexpr (OP == NP_PROD) {
+            if (prod_quirk && r == 0.0f) r = 0.0f;   // see reduce_rows_wave
+        }
+        out[(size_t)row * gridDim.y + chunk] = r;
     }
 }
 
@@ -566,30 +641,55 @@ size_t choose_splits(size_t outer, size_t axis_len, size_t inner4) {
     return s < 1 ? 1 : s;
 }
 
+// mean_div_override != 0: this call folds the partials of an earlier pass — MEAN divides by the
+// original axis length, not by the number of partials.
 template <int OP, typename I>
 int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t inner, float *out,
-                       unsigned flags) {
+                       unsigned flags, float mean_div_override = 0.0f) {
     hipStream_t s = np::stream();
-    const float mean_div = (float)(long)axis_len;   // CreateFromLongScalar, numpower.c:2666
+    const float mean_div = mean_div_override != 0.0f ? mean_div_override
+                                                      : (float)(long)axis_len;   // CreateFromLongScalar, numpower.c:2666
     const int quirk = (OP == NP_PROD && (flags & NP_QUIRK_AVX_BODY) && axis_len > 1) ? 1 : 0;
     const size_t body_end = np_avx_body_end(inner);
+    constexpr int P1 = (OP == NP_MEAN) ? NP_SUM : OP;   // what a non-final pass computes
+    const size_t target_wg = (size_t)np::num_cus() * 8;
 
     if (inner == 1) {
         // contiguous rows
         if (axis_len >= 4096) {
             if (outer > 0x7fffffffu)
                 return np::fail(NP_ERR_INVALID, "np_reduce_axis: too many rows for row reduce");
-            reduce_rows_block<OP, I><<<(unsigned)outer, 256, 0, s>>>(in, out, (I)outer, (I)axis_len,
-                                                                  mean_div);
-            NP_LAUNCH_CHECK("reduce_rows_block");
-            return NP_OK;
+            // few long rows (a (3, 30M) array, a column vector): cut each row into chunks so that
+            // the grid still fills the chip, then fold the chunks
+            size_t chunks = 1;
+            if (outer < target_wg) {
+                chunks = (target_wg + outer - 1) / outer;
+                const size_t max_chunks = axis_len / 2048;
+                if (chunks > max_chunks) chunks = max_chunks;
+                if (chunks > 65535) chunks = 65535;
+                if (chunks < 1) chunks = 1;
+            }
+            if (chunks == 1) {
+                reduce_rows_block<OP, I><<<(unsigned)outer, 256, 0, s>>>(in, out, (I)outer, (I)axis_len,
+                                                                      mean_div, (I)axis_len, quirk);
+                NP_LAUNCH_CHECK("reduce_rows_block");
+                return NP_OK;
+            }
+            const size_t chunk_len = ((axis_len + chunks - 1) / chunks + 3) / 4 * 4;
+            chunks = (axis_len + chunk_len - 1) / chunk_len;
+            np::Scratch partials;
+            if (int rc = partials.alloc(outer * chunks * sizeof(float))) return rc;
+            reduce_rows_block<P1, I><<<dim3((unsigned)outer, (unsigned)chunks), 256, 0, s>>>(
+                in, (float *)partials.ptr, (I)outer, (I)axis_len, 1.0f, (I)chunk_len, 0);
+            NP_LAUNCH_CHECK("reduce_rows_block(chunks)");
+            return launch_reduce_axis<OP, I>((const float *)partials.ptr, outer, chunks, 1, out, flags, mean_div);
         }
         if (axis_len >= 32) {
             const size_t blocks = (outer + 3) / 4;
             if (blocks > 0x7fffffffu)
                 return np::fail(NP_ERR_INVALID, "np_reduce_axis: too many rows for row reduce");
             reduce_rows_wave<OP, I><<<(unsigned)blocks, 256, 0, s>>>(in, out, (I)outer, (I)axis_len,
-                                                                  mean_div);
+                                                                  mean_div, quirk);
             NP_LAUNCH_CHECK("reduce_rows_wave");
             return NP_OK;
         }
@@ -616,18 +716,54 @@ int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t in
                                                          quirk, (I)body_end);
         NP_LAUNCH_CHECK("reduce_axis_cols(pass 2)");
         return NP_OK;
+    } else if (inner <= 64 && axis_len >= 512 && outer <= 65535 && outer * inner < target_wg * 64) {
+        // a handful of columns, many rows: flat coalesced slabs, then fold the per-slab partials
+        size_t blocks = target_wg / outer;
+        const size_t max_blocks = axis_len / 256;
+        if (blocks > max_blocks) blocks = max_blocks;
+        if (blocks < 1) blocks = 1;
+        const size_t rows_per_block = (axis_len + blocks - 1) / blocks;
+        blocks = (axis_len + rows_per_block - 1) / rows_per_block;
+        np::Scratch partials;
+        if (int rc = partials.alloc(outer * blocks * inner * sizeof(float))) return rc;
+        reduce_small_inner<P1, I><<<dim3((unsigned)blocks, (unsigned)outer), 256, 0, s>>>(
+            in, (float *)partials.ptr, (I)axis_len, (I)inner, (I)rows_per_block);
+        NP_LAUNCH_CHECK("reduce_small_inner");
+        return launch_reduce_axis<OP, I>((const float *)partials.ptr, outer, blocks, inner, out, flags, mean_div);
     }
-    // generic fallback
-    const size_t total = outer * inner;
+    // generic fallback (ragged inner, misaligned views, tiny problems): one thread per output and
+    // axis chunk; chunk the axis when the outputs alone cannot fill the machine
+    const size_t outputs = outer * inner;
+    const size_t target_threads = (size_t)np::num_cus() * 2048;
+    size_t chunks = 1;
+    if (outputs < target_threads && axis_len >= 128) {
+        chunks = (target_threads + outputs - 1) / outputs;
+        const size_t max_chunks = axis_len / 32;
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks < 1) chunks = 1;
+    }
+    const size_t chunk_len = (axis_len + chunks - 1) / chunks;
+    chunks = chunk_len ? (axis_len + chunk_len - 1) / chunk_len : 1;
+    if (chunks < 1) chunks = 1;
+    const size_t total = outputs * chunks;
     size_t blocks = (total + 255) / 256;
     const size_t cap = (size_t)np::num_cus() * 16;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    reduce_axis_generic<OP, I><<<(unsigned)blocks, 256, 0, s>>>(in, out, (I)outer, (I)axis_len,
-                                                             (I)inner, mean_div, quirk,
-                                                             (I)body_end);
-    NP_LAUNCH_CHECK("reduce_axis_generic");
-    return NP_OK;
+    if (chunks == 1) {
+        reduce_axis_generic<OP, I><<<(unsigned)blocks, 256, 0, s>>>(in, out, (I)outer, (I)axis_len,
+                                                                 (I)inner, mean_div, quirk,
+                                                                 (I)body_end, (I)1, (I)axis_len);
+        NP_LAUNCH_CHECK("reduce_axis_generic");
+        return NP_OK;
+    }
+    np::Scratch partials;
+    if (int rc = partials.alloc(total * sizeof(float))) return rc;
+    reduce_axis_generic<P1, I><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (I)outer,
+                                                             (I)axis_len, (I)inner, 1.0f, 0, (I)0,
+                                                             (I)chunks, (I)chunk_len);
+    NP_LAUNCH_CHECK("reduce_axis_generic(chunks)");
+    return launch_reduce_axis<OP, I>((const float *)partials.ptr, outer, chunks, inner, out, flags, mean_div);
 }
 
 template <int OP>

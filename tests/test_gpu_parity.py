@@ -576,3 +576,38 @@ def test_fast_hyperbolic_accuracy(op, hip, oracle):
     assert (np.isinf(g[m]) == np.isinf(r[m])).all() and (np.signbit(g[m]) == np.signbit(r[m])).all()
     fin = m & np.isfinite(r)
     assert np.allclose(g[fin], r[fin], rtol=1e-5, atol=0.0)
+
+
+@pytest.mark.parametrize("shape,axis", [((3, 300_000), 1), ((300_000, 3), 0), ((1_000_003, 1), 0), ((1, 1_000_003), 1),
+                                        ((5, 70_000, 3), 1), ((2, 40_000, 17), 1), ((1001, 1003), 0), ((4001, 250), 0),
+                                        ((9, 20_011), 1), ((200_000, 2), 0), ((64, 5000, 64), 1), ((7, 600, 1), 1)])
+def test_axis_reduce_few_outputs_long_axis(shape, axis, hip, oracle):
+    """Shapes where the outputs alone cannot fill the machine — a few long rows, column sums of an
+    N x 3 array, ragged inner sizes: the axis is cut into chunks / flat slabs (reduce_rows_block
+    chunks, reduce_small_inner, chunked reduce_axis_generic in np_reduce.hip) and the partials are
+    folded by a second pass.  sum / mean vs fp64, min / max exact, prod's zero-sign quirk vs the
+    oracle."""
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform(shape, 41, -1.0, 1.0)
+    gx = NDArray.array(x).gpu()
+    ref64 = x.astype(np.float64).sum(axis)
+    scale = np.abs(x).astype(np.float64).sum(axis)
+
+    def host(v):
+        return v.cpu().numpy() if not isinstance(v, float) else np.float32(v)
+    got = host(NDArray.sum(gx, axis))
+    assert got.shape == ref64.shape
+    assert (np.abs(got - ref64) <= 1e-5 * scale).all()
+    gm = host(NDArray.mean(gx, axis))
+    assert (np.abs(gm - ref64 / shape[axis]) <= 1e-5 * scale / shape[axis]).all()
+    assert_bit_equal(host(NDArray.max(gx, axis)), x.max(axis), "max")
+    assert_bit_equal(host(NDArray.min(gx, axis)), x.min(axis), "min")
+    # prod: values whose products are exact, zeros of both signs
+    rng = np.random.default_rng(5)
+    p = rng.choice(np.array([1.0, -1.0, 1.0, 1.0], dtype=np.float32), size=shape)
+    p.reshape(-1)[::997] = 0.0
+    p.reshape(-1)[5::1009] = -0.0
+    small = tuple(min(s, 3000) if i == axis else s for i, s in enumerate(shape))   # oracle's slice-by-slice reduce() is slow
+    p = np.ascontiguousarray(p[tuple(slice(0, s) for s in small)])
+    got = host(NDArray.prod(NDArray.array(p).gpu(), axis))
+    assert_bit_equal(got, oracle.reduce_axis("prod", p, axis), "prod")
