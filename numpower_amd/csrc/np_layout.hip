@@ -15,6 +15,9 @@
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+// a float4 that is only 4-byte aligned: global_load/store_dwordx4 take dword-aligned addresses, which
+// is all a row of odd length offers
+struct __attribute__((packed, aligned(4))) U4 { v4f v; };
 
 // in: [batch][rows][cols] -> out: [batch][cols][rows].  TILE x TILE floats per workgroup; the LDS
 // tile is padded to TILE+1 floats per row.  Global reads and writes are float4 per lane along
@@ -22,7 +25,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <int TILE, bool VEC>
 __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__restrict__ in,
                                                              float *__restrict__ out, unsigned rows,
-                                                             unsigned cols) {
+                                                             unsigned cols, unsigned tiles_x,
+                                                             unsigned tiles_y) {
     constexpr int LDT = TILE + 1;
     constexpr int C4 = TILE / 4;     // float4 columns per tile row
     constexpr int RPP = 256 / C4;    // tile rows covered per pass of the 256 threads
@@ -34,8 +38,10 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
     // diagonal tile order: workgroups that run at the same time (consecutive blockIdx.x) read
     // neighbouring column blocks AND write different column offsets of the output, instead of all
     // writing segments a power-of-two stride apart (HBM channel camping on 8192 x 8192 etc.)
-    const unsigned by = (blockIdx.y + blockIdx.x) % gridDim.y;
-    const unsigned r0 = by * TILE, c0 = blockIdx.x * TILE;
+    // (the grid is linear in x: a 10^7 x 3 matrix has more tile rows than gridDim.y allows)
+    const unsigned bx = blockIdx.x % tiles_x;
+    const unsigned by = (blockIdx.x / tiles_x + bx) % tiles_y;
+    const unsigned r0 = by * TILE, c0 = bx * TILE;
     const unsigned tx4 = threadIdx.x % C4, ty = threadIdx.x / C4;
 
     // load: rows of the input tile; all PASSES loads are issued before the first LDS store
@@ -46,6 +52,8 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
         v[j] = v4f{0, 0, 0, 0};
         if constexpr (VEC) {
             if (r < rows && c < cols) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)r * cols + c));
+        } else if (r < rows && c + 3 < cols) {
+            v[j] = ((const U4 *)(src + (size_t)r * cols + c))->v;
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -67,10 +75,35 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
         for (int k = 0; k < 4; ++k) w[k] = tile[oc * LDT + 4 * tx4 + k];
         if constexpr (VEC) {
             if (orow < cols && ocol < rows) __builtin_nontemporal_store(w, (v4f *)(dst + (size_t)orow * rows + ocol));
+        } else if (orow < cols && ocol + 3 < rows) {
+            ((U4 *)(dst + (size_t)orow * rows + ocol))->v = w;
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (orow < cols && ocol + k < rows) dst[(size_t)orow * rows + ocol + k] = w[k];
+        }
+    }
+}
+
+// Skinny matrices (one side <= 16): a 64 x 64 tile would be >= 75 % padding.  One thread per LONG-side
+// index walks the short side: TALL (rows long): reads row r's `cols` floats, writes out[c][r]
+// (coalesced per c); !TALL (cols long): reads in[r][c] (coalesced per r), writes the `rows` floats of
+// out[c][.].  The strided side touches each cache line from consecutive instructions of the same
+// wave, so it is served from the vector L1.
+template <bool TALL>
+__global__ __launch_bounds__(256) void transpose_skinny_kernel(const float *__restrict__ in,
+                                                               float *__restrict__ out, size_t rows,
+                                                               size_t cols) {
+    const size_t plane = rows * cols;
+    const float *src = in + (size_t)blockIdx.y * plane;
+    float *dst = out + (size_t)blockIdx.y * plane;
+    const size_t n_long = TALL ? rows : cols, n_short = TALL ? cols : rows;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_long; i += (size_t)gridDim.x * blockDim.x) {
+        for (size_t k = 0; k < n_short; ++k) {
+            if (TALL)
+                dst[k * rows + i] = src[i * cols + k];
+            else
+                dst[i * rows + k] = src[k * cols + i];
         }
     }
 }
@@ -102,19 +135,69 @@ __global__ __launch_bounds__(256) void permute_gather_kernel(const float *__rest
     }
 }
 
+// General permutation whose output-fastest axis is NOT the input-fastest axis (the default
+// transpose() of a 3-D array reverses all axes): the gather kernel above would read with a large
+// stride per lane (0.4-0.5 TB/s).  Here the plane spanned by the input axis that becomes
+// output-fastest (A) and the input-fastest axis (B) goes through a 64 x 64 LDS tile — reads run
+// along B, writes along A, both coalesced — and every other axis is a batch index.
+struct TiledPermuteArgs {
+    unsigned A, B;                  // extents of the two plane axes
+    size_t a_in, b_out;             // input stride of A (B's is 1), output stride of B (A's is 1)
+    unsigned nbatch;                // number of batch axes
+    unsigned bshape[MAX_ND];
+    size_t bin[MAX_ND], bout[MAX_ND];
+    unsigned tiles_a, tiles_b;
+};
+
+__global__ __launch_bounds__(256) void permute_tiled_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                            TiledPermuteArgs p) {
+    __shared__ float tile[64][65];
+    unsigned id = blockIdx.x;
+    const unsigned tb = id % p.tiles_b;
+    id /= p.tiles_b;
+    const unsigned ta = id % p.tiles_a;
+    unsigned batch = id / p.tiles_a;
+    size_t off_in = 0, off_out = 0;
+#pragma unroll
+    for (int d = MAX_ND - 1; d >= 0; --d) {
+        if (d < (int)p.nbatch) {
+            const unsigned q = batch / p.bshape[d], r = batch - q * p.bshape[d];
+            off_in += (size_t)r * p.bin[d];
+            off_out += (size_t)r * p.bout[d];
+            batch = q;
+        }
+    }
+    const unsigned a0 = ta * 64, b0 = tb * 64;
+    const unsigned tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const unsigned a = a0 + ty + 4 * j, b = b0 + tx;
+        if (a < p.A && b < p.B) tile[ty + 4 * j][tx] = in[off_in + (size_t)a * p.a_in + b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const unsigned b = b0 + ty + 4 * j, a = a0 + tx;
+        if (a < p.A && b < p.B) out[off_out + (size_t)b * p.b_out + a] = tile[tx][ty + 4 * j];
+    }
+}
+
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 int g_tile = 0;   // 0 = default, else 64 / 128 (np_layout_set_variant)
 
 template <int TILE>
 int launch_transpose(const float *in, float *out, size_t batch, size_t rows, size_t cols, bool vec) {
-    const dim3 grid((unsigned)((cols + TILE - 1) / TILE), (unsigned)((rows + TILE - 1) / TILE), (unsigned)batch);
-    if (grid.y > 65535) return np::fail(NP_ERR_INVALID, "np_transpose2d: too many row tiles");
+    const size_t tiles_x = (cols + TILE - 1) / TILE, tiles_y = (rows + TILE - 1) / TILE;
+    if (tiles_x * tiles_y > 0x7fffffffu) return np::fail(NP_ERR_INVALID, "np_transpose2d: too many tiles");
+    const dim3 grid((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch);
     const size_t lds = (size_t)TILE * (TILE + 1) * sizeof(float);
     if (vec)
-        transpose_tile_kernel<TILE, true><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols);
+        transpose_tile_kernel<TILE, true><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols,
+                                                                           (unsigned)tiles_x, (unsigned)tiles_y);
     else
-        transpose_tile_kernel<TILE, false><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols);
+        transpose_tile_kernel<TILE, false><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols,
+                                                                            (unsigned)tiles_x, (unsigned)tiles_y);
     NP_LAUNCH_CHECK("transpose_tile_kernel");
     return NP_OK;
 }
@@ -135,6 +218,20 @@ int np_transpose2d(const float *in, float *out, size_t batch, size_t rows, size_
     if (rows > 0x7fffffffu || cols > 0x7fffffffu || batch > 65535)
         return np::fail(NP_ERR_INVALID, "np_transpose2d: dimension too large");
     if (int rc = np::ensure_init()) return rc;
+    if ((rows <= 16 || cols <= 16) && g_tile == 0) {
+        const bool tall = cols <= rows;
+        const size_t n_long = tall ? rows : cols;
+        size_t blocks = (n_long + 255) / 256;
+        const size_t cap = (size_t)np::num_cus() * 32;
+        if (blocks > cap) blocks = cap;
+        const dim3 grid((unsigned)blocks, (unsigned)batch);
+        if (tall)
+            transpose_skinny_kernel<true><<<grid, 256, 0, np::stream()>>>(in, out, rows, cols);
+        else
+            transpose_skinny_kernel<false><<<grid, 256, 0, np::stream()>>>(in, out, rows, cols);
+        NP_LAUNCH_CHECK("transpose_skinny_kernel");
+        return NP_OK;
+    }
     const bool vec = rows % 4 == 0 && cols % 4 == 0 && aligned16(in) && aligned16(out);
     // 128 x 128 tiles (512-byte row segments) for large matrices, 64 x 64 when that would leave
     // CUs without work
@@ -172,6 +269,51 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
     if (!in || !out) return np::fail(NP_ERR_INVALID, "np_permute: null pointer");
     if (int rc = np::ensure_init()) return rc;
 
+    // Simplify first: drop axes of extent 1 and fuse input axes that stay adjacent and in order in the
+    // output.  NCHW -> NHWC, (N, C, H, W) perm (0, 2, 3, 1), becomes (N, C, H*W) perm (0, 2, 1): a
+    // batched 2-D transpose of C x HW planes instead of a 4-D gather.
+    int fshape[MAX_ND], fperm[MAX_ND];
+    {
+        int pos[MAX_ND];                       // output position of each input axis
+        for (int o = 0; o < ndim; ++o) pos[host_perm[o]] = o;
+        int group_of[MAX_ND], ngroups = 0, first_pos[MAX_ND];
+        int prev = -1;                         // previous kept input axis
+        for (int i = 0; i < ndim; ++i) {
+            if (host_shape[i] == 1) {
+                group_of[i] = -1;
+                continue;
+            }
+            // same group as the previous kept axis iff every output slot between them holds an extent-1 axis
+            bool fuse = prev >= 0 && pos[i] > pos[prev];
+            if (fuse)
+                for (int o = pos[prev] + 1; o < pos[i]; ++o) fuse = fuse && host_shape[host_perm[o]] == 1;
+            if (fuse) {
+                group_of[i] = ngroups - 1;
+                fshape[ngroups - 1] *= host_shape[i];
+            } else {
+                group_of[i] = ngroups;
+                fshape[ngroups] = host_shape[i];
+                first_pos[ngroups] = pos[i];
+                ++ngroups;
+            }
+            prev = i;
+        }
+        // order the groups by output position
+        int order[MAX_ND];
+        for (int g = 0; g < ngroups; ++g) order[g] = g;
+        for (int a = 0; a < ngroups; ++a)
+            for (int b = a + 1; b < ngroups; ++b)
+                if (first_pos[order[b]] < first_pos[order[a]]) {
+                    const int t = order[a];
+                    order[a] = order[b];
+                    order[b] = t;
+                }
+        for (int o = 0; o < ngroups; ++o) fperm[o] = order[o];
+        ndim = ngroups;
+        host_shape = fshape;
+        host_perm = fperm;
+    }
+
     bool identity = true;
     for (int i = 0; i < ndim; ++i) identity = identity && host_perm[i] == i;
     if (identity) return np_memcpy_d2d(out, in, n * sizeof(float));
@@ -184,13 +326,54 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
         if (batch <= 65535 && (size_t)host_shape[ndim - 2] <= (size_t)65535 * 64)
             return np_transpose2d(in, out, batch, (size_t)host_shape[ndim - 2], (size_t)host_shape[ndim - 1]);
     }
-    // general gather
     size_t in_strides[MAX_ND];
     size_t s = 1;
     for (int i = ndim - 1; i >= 0; --i) {
         in_strides[i] = s;
         s *= (size_t)host_shape[i];
     }
+    // output-fastest axis is not the input-fastest one: LDS-tiled plane transpose, batched
+    if (ndim >= 2 && host_perm[ndim - 1] != ndim - 1 && g_tile == 0) {
+        const int ax_a = host_perm[ndim - 1], ax_b = ndim - 1;   // input axes
+        size_t out_strides[MAX_ND];   // output stride of each OUTPUT axis
+        size_t t = 1;
+        for (int i = ndim - 1; i >= 0; --i) {
+            out_strides[i] = t;
+            t *= (size_t)host_shape[host_perm[i]];
+        }
+        TiledPermuteArgs p;
+        p.A = (unsigned)host_shape[ax_a];
+        p.B = (unsigned)host_shape[ax_b];
+        p.a_in = in_strides[ax_a];
+        p.b_out = 0;
+        p.nbatch = 0;
+        size_t batch = 1;
+        for (int i = 0; i < MAX_ND; ++i) {
+            p.bshape[i] = 1;
+            p.bin[i] = p.bout[i] = 0;
+        }
+        for (int o = 0; o < ndim; ++o) {          // o: output axis, fed by input axis host_perm[o]
+            const int ia = host_perm[o];
+            if (ia == ax_b) {
+                p.b_out = out_strides[o];
+            } else if (ia != ax_a) {
+                p.bshape[p.nbatch] = (unsigned)host_shape[ia];
+                p.bin[p.nbatch] = in_strides[ia];
+                p.bout[p.nbatch] = out_strides[o];
+                ++p.nbatch;
+                batch *= (size_t)host_shape[ia];
+            }
+        }
+        p.tiles_a = (p.A + 63) / 64;
+        p.tiles_b = (p.B + 63) / 64;
+        const size_t blocks = (size_t)p.tiles_a * p.tiles_b * batch;
+        if (blocks <= 0x7fffffffu) {
+            permute_tiled_kernel<<<(unsigned)blocks, 256, 0, np::stream()>>>(in, out, p);
+            NP_LAUNCH_CHECK("permute_tiled_kernel");
+            return NP_OK;
+        }
+    }
+    // general gather
     PermuteArgs a;
     a.ndim = (unsigned)ndim;
     for (int i = 0; i < MAX_ND; ++i) {

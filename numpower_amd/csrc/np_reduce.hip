@@ -231,15 +231,35 @@ __global__ __launch_bounds__(256) void argreduce_rows_kernel(const float *__rest
     const float *p = in + (size_t)row * len;
     ArgPair best{IS_MAX ? -INFINITY : INFINITY, 0xffffffffu};
     bool have = false;
-    for (unsigned i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const ArgPair c{arg_key<IS_MAX>(p[i], i), i};
+    auto take = [&](float x, unsigned i) {
+        const ArgPair c{arg_key<IS_MAX>(x, i), i};
         if (!have) {
             best = c;
             have = true;
         } else {
             best = arg_combine<IS_MAX>(best, c);
         }
+    };
+    // 4 consecutive elements per lane per trip (dword-aligned dwordx4 loads: rows start anywhere),
+    // two trips in flight; ties are broken by index, so the visiting order does not matter
+    struct __attribute__((packed, aligned(4))) U4 { v4f v; };
+    const unsigned nvec = (hi - lo) / 4;
+    unsigned v = threadIdx.x;
+    for (; v + blockDim.x < nvec; v += 2 * blockDim.x) {
+        const unsigned i0 = lo + 4 * v, i1 = lo + 4 * (v + blockDim.x);
+        const v4f x0 = ((const U4 *)(p + i0))->v, x1 = ((const U4 *)(p + i1))->v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) take(x0[k], i0 + k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) take(x1[k], i1 + k);
     }
+    for (; v < nvec; v += blockDim.x) {
+        const unsigned i0 = lo + 4 * v;
+        const v4f x0 = ((const U4 *)(p + i0))->v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) take(x0[k], i0 + k);
+    }
+    for (unsigned i = lo + 4 * nvec + threadIdx.x; i < hi; i += blockDim.x) take(p[i], i);
     // lanes without a candidate carry index 0xffffffff and a neutral value: they lose every tie
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -267,18 +287,88 @@ __global__ __launch_bounds__(256) void argreduce_rows_kernel(const float *__rest
 
 // fold the per-chunk partials of each row (chunks are in index order) and write the float index
 template <bool IS_MAX>
+// partials are laid out [outer][chunks][inner]; output element = (o, j)
 __global__ __launch_bounds__(256) void argreduce_fold_kernel(const float *__restrict__ pv,
                                                              const unsigned *__restrict__ pi,
-                                                             float *__restrict__ out, unsigned rows,
-                                                             unsigned chunks) {
-    const unsigned row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    ArgPair r{pv[(size_t)row * chunks], pi[(size_t)row * chunks]};
+                                                             float *__restrict__ out, size_t outputs,
+                                                             unsigned chunks, size_t inner) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= outputs) return;
+    const size_t o = idx / inner, j = idx - o * inner;
+    const size_t base = o * chunks * inner + j;
+    ArgPair r{pv[base], pi[base]};
     for (unsigned c = 1; c < chunks; ++c) {
-        const ArgPair o{pv[(size_t)row * chunks + c], pi[(size_t)row * chunks + c]};
-        if (o.i != 0xffffffffu) r = (r.i == 0xffffffffu) ? o : arg_combine<IS_MAX>(r, o);
+        const ArgPair q{pv[base + (size_t)c * inner], pi[base + (size_t)c * inner]};
+        if (q.i != 0xffffffffu) r = (r.i == 0xffffffffu) ? q : arg_combine<IS_MAX>(r, q);
     }
-    out[row] = (float)r.i;
+    out[idx] = (float)r.i;
+}
+
+// the same fold with one WORKGROUP per output: with few outputs the chunk lists are long (3 outputs x
+// 170 000 chunks for an N x 3 array) and a single thread walking one would take milliseconds
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void argreduce_fold_block_kernel(const float *__restrict__ pv,
+                                                                   const unsigned *__restrict__ pi,
+                                                                   float *__restrict__ out, unsigned chunks,
+                                                                   size_t inner) {
+    __shared__ float sv[4];
+    __shared__ unsigned si[4];
+    const size_t idx = blockIdx.x;
+    const size_t o = idx / inner, j = idx - o * inner;
+    const size_t base = o * chunks * inner + j;
+    ArgPair best{IS_MAX ? -INFINITY : INFINITY, 0xffffffffu};
+    for (unsigned c = threadIdx.x; c < chunks; c += blockDim.x) {
+        const ArgPair q{pv[base + (size_t)c * inner], pi[base + (size_t)c * inner]};
+        if (q.i != 0xffffffffu) best = (best.i == 0xffffffffu) ? q : arg_combine<IS_MAX>(best, q);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ArgPair q;
+        q.v = __shfl_down(best.v, off, 64);
+        q.i = __shfl_down(best.i, off, 64);
+        if (q.i != 0xffffffffu) best = (best.i == 0xffffffffu) ? q : arg_combine<IS_MAX>(best, q);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sv[wave] = best.v;
+        si[wave] = best.i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ArgPair r{sv[0], si[0]};
+        for (int w = 1; w < 4; ++w) {
+            const ArgPair q{sv[w], si[w]};
+            if (q.i != 0xffffffffu) r = (r.i == 0xffffffffu) ? q : arg_combine<IS_MAX>(r, q);
+        }
+        out[idx] = (float)r.i;
+    }
+}
+
+// generic with the axis cut into chunks: one thread per (output, chunk), coalesced across the inner
+// index; writes (value, index) partials [outer][chunks][inner] for argreduce_fold_kernel
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void argreduce_chunks_kernel(const float *__restrict__ in, float *__restrict__ pv,
+                                                               unsigned *__restrict__ pi, size_t outer,
+                                                               unsigned axis_len, size_t inner, unsigned chunks,
+                                                               unsigned chunk_len) {
+    const size_t total = outer * chunks * inner;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const size_t oc = idx / inner, j = idx - oc * inner;
+        const size_t o = oc / chunks;
+        const unsigned c = (unsigned)(oc - o * chunks);
+        const unsigned a0 = c * chunk_len;
+        unsigned a1 = a0 + chunk_len;
+        if (a1 > axis_len) a1 = axis_len;
+        const float *p = in + o * axis_len * inner + j;
+        ArgPair best{arg_key<IS_MAX>(p[(size_t)a0 * inner], a0), a0};
+        for (unsigned a = a0 + 1; a < a1; ++a) {
+            const ArgPair q{arg_key<IS_MAX>(p[(size_t)a * inner], a), a};
+            best = arg_combine<IS_MAX>(best, q);
+        }
+        pv[idx] = best.v;
+        pi[idx] = best.i;
+    }
 }
 
 // generic: one thread per output element, sequential over the axis exactly like the reference loop
@@ -829,6 +919,28 @@ static int xform_sum(const float *in, const float *in2, size_t n, float p0, floa
     return NP_OK;
 }
 
+// fold [outer][chunks][inner] partials: thread per output for short chunk lists, workgroup per output
+// for long ones
+static int launch_arg_fold(int is_max, const float *pv, const unsigned *pi, float *out, size_t outputs,
+                           size_t chunks, size_t inner) {
+    hipStream_t s = np::stream();
+    if (chunks > 64 && outputs <= 0x7fffffffu) {
+        if (is_max)
+            argreduce_fold_block_kernel<true><<<(unsigned)outputs, 256, 0, s>>>(pv, pi, out, (unsigned)chunks, inner);
+        else
+            argreduce_fold_block_kernel<false><<<(unsigned)outputs, 256, 0, s>>>(pv, pi, out, (unsigned)chunks, inner);
+        NP_LAUNCH_CHECK("argreduce_fold_block_kernel");
+        return NP_OK;
+    }
+    const unsigned fgrid = (unsigned)((outputs + 255) / 256);
+    if (is_max)
+        argreduce_fold_kernel<true><<<fgrid, 256, 0, s>>>(pv, pi, out, outputs, (unsigned)chunks, inner);
+    else
+        argreduce_fold_kernel<false><<<fgrid, 256, 0, s>>>(pv, pi, out, outputs, (unsigned)chunks, inner);
+    NP_LAUNCH_CHECK("argreduce_fold_kernel");
+    return NP_OK;
+}
+
 extern "C" {
 
 int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, size_t inner, float *out) {
@@ -857,15 +969,33 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
         else
             argreduce_rows_kernel<false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)chunks);
         NP_LAUNCH_CHECK("argreduce_rows_kernel");
-        const unsigned fgrid = (unsigned)((outer + 255) / 256);
-        if (is_max)
-            argreduce_fold_kernel<true><<<fgrid, 256, 0, s>>>((const float *)pv.ptr, (const unsigned *)pi.ptr, out, (unsigned)outer, (unsigned)chunks);
-        else
-            argreduce_fold_kernel<false><<<fgrid, 256, 0, s>>>((const float *)pv.ptr, (const unsigned *)pi.ptr, out, (unsigned)outer, (unsigned)chunks);
-        NP_LAUNCH_CHECK("argreduce_fold_kernel");
-        return NP_OK;
+        return launch_arg_fold(is_max, (const float *)pv.ptr, (const unsigned *)pi.ptr, out, outer, chunks, 1);
     }
     const size_t total = outer * inner;
+    // few outputs, long axis (argmax over the rows of an N x 3 array): one thread per output would
+    // leave the chip idle — cut the axis into chunks, then fold the (value, index) partials
+    const size_t target_threads = (size_t)np::num_cus() * 2048;
+    if (total < target_threads && axis_len >= 128) {
+        size_t chunks = (target_threads + total - 1) / total;
+        const size_t max_chunks = axis_len / 32;
+        if (chunks > max_chunks) chunks = max_chunks;
+        const size_t chunk_len = (axis_len + chunks - 1) / chunks;
+        chunks = (axis_len + chunk_len - 1) / chunk_len;
+        if (chunks > 1) {
+            np::Scratch pv, pi;
+            if (int rc = pv.alloc(total * chunks * sizeof(float))) return rc;
+            if (int rc = pi.alloc(total * chunks * sizeof(unsigned))) return rc;
+            size_t blocks = (total * chunks + 255) / 256;
+            const size_t cap = (size_t)np::num_cus() * 16;
+            if (blocks > cap) blocks = cap;
+            if (is_max)
+                argreduce_chunks_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, outer, (unsigned)axis_len, inner, (unsigned)chunks, (unsigned)chunk_len);
+            else
+                argreduce_chunks_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, outer, (unsigned)axis_len, inner, (unsigned)chunks, (unsigned)chunk_len);
+            NP_LAUNCH_CHECK("argreduce_chunks_kernel");
+            return launch_arg_fold(is_max, (const float *)pv.ptr, (const unsigned *)pi.ptr, out, total, chunks, inner);
+        }
+    }
     size_t blocks = (total + 255) / 256;
     const size_t cap = (size_t)np::num_cus() * 16;
     if (blocks > cap) blocks = cap;

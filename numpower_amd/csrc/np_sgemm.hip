@@ -692,6 +692,59 @@ __global__ __launch_bounds__(256) void sgemv_kernel(const float *__restrict__ A,
     if (lane == 0) y[row] = acc;
 }
 
+// Few long rows (an inner product is 1 x N): one wave per row leaves the chip idle (1 x 10^8 took
+// 179 ms).  Each row is cut into chunks, one workgroup per (chunk, row) -> partial[row][chunk]; the
+// caller folds the chunks with np_reduce_axis.  Dword-aligned float4 loads: rows start anywhere.
+__global__ __launch_bounds__(256) void sgemv_chunks_kernel(const float *__restrict__ A,
+                                                           const float *__restrict__ x,
+                                                           float *__restrict__ partial, unsigned N,
+                                                           unsigned chunk_len) {
+    struct __attribute__((packed, aligned(4))) U4 { v4f v; };
+    __shared__ float lds4[4];
+    const unsigned row = blockIdx.y, chunk = blockIdx.x;
+    const unsigned k0 = chunk * chunk_len;
+    const unsigned len = (N - k0 < chunk_len) ? N - k0 : chunk_len;
+    const float *a = A + (size_t)row * N + k0;
+    const float *xx = x + k0;
+    float acc0 = 0.0f, acc1 = 0.0f;
+    const unsigned n4 = len / 4;
+    unsigned v = threadIdx.x;
+    for (; v + 256 < n4; v += 512) {
+        const v4f a0 = ((const U4 *)(a + (size_t)v * 4))->v, x0 = ((const U4 *)(xx + (size_t)v * 4))->v;
+        const v4f a1 = ((const U4 *)(a + (size_t)(v + 256) * 4))->v, x1 = ((const U4 *)(xx + (size_t)(v + 256) * 4))->v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc0 = fmaf(a0[k], x0[k], acc0);
+            acc1 = fmaf(a1[k], x1[k], acc1);
+        }
+    }
+    for (; v < n4; v += 256) {
+        const v4f a0 = ((const U4 *)(a + (size_t)v * 4))->v, x0 = ((const U4 *)(xx + (size_t)v * 4))->v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc0 = fmaf(a0[k], x0[k], acc0);
+    }
+    for (unsigned k = n4 * 4 + threadIdx.x; k < len; k += 256) acc0 = fmaf(a[k], xx[k], acc0);
+    float acc = acc0 + acc1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)row * gridDim.x + chunk] = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+// Many short rows (N <= 32, a 10^7 x 10 matrix): one THREAD per row; a wave per row would use 10 of
+// its 64 lanes.  A row's floats are consecutive, so neighbouring lanes share cache lines.
+__global__ __launch_bounds__(256) void sgemv_short_rows_kernel(const float *__restrict__ A,
+                                                               const float *__restrict__ x,
+                                                               float *__restrict__ y, size_t M, unsigned N) {
+    for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < M; row += (size_t)gridDim.x * blockDim.x) {
+        const float *a = A + row * N;
+        float acc = 0.0f;
+        for (unsigned k = 0; k < N; ++k) acc = fmaf(a[k], x[k], acc);
+        y[row] = acc;
+    }
+}
+
 int g_variant = 0;
 unsigned long long *g_probe = nullptr;
 
@@ -1014,6 +1067,29 @@ int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y) {
     if (M > 0x7fffffffu || N > 0x7fffffffu)
         return np::fail(NP_ERR_INVALID, "np_sgemv: dimension too large");
     if (int rc = np::ensure_init()) return rc;
+    const size_t target = (size_t)np::num_cus() * 8;
+    if (N <= 32 && M >= 4096) {
+        size_t blocks = (M + 255) / 256;
+        if (blocks > target * 4) blocks = target * 4;
+        sgemv_short_rows_kernel<<<(unsigned)blocks, 256, 0, np::stream()>>>(A, x, y, M, (unsigned)N);
+        NP_LAUNCH_CHECK("sgemv_short_rows_kernel");
+        return NP_OK;
+    }
+    if (M < 2 * target && N >= 16384 && M <= 65535) {   // one wave per row would leave most of the chip idle
+        size_t chunks = (2 * target + M - 1) / M;
+        const size_t max_chunks = N / 4096;
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks >= 2) {
+            const size_t chunk_len = ((N + chunks - 1) / chunks + 3) / 4 * 4;
+            chunks = (N + chunk_len - 1) / chunk_len;
+            np::Scratch partial;
+            if (int rc = partial.alloc(M * chunks * sizeof(float))) return rc;
+            sgemv_chunks_kernel<<<dim3((unsigned)chunks, (unsigned)M), 256, 0, np::stream()>>>(
+                A, x, (float *)partial.ptr, (unsigned)N, (unsigned)chunk_len);
+            NP_LAUNCH_CHECK("sgemv_chunks_kernel");
+            return np_reduce_axis(NP_SUM, (const float *)partial.ptr, M, chunks, 1, y, 0);
+        }
+    }
     const int vec = (N % 4 == 0) && aligned16(A) && aligned16(x);
     sgemv_kernel<<<(unsigned)((M + 3) / 4), 256, 0, np::stream()>>>(A, x, y, (unsigned)M,
                                                                   (unsigned)N, vec);

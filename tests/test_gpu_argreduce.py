@@ -82,3 +82,23 @@ def test_argmax_1e8(hip):
     assert out.to_host()[0] == np.float32(12_345)
     d.free()
     del C
+
+
+@pytest.mark.parametrize("shape,axis", [((300_000, 3), 0), ((3, 300_000), 1), ((1, 1_000_003), 1), ((1_000_003,), None),
+                                        ((2000, 1003), 0), ((5, 40_000, 7), 1), ((70_000, 1), 0), ((2, 3, 50_000), 2)])
+def test_argreduce_few_outputs_long_axis(shape, axis, hip, oracle):
+    """Shapes where one thread per output would idle the chip: the axis is cut into chunks whose
+    (value, index) partials are folded (argreduce_chunks_kernel / vectorised argreduce_rows_kernel).
+    First-occurrence ties and the NaN rules must survive the chunk boundaries."""
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform(shape, 51, -1.0, 1.0)
+    flat = x.reshape(-1)
+    flat[::7] = np.float32(0.75)                    # many exact ties for the maximum region
+    flat[3::11] = np.float32(-0.75)
+    flat[flat.size // 2] = np.nan                   # a NaN that is not in position 0
+    g = NDArray.array(x).gpu()
+    for is_max in (True, False):
+        got = NDArray.argmax(g, axis) if is_max else NDArray.argmin(g, axis)
+        got = got.cpu().numpy() if not isinstance(got, float) else np.float32(got)
+        want = oracle.argreduce(x, axis, is_max)
+        assert np.array_equal(np.asarray(got, np.float32).reshape(-1), np.asarray(want, np.float32).reshape(-1))

@@ -72,3 +72,37 @@ def test_transpose_16384x4096(hip):
     dx.free()
     out.free()
     del C
+
+
+PERMS = [((30, 3, 64, 65), (0, 2, 3, 1)),        # NCHW -> NHWC: fuses to a batched 3 x 4160 transpose (skinny path)
+         ((30, 64, 65, 3), (0, 3, 1, 2)),        # NHWC -> NCHW
+         ((70, 130, 66), (2, 1, 0)),             # full reversal: LDS-tiled plane transpose, batch = middle axis
+         ((9, 10, 11, 12), (3, 2, 1, 0)),
+         ((5, 1, 7, 1, 9), (4, 3, 2, 1, 0)),     # extent-1 axes are dropped before dispatch
+         ((2, 3, 4, 5, 6, 7), (5, 0, 1, 2, 3, 4)),   # rotate: fuses to (720, 7) -> (7, 720)
+         ((2, 3, 4, 5, 6, 7), (1, 0, 3, 2, 5, 4)),
+         ((129, 257, 3), (1, 0, 2)),             # innermost axis kept: gather path
+         ((4, 5, 6, 7, 8, 3, 2, 2), (7, 6, 5, 4, 3, 2, 1, 0)),
+         ((64, 64, 64), (1, 2, 0))]
+
+
+@pytest.mark.parametrize("shape,axes", PERMS)
+def test_permute_paths(shape, axes, hip):
+    """np_permute after axis fusion: every dispatch (copy, batched 2-D transpose incl. the skinny
+    kernel, LDS-tiled plane transpose, gather) against numpy, bit for bit."""
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform(shape, 73, -1.0, 1.0)
+    got = NDArray.transpose(NDArray.array(x).gpu(), axes).cpu().numpy()
+    want = np.ascontiguousarray(np.transpose(x, axes))
+    assert got.shape == want.shape and (_bits(got) == _bits(want)).all()
+
+
+@pytest.mark.parametrize("rc", [(100_003, 3), (3, 100_003), (70_000, 1), (1, 70_000), (5000, 16), (16, 5000), (1031, 1033),
+                                (4099, 257), (2, 2), (17, 17)])
+def test_transpose2d_skinny_and_odd(rc, hip):
+    """Tall-skinny / short-wide matrices (one side <= 16: transpose_skinny_kernel; these also have
+    more tile rows than gridDim.y allows) and odd sizes (dword-aligned float4 path)."""
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform(rc, 74, -1.0, 1.0)
+    got = NDArray.transpose(NDArray.array(x).gpu()).cpu().numpy()
+    assert got.shape == (rc[1], rc[0]) and (_bits(got) == _bits(np.ascontiguousarray(x.T))).all()

@@ -611,3 +611,25 @@ def test_axis_reduce_few_outputs_long_axis(shape, axis, hip, oracle):
     p = np.ascontiguousarray(p[tuple(slice(0, s) for s in small)])
     got = host(NDArray.prod(NDArray.array(p).gpu(), axis))
     assert_bit_equal(got, oracle.reduce_axis("prod", p, axis), "prod")
+
+
+@pytest.mark.parametrize("mn", [(1, 3_000_001), (1, 65536), (10, 500_000), (7, 16385), (200_000, 10), (5000, 1), (4096, 33),
+                                (300, 70_001)])
+def test_sgemv_shapes(mn, hip, oracle):
+    """np_sgemv / NDArray_Dot outside the square case: inner products and few long rows (chunked:
+    sgemv_chunks_kernel + fold), many short rows (thread per row), against fp64 and the oracle's
+    OpenBLAS sgemv."""
+    from numpower_amd.ndarray import NDArray
+    m, n = mn
+    a = synth.uniform((m, n), 37, -1.0, 1.0)
+    x = synth.uniform((n,), 38, -1.0, 1.0)
+    ga, gx = NDArray.array(a).gpu(), NDArray.array(x).gpu()
+    got = NDArray.dot(ga, gx).cpu().numpy()
+    ref64 = a.astype(np.float64) @ x.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(x).astype(np.float64)
+    assert got.shape == (m,)
+    assert (np.abs(got - ref64) <= 1e-5 * scale).all()
+    assert (np.abs(oracle.matvec(a, x) - ref64) <= 1e-5 * scale).all()
+    if m == 1:   # 1-D . 1-D -> NDArray_Inner
+        v = NDArray.dot(NDArray.array(a[0]).gpu(), gx)
+        assert abs(float(v) - ref64[0]) <= 1e-5 * scale[0]
