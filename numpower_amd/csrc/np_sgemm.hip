@@ -1058,7 +1058,14 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K, const f
         return NP_OK;
     }
     if (!A || !B) return np::fail(NP_ERR_INVALID, "np_sgemm: null input");
-    return launch_sgemm(batch, M, N, K, A, K, stride_a, B, stride_b, C, stride_c);
+    // blockIdx.z carries the batch index: more than 65535 matrices go in slabs
+    for (size_t b0 = 0; b0 < batch; b0 += 65535) {
+        const size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        if (int rc = launch_sgemm(nb, M, N, K, A + b0 * stride_a, K, stride_a, B + b0 * stride_b, stride_b,
+                                  C + b0 * stride_c, stride_c))
+            return rc;
+    }
+    return NP_OK;
 }
 
 int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y) {

@@ -633,3 +633,17 @@ def test_sgemv_shapes(mn, hip, oracle):
     if m == 1:   # 1-D . 1-D -> NDArray_Inner
         v = NDArray.dot(NDArray.array(a[0]).gpu(), gx)
         assert abs(float(v) - ref64[0]) <= 1e-5 * scale[0]
+
+
+def test_batched_matmul_more_than_65535_matrices(hip):
+    """blockIdx.z carries the batch index; 70 000 small matrices go in slabs (np_sgemm_strided_batched)."""
+    from numpower_amd import _lib
+    from numpower_amd import device as D
+    batch, m, n, k = 70_000, 4, 5, 6
+    a = synth.uniform((batch, m, k), 39, -1.0, 1.0)
+    b = synth.uniform((batch, k, n), 40, -1.0, 1.0)
+    da, db, dc = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b), D.DeviceArray((batch, m, n))
+    _lib.check(_lib.load().np_sgemm_strided_batched(batch, m, n, k, da.ptr, m * k, db.ptr, k * n, dc.ptr, m * n))
+    got = dc.to_host()
+    ref = np.einsum("bmk,bkn->bmn", a.astype(np.float64), b.astype(np.float64))
+    assert np.abs(got - ref).max() <= 1e-5
