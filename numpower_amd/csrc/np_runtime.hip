@@ -33,7 +33,8 @@ struct Runtime {
     hipStream_t cur_stream = nullptr;
     // caching pool
     std::map<size_t, std::vector<void *>> free_blocks;   // rounded size -> blocks
-    std::unordered_map<void *, size_t> live;             // ptr -> rounded size
+    struct Block { size_t size; int device; };
+    std::unordered_map<void *, Block> live;              // ptr -> rounded size, owning device
     size_t reserved = 0;                                 // bytes held (live + cached)
     long live_count = 0;
 };
@@ -234,7 +235,7 @@ int np_malloc(void **dev_ptr, size_t bytes) {
         }
         r.reserved += sz;
     }
-    r.live[p] = sz;
+    r.live[p] = Runtime::Block{sz, r.device};
     r.live_count++;
     *dev_ptr = p;
     return NP_OK;
@@ -247,7 +248,14 @@ int np_free(void *dev_ptr) {
     auto it = r.live.find(dev_ptr);
     if (it == r.live.end())
         return np::fail(NP_ERR_INVALID, "np_free: pointer %p was not allocated by np_malloc", dev_ptr);
-    r.free_blocks[it->second].push_back(dev_ptr);
+    if (it->second.device == r.device) {
+        r.free_blocks[it->second.size].push_back(dev_ptr);
+    } else {
+        // allocated before an NDArray::setDevice to another GPU: the cache only holds blocks of the
+        // current device, so this one goes straight back to the driver
+        (void)hipFree(dev_ptr);
+        r.reserved -= it->second.size;
+    }
     r.live.erase(it);
     r.live_count--;
     return NP_OK;
