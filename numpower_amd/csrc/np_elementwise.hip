@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ out, floa
     const I stride = (I)gridDim.x * blockDim.x;
     const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
     const v4f v{value, value, value, value};
-    for (I i = tid; i < nvec; i += stride) *(v4f *)(out + head + (size_t)i * 4) = v;
+    for (I i = tid; i < nvec; i += stride) __builtin_nontemporal_store(v, (v4f *)(out + head + (size_t)i * 4));
     if (blockIdx.x == 0) {
         if (threadIdx.x < head) out[threadIdx.x] = value;
         const I t = head + nvec * 4 + threadIdx.x;
@@ -378,6 +378,27 @@ __global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ out, floa
 // ------------------------------------------------------------------------------------------
 // launch configuration
 // ------------------------------------------------------------------------------------------
+
+// Plain device-to-device copy of 4-byte words (np::device_copy): the same float4 / non-temporal stream
+// as the unary kernels; hipMemcpyAsync's blit reaches 5.1-5.3 TB/s on large buffers, this 6.0-6.4.
+template <typename I>
+__global__ __launch_bounds__(256) void copy_vec_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                       I nvec, I n) {
+    const I stride = (I)gridDim.x * blockDim.x;
+    const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    for (I base = tid; base < nvec; base += 2 * stride) {
+        const I v1 = base + stride;
+        const v4f x0 = ld4<true>(in + (size_t)base * 4);
+        v4f x1{0, 0, 0, 0};
+        if (v1 < nvec) x1 = ld4<true>(in + (size_t)v1 * 4);
+        st4<true>(out + (size_t)base * 4, x0);
+        if (v1 < nvec) st4<true>(out + (size_t)v1 * 4, x1);
+    }
+    if (blockIdx.x == 0) {
+        const I t = nvec * 4 + threadIdx.x;
+        if (t < n) out[t] = in[t];
+    }
+}
 
 // out[i][j] = 0 + a[i] * b[j]: cblas_sger on a zeroed matrix (linalg.c:741-742) — the "0 +" matters
 // only for the sign of zero products (-0 + +0 = +0).  Write-bound: 4 B/elem.
@@ -993,6 +1014,19 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     return NP_OK;
 }
 
+namespace np {
+int device_copy(void *dst, const void *src, size_t bytes) {
+    const size_t n = bytes / 4;
+    const unsigned grid = grid_for(n / 4 + 1, 2, 0);
+    if (n < (size_t(1) << 31))
+        copy_vec_kernel<uint32_t><<<grid, 256, 0, np::stream()>>>((const float *)src, (float *)dst, (uint32_t)(n / 4), (uint32_t)n);
+    else
+        copy_vec_kernel<uint64_t><<<grid, 256, 0, np::stream()>>>((const float *)src, (float *)dst, (uint64_t)(n / 4), (uint64_t)n);
+    NP_LAUNCH_CHECK("copy_vec_kernel");
+    return NP_OK;
+}
+}  // namespace np
+
 extern "C" {
 
 int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inputs,
@@ -1110,7 +1144,7 @@ int np_fill(float *dev_ptr, float value, size_t n) {
     size_t head = ((16 - ((uintptr_t)dev_ptr & 15u)) & 15u) / 4;
     if (head > n) head = n;
     const size_t nvec = (n - head) / 4;
-    const unsigned grid = grid_for(nvec + 1, 4, 8);
+    const unsigned grid = grid_for(nvec + 1, 2, 0);   // write-only stream: uncapped grid, non-temporal stores
     if (n < (size_t(1) << 31))
         fill_kernel<uint32_t><<<grid, 256, 0, np::stream()>>>(dev_ptr, value, (uint32_t)n,
                                                               (uint32_t)head, (uint32_t)nvec);

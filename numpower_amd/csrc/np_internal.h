@@ -19,6 +19,8 @@ hipStream_t stream();
 int ensure_init();
 // Device properties cached at init.
 int num_cus();
+// Copy kernel for large word-aligned device-to-device copies (np_elementwise.hip); bytes % 4 == 0.
+int device_copy(void *dst, const void *src, size_t bytes);
 
 // Scratch from the caching pool, released back to the pool when the object dies.  Freed blocks
 // are only reused by later launches on the same stream, so releasing right after the launch

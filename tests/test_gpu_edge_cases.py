@@ -108,3 +108,30 @@ def test_past_2_to_31_elements(hip):
         buf.free()
     freed = C.c_size_t()
     _lib.check(lib.np_pool_trim(C.byref(freed)))        # hand the 26 GB back to the driver
+
+
+def test_device_copy_and_fill_are_bit_exact(hip):
+    """Large np_memcpy_d2d goes through the library's copy kernel (np::device_copy), small / odd ones
+    through hipMemcpyAsync: every bit pattern (NaN payloads, -0, denormals) must survive, at any
+    word alignment; np_fill writes exactly n elements."""
+    from numpower_amd import _lib
+    lib = _lib.load()
+    n = 5_000_003
+    bits = (np.arange(n, dtype=np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)   # all kinds of patterns
+    bits[:4] = [0x7fc00001, 0xffc12345, 0x80000000, 0x00000001]
+    src = _lib.DeviceBuffer(4 * (n + 8)); dst = _lib.DeviceBuffer(4 * (n + 8))
+    for off_s, off_d, cnt in ((0, 0, n), (1, 0, n), (0, 3, n), (2, 1, n - 5), (0, 0, 1000), (1, 1, 3)):
+        _lib.check(lib.np_memset0(dst.ptr, 4 * (n + 8)))
+        _lib.check(lib.np_memcpy_h2d(src.ptr + 4 * off_s, bits.ctypes.data, 4 * cnt))
+        _lib.check(lib.np_memcpy_d2d(dst.ptr + 4 * off_d, src.ptr + 4 * off_s, 4 * cnt))
+        back = np.empty(n + 8, np.uint32)
+        _lib.check(lib.np_memcpy_d2h(back.ctypes.data, dst.ptr, 4 * (n + 8)))
+        assert (back[off_d:off_d + cnt] == bits[:cnt]).all()
+        assert (back[:off_d] == 0).all() and (back[off_d + cnt:] == 0).all()
+    for off, cnt in ((0, n), (1, n), (3, n - 2), (2, 5)):
+        _lib.check(lib.np_memset0(dst.ptr, 4 * (n + 8)))
+        _lib.check(lib.np_fill(dst.ptr + 4 * off, -0.0, cnt))
+        back = np.empty(n + 8, np.uint32)
+        _lib.check(lib.np_memcpy_d2h(back.ctypes.data, dst.ptr, 4 * (n + 8)))
+        assert (back[off:off + cnt] == 0x80000000).all() and (back[:off] == 0).all() and (back[off + cnt:] == 0).all()
+    src.free(); dst.free()
