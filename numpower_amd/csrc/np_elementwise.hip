@@ -231,16 +231,55 @@ __device__ __forceinline__ void st4(float *p, v4f v) {
         *(v4f_u *)p = v;
 }
 
+// Division of a 32-bit index by the (run-time, per-launch constant) row length as multiply-high +
+// shifts (Granlund-Montgomery round-up method): a plain u32 division is ~40 VALU instructions, which
+// is what made exp(X) + row VALU-bound.  q = (t + ((n - t) >> s1)) >> s2 with t = umulhi(m, n).
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned m, unsigned s1, unsigned s2) {
+    const unsigned t = __umulhi(m, n);
+    return (t + ((n - t) >> s1)) >> s2;
+}
+
+// Row length of a broadcast whose float4s may straddle rows (cols % 4 != 0): `cols` = 0 means "not
+// ragged" (the fast path below), else the per-element (row, col) come from fast_div.
+template <typename I>
+struct Ragged {
+    I cols;
+    unsigned m, s1, s2;
+};
+
+template <typename I>
+__device__ __forceinline__ I ragged_row(const Ragged<I> &r, I e) {
+    if constexpr (sizeof(I) == 4) return (I)fast_div((unsigned)e, r.m, r.s1, r.s2);
+    return e / r.cols;
+}
+
 // Operand fetch for the vector path: `v` is the float4 index into the rows x cols output,
-// cols4 = cols / 4 (the vector path requires cols % 4 == 0 for ROW/COL operands).
+// cols4 = cols / 4.  With cols % 4 == 0 a float4 never straddles a row: ROW is one float4 load, COL
+// one scalar.  Otherwise (rg.cols != 0, a uniform branch) each of the four elements gets its own
+// row / column index; the row / column vector itself is cache-resident.
 template <int KIND, bool NT, typename I>
-__device__ __forceinline__ v4f fetch4(const float *p, I v, I cols4, float splat) {
+__device__ __forceinline__ v4f fetch4(const float *p, I v, I cols4, float splat, const Ragged<I> &rg) {
     if constexpr (KIND == NP_FULL) return ld4<NT>(p + (size_t)v * 4);
     if constexpr (KIND == NP_SCALAR) return v4f{splat, splat, splat, splat};
-    if constexpr (KIND == NP_ROW) return *(const v4f_u *)(p + (size_t)(v % cols4) * 4);
+    if constexpr (KIND == NP_ROW) {
+        if (rg.cols == 0) return *(const v4f_u *)(p + (size_t)(v % cols4) * 4);
+        v4f r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const I e = v * 4 + k;
+            r[k] = p[(size_t)(e - ragged_row(rg, e) * rg.cols)];
+        }
+        return r;
+    }
     if constexpr (KIND == NP_COL) {
-        const float s = p[(size_t)(v / cols4)];
-        return v4f{s, s, s, s};
+        if (rg.cols == 0) {
+            const float s = p[(size_t)(v / cols4)];
+            return v4f{s, s, s, s};
+        }
+        v4f r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = p[(size_t)ragged_row(rg, (I)(v * 4 + k))];
+        return r;
     }
     return v4f{0, 0, 0, 0};
 }
@@ -256,7 +295,7 @@ __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict
                                                          const float *__restrict__ b,
                                                          float *__restrict__ out, I nvec, I cols4,
                                                          I tail_start, I n, I body_end, float ha,
-                                                         float hb) {
+                                                         float hb, Ragged<I> rg) {
     const I stride = (I)gridDim.x * blockDim.x;
     const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
     // scalar operands: device pointer, or (null pointer) a value handed over by the host
@@ -270,8 +309,8 @@ __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict
         for (int u = 0; u < UNROLL; ++u) {
             const I v = base + (I)u * stride;
             if (v < nvec) {
-                va[u] = fetch4<AK, NT, I>(a, v, cols4, sa);
-                vb[u] = fetch4<BK, NT, I>(b, v, cols4, sb);
+                va[u] = fetch4<AK, NT, I>(a, v, cols4, sa, rg);
+                vb[u] = fetch4<BK, NT, I>(b, v, cols4, sb, rg);
             }
         }
 #pragma unroll
@@ -287,13 +326,17 @@ __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict
             }
         }
     }
-    // ragged tail (n % 4 elements), only reachable for FULL/SCALAR operand kinds
+    // ragged tail (n % 4 elements): FULL/SCALAR operand kinds, or a ragged broadcast
     if (blockIdx.x == 0) {
         const I i = tail_start + threadIdx.x;
         if (i < n) {
-            const float x = (AK == NP_SCALAR) ? sa : a[i];
-            const float y = (BK == NP_SCALAR) ? sb : b[i];
-            out[i] = binary_apply<OP, QUIRK>(x, y, i < body_end);
+            auto at = [&](const float *p, int kind, float splat) -> float {
+                if (kind == NP_SCALAR) return splat;
+                if (kind == NP_FULL) return p[i];
+                const I row = ragged_row(rg, i);
+                return kind == NP_ROW ? p[(size_t)(i - row * rg.cols)] : p[(size_t)row];
+            };
+            out[i] = binary_apply<OP, QUIRK>(at(a, AK, sa), at(b, BK, sb), i < body_end);
         }
     }
 }
@@ -478,10 +521,21 @@ int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size
     const I nvec = (I)(n / 4), cols4 = (I)(cols / 4), tail = (I)(n / 4 * 4);
     const unsigned grid = grid_for(n / 4 + 1, c.unroll, c.blocks_per_cu);
     hipStream_t s = np::stream();
+    Ragged<I> rg{0, 0, 0, 0};
+    if ((AK == NP_ROW || AK == NP_COL || BK == NP_ROW || BK == NP_COL) && cols % 4 != 0) {
+        rg.cols = (I)cols;
+        if (cols > 1 && cols <= 0xffffffffull) {   // fast_div constants (cols == 1: q = n)
+            unsigned l = 0;
+            while ((1ull << l) < cols) ++l;
+            rg.m = (unsigned)((((1ull << 32) * ((1ull << l) - cols)) / cols) + 1);
+            rg.s1 = 1;
+            rg.s2 = l - 1;
+        }
+    }
 #define NP_BV(U, NT)                                                                       \
     binary_vec_kernel<OP, AK, BK, QUIRK, U, NT, I><<<grid, 256, 0, s>>>(a, b, out, nvec,   \
                                                                          cols4, tail, (I)n, \
-                                                                         (I)body_end, ha, hb)
+                                                                         (I)body_end, ha, hb, rg)
     // only the measured-useful variants are instantiated (the full unroll x nt sweep lives in
     // tools/explore/add_bw.hip): UNROLL 2 (default) and 4, non-temporal
     if (c.unroll == 4)
@@ -510,8 +564,10 @@ int dispatch_binary_kinds(const float *a, int ak, const float *b, int bk, float 
     // vector path: ROW/COL operands need cols % 4 == 0 so that a float4 never straddles a row;
     // pointers may have any (4-byte) alignment.
     const bool bcast = (ak == NP_ROW || ak == NP_COL || bk == NP_ROW || bk == NP_COL);
-    bool vec = n >= 4;   // no alignment requirement: ld4 / st4 are dword-aligned float4 accesses
-    if (bcast) vec = vec && (cols % 4 == 0);
+    // no alignment requirement (ld4 / st4 are dword-aligned float4 accesses) and no row-length
+    // requirement (ragged broadcasts index per element, see fetch4)
+    const bool vec = n >= 4;
+    (void)bcast;
     if (vec) {
 #define NP_BK(AK_, BK_)                                                                     \
     if (ak == AK_ && bk == BK_)                                                             \
@@ -622,14 +678,6 @@ struct FusedArgs {
 // copy the whole struct to scratch (private memory) first; reading it through the kernarg segment
 // pointer (constant address space) keeps every descriptor fetch a scalar load.
 typedef const __attribute__((address_space(4))) FusedArgs *FusedArgsK;
-
-// Division of a 32-bit index by the (run-time, per-launch constant) row length as multiply-high +
-// shifts (Granlund-Montgomery round-up method): a plain u32 division is ~40 VALU instructions, which
-// is what made exp(X) + row VALU-bound.  q = (t + ((n - t) >> s1)) >> s2 with t = umulhi(m, n).
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned m, unsigned s1, unsigned s2) {
-    const unsigned t = __umulhi(m, n);
-    return (t + ((n - t) >> s1)) >> s2;
-}
 
 constexpr bool binary_has_quirk(int op) {
     return op == NP_MULTIPLY || op == NP_MOD || op == NP_EQUAL || op == NP_NOT_EQUAL;
