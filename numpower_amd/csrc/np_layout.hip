@@ -115,10 +115,13 @@ struct PermuteArgs {
     size_t in_stride[MAX_ND];   // element stride of the input axis that feeds output axis i
 };
 
-template <typename I>
+// W = floats moved per "element": 4 when the innermost axis is kept, contiguous and a multiple of 4
+// long (shape / strides are then in float4 units; dword-aligned float4 accesses).
+template <typename I, int W>
 __global__ __launch_bounds__(256) void permute_gather_kernel(const float *__restrict__ in,
                                                              float *__restrict__ out, I n,
                                                              PermuteArgs a) {
+    typedef v4f v4f_u __attribute__((aligned(4)));
     const I stride = (I)gridDim.x * blockDim.x;
     for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         I rem = i;
@@ -131,8 +134,41 @@ __global__ __launch_bounds__(256) void permute_gather_kernel(const float *__rest
                 rem = q;
             }
         }
-        out[i] = in[off];
+        if constexpr (W == 4)
+            *(v4f_u *)(out + (size_t)i * 4) = *(const v4f_u *)(in + off * 4);
+        else
+            out[i] = in[off];
     }
+}
+
+// shared launcher: switches to float4 elements when the innermost output axis reads contiguous input
+int launch_gather(const float *in, float *out, size_t n, PermuteArgs a) {
+    const int last = (int)a.ndim - 1;
+    // (short rows stay scalar: with 8-float rows the float4 form measured 2.7 vs 3.4 TB/s)
+    bool vec4 = last >= 0 && a.in_stride[last] == 1 && a.out_shape[last] % 4 == 0 && a.out_shape[last] >= 32;
+    for (int i = 0; vec4 && i < last; ++i) vec4 = a.in_stride[i] % 4 == 0;   // (negative strides wrap: still multiples of 4)
+    if (vec4) {
+        a.out_shape[last] /= 4;
+        for (int i = 0; i < last; ++i) a.in_stride[i] = (size_t)((long long)a.in_stride[i] / 4);
+        n /= 4;
+    }
+    size_t blocks = (n + 255) / 256;
+    const size_t cap = (size_t)np::num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipStream_t s = np::stream();
+    if (n < (size_t(1) << 31)) {
+        if (vec4)
+            permute_gather_kernel<uint32_t, 4><<<(unsigned)blocks, 256, 0, s>>>(in, out, (uint32_t)n, a);
+        else
+            permute_gather_kernel<uint32_t, 1><<<(unsigned)blocks, 256, 0, s>>>(in, out, (uint32_t)n, a);
+    } else {
+        if (vec4)
+            permute_gather_kernel<uint64_t, 4><<<(unsigned)blocks, 256, 0, s>>>(in, out, (uint64_t)n, a);
+        else
+            permute_gather_kernel<uint64_t, 1><<<(unsigned)blocks, 256, 0, s>>>(in, out, (uint64_t)n, a);
+    }
+    NP_LAUNCH_CHECK("permute_gather_kernel");
+    return NP_OK;
 }
 
 // General permutation whose output-fastest axis is NOT the input-fastest axis (the default
@@ -384,15 +420,7 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
         a.out_shape[i] = (unsigned)host_shape[host_perm[i]];
         a.in_stride[i] = in_strides[host_perm[i]];
     }
-    size_t blocks = (n + 255) / 256;
-    const size_t cap = (size_t)np::num_cus() * 16;
-    if (blocks > cap) blocks = cap;
-    if (n < (size_t(1) << 31))
-        permute_gather_kernel<uint32_t><<<(unsigned)blocks, 256, 0, np::stream()>>>(in, out, (uint32_t)n, a);
-    else
-        permute_gather_kernel<uint64_t><<<(unsigned)blocks, 256, 0, np::stream()>>>(in, out, (uint64_t)n, a);
-    NP_LAUNCH_CHECK("permute_gather_kernel");
-    return NP_OK;
+    return launch_gather(in, out, n, a);
 }
 
 int np_strided_copy(const float *in, float *out, int ndim, const int *host_shape, const long long *host_strides) {
@@ -423,15 +451,7 @@ int np_strided_copy(const float *in, float *out, int ndim, const int *host_shape
         a.out_shape[i] = (unsigned)host_shape[i];
         a.in_stride[i] = (size_t)host_strides[i];   // negative strides wrap modulo 2^64, as pointer arithmetic does
     }
-    size_t blocks = (n + 255) / 256;
-    const size_t cap = (size_t)np::num_cus() * 16;
-    if (blocks > cap) blocks = cap;
-    if (n < (size_t(1) << 31))
-        permute_gather_kernel<uint32_t><<<(unsigned)blocks, 256, 0, np::stream()>>>(in, out, (uint32_t)n, a);
-    else
-        permute_gather_kernel<uint64_t><<<(unsigned)blocks, 256, 0, np::stream()>>>(in, out, (uint64_t)n, a);
-    NP_LAUNCH_CHECK("permute_gather_kernel");
-    return NP_OK;
+    return launch_gather(in, out, n, a);
 }
 
 }  // extern "C"
