@@ -920,6 +920,46 @@ static int xform_sum(const float *in, const float *in2, size_t n, float p0, floa
     return NP_OK;
 }
 
+// argmax / argmin with a handful of columns and many rows (inner <= 64): slabs of rows read as flat
+// memory, as reduce_small_inner does — a thread's column never changes (stride T is a multiple of
+// inner), its row advances by T / inner per step.  Partials [outer][blocks][inner].
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void argreduce_small_inner(const float *__restrict__ in, float *__restrict__ pv,
+                                                             unsigned *__restrict__ pi, unsigned axis_len,
+                                                             unsigned inner, unsigned rows_per_block) {
+    __shared__ float sv[256];
+    __shared__ unsigned si[256];
+    const unsigned T = (256u / inner) * inner;
+    const unsigned o = blockIdx.y, b = blockIdx.x;
+    const unsigned r0 = b * rows_per_block;
+    unsigned r1 = r0 + rows_per_block;
+    if (r1 > axis_len) r1 = axis_len;
+    const size_t cnt = (size_t)(r1 - r0) * inner;
+    const float *p = in + ((size_t)o * axis_len + r0) * inner;
+    ArgPair best{IS_MAX ? -INFINITY : INFINITY, 0xffffffffu};
+    if (threadIdx.x < T) {
+        unsigned row = r0 + threadIdx.x / inner;
+        const unsigned row_step = T / inner;
+        for (size_t e = threadIdx.x; e < cnt; e += T, row += row_step) {
+            const ArgPair c{arg_key<IS_MAX>(p[e], row), row};
+            best = (best.i == 0xffffffffu) ? c : arg_combine<IS_MAX>(best, c);
+        }
+    }
+    sv[threadIdx.x] = best.v;
+    si[threadIdx.x] = best.i;
+    __syncthreads();
+    if (threadIdx.x < inner) {
+        ArgPair r{sv[threadIdx.x], si[threadIdx.x]};
+        for (unsigned k = threadIdx.x + inner; k < T; k += inner) {
+            const ArgPair q{sv[k], si[k]};
+            if (q.i != 0xffffffffu) r = (r.i == 0xffffffffu) ? q : arg_combine<IS_MAX>(r, q);
+        }
+        const size_t at = ((size_t)o * gridDim.x + b) * inner + threadIdx.x;
+        pv[at] = r.v;
+        pi[at] = r.i;
+    }
+}
+
 // fold [outer][chunks][inner] partials: thread per output for short chunk lists, workgroup per output
 // for long ones
 static int launch_arg_fold(int is_max, const float *pv, const unsigned *pi, float *out, size_t outputs,
@@ -973,6 +1013,25 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
         return launch_arg_fold(is_max, (const float *)pv.ptr, (const unsigned *)pi.ptr, out, outer, chunks, 1);
     }
     const size_t total = outer * inner;
+    if (inner <= 64 && axis_len >= 512 && outer <= 65535 && total < (size_t)np::num_cus() * 8 * 64) {
+        const size_t target_wg = (size_t)np::num_cus() * 8;
+        size_t blocks = target_wg / outer;
+        const size_t max_blocks = axis_len / 256;
+        if (blocks > max_blocks) blocks = max_blocks;
+        if (blocks < 1) blocks = 1;
+        const size_t rows_per_block = (axis_len + blocks - 1) / blocks;
+        blocks = (axis_len + rows_per_block - 1) / rows_per_block;
+        np::Scratch pv, pi;
+        if (int rc = pv.alloc(total * blocks * sizeof(float))) return rc;
+        if (int rc = pi.alloc(total * blocks * sizeof(unsigned))) return rc;
+        const dim3 grid((unsigned)blocks, (unsigned)outer);
+        if (is_max)
+            argreduce_small_inner<true><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)inner, (unsigned)rows_per_block);
+        else
+            argreduce_small_inner<false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)inner, (unsigned)rows_per_block);
+        NP_LAUNCH_CHECK("argreduce_small_inner");
+        return launch_arg_fold(is_max, (const float *)pv.ptr, (const unsigned *)pi.ptr, out, total, blocks, inner);
+    }
     // few outputs, long axis (argmax over the rows of an N x 3 array): one thread per output would
     // leave the chip idle — cut the axis into chunks, then fold the (value, index) partials
     const size_t target_threads = (size_t)np::num_cus() * 2048;
