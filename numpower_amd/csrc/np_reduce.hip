@@ -688,7 +688,6 @@ __global__ __launch_bounds__(256) void reduce_rows_block(const float *__restrict
 // host side
 // ------------------------------------------------------------------------------------------
 
-inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 template <int OP, typename I>
 int launch_reduce_all(const float *in, size_t n, float *dev_out) {
