@@ -694,18 +694,21 @@ __device__ __forceinline__ void unary_all(float (&acc)[N], float p0, float p1) {
 template <int OP, int N>
 __device__ __forceinline__ void binary_all(float (&acc)[N], const float (&oth)[N], bool swap, bool quirk,
                                            const bool (&body)[N]) {
+    // `swap` and `quirk` are uniform: one branch each per step, not a select per element
     if (binary_has_quirk(OP) && quirk) {
+        if (swap) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-            const float x = swap ? oth[e] : acc[e], y = swap ? acc[e] : oth[e];
-            acc[e] = binary_apply<OP, binary_has_quirk(OP)>(x, y, body[e]);
+            for (int e = 0; e < N; ++e) acc[e] = binary_apply<OP, binary_has_quirk(OP)>(oth[e], acc[e], body[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < N; ++e) acc[e] = binary_apply<OP, binary_has_quirk(OP)>(acc[e], oth[e], body[e]);
         }
+    } else if (swap) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] = binary_apply<OP, false>(oth[e], acc[e], false);
     } else {
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-            const float x = swap ? oth[e] : acc[e], y = swap ? acc[e] : oth[e];
-            acc[e] = binary_apply<OP, false>(x, y, false);
-        }
+        for (int e = 0; e < N; ++e) acc[e] = binary_apply<OP, false>(acc[e], oth[e], false);
     }
 }
 
@@ -866,9 +869,20 @@ __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out
             }
             float oth[N];
             bool body[N];
+            // one uniform branch per step (written per element, the compiler emitted a branch ladder
+            // for every one of the N selects)
+            if (o.src_kind == FUSED_SRC_STREAM) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) oth[e] = nxt[e];
+            } else if (o.src_kind == FUSED_SRC_INPUT0) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) oth[e] = x0[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < N; ++e) oth[e] = o.scalar;
+            }
 #pragma unroll
             for (int e = 0; e < N; ++e) {
-                oth[e] = (o.src_kind == FUSED_SRC_STREAM) ? nxt[e] : (o.src_kind == FUSED_SRC_INPUT0) ? x0[e] : o.scalar;
                 // body_end is a multiple of 8 and float4 slots start at multiples of 4: one flag per slot
                 body[e] = (size_t)first[e / G] < o.body_end;
             }
@@ -879,12 +893,20 @@ __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out
         if (sink >= 0) {
             // reduction at the end of the chain: the value never goes to memory (uniform branch;
             // same combine rules as np_reduce_all: NaN never replaces in min / max)
+            if (sink == NP_SUM) {
 #pragma unroll
-            for (int e = 0; e < N; ++e) {
-                if (!live[e / G]) continue;
-                const float v = acc[e];
-                racc = sink == NP_SUM ? racc + v : sink == NP_PROD ? racc * v
-                     : sink == NP_MIN ? ((v < racc) ? v : racc) : ((v > racc) ? v : racc);
+                for (int e = 0; e < N; ++e) racc += live[e / G] ? acc[e] : 0.0f;
+            } else if (sink == NP_PROD) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) racc *= live[e / G] ? acc[e] : 1.0f;
+            } else if (sink == NP_MIN) {
+#pragma unroll
+                for (int e = 0; e < N; ++e)
+                    if (live[e / G] && acc[e] < racc) racc = acc[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < N; ++e)
+                    if (live[e / G] && acc[e] > racc) racc = acc[e];
             }
             continue;
         }
