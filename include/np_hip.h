@@ -300,6 +300,16 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
  * (manipulation.c:193-283) reduce to. */
 int np_strided_copy(const float *in, float *out, int ndim, const int *host_shape, const long long *host_strides);
 
+/* ---- device-side initializers (the reference's own phpbench suite, benchmarks/initializers/) ------
+ * The reference builds every array on the CPU (initializers.c) and a GPU user pays the PCIe copy on
+ * ->gpu(); zeros / ones / full are np_memset0 / np_fill above.
+ * np_identity: n x n, ones on the diagonal (NDArray_Identity, initializers.c:479-510).
+ * np_arange:   x[0] = (float)start, x[i] = (float)((double)x[i-1] + step) — NDArray_Arange's
+ *              recurrence (initializers.c:836-839), bit for bit, evaluated as per-binade arithmetic
+ *              segments (see np_layout.hip). */
+int np_identity(float *out, size_t n);
+int np_arange(float *out, double start, double step, size_t n);
+
 /* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 = whole-K plans only,
  * -2 = default planner again, -3 = default planner + always pad unaligned operands). */
 int np_sgemm_set_variant(int variant);

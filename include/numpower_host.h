@@ -125,6 +125,18 @@ typedef struct NDArray_Dims {   /* src/ndarray.h:40-43 */
 /* New contiguous array with the axes permuted (NULL = reverse all axes). */
 NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute);
 
+/* ---- initializers (src/initializers.c:458-510,655-660,818-841; the reference's benchmarks/initializers) ----
+ * Reference names create CPU arrays as in the reference; the ...On variants take the device, so an
+ * array can be born on the GPU without a PCIe copy.  NDArray_ArangeOn reproduces the reference's
+ * float recurrence bit for bit (np_arange); on NDARRAY_DEVICE_CPU it raises (host arithmetic stays
+ * the reference's own code). */
+NDArray *NDArray_Ones(const int *shape, int ndim, const char *type);
+NDArray *NDArray_Full(const int *shape, int ndim, double fill_value);
+NDArray *NDArray_Identity(int size);
+NDArray *NDArray_FullOn(const int *shape, int ndim, double fill_value, int device);
+NDArray *NDArray_IdentityOn(int size, int device);
+NDArray *NDArray_ArangeOn(double start, double stop, double step, int device);
+
 /* ---- views, layout and equality around the path ----
  * NDArray_ArrayEqual   logic.c:703-716      1 / 0 (0 on shape mismatch)
  * NDArray_AllClose     logic.c:750-772      1 / 0, -1 + error on shape / device mismatch (the

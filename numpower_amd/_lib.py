@@ -90,6 +90,8 @@ PROTOTYPES = {
     "np_transpose2d": (C.c_int, [_f32p, _f32p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "np_permute": (C.c_int, [_f32p, _f32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "np_strided_copy": (C.c_int, [_f32p, _f32p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    "np_identity": (C.c_int, [_f32p, C.c_size_t]),
+    "np_arange": (C.c_int, [_f32p, C.c_double, C.c_double, C.c_size_t]),
     "np_sgemm_set_variant": (C.c_int, [C.c_int]),
     "np_elementwise_set_variant": (C.c_int, [C.c_int]),
     "np_layout_set_variant": (C.c_int, [C.c_int]),

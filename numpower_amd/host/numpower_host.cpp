@@ -19,6 +19,7 @@
 //                    -> np_sgemm
 #include "numpower_host.h"
 
+#include <limits.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -496,6 +497,78 @@ NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute) {
         return nullptr;
     }
     return ret;
+}
+
+/* ---- initializers (src/initializers.c:379-510,633-660,818-841; the reference's phpbench suite) ---- */
+// The reference creates every array on the CPU; `...On(…, device)` lets it be born on the GPU
+// (np_fill / np_identity / np_arange: no PCIe copy).  With NDARRAY_DEVICE_CPU the fills are plain
+// store loops (placement plumbing); arange on the CPU stays the reference's own loop.
+NDArray *NDArray_FullOn(const int *shape, int ndim, double fill_value, int device) {   // initializers.c:655-660
+    if (ndim > 0 && !shape) return nullptr;
+    NDArray *rtn = new_array(shape, ndim, device, false);
+    if (!rtn) return nullptr;
+    if (!NDArray_Fill(rtn, (float)fill_value)) {
+        NDArray_FREE(rtn);
+        return nullptr;
+    }
+    return rtn;
+}
+NDArray *NDArray_Full(const int *shape, int ndim, double fill_value) {
+    return NDArray_FullOn(shape, ndim, fill_value, NDARRAY_DEVICE_CPU);
+}
+NDArray *NDArray_Ones(const int *shape, int ndim, const char *type) {   // initializers.c:458-470
+    (void)type;
+    return NDArray_FullOn(shape, ndim, 1.0, NDARRAY_DEVICE_CPU);
+}
+
+NDArray *NDArray_IdentityOn(int size, int device) {   // initializers.c:479-510
+    if (size < 0) {
+        throw_error("negative dimensions are not allowed");
+        return nullptr;
+    }
+    if (size == 0) {
+        const int shape[1] = {0};
+        return new_array(shape, 1, device, false);
+    }
+    const int shape[2] = {size, size};
+    if (device == NDARRAY_DEVICE_GPU) {
+        NDArray *rtn = new_array(shape, 2, device, false);
+        if (rtn && !dev_ok(np_identity(NDArray_FDATA(rtn), (size_t)size))) {
+            NDArray_FREE(rtn);
+            return nullptr;
+        }
+        return rtn;
+    }
+    NDArray *rtn = new_array(shape, 2, device, true);
+    if (rtn)
+        for (int i = 0; i < size; ++i) NDArray_FDATA(rtn)[(size_t)i * size + i] = 1.0f;
+    return rtn;
+}
+NDArray *NDArray_Identity(int size) { return NDArray_IdentityOn(size, NDARRAY_DEVICE_CPU); }
+
+NDArray *NDArray_ArangeOn(double start, double stop, double step, int device) {   // initializers.c:818-841
+    const double ivalue = ceil((stop - start) / step);   // safe_ceil_to_int, initializers.c:797-807
+    if (!(ivalue >= (double)INT_MIN && ivalue <= (double)INT_MAX)) {
+        throw_error("arange: overflow while computing length");
+        return nullptr;
+    }
+    const int length = (int)ivalue;
+    if (length <= 0) {
+        throw_error("arange: zero length");
+        return nullptr;
+    }
+    if (device != NDARRAY_DEVICE_GPU) {
+        throw_error("arange: operand is on the CPU; numpower_amd only computes on the GPU "
+                    "(the CPU path is the reference's own)");
+        return nullptr;
+    }
+    const int shape[1] = {length};
+    NDArray *rtn = new_array(shape, 1, device, false);
+    if (rtn && !dev_ok(np_arange(NDArray_FDATA(rtn), start, step, (size_t)length))) {
+        NDArray_FREE(rtn);
+        return nullptr;
+    }
+    return rtn;
 }
 
 /* ---- views, layout and equality around the path ---- */

@@ -113,6 +113,9 @@ def _load_host():
     sig["NDArray_Variance"] = (_P, [_P])
     sig["NDArray_Std"] = (_P, [_P])
     sig["NDArray_Average"] = (_P, [_P, _P])
+    sig["NDArray_FullOn"] = (_P, [ip, C.c_int, C.c_double, C.c_int])
+    sig["NDArray_IdentityOn"] = (_P, [C.c_int, C.c_int])
+    sig["NDArray_ArangeOn"] = (_P, [C.c_double, C.c_double, C.c_double, C.c_int])
     sig["NDArray_ArrayEqual"] = (C.c_int, [_P, _P])
     sig["NDArray_AllClose"] = (C.c_int, [_P, _P, C.c_float, C.c_float])
     sig["NDArray_ToContiguous"] = (_P, [_P])
@@ -221,6 +224,24 @@ class NDArray:
         return NDArray(h.NDArray_Zeros(s, len(shape), b"float32", device))
 
     # ---- placement ---------------------------------------------------------------------------
+    @staticmethod
+    def full(shape, fill_value, device=CPU) -> "NDArray":      # PHP_METHOD full, numpower.c:1214
+        h = _load_host()
+        arr = (C.c_int * max(len(shape), 1))(*[int(v) for v in shape])
+        return NDArray(h.NDArray_FullOn(arr, len(shape), float(fill_value), device))
+
+    @staticmethod
+    def ones(shape, device=CPU) -> "NDArray":                  # numpower.c:1261
+        return NDArray.full(shape, 1.0, device)
+
+    @staticmethod
+    def identity(size: int, device=CPU) -> "NDArray":          # numpower.c:940
+        return NDArray(_load_host().NDArray_IdentityOn(int(size), device))
+
+    @staticmethod
+    def arange(stop, start=0.0, step=1.0, device=GPU) -> "NDArray":   # numpower.c:1284-1302: (stop, start, step)
+        return NDArray(_load_host().NDArray_ArangeOn(float(start), float(stop), float(step), device))
+
     def gpu(self) -> "NDArray":
         """$a->gpu(): always a new array (NDArray_ToGPU, ndarray.c:1037-1068)."""
         return NDArray(self._h.NDArray_ToGPU(self._p))

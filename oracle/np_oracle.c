@@ -499,6 +499,14 @@ float oracle_all(const float *array, long n) {
     return 1;
 }
 
+/* NDArray_Arange (initializers.c:836-839): x[0] = (float)start; x[i] = x[i-1] + step with the sum
+ * formed in double (float + double) and stored as float */
+void oracle_arange(float *out, double start, double step, long n) {
+    if (n <= 0) return;
+    out[0] = (float)start;
+    for (long i = 1; i < n; i++) out[i] = out[i - 1] + step;
+}
+
 /* compare_ndarrays (logic.c:678-693), CPU branch: 1 unless some a[i] != b[i] (NaN != NaN) */
 int oracle_array_equal(const float *a, const float *b, long n) {
     int same = 1;

@@ -168,6 +168,35 @@ def transpose(x, axes=None) -> np.ndarray:
     return out.reshape(tuple(oshape[i] for i in range(x.ndim)))
 
 
+def arange(stop, start=0.0, step=1.0) -> np.ndarray:
+    """NDArray::arange(stop, start, step) -> NDArray_Arange(start, stop, step) (numpower.c:1284-1302,
+    initializers.c:818-841): length = ceil((stop - start) / step), then the float recurrence."""
+    import math
+    length = math.ceil((stop - start) / step)
+    if not (-2 ** 31 <= length <= 2 ** 31 - 1):
+        raise OracleError("arange: overflow while computing length")
+    if length <= 0:
+        raise OracleError("arange: zero length")
+    lib = load()
+    lib.oracle_arange.restype = None
+    lib.oracle_arange.argtypes = [_fp, C.c_double, C.c_double, C.c_long]
+    out = np.empty(int(length), dtype=np.float32)
+    lib.oracle_arange(_ptr(out), float(start), float(step), int(length))
+    return out
+
+
+def identity(size: int) -> np.ndarray:
+    """NDArray_Identity (initializers.c:479-510)."""
+    if size < 0:
+        raise OracleError("negative dimensions are not allowed")
+    return np.eye(size, dtype=np.float32) if size else np.empty((0,), np.float32)
+
+
+def full(shape, value) -> np.ndarray:
+    """NDArray_Full / NDArray_Ones / NDArray_Zeros (initializers.c:379-470,655-660)."""
+    return np.full(tuple(int(v) for v in shape), np.float32(value), dtype=np.float32)
+
+
 def array_equal(a, b) -> int:
     """NDArray_ArrayEqual (logic.c:703-716)."""
     a, b = _f(a), _f(b)

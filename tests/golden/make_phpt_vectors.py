@@ -26,6 +26,9 @@ FILES += [f for f in sorted((REF / "tests" / "logic").glob("*.phpt")) if "allclo
 # §8f row 3 (layout ops on device)
 FILES += sorted((REF / "tests" / "manipulation").glob("*.phpt"))
 FILES += [REF / "tests" / "linalg" / "003-ndarray-trace.phpt", REF / "tests" / "logic" / "002-ndarray-allclose.phpt"]
+# the initializers the reference's own phpbench suite times (benchmarks/initializers): born on the device here
+FILES += [REF / "tests" / "initializers" / n for n in ("045-ndarray-arange.phpt", "046-ndarray-identity.phpt",
+                                                       "047-ndarray-ones.phpt", "048-ndarray-zeros.phpt")]
 
 ASSIGN = re.compile(r"^\$(\w+) = \\NDArray::array\((.*)\);$")
 PRINT = re.compile(r"^(print_r|var_dump)\((.*)\);$")
@@ -96,6 +99,13 @@ def parse_file(path):
         if a:
             rec["vars"][a.group(1)] = ast.literal_eval(a.group(2))
             continue
+        la = re.match(r"^\$(\w+) = (\\NDArray::\w+\(.*\));$", line)
+        if la:                                  # $a = \NDArray::arange(20, 10, 1);  (no output)
+            call = static_call(CALL.match(la.group(2)))
+            call["assign"] = la.group(1)
+            call["to_array"] = False
+            rec["calls"].append(call)
+            continue
         p = PRINT.match(line)
         if not p:
             raise ValueError("%s: unsupported statement %r" % (path.name, line))
@@ -110,6 +120,10 @@ def parse_file(path):
         to_array = expr.endswith("->toArray()")
         if to_array:
             expr = expr[:-len("->toArray()")]
+        v = re.fullmatch(r"\$(\w+)", expr)
+        if v:                                   # print_r($a->toArray()) of an earlier assignment
+            rec["calls"].append({"kind": "var", "var": v.group(1), "to_array": to_array})
+            continue
         c = CALL.match(expr)
         if not c:
             raise ValueError("%s: unsupported expression %r" % (path.name, expr))

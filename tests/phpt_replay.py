@@ -89,8 +89,13 @@ LAYOUT_OPS = {"reshape", "flatten", "expand_dims", "append", "trace", "allclose"
 
 
 def _call(backend, env, call):
+    if call["kind"] == "var":
+        return env[call["var"]]
     op = call["op"]
     kw = call.get("kwargs", {})
+    if op in ("arange", "identity", "ones", "zeros"):     # initializers: plain numbers / a shape list
+        lits = [a["lit"] for a in call["args"]]
+        return getattr(backend, op)(*lits)
     if call["kind"] == "operator":
         args = [_operand(backend, env, a) for a in call["args"]]
         return backend.binary(OPERATORS[op], args[0], args[1])
@@ -126,6 +131,9 @@ def replay(backend, test) -> str:
     text = ""
     for call in test["calls"]:
         res = _call(backend, env, call)
+        if "assign" in call:                    # $a = \\NDArray::f(...): no output
+            env[call["assign"]] = res
+            continue
         if call.get("printer") == "var_dump":
             text += "bool(%s)\n" % ("true" if res else "false")
         elif call["to_array"]:
@@ -193,6 +201,19 @@ class GpuBackend:
     def allclose(self, x, y):
         return self.nd.allclose(x, y)
 
+    # initializers: born on the GPU
+    def arange(self, stop, start=0.0, step=1.0):
+        return self.nd.arange(stop, start, step, 1)
+
+    def identity(self, size):
+        return self.nd.identity(size, 1)
+
+    def ones(self, shape):
+        return self.nd.ones(shape, 1)
+
+    def zeros(self, shape):
+        return self.nd.zeros(shape, 1)
+
     def to_list(self, h):
         return (h.cpu() if h.isGPU() else h).toArray()
 
@@ -254,6 +275,18 @@ class OracleBackend:
 
     def allclose(self, x, y):
         return True if x is y else bool(self.o.allclose(x, y))   # identical handles: numpower.c:1372-1375
+
+    def arange(self, stop, start=0.0, step=1.0):
+        return self.o.arange(stop, start, step)
+
+    def identity(self, size):
+        return self.o.identity(size)
+
+    def ones(self, shape):
+        return self.o.full(shape, 1.0)
+
+    def zeros(self, shape):
+        return self.o.full(shape, 0.0)
 
     def to_list(self, h):
         return np.asarray(h, dtype=np.float64).tolist()
