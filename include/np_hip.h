@@ -109,6 +109,10 @@ typedef enum np_binary_op {
      * body/tail split, flags = 0 the tolerance form everywhere. */
     NP_EQUAL = 7, NP_NOT_EQUAL = 8, NP_GREATER = 9, NP_GREATER_EQUAL = 10, NP_LESS = 11,
     NP_LESS_EQUAL = 12,
+    /* NDArray_Maximum / NDArray_Minimum (ndarray.c:853-931): fmaxf / fminf per element, with glibc's
+     * rules — a NaN loses to a number, and when the operands compare equal (+0 / -0) the FIRST one is
+     * returned.  (The reference refuses GPU arrays here and its CPU loop stops at numel(a).) */
+    NP_MAXIMUM = 13, NP_MINIMUM = 14,
     NP_BINARY_OP_COUNT
 } np_binary_op;
 

@@ -115,6 +115,9 @@ NDArray *NDArray_Greater(NDArray *nda, NDArray *ndb);
 NDArray *NDArray_GreaterEqual(NDArray *nda, NDArray *ndb);
 NDArray *NDArray_Less(NDArray *nda, NDArray *ndb);
 NDArray *NDArray_LessEqual(NDArray *nda, NDArray *ndb);
+/* elementwise fmaxf / fminf with broadcast (ndarray.c:853-931; GPU arrays are refused there) */
+NDArray *NDArray_Maximum(NDArray *a, NDArray *b);
+NDArray *NDArray_Minimum(NDArray *a, NDArray *b);
 float NDArray_All(NDArray *a);   /* 1 / 0, reproduces the reference's CPU result (logic.c:25-58) */
 
 /* ---- layout (src/manipulation.c:68-130) ---- */
@@ -210,6 +213,7 @@ NDArray *NDArray_Matmul(NDArray *a, NDArray *b);
 NDArray *NDArray_FMatmul(NDArray *a, NDArray *b);
 NDArray *NDArray_Dot(NDArray *nda, NDArray *ndb);
 NDArray *NDArray_Outer(NDArray *a, NDArray *b);   /* linalg.c:724-751 */
+NDArray *NDArray_Inner(NDArray *nda, NDArray *ndb);   /* linalg.c:310-345: sum of all products */
 /* batch x M x K times batch x K x N -> batch x M x N (BASELINE config 5; no reference entry
  * point: linalg.c:239-242 rejects ndim > 2 with "Stack of matrices not allowed") */
 NDArray *NDArray_BatchedMatmul(NDArray *a, NDArray *b);

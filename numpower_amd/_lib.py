@@ -15,7 +15,7 @@ LIBDIR = Path(__file__).resolve().parent / "lib"
 NP_OK = 0
 BINARY_OPS = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "mod": 4, "pow": 5,
               "arctan2": 6, "equal": 7, "not_equal": 8, "greater": 9, "greater_equal": 10,
-              "less": 11, "less_equal": 12}
+              "less": 11, "less_equal": 12, "maximum": 13, "minimum": 14}
 NP_FULL, NP_SCALAR, NP_ROW, NP_COL = 0, 1, 2, 3
 NP_QUIRK_AVX_BODY = 1
 UNARY_OPS = {name: i for i, name in enumerate([

@@ -61,6 +61,9 @@ __device__ __forceinline__ float binary_apply(float a, float b, bool body) {
     if constexpr (OP == NP_GREATER_EQUAL) return (a >= b) ? 1.0f : 0.0f;
     if constexpr (OP == NP_LESS) return (a < b) ? 1.0f : 0.0f;
     if constexpr (OP == NP_LESS_EQUAL) return (a <= b) ? 1.0f : 0.0f;
+    // glibc's fmaxf / fminf (math/s_fmax_template.c): x if x >= y, y if x < y, else the non-NaN one
+    if constexpr (OP == NP_MAXIMUM) return (a >= b || b != b) ? a : b;
+    if constexpr (OP == NP_MINIMUM) return (a <= b || b != b) ? a : b;
     if constexpr (OP == NP_EQUAL) {
         // AVX2 body: _CMP_EQ_OQ (logic.c:541); tail and CUDA kernel: |a-b| <= 1e-7 (logic.c:552)
         if (QUIRK && body) return (a == b) ? 1.0f : 0.0f;
@@ -760,7 +763,7 @@ __device__ __forceinline__ void binary_dispatch(int op, float (&acc)[N], const f
     switch (op) {
         NP_BD(NP_ADD); NP_BD(NP_SUBTRACT); NP_BD(NP_MULTIPLY); NP_BD(NP_DIVIDE); NP_BD(NP_MOD); NP_BD(NP_POW);
         NP_BD(NP_ARCTAN2); NP_BD(NP_EQUAL); NP_BD(NP_NOT_EQUAL); NP_BD(NP_GREATER); NP_BD(NP_GREATER_EQUAL);
-        NP_BD(NP_LESS); NP_BD(NP_LESS_EQUAL);
+        NP_BD(NP_LESS); NP_BD(NP_LESS_EQUAL); NP_BD(NP_MAXIMUM); NP_BD(NP_MINIMUM);
         default: break;
     }
 #undef NP_BD
@@ -1155,6 +1158,8 @@ int np_binary(int op, const float *a, int a_kind, const float *b, int b_kind, fl
         case NP_GREATER_EQUAL: return dispatch_binary_quirk<NP_GREATER_EQUAL>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         case NP_LESS: return dispatch_binary_quirk<NP_LESS>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         case NP_LESS_EQUAL: return dispatch_binary_quirk<NP_LESS_EQUAL>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_MAXIMUM: return dispatch_binary_quirk<NP_MAXIMUM>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_MINIMUM: return dispatch_binary_quirk<NP_MINIMUM>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         default: return dispatch_binary_quirk<NP_ARCTAN2>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
     }
 }

@@ -453,6 +453,9 @@ NDArray *NDArray_Greater(NDArray *nda, NDArray *ndb) { return binary_op(NP_GREAT
 NDArray *NDArray_GreaterEqual(NDArray *nda, NDArray *ndb) { return binary_op(NP_GREATER_EQUAL, nda, ndb); }
 NDArray *NDArray_Less(NDArray *nda, NDArray *ndb) { return binary_op(NP_LESS, nda, ndb); }
 NDArray *NDArray_LessEqual(NDArray *nda, NDArray *ndb) { return binary_op(NP_LESS_EQUAL, nda, ndb); }
+/* ndarray.c:853-931: the reference throws "NDArray_Maximum not implemented for GPU" */
+NDArray *NDArray_Maximum(NDArray *a, NDArray *b) { return binary_op(NP_MAXIMUM, a, b); }
+NDArray *NDArray_Minimum(NDArray *a, NDArray *b) { return binary_op(NP_MINIMUM, a, b); }
 
 /* ---- layout (manipulation.c:68-130) ---- */
 NDArray *NDArray_Transpose(NDArray *a, NDArray_Dims *permute) {
@@ -1219,6 +1222,43 @@ NDArray *NDArray_Dot(NDArray *nda, NDArray *ndb) {   // linalg.c:354-393
     }
     throw_error("Not implemented");   // linalg.c:387-390
     return nullptr;
+}
+
+// NDArray_Inner (linalg.c:310-345): Multiply_Float then Sum_Float of EVERYTHING — for N-D operands it
+// is not a per-row inner product but one number, shaped (1, ..., 1).  Here: one fused multiply-sum
+// pass (np_fused_chain_reduce), the products never go to memory.
+NDArray *NDArray_Inner(NDArray *nda, NDArray *ndb) {
+    if (!nda || !ndb) return nullptr;
+    if (NDArray_NDIM(nda) == 0 && NDArray_NDIM(ndb) == 0) return NDArray_Multiply_Float(nda, ndb);
+    if (NDArray_DEVICE(nda) != NDArray_DEVICE(ndb)) {
+        throw_error("Device mismatch, both NDArray must be in the same device.");
+        return nullptr;
+    }
+    if (NDArray_NDIM(nda) == 0 || NDArray_NDIM(ndb) == 0 ||
+        nda->dimensions[nda->ndim - 1] != ndb->dimensions[ndb->ndim - 1]) {
+        throw_error("Shape is not aligned to perform the inner product.");
+        return nullptr;
+    }
+    // the chain starts from the larger operand (the other one broadcasts onto it)
+    NDArray *big = NDArray_NUMELEMENTS(nda) >= NDArray_NUMELEMENTS(ndb) ? nda : ndb;
+    NDArray *small = big == nda ? ndb : nda;
+    NDArray *inputs[2] = {big, small};
+    np_fused_op op{};
+    op.kind = NP_FUSED_BINARY;
+    op.op = NP_MULTIPLY;
+    op.operand = 1;
+    op.swap = big == nda ? 0 : 1;
+    numpower_host_clear_error();
+    const float total = NDArray_FusedChainReduce(inputs, 2, &op, 1, NP_SUM);
+    if (g_error[0]) return nullptr;
+    const int nd = NDArray_NDIM(nda);
+    if (nd <= 1) return NDArray_CreateFromFloatScalar(total);
+    int ones[NP_MAX_ND_HOST];
+    if (nd > NP_MAX_ND_HOST) return NDArray_CreateFromFloatScalar(total);
+    for (int i = 0; i < nd; ++i) ones[i] = 1;
+    NDArray *rtn = new_array(ones, nd, NDARRAY_DEVICE_CPU, false);
+    if (rtn) NDArray_FDATA(rtn)[0] = total;
+    return rtn;
 }
 
 NDArray *NDArray_Outer(NDArray *a, NDArray *b) {   // linalg.c:724-751

@@ -101,11 +101,12 @@ def _load_host():
         "NDArray_Matmul": (_P, [_P, _P]),
         "NDArray_Dot": (_P, [_P, _P]),
         "NDArray_Outer": (_P, [_P, _P]),
+        "NDArray_Inner": (_P, [_P, _P]),
         "NDArray_BatchedMatmul": (_P, [_P, _P]),
     }
     for name in ("Add", "Subtract", "Multiply", "Divide", "Mod", "Pow"):
         sig[f"NDArray_{name}_Float"] = (_P, [_P, _P])
-    for name in ("Equal", "NotEqual", "Greater", "GreaterEqual", "Less", "LessEqual"):
+    for name in ("Equal", "NotEqual", "Greater", "GreaterEqual", "Less", "LessEqual", "Maximum", "Minimum"):
         sig[f"NDArray_{name}"] = (_P, [_P, _P])
     sig["NDArray_All"] = (C.c_float, [_P])
     sig["NDArray_Transpose"] = (_P, [_P, C.POINTER(_CDims)])
@@ -151,7 +152,8 @@ _BINARY_FN = {"add": "NDArray_Add_Float", "subtract": "NDArray_Subtract_Float",
               # comparison family (src/logic.c), PHP methods equal / not_equal / greater / ...
               "equal": "NDArray_Equal", "not_equal": "NDArray_NotEqual", "greater": "NDArray_Greater",
               "greater_equal": "NDArray_GreaterEqual", "less": "NDArray_Less",
-              "less_equal": "NDArray_LessEqual"}
+              "less_equal": "NDArray_LessEqual",
+              "maximum": "NDArray_Maximum", "minimum": "NDArray_Minimum"}
 
 # PHP method name -> np_unary_op for the plain NDArrayMathGPU_ElementWise family
 # (method table numpower.c:5136-5174)
@@ -310,6 +312,8 @@ class NDArray:
     greater_equal = staticmethod(lambda a, b: NDArray._binary("greater_equal", a, b))
     less = staticmethod(lambda a, b: NDArray._binary("less", a, b))
     less_equal = staticmethod(lambda a, b: NDArray._binary("less_equal", a, b))
+    maximum = staticmethod(lambda a, b: NDArray._binary("maximum", a, b))
+    minimum = staticmethod(lambda a, b: NDArray._binary("minimum", a, b))
 
     @staticmethod
     def all(a) -> int:
@@ -539,6 +543,16 @@ class NDArray:
         return NDArray._wrap(h.NDArray_Dot(x._p, y._p))
 
     @staticmethod
+    def inner(a, b):         # PHP_METHOD inner
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        y, _ = NDArray._coerce(b)
+        return NDArray._wrap(h.NDArray_Inner(x._p, y._p))
+
+    def copy(self):          # PHP_METHOD copy: NDArray_Copy on the array's own device
+        return NDArray._wrap(_load_host().NDArray_Copy(self._p, C.cast(self._p, _P).contents.device))
+
+    @staticmethod
     def outer(a, b):
         h = _load_host()
         x, _ = NDArray._coerce(a)
@@ -563,5 +577,6 @@ def _install_unary_methods():
 
 
 _install_unary_methods()
+NDArray.negative = NDArray.negate   # PHP method name (numpower.c method table); float_negate underneath
 # `abs` goes through NDArray_Abs in the reference (arithmetics.c:934-947); same kernel
 nd = NDArray

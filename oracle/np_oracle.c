@@ -45,7 +45,7 @@
 
 enum { O_ADD = 0, O_SUBTRACT, O_MULTIPLY, O_DIVIDE, O_MOD, O_POW, O_ARCTAN2,
        /* comparisons, src/logic.c:67-670 */
-       O_EQUAL, O_NOT_EQUAL, O_GREATER, O_GREATER_EQUAL, O_LESS, O_LESS_EQUAL };
+       O_EQUAL, O_NOT_EQUAL, O_GREATER, O_GREATER_EQUAL, O_LESS, O_LESS_EQUAL, O_MAXIMUM, O_MINIMUM };
 
 enum {
     U_ABS = 0, U_SQRT, U_EXP, U_EXP2, U_EXPM1, U_LOG, U_LOG2, U_LOG10, U_LOG1P, U_LOGB,
@@ -253,7 +253,7 @@ static __m256 fix_negative_zero(__m256 vec) {   /* arithmetics.c:280-284 */
  * 527-541, 664-678, 788-802; pow has no AVX body :912-914). */
 static void binary_loop(int op, const float *a, const float *b, float *r, long n, long loop_numel_a) {
     long i = 0;
-    if (op != O_POW && op != O_ARCTAN2) {
+    if (op != O_POW && op != O_ARCTAN2 && op != O_MAXIMUM && op != O_MINIMUM) {
         for (i = 0; i < loop_numel_a - 7; i += 8) {
             __m256 v1 = _mm256_loadu_ps(&a[i]);
             __m256 v2 = _mm256_loadu_ps(&b[i]);
@@ -296,6 +296,10 @@ static void binary_loop(int op, const float *a, const float *b, float *r, long n
             case O_GREATER_EQUAL: r[i] = a[i] >= b[i] ? 1.0f : 0.0f; break;
             case O_LESS: r[i] = a[i] < b[i] ? 1.0f : 0.0f; break;
             case O_LESS_EQUAL: r[i] = a[i] <= b[i] ? 1.0f : 0.0f; break;
+            /* NDArray_Maximum / NDArray_Minimum: plain scalar loops over fmaxf / fminf (ndarray.c:880-882,
+             * 923-925; the loop bound there is numel(a) BEFORE the broadcast — restated over all elements) */
+            case O_MAXIMUM: r[i] = fmaxf(a[i], b[i]); break;
+            case O_MINIMUM: r[i] = fminf(a[i], b[i]); break;
             default: r[i] = atan2f(a[i], b[i]); break;   /* float_arctan2 via Map1ND, ndarray.c:716 */
         }
     }

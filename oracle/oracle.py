@@ -19,7 +19,7 @@ HERE = Path(__file__).resolve().parent
 LIB = HERE / "lib" / "libnp_oracle.so"
 
 BINARY = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "mod": 4, "pow": 5, "arctan2": 6,
-          "equal": 7, "not_equal": 8, "greater": 9, "greater_equal": 10, "less": 11, "less_equal": 12}
+          "equal": 7, "not_equal": 8, "greater": 9, "greater_equal": 10, "less": 11, "less_equal": 12, "maximum": 13, "minimum": 14}
 UNARY = {name: i for i, name in enumerate([
     "abs", "sqrt", "exp", "exp2", "expm1", "log", "log2", "log10", "log1p", "logb",
     "sin", "cos", "tan", "arcsin", "arccos", "arctan", "degrees", "radians",

@@ -107,3 +107,63 @@ def test_all_plain_flag(hip):
         v = C.c_int()
         check(load().np_all(d.ptr, x.size, 0, C.byref(v)))
         assert v.value == want
+
+
+@pytest.mark.parametrize("shape", [(1000, 1000), (257, 1001), (7,), (3, 5)])
+def test_maximum_minimum(shape, hip, oracle):
+    """NDArray_Maximum / NDArray_Minimum (ndarray.c:853-931; the reference refuses GPU arrays): glibc
+    fmaxf / fminf semantics — a NaN loses to a number — with scalar / row / column broadcast."""
+    from numpower_amd.ndarray import NDArray
+    a = synth.uniform(shape, 81, -2.0, 2.0)
+    b = synth.uniform(shape, 82, -2.0, 2.0)
+    a.reshape(-1)[::9] = np.nan
+    b.reshape(-1)[::13] = np.nan
+    b.reshape(-1)[4::17] = a.reshape(-1)[4::17]          # exact ties
+    ga, gb = NDArray.array(a).gpu(), NDArray.array(b).gpu()
+    for name, ref in (("maximum", np.fmax), ("minimum", np.fmin)):
+        got = getattr(NDArray, name)(ga, gb).cpu().numpy()
+        want = oracle.binary(name, a, b)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), name
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(got, ref(a, b), equal_nan=True)
+        # scalar operand, either side
+        got = getattr(NDArray, name)(ga, 0.5).cpu().numpy()
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(got, ref(a, np.float32(0.5)), equal_nan=True)
+        got = getattr(NDArray, name)(-0.25, gb).cpu().numpy()
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(got, ref(np.float32(-0.25), b), equal_nan=True)
+    if len(shape) == 2:
+        row = synth.uniform((shape[1],), 83, -1.0, 1.0)
+        col = synth.uniform((shape[0], 1), 84, -1.0, 1.0)
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(NDArray.maximum(ga, NDArray.array(row).gpu()).cpu().numpy(), np.fmax(a, row[None, :]), equal_nan=True)
+            assert np.array_equal(NDArray.minimum(NDArray.array(col).gpu(), ga).cpu().numpy(), np.fmin(col, a), equal_nan=True)
+    # inside a fused chain: relu(x * w) = maximum(x * w, 0)
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    c = np.nan_to_num(a, nan=0.5)
+    gc = NDArray.array(c).gpu()
+    fused = (gc.lazy() * 1.5).maximum(0.0).eval().cpu().numpy()
+    assert np.array_equal(fused, np.fmax(c * np.float32(1.5), np.float32(0.0)))
+
+
+def test_inner_copy_negative(hip, oracle):
+    from numpower_amd.ndarray import Error, NDArray
+    a = synth.uniform((300, 70), 85, -1.0, 1.0)
+    b = synth.uniform((300, 70), 86, -1.0, 1.0)
+    ga, gb = NDArray.array(a).gpu(), NDArray.array(b).gpu()
+    want = float((a.astype(np.float64) * b).sum())
+    got = NDArray.inner(ga, gb)                       # N-D: one number shaped (1, 1)
+    assert got.shape() == [1, 1] and abs(got.toArray()[0][0] - want) <= 1e-5 * np.abs(a * b).sum()
+    v = NDArray.inner(NDArray.array(a[0]).gpu(), NDArray.array(b[0]).gpu())
+    assert isinstance(v, float) and abs(v - float((a[0].astype(np.float64) * b[0]).sum())) <= 1e-5 * np.abs(a[0] * b[0]).sum()
+    row = NDArray.inner(ga, NDArray.array(b[0]).gpu())   # (300, 70) . (70,): Multiply broadcasts, then sums everything
+    assert abs(row.toArray()[0][0] - float((a.astype(np.float64) * b[0][None, :]).sum())) <= 1e-5 * np.abs(a * b[0]).sum()
+    with pytest.raises(Error, match="Shape is not aligned"):
+        NDArray.inner(ga, NDArray.array(np.ones((300, 69), np.float32)).gpu())
+    c = ga.copy()
+    assert c.isGPU() and np.array_equal(c.cpu().numpy(), a)
+    ga.fill(0.0)
+    assert np.array_equal(c.cpu().numpy(), a)          # a real copy
+    assert np.array_equal(NDArray.negative(gb).cpu().numpy(), -b)
