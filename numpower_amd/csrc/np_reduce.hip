@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void reduce_axis_generic(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------
-// axis reduction, small inner (2..64 columns: column sums of an N x 3 point cloud): the generic
+// axis reduction, small inner (2..128 columns: column sums of an N x 3 point cloud): the generic
 // kernel would give each of the few columns ONE thread.  Here a workgroup reads its slab of rows as
 // flat memory (coalesced dword loads); with T = (256 / inner) * inner active threads and a stride
 // of T the column of a thread never changes (t % inner), so it accumulates in a register; LDS folds
@@ -783,7 +783,10 @@ int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t in
             NP_LAUNCH_CHECK("reduce_rows_wave");
             return NP_OK;
         }
-    } else if (inner % 4 == 0 && outer <= 65535) {   // any pointer alignment: dword-aligned float4 accesses
+    } else if (inner % 4 == 0 && outer <= 65535 &&
+               !(inner <= 128 && axis_len >= 512 && outer * inner < target_wg * 64)) {
+        // (a handful of float4 columns would use a fraction of the 64-column tile: those go to the
+        // flat small-inner kernel below; any pointer alignment: dword-aligned float4 accesses)
         const size_t inner4 = inner / 4;
         const size_t splits = choose_splits(outer, axis_len, inner4);
         const dim3 grid((unsigned)((inner4 + 63) / 64), (unsigned)splits, (unsigned)outer);
@@ -806,7 +809,7 @@ int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t in
                                                          quirk, (I)body_end);
         NP_LAUNCH_CHECK("reduce_axis_cols(pass 2)");
         return NP_OK;
-    } else if (inner <= 64 && axis_len >= 512 && outer <= 65535 && outer * inner < target_wg * 64) {
+    } else if (inner <= 128 && axis_len >= 512 && outer <= 65535 && outer * inner < target_wg * 64) {
         // a handful of columns, many rows: flat coalesced slabs, then fold the per-slab partials
         size_t blocks = target_wg / outer;
         const size_t max_blocks = axis_len / 256;

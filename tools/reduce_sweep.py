@@ -29,7 +29,8 @@ print("axis reductions")
 CASES = [((65536, 4096), 0), ((65536, 4096), 1), ((4096, 65536), 0), ((4096, 65536), 1), ((1000, 1000), 0), ((1000, 1000), 1),
          ((256, 1024, 1024), 1), ((256, 1024, 1024), 0), ((256, 1024, 1024), 2), ((30_000_000, 3), 0), ((30_000_000, 3), 1),
          ((3, 30_000_000), 0), ((3, 30_000_000), 1), ((100_000_000, 1), 0), ((16, 16, 16, 16, 16, 64), 3), ((10007, 10007), 0),
-         ((10007, 10007), 1)]
+         ((10007, 10007), 1), ((30_000_000, 4), 0), ((12_000_000, 8), 0), ((100_000, 64, 16), 1), ((3, 10_000_000, 2), 1),
+         ((1_000_000, 64), 0), ((400_000, 128), 0)]
 for shape, axis in CASES:
     n = int(np.prod(shape))
     x = D.DeviceArray(shape); D.fill(x, 1.0)
