@@ -1037,6 +1037,10 @@ int np_sgemm_set_variant(int variant) {
         g_force_pad = variant == -3;
         return NP_OK;
     }
+    // variants >= 1000 switch parts of the pipelined kernel OFF to time them (tools/gemm_ab.py): the
+    // products they compute are wrong by construction, so they need an explicit opt-in
+    if (variant >= 1000 && !getenv("NP_ALLOW_ABLATION"))
+        return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: ablation variants need NP_ALLOW_ABLATION=1");
     g_variant = variant;
     return NP_OK;
 }
