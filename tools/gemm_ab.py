@@ -1,5 +1,7 @@
 """A/B harness (dev tool): interleaved rounds over sgemm variants at 4096^3 (+ correctness)."""
+import os
 import sys, json
+os.environ.setdefault("NP_ALLOW_ABLATION", "1")   # variants >= 1000 time parts of the kernel by switching them off
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np
