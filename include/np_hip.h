@@ -66,6 +66,16 @@ int np_timer_stop(void *timer);
 int np_timer_elapsed_ms(void *timer, float *host_ms);   /* blocks until stop event done */
 int np_timer_destroy(void *timer);
 
+/* Launch-bound sequences as HIP graphs: capture what the library enqueues between begin and end,
+ * replay it with one launch.  The reference synchronises after every kernel (cuda_math.cu:1104-1109),
+ * so a chain of small ops costs a launch + sync each; a captured chain costs one graph launch.
+ * Inside the captured region: no host-result calls (np_reduce_all, np_read_float, np_memcpy_*2h/h2d
+ * ...), and warm the sequence up once first so the pool does not have to hipMalloc. */
+int np_graph_begin(void);
+int np_graph_end(void **graph_exec);
+int np_graph_launch(void *graph_exec);
+int np_graph_destroy(void *graph_exec);
+
 /* ---- device-buffer layer (replaces src/gpu_alloc.c) ---------------------------------- */
 
 /* vmalloc (gpu_alloc.c:11-17).  size_t instead of the reference's `unsigned int` (4 GiB cap).

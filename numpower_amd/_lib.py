@@ -52,6 +52,10 @@ PROTOTYPES = {
     "np_timer_stop": (C.c_int, [C.c_void_p]),
     "np_timer_elapsed_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "np_timer_destroy": (C.c_int, [C.c_void_p]),
+    "np_graph_begin": (C.c_int, []),
+    "np_graph_end": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "np_graph_launch": (C.c_int, [C.c_void_p]),
+    "np_graph_destroy": (C.c_int, [C.c_void_p]),
     "np_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "np_free": (C.c_int, [C.c_void_p]),
     "np_live_allocs": (C.c_long, []),

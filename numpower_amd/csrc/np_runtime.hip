@@ -205,6 +205,44 @@ int np_timer_destroy(void *timer) {
     return NP_OK;
 }
 
+/* ---- launch-bound sequences as HIP graphs ---- */
+// A script that applies the same short sequence of ops to small arrays over and over is bound by
+// launch latency (~5 us per kernel), not by the kernels.  Everything this library enqueues goes to
+// one stream and nothing but the host-result calls synchronises, so a sequence can be captured
+// once and replayed as ONE graph launch.  Rules of capture (HIP's): no call that returns a value to
+// the host or copies to/from pageable memory inside the captured region, and run the sequence once
+// beforehand so that the pool already holds every block it will ask for (hipMalloc cannot be
+// captured).
+int np_graph_begin(void) {
+    if (int rc = np::ensure_init()) return rc;
+    NP_HIP_CHECK(hipStreamBeginCapture(rt().cur_stream, hipStreamCaptureModeThreadLocal));
+    return NP_OK;
+}
+
+int np_graph_end(void **graph_exec) {
+    if (!graph_exec) return np::fail(NP_ERR_INVALID, "np_graph_end: null output");
+    *graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    NP_HIP_CHECK(hipStreamEndCapture(rt().cur_stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return np::fail(NP_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    *graph_exec = (void *)exec;
+    return NP_OK;
+}
+
+int np_graph_launch(void *graph_exec) {
+    if (!graph_exec) return np::fail(NP_ERR_INVALID, "np_graph_launch: null graph");
+    NP_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, rt().cur_stream));
+    return NP_OK;
+}
+
+int np_graph_destroy(void *graph_exec) {
+    if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+    return NP_OK;
+}
+
 /* ---- device buffers ---- */
 
 int np_malloc(void **dev_ptr, size_t bytes) {
