@@ -56,7 +56,8 @@ def _worker(rank, world, port, batch, gather, q, kind="matmul"):
         def compute(x, y, out):
             torch.bmm(x, y, out=out)
 
-        res = parallel.sharded_batched_matmul(a, b, batch, compute, dist=dist, gather=gather)
+        res = parallel.sharded_batched_matmul(a, b, batch, compute, dist=dist, gather=gather,
+                                              overlap_chunks=2 if kind == "overlap" else 1)
         q.put((rank, res.numpy()))
     finally:
         dist.destroy_process_group()
@@ -109,3 +110,12 @@ def test_sharded_elementwise(world, batch, gather):
         else:
             slab = parallel.slab_for(batch, world, rank)
             np.testing.assert_array_equal(out[rank], want[slab.start:slab.stop])
+
+
+def test_sharded_batched_matmul_overlapped_gather():
+    """overlap_chunks: per-piece compute + asynchronous all-gather into the right windows of the
+    replicated result (world 2, slabs of 4 in 2 pieces)."""
+    out = _run(2, 8, gather=True, kind="overlap")
+    want = _expected(8)
+    for rank in range(2):
+        np.testing.assert_allclose(out[rank], want, rtol=1e-6, atol=1e-6)
