@@ -462,7 +462,9 @@ __global__ __launch_bounds__(256, 2) void sgemm_pipe_kernel(GemmArgs g) {
 // are still required).  Out-of-range A rows and B columns are fetched from CLAMPED addresses (row
 // M-1, columns N-4..N-1): whatever lands in those LDS slots only ever reaches C rows >= M or
 // columns >= N, which the guarded epilogue does not store — no zero fill, no extra work in the loop.
-template <bool EDGE>
+// KTAIL = K % 16 != 0 (its own instantiation: the tail bookkeeping costs the aligned case 0.5-1 %
+// when it is merely a run-time flag, profiles/r01/gemm_ktail_ab.log).
+template <bool EDGE, bool KTAIL>
 __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     if (g.K_last && blockIdx.z + 1 == gridDim.z) g.K = g.K_last;   // uniform: split-K remainder chunk
     constexpr int BM = 256, BN = 128, BK = 16;
@@ -492,7 +494,14 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     // A: the wave moves 4 chunks of 16 rows x 64 B; lane = (row_in_chunk, slot); slot p of row r
     //    fetches k-chunk p ^ ((r >> 2) & 3).
     // B: the wave moves 2 chunks of 2 k-rows x 512 B, straight row-major.
+    // K tail: the last K-tile may hold only kr = 4, 8 or 12 valid k (K % 16, rows are float4-aligned so
+    // K % 4 == 0).  Its out-of-range slots are fetched from clamped addresses (k-chunk 0 / B row
+    // kr-1: valid memory) and overwritten with zeros by the lane that DMA'd them, after they have
+    // landed and before the barrier that publishes the tile — the loop itself is unchanged.
+    const unsigned nk = (g.K + BK - 1) / BK;
+    const unsigned kr = g.K - (nk - 1) * BK;          // 16 = no tail
     const float *a_src[4];
+    unsigned a_q[4];                                   // k-chunk (0..3) this lane fetches for chunk c
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const unsigned r = (wave * 4 + c) * 16 + (lane >> 2);
@@ -500,33 +509,52 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
         unsigned grow = m0 + r;
         if (EDGE && grow >= g.M) grow = g.M - 1;
         a_src[c] = A + (size_t)grow * g.lda + q * 4;
+        a_q[c] = q;
     }
     const float *b_src[2];
+    unsigned b_k[2];                                   // k row (0..15) this lane fetches for chunk c
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const unsigned krow = (wave * 2 + c) * 2 + (lane >> 5);
         unsigned gcol = n0 + (lane & 31) * 4;
         if (EDGE && gcol + 4 > g.N) gcol = g.N - 4;
         b_src[c] = B + (size_t)krow * g.ldb + gcol;
+        b_k[c] = krow;
     }
     const size_t b_step = (size_t)BK * g.ldb;
 
-    auto dma_tile = [&](unsigned buf) {
+    auto dma_tile = [&](unsigned buf, bool tail) {   // tail: this is the last tile and kr < 16 (uniform)
         float *as = As + buf * A_SZ + wave * 1024;   // 4 chunks x 256 floats per wave
         float *bs = Bs + buf * B_SZ + wave * 512;    // 2 chunks x 256 floats per wave
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)a_src[c],
+            const float *src = a_src[c];
+            if (KTAIL && tail && a_q[c] * 4 >= kr) src -= a_q[c] * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(as + c * 256), 16, 0, 0);
             a_src[c] += BK;
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)b_src[c],
+            const float *src = b_src[c];
+            if (KTAIL && tail && b_k[c] >= kr) src -= (size_t)(b_k[c] - (kr - 1)) * g.ldb;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(bs + c * 256), 16, 0, 0);
             b_src[c] += b_step;
         }
     };
+    // after the tail tile has landed (vmcnt(0)): zero the slots this lane fetched from clamped addresses
+    auto zero_tail = [&](unsigned buf) {
+        float *as = As + buf * A_SZ + wave * 1024 + lane * 4;
+        float *bs = Bs + buf * B_SZ + wave * 512 + lane * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (a_q[c] * 4 >= kr) *(v4f *)(as + c * 256) = v4f{0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (b_k[c] >= kr) *(v4f *)(bs + c * 256) = v4f{0, 0, 0, 0};
+    };
+    const bool has_tail = KTAIL && kr < BK;
 
     v16f acc[TM][TN];
 #pragma unroll
@@ -565,17 +593,18 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a4[i][s], f.bv[s][j], acc[i][j], 0, 0, 0);
     };
 
-    const unsigned nk = g.K / BK;
     Frag f0, f1;
-    dma_tile(0);
-    if (nk > 1) dma_tile(1);
+    dma_tile(0, has_tail && nk == 1);
+    if (nk > 1) dma_tile(1, has_tail && nk == 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (has_tail && nk <= 2) zero_tail(nk - 1);
     __syncthreads();
     read_frag(f0, 0, 0);
 
     // One K-tile.  DMA / NEXT are compile-time so that the steady-state iteration is a single
     // basic block per half and the issue-order hints below can interleave across it.
     unsigned cur = 0;
+    unsigned kt = 0;
     auto k_tile = [&](auto dma_c, auto next_c) {
         constexpr bool DMA = decltype(dma_c)::value, NEXT = decltype(next_c)::value;
         const unsigned nxt = (cur == 2) ? 0 : cur + 1;
@@ -597,11 +626,12 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
             // tile kt+1 (DMA issued one tile ago) must have landed for every wave before anyone
             // reads it; the same barrier tells everyone that tile kt-1's buffer is free
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (has_tail && kt + 2 == nk) zero_tail(nxt);   // tile kt+1 is the ragged last one
             __syncthreads();
         }
         // second half: MFMAs of k group 1 with 6 LDS-DMA issues (tile kt+2 -> the buffer tile kt-1
         // vacated) and the 8 LDS reads of the next tile's group 0, each behind its own MFMA
-        if constexpr (DMA) dma_tile(nn);
+        if constexpr (DMA) dma_tile(nn, has_tail && kt + 3 == nk);
         if constexpr (NEXT) read_frag(f0, nxt, 0);
         mfma_group(f1);
         if constexpr (DMA) {
@@ -624,7 +654,9 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     };
     using T = std::true_type;
     using F = std::false_type;
-    unsigned kt = 0;
+    // (a compile-time "tail DMA" variant of k_tile, peeled into its own iteration, pushed the kernel
+    // to 256 VGPRs + 600 B/lane of scratch and 4096^3 from 144 to 130 TFLOP/s: the flag stays uniform
+    // run-time state)
     for (; kt + 2 < nk; ++kt) k_tile(T{}, T{});
     if (kt + 1 < nk) k_tile(F{}, T{});
     k_tile(F{}, F{});
@@ -805,10 +837,16 @@ int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
         // 256 MiB Infinity Cache) but the workgroups of one XCD share panels in its L2, L2->fabric
         // reads 944 -> 691 MB per launch (tools/gemm_swizzle_pmc.py, profiles/r01/gemm_swizzle_pmc.log)
         if (g_variant == 0 && g.tiles_m >= 8) g.swizzle = 4;
-        if (g.M % 256 || g.N % 128 || g.n_store)
-            sgemm_dma_kernel<true><<<grid, 256, 0, np::stream()>>>(g);
+        const bool edge = g.M % 256 || g.N % 128 || g.n_store;
+        const bool ktail = g.K % 16 || g.K_last % 16;
+        if (edge && ktail)
+            sgemm_dma_kernel<true, true><<<grid, 256, 0, np::stream()>>>(g);
+        else if (edge)
+            sgemm_dma_kernel<true, false><<<grid, 256, 0, np::stream()>>>(g);
+        else if (ktail)
+            sgemm_dma_kernel<false, true><<<grid, 256, 0, np::stream()>>>(g);
         else
-            sgemm_dma_kernel<false><<<grid, 256, 0, np::stream()>>>(g);
+            sgemm_dma_kernel<false, false><<<grid, 256, 0, np::stream()>>>(g);
         NP_LAUNCH_CHECK("sgemm_dma_kernel");
         return NP_OK;
     }
@@ -912,7 +950,7 @@ int launch_padded(const GemmArgs &g, const Plan &p, size_t Kp, size_t Np) {
 
 int launch_planned(GemmArgs g, size_t batch, bool vec) {
     const size_t M = g.M, N = g.N, K = g.K;
-    const bool dma_ok = vec && K % 16 == 0 && N >= 4;   // M, N edges: sgemm_dma_kernel<EDGE>
+    const bool dma_ok = vec && N >= 4;   // M, N edges: sgemm_dma_kernel<EDGE>; K % 16: zeroed tail slots
     Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec);
     static const bool debug = getenv("NP_SGEMM_PLAN_DEBUG") != nullptr;
     if (!dma_ok && batch == 1 && g_splitk && N >= 1) {
@@ -1014,7 +1052,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
         case 5: return launch_sgemm_pipe<128, 128, 0>(g, (unsigned)batch, vec);
         case 6: return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
         case 7:
-            if (vec && K % 16 == 0 && N >= 4) return launch_cfg(0, g, (unsigned)batch, vec);
+            if (vec && N >= 4) return launch_cfg(0, g, (unsigned)batch, vec);
             return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
         default: break;
     }

@@ -457,7 +457,11 @@ def test_matmul_splitk_small_result_long_k(mnk, hip, oracle):
 
 
 @pytest.mark.parametrize("mnk", [(2000, 2004, 2000), (300, 516, 2048), (257, 4, 4096), (3, 132, 64), (255, 127, 16),
-                                 (513, 260, 1024), (4000, 4000, 496)])
+                                 (513, 260, 1024), (4000, 4000, 496),
+                                 # K tails (K % 16 = 4, 8, 12): clamped fetch + zeroed LDS slots, incl. the
+                                 # cases where the ragged tile is loaded by the prologue (K < 32)
+                                 (1000, 1000, 1000), (512, 256, 4), (512, 256, 8), (512, 256, 12), (512, 256, 20),
+                                 (512, 256, 28), (256, 128, 36), (300, 260, 44), (1500, 1500, 1500), (64, 64, 3000)])
 def test_matmul_dma_edge_kernel(mnk, hip):
     """sgemm_dma_kernel<EDGE> forced (variant 7): M / N not multiples of the 256 x 128 tile — source
     rows / columns are clamped, the garbage only reaches rows >= M / columns >= N that the guarded
@@ -469,6 +473,8 @@ def test_matmul_dma_edge_kernel(mnk, hip):
     m, n, k = mnk
     a = synth.uniform((m, k), 33, -1.0, 1.0)
     b = synth.uniform((k, n), 34, -1.0, 1.0)
+    # A and B sit at the very end of poisoned allocations: a K tail that read past its row would pick up
+    # NaNs (and the clamped fetches must stay inside the buffers)
     da, db = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b)
     pad = 4096                                             # floats of canary before and after C
     frame = D.DeviceArray((m * n + 2 * pad,))
