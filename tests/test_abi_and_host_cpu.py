@@ -102,3 +102,45 @@ def test_product_never_imports_the_oracle():
     for path in (ROOT / "numpower_amd").rglob("*"):
         if path.suffix in (".py", ".hip", ".cpp", ".h") and path.name != "build.py":
             assert not banned.search(path.read_text()), "%s references the oracle" % path
+
+
+def test_views_and_initializers_on_cpu_arrays():
+    """Metadata-only host functions work on CPU-resident arrays too (no kernel is needed): reshape /
+    flatten / expand_dims / contiguous slices are views or plain copies, full / identity are plain
+    stores; anything that would need arithmetic or a gather on the host raises."""
+    from numpower_amd.ndarray import Error, NDArray
+    x = np.arange(24, dtype=np.float32).reshape(4, 6)
+    a = NDArray.array(x)
+    r = NDArray.reshape(a, [3, 8])
+    assert not r.isGPU() and r.toArray() == x.reshape(3, 8).tolist()
+    assert NDArray.flatten(a).toArray() == x.reshape(-1).tolist()
+    assert NDArray.expand_dims(a, [0, -1]).shape() == [1, 4, 6, 1]
+    assert a.slice([1, 3]).toArray() == x[1:3].tolist()          # contiguous rows: a view
+    assert a.slice([2]).toArray() == x[2].tolist()
+    assert a.slice([-1]).toArray() == x[3].tolist()
+    assert a.slice([1, 3]).slice([0, 1]).toArray() == x[1:2].tolist()
+    with pytest.raises(Error, match="only computes on the GPU"):
+        a.slice([0, 4, 2])                                        # strided: would need a gather
+    with pytest.raises(Error, match="too many indices for array."):
+        a.slice([0], [0], [0])
+    with pytest.raises(Error, match="slice step cannot be zero"):
+        a.slice([0, 2, 0])
+    with pytest.raises(Error, match="incompatible shape in reshape call."):
+        NDArray.reshape(a, [5, 5])
+    with pytest.raises(Error, match="invalid axis or axes provided."):
+        NDArray.expand_dims(a, 7)
+    assert NDArray.full([2, 3], 1.5).toArray() == [[1.5] * 3] * 2
+    assert NDArray.ones([3]).toArray() == [1.0, 1.0, 1.0]
+    assert NDArray.identity(2).toArray() == [[1.0, 0.0], [0.0, 1.0]]
+    assert NDArray.identity(0).shape() == [0]
+    with pytest.raises(Error, match="negative dimensions are not allowed"):
+        NDArray.identity(-1)
+    with pytest.raises(Error, match="only computes on the GPU"):
+        NDArray.arange(10, 0, 1, 0)
+    with pytest.raises(Error, match="arange: zero length"):
+        NDArray.arange(0, 5, 1, 0)
+    # compute entry points refuse CPU arrays with the same message everywhere
+    for fn in (lambda: NDArray.maximum(a, a), lambda: NDArray.array_equal(a, a), lambda: NDArray.diagonal(a),
+               lambda: NDArray.outer(NDArray.array(x[0]), NDArray.array(x[1])), lambda: a.contiguous()):
+        with pytest.raises(Error, match="only computes on the GPU"):
+            fn()
