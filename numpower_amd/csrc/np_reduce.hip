@@ -363,7 +363,16 @@ __global__ __launch_bounds__(256) void argreduce_chunks_kernel(const float *__re
         if (a1 > axis_len) a1 = axis_len;
         const float *p = in + o * axis_len * inner + j;
         ArgPair best{arg_key<IS_MAX>(p[(size_t)a0 * inner], a0), a0};
-        for (unsigned a = a0 + 1; a < a1; ++a) {
+        // four loads in flight; ties are broken by index, so the combining order does not matter
+        unsigned a = a0 + 1;
+        for (; a + 3 < a1; a += 4) {
+            const float x0 = p[(size_t)a * inner], x1 = p[(size_t)(a + 1) * inner];
+            const float x2 = p[(size_t)(a + 2) * inner], x3 = p[(size_t)(a + 3) * inner];
+            const ArgPair q0{arg_key<IS_MAX>(x0, a), a}, q1{arg_key<IS_MAX>(x1, a + 1), a + 1};
+            const ArgPair q2{arg_key<IS_MAX>(x2, a + 2), a + 2}, q3{arg_key<IS_MAX>(x3, a + 3), a + 3};
+            best = arg_combine<IS_MAX>(best, arg_combine<IS_MAX>(arg_combine<IS_MAX>(q0, q1), arg_combine<IS_MAX>(q2, q3)));
+        }
+        for (; a < a1; ++a) {
             const ArgPair q{arg_key<IS_MAX>(p[(size_t)a * inner], a), a};
             best = arg_combine<IS_MAX>(best, q);
         }
@@ -383,7 +392,15 @@ __global__ __launch_bounds__(256) void argreduce_generic_kernel(const float *__r
         const size_t o = idx / inner, j = idx % inner;
         const float *p = in + o * axis_len * inner + j;
         ArgPair best{arg_key<IS_MAX>(p[0], 0), 0};
-        for (unsigned a = 1; a < axis_len; ++a) {
+        unsigned a = 1;
+        for (; a + 3 < axis_len; a += 4) {   // four loads in flight (index tie-break: order-independent)
+            const float x0 = p[(size_t)a * inner], x1 = p[(size_t)(a + 1) * inner];
+            const float x2 = p[(size_t)(a + 2) * inner], x3 = p[(size_t)(a + 3) * inner];
+            const ArgPair q0{arg_key<IS_MAX>(x0, a), a}, q1{arg_key<IS_MAX>(x1, a + 1), a + 1};
+            const ArgPair q2{arg_key<IS_MAX>(x2, a + 2), a + 2}, q3{arg_key<IS_MAX>(x3, a + 3), a + 3};
+            best = arg_combine<IS_MAX>(best, arg_combine<IS_MAX>(arg_combine<IS_MAX>(q0, q1), arg_combine<IS_MAX>(q2, q3)));
+        }
+        for (; a < axis_len; ++a) {
             const ArgPair c{arg_key<IS_MAX>(p[(size_t)a * inner], a), a};
             best = arg_combine<IS_MAX>(best, c);
         }
