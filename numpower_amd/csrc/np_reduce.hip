@@ -654,6 +654,38 @@ __global__ __launch_bounds__(256) void reduce_rows_wave(const float *__restrict_
     }
 }
 
+// Short rows (5 .. ~500 elements): L lanes per row (L = 2 .. 32, a power of two), 64 / L rows per wave.
+// A wave per row would use 8 of its 64 lanes on a 33-element row (0.7 TB/s); a thread per row reads
+// with a large stride.  Lanes of a group read the row interleaved (coalesced inside the group,
+// neighbouring groups read neighbouring rows) and fold with xor-shuffles.
+template <int OP, int L, typename I>
+__global__ __launch_bounds__(256) void reduce_rows_group(const float *__restrict__ in, float *__restrict__ out,
+                                                         I rows, I len, float mean_div, int prod_quirk) {
+    const I row = ((I)blockIdx.x * 256 + threadIdx.x) / L;
+    const unsigned l = threadIdx.x % L;
+    float r = r_identity<OP>();
+    if (row < rows) {
+        const float *p = in + (size_t)row * len;
+        float r1 = r;
+        I j = l;
+        for (; j + L < len; j += 2 * L) {
+            r = r_combine<OP>(r, p[j]);
+            r1 = r_combine<OP>(r1, p[j + L]);
+        }
+        if (j < len) r = r_combine<OP>(r, p[j]);
+        r = r_combine<OP>(r, r1);
+    }
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) r = r_combine<OP>(r, __shfl_xor(r, off, 64));
+    if (l == 0 && row < rows) {
+        if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, mean_div);
+        if constexpr (OP == NP_PROD) {
+            if (prod_quirk && r == 0.0f) r = 0.0f;   // see reduce_rows_wave
+        }
+        out[row] = r;
+    }
+}
+
 // blockIdx.y = chunk of the row (chunks > 1: few rows, long rows — out[row][chunk], a later pass
 // folds the chunks; the MEAN division then happens there).
 template <int OP, typename I>
@@ -790,6 +822,26 @@ int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t in
                 in, (float *)partials.ptr, (I)outer, (I)axis_len, 1.0f, (I)chunk_len, 0);
             NP_LAUNCH_CHECK("reduce_rows_block(chunks)");
             return launch_reduce_axis<OP, I>((const float *)partials.ptr, outer, chunks, 1, out, flags, mean_div);
+        }
+        if (axis_len > 4 && axis_len <= 256) {
+            // L lanes per row with at most ~8 elements per lane
+            size_t L = 2;
+            while (L * 8 < axis_len) L *= 2;
+            const size_t rows_per_block = 256 / L;
+            const size_t blocks = (outer + rows_per_block - 1) / rows_per_block;
+            if (blocks > 0x7fffffffu)
+                return np::fail(NP_ERR_INVALID, "np_reduce_axis: too many rows for row reduce");
+#define NP_RG(L_) reduce_rows_group<OP, L_, I><<<(unsigned)blocks, 256, 0, s>>>(in, out, (I)outer, (I)axis_len, mean_div, quirk)
+            switch (L) {
+                case 2: NP_RG(2); break;
+                case 4: NP_RG(4); break;
+                case 8: NP_RG(8); break;
+                case 16: NP_RG(16); break;
+                default: NP_RG(32); break;
+            }
+#undef NP_RG
+            NP_LAUNCH_CHECK("reduce_rows_group");
+            return NP_OK;
         }
         if (axis_len >= 32) {
             const size_t blocks = (outer + 3) / 4;

@@ -653,3 +653,22 @@ def test_batched_matmul_more_than_65535_matrices(hip):
     got = dc.to_host()
     ref = np.einsum("bmk,bkn->bmn", a.astype(np.float64), b.astype(np.float64))
     assert np.abs(got - ref).max() <= 1e-5
+
+
+@pytest.mark.parametrize("cols", [5, 7, 8, 9, 16, 24, 33, 64, 100, 129, 255, 256, 257, 511])
+def test_row_reductions_short_rows(cols, hip, oracle):
+    """Rows of 5 .. ~500 elements: L lanes per row (reduce_rows_group), 257+ a wave per row."""
+    from numpower_amd.ndarray import NDArray
+    rows = 3001
+    x = synth.uniform((rows, cols), 43, -1.0, 1.0)
+    gx = NDArray.array(x).gpu()
+    ref64 = x.astype(np.float64).sum(1)
+    scale = np.abs(x).astype(np.float64).sum(1)
+    got = NDArray.sum(gx, 1).cpu().numpy()
+    assert (np.abs(got - ref64) <= 1e-5 * scale).all()
+    assert (np.abs(NDArray.mean(gx, 1).cpu().numpy() - ref64 / cols) <= 1e-5 * scale / cols).all()
+    assert_bit_equal(NDArray.max(gx, 1).cpu().numpy(), x.max(1), "max")
+    assert_bit_equal(NDArray.min(gx, 1).cpu().numpy(), x.min(1), "min")
+    p = np.where(synth.uniform((rows, cols), 44, 0.0, 1.0) < 0.02, np.float32(-0.0), np.float32(1.0)).astype(np.float32)
+    p[::3] = np.abs(p[::3])
+    assert_bit_equal(NDArray.prod(NDArray.array(p).gpu(), 1).cpu().numpy(), oracle.reduce_axis("prod", p, 1), "prod")
