@@ -764,17 +764,23 @@ __global__ __launch_bounds__(256) void sgemv_chunks_kernel(const float *__restri
     if (threadIdx.x == 0) partial[(size_t)row * gridDim.x + chunk] = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
-// Many short rows (N <= 32, a 10^7 x 10 matrix): one THREAD per row; a wave per row would use 10 of
-// its 64 lanes.  A row's floats are consecutive, so neighbouring lanes share cache lines.
+// Many short rows (N <= 256, a 10^7 x 10 matrix): L lanes per row (L = 1 .. 32, a power of two) instead
+// of a whole wave, which would use 10 of its 64 lanes.  Lanes of a group read the row interleaved and
+// fold with xor-shuffles; neighbouring groups read neighbouring (contiguous) rows.
+template <int L>
 __global__ __launch_bounds__(256) void sgemv_short_rows_kernel(const float *__restrict__ A,
                                                                const float *__restrict__ x,
                                                                float *__restrict__ y, size_t M, unsigned N) {
-    for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < M; row += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = ((size_t)blockIdx.x * 256 + threadIdx.x) / L;
+    const unsigned l = threadIdx.x % L;
+    float acc = 0.0f;
+    if (row < M) {
         const float *a = A + row * N;
-        float acc = 0.0f;
-        for (unsigned k = 0; k < N; ++k) acc = fmaf(a[k], x[k], acc);
-        y[row] = acc;
+        for (unsigned k = l; k < N; k += L) acc = fmaf(a[k], x[k], acc);
     }
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (l == 0 && row < M) y[row] = acc;
 }
 
 int g_variant = 0;
@@ -1117,12 +1123,24 @@ int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y) {
         return np::fail(NP_ERR_INVALID, "np_sgemv: dimension too large");
     if (int rc = np::ensure_init()) return rc;
     const size_t target = (size_t)np::num_cus() * 8;
-    if (N <= 32 && M >= 4096) {
-        size_t blocks = (M + 255) / 256;
-        if (blocks > target * 4) blocks = target * 4;
-        sgemv_short_rows_kernel<<<(unsigned)blocks, 256, 0, np::stream()>>>(A, x, y, M, (unsigned)N);
-        NP_LAUNCH_CHECK("sgemv_short_rows_kernel");
-        return NP_OK;
+    if (N <= 256 && M >= 1024) {
+        size_t L = 1;
+        while (L * 8 < N) L *= 2;          // ~8 elements per lane
+        const size_t blocks = (M * L + 255) / 256;
+        if (blocks <= 0x7fffffffu) {
+#define NP_SR(L_) sgemv_short_rows_kernel<L_><<<(unsigned)blocks, 256, 0, np::stream()>>>(A, x, y, M, (unsigned)N)
+            switch (L) {
+                case 1: NP_SR(1); break;
+                case 2: NP_SR(2); break;
+                case 4: NP_SR(4); break;
+                case 8: NP_SR(8); break;
+                case 16: NP_SR(16); break;
+                default: NP_SR(32); break;
+            }
+#undef NP_SR
+            NP_LAUNCH_CHECK("sgemv_short_rows_kernel");
+            return NP_OK;
+        }
     }
     if (M < 2 * target && N >= 16384 && M <= 65535) {   // one wave per row would leave most of the chip idle
         size_t chunks = (2 * target + M - 1) / M;
