@@ -1031,6 +1031,32 @@ __global__ __launch_bounds__(256) void argreduce_small_inner(const float *__rest
     }
 }
 
+// argmax / argmin over SHORT contiguous rows (the class scores of a sample: an N x 10 array, axis 1):
+// L lanes per row (L = 1 .. 32), folded with xor-shuffles; a workgroup per row left 255 of 256 threads
+// idle (10^7 x 10: 9 ms).
+template <bool IS_MAX, int L>
+__global__ __launch_bounds__(256) void argreduce_rows_group(const float *__restrict__ in, float *__restrict__ out,
+                                                            size_t rows, unsigned len) {
+    const size_t row = ((size_t)blockIdx.x * 256 + threadIdx.x) / L;
+    const unsigned l = threadIdx.x % L;
+    ArgPair best{IS_MAX ? -INFINITY : INFINITY, 0xffffffffu};
+    if (row < rows) {
+        const float *p = in + row * len;
+        for (unsigned j = l; j < len; j += L) {
+            const ArgPair c{arg_key<IS_MAX>(p[j], j), j};
+            best = (best.i == 0xffffffffu) ? c : arg_combine<IS_MAX>(best, c);
+        }
+    }
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) {
+        ArgPair q;
+        q.v = __shfl_xor(best.v, off, 64);
+        q.i = __shfl_xor(best.i, off, 64);
+        if (q.i != 0xffffffffu) best = (best.i == 0xffffffffu) ? q : arg_combine<IS_MAX>(best, q);
+    }
+    if (l == 0 && row < rows) out[row] = (float)best.i;
+}
+
 // fold [outer][chunks][inner] partials: thread per output for short chunk lists, workgroup per output
 // for long ones
 static int launch_arg_fold(int is_max, const float *pv, const unsigned *pi, float *out, size_t outputs,
@@ -1062,6 +1088,31 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
     if (axis_len > 0xfffffffeull) return np::fail(NP_ERR_INVALID, "np_argreduce: axis too long");
     if (int rc = np::ensure_init()) return rc;
     hipStream_t s = np::stream();
+    if (inner == 1 && axis_len <= 256 && outer >= 1024) {
+        size_t L = 1;
+        while (L * 8 < axis_len) L *= 2;
+        const size_t blocks = (outer * L + 255) / 256;
+        if (blocks <= 0x7fffffffu) {
+#define NP_AG(L_)                                                                                         \
+    do {                                                                                                  \
+        if (is_max)                                                                                       \
+            argreduce_rows_group<true, L_><<<(unsigned)blocks, 256, 0, s>>>(in, out, outer, (unsigned)axis_len);  \
+        else                                                                                              \
+            argreduce_rows_group<false, L_><<<(unsigned)blocks, 256, 0, s>>>(in, out, outer, (unsigned)axis_len); \
+    } while (0)
+            switch (L) {
+                case 1: NP_AG(1); break;
+                case 2: NP_AG(2); break;
+                case 4: NP_AG(4); break;
+                case 8: NP_AG(8); break;
+                case 16: NP_AG(16); break;
+                default: NP_AG(32); break;
+            }
+#undef NP_AG
+            NP_LAUNCH_CHECK("argreduce_rows_group");
+            return NP_OK;
+        }
+    }
     if (inner == 1) {
         // contiguous rows: (row, chunk) workgroups + a fold over the chunks of each row
         const size_t target = (size_t)np::num_cus() * 8;

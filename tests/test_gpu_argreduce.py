@@ -102,3 +102,22 @@ def test_argreduce_few_outputs_long_axis(shape, axis, hip, oracle):
         got = got.cpu().numpy() if not isinstance(got, float) else np.float32(got)
         want = oracle.argreduce(x, axis, is_max)
         assert np.array_equal(np.asarray(got, np.float32).reshape(-1), np.asarray(want, np.float32).reshape(-1))
+
+
+@pytest.mark.parametrize("cols", [1, 2, 3, 4, 5, 8, 10, 16, 33, 100, 255, 256, 257])
+def test_argreduce_short_rows(cols, hip, oracle):
+    """argmax / argmin over the class scores of many samples ((N, 10), axis 1): lane groups per row
+    (argreduce_rows_group), with ties and NaNs in every position."""
+    from numpower_amd.ndarray import NDArray
+    rows = 5003
+    x = synth.uniform((rows, cols), 52, -1.0, 1.0)
+    x[::7, :] = np.float32(0.5)                        # whole rows of ties: first index wins
+    if cols > 1:
+        x[1::11, cols // 2] = np.nan
+        x[2::13, 0] = np.nan                           # NaN in position 0: maximal for argmax, first NaN for argmin
+        x[3::17, cols - 1] = np.float32(2.0)
+    g = NDArray.array(x).gpu()
+    for is_max in (True, False):
+        got = (NDArray.argmax(g, 1) if is_max else NDArray.argmin(g, 1)).cpu().numpy()
+        want = oracle.argreduce(x, 1, is_max)
+        assert np.array_equal(np.asarray(got, np.float32), np.asarray(want, np.float32)), (cols, is_max)
