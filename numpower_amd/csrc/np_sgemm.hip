@@ -783,6 +783,80 @@ __global__ __launch_bounds__(256) void sgemv_short_rows_kernel(const float *__re
     if (l == 0 && row < M) y[row] = acc;
 }
 
+// ---- thin products: C = A (M x K) . B (K x N) with N <= 32 --------------------------------------
+// (points x 3) . (3 x 3), (samples x 784) . (784 x 10): these are HBM-bound reads of A — a 64 x 64
+// MFMA tile would be 90 % padding (10^7 x 3 x 3 ran at 0.46 TB/s).  They are GEMVs with NV right-hand
+// sides: L lanes per row of A (L = 1 .. 64, power of two; lane l takes k = l, l + L, ...), NV
+// accumulators per lane, xor-shuffle fold, lane 0 of the group writes the N results of its row.  B is
+// at most K x 32 floats and is read through the caches.  A is read exactly once, coalesced (a group
+// reads its row contiguously, neighbouring groups read neighbouring rows).
+template <int NV, int L>
+__global__ __launch_bounds__(256) void sgemm_thin_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                         float *__restrict__ C, size_t M, unsigned N, unsigned K) {
+    const size_t row = ((size_t)blockIdx.x * 256 + threadIdx.x) / L;
+    const unsigned l = threadIdx.x % L;
+    float acc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] = 0.0f;
+    if (row < M) {
+        const float *a = A + row * K;
+        for (unsigned k = l; k < K; k += L) {
+            const float x = a[k];
+            const float *b = B + (size_t)k * N;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                if (j < (int)N) acc[j] = fmaf(x, b[j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+    if (l == 0 && row < M) {
+        float *c = C + row * N;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (j < (int)N) c[j] = acc[j];
+    }
+}
+
+// Few rows of A, a long K, N <= 32 (X^T X of a 10^7 x 3 array): (chunk, row) workgroups as in
+// sgemv_chunks_kernel, with NV accumulators; partial[row][chunk][N], folded by np_reduce_axis.
+template <int NV>
+__global__ __launch_bounds__(256) void sgemm_thin_chunks_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                                float *__restrict__ partial, unsigned N, unsigned K,
+                                                                unsigned chunk_len) {
+    __shared__ float lds[4][NV];
+    const unsigned row = blockIdx.y, chunk = blockIdx.x;
+    const unsigned k0 = chunk * chunk_len;
+    const unsigned len = (K - k0 < chunk_len) ? K - k0 : chunk_len;
+    const float *a = A + (size_t)row * K + k0;
+    const float *b = B + (size_t)k0 * N;
+    float acc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] = 0.0f;
+    for (unsigned k = threadIdx.x; k < len; k += 256) {
+        const float x = a[k];
+        const float *bk = b + (size_t)k * N;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (j < (int)N) acc[j] = fmaf(x, bk[j], acc[j]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) lds[wave][j] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < N)
+        partial[((size_t)row * gridDim.x + chunk) * N + threadIdx.x] =
+            (lds[0][threadIdx.x] + lds[1][threadIdx.x]) + (lds[2][threadIdx.x] + lds[3][threadIdx.x]);
+}
+
 int g_variant = 0;
 unsigned long long *g_probe = nullptr;
 
@@ -1065,6 +1139,59 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
     return launch_planned(g, batch, vec);
 }
 
+// N <= 32: the GEMV-with-several-right-hand-sides kernels.  Returns 1 when the shape is left to the
+// tiled kernels (few rows and a short K: nothing to gain).
+template <int NV>
+int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B, float *C) {
+    hipStream_t s = np::stream();
+    const size_t target = (size_t)np::num_cus() * 8;
+    // measured (profiles/r01/skinny_gemm.log): with N <= 4 the per-k loads of B are few enough that the
+    // kernel stays HBM-bound (10^7 x 3 x 3: 0.53 -> 0.045 ms); with 8-32 accumulators it turns
+    // load-issue-bound and loses to the tiled kernels, so those shapes are left to the planner
+    if (M >= 2048 && N <= 4 && K * N <= 16384) {   // B stays in the vector L1 / L2 while every row streams past it
+        size_t L = 1;
+        while (L * 8 < K && L < 64) L *= 2;    // ~8 k per lane
+        const size_t blocks = (M * L + 255) / 256;
+        if (blocks > 0x7fffffffu) return 1;
+#define NP_TH(L_) sgemm_thin_kernel<NV, L_><<<(unsigned)blocks, 256, 0, s>>>(A, B, C, M, (unsigned)N, (unsigned)K)
+        switch (L) {
+            case 1: NP_TH(1); break;
+            case 2: NP_TH(2); break;
+            case 4: NP_TH(4); break;
+            case 8: NP_TH(8); break;
+            case 16: NP_TH(16); break;
+            case 32: NP_TH(32); break;
+            default: NP_TH(64); break;
+        }
+#undef NP_TH
+        NP_LAUNCH_CHECK("sgemm_thin_kernel");
+        return NP_OK;
+    }
+    if (M <= 16 && N <= 8 && K >= 65536) {   // X^T X of a tall-skinny X
+        size_t chunks = (2 * target + M - 1) / M;
+        const size_t max_chunks = K / 4096;
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks < 1) chunks = 1;
+        const size_t chunk_len = (K + chunks - 1) / chunks;
+        chunks = (K + chunk_len - 1) / chunk_len;
+        if (chunks > 65535) return 1;
+        np::Scratch partial;
+        if (int rc = partial.alloc(M * chunks * N * sizeof(float))) return rc;
+        sgemm_thin_chunks_kernel<NV><<<dim3((unsigned)chunks, (unsigned)M), 256, 0, s>>>(
+            A, B, (float *)partial.ptr, (unsigned)N, (unsigned)K, (unsigned)chunk_len);
+        NP_LAUNCH_CHECK("sgemm_thin_chunks_kernel");
+        return np_reduce_axis(NP_SUM, (const float *)partial.ptr, M, chunks, N, C, 0);
+    }
+    return 1;
+}
+
+int launch_thin(size_t M, size_t N, size_t K, const float *A, const float *B, float *C) {
+    if (N <= 4) return launch_thin_nv<4>(M, N, K, A, B, C);
+    if (N <= 8) return launch_thin_nv<8>(M, N, K, A, B, C);
+    if (N <= 16) return launch_thin_nv<16>(M, N, K, A, B, C);
+    return launch_thin_nv<32>(M, N, K, A, B, C);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1106,6 +1233,10 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K, const f
         return NP_OK;
     }
     if (!A || !B) return np::fail(NP_ERR_INVALID, "np_sgemm: null input");
+    if (batch == 1 && N <= 32 && g_variant == 0 && K <= 0x7fffffffu) {
+        const int rc = launch_thin(M, N, K, A, B, C);
+        if (rc != 1) return rc;   // 1 = shape not taken
+    }
     // blockIdx.z carries the batch index: more than 65535 matrices go in slabs
     for (size_t b0 = 0; b0 < batch; b0 += 65535) {
         const size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;

@@ -672,3 +672,19 @@ def test_row_reductions_short_rows(cols, hip, oracle):
     p = np.where(synth.uniform((rows, cols), 44, 0.0, 1.0) < 0.02, np.float32(-0.0), np.float32(1.0)).astype(np.float32)
     p[::3] = np.abs(p[::3])
     assert_bit_equal(NDArray.prod(NDArray.array(p).gpu(), 1).cpu().numpy(), oracle.reduce_axis("prod", p, 1), "prod")
+
+
+@pytest.mark.parametrize("mnk", [(100_000, 3, 3), (50_000, 10, 784), (20_000, 16, 16), (30_000, 8, 64), (5000, 1, 64), (4097, 32, 100),
+                                 (2048, 5, 7), (3, 3, 1_000_000), (10, 7, 300_001), (64, 32, 70_000), (1, 1, 200_000), (2047, 3, 3)])
+def test_matmul_thin(mnk, hip, oracle):
+    """N <= 32: GEMV-with-several-right-hand-sides kernels (sgemm_thin_kernel: lane groups per row of A;
+    sgemm_thin_chunks_kernel: few rows, long K) instead of mostly empty MFMA tiles."""
+    from numpower_amd.ndarray import NDArray
+    m, n, k = mnk
+    a = synth.uniform((m, k), 45, -1.0, 1.0)
+    b = synth.uniform((k, n), 46, -1.0, 1.0)
+    got = NDArray.matmul(NDArray.array(a).gpu(), NDArray.array(b).gpu()).cpu().numpy()
+    ref64 = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert got.shape == (m, n)
+    assert (np.abs(got - ref64) <= 1e-6 * np.maximum(scale, 1e-30)).all()
