@@ -820,6 +820,46 @@ __global__ __launch_bounds__(256) void sgemm_thin_kernel(const float *__restrict
     }
 }
 
+// The mirror image: M <= 16 rows of A, K <= 64, a very wide B ((3 x 3) . (3 x 10^7)): every thread owns four
+// columns, reads the K float4s of B above them (coalesced rows) and keeps MV float4 accumulators; A is
+// a handful of uniform scalars.  B is read once, C written once.
+template <int MV>
+__global__ __launch_bounds__(256) void sgemm_thin_left_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                              float *__restrict__ C, unsigned M, size_t N, unsigned K) {
+    typedef v4f v4f_u __attribute__((aligned(4)));
+    const size_t nvec = N / 4;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256) {
+        v4f acc[MV];
+#pragma unroll
+        for (int i = 0; i < MV; ++i) acc[i] = v4f{0, 0, 0, 0};
+        for (unsigned k = 0; k < K; ++k) {
+            const v4f b = __builtin_nontemporal_load((const v4f_u *)(B + (size_t)k * N + v * 4));
+#pragma unroll
+            for (int i = 0; i < MV; ++i) {
+                if (i < (int)M) {
+                    const float a = A[(size_t)i * K + k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(a, b[e], acc[i][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MV; ++i)
+            if (i < (int)M) __builtin_nontemporal_store(acc[i], (v4f_u *)(C + (size_t)i * N + v * 4));
+    }
+    // ragged tail: N % 4 columns
+    if (blockIdx.x == 0) {
+        const size_t j = nvec * 4 + threadIdx.x;
+        if (j < N) {
+            for (unsigned i = 0; i < M; ++i) {
+                float acc = 0.0f;
+                for (unsigned k = 0; k < K; ++k) acc = fmaf(A[(size_t)i * K + k], B[(size_t)k * N + j], acc);
+                C[(size_t)i * N + j] = acc;
+            }
+        }
+    }
+}
+
 // Few rows of A, a long K, N <= 32 (X^T X of a 10^7 x 3 array): (chunk, row) workgroups as in
 // sgemv_chunks_kernel, with NV accumulators; partial[row][chunk][N], folded by np_reduce_axis.
 template <int NV>
@@ -1236,6 +1276,20 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K, const f
     if (batch == 1 && N <= 32 && g_variant == 0 && K <= 0x7fffffffu) {
         const int rc = launch_thin(M, N, K, A, B, C);
         if (rc != 1) return rc;   // 1 = shape not taken
+    }
+    if (batch == 1 && M <= 16 && K <= 64 && N >= 65536 && g_variant == 0) {
+        size_t blocks = (N / 4 + 255) / 256;
+        const size_t cap = (size_t)np::num_cus() * 64;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        if (M <= 4)
+            sgemm_thin_left_kernel<4><<<(unsigned)blocks, 256, 0, np::stream()>>>(A, B, C, (unsigned)M, N, (unsigned)K);
+        else if (M <= 8)
+            sgemm_thin_left_kernel<8><<<(unsigned)blocks, 256, 0, np::stream()>>>(A, B, C, (unsigned)M, N, (unsigned)K);
+        else
+            sgemm_thin_left_kernel<16><<<(unsigned)blocks, 256, 0, np::stream()>>>(A, B, C, (unsigned)M, N, (unsigned)K);
+        NP_LAUNCH_CHECK("sgemm_thin_left_kernel");
+        return NP_OK;
     }
     // blockIdx.z carries the batch index: more than 65535 matrices go in slabs
     for (size_t b0 = 0; b0 < batch; b0 += 65535) {

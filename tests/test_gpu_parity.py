@@ -675,7 +675,10 @@ def test_row_reductions_short_rows(cols, hip, oracle):
 
 
 @pytest.mark.parametrize("mnk", [(100_000, 3, 3), (50_000, 10, 784), (20_000, 16, 16), (30_000, 8, 64), (5000, 1, 64), (4097, 32, 100),
-                                 (2048, 5, 7), (3, 3, 1_000_000), (10, 7, 300_001), (64, 32, 70_000), (1, 1, 200_000), (2047, 3, 3)])
+                                 (2048, 5, 7), (3, 3, 1_000_000), (10, 7, 300_001), (64, 32, 70_000), (1, 1, 200_000), (2047, 3, 3),
+                                 # tiny M, wide N: sgemm_thin_left_kernel
+                                 (3, 1_000_003, 3), (4, 400_000, 4), (8, 70_001, 64), (1, 65536, 8), (5, 100_002, 17), (16, 66_000, 33),
+                                 (10, 100_000, 16)])
 def test_matmul_thin(mnk, hip, oracle):
     """N <= 32: GEMV-with-several-right-hand-sides kernels (sgemm_thin_kernel: lane groups per row of A;
     sgemm_thin_chunks_kernel: few rows, long K) instead of mostly empty MFMA tiles."""
