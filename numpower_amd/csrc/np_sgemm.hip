@@ -820,6 +820,95 @@ __global__ __launch_bounds__(256) void sgemm_thin_kernel(const float *__restrict
     }
 }
 
+// N = 5 .. 32 columns ((samples x 784) . (784 x 10), a projection onto a few components): too many
+// accumulators for the lane-group kernel above (it turns load-issue-bound), too few columns for a
+// 64-wide tile.  One wave = ROWS rows of A x ROWS (padded) columns on the fp32 MFMA (32x32x2 for
+// N > 16, 16x16x4 — half the matrix-core time per element of A — for N <= 16), operands straight from
+// global memory, no LDS: lane (i, q) owns the q-th 128 / KK bytes of row i's next 128-byte stretch and
+// loads them with back-to-back float4 loads (so a line is consumed in one go — with one float4 per
+// step the 32 lines per wave x 32 waves per CU fell out of the vector L1 before their fourth use),
+// then feeds one component to each of W MFMAs; the MFMA sums over q, so every k of the 32-wide step is
+// covered exactly once as long as B is indexed the same way.  B reaches the MFMA through LDS: the four
+// waves of a block walk K in lockstep, 64 rows of B (zero-padded to ROWS columns) per chunk, double
+// buffered so one barrier per chunk is enough (every wave reading B out of the caches itself moved
+// as many bytes of B as of A).
+template <int ROWS>
+__global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                              float *__restrict__ C, size_t M, unsigned N, unsigned K) {
+    typedef v4f v4f_u __attribute__((aligned(4)));
+    constexpr int KK = 64 / ROWS;          // k-slices the MFMA sums over (2 or 4)
+    constexpr int W = 32 / KK;             // k values per lane per step (16 or 8)
+    constexpr int NACC = ROWS * ROWS / 64; // 16 or 4
+    constexpr int CH = 64;                 // k rows of B per LDS chunk = two steps
+    constexpr int STR = ROWS == 32 ? 32 : 18;   // 16-wide rows: q and q + 1 land 16 banks apart
+    constexpr int NB = CH * ROWS / 256;    // staged elements per thread
+    typedef float acc_t __attribute__((ext_vector_type(NACC)));
+    __shared__ float Bs[2][CH * STR];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned i = lane % ROWS, q = lane / ROWS;
+    const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * ROWS;
+    const size_t row = r0 + i;
+    const bool row_ok = row < M;
+    const float *a = A + (row_ok ? row : 0) * (size_t)K + W * q;
+    acc_t acc;
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) acc[r] = 0.0f;
+    auto fetch = [&](unsigned k0, float (&av)[W]) {
+        const unsigned k = k0 + W * q;               // K % 4 == 0: each float4 is all in or all out
+#pragma unroll
+        for (int v = 0; v < W / 4; ++v) {
+            v4f x = {0, 0, 0, 0};
+            if (row_ok && k + 4 * v < K) x = *(const v4f_u *)(a + k0 + 4 * v);
+            av[4 * v] = x[0]; av[4 * v + 1] = x[1]; av[4 * v + 2] = x[2]; av[4 * v + 3] = x[3];
+        }
+    };
+    auto stage_load = [&](unsigned kc, float (&reg)[NB]) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const unsigned e = threadIdx.x + 256 * u, kk = e / ROWS, j = e % ROWS;
+            reg[u] = (j < N && kc + kk < K) ? B[(size_t)(kc + kk) * N + j] : 0.0f;
+        }
+    };
+    auto stage_store = [&](int buf, const float (&reg)[NB]) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const unsigned e = threadIdx.x + 256 * u, kk = e / ROWS, j = e % ROWS;
+            Bs[buf][kk * STR + j] = reg[u];
+        }
+    };
+    auto mma = [&](const float (&av)[W], const float *bs) {   // bs: this step's 32 rows of the chunk
+#pragma unroll
+        for (int t = 0; t < W; ++t) {
+            const float bv = bs[(W * q + t) * STR + i];
+            if constexpr (ROWS == 32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc, 0, 0, 0);
+        }
+    };
+    float a0[W], a1[W], breg[NB];
+    stage_load(0, breg);
+    fetch(0, a0);
+    stage_store(0, breg);
+    __syncthreads();
+    int buf = 0;
+    for (unsigned kc = 0; kc < K; kc += CH, buf ^= 1) {
+        const bool more = kc + CH < K;                // uniform
+        if (more) stage_load(kc + CH, breg);
+        fetch(kc + 32, a1);                           // next step in flight under the MFMAs
+        mma(a0, &Bs[buf][0]);
+        fetch(kc + 64, a0);
+        mma(a1, &Bs[buf][32 * STR]);
+        if (more) stage_store(buf ^ 1, breg);
+        __syncthreads();
+    }
+    if (i < N) {
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            const size_t orow = ROWS == 32 ? r0 + (r & 3) + 8 * (r >> 2) + 4 * q : r0 + 4 * q + r;
+            if (orow < M) C[orow * N + i] = acc[r];
+        }
+    }
+}
+
 // The mirror image: M <= 16 rows of A, K <= 64, a very wide B ((3 x 3) . (3 x 10^7)): every thread owns four
 // columns, reads the K float4s of B above them (coalesced rows) and keeps MV float4 accumulators; A is
 // a handful of uniform scalars.  B is read once, C written once.
@@ -1205,6 +1294,15 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
         }
 #undef NP_TH
         NP_LAUNCH_CHECK("sgemm_thin_kernel");
+        return NP_OK;
+    }
+    if (M >= 2048 && N > 4 && K % 4 == 0 && K >= 8 && ((uintptr_t)A & 3u) == 0) {
+        const size_t rows_per_block = N <= 16 ? 64 : 128;
+        const size_t blocks = (M + rows_per_block - 1) / rows_per_block;
+        if (blocks > 0x7fffffffu) return 1;
+        if (N <= 16) sgemm_thin_mfma_kernel<16><<<(unsigned)blocks, 256, 0, s>>>(A, B, C, M, (unsigned)N, (unsigned)K);
+        else sgemm_thin_mfma_kernel<32><<<(unsigned)blocks, 256, 0, s>>>(A, B, C, M, (unsigned)N, (unsigned)K);
+        NP_LAUNCH_CHECK("sgemm_thin_mfma_kernel");
         return NP_OK;
     }
     if (M <= 16 && N <= 8 && K >= 65536) {   // X^T X of a tall-skinny X

@@ -678,10 +678,15 @@ def test_row_reductions_short_rows(cols, hip, oracle):
                                  (2048, 5, 7), (3, 3, 1_000_000), (10, 7, 300_001), (64, 32, 70_000), (1, 1, 200_000), (2047, 3, 3),
                                  # tiny M, wide N: sgemm_thin_left_kernel
                                  (3, 1_000_003, 3), (4, 400_000, 4), (8, 70_001, 64), (1, 65536, 8), (5, 100_002, 17), (16, 66_000, 33),
-                                 (10, 100_000, 16)])
+                                 (10, 100_000, 16),
+                                 # N = 5..32, K % 4 == 0: sgemm_thin_mfma_kernel (16x16x4 for N <= 16, 32x32x2 above); K tails
+                                 # inside a 32-step and a 64-chunk, M not a multiple of the wave's rows
+                                 (2049, 31, 36), (5001, 17, 8), (3001, 12, 132), (2500, 9, 64), (2100, 16, 96), (70_001, 24, 1024),
+                                 (2048, 5, 12), (9999, 32, 260), (100_003, 6, 4)])
 def test_matmul_thin(mnk, hip, oracle):
     """N <= 32: GEMV-with-several-right-hand-sides kernels (sgemm_thin_kernel: lane groups per row of A;
-    sgemm_thin_chunks_kernel: few rows, long K) instead of mostly empty MFMA tiles."""
+    sgemm_thin_mfma_kernel: one wave = 16 / 32 rows on the MFMA with B through LDS; sgemm_thin_chunks_kernel:
+    few rows, long K) instead of mostly empty 64-wide tiles."""
     from numpower_amd.ndarray import NDArray
     m, n, k = mnk
     a = synth.uniform((m, k), 45, -1.0, 1.0)
