@@ -172,6 +172,46 @@ def test_pow_and_arctan2(shape, hip, oracle):
     assert_close(got, oracle.binary("arctan2", ex, y), "arctan2")
 
 
+def test_pow_special_cases_and_range(hip, oracle):
+    """pow: the fp64 fast path (finite normal base, finite exponent, negative bases with integer exponents)
+    and the library fallback (zeros, denormals, inf, NaN) against glibc's powf (arithmetics.c:912-914):
+    same NaN pattern, same zeros / infinities with sign, finite results within 1 ulp; over / underflow
+    into inf, denormals and zero."""
+    from numpower_amd.ndarray import NDArray
+    f = np.float32
+    xs = f([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 2.0, -2.0, 3.0, -3.0, np.inf, -np.inf, np.nan, 1e-40, -1e-40, 3.4028235e38,
+            -3.4028235e38, 1.1754944e-38, -1.1754944e-38, 1e-30, 1e30, -1e30, 0.99999994, 1.0000001, -7.5, 10.0])
+    ys = f([0.0, -0.0, 1.0, -1.0, 2.0, -2.0, 3.0, -3.0, 0.5, -0.5, 1.5, np.inf, -np.inf, np.nan, 1e10, -1e10, 16777216.0,
+            16777215.0, -16777215.0, 33554432.0, 127.0, -149.0, 1e-40, 4.0, 5.0, 1e-3, 38.5, -45.25])
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    X = np.ascontiguousarray(X); Y = np.ascontiguousarray(Y)
+    got = NDArray.pow(NDArray.array(X).gpu(), NDArray.array(Y).gpu()).cpu().numpy()
+    with np.errstate(all="ignore"):
+        want = oracle.binary("pow", X, Y)
+    assert (np.isnan(got) == np.isnan(want)).all(), list(zip(X[np.isnan(got) != np.isnan(want)], Y[np.isnan(got) != np.isnan(want)]))
+    special = ~np.isnan(want) & ((want == 0) | np.isinf(want))
+    bad = special & (got.view(np.uint32) != want.view(np.uint32))
+    assert not bad.any(), list(zip(X[bad], Y[bad], got[bad], want[bad]))
+    fin = ~np.isnan(want) & ~special
+    ulp = np.abs(got[fin].view(np.int32).astype(np.int64) - want[fin].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, (X[fin][ulp.argmax()], Y[fin][ulp.argmax()])
+    # wide random range, both signs, integer and fractional exponents
+    n = 1_000_000
+    mag = np.exp(synth.uniform((n,), 61, -80.0, 80.0).astype(np.float64)).astype(np.float32)
+    sign = np.where(synth.uniform((n,), 62, 0.0, 1.0) < 0.3, f(-1), f(1))
+    x = (mag * sign).astype(np.float32)
+    y = synth.uniform((n,), 63, -10.0, 10.0)
+    y[::3] = np.rint(y[::3])
+    got = NDArray.pow(NDArray.array(x).gpu(), NDArray.array(y).gpu()).cpu().numpy()
+    with np.errstate(all="ignore"):
+        want = oracle.binary("pow", x, y)
+    assert (np.isnan(got) == np.isnan(want)).all()
+    ok = ~np.isnan(want)
+    ulp = np.abs(got[ok].view(np.int32).astype(np.int64) - want[ok].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, (x[ok][ulp.argmax()], y[ok][ulp.argmax()], got[ok][ulp.argmax()], want[ok][ulp.argmax()])
+    assert (ulp == 0).mean() > 0.995
+
+
 def test_binary_errors(hip):
     from numpower_amd.ndarray import Error, NDArray
     a = NDArray.array(np.ones((4, 6), np.float32)).gpu()
