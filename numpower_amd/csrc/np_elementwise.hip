@@ -1208,7 +1208,12 @@ int np_binary(int op, const float *a, int a_kind, const float *b, int b_kind, fl
         case NP_MULTIPLY: return dispatch_binary_quirk<NP_MULTIPLY>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         case NP_DIVIDE: return dispatch_binary_quirk<NP_DIVIDE>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         case NP_MOD: return dispatch_binary_quirk<NP_MOD>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
-        case NP_POW: return dispatch_binary_quirk<NP_POW>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
+        case NP_POW:
+            // `$a ** 2`: x * x is the correctly rounded square (what powf returns in all but its rare
+            // non-correctly-rounded cases) and has the same zeros / infinities / NaNs, at the cost of an add
+            if (a_kind == NP_FULL && b_kind == NP_SCALAR && !b && hb == 2.0f)
+                return dispatch_binary_quirk<NP_MULTIPLY>(a, NP_FULL, a, NP_FULL, out, rows, cols, 0u, 0, 0.0f, 0.0f);
+            return dispatch_binary_quirk<NP_POW>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         case NP_EQUAL: return dispatch_binary_quirk<NP_EQUAL>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         case NP_NOT_EQUAL: return dispatch_binary_quirk<NP_NOT_EQUAL>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);
         case NP_GREATER: return dispatch_binary_quirk<NP_GREATER>(a, a_kind, b, b_kind, out, rows, cols, flags, body_end, ha, hb);

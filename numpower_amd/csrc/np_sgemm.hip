@@ -854,11 +854,17 @@ __global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__res
 #pragma unroll
     for (int r = 0; r < NACC; ++r) acc[r] = 0.0f;
     auto fetch = [&](unsigned k0, float (&av)[W]) {
-        const unsigned k = k0 + W * q;               // K % 4 == 0: each float4 is all in or all out
+        const unsigned k = k0 + W * q;
 #pragma unroll
         for (int v = 0; v < W / 4; ++v) {
             v4f x = {0, 0, 0, 0};
-            if (row_ok && k + 4 * v < K) x = *(const v4f_u *)(a + k0 + 4 * v);
+            const unsigned kv = k + 4 * v;
+            if (row_ok && kv + 3 < K) x = *(const v4f_u *)(a + k0 + 4 * v);   // dword-aligned is enough
+            else if (row_ok && kv < K) {                                       // the float4 that straddles K
+                x[0] = a[k0 + 4 * v];
+                if (kv + 1 < K) x[1] = a[k0 + 4 * v + 1];
+                if (kv + 2 < K) x[2] = a[k0 + 4 * v + 2];
+            }
             av[4 * v] = x[0]; av[4 * v + 1] = x[1]; av[4 * v + 2] = x[2]; av[4 * v + 3] = x[3];
         }
     };
@@ -1296,7 +1302,7 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
         NP_LAUNCH_CHECK("sgemm_thin_kernel");
         return NP_OK;
     }
-    if (M >= 2048 && N > 4 && K % 4 == 0 && K >= 8 && ((uintptr_t)A & 3u) == 0) {
+    if (M >= 2048 && N > 4 && K >= 4) {
         const size_t rows_per_block = N <= 16 ? 64 : 128;
         const size_t blocks = (M + rows_per_block - 1) / rows_per_block;
         if (blocks > 0x7fffffffu) return 1;

@@ -212,6 +212,21 @@ def test_pow_special_cases_and_range(hip, oracle):
     assert (ulp == 0).mean() > 0.995
 
 
+def test_pow_scalar_two_is_a_square(hip, oracle):
+    """`$a ** 2` takes the multiply kernel: same values as glibc's powf(x, 2) up to its own rounding slack
+    (<= 1 ulp), same zeros / infinities / NaNs."""
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform((300_007,), 64, -1e3, 1e3)
+    x[:8] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-30, -3e19, 1e-23]
+    got = (NDArray.array(x).gpu() ** 2.0).cpu().numpy()
+    with np.errstate(all="ignore"):
+        want = oracle.binary("pow", x, np.float32(2.0))
+    assert (np.isnan(got) == np.isnan(want)).all()
+    ok = ~np.isnan(want)
+    ulp = np.abs(got[ok].view(np.int32).astype(np.int64) - want[ok].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp == 0).mean() > 0.995    # measured 0.9989: powf(x, 2) is not always correctly rounded
+
+
 def test_binary_errors(hip):
     from numpower_amd.ndarray import Error, NDArray
     a = NDArray.array(np.ones((4, 6), np.float32)).gpu()
@@ -722,7 +737,8 @@ def test_row_reductions_short_rows(cols, hip, oracle):
                                  # N = 5..32, K % 4 == 0: sgemm_thin_mfma_kernel (16x16x4 for N <= 16, 32x32x2 above); K tails
                                  # inside a 32-step and a 64-chunk, M not a multiple of the wave's rows
                                  (2049, 31, 36), (5001, 17, 8), (3001, 12, 132), (2500, 9, 64), (2100, 16, 96), (70_001, 24, 1024),
-                                 (2048, 5, 12), (9999, 32, 260), (100_003, 6, 4)])
+                                 (2048, 5, 12), (9999, 32, 260), (100_003, 6, 4),
+                                 (50_000, 10, 785), (3000, 20, 7), (4099, 16, 33), (2050, 30, 66), (2500, 8, 5)])
 def test_matmul_thin(mnk, hip, oracle):
     """N <= 32: GEMV-with-several-right-hand-sides kernels (sgemm_thin_kernel: lane groups per row of A;
     sgemm_thin_mfma_kernel: one wave = 16 / 32 rows on the MFMA with B through LDS; sgemm_thin_chunks_kernel:
