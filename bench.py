@@ -25,9 +25,11 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import datetime
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -108,7 +110,8 @@ class Dist:
             # RCCL prints a version banner through C stdio on stdout when the communicator comes up;
             # stdout must carry exactly one JSON line, so the banner is flushed into /dev/null.
             with _stdout_to_devnull():
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank),
+                                        timeout=datetime.timedelta(seconds=240))
                 warm = torch.zeros(1, device="cuda")
                 dist.all_reduce(warm)
                 torch.cuda.synchronize()
@@ -474,10 +477,21 @@ def main():
             except Exception as e:   # extras must never take the headline down
                 extras = {"error": repr(e)}
         else:
+            # the sharded extra has collectives in it: if a peer dies there, the headline measured above
+            # must still be reported — after 200 s rank 0 prints it without the extra and every rank leaves
+            def bail():
+                if rank0:
+                    result["extras"] = {"error": "config 5 (sharded batched matmul + all-gather) did not finish in 200 s"}
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(200.0, bail)
+            watchdog.daemon = True
+            watchdog.start()
             try:
                 extras = {"config5_batched_matmul_allgather": bench_config5(dist, max(3, args.steps // 10), 2)}
             except Exception as e:
                 extras = {"error": repr(e)}
+            watchdog.cancel()
     # HBM traffic per launch from the committed PMC passes (profiles/rNN/pmc_traffic.json)
     traffic, src = pmc_traffic()
     if traffic:
