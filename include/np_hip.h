@@ -265,6 +265,17 @@ typedef enum np_mismatch_mode { NP_MISMATCH_EXACT = 0, NP_MISMATCH_ALLCLOSE = 1 
 int np_count_mismatch(int mode, const float *a, const float *b, size_t n, float rtol, float atol,
                       int *host_any);
 
+/* Order statistics: host_out2[0] = the k-th smallest element (k counted from 0), host_out2[1] = the
+ * (k+1)-th (= the k-th again when k is the last rank).  Exact, by a three-pass radix select (12 B/elem
+ * of reads, no sort, no copy) — replaces the copy + qsort() of calculate_median
+ * (src/ndmath/arithmetics.c:111-138) and calculate_quantile (src/ndmath/statistics.c:14-50), whose
+ * results depend on exactly these two values.  Ordering: IEEE total order on the bits (-0.0 before
+ * +0.0, which the reference's comparator calls equal; NaNs at the ends by sign — the comparator is
+ * inconsistent for NaNs, so the reference's own result is unspecified there).
+ * np_order_stat_dev leaves the two floats in device memory (no synchronisation). */
+int np_order_stat(const float *in, size_t n, size_t k, float *host_out2);
+int np_order_stat_dev(const float *in, size_t n, size_t k, float *dev_out2);
+
 /* Reduce the middle axis of a contiguous array viewed as outer x axis_len x inner; out has
  * outer*inner elements.  Replaces the host-side recursion reduce()/_reduce()/apply_reduce()
  * (ndarray.c:523-578,394-429,358-368), which issues one Add_Float + alloc + D2D copy + free

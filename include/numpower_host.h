@@ -199,6 +199,17 @@ float NDArray_Float_Prod(NDArray *a);
 float NDArray_Mean_Float(NDArray *a);
 float NDArray_Min(NDArray *target);
 float NDArray_Max(NDArray *target);
+/* NDArray_Median_Float  arithmetics.c:149-158 (calculate_median :111-138): (t[n/2-1] + t[n/2]) / 2.0f for an
+ *                       even count, t[n/2] for an odd one, t = the sorted elements.
+ * NDArray_Quantile      statistics.c:60-79 (calculate_quantile :14-50): q a 0-d array in [0, 1];
+ *                       index = (float)(n-1)*q, linear interpolation between t[(int)index] and the next
+ *                       element, in the reference build's arithmetic (one fma); errors "Q must be a
+ *                       scalar", "Q must be between 0 and 1".  Returns a 0-d array on the device.
+ * The reference refuses device arrays for both ("Median not available for GPU.", "Quantile not
+ * available for GPU device.") and sorts a host copy; here the two order statistics come from
+ * np_order_stat (radix select on the device). */
+float NDArray_Median_Float(NDArray *a);
+NDArray *NDArray_Quantile(NDArray *target, NDArray *q);
 /* operation must be NDArray_Add_Float or NDArray_Multiply_Float (the two the reference passes,
  * numpower.c:4637,4742,2661); anything else is an error. */
 NDArray *reduce(NDArray *array, int *axis, NDArray *(*operation)(NDArray *, NDArray *));

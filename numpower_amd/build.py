@@ -24,7 +24,7 @@ INCLUDE = ROOT / "include"
 LIBDIR = ROOT / "numpower_amd" / "lib"
 OBJDIR = ROOT / "build" / "obj"
 
-HIP_SOURCES = ["np_runtime.hip", "np_elementwise.hip", "np_reduce.hip", "np_sgemm.hip", "np_layout.hip"]
+HIP_SOURCES = ["np_runtime.hip", "np_elementwise.hip", "np_reduce.hip", "np_sgemm.hip", "np_layout.hip", "np_select.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 

@@ -1133,6 +1133,62 @@ float NDArray_Mean_Float(NDArray *a) { return reduce_all(a, NP_MEAN, "mean"); }
 float NDArray_Min(NDArray *target) { return reduce_all(target, NP_MIN, "min"); }
 float NDArray_Max(NDArray *target) { return reduce_all(target, NP_MAX, "max"); }
 
+float NDArray_Median_Float(NDArray *a) {   // arithmetics.c:149-158, calculate_median :111-138
+    if (!a || !require_gpu(a, "median")) return -1.0f;
+    const size_t n = (size_t)NDArray_NUMELEMENTS(a);
+    if (n == 0) {
+        throw_error("median of an empty array");
+        return -1.0f;
+    }
+    float t[2];
+    if (n % 2 == 0) {
+        if (!dev_ok(np_order_stat(NDArray_FDATA(a), n, n / 2 - 1, t))) return -1.0f;
+        return (t[0] + t[1]) / 2.0f;
+    }
+    if (!dev_ok(np_order_stat(NDArray_FDATA(a), n, n / 2, t))) return -1.0f;
+    return t[0];
+}
+
+NDArray *NDArray_Quantile(NDArray *target, NDArray *q) {   // statistics.c:60-79
+    if (!target || !q) return nullptr;
+    if (NDArray_NDIM(q) > 0) {
+        throw_error("Q must be a scalar");
+        return nullptr;
+    }
+    float quantile = 0.0f;
+    if (NDArray_DEVICE(q) == NDARRAY_DEVICE_GPU) {
+        if (!dev_ok(np_read_float(NDArray_FDATA(q), 0, &quantile))) return nullptr;
+    } else {
+        quantile = NDArray_FDATA(q)[0];
+    }
+    if (quantile < 0 || quantile > 1) {
+        throw_error("Q must be between 0 and 1");
+        return nullptr;
+    }
+    if (!require_gpu(target, "quantile")) return nullptr;
+    const size_t n = (size_t)NDArray_NUMELEMENTS(target);
+    if (n == 0) {
+        throw_error("quantile of an empty array");
+        return nullptr;
+    }
+    // calculate_quantile, statistics.c:31-44
+    const float index = (float)(n - 1) * quantile;
+    const int lower_index = (int)index;
+    const float weight = index - (float)lower_index;
+    float t[2];
+    if (!dev_ok(np_order_stat(NDArray_FDATA(target), n, (size_t)lower_index, t))) return nullptr;
+    // (1 - weight) * lower + weight * upper as gcc -march=native compiles it: the second product
+    // rounded, the first fused into the sum (vmulss + vfmadd132ss)
+    const float value = fmaf(1.0f - weight, t[0], weight * t[1]);
+    NDArray *rtn = new_array(nullptr, 0, NDARRAY_DEVICE_GPU, false);
+    if (!rtn) return nullptr;
+    if (!dev_ok(np_fill(NDArray_FDATA(rtn), value, 1))) {
+        NDArray_FREE(rtn);
+        return nullptr;
+    }
+    return rtn;
+}
+
 NDArray *reduce(NDArray *array, int *axis, NDArray *(*operation)(NDArray *, NDArray *)) {
     const int ax = axis ? *axis : 0;   // ndarray.c:528-532
     if (operation == NDArray_Add_Float) return reduce_axis(array, ax, NP_SUM, false);

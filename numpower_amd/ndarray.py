@@ -94,6 +94,8 @@ def _load_host():
         "NDArray_Sum_Float": (C.c_float, [_P]),
         "NDArray_Float_Prod": (C.c_float, [_P]),
         "NDArray_Mean_Float": (C.c_float, [_P]),
+        "NDArray_Median_Float": (C.c_float, [_P]),
+        "NDArray_Quantile": (_P, [_P, _P]),
         "NDArray_Min": (C.c_float, [_P]),
         "NDArray_Max": (C.c_float, [_P]),
         "NDArray_MinAxis": (_P, [_P, C.c_int]),
@@ -409,6 +411,25 @@ class NDArray:
         if isinstance(total, float):   # 1-D input: 0-d sum
             return float(np.float32(total) / np.float32(x.shape()[int(axis)]))
         return NDArray._binary("divide", total, count)
+
+    @staticmethod
+    def median(a):
+        """PHP_METHOD(NDArray, median) (numpower.c:2700-2731) -> float; on the device (radix select)."""
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        h.numpower_host_clear_error()
+        v = h.NDArray_Median_Float(x._p)
+        if h.numpower_host_last_error():
+            _raise_pending(h)
+        return float(v)
+
+    @staticmethod
+    def quantile(a, q):
+        """PHP_METHOD(NDArray, quantile) (numpower.c:2788): q a scalar in [0, 1] -> float."""
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        qq, _ = NDArray._coerce(q)
+        return NDArray._wrap(h.NDArray_Quantile(x._p, qq._p))
 
     # ---- layout (PHP_METHOD transpose, numpower.c:1404-1450) ----
     @staticmethod

@@ -534,6 +534,47 @@ int oracle_allclose(const float *a, const float *b, long n, float rtol, float at
     return 1;
 }
 
+/* Comparator of both qsort() calls (arithmetics.c:105-109, statistics.c:8-12). */
+static int cmp_float(const void *a, const void *b) {
+    float fa = *(const float *)a, fb = *(const float *)b;
+    return (fa > fb) - (fa < fb);
+}
+
+/* calculate_median (arithmetics.c:111-138): sort a copy; even count -> (t[n/2-1] + t[n/2]) / 2.0f,
+ * odd -> t[n/2].  out2 (optional) receives the two order statistics the value was formed from. */
+float oracle_median(const float *a, long n, float *out2) {
+    float *t = (float *)malloc((size_t)n * sizeof(float));
+    memcpy(t, a, (size_t)n * sizeof(float));
+    qsort(t, (size_t)n, sizeof(float), cmp_float);
+    float lo = (n % 2 == 0) ? t[n / 2 - 1] : t[n / 2], hi = t[n / 2];
+    float median = (n % 2 == 0) ? (lo + hi) / 2.0f : hi;
+    if (out2) { out2[0] = lo; out2[1] = hi; }
+    free(t);
+    return median;
+}
+
+/* calculate_quantile (statistics.c:14-50): index = (float)(n-1) * q; lower = (int)index; upper = lower+1;
+ * weight = index - (float)lower; (1 - weight) * t[lower] + weight * t[upper].  The reference reads
+ * t[n] (one past its malloc) when q == 1, and multiplies it by weight 0: restated with the last
+ * element there, which gives the same value whenever that stray float is finite.  The arithmetic
+ * is left to the compiler exactly as in the reference (gcc -mfma contracts it). */
+float oracle_quantile(const float *a, long n, float quantile, float *out2) {
+    float *t = (float *)malloc((size_t)n * sizeof(float));
+    memcpy(t, a, (size_t)n * sizeof(float));
+    qsort(t, (size_t)n, sizeof(float), cmp_float);
+    float index = (float)(n - 1) * quantile;
+    int lower_index = (int)index;
+    int upper_index = lower_index + 1;
+    if (upper_index > n - 1) upper_index = (int)(n - 1);
+    float weight = index - (float)lower_index;
+    float lower_value = t[lower_index];
+    float upper_value = t[upper_index];
+    float quantile_value = (1 - weight) * lower_value + weight * upper_value;
+    if (out2) { out2[0] = lower_value; out2[1] = upper_value; }
+    free(t);
+    return quantile_value;
+}
+
 /* NDArray::mean without axis: NDArray_Sum_Float(nda) / NDArray_NUMELEMENTS(nda) (numpower.c:2659) */
 float oracle_mean(const float *a, long n) { return oracle_sum(a, n) / n; }
 

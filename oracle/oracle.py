@@ -219,6 +219,30 @@ def allclose(a, b, rtol: float = 1e-05, atol: float = 1e-08) -> int:
     return int(lib.oracle_allclose(_ptr(a), _ptr(b), a.size, rtol, atol))
 
 
+def median(a, with_stats: bool = False):
+    """calculate_median (arithmetics.c:111-138) on the flattened array."""
+    a = _f(a).reshape(-1)
+    lib = load()
+    lib.oracle_median.restype = C.c_float
+    lib.oracle_median.argtypes = [_fp, C.c_long, _fp]
+    stats = np.zeros(2, np.float32)
+    v = np.float32(lib.oracle_median(_ptr(a), a.size, _ptr(stats)))
+    return (v, stats) if with_stats else v
+
+
+def quantile(a, q: float, with_stats: bool = False):
+    """NDArray_Quantile (statistics.c:60-79): `q` a scalar in [0, 1], the array flattened."""
+    a = _f(a).reshape(-1)
+    if q < 0 or q > 1:
+        raise OracleError("Q must be between 0 and 1")
+    lib = load()
+    lib.oracle_quantile.restype = C.c_float
+    lib.oracle_quantile.argtypes = [_fp, C.c_long, C.c_float, _fp]
+    stats = np.zeros(2, np.float32)
+    v = np.float32(lib.oracle_quantile(_ptr(a), a.size, float(q), _ptr(stats)))
+    return (v, stats) if with_stats else v
+
+
 # ---- views / layout: index bookkeeping only (bit-exact by construction), numpy restatements ----
 
 def reshape(x, shape) -> np.ndarray:
