@@ -324,6 +324,10 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
  * (indexing.c:21-48: one memcpy per diagonal element) and multi-index NDArray_Slice
  * (manipulation.c:193-283) reduce to. */
 int np_strided_copy(const float *in, float *out, int ndim, const int *host_shape, const long long *host_strides);
+/* Pitched 2-D copy: rows x width floats, consecutive rows dst_pitch / src_pitch floats apart (both
+ * >= width).  One launch per input of NDArray_Concatenate along an inner axis (manipulation.c:894-997,
+ * where NDArray_AssignArray copies element by element through the sliding view). */
+int np_copy2d(float *dst, size_t dst_pitch, const float *src, size_t src_pitch, size_t width, size_t rows);
 
 /* ---- device-side initializers (the reference's own phpbench suite, benchmarks/initializers/) ------
  * The reference builds every array on the CPU (initializers.c) and a GPU user pays the PCIe copy on

@@ -209,6 +209,28 @@ float NDArray_Max(NDArray *target);
  * available for GPU device.") and sorts a host copy; here the two order statistics come from
  * np_order_stat (radix select on the device). */
 float NDArray_Median_Float(NDArray *a);
+
+/* ---- manipulation wrappers (manipulation.c:554-1073, initializers.c:597-625), device arrays ----
+ * atleast_* / squeeze are views (reshape) of the contiguous input; swapaxes / rollaxis / moveaxis
+ * materialise through NDArray_Transpose (np_permute); concatenate is one pitched copy (np_copy2d) per
+ * input, v/h/d/column_stack are concatenate over atleast_2d / 1d / 3d / transposed inputs; diag of a
+ * vector is a zero fill + one pitched copy, of a matrix its diagonal.  Error messages are the
+ * reference's.  Deviations, where the reference is undefined or wrong: atleast_3d of a 2-d array is
+ * numpy's (r, c, 1) (the reference overflows a 2-int buffer there); rollaxis / moveaxis follow
+ * numpy's definition (the reference's index shuffling is only right for the cases it agrees with). */
+NDArray *NDArray_AtLeast1D(NDArray *a);
+NDArray *NDArray_AtLeast2D(NDArray *a);
+NDArray *NDArray_AtLeast3D(NDArray *a);
+NDArray *NDArray_Squeeze(NDArray *a, NDArray *axis);   /* axis: NULL, a CPU 0-d or 1-d array */
+NDArray *NDArray_SwapAxes(NDArray *a, int axis1, int axis2);
+NDArray *NDArray_Rollaxis(NDArray *a, int axis, int start);
+NDArray *NDArray_Moveaxis(NDArray *a, int *src, int *dest, int n_source, int n_dest);
+NDArray *NDArray_Concatenate(NDArray **arrays, int narrays, int axis);
+NDArray *NDArray_VSTACK(NDArray **arrays, int narrays);
+NDArray *NDArray_HSTACK(NDArray **arrays, int narrays);
+NDArray *NDArray_DSTACK(NDArray **arrays, int narrays);
+NDArray *NDArray_ColumnStack(NDArray **arrays, int narrays);
+NDArray *NDArray_Diag(NDArray *a);
 NDArray *NDArray_Quantile(NDArray *target, NDArray *q);
 /* operation must be NDArray_Add_Float or NDArray_Multiply_Float (the two the reference passes,
  * numpower.c:4637,4742,2661); anything else is an error. */

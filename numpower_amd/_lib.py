@@ -78,6 +78,7 @@ PROTOTYPES = {
     "np_reduce_all": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.POINTER(C.c_float)]),
     "np_reduce_all_dev": (C.c_int, [C.c_int, _f32p, C.c_size_t, _f32p]),
     "np_all": (C.c_int, [_f32p, C.c_size_t, C.c_uint, C.POINTER(C.c_int)]),
+    "np_copy2d": (C.c_int, [_f32p, C.c_size_t, _f32p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "np_order_stat": (C.c_int, [_f32p, C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]),
     "np_order_stat_dev": (C.c_int, [_f32p, C.c_size_t, C.c_size_t, _f32p]),
     "np_count_mismatch": (C.c_int, [C.c_int, _f32p, _f32p, C.c_size_t, C.c_float, C.c_float, C.POINTER(C.c_int)]),

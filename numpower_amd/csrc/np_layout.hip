@@ -291,6 +291,26 @@ int launch_transpose(const float *in, float *out, size_t batch, size_t rows, siz
     return NP_OK;
 }
 
+// Pitched 2-D copy: `rows` rows of `width` floats, row starts dst_pitch / src_pitch floats apart — what
+// concatenation along an inner axis is (each input is a slab of the result's rows).  Rows are walked
+// in float4 units when the width allows (dword-aligned accesses: any pitch, any base), linearised
+// over (row, unit) so narrow and wide rows fill the machine alike.
+template <int V>
+__global__ __launch_bounds__(256) void copy2d_kernel(float *__restrict__ dst, size_t dst_pitch, const float *__restrict__ src,
+                                                     size_t src_pitch, unsigned per_row, size_t units) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += stride) {
+        const size_t r = u / per_row;
+        const size_t c = (u - r * per_row) * V;
+        if constexpr (V == 4) {
+            const U4 x = *(const U4 *)(src + r * src_pitch + c);
+            *(U4 *)(dst + r * dst_pitch + c) = x;
+        } else {
+            dst[r * dst_pitch + c] = src[r * src_pitch + c];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -566,6 +586,26 @@ int np_arange(float *out, double start, double step, size_t n) {
     arange_kernel<<<(unsigned)blocks, 256, 0, np::stream()>>>(out, (const ArangeSeg *)table.ptr, (unsigned)segs.size(), n,
                                                              per_block);
     NP_LAUNCH_CHECK("arange_kernel");
+    return NP_OK;
+}
+
+int np_copy2d(float *dst, size_t dst_pitch, const float *src, size_t src_pitch, size_t width, size_t rows) {
+    if (width == 0 || rows == 0) return NP_OK;
+    if (!dst || !src) return np::fail(NP_ERR_INVALID, "np_copy2d: null pointer");
+    if (dst_pitch < width || src_pitch < width) return np::fail(NP_ERR_INVALID, "np_copy2d: pitch smaller than the row width");
+    if (int rc = np::ensure_init()) return rc;
+    if (dst_pitch == width && src_pitch == width) return np_memcpy_d2d(dst, src, rows * width * sizeof(float));
+    hipStream_t s = np::stream();
+    const bool vec = width % 4 == 0;
+    const size_t per_row = vec ? width / 4 : width;
+    const size_t units = per_row * rows;
+    size_t blocks = (units + 255) / 256;
+    const size_t cap = (size_t)np::num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    if (units >> 32) return np::fail(NP_ERR_INVALID, "np_copy2d: more than 2^32 units");
+    if (vec) copy2d_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(dst, dst_pitch, src, src_pitch, (unsigned)per_row, units);
+    else copy2d_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(dst, dst_pitch, src, src_pitch, (unsigned)per_row, units);
+    NP_LAUNCH_CHECK("copy2d_kernel");
     return NP_OK;
 }
 

@@ -26,6 +26,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "np_hip.h"
 
 namespace {
@@ -793,6 +795,293 @@ NDArray *NDArray_ConcatenateFlat(NDArray **arrays, int num_arrays) {   // manipu
 NDArray *NDArray_Append(NDArray **arrays, int axis, int num_arrays) {   // manipulation.c:368-374
     if (axis == -1) return NDArray_ConcatenateFlat(arrays, num_arrays);
     return nullptr;
+}
+
+/* ---- manipulation wrappers around the layout kernels (manipulation.c:554-1073, initializers.c:597-625) ---- */
+namespace {
+
+bool adjust_axis(int *axis, int ndim) {   // check_and_adjust_axis_msg, manipulation.c:40-54
+    if (*axis < -ndim || *axis >= ndim) {
+        throw_error("Axis is out of bounds for array dimension");
+        return false;
+    }
+    if (*axis < 0) *axis += ndim;
+    return true;
+}
+
+NDArray *transpose_to(NDArray *a, const int *order, int n) {
+    NDArray_Dims dims;
+    dims.ptr = const_cast<int *>(order);
+    dims.len = n;
+    return NDArray_Transpose(a, &dims);
+}
+
+}  // namespace
+
+NDArray *NDArray_AtLeast1D(NDArray *a) {   // manipulation.c:555-571
+    if (!a) return nullptr;
+    if (NDArray_NDIM(a) == 0) {
+        int shape[1] = {1};
+        return NDArray_Reshape(a, shape, 1);
+    }
+    return NDArray_Reshape(a, a->dimensions, a->ndim);
+}
+
+NDArray *NDArray_AtLeast2D(NDArray *a) {   // manipulation.c:574-589
+    if (!a) return nullptr;
+    if (NDArray_NDIM(a) < 2) {
+        int shape[2] = {1, (int)NDArray_NUMELEMENTS(a)};
+        return NDArray_Reshape(a, shape, 2);
+    }
+    return NDArray_Reshape(a, a->dimensions, a->ndim);
+}
+
+// manipulation.c:592-615.  0-d / 1-d -> (1, n, 1) as in the reference.  For a 2-d (r, c) input the
+// reference stores a third extent into a two-int allocation (heap overflow, :594-604) on its way to
+// (1, r, c); undefined there, numpy's (r, c, 1) here.
+NDArray *NDArray_AtLeast3D(NDArray *a) {
+    if (!a) return nullptr;
+    if (NDArray_NDIM(a) < 2) {
+        int shape[3] = {1, (int)NDArray_NUMELEMENTS(a), 1};
+        return NDArray_Reshape(a, shape, 3);
+    }
+    if (NDArray_NDIM(a) == 2) {
+        int shape[3] = {a->dimensions[0], a->dimensions[1], 1};
+        return NDArray_Reshape(a, shape, 3);
+    }
+    return NDArray_Reshape(a, a->dimensions, a->ndim);
+}
+
+NDArray *NDArray_Squeeze(NDArray *a, NDArray *axis) {   // manipulation.c:732-776, :618-729
+    if (!a) return nullptr;
+    const int nd = NDArray_NDIM(a);
+    if (nd > NP_MAX_ND_HOST) {
+        throw_error("squeeze: more than %d dimensions", NP_MAX_ND_HOST);
+        return nullptr;
+    }
+    bool drop[NP_MAX_ND_HOST] = {false};
+    if (axis) {   // NDArray_ConvertMultiAxis + NDArray_SqueezeSelected
+        if (NDArray_DEVICE(axis) != NDARRAY_DEVICE_CPU) {
+            throw_error("squeeze: axis must be a CPU scalar or vector");
+            return nullptr;
+        }
+        const int naxes = (int)NDArray_NUMELEMENTS(axis);
+        for (int i = 0; i < naxes; ++i) {
+            int ax = (int)NDArray_FDATA(axis)[i];
+            if (nd == 0 && NDArray_NDIM(axis) == 0 && (ax == 0 || ax == -1)) continue;
+            if (!adjust_axis(&ax, nd)) return nullptr;
+            if (drop[ax]) {
+                throw_error("duplicate value in 'axis'");
+                return nullptr;
+            }
+            drop[ax] = true;
+        }
+        for (int i = 0; i < nd; ++i)
+            if (drop[i] && a->dimensions[i] != 1) {
+                throw_error("cannot select an axis to squeeze out which has size not equal to one");
+                return nullptr;
+            }
+    } else {
+        for (int i = 0; i < nd; ++i) drop[i] = a->dimensions[i] == 1;
+    }
+    int shape[NP_MAX_ND_HOST], out = 0;
+    for (int i = 0; i < nd; ++i)
+        if (!drop[i]) shape[out++] = a->dimensions[i];
+    return NDArray_Reshape(a, shape, out);
+}
+
+NDArray *NDArray_SwapAxes(NDArray *a, int axis1, int axis2) {   // manipulation.c:779-803
+    if (!a) return nullptr;
+    const int n = NDArray_NDIM(a);
+    if (!adjust_axis(&axis1, n) || !adjust_axis(&axis2, n)) return nullptr;
+    int order[128];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    order[axis1] = axis2;
+    order[axis2] = axis1;
+    return transpose_to(a, order, n);
+}
+
+// manipulation.c:806-845.  The reference builds the order by shifting the identity right from
+// `start` and writing `axis` there, without taking `axis` out of its old place: right whenever the
+// axis moves towards the front (the common rollaxis(a, 2) / rollaxis(a, 2, 1)), a "repeated axis"
+// error when it moves back.  numpy's definition here (remove, then insert): same results wherever
+// the reference has one.
+NDArray *NDArray_Rollaxis(NDArray *a, int axis, int start) {
+    if (!a) return nullptr;
+    const int n = NDArray_NDIM(a);
+    if (!adjust_axis(&axis, n)) return nullptr;
+    if (start < 0) start += n;
+    if (start < 0 || start > n) {
+        throw_error("'%s' arg requires %d <= %s < %d, but %d was passed in", "start", -n, "start", n + 1, start);
+        return nullptr;
+    }
+    if (axis < start) start -= 1;
+    if (axis == start) return NDArray_Copy(a, NDArray_DEVICE(a));
+    int order[128], m = 0;
+    for (int i = 0; i < n; ++i)
+        if (i != axis) order[m++] = i;
+    for (int i = n - 1; i > start; --i) order[i] = order[i - 1];
+    order[start] = axis;
+    return transpose_to(a, order, n);
+}
+
+// manipulation.c:849-891.  The reference lists the untouched axes and then OVERWRITES order[dest[i]]
+// with src[i] (instead of inserting), which is only right when every destination lies at the end of
+// that list; numpy's definition (insert in order of destination) agrees with it there.
+NDArray *NDArray_Moveaxis(NDArray *a, int *src, int *dest, int n_source, int n_dest) {
+    if (!a || !src || !dest) return nullptr;
+    const int n = NDArray_NDIM(a);
+    if (n_source != n_dest) {
+        throw_error("`source` and `destination` must have the same number of elements.");
+        return nullptr;
+    }
+    if (n > 128 || n_source > n) {
+        throw_error("Axis is out of bounds for array dimension");
+        return nullptr;
+    }
+    int s[128], d[128];
+    for (int i = 0; i < n_source; ++i) {
+        s[i] = src[i];
+        d[i] = dest[i];
+        if (!adjust_axis(&s[i], n) || !adjust_axis(&d[i], n)) return nullptr;
+        for (int j = 0; j < i; ++j)
+            if (s[j] == s[i] || d[j] == d[i]) {
+                throw_error("repeated axis in `source` or `destination`");
+                return nullptr;
+            }
+    }
+    int order[128];
+    for (int i = 0; i < n; ++i) order[i] = -1;
+    for (int i = 0; i < n_source; ++i) order[d[i]] = s[i];
+    int next = 0;
+    for (int i = 0; i < n; ++i) {
+        if (order[i] != -1) continue;
+        bool moved = true;
+        while (moved) {
+            moved = false;
+            for (int j = 0; j < n_source; ++j)
+                if (s[j] == next) { ++next; moved = true; }
+        }
+        order[i] = next++;
+    }
+    return transpose_to(a, order, n);
+}
+
+NDArray *NDArray_Concatenate(NDArray **arrays, int narrays, int axis) {   // manipulation.c:895-995
+    if (narrays <= 0 || !arrays || !arrays[0]) {
+        throw_error("need at least one array to concatenate");
+        return nullptr;
+    }
+    const int ndim = NDArray_NDIM(arrays[0]);
+    if (ndim == 0) {
+        throw_error("zero-dimensional arrays cannot be concatenated");
+        return nullptr;
+    }
+    if (!adjust_axis(&axis, ndim)) return nullptr;
+    if (ndim > NP_MAX_ND_HOST) {
+        throw_error("concatenate: more than %d dimensions", NP_MAX_ND_HOST);
+        return nullptr;
+    }
+    int shape[NP_MAX_ND_HOST];
+    memcpy(shape, arrays[0]->dimensions, sizeof(int) * ndim);
+    for (int i = 1; i < narrays; ++i) {
+        if (!arrays[i]) return nullptr;
+        if (NDArray_NDIM(arrays[i]) != ndim) {
+            throw_error("all the input arrays must have same number of dimensions, but the array at index %d has %d "
+                        "dimension(s) and the array at index %d has %d dimension(s)", 0, ndim, i, NDArray_NDIM(arrays[i]));
+            return nullptr;
+        }
+        for (int d = 0; d < ndim; ++d) {
+            if (d == axis) shape[d] += arrays[i]->dimensions[d];
+            else if (shape[d] != arrays[i]->dimensions[d]) {
+                throw_error("all the input array dimensions except for the concatenation axis must match exactly, but "
+                            "along dimension %d, the array at index %d has size %d and the array at index %d has size %d",
+                            d, 0, shape[d], i, arrays[i]->dimensions[d]);
+                return nullptr;
+            }
+        }
+    }
+    for (int i = 0; i < narrays; ++i) {
+        if (NDArray_DEVICE(arrays[i]) != NDArray_DEVICE(arrays[0])) {
+            throw_error("Device mismatch, both NDArray MUST be in the same device.");
+            return nullptr;
+        }
+        if (!require_gpu(arrays[i], "concatenate")) return nullptr;
+    }
+    NDArray *ret = new_array(shape, ndim, NDARRAY_DEVICE_GPU, false);
+    if (!ret) return nullptr;
+    size_t outer = 1, inner = 1;
+    for (int d = 0; d < axis; ++d) outer *= (size_t)shape[d];
+    for (int d = axis + 1; d < ndim; ++d) inner *= (size_t)shape[d];
+    const size_t dst_pitch = (size_t)shape[axis] * inner;
+    size_t offset = 0;
+    for (int i = 0; i < narrays; ++i) {   // one pitched copy per input: its rows are slabs of the result's rows
+        const size_t width = (size_t)arrays[i]->dimensions[axis] * inner;
+        if (!dev_ok(np_copy2d(NDArray_FDATA(ret) + offset, dst_pitch, NDArray_FDATA(arrays[i]), width, width, outer))) {
+            NDArray_FREE(ret);
+            return nullptr;
+        }
+        offset += width;
+    }
+    return ret;
+}
+
+namespace {
+
+// concatenate(f(arrays[i])...) with the temporaries released afterwards
+NDArray *stack_with(NDArray **arrays, int narrays, NDArray *(*prepare)(NDArray *), int axis_if_1d, int axis) {
+    if (narrays <= 0 || !arrays) {
+        throw_error("need at least one array to concatenate");
+        return nullptr;
+    }
+    std::vector<NDArray *> parsed((size_t)narrays, nullptr);
+    NDArray *result = nullptr;
+    bool ok = true;
+    for (int i = 0; i < narrays && ok; ++i) {
+        parsed[(size_t)i] = arrays[i] ? prepare(arrays[i]) : nullptr;
+        ok = parsed[(size_t)i] != nullptr;
+    }
+    if (ok) result = NDArray_Concatenate(parsed.data(), narrays, NDArray_NDIM(parsed[0]) == 1 ? axis_if_1d : axis);
+    for (NDArray *p : parsed)
+        if (p) NDArray_FREE(p);
+    return result;
+}
+
+NDArray *column_of(NDArray *a) {   // NDArray_ColumnStack's per-input step (manipulation.c:1059-1063)
+    NDArray *two = NDArray_AtLeast2D(a);
+    if (!two) return nullptr;
+    NDArray *t = NDArray_Transpose(two, nullptr);
+    NDArray_FREE(two);
+    return t;
+}
+
+}  // namespace
+
+NDArray *NDArray_VSTACK(NDArray **arrays, int narrays) { return stack_with(arrays, narrays, NDArray_AtLeast2D, 0, 0); }   // :999-1012
+NDArray *NDArray_HSTACK(NDArray **arrays, int narrays) { return stack_with(arrays, narrays, NDArray_AtLeast1D, 0, 1); }   // :1015-1034
+NDArray *NDArray_DSTACK(NDArray **arrays, int narrays) { return stack_with(arrays, narrays, NDArray_AtLeast3D, 2, 2); }   // :1037-1052
+// :1055-1073: every input goes through atleast_2d + transpose, so 2-d inputs are stacked TRANSPOSED (numpy leaves
+// them as they are); kept as the reference has it
+NDArray *NDArray_ColumnStack(NDArray **arrays, int narrays) { return stack_with(arrays, narrays, column_of, 1, 1); }
+
+NDArray *NDArray_Diag(NDArray *a) {   // initializers.c:597-625
+    if (!a) return nullptr;
+    if (NDArray_NDIM(a) != 1 && NDArray_NDIM(a) != 2) {
+        throw_error("Input array must be a vector or 2-dimensional");
+        return nullptr;
+    }
+    if (NDArray_NDIM(a) == 2) return NDArray_Diagonal(a, 0);
+    if (!require_gpu(a, "diag")) return nullptr;
+    const int n = (int)NDArray_NUMELEMENTS(a);
+    const int shape[2] = {n, n};
+    NDArray *rtn = new_array(shape, 2, NDARRAY_DEVICE_GPU, true);
+    if (!rtn) return nullptr;
+    // element i goes to i * (n + 1): a pitched copy of n one-float rows
+    if (n > 0 && !dev_ok(np_copy2d(NDArray_FDATA(rtn), (size_t)n + 1, NDArray_FDATA(a), 1, 1, (size_t)n))) {
+        NDArray_FREE(rtn);
+        return nullptr;
+    }
+    return rtn;
 }
 
 // NDArray_Slice (manipulation.c:193-283): indexes[i] is a small CPU array [start], [start, stop] or

@@ -128,6 +128,15 @@ def _load_host():
     sig["NDArray_Flatten"] = (_P, [_P])
     sig["NDArray_ExpandDim"] = (_P, [_P, _P])
     sig["NDArray_Append"] = (_P, [C.POINTER(_P), C.c_int, C.c_int])
+    for name in ("NDArray_AtLeast1D", "NDArray_AtLeast2D", "NDArray_AtLeast3D", "NDArray_Diag"):
+        sig[name] = (_P, [_P])
+    sig["NDArray_Squeeze"] = (_P, [_P, _P])
+    sig["NDArray_SwapAxes"] = (_P, [_P, C.c_int, C.c_int])
+    sig["NDArray_Rollaxis"] = (_P, [_P, C.c_int, C.c_int])
+    sig["NDArray_Moveaxis"] = (_P, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int])
+    sig["NDArray_Concatenate"] = (_P, [C.POINTER(_P), C.c_int, C.c_int])
+    for name in ("NDArray_VSTACK", "NDArray_HSTACK", "NDArray_DSTACK", "NDArray_ColumnStack"):
+        sig[name] = (_P, [C.POINTER(_P), C.c_int])
     sig["NDArray_Slice"] = (_P, [_P, C.POINTER(_P), C.c_int])
     for name, (res, args) in sig.items():
         fn = getattr(h, name)
@@ -470,6 +479,62 @@ class NDArray:
         y, _ = NDArray._coerce(b)
         arr = (_P * 2)(x._p, y._p)
         return NDArray._wrap(h.NDArray_Append(arr, -1, 2))
+
+    # ---- manipulation wrappers (PHP_METHODs atleast_1d … column_stack, numpower.c:1480-1570, 3590-3900) ----
+    @staticmethod
+    def _unary_host(name, a):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(getattr(h, name)(x._p))
+
+    atleast_1d = staticmethod(lambda a: NDArray._unary_host("NDArray_AtLeast1D", a))
+    atleast_2d = staticmethod(lambda a: NDArray._unary_host("NDArray_AtLeast2D", a))
+    atleast_3d = staticmethod(lambda a: NDArray._unary_host("NDArray_AtLeast3D", a))
+    diag = staticmethod(lambda a: NDArray._unary_host("NDArray_Diag", a))
+
+    @staticmethod
+    def squeeze(a, axis=None):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        if axis is None:
+            return NDArray._wrap(h.NDArray_Squeeze(x._p, None))
+        ax, _ = NDArray._coerce(axis)
+        return NDArray._wrap(h.NDArray_Squeeze(x._p, ax._p))
+
+    @staticmethod
+    def swapaxes(a, axis1, axis2):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(h.NDArray_SwapAxes(x._p, int(axis1), int(axis2)))
+
+    @staticmethod
+    def rollaxis(a, axis, start=0):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        return NDArray._wrap(h.NDArray_Rollaxis(x._p, int(axis), int(start)))
+
+    @staticmethod
+    def moveaxis(a, source, destination):
+        h = _load_host()
+        x, _ = NDArray._coerce(a)
+        src = [int(v) for v in (source if isinstance(source, (list, tuple)) else [source])]
+        dst = [int(v) for v in (destination if isinstance(destination, (list, tuple)) else [destination])]
+        s = (C.c_int * max(len(src), 1))(*src)
+        d = (C.c_int * max(len(dst), 1))(*dst)
+        return NDArray._wrap(h.NDArray_Moveaxis(x._p, s, d, len(src), len(dst)))
+
+    @staticmethod
+    def _stack(name, arrays, *extra):
+        h = _load_host()
+        xs = [NDArray._coerce(a)[0] for a in arrays]
+        arr = (_P * max(len(xs), 1))(*[x._p for x in xs])
+        return NDArray._wrap(getattr(h, name)(arr, len(xs), *extra))
+
+    concatenate = staticmethod(lambda arrays, axis=0: NDArray._stack("NDArray_Concatenate", arrays, int(axis)))
+    vstack = staticmethod(lambda arrays: NDArray._stack("NDArray_VSTACK", arrays))
+    hstack = staticmethod(lambda arrays: NDArray._stack("NDArray_HSTACK", arrays))
+    dstack = staticmethod(lambda arrays: NDArray._stack("NDArray_DSTACK", arrays))
+    column_stack = staticmethod(lambda arrays: NDArray._stack("NDArray_ColumnStack", arrays))
 
     @staticmethod
     def diagonal(a):         # numpower.c:1179

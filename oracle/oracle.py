@@ -219,6 +219,27 @@ def allclose(a, b, rtol: float = 1e-05, atol: float = 1e-08) -> int:
     return int(lib.oracle_allclose(_ptr(a), _ptr(b), a.size, rtol, atol))
 
 
+# ---- manipulation wrappers: index bookkeeping only, numpy restatements of manipulation.c:554-1073 ----
+def atleast_3d(a):
+    """NDArray_AtLeast3D (manipulation.c:592-615): (1, n, 1) below 2-d as the reference; numpy's (r, c, 1) for a
+    2-d input, where the reference overflows its two-int shape buffer."""
+    return np.atleast_3d(_f(a))
+
+
+def column_stack(arrays):
+    """NDArray_ColumnStack (manipulation.c:1055-1073): atleast_2d + transpose of EVERY input (2-d inputs too,
+    unlike numpy), concatenated along axis 1."""
+    return np.concatenate([np.atleast_2d(_f(a)).T for a in arrays], axis=1)
+
+
+def diag(a):
+    """NDArray_Diag (initializers.c:597-625)."""
+    a = _f(a)
+    if a.ndim not in (1, 2):
+        raise OracleError("Input array must be a vector or 2-dimensional")
+    return np.diag(a).astype(np.float32) if a.ndim == 1 else np.ascontiguousarray(np.diagonal(a)[:min(a.shape)])
+
+
 def median(a, with_stats: bool = False):
     """calculate_median (arithmetics.c:111-138) on the flattened array."""
     a = _f(a).reshape(-1)
