@@ -111,7 +111,7 @@ class Dist:
             # stdout must carry exactly one JSON line, so the banner is flushed into /dev/null.
             with _stdout_to_devnull():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank),
-                                        timeout=datetime.timedelta(seconds=240))
+                                        timeout=datetime.timedelta(seconds=600))
                 warm = torch.zeros(1, device="cuda")
                 dist.all_reduce(warm)
                 torch.cuda.synchronize()
