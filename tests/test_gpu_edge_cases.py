@@ -104,6 +104,14 @@ def test_past_2_to_31_elements(hip):
     want = float(np.sqrt(np.float32(3.0)))
     assert [probe(out, i) for i in probes[:-1]] == [want] * 6
     assert probe(out, n - 1) == float(np.sqrt(np.float32(15.0)))
+    # order statistics with 64-bit indices: b is 2.0 everywhere except b[n-1] = 10
+    two = (C.c_float * 2)()
+    _lib.check(lib.np_order_stat(b.ptr, n, n - 1, two))
+    assert list(two) == [10.0, 10.0]
+    _lib.check(lib.np_order_stat(b.ptr, n, n - 2, two))
+    assert list(two) == [2.0, 10.0]
+    _lib.check(lib.np_order_stat(b.ptr, n, 0, two))
+    assert list(two) == [2.0, 2.0]
     for buf in (a, b, out):
         buf.free()
     freed = C.c_size_t()
