@@ -264,6 +264,25 @@ def bench_extras(dist: Dist, steps, warmup):
     r["parity_ok"] = bool(flag.value == 1)      # a, b are independent uniforms: not close
     r["note"] = "includes the 4-byte D2H of the verdict per call"
     ex["allclose_1e8"] = r
+    # pow on the path's six binary ops is the one with real arithmetic: fp64 2^(y log2 x) per element
+    r = hbm_case("pow 1e8 fp32 (arithmetics.c:825)", 12.0 * N,
+                 lambda: D.binary("pow", da, "full", db, "full", 1, N, out=do), steps, warmup, dist)
+    sample = slice(0, 2_000_000)
+    with np.errstate(all="ignore"):
+        ref = np.power(a[sample].astype(np.float64), b[sample].astype(np.float64))
+    gotp = do.to_host().reshape(-1)[sample].astype(np.float64)
+    r["parity_max_rel_err_vs_fp64"] = float((np.abs(gotp - ref) / np.maximum(ref, 1e-300)).max())
+    r["parity_ok"] = bool(r["parity_max_rel_err_vs_fp64"] <= 1e-5)
+    ex["pow_1e8"] = r
+    # median of 1e8 floats: np_order_stat, three histogram passes = 12 B/elem read, nothing written
+    two_f = (C.c_float * 2)()
+    r = hbm_case("median 1e8 fp32 (radix select; arithmetics.c:111-158 sorts a host copy)", 12.0 * N,
+                 lambda: _check(lib0.np_order_stat(da.ptr, N, N // 2 - 1, two_f)), steps, warmup, dist)
+    part = np.partition(a, [N // 2 - 1, N // 2])
+    r["parity_ok"] = bool(two_f[0] == part[N // 2 - 1] and two_f[1] == part[N // 2])
+    r["note"] = "includes the 8-byte D2H of the two order statistics per call"
+    ex["median_1e8"] = r
+    del part
     # exp(a) * b + 2 as ONE fused kernel (12 B/elem) vs three launches
     from numpower_amd._lib import BINARY_OPS, UNARY_OPS, FusedOp, check
     prog = (FusedOp * 3)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0),

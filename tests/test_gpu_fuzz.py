@@ -1,0 +1,156 @@
+"""Seeded random-shape parity sweep: the specialised kernels (thin / split-K / padded GEMMs, lane-group
+and chunked reductions, tiled / skinny / gathered permutes, ragged broadcasts, pitched copies, radix
+select) are picked by shape, so shapes are drawn from a pool rich in the dispatch boundaries (1, 3, 4, 5,
+16, 17, 31..33, 63..65, 255..257, 1000, 2048, 4099, 65536, ...).  NP_FUZZ_CASES scales the sweep
+(tools/fuzz_parity.py runs it long)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from numpower_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+POOL = [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, 511, 1000, 1024, 2047, 2048,
+        2049, 4099, 10_000, 65_535, 65_536, 100_003, 1_000_000]
+CASES = int(os.environ.get("NP_FUZZ_CASES", "60"))
+
+
+def _nd():
+    from numpower_amd.ndarray import NDArray
+    return NDArray
+
+
+def _shape(rng, ndim, budget):
+    """ndim extents from POOL whose product stays within budget (drawn one by one from what still fits)."""
+    dims, left = [], budget
+    for _ in range(ndim):
+        fits = [p for p in POOL if p <= left]
+        d = int(rng.choice(fits))
+        dims.append(d)
+        left //= d
+    order = rng.permutation(ndim)
+    return tuple(dims[i] for i in order)
+
+
+def _bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def test_fuzz_axis_reductions(hip, oracle):
+    nd = _nd()
+    rng = np.random.default_rng(1234)
+    for case in range(CASES):
+        ndim = int(rng.integers(1, 5))
+        shape = _shape(rng, ndim, 3_000_000)
+        axis = int(rng.integers(0, ndim))
+        x = synth.uniform(shape, 1000 + case, -1.0, 1.0)
+        g = nd.array(x).gpu()
+        n_axis = shape[axis]
+        for op in ("sum", "max", "min", "mean"):
+            got = getattr(nd, op)(g, axis)
+            got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
+            if op in ("max", "min"):
+                want = getattr(x, op)(axis=axis)
+                assert (_bits(got) == _bits(want)).all(), (op, shape, axis)
+            else:
+                ref = x.astype(np.float64).sum(axis=axis) / (n_axis if op == "mean" else 1)
+                scale = np.abs(x).astype(np.float64).sum(axis=axis) / (n_axis if op == "mean" else 1)
+                assert (np.abs(got - ref) <= 1e-5 * np.maximum(scale, 1e-30)).all(), (op, shape, axis)
+        for name, fn in (("argmax", np.argmax), ("argmin", np.argmin)):
+            got = getattr(nd, name)(g, axis)
+            got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
+            assert (np.asarray(got, np.float32) == fn(x, axis=axis).astype(np.float32)).all(), (name, shape, axis)
+
+
+def test_fuzz_broadcast_binary(hip, oracle):
+    nd = _nd()
+    rng = np.random.default_rng(99)
+    ops = ["add", "subtract", "multiply", "divide", "greater", "maximum", "mod", "equal"]
+    for case in range(CASES):
+        rows, cols = _shape(rng, 2, 4_000_000)
+        kind = rng.choice(["full", "row", "col", "scalar"])
+        a = synth.uniform((rows, cols), 2000 + case, -2.0, 2.0)
+        a.reshape(-1)[::7] = 0.0
+        b = {"full": lambda: synth.uniform((rows, cols), 3000 + case, 0.5, 2.0),
+             "row": lambda: synth.uniform((cols,), 3000 + case, 0.5, 2.0),
+             "col": lambda: synth.uniform((rows, 1), 3000 + case, 0.5, 2.0),
+             "scalar": lambda: np.float32(1.5)}[kind]()
+        op = ops[case % len(ops)]
+        ga, gb = nd.array(a).gpu(), (nd.array(b).gpu() if kind != "scalar" else float(b))
+        for left, right, hl, hr in ((ga, gb, a, b), (gb, ga, b, a)):
+            if op in ("maximum", "minimum") and kind == "scalar":
+                continue
+            try:
+                want = oracle.binary(op, hl, hr)
+            except Exception:
+                continue      # a combination the reference rejects (e.g. (R,1) on the left)
+            got = nd._binary(op, left, right).cpu().numpy()
+            # x % 0 is NaN on both sides, but x86 and gfx950 produce different default-NaN sign bits
+            same = (_bits(got) == _bits(want)) | (np.isnan(got) & np.isnan(want))
+            assert same.all(), (op, kind, rows, cols)
+
+
+def test_fuzz_matmul(hip):
+    nd = _nd()
+    rng = np.random.default_rng(7)
+    pool = [p for p in POOL if p <= 100_003]
+    done = 0
+    while done < CASES:
+        m, n, k = (int(rng.choice(pool)) for _ in range(3))
+        if m * k > 40_000_000 or k * n > 40_000_000 or m * n > 40_000_000 or m * n * k > 60_000_000_000:
+            continue
+        done += 1
+        a = synth.uniform((m, k), 4000 + done, -1.0, 1.0)
+        b = synth.uniform((k, n), 5000 + done, -1.0, 1.0)
+        got = nd.matmul(nd.array(a).gpu(), nd.array(b).gpu()).cpu().numpy()
+        # spot-check up to 64 rows x 64 columns against fp64 (the full product would dominate the run time)
+        ri = np.unique(rng.integers(0, m, size=min(m, 64)))
+        ci = np.unique(rng.integers(0, n, size=min(n, 64)))
+        ref = a[ri].astype(np.float64) @ b[:, ci].astype(np.float64)
+        scale = np.abs(a[ri]).astype(np.float64) @ np.abs(b[:, ci]).astype(np.float64)
+        assert got.shape == (m, n)
+        assert (np.abs(got[np.ix_(ri, ci)] - ref) <= 2e-6 * np.maximum(scale, 1e-30)).all(), (m, n, k)
+        if m * n <= 4_000_000:      # and nothing written outside / left unwritten
+            assert np.isfinite(got).all()
+
+
+def test_fuzz_permute_and_concatenate(hip):
+    nd = _nd()
+    rng = np.random.default_rng(5)
+    for case in range(CASES):
+        ndim = int(rng.integers(2, 6))
+        shape = _shape(rng, ndim, 3_000_000)
+        perm = [int(p) for p in rng.permutation(ndim)]
+        x = synth.uniform(shape, 6000 + case, -1.0, 1.0)
+        g = nd.array(x).gpu()
+        got = nd.transpose(g, perm).cpu().numpy()
+        assert (_bits(got) == _bits(np.transpose(x, perm))).all(), (shape, perm)
+        axis = int(rng.integers(0, ndim))
+        other = list(shape)
+        other[axis] = int(rng.choice([1, 2, 3, 17, 64]))
+        if math.prod(other) > 3_000_000:
+            continue
+        y = synth.uniform(tuple(other), 7000 + case, -1.0, 1.0)
+        got = nd.concatenate([g, nd.array(y).gpu(), g], axis).cpu().numpy()
+        assert (_bits(got) == _bits(np.concatenate([x, y, x], axis))).all(), (shape, axis)
+
+
+def test_fuzz_order_statistics(hip, oracle):
+    nd = _nd()
+    rng = np.random.default_rng(11)
+    for case in range(CASES):
+        n = int(rng.choice([p for p in POOL if p >= 2]))
+        style = case % 3
+        x = synth.uniform((n,), 8000 + case, -1.0, 1.0)
+        if style == 1:
+            x = np.rint(x * 3).astype(np.float32)            # heavy duplicates
+        elif style == 2:
+            x = (x * np.float32(1e-3) + np.float32(1.0)).astype(np.float32)   # one binade: ranks part in the low digits
+        x[x == 0] = 0.0                                      # the reference's comparator cannot order -0 / +0
+        g = nd.array(x).gpu()
+        assert np.float32(nd.median(g)).view(np.uint32) == oracle.median(x).view(np.uint32), (n, style)
+        q = float(rng.uniform(0.0, 1.0))
+        assert np.float32(nd.quantile(g, q)).view(np.uint32) == oracle.quantile(x, q).view(np.uint32), (n, style, q)
