@@ -154,3 +154,88 @@ def test_fuzz_order_statistics(hip, oracle):
         assert np.float32(nd.median(g)).view(np.uint32) == oracle.median(x).view(np.uint32), (n, style)
         q = float(rng.uniform(0.0, 1.0))
         assert np.float32(nd.quantile(g, q)).view(np.uint32) == oracle.quantile(x, q).view(np.uint32), (n, style, q)
+
+
+def test_fuzz_fused_chains(hip):
+    """Random linear chains (<= 10 steps, row / column / 0-d / python-scalar operands on either side)
+    through the one-kernel interpreter vs the same ops issued one by one: bit-identical."""
+    from numpower_amd.lazy import Lazy   # noqa: F401  (installs NDArray.lazy)
+    nd = _nd()
+    rng = np.random.default_rng(21)
+    unary = ["abs", "exp", "sqrt", "sin", "cos", "tanh", "negate", "floor", "ceil", "sign", "log1p", "arctan", "rint",
+             "trunc", "sinh", "reciprocal", "log", "expm1"]
+    binary = ["add", "subtract", "multiply", "divide", "maximum", "minimum", "greater", "less_equal", "mod", "pow", "equal"]
+    for case in range(max(CASES // 2, 10)):
+        rows, cols = _shape(rng, 2, 2_000_000)
+        a = synth.uniform((rows, cols), 9000 + case, -1.5, 1.5)
+        a.reshape(-1)[::5] = 0.0
+        ga = nd.array(a).gpu()
+        operands = {"full": nd.array(synth.uniform((rows, cols), 9500 + case, 0.25, 2.0)).gpu(),
+                    "row": nd.array(synth.uniform((cols,), 9600 + case, 0.25, 2.0)).gpu(),
+                    "col": nd.array(synth.uniform((rows, 1), 9700 + case, 0.25, 2.0)).gpu(),
+                    "zero_d": nd.array(np.float32(1.25)).gpu(), "py": 0.75}
+        lz, eager, desc = ga.lazy(), ga, []
+        for _ in range(int(rng.integers(1, 11))):
+            if rng.random() < 0.45:
+                name = str(rng.choice(unary))
+                lz = getattr(lz, name)()
+                eager = nd._unary(name, eager) if hasattr(nd, "_unary") else getattr(nd, name)(eager)
+                desc.append(name)
+            else:
+                name, kind, swap = str(rng.choice(binary)), str(rng.choice(list(operands))), bool(rng.random() < 0.3)
+                if kind == "col" and swap:
+                    swap = False          # (R,1) on the left of an (R,C) array: rejected by the reference's broadcast
+                if kind == "py" and name in ("maximum", "minimum", "greater", "less_equal", "equal"):
+                    kind = "zero_d"
+                other = operands[kind]
+                if swap:
+                    lz = lz._binary(name, other, True)
+                    eager = nd._binary(name, other, eager)
+                else:
+                    lz = lz._binary(name, other, False)
+                    eager = nd._binary(name, eager, other)
+                desc.append("%s(%s%s)" % (name, kind, ",swapped" if swap else ""))
+        got, want = lz.eval().cpu().numpy(), eager.cpu().numpy()
+        same = (_bits(got) == _bits(want)) | (np.isnan(got) & np.isnan(want))
+        assert got.shape == want.shape and same.all(), ((rows, cols), desc)
+
+
+def test_fuzz_vectors_statistics_slices(hip, oracle):
+    """dot (matrix . vector, vector . vector), outer, variance / std, array_equal / allclose and strided
+    slices at random shapes."""
+    nd = _nd()
+    rng = np.random.default_rng(31)
+    for case in range(CASES):
+        m, n = _shape(rng, 2, 6_000_000)
+        a = synth.uniform((m, n), 11000 + case, -1.0, 1.0)
+        x = synth.uniform((n,), 12000 + case, -1.0, 1.0)
+        ga, gx = nd.array(a).gpu(), nd.array(x).gpu()
+        got = nd.dot(ga, gx)
+        got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
+        ref = a.astype(np.float64) @ x.astype(np.float64)
+        scale = np.abs(a).astype(np.float64) @ np.abs(x).astype(np.float64)
+        assert (np.abs(got - ref) <= 2e-6 * np.maximum(scale, 1e-30)).all(), ("matvec", m, n)
+        got = np.float32(nd.dot(gx, gx))
+        ref = float((x.astype(np.float64) ** 2).sum())
+        assert abs(got - ref) <= 2e-6 * max(ref, 1e-30), ("inner", n)
+        if m * n <= 2_000_000:
+            y = synth.uniform((m,), 13000 + case, -1.0, 1.0)
+            got = nd.outer(nd.array(y).gpu(), gx).cpu().numpy()
+            assert (_bits(got) == _bits(np.outer(y, x))).all(), ("outer", m, n)
+        flat = a.reshape(-1)
+        var = float(np.float32(nd.variance(ga)))
+        ref = float(flat.astype(np.float64).var())
+        assert abs(var - ref) <= 1e-5 * max(ref, 1e-30), ("variance", m, n)
+        std = float(np.float32(nd.std(ga)))
+        assert abs(std - ref ** 0.5) <= 1e-5 * max(ref ** 0.5, 1e-30), ("std", m, n)
+        b = a.copy()
+        assert nd.array_equal(ga, nd.array(b).gpu()) is True and nd.allclose(ga, nd.array(b).gpu()) is True
+        i = int(rng.integers(0, m)); j = int(rng.integers(0, n))
+        b[i, j] += np.float32(0.5)
+        gb = nd.array(b).gpu()
+        assert nd.array_equal(ga, gb) is False and nd.allclose(ga, gb) is False, (m, n, i, j)
+        # strided slice on both axes: [start, stop, step]
+        r0 = int(rng.integers(0, m)); r1 = int(rng.integers(r0, m)) + 1; rs = int(rng.integers(1, 4))
+        c0 = int(rng.integers(0, n)); c1 = int(rng.integers(c0, n)) + 1; cs = int(rng.integers(1, 4))
+        got = ga.slice([r0, r1, rs], [c0, c1, cs]).cpu().numpy()
+        assert (_bits(got) == _bits(a[r0:r1:rs, c0:c1:cs])).all(), ("slice", (m, n), (r0, r1, rs), (c0, c1, cs))
