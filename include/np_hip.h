@@ -214,6 +214,16 @@ int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inp
 int np_fused_chain_reduce(const float *const *inputs, const int *input_kinds, int n_inputs,
                           const np_fused_op *ops, int n_ops, int reduce_op, size_t rows, size_t cols,
                           float *host_out);
+/* ... and with a reduction over ONE axis of the rows x cols chain value as the last step: axis 1 (the
+ * last axis) -> out[rows], axis 0 -> out[cols]; out is a DEVICE pointer.  sum(exp(X), 1), max(X - c, 1),
+ * mean((X - mu) * (X - mu), 0) in one pass over X: 4 B/elem instead of 12.  Last axis: a wave (or, for
+ * long or few rows, a workgroup) per row; first axis: a lane per 4-column slot, the workgroup's waves
+ * interleaved over a chunk of rows, chunk partials folded by np_reduce_axis.  Shapes those kernels would
+ * run mostly idle on (rows shorter than 64, fewer than 128 rows, fewer than 32 column slots) take one
+ * fused pass into a temporary + np_reduce_axis instead.  Same combine rules as np_reduce_axis. */
+int np_fused_chain_reduce_axis(const float *const *inputs, const int *input_kinds, int n_inputs,
+                               const np_fused_op *ops, int n_ops, int reduce_op, size_t rows, size_t cols, int axis,
+                               float *out);
 
 /* ---- reductions -------------------------------------------------------------------------- */
 

@@ -173,6 +173,12 @@ NDArray *NDArray_FusedChain(NDArray **inputs, int n_inputs, const np_fused_op *o
 /* ... ending in a full reduction (np_reduce_op: sum / prod / min / max / mean) of the chain value,
  * which is never written to memory.  Returns NaN and raises on error. */
 float NDArray_FusedChainReduce(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops, int reduce_op);
+/* ... ending in a reduction over one axis (same `axis` rules and error as reduce(), ndarray.c:534-538): the
+ * result has the chain's shape without that axis.  The last axis of any array and the first axis of a
+ * 2-d array run as ONE kernel (np_fused_chain_reduce_axis); any other axis evaluates the chain into a
+ * temporary and reduces that. */
+NDArray *NDArray_FusedChainReduceAxis(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops, int reduce_op,
+                                      int axis);
 
 /* ---- argmax / argmin (src/ndmath/calculation.c:73-194) ----
  * axis = 128 (NDARRAY_MAX_DIMS) reduces the flattened array; indices are returned as floats. */

@@ -871,9 +871,11 @@ __device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p,
     }
 }
 
-template <int U, int G, bool LIGHT, typename I>
-__device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out, I elem0, I nslots, I tid,
-                                           I stride, float &racc) {
+// VACC: the sink accumulates per register element (rv[u * G + e], for column reductions where every
+// element of a slot belongs to a different result) instead of into the one scalar racc.
+template <int U, int G, bool LIGHT, typename I, bool VACC>
+__device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict__ out, I elem0, I nslots, I tid,
+                                                I stride, float &racc, float (&rv)[U * G]) {
     constexpr int N = U * G;
     const int sink = f->sink;
     const int n_ops = f->n_ops;
@@ -950,6 +952,24 @@ __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out
                 fused_fetch<U, G, I>(nxt, o.prefetch, o.prefetch_idx, first, row, col, live);
             binary_dispatch<N, LIGHT>(o.op, acc, oth, o.swap != 0, o.quirk != 0, body);
         }
+        if constexpr (VACC) {
+            if (sink == NP_SUM) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) rv[e] += live[e / G] ? acc[e] : 0.0f;
+            } else if (sink == NP_PROD) {
+#pragma unroll
+                for (int e = 0; e < N; ++e) rv[e] *= live[e / G] ? acc[e] : 1.0f;
+            } else if (sink == NP_MIN) {
+#pragma unroll
+                for (int e = 0; e < N; ++e)
+                    if (live[e / G] && acc[e] < rv[e]) rv[e] = acc[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < N; ++e)
+                    if (live[e / G] && acc[e] > rv[e]) rv[e] = acc[e];
+            }
+            continue;
+        }
         if (sink >= 0) {
             // reduction at the end of the chain: the value never goes to memory (uniform branch;
             // same combine rules as np_reduce_all: NaN never replaces in min / max)
@@ -978,6 +998,100 @@ __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out
                                             (v4f_u *)(out + (size_t)first[u]));
             else
                 out[first[u]] = acc[u];
+        }
+    }
+}
+
+template <int U, int G, bool LIGHT, typename I>
+__device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out, I elem0, I nslots, I tid,
+                                           I stride, float &racc) {
+    float unused[U * G];
+    fused_span_impl<U, G, LIGHT, I, false>(f, out, elem0, nslots, tid, stride, racc, unused);
+}
+
+__device__ __forceinline__ float sink_identity(int sink) {
+    return sink == NP_SUM ? 0.0f : sink == NP_PROD ? 1.0f : sink == NP_MIN ? INFINITY : -INFINITY;
+}
+__device__ __forceinline__ float sink_combine(int sink, float a, float b) {   // np::dev::r_combine with a run-time op
+    if (sink == NP_SUM) return a + b;
+    if (sink == NP_PROD) return a * b;
+    if (sink == NP_MIN) return (b < a) ? b : a;
+    return (b > a) ? b : a;
+}
+
+// Chain ending in a reduction over the LAST axis: out[r] = reduce_c chain(r, c).  One wave per row
+// (BLOCK = false; rows of up to a few thousand elements, no barrier anywhere) or one workgroup per
+// row (BLOCK = true).  scale = 1 / cols for a mean (applied as a division, like NDArray::mean).
+template <int G, bool LIGHT, bool BLOCK, typename I>
+__global__ __launch_bounds__(256) void fused_chain_rows_kernel(FusedArgs by_value, float *__restrict__ out, I rows, I cols,
+                                                               unsigned L, float mean_div) {
+    (void)by_value;
+    FusedArgsK f = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    const int sink = f->sink;
+    // wave mode: groups of L lanes (a power of two <= 64) own a row each, so short rows still fill the wave
+    const I lane = BLOCK ? threadIdx.x : (threadIdx.x & (L - 1));
+    const I width = BLOCK ? 256 : L;
+    const I groups = 64 / L;
+    const I first_row = BLOCK ? (I)blockIdx.x : ((I)blockIdx.x * 4 + (threadIdx.x >> 6)) * groups + (threadIdx.x & 63) / L;
+    const I row_stride = BLOCK ? (I)gridDim.x : (I)gridDim.x * 4 * groups;
+    __shared__ float lds4[4];
+    for (I r = first_row; r < rows; r += row_stride) {
+        float racc = sink_identity(sink);
+        fused_span<2, G, LIGHT, I>(f, out, r * cols, cols / G, lane, width, racc);
+        if constexpr (BLOCK) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) racc = sink_combine(sink, racc, __shfl_down(racc, off, 64));
+        } else {
+            for (unsigned off = L >> 1; off > 0; off >>= 1) racc = sink_combine(sink, racc, __shfl_xor(racc, (int)off, 64));
+        }
+        if constexpr (BLOCK) {
+            if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = racc;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float v = lds4[0];
+                for (int w = 1; w < 4; ++w) v = sink_combine(sink, v, lds4[w]);
+                out[r] = mean_div != 0.0f ? v / mean_div : v;
+            }
+            __syncthreads();
+        } else if (lane == 0) {
+            out[r] = mean_div != 0.0f ? racc / mean_div : racc;
+        }
+    }
+}
+
+// Chain ending in a reduction over the FIRST axis of a rows x cols result: out[c] = reduce_r chain(r, c).
+// A workgroup owns 64 slots of G columns; its four waves take every fourth row of the block's row chunk
+// (blockIdx.y), each lane accumulating its own G columns (VACC), and are combined through LDS.  With
+// more than one row chunk the partials [chunk][cols] are folded by np_reduce_axis.
+template <int G, bool LIGHT, typename I>
+__global__ __launch_bounds__(256) void fused_chain_cols_kernel(FusedArgs by_value, float *__restrict__ out, I rows, I cols,
+                                                               I rows_per_chunk, float mean_div) {
+    (void)by_value;
+    FusedArgsK f = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    const int sink = f->sink;
+    const I lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const I slots_per_row = cols / G;             // cols % G == 0
+    const I slot = (I)blockIdx.x * 64 + lane;
+    const I r0 = (I)blockIdx.y * rows_per_chunk;
+    const I r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+    float rv[2 * G], racc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 2 * G; ++e) rv[e] = sink_identity(sink);
+    // slot index v of the span <-> (row r0 + v / slots_per_row, slot v % slots_per_row): this thread's
+    // slots are v = (wave + 4 i) * slots_per_row + slot
+    if (slot < slots_per_row)
+        fused_span_impl<2, G, LIGHT, I, true>(f, out, r0 * cols, (r1 - r0) * slots_per_row, wave * slots_per_row + slot,
+                                              4 * slots_per_row, racc, rv);
+    __shared__ float part[4][64][G];
+#pragma unroll
+    for (int e = 0; e < G; ++e) part[wave][lane][e] = sink_combine(sink, rv[e], rv[G + e]);
+    __syncthreads();
+    if (wave == 0 && slot < slots_per_row) {
+#pragma unroll
+        for (int e = 0; e < G; ++e) {
+            float v = part[0][lane][e];
+            for (int w = 1; w < 4; ++w) v = sink_combine(sink, v, part[w][lane][e]);
+            out[(size_t)blockIdx.y * cols + (size_t)slot * G + e] = mean_div != 0.0f ? v / mean_div : v;
         }
     }
 }
@@ -1014,9 +1128,19 @@ extern "C" {
 
 }  // extern "C"
 
-// sink < 0: out receives rows*cols values; else out is a device float receiving the reduction
+// whether the axis-sink kernels take this shape (otherwise: materialise the chain, then np_reduce_axis)
+static bool fused_axis_shape_ok(size_t rows, size_t cols, int axis) {
+    if (rows * cols >= (size_t(1) << 32)) return false;
+    if (axis == 1) return cols >= 16 && rows >= 128;          // a lane group / wave / workgroup per row
+    return cols / (cols % 4 == 0 ? 4 : 1) >= 32;              // first axis: a lane per column slot
+}
+
+// sink < 0: out receives rows*cols values; else out is a device float receiving the reduction — or,
+// with axis_mode 1 / 0, rows / cols floats: the reduction over the last / first axis (mean_div != 0:
+// divide the result by it)
 static int fused_chain_impl(const float *const *inputs, const int *input_kinds, int n_inputs,
-                            const np_fused_op *ops, int n_ops, float *out, size_t rows, size_t cols, int sink) {
+                            const np_fused_op *ops, int n_ops, float *out, size_t rows, size_t cols, int sink,
+                            int axis_mode = -1, float mean_div = 0.0f) {
     const size_t n = rows * cols;
     if (n_inputs < 1 || n_inputs > FUSED_MAX_IN)
         return np::fail(NP_ERR_INVALID, "np_fused_chain: 1..%d inputs supported", FUSED_MAX_IN);
@@ -1060,7 +1184,7 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     np::Scratch partials;
     float *result = out;
     unsigned reduce_blocks = 0;
-    if (sink >= 0) {
+    if (sink >= 0 && axis_mode < 0) {
         if (n >= (size_t(1) << 31)) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: array too large");
         // grid-stride loop over a capped grid: one workgroup-reduce + partial per block, so few,
         // long-lived blocks (NP_FUSED_RBPC blocks per CU for tools/fused_ab.py)
@@ -1120,6 +1244,56 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     static const int fu_env = getenv("NP_FUSED_U") ? atoi(getenv("NP_FUSED_U")) : 0;
     static const bool force_full = getenv("NP_FUSED_FULL") != nullptr;
     hipStream_t s = np::stream();
+    if (force_full) light = false;
+    if (axis_mode == 1) {
+        // last axis: a wave per row while rows are plentiful and short enough to leave a wave busy, else a workgroup
+        const bool block = cols >= 16384 || rows < (size_t)np::num_cus() * 16;
+        const size_t slots = cols / (cols % 4 == 0 ? 4 : 1);
+        unsigned L = 64;                                   // ~2 slots per lane per trip
+        while (L > 4 && (size_t)L >= slots) L >>= 1;
+        size_t grid = block ? rows : (rows + 4 * (64 / L) - 1) / (4 * (64 / L));
+        const size_t cap = (size_t)np::num_cus() * 16;
+        if (grid > cap) grid = cap;
+#define NP_FR(G_, LIGHT_, BLOCK_) fused_chain_rows_kernel<G_, LIGHT_, BLOCK_, uint32_t><<<(unsigned)grid, 256, 0, s>>>(f, out, (uint32_t)rows, (uint32_t)cols, L, mean_div)
+        if (cols % 4 == 0) {
+            if (light) { if (block) NP_FR(4, true, true); else NP_FR(4, true, false); }
+            else { if (block) NP_FR(4, false, true); else NP_FR(4, false, false); }
+        } else {
+            if (light) { if (block) NP_FR(1, true, true); else NP_FR(1, true, false); }
+            else { if (block) NP_FR(1, false, true); else NP_FR(1, false, false); }
+        }
+#undef NP_FR
+        NP_LAUNCH_CHECK("fused_chain_rows_kernel");
+        return NP_OK;
+    }
+    if (axis_mode == 0) {
+        const size_t g = cols % 4 == 0 ? 4 : 1;
+        const size_t col_blocks = (cols / g + 63) / 64;
+        size_t chunks = ((size_t)np::num_cus() * 8 + col_blocks - 1) / col_blocks;
+        const size_t max_chunks = rows / 32 ? rows / 32 : 1;
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks > 65535) chunks = 65535;
+        const size_t rows_per_chunk = (rows + chunks - 1) / chunks;
+        chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+        np::Scratch partial;
+        float *dst = out;
+        if (chunks > 1) {
+            if (int rc = partial.alloc(chunks * cols * sizeof(float))) return rc;
+            dst = (float *)partial.ptr;
+        }
+        const float div = chunks > 1 ? 0.0f : mean_div;
+        const dim3 grid((unsigned)col_blocks, (unsigned)chunks);
+#define NP_FCOL(G_, LIGHT_) fused_chain_cols_kernel<G_, LIGHT_, uint32_t><<<grid, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, (uint32_t)rows_per_chunk, div)
+        if (g == 4) { if (light) NP_FCOL(4, true); else NP_FCOL(4, false); }
+        else { if (light) NP_FCOL(1, true); else NP_FCOL(1, false); }
+#undef NP_FCOL
+        NP_LAUNCH_CHECK("fused_chain_cols_kernel");
+        if (chunks > 1) {
+            if (int rc = np_reduce_axis(sink, dst, 1, chunks, cols, out, 0)) return rc;
+            if (mean_div != 0.0f) return np_binary(NP_DIVIDE, out, NP_FULL, &mean_div, NP_HOST_SCALAR, out, 1, cols, 0, 0);
+        }
+        return NP_OK;
+    }
     const bool small = n < (size_t(1) << 31);
 #define NP_FC(VEC_, U_, LIGHT_)                                                                          \
     do {                                                                                                 \
@@ -1129,7 +1303,6 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         else                                                                                             \
             fused_chain_kernel<VEC_, U_, LIGHT_, uint64_t><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);    \
     } while (0)
-    if (force_full) light = false;
     const int fu = fu_env ? fu_env : (light ? 1 : 2);
     if (!vec) {
         if (light) NP_FC(false, 2, true); else NP_FC(false, 2, false);
@@ -1182,6 +1355,29 @@ int np_fused_chain_reduce(const float *const *inputs, const int *input_kinds, in
     if (int rc = np_memcpy_d2h(&v, dev.ptr, sizeof(float))) return rc;
     *host_out = reduce_op == NP_MEAN ? v / (float)(rows * cols) : v;
     return NP_OK;
+}
+
+int np_fused_chain_reduce_axis(const float *const *inputs, const int *input_kinds, int n_inputs,
+                               const np_fused_op *ops, int n_ops, int reduce_op, size_t rows, size_t cols, int axis,
+                               float *out) {
+    if (!out) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce_axis: null output");
+    if (axis != 0 && axis != 1) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce_axis: axis %d of a rows x cols chain", axis);
+    if (reduce_op != NP_SUM && reduce_op != NP_PROD && reduce_op != NP_MIN && reduce_op != NP_MAX &&
+        reduce_op != NP_MEAN)
+        return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce_axis: unknown reduction %d", reduce_op);
+    if (rows * cols == 0) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce_axis: empty input");
+    if (int rc = np::ensure_init()) return rc;
+    const int sink = reduce_op == NP_MEAN ? NP_SUM : reduce_op;
+    const float mean_div = reduce_op == NP_MEAN ? (float)(axis == 1 ? cols : rows) : 0.0f;
+    if (fused_axis_shape_ok(rows, cols, axis))
+        return fused_chain_impl(inputs, input_kinds, n_inputs, ops, n_ops, out, rows, cols, sink, axis, mean_div);
+    // shapes the sink kernels would run mostly idle on: one fused pass into a temporary, then the
+    // stand-alone axis reduction
+    np::Scratch tmp;
+    if (int rc = tmp.alloc(rows * cols * sizeof(float))) return rc;
+    if (int rc = fused_chain_impl(inputs, input_kinds, n_inputs, ops, n_ops, (float *)tmp.ptr, rows, cols, -1)) return rc;
+    return axis == 1 ? np_reduce_axis(reduce_op, (const float *)tmp.ptr, rows, cols, 1, out, 0)
+                     : np_reduce_axis(reduce_op, (const float *)tmp.ptr, 1, rows, cols, out, 0);
 }
 
 int np_elementwise_set_variant(int variant) {

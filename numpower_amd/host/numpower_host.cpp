@@ -1288,6 +1288,49 @@ float NDArray_FusedChainReduce(NDArray **inputs, int n_inputs, const np_fused_op
     return v;
 }
 
+NDArray *NDArray_FusedChainReduceAxis(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops, int reduce_op,
+                                      int axis) {
+    ChainCall c;
+    if (!prepare_chain(inputs, n_inputs, ops, n_ops, c)) return nullptr;
+    NDArray *first = inputs[0];
+    const int nd = NDArray_NDIM(first);
+    if (axis >= nd || axis < 0) {   // ndarray.c:534-538
+        throw_error("axis %d is out of bounds for array of dimension %d", axis, nd);
+        return nullptr;
+    }
+    const size_t n = (size_t)NDArray_NUMELEMENTS(first);
+    size_t rows = 0, cols = 0;
+    int ax = -1;
+    if (axis == nd - 1) {
+        cols = (size_t)first->dimensions[nd - 1];
+        rows = cols ? n / cols : 0;
+        ax = 1;
+    } else if (axis == 0 && nd == 2) {
+        rows = (size_t)first->dimensions[0];
+        cols = (size_t)first->dimensions[1];
+        ax = 0;
+    }
+    const bool flat_chain = c.rows == 1 && c.cols == n;             // no broadcast operand: any rows x cols view will do
+    if (ax < 0 || n == 0 || (!flat_chain && (c.rows != rows || c.cols != cols))) {
+        NDArray *value = NDArray_FusedChain(inputs, n_inputs, ops, n_ops);
+        if (!value) return nullptr;
+        NDArray *r = reduce_axis(value, axis, reduce_op, false);
+        NDArray_FREE(value);
+        return r;
+    }
+    int out_shape[128], j = 0;
+    for (int i = 0; i < nd; ++i)
+        if (i != axis) out_shape[j++] = first->dimensions[i];
+    NDArray *result = new_array(out_shape, nd - 1, NDARRAY_DEVICE_GPU, false);
+    if (!result) return nullptr;
+    if (!dev_ok(np_fused_chain_reduce_axis(c.ptrs, c.kinds, n_inputs, c.prog, n_ops, reduce_op, rows, cols, ax,
+                                           NDArray_FDATA(result)))) {
+        NDArray_FREE(result);
+        return nullptr;
+    }
+    return result;
+}
+
 /* ---- argmax / argmin (calculation.c:73-194) ---- */
 // axis == NDARRAY_MAX_DIMS (128) means "flattened" (numpower.c:2588-2590); the reference moves the
 // axis last with a Transpose copy and walks rows — here the (outer, axis, inner) view is reduced

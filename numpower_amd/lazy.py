@@ -98,10 +98,18 @@ class Lazy:
 
 
 def _reduce_method(name):
-    def method(self) -> float:
-        """Flush the chain INTO a full reduction: the expression's values are never stored."""
+    def method(self, axis=None):
+        """Flush the chain INTO a reduction — of everything (-> float) or over one axis (-> NDArray): the
+        expression's values are never stored."""
         from ._lib import REDUCE_OPS
         h = _load_host()
+        if axis is not None:
+            h.NDArray_FusedChainReduceAxis.restype = _P
+            h.NDArray_FusedChainReduceAxis.argtypes = [C.POINTER(_P), C.c_int, C.POINTER(FusedOp), C.c_int, C.c_int, C.c_int]
+            arr = (_P * len(self.inputs))(*[x._p for x in self.inputs])
+            ops = (FusedOp * max(len(self.ops), 1))(*self.ops)
+            return NDArray._wrap(h.NDArray_FusedChainReduceAxis(arr, len(self.inputs), ops, len(self.ops),
+                                                                REDUCE_OPS[name], int(axis)))
         h.NDArray_FusedChainReduce.restype = C.c_float
         h.NDArray_FusedChainReduce.argtypes = [C.POINTER(_P), C.c_int, C.POINTER(FusedOp), C.c_int, C.c_int]
         arr = (_P * len(self.inputs))(*[x._p for x in self.inputs])

@@ -161,3 +161,66 @@ def test_fused_broadcast_index_arithmetic(cols, hip):
     gx, gr, gc = NDArray.array(x).gpu(), NDArray.array(r).gpu(), NDArray.array(c).gpu()
     got = (gx.lazy() + gr - gc).eval().cpu().numpy()
     assert np.array_equal(got, (x + r[None, :]) - c)
+
+
+@pytest.mark.parametrize("shape", [(25000, 4000), (4096, 1000), (300, 70_000), (5000, 257), (1000, 66), (129, 64), (2000, 48), (50, 1000),
+                                   (100_000, 12), (7, 5), (3, 1_000_000), (64, 128, 96), (1000,)])
+def test_chain_ending_in_an_axis_reduction(shape, hip):
+    """sum / max / min / mean / prod over the last axis (any rank) and the first axis (2-d) as the chain's
+    last step (np_fused_chain_reduce_axis: row-sink and column-sink kernels, or the temporary + reduce
+    fallback for shapes they would idle on) against the op-by-op path: min / max bit-identical, sums within
+    1e-5 of fp64 of the same chain values."""
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    from numpower_amd.ndarray import NDArray
+    a = synth.uniform(shape, 301, -1.0, 1.0)
+    ga = NDArray.array(a).gpu()
+    nd = len(shape)
+    last = shape[-1]
+    row = NDArray.array(synth.uniform((last,), 302, 0.5, 1.5)).gpu()
+    col = NDArray.array(synth.uniform((shape[0], 1), 303, 0.5, 1.5)).gpu() if nd == 2 else None
+    axes = [nd - 1] + ([0] if nd == 2 else []) + ([1] if nd == 3 else [])
+
+    def chains():
+        yield "exp", lambda x: x.exp(), lambda x: NDArray.exp(x)
+        yield "x*row+0.5", lambda x: x * row + 0.5, lambda x: (x * row) + 0.5
+        if col is not None:
+            yield "(x-col)^2", lambda x: (x - col) * (x - col).eval() if False else ((x - col).abs() * 2.0), lambda x: NDArray.abs(x - col) * 2.0
+        yield "tanh(x)+x", lambda x: x.tanh() + ga, lambda x: NDArray.tanh(x) + ga      # full interpreter + input 0 reused
+
+    for label, build, eager in chains():
+        value = eager(ga).cpu().numpy()
+        v64 = value.astype(np.float64)
+        for axis in axes:
+            n_axis = shape[axis]
+            got = build(ga.lazy()).max(axis=axis)
+            got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
+            assert _same(got, value.max(axis=axis)), (label, shape, axis, "max")
+            got = build(ga.lazy()).min(axis=axis)
+            got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
+            assert _same(got, value.min(axis=axis)), (label, shape, axis, "min")
+            for op, ref, scale in (("sum", v64.sum(axis=axis), np.abs(v64).sum(axis=axis)),
+                                   ("mean", v64.sum(axis=axis) / n_axis, np.abs(v64).sum(axis=axis) / n_axis)):
+                got = getattr(build(ga.lazy()), op)(axis=axis)
+                got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
+                assert got.shape == np.asarray(ref).shape, (label, shape, axis, op)
+                assert (np.abs(got - ref) <= 1e-5 * np.maximum(scale, 1e-30)).all(), (label, shape, axis, op)
+    # prod: values near 1 so that long rows neither overflow nor vanish.  Factors this close to 1 are the
+    # worst case for any fp32 product TREE: a pairwise fp32 product of 10^6 of them is 9e-4 off fp64 on the
+    # CPU as well (the rounding of products straddling 1.0 does not average out), ~1e-9 per factor
+    p = (1.0 + synth.uniform(shape, 304, -1.0, 1.0) * np.float32(1e-3)).astype(np.float32)
+    gp = NDArray.array(p).gpu()
+    for axis in axes:
+        got = (gp.lazy() * 1.0).prod(axis=axis)
+        got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
+        ref = p.astype(np.float64).prod(axis=axis)
+        assert (np.abs(got - ref) <= (1e-5 + 2e-9 * shape[axis]) * np.abs(ref)).all(), (shape, axis, "prod")
+
+
+def test_chain_axis_reduction_errors(hip):
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    from numpower_amd.ndarray import Error, NDArray
+    g = NDArray.array(synth.uniform((10, 20), 305, 0.0, 1.0)).gpu()
+    with pytest.raises(Error, match="axis 2 is out of bounds for array of dimension 2"):
+        g.lazy().exp().sum(axis=2)
+    with pytest.raises(Error, match="axis -1 is out of bounds for array of dimension 2"):
+        g.lazy().exp().sum(axis=-1)
