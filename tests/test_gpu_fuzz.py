@@ -239,3 +239,36 @@ def test_fuzz_vectors_statistics_slices(hip, oracle):
         c0 = int(rng.integers(0, n)); c1 = int(rng.integers(c0, n)) + 1; cs = int(rng.integers(1, 4))
         got = ga.slice([r0, r1, rs], [c0, c1, cs]).cpu().numpy()
         assert (_bits(got) == _bits(a[r0:r1:rs, c0:c1:cs])).all(), ("slice", (m, n), (r0, r1, rs), (c0, c1, cs))
+
+
+def test_fuzz_chain_axis_ends(hip):
+    """Chains ending in an axis reduction at random 2-d / 3-d shapes (every row-length regime of the sink
+    kernels and the fallback) vs the materialised chain reduced by numpy."""
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    nd = _nd()
+    rng = np.random.default_rng(41)
+    for case in range(CASES):
+        ndim = int(rng.integers(1, 4))
+        shape = _shape(rng, ndim, 3_000_000)
+        a = synth.uniform(shape, 14000 + case, -1.0, 1.0)
+        ga = nd.array(a).gpu()
+        row = nd.array(synth.uniform((shape[-1],), 15000 + case, 0.5, 1.5)).gpu()
+        kind = case % 3
+        if kind == 0:
+            lz, value = ga.lazy().exp(), nd.exp(ga)
+        elif kind == 1:
+            lz, value = (ga.lazy() * row).abs(), nd.abs(ga * row)
+        else:
+            lz, value = ga.lazy().sin() * ga, nd.sin(ga) * ga
+        v = value.cpu().numpy()
+        axis = int(rng.integers(0, ndim))
+        op = ("sum", "max", "min", "mean")[int(rng.integers(0, 4))]
+        got = getattr(lz, op)(axis=axis)
+        got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
+        if op in ("max", "min"):
+            assert (_bits(got) == _bits(getattr(v, op)(axis=axis))).all(), (shape, axis, op, kind)
+        else:
+            div = shape[axis] if op == "mean" else 1
+            ref = v.astype(np.float64).sum(axis=axis) / div
+            scale = np.abs(v).astype(np.float64).sum(axis=axis) / div
+            assert got.shape == ref.shape and (np.abs(got - ref) <= 1e-5 * np.maximum(scale, 1e-30)).all(), (shape, axis, op, kind)
