@@ -8,7 +8,9 @@ flushed as ONE kernel (NDArray_FusedChain -> np_fused_chain) when a value is nee
     y = (a.lazy().exp() * b + 2.0).eval()        # one pass over HBM, bit-identical to
     y = (NDArray.exp(a) * b) + 2.0               # three passes and two temporaries
 
-Chains are linear: acc = f_k(... f_1(a)); binary steps take another GPU array of the same size, a
+Chains are linear: acc = f_k(... f_1(a)) and keep the shape of `a` throughout (eagerly, `$vector + $a` with
+a 1 x C `$a` is a flat op whose result takes the vector's shape, arithmetics.c:194-197; inside a chain it stays
+1 x C); binary steps take another GPU array of the same size, a
 smaller GPU array that broadcasts onto the chain's shape (row vector, column, 0-d) or a Python
 number.  Anything else (reductions, matmul) is evaluated eagerly by NDArray as before.
 """
