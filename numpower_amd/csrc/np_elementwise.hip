@@ -1124,10 +1124,6 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, fl
 
 }  // namespace
 
-extern "C" {
-
-}  // extern "C"
-
 // whether the axis-sink kernels take this shape (otherwise: materialise the chain, then np_reduce_axis)
 static bool fused_axis_shape_ok(size_t rows, size_t cols, int axis) {
     if (rows * cols >= (size_t(1) << 32)) return false;

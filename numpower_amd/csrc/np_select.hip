@@ -31,7 +31,6 @@ struct SelectState {
     unsigned succ_min;           // running minimum key of that group (atomicMin)
     unsigned succ_key;           // mode 2: the successor's key
     int mode;                    // 0: successor still in the same bin; 1: group known; 2: key known; 3: none
-    unsigned result_key;         // the k-th smallest key (after the last pass)
 };
 
 __device__ __forceinline__ unsigned to_key(float x) {
@@ -177,7 +176,6 @@ __global__ void select_init_kernel(SelectState *st, unsigned long long *hist, un
         st->succ_min = 0xffffffffu;
         st->succ_key = 0;
         st->mode = 0;
-        st->result_key = 0;
     }
 }
 
