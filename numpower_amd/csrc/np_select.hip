@@ -63,10 +63,32 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float *__restric
     const unsigned succ_prefix = st->succ_prefix;
     unsigned *mine = h[threadIdx.x & (COPIES - 1)];
     unsigned local_min = 0xffffffffu;
-    auto take = [&](float x) {
+    const unsigned lane = threadIdx.x & 63;
+    // Duplicate-heavy data (half of a ReLU output is one value; a constant array is the extreme) sends most
+    // of a wave to ONE LDS address, which the LDS serialises (constant 10^8: 0.55 ms).  Voting — the first
+    // hitting lane's bin is counted once for all lanes that share it — fixes that (0.30 ms) but costs random
+    // data 10 %, so every trip votes on its first element only and lets the result (>= 24 lanes agreed)
+    // decide how the trip's other elements are counted.
+    bool vote = false;   // wave-uniform
+    auto take = [&](float x, bool probe) {
         const unsigned key = to_key(x);
-        if (PASS == 0 || (key & Digit<PASS>::above) == prefix)
-            atomicAdd(&mine[(key >> Digit<PASS>::shift) & (Digit<PASS>::bins - 1)], 1u);
+        const bool hit = PASS == 0 || (key & Digit<PASS>::above) == prefix;
+        const unsigned bin = (key >> Digit<PASS>::shift) & (Digit<PASS>::bins - 1);
+        if (probe || vote) {
+            const unsigned long long hits = __ballot(hit);
+            if (hits) {
+                const int leader = __ffsll((long long)hits) - 1;
+                const unsigned hot = (unsigned)__shfl((int)bin, leader, 64);
+                const unsigned long long same = __ballot(hit && bin == hot);
+                if ((int)lane == leader) atomicAdd(&mine[hot], (unsigned)__popcll(same));
+                else if (hit && bin != hot) atomicAdd(&mine[bin], 1u);
+                if (probe) vote = __popcll(same) >= 24;
+            } else if (probe) {
+                vote = false;
+            }
+        } else if (hit) {
+            atomicAdd(&mine[bin], 1u);
+        }
         if (PASS > 0 && want_succ && (key & Digit<PASS>::above) == succ_prefix) local_min = min(local_min, key);
     };
     const I nvec = n / 4;
@@ -77,13 +99,13 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float *__restric
 #pragma unroll
         for (int u = 0; u < 4; ++u) x[u] = __builtin_nontemporal_load((const v4f_u *)(in + (size_t)(v + u * stride) * 4));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { take(x[u][0]); take(x[u][1]); take(x[u][2]); take(x[u][3]); }
+        for (int u = 0; u < 4; ++u) { take(x[u][0], u == 0); take(x[u][1], false); take(x[u][2], false); take(x[u][3], false); }
     }
     for (; v < nvec; v += stride) {
         const v4f x = __builtin_nontemporal_load((const v4f_u *)(in + (size_t)v * 4));
-        take(x[0]); take(x[1]); take(x[2]); take(x[3]);
+        take(x[0], true); take(x[1], false); take(x[2], false); take(x[3], false);
     }
-    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - nvec * 4)) take(in[(size_t)nvec * 4 + threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - nvec * 4)) take(in[(size_t)nvec * 4 + threadIdx.x], true);
     __syncthreads();
     for (unsigned b = threadIdx.x; b < Digit<PASS>::bins; b += 256) {
         const unsigned c = h[0][b] + h[1][b] + h[2][b] + h[3][b];

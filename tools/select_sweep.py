@@ -13,9 +13,10 @@ out = (C.c_float * 2)()
 for label, host in (("U[0,1)", lambda: synth.uniform((N,), 5, 0.0, 1.0)),
                     ("U[-3,5)", lambda: synth.uniform((N,), 6, -3.0, 5.0)),
                     ("10 distinct values", lambda: np.rint(synth.uniform((N,), 7, 0.0, 9.0)).astype(np.float32)),
+                    ("relu(U[-1,1))", lambda: np.maximum(synth.uniform((N,), 8, -1.0, 1.0), np.float32(0.0))),
                     ("constant", lambda: np.full((N,), 2.5, np.float32))):
     x = D.DeviceArray.from_host(host())
-    for k in (N // 2, N - 1):
+    for k in (N // 2, (3 * N) // 4, N - 1):
         for _ in range(2): _lib.check(lib.np_order_stat(x.ptr, N, k, out))
         D.sync(); t.start()
         for _ in range(5): _lib.check(lib.np_order_stat(x.ptr, N, k, out))
