@@ -144,3 +144,44 @@ def test_views_and_initializers_on_cpu_arrays():
                lambda: NDArray.outer(NDArray.array(x[0]), NDArray.array(x[1])), lambda: a.contiguous()):
         with pytest.raises(Error, match="only computes on the GPU"):
             fn()
+
+
+def test_manipulation_and_order_stat_argument_checks_on_cpu_arrays():
+    """The manipulation wrappers that are pure views work on CPU arrays; the ones that move data, and
+    median / quantile, check their arguments first (the reference's messages) and then refuse CPU data
+    loudly instead of computing on the host."""
+    from numpower_amd.ndarray import Error, NDArray
+    x = np.arange(12, dtype=np.float32).reshape(1, 3, 1, 4)
+    a = NDArray.array(x)
+    assert NDArray.squeeze(a).shape() == [3, 4] and NDArray.squeeze(a, 0).shape() == [3, 1, 4]
+    assert NDArray.squeeze(a, [0, 2]).toArray() == x.reshape(3, 4).tolist()
+    assert NDArray.atleast_1d(NDArray.array(np.float32(2.0))).shape() == [1]
+    assert NDArray.atleast_2d(NDArray.array(np.float32([1, 2, 3]))).shape() == [1, 3]
+    assert NDArray.atleast_3d(NDArray.array(np.float32([1, 2, 3]))).shape() == [1, 3, 1]
+    assert NDArray.atleast_3d(NDArray.array(np.zeros((2, 5), np.float32))).shape() == [2, 5, 1]
+    with pytest.raises(Error, match="cannot select an axis to squeeze out which has size not equal to one"):
+        NDArray.squeeze(a, 1)
+    with pytest.raises(Error, match="duplicate value in 'axis'"):
+        NDArray.squeeze(a, [0, 0])
+    m = NDArray.array(np.zeros((2, 3), np.float32))
+    v = NDArray.array(np.zeros((3,), np.float32))
+    with pytest.raises(Error, match="same number of dimensions"):
+        NDArray.concatenate([m, v], 0)
+    with pytest.raises(Error, match="along dimension 1, the array at index 0 has size 3 and the array at index 1 has size 2"):
+        NDArray.concatenate([m, NDArray.array(np.zeros((2, 2), np.float32))], 0)
+    with pytest.raises(Error, match="zero-dimensional arrays cannot be concatenated"):
+        NDArray.concatenate([NDArray.array(np.float32(1.0))], 0)
+    with pytest.raises(Error, match="Axis is out of bounds for array dimension"):
+        NDArray.swapaxes(m, 0, 2)
+    with pytest.raises(Error, match="must have the same number of elements"):
+        NDArray.moveaxis(m, [0, 1], [0])
+    with pytest.raises(Error, match="Input array must be a vector or 2-dimensional"):
+        NDArray.diag(a)
+    with pytest.raises(Error, match="Q must be between 0 and 1"):
+        NDArray.quantile(v, 2.0)
+    with pytest.raises(Error, match="Q must be a scalar"):
+        NDArray.quantile(v, [0.1, 0.2])
+    for fn in (lambda: NDArray.concatenate([m, m], 0), lambda: NDArray.vstack([v, v]), lambda: NDArray.swapaxes(m, 0, 1),
+               lambda: NDArray.diag(v), lambda: NDArray.median(v), lambda: NDArray.quantile(v, 0.5)):
+        with pytest.raises(Error, match="only computes on the GPU"):
+            fn()
