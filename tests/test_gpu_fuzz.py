@@ -281,3 +281,40 @@ def test_fuzz_chain_axis_ends(hip):
             ref = v.astype(np.float64).sum(axis=axis) / div
             scale = np.abs(v).astype(np.float64).sum(axis=axis) / div
             assert got.shape == ref.shape and (np.abs(got - ref) <= 1e-5 * np.maximum(scale, 1e-30)).all(), (shape, axis, op, kind)
+
+
+def test_fuzz_views_at_odd_offsets(hip, oracle):
+    """Row views of matrices with odd row lengths start at any 4-byte offset: every elementwise / reduction
+    kernel behind them must take dword-aligned pointers and ragged lengths (float4 bodies, scalar tails)."""
+    nd = _nd()
+    rng = np.random.default_rng(51 + SEED)
+    exact = ["abs", "sqrt", "floor", "ceil", "rint", "negate", "sign", "reciprocal", "trunc"]
+    loose = ["exp", "log", "sin", "tanh", "log1p", "arctan", "sinh"]
+    for case in range(CASES):
+        cols = int(rng.choice([1, 3, 5, 7, 9, 13, 17, 31, 33, 63, 65, 127, 129, 255, 257, 1001, 4099, 65_537, 1_000_003]))
+        rows = int(rng.integers(2, 6))
+        m = synth.uniform((rows, cols), 16000 + case + 100_000 * SEED, 0.25, 3.0)
+        w = synth.uniform((rows, cols), 17000 + case + 100_000 * SEED, 0.5, 2.0)
+        gm, gw = nd.array(m).gpu(), nd.array(w).gpu()
+        i, j = int(rng.integers(0, rows)), int(rng.integers(0, rows))
+        va, vb = gm.slice([i]), gw.slice([j])            # contiguous views at offsets i*cols, j*cols floats
+        ha, hb = m[i], w[j]
+        op = str(rng.choice(exact))
+        assert (_bits(nd._unary(op, va).cpu().numpy()) == _bits(oracle.unary(op, ha))).all(), (op, cols, i)
+        op = str(rng.choice(loose))
+        got, want = nd._unary(op, va).cpu().numpy().astype(np.float64), oracle.unary(op, ha).astype(np.float64)
+        assert (np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-11).all(), (op, cols, i)
+        for bop in ("add", "multiply", "divide", "greater", "maximum"):
+            got = nd._binary(bop, va, vb).cpu().numpy()
+            assert (_bits(got) == _bits(oracle.binary(bop, ha, hb))).all(), (bop, cols, i, j)
+        assert (_bits(nd._binary("subtract", va, 1.5).cpu().numpy()) == _bits(oracle.binary("subtract", ha, np.float32(1.5)))).all()
+        s = float(nd.sum(va)); ref = float(ha.astype(np.float64).sum())
+        assert abs(s - ref) <= 1e-5 * ref, ("sum", cols, i)
+        assert np.float32(nd.max(va)) == ha.max() and np.float32(nd.min(vb)) == hb.min(), ("minmax", cols, i, j)
+        assert np.float32(nd.median(va)).view(np.uint32) == oracle.median(ha).view(np.uint32), ("median", cols, i)
+        d = float(np.float32(nd.dot(va, vb))); ref = float(ha.astype(np.float64) @ hb.astype(np.float64))
+        assert abs(d - ref) <= 2e-6 * float(np.abs(ha).astype(np.float64) @ np.abs(hb).astype(np.float64)), ("dot", cols)
+        if cols <= 4099:
+            got = nd.matmul(gm, nd.transpose(gw)).cpu().numpy()           # (rows x cols) . (cols x rows)
+            ref = m.astype(np.float64) @ w.astype(np.float64).T
+            assert (np.abs(got - ref) <= 2e-6 * (np.abs(m).astype(np.float64) @ np.abs(w).astype(np.float64).T)).all(), ("matmul", cols)
