@@ -219,8 +219,9 @@ int np_fused_chain_reduce(const float *const *inputs, const int *input_kinds, in
  * mean((X - mu) * (X - mu), 0) in one pass over X: 4 B/elem instead of 12.  Last axis: a wave (or, for
  * long or few rows, a workgroup) per row; first axis: a lane per 4-column slot, the workgroup's waves
  * interleaved over a chunk of rows, chunk partials folded by np_reduce_axis.  Shapes those kernels would
- * run mostly idle on (rows shorter than 64, fewer than 128 rows, fewer than 32 column slots) take one
- * fused pass into a temporary + np_reduce_axis instead.  Same combine rules as np_reduce_axis. */
+ * run mostly idle on (last axis: rows shorter than 16 floats, or fewer than 128 rows of a small array — a
+ * handful of very long rows is cut into several workgroups per row; first axis: fewer than 32 rows or 32
+ * column slots) take one fused pass into a temporary + np_reduce_axis instead.  Same combine rules as np_reduce_axis. */
 int np_fused_chain_reduce_axis(const float *const *inputs, const int *input_kinds, int n_inputs,
                                const np_fused_op *ops, int n_ops, int reduce_op, size_t rows, size_t cols, int axis,
                                float *out);

@@ -1024,7 +1024,7 @@ __device__ __forceinline__ float sink_combine(int sink, float a, float b) {   //
 // row (BLOCK = true).  scale = 1 / cols for a mean (applied as a division, like NDArray::mean).
 template <int G, bool LIGHT, bool BLOCK, typename I>
 __global__ __launch_bounds__(256) void fused_chain_rows_kernel(FusedArgs by_value, float *__restrict__ out, I rows, I cols,
-                                                               unsigned L, float mean_div) {
+                                                               unsigned L, I chunk_slots, float mean_div) {
     (void)by_value;
     FusedArgsK f = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
     const int sink = f->sink;
@@ -1035,9 +1035,14 @@ __global__ __launch_bounds__(256) void fused_chain_rows_kernel(FusedArgs by_valu
     const I first_row = BLOCK ? (I)blockIdx.x : ((I)blockIdx.x * 4 + (threadIdx.x >> 6)) * groups + (threadIdx.x & 63) / L;
     const I row_stride = BLOCK ? (I)gridDim.x : (I)gridDim.x * 4 * groups;
     __shared__ float lds4[4];
+    // workgroup mode may cut a row into gridDim.y chunks of chunk_slots slots (a handful of very long rows):
+    // out then holds [row][chunk] partials for np_reduce_axis to fold
+    const I slot0 = BLOCK ? (I)blockIdx.y * chunk_slots : 0;
+    const I nslots = BLOCK ? (slot0 + chunk_slots < cols / G ? chunk_slots : cols / G - slot0) : cols / G;
+    const I out_stride = BLOCK ? (I)gridDim.y : 1, out_off = BLOCK ? (I)blockIdx.y : 0;
     for (I r = first_row; r < rows; r += row_stride) {
         float racc = sink_identity(sink);
-        fused_span<2, G, LIGHT, I>(f, out, r * cols, cols / G, lane, width, racc);
+        fused_span<2, G, LIGHT, I>(f, out, r * cols + slot0 * G, nslots, lane, width, racc);
         if constexpr (BLOCK) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) racc = sink_combine(sink, racc, __shfl_down(racc, off, 64));
@@ -1050,7 +1055,7 @@ __global__ __launch_bounds__(256) void fused_chain_rows_kernel(FusedArgs by_valu
             if (threadIdx.x == 0) {
                 float v = lds4[0];
                 for (int w = 1; w < 4; ++w) v = sink_combine(sink, v, lds4[w]);
-                out[r] = mean_div != 0.0f ? v / mean_div : v;
+                out[(size_t)r * out_stride + out_off] = mean_div != 0.0f ? v / mean_div : v;
             }
             __syncthreads();
         } else if (lane == 0) {
@@ -1127,8 +1132,8 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, fl
 // whether the axis-sink kernels take this shape (otherwise: materialise the chain, then np_reduce_axis)
 static bool fused_axis_shape_ok(size_t rows, size_t cols, int axis) {
     if (rows * cols >= (size_t(1) << 32)) return false;
-    if (axis == 1) return cols >= 16 && rows >= 128;          // a lane group / wave / workgroup per row
-    return cols / (cols % 4 == 0 ? 4 : 1) >= 32;              // first axis: a lane per column slot
+    if (axis == 1) return cols >= 16 && (rows >= 128 || rows * cols >= (size_t(1) << 20));   // a lane group / wave / workgroup (or several) per row
+    return rows >= 32 && cols / (cols % 4 == 0 ? 4 : 1) >= 32;   // first axis: a lane per column slot, waves interleaved over rows
 }
 
 // sink < 0: out receives rows*cols values; else out is a device float receiving the reduction — or,
@@ -1250,7 +1255,25 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         size_t grid = block ? rows : (rows + 4 * (64 / L) - 1) / (4 * (64 / L));
         const size_t cap = (size_t)np::num_cus() * 16;
         if (grid > cap) grid = cap;
-#define NP_FR(G_, LIGHT_, BLOCK_) fused_chain_rows_kernel<G_, LIGHT_, BLOCK_, uint32_t><<<(unsigned)grid, 256, 0, s>>>(f, out, (uint32_t)rows, (uint32_t)cols, L, mean_div)
+        // a handful of very long rows: several workgroups per row (>= 1024 slots each), partials folded afterwards
+        size_t chunks = 1;
+        if (block && rows < (size_t)np::num_cus() * 4) {
+            chunks = ((size_t)np::num_cus() * 8 + rows - 1) / rows;
+            const size_t max_chunks = slots / 1024 ? slots / 1024 : 1;
+            if (chunks > max_chunks) chunks = max_chunks;
+            if (chunks > 65535) chunks = 65535;
+        }
+        const size_t chunk_slots = (slots + chunks - 1) / chunks;
+        chunks = (slots + chunk_slots - 1) / chunk_slots;
+        np::Scratch partial;
+        float *dst = out;
+        if (chunks > 1) {
+            if (int rc = partial.alloc(rows * chunks * sizeof(float))) return rc;
+            dst = (float *)partial.ptr;
+        }
+        const float div = chunks > 1 ? 0.0f : mean_div;
+        const dim3 grid2((unsigned)grid, (unsigned)chunks);
+#define NP_FR(G_, LIGHT_, BLOCK_) fused_chain_rows_kernel<G_, LIGHT_, BLOCK_, uint32_t><<<grid2, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, L, (uint32_t)chunk_slots, div)
         if (cols % 4 == 0) {
             if (light) { if (block) NP_FR(4, true, true); else NP_FR(4, true, false); }
             else { if (block) NP_FR(4, false, true); else NP_FR(4, false, false); }
@@ -1260,6 +1283,10 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         }
 #undef NP_FR
         NP_LAUNCH_CHECK("fused_chain_rows_kernel");
+        if (chunks > 1) {
+            if (int rc = np_reduce_axis(sink, dst, rows, chunks, 1, out, 0)) return rc;
+            if (mean_div != 0.0f) return np_binary(NP_DIVIDE, out, NP_FULL, &mean_div, NP_HOST_SCALAR, out, 1, rows, 0, 0);
+        }
         return NP_OK;
     }
     if (axis_mode == 0) {

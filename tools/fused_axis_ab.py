@@ -8,7 +8,7 @@ from numpower_amd import device as D, _lib
 from numpower_amd._lib import UNARY_OPS, FusedOp, Timer, check
 D.init(0); lib = _lib.load(); t = Timer()
 prog = (FusedOp * 1)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0))
-for rows, cols in ((25000, 4000), (65536, 4096), (1_000_000, 100), (4_000_000, 24), (200_000, 512), (4096, 25000), (400, 250_000), (100_000, 1000)):
+for rows, cols in ((25000, 4000), (65536, 4096), (1_000_000, 100), (4_000_000, 24), (200_000, 512), (4096, 25000), (400, 250_000), (3, 30_000_000), (100_000, 1000)):
     n = rows * cols
     x = D.DeviceArray((rows, cols)); D.fill(x, 0.5); tmp = D.DeviceArray((rows, cols))
     ptrs = (C.c_void_p * 1)(x.ptr); kinds = (C.c_int * 1)(0)
