@@ -375,6 +375,30 @@ def bench_extras(dist: Dist, steps, warmup):
         r["speedup_vs_unfused"] = (ev_ms / steps) / r["ms_per_launch"]
         r["parity_ok"] = bool((fused_out.view(np.uint32) == do.to_host().reshape(-1).view(np.uint32)).all())
         ex["exp_plus_%s_fused" % label] = r
+    # ... and with a reduction over an axis as the chain's last step: sum(exp(X), axis) reads X once (4 B/elem)
+    prog1 = (FusedOp * 1)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0))
+    ptrs1 = (C.c_void_p * 1)(da.ptr)
+    kinds1 = (C.c_int * 1)(0)
+    e64 = np.exp(a.reshape(R, Cc).astype(np.float64))
+    for axis, nout in ((1, R), (0, Cc)):
+        dred = D.DeviceArray((nout,))
+        r = hbm_case("sum(exp(X), axis %d) fused, 25000x4000" % axis, 4.0 * N + 4.0 * nout,
+                     lambda: check(lib.np_fused_chain_reduce_axis(ptrs1, kinds1, 1, prog1, 1, 0, R, Cc, axis, dred.ptr)),
+                     steps, warmup, dist)
+        ref = e64.sum(axis=axis)
+        r["parity_max_rel_err_vs_fp64"] = float((np.abs(dred.to_host().astype(np.float64) - ref) / ref).max())
+        r["parity_ok"] = bool(r["parity_max_rel_err_vs_fp64"] <= 1e-5)
+
+        def exp_then_reduce():
+            D.unary("exp", da, out=tmp)
+            check(lib.np_reduce_axis(0, tmp.ptr, R if axis == 1 else 1, Cc if axis == 1 else R, 1 if axis == 1 else Cc, dred.ptr, 0))
+
+        _, ev_ms = timed(dist, exp_then_reduce, steps, warmup)
+        r["unfused_ms_per_chain"] = ev_ms / steps
+        r["speedup_vs_unfused"] = (ev_ms / steps) / r["ms_per_launch"]
+        ex["sum_exp_axis%d_fused" % axis] = r
+        dred.free()
+    del e64
     tmp.free()
     for d in (da, db, do, drow, dcol):
         d.free()
