@@ -751,9 +751,19 @@ __device__ __forceinline__ void unary_all(float (&acc)[N], float p0, float p1) {
     for (int e = 0; e < N; ++e) acc[e] = unary_apply<OP>(acc[e], p0, p1);
 }
 
+// pow inside the chain interpreter goes through ONE out-of-line copy: inlined, its fp64 temporaries for 8
+// elements took the full interpreter from 124 to 139 VGPRs (4 -> 3 waves per SIMD) for every chain
+// that merely might contain a pow.
+__device__ __attribute__((noinline)) float pow_outlined(float x, float y) { return fast_pow(x, y); }
+
 template <int OP, int N>
 __device__ __forceinline__ void binary_all(float (&acc)[N], const float (&oth)[N], bool swap, bool quirk,
                                            const bool (&body)[N]) {
+    if constexpr (OP == NP_POW) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] = swap ? pow_outlined(oth[e], acc[e]) : pow_outlined(acc[e], oth[e]);
+        return;
+    }
     // `swap` and `quirk` are uniform: one branch each per step, not a select per element
     if (binary_has_quirk(OP) && quirk) {
         if (swap) {
