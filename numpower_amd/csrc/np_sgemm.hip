@@ -833,9 +833,17 @@ __global__ __launch_bounds__(256) void sgemm_thin_kernel(const float *__restrict
 // buffered so one barrier per chunk is enough (every wave reading B out of the caches itself moved
 // as many bytes of B as of A).
 template <int ROWS>
-__global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__restrict__ A, const float *__restrict__ B,
-                                                              float *__restrict__ C, size_t M, unsigned N, unsigned K) {
+__global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__restrict__ A0, const float *__restrict__ B0,
+                                                              float *__restrict__ C0, size_t M, unsigned N, unsigned Ktotal,
+                                                              unsigned kc) {
     typedef v4f v4f_u __attribute__((aligned(4)));
+    // split-K (gridDim.y > 1; a few hundred rows against a very long K — X^T . G of a dense layer's backward
+    // pass): chunk blockIdx.y covers k in [k_begin, k_begin + K) and writes its own M x N partial
+    const unsigned k_begin = blockIdx.y * kc;
+    const unsigned K = Ktotal - k_begin < kc ? Ktotal - k_begin : kc;
+    const float *A = A0 + k_begin;
+    const float *B = B0 + (size_t)k_begin * N;
+    float *C = C0 + (size_t)blockIdx.y * M * N;
     constexpr int KK = 64 / ROWS;          // k-slices the MFMA sums over (2 or 4)
     constexpr int W = 32 / KK;             // k values per lane per step (16 or 8)
     constexpr int NACC = ROWS * ROWS / 64; // 16 or 4
@@ -849,7 +857,7 @@ __global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__res
     const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * ROWS;
     const size_t row = r0 + i;
     const bool row_ok = row < M;
-    const float *a = A + (row_ok ? row : 0) * (size_t)K + W * q;
+    const float *a = A + (row_ok ? row : 0) * (size_t)Ktotal + W * q;
     acc_t acc;
 #pragma unroll
     for (int r = 0; r < NACC; ++r) acc[r] = 0.0f;
@@ -1306,10 +1314,32 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
         const size_t rows_per_block = N <= 16 ? 64 : 128;
         const size_t blocks = (M + rows_per_block - 1) / rows_per_block;
         if (blocks > 0x7fffffffu) return 1;
-        if (N <= 16) sgemm_thin_mfma_kernel<16><<<(unsigned)blocks, 256, 0, s>>>(A, B, C, M, (unsigned)N, (unsigned)K);
-        else sgemm_thin_mfma_kernel<32><<<(unsigned)blocks, 256, 0, s>>>(A, B, C, M, (unsigned)N, (unsigned)K);
+        if (N <= 16) sgemm_thin_mfma_kernel<16><<<(unsigned)blocks, 256, 0, s>>>(A, B, C, M, (unsigned)N, (unsigned)K, (unsigned)K);
+        else sgemm_thin_mfma_kernel<32><<<(unsigned)blocks, 256, 0, s>>>(A, B, C, M, (unsigned)N, (unsigned)K, (unsigned)K);
         NP_LAUNCH_CHECK("sgemm_thin_mfma_kernel");
         return NP_OK;
+    }
+    if (M > 16 && M < 2048 && K >= 16384) {
+        // a few hundred rows, a very long K: the same kernel over K-chunks (the tiled split-K plan reads A at
+        // 2.2 TB/s on 64-wide tiles that are mostly padding), partials [chunk][M][N] folded by np_reduce_axis
+        const size_t rows_per_block = N <= 16 ? 64 : 128;
+        const size_t blocks = (M + rows_per_block - 1) / rows_per_block;
+        size_t chunks = (target * 2 + blocks - 1) / blocks;
+        const size_t max_chunks = K / 2048;
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks > 65535) chunks = 65535;
+        if (chunks >= 2) {
+            size_t kc = (K + chunks - 1) / chunks;
+            kc = (kc + 63) / 64 * 64;
+            chunks = (K + kc - 1) / kc;
+            np::Scratch partial;
+            if (int rc = partial.alloc(chunks * M * N * sizeof(float))) return rc;
+            const dim3 grid((unsigned)blocks, (unsigned)chunks);
+            if (N <= 16) sgemm_thin_mfma_kernel<16><<<grid, 256, 0, s>>>(A, B, (float *)partial.ptr, M, (unsigned)N, (unsigned)K, (unsigned)kc);
+            else sgemm_thin_mfma_kernel<32><<<grid, 256, 0, s>>>(A, B, (float *)partial.ptr, M, (unsigned)N, (unsigned)K, (unsigned)kc);
+            NP_LAUNCH_CHECK("sgemm_thin_mfma_kernel");
+            return np_reduce_axis(NP_SUM, (const float *)partial.ptr, 1, chunks, M * N, C, 0);
+        }
     }
     if (M <= 16 && N <= 8 && K >= 65536) {   // X^T X of a tall-skinny X
         size_t chunks = (2 * target + M - 1) / M;
