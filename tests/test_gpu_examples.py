@@ -9,9 +9,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _load():
-    path = Path(__file__).resolve().parent.parent / "examples" / "softmax_regression.py"
-    spec = importlib.util.spec_from_file_location("softmax_regression", path)
+def _load(name="softmax_regression"):
+    path = Path(__file__).resolve().parent.parent / "examples" / (name + ".py")
+    spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -27,3 +27,32 @@ def test_softmax_regression_tracks_numpy(samples, features, hip):
     assert losses[-1] < losses[0]
     scale = np.abs(W_ref).max()
     assert np.abs(W - W_ref).max() <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("n,d,k", [(20_000, 16, 8), (50_000, 64, 32), (7001, 3, 5)])
+def test_kmeans_tracks_numpy(n, d, k, hip):
+    """examples/kmeans.py: thin GEMM + a chain with a column AND a row operand + argmin over short rows + a one-hot
+    built by a broadcast compare + split-K GEMM + column divide, against numpy fp64.  A point within fp32 rounding of
+    two centroids may be assigned differently (and Lloyd's iteration amplifies a flip), so: one iteration is checked
+    exactly — label agreement, and centroids equal to the fp64 means of the GPU's own labels — and a longer run by its
+    inertia."""
+    ex = _load("kmeans")
+    X, _ = ex.make_points(n, d, k, seed=11)
+    C0 = X[:k].copy()
+    C1, labels = ex.kmeans_gpu(X, C0, 1)
+    _, labels_ref = ex.kmeans_numpy(X, C0, 1)
+    labels = labels.astype(np.int64)
+    assert (labels == labels_ref).mean() >= 0.999
+    H = np.eye(k)[labels]
+    means = (H.T @ X.astype(np.float64)) / np.maximum(H.sum(0), 1.0)[:, None]
+    assert np.abs(C1 - means).max() <= 1e-5 * max(1.0, np.abs(means).max())
+
+    def inertia(C):
+        Xd, Cd = X.astype(np.float64), C.astype(np.float64)
+        D = (Xd * Xd).sum(1)[:, None] - 2.0 * Xd @ Cd.T + (Cd * Cd).sum(1)[None, :]
+        return D.min(1).sum()
+
+    C5, _ = ex.kmeans_gpu(X, C0, 5)
+    C5_ref, _ = ex.kmeans_numpy(X, C0, 5)
+    assert np.isfinite(C5).all() and C5.shape == (k, d)
+    assert abs(inertia(C5) - inertia(C5_ref)) <= 2e-3 * inertia(C5_ref)
