@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void sgemm_thin_kernel(const float *__restrict
 // waves of a block walk K in lockstep, 64 rows of B (zero-padded to ROWS columns) per chunk, double
 // buffered so one barrier per chunk is enough (every wave reading B out of the caches itself moved
 // as many bytes of B as of A).
-template <int ROWS>
+template <int ROWS, int NCB = 1>   // NCB column blocks of ROWS columns (2 with ROWS = 32: N up to 64)
 __global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__restrict__ A0, const float *__restrict__ B0,
                                                               float *__restrict__ C0, size_t M, unsigned N, unsigned Ktotal,
                                                               unsigned kc) {
@@ -848,8 +848,9 @@ __global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__res
     constexpr int W = 32 / KK;             // k values per lane per step (16 or 8)
     constexpr int NACC = ROWS * ROWS / 64; // 16 or 4
     constexpr int CH = 64;                 // k rows of B per LDS chunk = two steps
-    constexpr int STR = ROWS == 32 ? 32 : 18;   // 16-wide rows: q and q + 1 land 16 banks apart
-    constexpr int NB = CH * ROWS / 256;    // staged elements per thread
+    constexpr int COLS = ROWS * NCB;
+    constexpr int STR = ROWS == 32 ? COLS : 18;   // 16-wide rows: q and q + 1 land 16 banks apart
+    constexpr int NB = CH * COLS / 256;    // staged elements per thread
     typedef float acc_t __attribute__((ext_vector_type(NACC)));
     __shared__ float Bs[2][CH * STR];
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -858,9 +859,11 @@ __global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__res
     const size_t row = r0 + i;
     const bool row_ok = row < M;
     const float *a = A + (row_ok ? row : 0) * (size_t)Ktotal + W * q;
-    acc_t acc;
+    acc_t acc[NCB];
 #pragma unroll
-    for (int r = 0; r < NACC; ++r) acc[r] = 0.0f;
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) acc[cb][r] = 0.0f;
     auto fetch = [&](unsigned k0, float (&av)[W]) {
         const unsigned k = k0 + W * q;
 #pragma unroll
@@ -879,23 +882,26 @@ __global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__res
     auto stage_load = [&](unsigned kc, float (&reg)[NB]) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const unsigned e = threadIdx.x + 256 * u, kk = e / ROWS, j = e % ROWS;
+            const unsigned e = threadIdx.x + 256 * u, kk = e / COLS, j = e % COLS;
             reg[u] = (j < N && kc + kk < K) ? B[(size_t)(kc + kk) * N + j] : 0.0f;
         }
     };
     auto stage_store = [&](int buf, const float (&reg)[NB]) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const unsigned e = threadIdx.x + 256 * u, kk = e / ROWS, j = e % ROWS;
+            const unsigned e = threadIdx.x + 256 * u, kk = e / COLS, j = e % COLS;
             Bs[buf][kk * STR + j] = reg[u];
         }
     };
     auto mma = [&](const float (&av)[W], const float *bs) {   // bs: this step's 32 rows of the chunk
 #pragma unroll
         for (int t = 0; t < W; ++t) {
-            const float bv = bs[(W * q + t) * STR + i];
-            if constexpr (ROWS == 32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc, 0, 0, 0);
-            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc, 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float bv = bs[(W * q + t) * STR + cb * ROWS + i];
+                if constexpr (ROWS == 32) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv, acc[cb], 0, 0, 0);
+                else acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv, acc[cb], 0, 0, 0);
+            }
         }
     };
     float a0[W], a1[W], breg[NB];
@@ -914,11 +920,14 @@ __global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__res
         if (more) stage_store(buf ^ 1, breg);
         __syncthreads();
     }
-    if (i < N) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const unsigned col = cb * ROWS + i;
+        if (col >= N) continue;
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
             const size_t orow = ROWS == 32 ? r0 + (r & 3) + 8 * (r >> 2) + 4 * q : r0 + 4 * q + r;
-            if (orow < M) C[orow * N + i] = acc[r];
+            if (orow < M) C[orow * N + col] = acc[cb][r];
         }
     }
 }
@@ -1310,7 +1319,7 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
         NP_LAUNCH_CHECK("sgemm_thin_kernel");
         return NP_OK;
     }
-    if (M >= 2048 && N > 4 && K >= 4) {
+    if (M >= 2048 && N > 4 && N <= 32 && K >= 4) {
         const size_t rows_per_block = N <= 16 ? 64 : 128;
         const size_t blocks = (M + rows_per_block - 1) / rows_per_block;
         if (blocks > 0x7fffffffu) return 1;
@@ -1336,7 +1345,8 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
             if (int rc = partial.alloc(chunks * M * N * sizeof(float))) return rc;
             const dim3 grid((unsigned)blocks, (unsigned)chunks);
             if (N <= 16) sgemm_thin_mfma_kernel<16><<<grid, 256, 0, s>>>(A, B, (float *)partial.ptr, M, (unsigned)N, (unsigned)K, (unsigned)kc);
-            else sgemm_thin_mfma_kernel<32><<<grid, 256, 0, s>>>(A, B, (float *)partial.ptr, M, (unsigned)N, (unsigned)K, (unsigned)kc);
+            else if (N <= 32) sgemm_thin_mfma_kernel<32><<<grid, 256, 0, s>>>(A, B, (float *)partial.ptr, M, (unsigned)N, (unsigned)K, (unsigned)kc);
+            else sgemm_thin_mfma_kernel<32, 2><<<grid, 256, 0, s>>>(A, B, (float *)partial.ptr, M, (unsigned)N, (unsigned)K, (unsigned)kc);
             NP_LAUNCH_CHECK("sgemm_thin_mfma_kernel");
             return np_reduce_axis(NP_SUM, (const float *)partial.ptr, 1, chunks, M * N, C, 0);
         }
@@ -1407,7 +1417,8 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K, const f
         return NP_OK;
     }
     if (!A || !B) return np::fail(NP_ERR_INVALID, "np_sgemm: null input");
-    if (batch == 1 && N <= 32 && g_variant == 0 && K <= 0x7fffffffu) {
+    // (N up to 64 for the split-K thin path only: a few hundred rows x a very long K, two 32-column blocks)
+    if (batch == 1 && (N <= 32 || (N <= 64 && M < 2048 && K >= 16384)) && g_variant == 0 && K <= 0x7fffffffu) {
         const int rc = launch_thin(M, N, K, A, B, C);
         if (rc != 1) return rc;   // 1 = shape not taken
     }
