@@ -823,8 +823,8 @@ __global__ __launch_bounds__(256) void sgemm_thin_kernel(const float *__restrict
 // N = 5 .. 32 columns ((samples x 784) . (784 x 10), a projection onto a few components): too many
 // accumulators for the lane-group kernel above (it turns load-issue-bound), too few columns for a
 // 64-wide tile.  One wave = ROWS rows of A x ROWS (padded) columns on the fp32 MFMA (32x32x2 for
-// N > 16, 16x16x4 — half the matrix-core time per element of A — for N <= 16), operands straight from
-// global memory, no LDS: lane (i, q) owns the q-th 128 / KK bytes of row i's next 128-byte stretch and
+// N > 16, 16x16x4 — half the matrix-core time per element of A — for N <= 16), A straight from
+// global memory into registers: lane (i, q) owns the q-th 128 / KK bytes of row i's next 128-byte stretch and
 // loads them with back-to-back float4 loads (so a line is consumed in one go — with one float4 per
 // step the 32 lines per wave x 32 waves per CU fell out of the vector L1 before their fourth use),
 // then feeds one component to each of W MFMAs; the MFMA sums over q, so every k of the 32-wide step is
