@@ -1216,15 +1216,15 @@ bool prepare_chain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n
             } else if (NDArray_NUMELEMENTS(x) == n) {
                 kinds[i] = NP_FULL;          // equal element counts: flat elementwise (arithmetics.c:194-197)
             } else if (NDArray_NUMELEMENTS(x) < n) {
-                size_t r = 1, c = 1;
-                const int k = broadcast_kind(x, first, &r, &c);
-                if (k < 0 || (have_2d && (r != rows || c != cols))) {
+                size_t br = 1, bc = 1;
+                const int k = broadcast_kind(x, first, &br, &bc);
+                if (k < 0 || (have_2d && (br != rows || bc != cols))) {
                     throw_error("Can't broadcast arrays.");
                     return false;
                 }
                 kinds[i] = k;
-                rows = r;
-                cols = c;
+                rows = br;
+                cols = bc;
                 have_2d = true;
             } else {
                 // the accumulator itself would have to grow: not a fused case
