@@ -742,7 +742,9 @@ def test_row_reductions_short_rows(cols, hip, oracle):
                                  # 17 <= M < 2048 against a very long K: the same kernel over K-chunks + a fold (X^T . G)
                                  (784, 10, 200_000), (500, 5, 30_001), (100, 17, 16_384), (2047, 3, 20_000), (17, 32, 100_000), (300, 16, 65_537),
                                  # ... and N = 33..64 there (two 32-column blocks): cluster sums H^T . X, Gram matrices of <= 64 features
-                                 (32, 64, 300_000), (64, 64, 100_001), (100, 33, 20_000), (2047, 50, 16_384), (40, 63, 70_000)])
+                                 (32, 64, 300_000), (64, 64, 100_001), (100, 33, 20_000), (2047, 50, 16_384), (40, 63, 70_000),
+                                 # fewer row tiles than four waves: 128- and 64-thread workgroups
+                                 (20, 8, 50_000), (30, 16, 20_000), (32, 32, 65_536), (33, 20, 40_000), (48, 12, 30_000)])
 def test_matmul_thin(mnk, hip, oracle):
     """N <= 32: GEMV-with-several-right-hand-sides kernels (sgemm_thin_kernel: lane groups per row of A;
     sgemm_thin_mfma_kernel: one wave = 16 / 32 rows on the MFMA with B through LDS; sgemm_thin_chunks_kernel:
