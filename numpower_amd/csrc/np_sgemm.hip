@@ -932,6 +932,80 @@ __global__ __launch_bounds__(256) void sgemm_thin_mfma_kernel(const float *__res
     }
 }
 
+// One or two row tiles (M <= 64) against a very long K — cluster sums H^T . X, Gram matrices of <= 64 features:
+// B (K x N, one contiguous stream) is the bigger operand and every row tile reads it once anyway, so nothing is
+// gained by sharing it through LDS; and with one or two row tiles a workgroup's waves should not be row tiles at
+// all.  Here every WAVE owns a K-chunk of its own: A as in the kernel above (lane (i, q) takes 64 contiguous bytes
+// of row i per 32-k step), B as plain dword loads — lanes j = 0..31 of a half-wave read 128 contiguous bytes of
+// one row of B per MFMA — no LDS, no barrier.  Partials [chunk][M][N], folded by np_reduce_axis.
+template <int NCB>
+__global__ __launch_bounds__(256) void sgemm_fewrows_splitk_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                                   float *__restrict__ P, unsigned M, unsigned N, unsigned K,
+                                                                   unsigned kc) {
+    typedef v4f v4f_u __attribute__((aligned(4)));
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned i = lane & 31, q = lane >> 5;
+    const unsigned chunk = blockIdx.y * 4 + wave;
+    const unsigned kb = chunk * kc;                 // kc is a multiple of 32
+    if (kb >= K) return;
+    const unsigned ke = kb + kc < K ? kb + kc : K;
+    const unsigned row = blockIdx.x * 32 + i;
+    const bool row_ok = row < M;
+    const float *a = A + (size_t)(row_ok ? row : 0) * K + 16 * q;
+    bool col_ok[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) col_ok[cb] = cb * 32 + i < N;
+    v16f acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+    auto fetch = [&](unsigned k0, float (&av)[16], float (&bv)[NCB][16]) {
+        const unsigned k = k0 + 16 * q;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            v4f x = {0, 0, 0, 0};
+            const unsigned kv = k + 4 * v;
+            if (row_ok && kv + 3 < ke) x = *(const v4f_u *)(a + k0 + 4 * v);
+            else if (row_ok && kv < ke) {
+                x[0] = a[k0 + 4 * v];
+                if (kv + 1 < ke) x[1] = a[k0 + 4 * v + 1];
+                if (kv + 2 < ke) x[2] = a[k0 + 4 * v + 2];
+            }
+            av[4 * v] = x[0]; av[4 * v + 1] = x[1]; av[4 * v + 2] = x[2]; av[4 * v + 3] = x[3];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+                bv[cb][t] = (col_ok[cb] && k + t < ke) ? B[(size_t)(k + t) * N + cb * 32 + i] : 0.0f;
+    };
+    auto mma = [&](const float (&av)[16], const float (&bv)[NCB][16]) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[cb][t], acc[cb], 0, 0, 0);
+    };
+    float a0[16], a1[16], b0[NCB][16], b1[NCB][16];
+    fetch(kb, a0, b0);
+    for (unsigned k0 = kb; k0 < ke; k0 += 64) {
+        fetch(k0 + 32, a1, b1);                      // (past ke: every guard fails, zeros)
+        mma(a0, b0);
+        fetch(k0 + 64, a0, b0);
+        mma(a1, b1);
+    }
+    float *out = P + (size_t)chunk * M * N;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (!col_ok[cb]) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned orow = blockIdx.x * 32 + (r & 3) + 8 * (r >> 2) + 4 * q;
+            if (orow < M) out[(size_t)orow * N + cb * 32 + i] = acc[cb][r];
+        }
+    }
+}
+
 // The mirror image: M <= 16 rows of A, K <= 64, a very wide B ((3 x 3) . (3 x 10^7)): every thread owns four
 // columns, reads the K float4s of B above them (coalesced rows) and keeps MV float4 accumulators; A is
 // a handful of uniform scalars.  B is read once, C written once.
@@ -1327,6 +1401,29 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
         else sgemm_thin_mfma_kernel<32><<<(unsigned)blocks, 256, 0, s>>>(A, B, C, M, (unsigned)N, (unsigned)K, (unsigned)K);
         NP_LAUNCH_CHECK("sgemm_thin_mfma_kernel");
         return NP_OK;
+    }
+    // measured (profiles/r01/skinny_gemm.log): wins for one or two row tiles and N > 16 (32 x 64 x 2e6: 0.334 -> 0.199 ms,
+    // 32 x 32 x 2e6: 0.183 -> 0.114); at four row tiles, or N <= 16 (the 16x16x4 tile), the LDS-staged kernel below is ahead
+    if (M > 16 && M <= 64 && N > 16 && K >= 16384) {
+        const size_t row_tiles = (M + 31) / 32;
+        size_t chunks = (target * 4 * 2 + row_tiles - 1) / row_tiles;      // wave-chunks
+        const size_t max_chunks = K / 1024;
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks >= 8) {
+            size_t kc = (K + chunks - 1) / chunks;
+            kc = (kc + 31) / 32 * 32;
+            chunks = (K + kc - 1) / kc;
+            const size_t groups = (chunks + 3) / 4;
+            if (groups <= 65535) {
+                np::Scratch partial;
+                if (int rc = partial.alloc(chunks * M * N * sizeof(float))) return rc;
+                const dim3 grid((unsigned)row_tiles, (unsigned)groups);
+                if (N <= 32) sgemm_fewrows_splitk_kernel<1><<<grid, 256, 0, s>>>(A, B, (float *)partial.ptr, (unsigned)M, (unsigned)N, (unsigned)K, (unsigned)kc);
+                else sgemm_fewrows_splitk_kernel<2><<<grid, 256, 0, s>>>(A, B, (float *)partial.ptr, (unsigned)M, (unsigned)N, (unsigned)K, (unsigned)kc);
+                NP_LAUNCH_CHECK("sgemm_fewrows_splitk_kernel");
+                return np_reduce_axis(NP_SUM, (const float *)partial.ptr, 1, chunks, M * N, C, 0);
+            }
+        }
     }
     if (M > 16 && M < 2048 && K >= 16384) {
         // a few hundred rows, a very long K: the same kernel over K-chunks (the tiled split-K plan reads A at
