@@ -7,7 +7,11 @@ A "step" is one pass of the hot path over one batch of synthetic input: one nd::
 4096 x 4096 fp32 matrices (BASELINE config 2, the configuration the metric is quoted on).
 Inputs are resident in HBM before the timed region.  K steps are launched back to back between
 a barrier + device sync on both sides; `value` = all ranks' FLOPs / max-over-ranks wall time.
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank multiplies its own
+With N > 1 every rank (one per GPU) multiplies its own independent matrices.  The ranks come
+either from an external launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE) or —
+when `--gpus N` is given and RANK is NOT in the environment — from this script itself: it spawns
+N copies of itself on 127.0.0.1 with those variables set, relays rank 0's JSON line and exits
+with rank 0's status (spawn_ranks).  Every rank multiplies its own
 independent matrices — the path shards over independent arrays with no data-path collective
 ("weak" scaling); BASELINE config 5 (batched matmul sharded over the ranks + one RCCL
 all-gather) is measured separately and reported under "extras".
@@ -85,9 +89,15 @@ class _stdout_to_devnull:
         return False
 
 
+DRYRUN = os.environ.get("NP_BENCH_DRYRUN") == "1"   # launcher / rendezvous logic only: gloo, no GPU, no kernels
+
+
 class Dist:
     """torch.distributed plumbing (only imported when N > 1, or when NP_BENCH_FORCE_DIST=1 asks for
-    the same code path on one GPU: world size 1, RCCL initialised, kernels on torch's stream)."""
+    the same code path on one GPU: world size 1, RCCL initialised, kernels on torch's stream).
+    NP_BENCH_DRYRUN=1 swaps RCCL for gloo and never touches a device: it exists so that the
+    self-launch path (spawn_ranks -> rendezvous -> barrier -> max over ranks -> one JSON line from
+    rank 0) can be exercised on a box without a GPU (tests/test_bench_launcher_cpu.py)."""
 
     def __init__(self, n):
         self.n = n
@@ -106,6 +116,12 @@ class Dist:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", str(n))
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if int(os.environ["WORLD_SIZE"]) != n:
+                raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (n, os.environ["WORLD_SIZE"]))
+            if DRYRUN:
+                with _stdout_to_devnull():      # gloo announces its peers on stdout
+                    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+                return
             torch.cuda.set_device(self.local_rank)
             # RCCL prints a version banner through C stdio on stdout when the communicator comes up;
             # stdout must carry exactly one JSON line, so the banner is flushed into /dev/null.
@@ -124,19 +140,21 @@ class Dist:
             torch.cuda.set_stream(self.stream)
             assert self.stream.cuda_stream != 0
             check(load().np_set_stream(self.stream.cuda_stream))
-        else:
+        elif not DRYRUN:
             D.init(0)
 
     def barrier_sync(self):
         if self.use_torch:
             self.dist.barrier()
-            self.torch.cuda.synchronize()
-        D.sync()
+            if not DRYRUN:
+                self.torch.cuda.synchronize()
+        if not DRYRUN:
+            D.sync()
 
     def max_over_ranks(self, x: float) -> float:
         if not self.use_torch:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if DRYRUN else "cuda")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -146,20 +164,79 @@ class Dist:
                 self.dist.destroy_process_group()
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv, timeout_s: float = 1500.0) -> int:
+    """`python bench.py --gpus N` without an external launcher: start N copies of this script, one
+    per GPU, with the variables torch.distributed.run would set (rendezvous on 127.0.0.1, a free
+    port), relay rank 0's stdout (the one JSON line) to ours, leave every rank's stderr attached,
+    and return rank 0's exit status.  A rank that dies takes the job down: the survivors are
+    terminated (by the exact PIDs started here) instead of sitting in the rendezvous timeout."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + timeout_s
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failed = (-1, "timeout after %.0f s" % timeout_s)
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        log("bench.py: rank %s failed (%s); stopping the other ranks" % failed)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    if out0 and out0[0]:
+        sys.stdout.write(out0[0].decode())
+        sys.stdout.flush()
+    if failed is not None:
+        return failed[1] if isinstance(failed[1], int) and failed[1] > 0 else 1
+    return 0
+
+
 def timed(dist: Dist, fn, steps: int, warmup: int):
     """-> (wall seconds max over ranks, HIP-event ms on this rank's stream) for `steps` calls."""
     for _ in range(warmup):
         fn()
     dist.barrier_sync()
-    ev = Timer()
+    ev = None if DRYRUN else Timer()
     t0 = time.perf_counter()
-    ev.start()
+    if ev:
+        ev.start()
     for _ in range(steps):
         fn()
-    ev.stop()
+    if ev:
+        ev.stop()
     dist.barrier_sync()
     wall = time.perf_counter() - t0
-    return dist.max_over_ranks(wall), ev.elapsed_ms()
+    return dist.max_over_ranks(wall), (ev.elapsed_ms() if ev else wall * 1e3)
 
 
 def cpu_time(fn, budget_s=8.0, max_iters=5):
@@ -486,8 +563,24 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline only")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no external launcher: this process becomes the launcher (one rank per GPU, see spawn_ranks)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    if DRYRUN and os.environ.get("NP_BENCH_DRYRUN_FAIL_RANK") == os.environ.get("RANK", ""):
+        sys.exit(3)     # test hook: this rank dies before the rendezvous (tests/test_bench_launcher_cpu.py)
     dist = Dist(args.gpus)
     rank0 = dist.rank == 0
+    if DRYRUN:
+        # launcher smoke without a GPU: the timed region is K sleeps; no throughput claim is made
+        wall, _ = timed(dist, lambda: time.sleep(0.001), args.steps, args.warmup)
+        ranks_seen = int(dist.max_over_ranks(float(dist.rank))) + 1      # collective: every rank calls it
+        if rank0:
+            print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "GFLOP/s", "n_gpus": args.gpus,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+                              "dry_run": True, "ranks_seen": ranks_seen}), flush=True)
+        dist.close()
+        return
     mm = bench_matmul(dist, args.steps, args.warmup, do_cpu=rank0 and args.gpus == 1)
     flop = mm["flop_per_step"]
     value = flop * args.steps * args.gpus / mm["wall_s"] / 1e9            # GFLOP/s, whole job
