@@ -1,0 +1,66 @@
+/*
+ * gpu_alloc_hip.c — the device-buffer layer of the reference (src/gpu_alloc.h:8-15, implemented
+ * for CUDA in src/gpu_alloc.c:11-54) over libnp_hip.so.  Same seven symbols, same signatures, so
+ * every call site in ndarray.c / initializers.c / arithmetics.c links unchanged.
+ *
+ * Differences a maintainer should know:
+ *   - blocks come from np_malloc's caching pool: the result allocation every op makes
+ *     (arithmetics.c:211-231) does not reach the driver in steady state;
+ *   - the reference's `unsigned int size` caps a buffer at 4 GiB; these entry points keep the
+ *     signature (they must, to stay drop-in) and widen to size_t immediately — callers that can
+ *     pass more should call np_malloc / np_memcpy_* (size_t) directly;
+ *   - nothing here synchronises the device except the two read-backs, which must.
+ */
+#include <stdio.h>
+
+#include "np_ext_hooks.h"
+#include "np_hip.h"
+
+/* prototypes = src/gpu_alloc.h:8-15 */
+void vmalloc(void **target, unsigned int size);
+void vfree(void *target);
+void vmemcheck(void);
+void vmemcpyd2d(char *target, char *dst, unsigned int size);
+void vmemcpyh2d(char *target, char *dst, unsigned int size);
+float NDArray_VFLOAT(char *target);
+float NDArray_VFLOATF_I(float *target, int index);
+
+/* gpu_alloc.c:11-17 */
+void vmalloc(void **target, unsigned int size) {
+    np_ext_count_device_alloc(+1);
+    if (np_malloc(target, (size_t)size) != NP_OK) np_ext_throw("device memory allocation failed");
+}
+
+/* gpu_alloc.c:30-33 */
+void vfree(void *target) {
+    np_ext_count_device_alloc(-1);
+    if (np_free(target) != NP_OK) np_ext_throw(np_last_error());
+}
+
+/* gpu_alloc.c:36-40 (NDARRAY_VCHECK at request shutdown) */
+void vmemcheck(void) {
+    const int leaked = np_ext_count_device_alloc(0);
+    if (leaked != 0) printf("\nVRAM MEMORY LEAK: leaked %d array(s)\n", leaked);
+}
+
+/* gpu_alloc.c:20-27.  NOTE the reference's argument order: (source, destination, bytes). */
+void vmemcpyd2d(char *target, char *dst, unsigned int size) {
+    if (np_memcpy_d2d(dst, target, (size_t)size) != NP_OK) np_ext_throw(np_last_error());
+}
+
+void vmemcpyh2d(char *target, char *dst, unsigned int size) {
+    if (np_memcpy_h2d(dst, target, (size_t)size) != NP_OK) np_ext_throw(np_last_error());
+}
+
+/* gpu_alloc.c:43-54: one float back to the host (blocks). */
+float NDArray_VFLOAT(char *target) {
+    float value = 0.0f;
+    if (np_read_float((const float *)target, 0, &value) != NP_OK) np_ext_throw(np_last_error());
+    return value;
+}
+
+float NDArray_VFLOATF_I(float *target, int index) {
+    float value = 0.0f;
+    if (np_read_float(target, (size_t)index, &value) != NP_OK) np_ext_throw(np_last_error());
+    return value;
+}

@@ -192,12 +192,26 @@ NDArray *NDArray_Variance(NDArray *a);
 NDArray *NDArray_Std(NDArray *a);
 NDArray *NDArray_Average(NDArray *a, NDArray *weights /* may be NULL */);
 
-/* ---- unary elementwise (cuda_math.cu:1532-1558; op = np_unary_op of np_hip.h) ---- */
-NDArray *NDArrayMathGPU_ElementWise(NDArray *ndarray, int op);
-NDArray *NDArrayMathGPU_ElementWise1F(NDArray *ndarray, int op, float val1);
-NDArray *NDArrayMathGPU_ElementWise2F(NDArray *ndarray, int op, float val1, float val2);
-NDArray *NDArrayMathGPU_ElementWise1N(NDArray *ndarray, int op /* np_binary_op */, NDArray *val1);
+/* ---- unary elementwise: the reference's drivers with the reference's signatures ----
+ * (src/ndmath/cuda/cuda_math.h:10-15,75-76; implemented in ext/hip_math_drivers.c).  `op` is one of the
+ * cuda_float_* functions of ext/hip_math.h — also exported by this library — exactly as numpower.c
+ * passes them: NDArrayMathGPU_ElementWise(nda, cuda_float_sin) (numpower.c:1651).  Recognised pointers
+ * run as ONE out-of-place np_unary pass (no NDArray_Copy first); any other pointer gets the reference's
+ * copy + in-place call. */
+#ifndef NUMPOWER_AMD_EXT_HIP_MATH_H
+typedef void (*ElementWiseFloatGPUOperation)(int, float *);
+typedef void (*ElementWiseFloatGPUOperation2F)(int, float *, float, float);
+typedef void (*ElementWiseFloatGPUOperation1F)(int, float *, float);
+typedef void (*ElementWiseFloatGPUOperation1N)(int, float *, float *);
+#endif
+NDArray *NDArrayMathGPU_ElementWise(NDArray *ndarray, ElementWiseFloatGPUOperation op);
+NDArray *NDArrayMathGPU_ElementWise1F(NDArray *ndarray, ElementWiseFloatGPUOperation1F op, float val1);
+NDArray *NDArrayMathGPU_ElementWise2F(NDArray *ndarray, ElementWiseFloatGPUOperation2F op, float val1, float val2);
+NDArray *NDArrayMathGPU_ElementWise1N(NDArray *ndarray, ElementWiseFloatGPUOperation1N op, NDArray *val1);
 NDArray *NDArray_Abs(NDArray *nda);
+/* float_rsqrt (double_math.c:111-126) on the device; numpower.c:1791 passes cuda_float_arccos to the
+ * driver for GPU arrays by mistake (no cuda_float_rsqrt exists), so rsqrt gets its own entry point */
+NDArray *NDArray_Rsqrt(NDArray *nda);
 
 /* ---- reductions ---- */
 float NDArray_Sum_Float(NDArray *a);

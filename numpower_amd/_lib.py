@@ -115,6 +115,11 @@ _lib = None
 
 
 def lib_path() -> Path:
+    # dev tools that force GEMM plans / time ablations ask for the -DNP_TUNING build explicitly
+    # (python -m numpower_amd.build --tuning); nothing in the package or the tests does.
+    import os
+    if os.environ.get("NP_HIP_USE_TUNING_BUILD") == "1":
+        return LIBDIR / "libnp_hip_tuning.so"
     return LIBDIR / "libnp_hip.so"
 
 

@@ -2,7 +2,10 @@
 
   numpower_amd/lib/libnp_hip.so         HIP kernels + C ABI (include/np_hip.h), hipcc, gfx950
   numpower_amd/lib/libnumpower_host.so  C++ host mirror of the reference's NDArray L2/L3
-                                        interface for the hot path (include/numpower_host.h)
+                                        interface for the hot path (include/numpower_host.h) + the
+                                        --with-hip glue of ext/ (cuda_* / vmalloc / drivers)
+  numpower_amd/lib/libnp_hipmath.so     the ext/ glue alone (reference's cuda_math.h + gpu_alloc.h
+                                        symbols over libnp_hip.so, no host layer)
   oracle/lib/libnp_oracle.so            CPU restatement of the reference (test infrastructure)
 
 hipcc cross-compiles for gfx950 without a GPU.  Objects are rebuilt only when a source or
@@ -49,45 +52,92 @@ def _run(cmd):
     return proc.stdout
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the HIP translation units for gfx950 and link libnp_hip.so."""
+def build_hip(force: bool = False, verbose: bool = False, tuning: bool = False) -> Path:
+    """Compile the HIP translation units for gfx950 and link libnp_hip.so.
+
+    tuning=True builds libnp_hip_tuning.so instead, with -DNP_TUNING: the plan-forcing environment
+    variables (NP_SGEMM_PLAN, NP_SGEMM_PLAN_DEBUG) and the deliberately wrong timing-ablation GEMM
+    variants exist only there (tools/gemm_plan_sweep.py, tools/gemm_ab.py); the shipped library reads
+    no environment variable."""
     hipcc = _hipcc()
-    OBJDIR.mkdir(parents=True, exist_ok=True)
+    objdir = OBJDIR.parent / "obj_tuning" if tuning else OBJDIR
+    flags = HIP_FLAGS + (["-DNP_TUNING"] if tuning else [])
+    objdir.mkdir(parents=True, exist_ok=True)
     LIBDIR.mkdir(parents=True, exist_ok=True)
     headers = list(INCLUDE.glob("*.h")) + list(CSRC.glob("*.h"))
     jobs = []
     objs = []
     for src in HIP_SOURCES:
         s = CSRC / src
-        o = OBJDIR / (s.stem + ".o")
+        o = objdir / (s.stem + ".o")
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([hipcc, *HIP_FLAGS, "-c", str(s), "-o", str(o)])
+            jobs.append([hipcc, *flags, "-c", str(s), "-o", str(o)])
     if jobs:
         if verbose:
             print("[build] compiling %d HIP translation unit(s) for gfx950" % len(jobs), flush=True)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             list(ex.map(_run, jobs))
-    lib = LIBDIR / "libnp_hip.so"
+    lib = LIBDIR / ("libnp_hip_tuning.so" if tuning else "libnp_hip.so")
     if force or jobs or _newer(lib, objs):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(lib)])
     return lib
 
 
+EXT = ROOT / "ext"
+# the --with-hip glue (plain C over np_hip.h; ext/README.md).  zend_hooks.c needs PHP's headers and is
+# compiled only inside a PHP extension build; standalone_hooks.c is for the glue-only test library.
+EXT_GLUE = ["hip_math.c", "gpu_alloc_hip.c"]
+EXT_CFLAGS = ["-O2", "-std=c99", "-fPIC", "-Wall", "-Wextra", "-Werror", f"-I{INCLUDE}", f"-I{EXT}"]
+
+
+def _ext_objects(names, force, verbose):
+    """gcc -c the given ext/*.c files -> build/obj/ext_<name>.o (rebuilt when a source / header is newer)."""
+    OBJDIR.mkdir(parents=True, exist_ok=True)
+    cc = shutil.which("gcc") or "gcc"
+    headers = list(INCLUDE.glob("*.h")) + list(EXT.glob("*.h"))
+    objs = []
+    for name in names:
+        src = EXT / name
+        obj = OBJDIR / ("ext_" + src.stem + ".o")
+        if force or _newer(obj, [src] + headers):
+            if verbose:
+                print("[build] compiling ext/%s" % name, flush=True)
+            _run([cc, *EXT_CFLAGS, "-c", str(src), "-o", str(obj)])
+        objs.append(obj)
+    return objs
+
+
+def build_ext_glue(force: bool = False, verbose: bool = False) -> Path:
+    """libnp_hipmath.so: ext/hip_math.c + ext/gpu_alloc_hip.c with the stand-alone hooks — the symbols
+    of the reference's cuda_math.h / gpu_alloc.h over libnp_hip.so and NOTHING of the host layer: proof
+    (and test vehicle) that the inner boundary of INTEGRATION.md section 2a is self-contained."""
+    lib = LIBDIR / "libnp_hipmath.so"
+    objs = _ext_objects(EXT_GLUE + ["standalone_hooks.c"], force, verbose)
+    if force or _newer(lib, objs + [LIBDIR / "libnp_hip.so"]):
+        cc = shutil.which("gcc") or "gcc"
+        _run([cc, "-shared", "-fPIC", *map(str, objs), "-o", str(lib), f"-L{LIBDIR}", "-lnp_hip",
+              "-Wl,-rpath,$ORIGIN", "-Wl,--no-undefined"])
+    return lib
+
+
 def build_host(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the C++ host layer (NDArray struct + the reference's L2 entry points)."""
+    """Compile the C++ host layer (NDArray struct + the reference's L2 entry points) and link the
+    --with-hip glue into it (cuda_* / vmalloc ... / NDArrayMathGPU_ElementWise* with the reference's
+    signatures, ext/): one library carries the whole outer boundary."""
     lib = LIBDIR / "libnumpower_host.so"
     srcs = sorted(HOST.glob("*.cpp"))
     if not srcs:
         return lib
     headers = list(INCLUDE.glob("*.h")) + list(HOST.glob("*.h"))
-    if force or _newer(lib, srcs + headers + [LIBDIR / "libnp_hip.so"]):
+    ext_objs = _ext_objects(EXT_GLUE + ["hip_math_drivers.c"], force, verbose)
+    if force or _newer(lib, srcs + headers + ext_objs + [LIBDIR / "libnp_hip.so"]):
         if verbose:
             print("[build] compiling host layer", flush=True)
         cxx = shutil.which("g++") or "g++"
-        _run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{HOST}",
-              *map(str, srcs), "-o", str(lib), f"-L{LIBDIR}", "-lnp_hip",
-              "-Wl,-rpath,$ORIGIN"])
+        _run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{HOST}", f"-I{EXT}",
+              *map(str, srcs), *map(str, ext_objs), "-o", str(lib), f"-L{LIBDIR}", "-lnp_hip",
+              "-Wl,-rpath,$ORIGIN", "-Wl,--no-undefined"])
     return lib
 
 
@@ -114,11 +164,15 @@ def build_oracle(force: bool = False, verbose: bool = False) -> Path:
 def build_all(force: bool = False, verbose: bool = False):
     hip = build_hip(force, verbose)
     host = build_host(force, verbose)
+    build_ext_glue(force, verbose)
     oracle = build_oracle(force, verbose)
     return hip, host, oracle
 
 
 if __name__ == "__main__":
+    if "--tuning" in sys.argv:
+        print(build_hip(force="--force" in sys.argv, verbose=True, tuning=True), "ok")
+        sys.exit(0)
     libs = build_all(force="--force" in sys.argv, verbose=True)
     for lib in libs:
         print(lib, "ok" if Path(lib).exists() else "(not built)")

@@ -88,9 +88,20 @@ int fail(int code, const char *fmt, ...) {
 hipStream_t stream() { return rt().cur_stream; }
 int num_cus() { return rt().cus; }
 
+// Entry-point guard.  First use: bind the library to the calling thread's CURRENT HIP device (whatever
+// the caller — PHP's setDevice, torch.cuda.set_device — selected; device 0 only if nothing did).  Later:
+// the HIP current device is per host thread, so a thread that never selected one would allocate on and
+// launch from device 0 while the pool and the stream belong to r.device — re-select r.device whenever
+// the thread's current device differs (a thread-local read; no driver call in the steady state).
 int ensure_init() {
-    if (rt().inited) return NP_OK;
-    return np_init(0);
+    Runtime &r = rt();
+    int cur = 0;
+    if (!r.inited) {
+        if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+        return np_init(cur);
+    }
+    if (hipGetDevice(&cur) == hipSuccess && cur != r.device) NP_HIP_CHECK(hipSetDevice(r.device));
+    return NP_OK;
 }
 
 int Scratch::alloc(size_t bytes) { return np_malloc(&ptr, bytes); }
@@ -157,9 +168,11 @@ int np_sync(void) {
 int np_set_stream(void *hip_stream) {
     if (int rc = np::ensure_init()) return rc;
     Runtime &r = rt();
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : r.own_stream;
+    if (next == r.cur_stream) return NP_OK;   // per-chunk callers (parallel.hip_compute) must not block here
     // drain the stream we are leaving so pool reuse stays ordered
     NP_HIP_CHECK(hipStreamSynchronize(r.cur_stream));
-    r.cur_stream = hip_stream ? (hipStream_t)hip_stream : r.own_stream;
+    r.cur_stream = next;
     return NP_OK;
 }
 

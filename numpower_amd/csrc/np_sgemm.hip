@@ -1258,7 +1258,11 @@ int launch_planned(GemmArgs g, size_t batch, bool vec) {
     const size_t M = g.M, N = g.N, K = g.K;
     const bool dma_ok = vec && N >= 4;   // M, N edges: sgemm_dma_kernel<EDGE>; K % 16: zeroed tail slots
     Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec);
+#ifdef NP_TUNING   // tuning builds only (python -m numpower_amd.build --tuning): plan tracing
     static const bool debug = getenv("NP_SGEMM_PLAN_DEBUG") != nullptr;
+#else
+    constexpr bool debug = false;
+#endif
     if (!dma_ok && batch == 1 && g_splitk && N >= 1) {
         const size_t Kp = (K + 15) / 16 * 16, Np = (N + 3) / 4 * 4;
         Plan pp = plan_sgemm(M, Np, Kp, 1, true, true);
@@ -1274,7 +1278,10 @@ int launch_planned(GemmArgs g, size_t batch, bool vec) {
             return launch_padded(g, pp, Kp, Np);
         }
     }
-    // tools/gemm_plan_sweep.py: NP_SGEMM_PLAN="cfg,tail_rows,S" forces a plan, NP_SGEMM_PLAN_DEBUG prints the choice
+#ifdef NP_TUNING
+    // tools/gemm_plan_sweep.py: NP_SGEMM_PLAN="cfg,tail_rows,S" forces a plan, NP_SGEMM_PLAN_DEBUG prints the
+    // choice.  Compiled into tuning builds only: the shipped library reads no environment variable, so a
+    // stray one cannot change which kernels a product call runs.
     static const char *forced = getenv("NP_SGEMM_PLAN");
     if (forced && batch == 1) {
         int c = 2, r = 0, S = 1;
@@ -1285,6 +1292,7 @@ int launch_planned(GemmArgs g, size_t batch, bool vec) {
             if (r > 0 && S >= 2) p.Kc = ((K + S - 1) / S + 15) / 16 * 16; else p.tail_rows = 0;
         }
     }
+#endif
     if (debug)
         fprintf(stderr, "[np_sgemm] %zux%zux%zu batch %zu -> cfg %d tail_rows %u S %u Kc %zu model %.1f us\n", M, N, K,
                 batch, p.cfg, p.tail_rows, p.S, p.Kc, p.t * 1e6);
@@ -1337,6 +1345,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(B) &&
                      (sa % 4 == 0) && (sb % 4 == 0);
     // variant = tile_code + 10 * swizzle_group ; 0 = default
+#ifdef NP_TUNING
     if (g_variant >= 1000) {   // timing ablations of the pipelined kernel (wrong results!)
         switch (g_variant - 1000) {
             case 3: return launch_sgemm_pipe<128, 128, 1 + 2>(g, (unsigned)batch, vec);
@@ -1348,6 +1357,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
             default: break;
         }
     }
+#endif
     const int tile = g_variant % 10;
     g.swizzle = (unsigned)(g_variant / 10);
     switch (tile) {
@@ -1490,9 +1500,14 @@ int np_sgemm_set_variant(int variant) {
         return NP_OK;
     }
     // variants >= 1000 switch parts of the pipelined kernel OFF to time them (tools/gemm_ab.py): the
-    // products they compute are wrong by construction, so they need an explicit opt-in
+    // products they compute are wrong by construction, so they exist in tuning builds (-DNP_TUNING) only
+#ifdef NP_TUNING
     if (variant >= 1000 && !getenv("NP_ALLOW_ABLATION"))
         return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: ablation variants need NP_ALLOW_ABLATION=1");
+#else
+    if (variant >= 1000)
+        return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: ablation variants exist only in tuning builds (-DNP_TUNING)");
+#endif
     g_variant = variant;
     return NP_OK;
 }

@@ -251,10 +251,19 @@ NDArray *unary_op(NDArray *x, int op, float p0, float p1) {
     return out;
 }
 
-float reduce_all(NDArray *a, int op, const char *what) {
-    if (!a || !require_gpu(a, what)) return -1.0f;
+// Full reduction to a host float.  The float-returning reference entry points (NDArray_Sum_Float ...) have no
+// error channel besides the raised error, so failure returns -1.0f WITH an error raised; callers that go on
+// computing with the value pass `ok` and stop when it comes back false.
+float reduce_all(NDArray *a, int op, const char *what, bool *ok = nullptr) {
+    if (ok) *ok = false;
+    if (!a) {
+        throw_error("%s: null array", what);
+        return -1.0f;
+    }
+    if (!require_gpu(a, what)) return -1.0f;
     float v = 0.0f;
     if (!dev_ok(np_reduce_all(op, NDArray_FDATA(a), (size_t)NDArray_NUMELEMENTS(a), &v))) return -1.0f;
+    if (ok) *ok = true;
     return v;
 }
 
@@ -672,10 +681,10 @@ NDArray *NDArray_Diagonal(NDArray *target, int offset) {   // indexing.c:21-48
 NDArray *NDArray_Trace(NDArray *a) {   // linalg.c:758-767
     NDArray *diagonal = NDArray_Diagonal(a, 0);
     if (!diagonal) return nullptr;
-    numpower_host_clear_error();
-    const float result = NDArray_Sum_Float(diagonal);
+    bool ok = false;
+    const float result = reduce_all(diagonal, NP_SUM, "trace", &ok);
     NDArray_FREE(diagonal);
-    if (g_error[0]) return nullptr;
+    if (!ok) return nullptr;
     return NDArray_CreateFromFloatScalar(result);
 }
 
@@ -794,6 +803,8 @@ NDArray *NDArray_ConcatenateFlat(NDArray **arrays, int num_arrays) {   // manipu
 
 NDArray *NDArray_Append(NDArray **arrays, int axis, int num_arrays) {   // manipulation.c:368-374
     if (axis == -1) return NDArray_ConcatenateFlat(arrays, num_arrays);
+    // the reference returns NULL silently here (manipulation.c:368-374: only axis -1 is implemented)
+    throw_error("append: only axis -1 (flattened) is implemented");
     return nullptr;
 }
 
@@ -1185,7 +1196,14 @@ struct ChainCall {
 
 // operand classification + quirk flags shared by NDArray_FusedChain / NDArray_FusedChainReduce
 bool prepare_chain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops, ChainCall &c) {
-    if (!inputs || n_inputs < 1 || !inputs[0]) return false;
+    if (!inputs || n_inputs < 1 || !inputs[0]) {
+        throw_error("fused chain: no input array");
+        return false;
+    }
+    if (!ops && n_ops > 0) {
+        throw_error("fused chain: null op list");
+        return false;
+    }
     NDArray *first = inputs[0];
     if (NDArray_NDIM(first) == 0) {
         throw_error("fused chain must start from an array");
@@ -1203,7 +1221,10 @@ bool prepare_chain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n
     bool have_2d = false;
     for (int i = 0; i < n_inputs; ++i) {
         NDArray *x = inputs[i];
-        if (!x) return false;
+        if (!x) {
+            throw_error("fused chain: input %d is null", i);
+            return false;
+        }
         if (NDArray_NDIM(x) == 0 && NDArray_DEVICE(x) == NDARRAY_DEVICE_CPU) {
             kinds[i] = NP_HOST_SCALAR;
         } else {
@@ -1396,7 +1417,9 @@ NDArray *NDArray_Std(NDArray *a) {   // statistics.c:88-108 (the reference rejec
 NDArray *NDArray_Average(NDArray *a, NDArray *weights) {   // statistics.c:131-154
     if (!a || !require_gpu(a, "average")) return nullptr;
     if (weights == nullptr) {
-        float s = reduce_all(a, NP_SUM, "average");
+        bool ok = false;
+        float s = reduce_all(a, NP_SUM, "average", &ok);
+        if (!ok) return nullptr;   // error already raised; never divide the failure value
         return NDArray_CreateFromFloatScalar(s / NDArray_NUMELEMENTS(a));
     }
     if (NDArray_DEVICE(a) != NDArray_DEVICE(weights)) {
@@ -1434,28 +1457,19 @@ int NDArray_IsBroadcastable(const NDArray *array1, const NDArray *array2) {   //
 }
 
 /* ---- unary ---- */
-NDArray *NDArrayMathGPU_ElementWise(NDArray *ndarray, int op) { return unary_op(ndarray, op, 0.0f, 0.0f); }
-NDArray *NDArrayMathGPU_ElementWise1F(NDArray *ndarray, int op, float val1) { return unary_op(ndarray, op, val1, 0.0f); }
-NDArray *NDArrayMathGPU_ElementWise2F(NDArray *ndarray, int op, float val1, float val2) {
-    return unary_op(ndarray, op, val1, val2);
+// NDArrayMathGPU_ElementWise{,1F,2F,1N}: ext/hip_math_drivers.c (reference signatures: the op is a
+// cuda_float_* function pointer), linked into this library together with ext/hip_math.c and
+// ext/gpu_alloc_hip.c.  Their two hooks into the host (np_ext_hooks.h):
+extern "C" void np_ext_throw(const char *message) { throw_error("%s", message ? message : ""); }
+extern "C" int np_ext_count_device_alloc(int delta) {
+    static int count = 0;   // vmalloc/vfree pairs issued through the reference-named layer (vmemcheck)
+    count += delta;
+    return count;
 }
-NDArray *NDArrayMathGPU_ElementWise1N(NDArray *ndarray, int op, NDArray *val1) {
-    // cuda_float_arctan2(n, x, y): x[i] = atan2f(x[i], y[i]) over numel(x) (cuda_math.cu:489,1224)
-    if (!ndarray || !val1) return nullptr;
-    if (!require_gpu(ndarray, "elementwise op") || !require_gpu(val1, "elementwise op")) return nullptr;
-    if (NDArray_NUMELEMENTS(val1) < NDArray_NUMELEMENTS(ndarray)) {
-        throw_error("Incompatible shapes");
-        return nullptr;
-    }
-    NDArray *out = new_array(ndarray->dimensions, ndarray->ndim, NDARRAY_DEVICE_GPU, false);
-    if (!out) return nullptr;
-    if (!dev_ok(np_binary(op, NDArray_FDATA(ndarray), NP_FULL, NDArray_FDATA(val1), NP_FULL, NDArray_FDATA(out), 1,
-                          (size_t)NDArray_NUMELEMENTS(ndarray), 0, 0))) {
-        NDArray_FREE(out);
-        return nullptr;
-    }
-    return out;
-}
+// rsqrt on the device: the reference's PHP_METHOD hands cuda_float_arccos to the driver for GPU arrays
+// (numpower.c:1791, a slip — there is no cuda_float_rsqrt); this is float_rsqrt's definition
+// (double_math.c:111-126: 0x5f3759df + one Newton step) as its own entry point.
+NDArray *NDArray_Rsqrt(NDArray *nda) { return unary_op(nda, NP_RSQRT, 0.0f, 0.0f); }
 NDArray *NDArray_Abs(NDArray *nda) { return unary_op(nda, NP_ABS, 0.0f, 0.0f); }   // arithmetics.c:934-947
 
 /* ---- reductions ---- */

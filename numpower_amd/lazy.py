@@ -27,43 +27,54 @@ MAX_INPUTS = 6
 
 
 class Lazy:
-    def __init__(self, first: NDArray):
-        if not isinstance(first, NDArray):
-            raise Error("Lazy chains start from an NDArray")
-        self.inputs = [first]
-        self.ops = []
+    """A pending chain.  Chains are PERSISTENT values: every step returns a NEW Lazy (inputs / ops lists
+    copied), so one chain can be continued in two directions —
+
+        base = a.lazy().exp();  y1 = base + 1;  y2 = base * 2
+
+    leaves `base`, `y1`, `y2` three different expressions (exp(a), exp(a)+1, exp(a)*2)."""
+
+    def __init__(self, first: NDArray, _inputs=None, _ops=None):
+        if _inputs is None:
+            if not isinstance(first, NDArray):
+                raise Error("Lazy chains start from an NDArray")
+            _inputs, _ops = [first], []
+        self.inputs = _inputs
+        self.ops = _ops
 
     # ---- building -----------------------------------------------------------------------------
-    def _flush_if_full(self, extra_inputs=0):
+    def _room_for(self, extra_inputs=0):
+        """-> (inputs, ops) copies to extend; a chain that is full is evaluated first and the copy
+        starts from its value (this object keeps its own pending ops)."""
         if len(self.ops) >= MAX_OPS or len(self.inputs) + extra_inputs > MAX_INPUTS:
-            done = self.eval()
-            self.inputs, self.ops = [done], []
+            return [self.eval()], []
+        return list(self.inputs), list(self.ops)
 
     def _unary(self, name, p0=0.0, p1=0.0):
-        self._flush_if_full()
-        self.ops.append(FusedOp(NP_FUSED_UNARY, UNARY_OPS[name], 0, 0, float(p0), float(p1), 0, 0))
-        return self
+        inputs, ops = self._room_for()
+        ops.append(FusedOp(NP_FUSED_UNARY, UNARY_OPS[name], 0, 0, float(p0), float(p1), 0, 0))
+        return Lazy(None, inputs, ops)
 
     def _binary(self, name, other, swap):
         if isinstance(other, Lazy):
             other = other.eval()
-        self._flush_if_full(1)
+        inputs, ops = self._room_for(1)
         if isinstance(other, NDArray):
             operand = None
-            for i, x in enumerate(self.inputs):      # reuse an input that is already bound
+            for i, x in enumerate(inputs):      # reuse an input that is already bound
                 if x is other:
                     operand = i
             if operand is None:
-                self.inputs.append(other)
-                operand = len(self.inputs) - 1
+                inputs.append(other)
+                operand = len(inputs) - 1
         elif isinstance(other, (int, float)) and not isinstance(other, bool):
             scalar, _ = NDArray._coerce(other)        # 0-d CPU scalar, as ZVAL_TO_NDARRAY makes it
-            self.inputs.append(scalar)
-            operand = len(self.inputs) - 1
+            inputs.append(scalar)
+            operand = len(inputs) - 1
         else:
             raise Error("argument must be an array, long, double, gdimage or ndarray.")
-        self.ops.append(FusedOp(NP_FUSED_BINARY, BINARY_OPS[name], operand, 1 if swap else 0, 0.0, 0.0, 0, 0))
-        return self
+        ops.append(FusedOp(NP_FUSED_BINARY, BINARY_OPS[name], operand, 1 if swap else 0, 0.0, 0.0, 0, 0))
+        return Lazy(None, inputs, ops)
 
     def __add__(self, o): return self._binary("add", o, False)
     def __radd__(self, o): return self._binary("add", o, True)

@@ -86,11 +86,13 @@ def _load_host():
         "NDArray_CopyToHostBuffer": (C.c_int, [_P, fp]),
         "NDArray_LiveDeviceAllocations": (C.c_long, []),
         "NDArray_IsBroadcastable": (C.c_int, [_P, _P]),
-        "NDArrayMathGPU_ElementWise": (_P, [_P, C.c_int]),
-        "NDArrayMathGPU_ElementWise1F": (_P, [_P, C.c_int, C.c_float]),
-        "NDArrayMathGPU_ElementWise2F": (_P, [_P, C.c_int, C.c_float, C.c_float]),
-        "NDArrayMathGPU_ElementWise1N": (_P, [_P, C.c_int, _P]),
+        # reference signatures (cuda_math.h:10-15,75-76): the op is a cuda_float_* FUNCTION POINTER
+        "NDArrayMathGPU_ElementWise": (_P, [_P, C.c_void_p]),
+        "NDArrayMathGPU_ElementWise1F": (_P, [_P, C.c_void_p, C.c_float]),
+        "NDArrayMathGPU_ElementWise2F": (_P, [_P, C.c_void_p, C.c_float, C.c_float]),
+        "NDArrayMathGPU_ElementWise1N": (_P, [_P, C.c_void_p, _P]),
         "NDArray_Abs": (_P, [_P]),
+        "NDArray_Rsqrt": (_P, [_P]),
         "NDArray_Sum_Float": (C.c_float, [_P]),
         "NDArray_Float_Prod": (C.c_float, [_P]),
         "NDArray_Mean_Float": (C.c_float, [_P]),
@@ -148,6 +150,12 @@ def _load_host():
     h.reduce.argtypes = [_P, C.POINTER(C.c_int), C.c_void_p]
     _host = h
     return h
+
+
+def _fn(h, symbol):
+    """Address of one of the library's own functions, passed where numpower.c passes the function name
+    (`NDArrayMathGPU_ElementWise(nda, cuda_float_sin)`, numpower.c:1651)."""
+    return C.cast(getattr(h, symbol), C.c_void_p)
 
 
 def _raise_pending(h, what="call"):
@@ -358,26 +366,33 @@ class NDArray:
         h = _load_host()
         a, _ = NDArray._coerce(x)
         b, _ = NDArray._coerce(y)
-        return NDArray._wrap(h.NDArrayMathGPU_ElementWise1N(a._p, BINARY_OPS["arctan2"], b._p))
+        return NDArray._wrap(h.NDArrayMathGPU_ElementWise1N(a._p, _fn(h, "cuda_float_arctan2"), b._p))
 
     # ---- unary ops ---------------------------------------------------------------------------------
     @staticmethod
     def _unary(name, a):
         h = _load_host()
         x, _ = NDArray._coerce(a)
-        return NDArray._wrap(h.NDArrayMathGPU_ElementWise(x._p, UNARY_OPS[name]))
+        if name == "rsqrt":
+            # numpower.c:1791 passes cuda_float_arccos for rsqrt on the GPU (a copy-paste slip: the reference has
+            # no cuda_float_rsqrt); the stand-in asks for the CPU definition (float_rsqrt, double_math.c:111-126)
+            # through NDArray_Rsqrt instead of reproducing the slip.
+            return NDArray._wrap(h.NDArray_Rsqrt(x._p))
+        if name == "abs":     # PHP_METHOD(NDArray, abs) calls NDArray_Abs (numpower.c:1619)
+            return NDArray._wrap(h.NDArray_Abs(x._p))
+        return NDArray._wrap(h.NDArrayMathGPU_ElementWise(x._p, _fn(h, "cuda_float_" + name)))
 
     @staticmethod
     def clip(a, min, max):
         h = _load_host()
         x, _ = NDArray._coerce(a)
-        return NDArray._wrap(h.NDArrayMathGPU_ElementWise2F(x._p, UNARY_OPS["clip"], float(min), float(max)))
+        return NDArray._wrap(h.NDArrayMathGPU_ElementWise2F(x._p, _fn(h, "cuda_float_clip"), float(min), float(max)))
 
     @staticmethod
     def round(a, precision=0):
         h = _load_host()
         x, _ = NDArray._coerce(a)
-        return NDArray._wrap(h.NDArrayMathGPU_ElementWise1F(x._p, UNARY_OPS["round"], float(precision)))
+        return NDArray._wrap(h.NDArrayMathGPU_ElementWise1F(x._p, _fn(h, "cuda_float_round"), float(precision)))
 
     # ---- reductions -----------------------------------------------------------------------------------
     @staticmethod

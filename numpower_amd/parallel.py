@@ -124,6 +124,16 @@ def sharded_elementwise(slabs, batch: int, compute, dist=None, gather: bool = Fa
     return _sharded(list(slabs), batch, tuple(slabs[0].shape[1:]), compute, dist, gather)
 
 
+def _bind_device(lib, device):
+    """The library is one device + one stream per process: bind it to the GPU the operands live on
+    before anything is launched (np_init is idempotent for the device it already holds).  Without
+    this a rank r > 0 whose caller never called np_init(r) would run — and take its split-K scratch
+    from — GPU 0."""
+    from ._lib import check
+    index = device.index if device.index is not None else 0
+    check(lib.np_init(index))
+
+
 def hip_elementwise(op: str):
     """compute() for GPU ranks: one np_binary (two operands) or np_unary (one operand) launch over
     the whole slab, ordered with torch's work like hip_compute."""
@@ -134,6 +144,7 @@ def hip_elementwise(op: str):
         lib = load()
         *ins, out = args
         n = out.numel()
+        _bind_device(lib, out.device)
         handle = torch.cuda.current_stream(out.device).cuda_stream
         if handle:
             check(lib.np_set_stream(handle))
@@ -163,6 +174,7 @@ def hip_compute(a, b, out):
     lib = load()
     s, m, k = a.shape
     n = b.shape[2]
+    _bind_device(lib, a.device)
     handle = torch.cuda.current_stream(a.device).cuda_stream
     if handle:
         check(lib.np_set_stream(handle))

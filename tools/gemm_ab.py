@@ -1,5 +1,6 @@
 """A/B harness (dev tool): interleaved rounds over sgemm variants at 4096^3 (+ correctness)."""
 import os
+os.environ.setdefault("NP_HIP_USE_TUNING_BUILD", "1")   # needs `python -m numpower_amd.build --tuning`
 import sys, json
 os.environ.setdefault("NP_ALLOW_ABLATION", "1")   # variants >= 1000 time parts of the kernel by switching them off
 from pathlib import Path

@@ -1,6 +1,7 @@
 """Measure forced np_sgemm plans (NP_SGEMM_PLAN="cfg,tail_rows,S", one subprocess per plan) to
 calibrate plan_sgemm's model.  Usage: python tools/gemm_plan_sweep.py"""
 import os
+os.environ.setdefault("NP_HIP_USE_TUNING_BUILD", "1")   # needs `python -m numpower_amd.build --tuning`
 import subprocess
 import sys
 from pathlib import Path
