@@ -14,7 +14,10 @@ N copies of itself on 127.0.0.1 with those variables set, relays rank 0's JSON l
 with rank 0's status (spawn_ranks).  Every rank multiplies its own
 independent matrices — the path shards over independent arrays with no data-path collective
 ("weak" scaling); BASELINE config 5 (batched matmul sharded over the ranks + one RCCL
-all-gather) is measured separately and reported under "extras".
+all-gather) is measured separately and reported under "extras", twice: with torch.distributed's
+all_gather_into_tensor and with the library's own np_allgather (RCCL behind the C ABI).  NP_COMM=abi
+runs the whole multi-rank bench without importing torch (rendezvous, barrier, max over ranks and the
+gather through np_comm_*).
 
 The JSON line also carries
   roofline      achieved vs peak for the dominant kernel (fp32 MFMA GEMM), from HIP events
@@ -105,6 +108,23 @@ class Dist:
         self.local_rank = 0
         self.torch = None
         self.use_torch = n > 1 or os.environ.get("NP_BENCH_FORCE_DIST") == "1"
+        # NP_COMM=abi: no torch anywhere — rendezvous, barrier, max-over-ranks and config 5's all-gather all go
+        # through the library's own np_comm_* entry points (RCCL behind the C ABI: what a PHP host would call)
+        self.abi = self.use_torch and os.environ.get("NP_COMM") == "abi" and not DRYRUN
+        if self.abi:
+            self.use_torch = False
+            self.rank = int(os.environ.get("RANK", "0"))
+            self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+            world = int(os.environ.get("WORLD_SIZE", str(n)))
+            if world != n:
+                raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (n, world))
+            D.init(self.local_rank)
+            from numpower_amd._lib import check
+            endpoint = "tcp://%s:%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29531"))
+            with _stdout_to_devnull():      # RCCL's banner
+                check(load().np_comm_init(self.rank, n, endpoint.encode()))
+                check(load().np_comm_barrier())
+            return
         if self.use_torch:
             import torch
             import torch.distributed as dist
@@ -144,6 +164,11 @@ class Dist:
             D.init(0)
 
     def barrier_sync(self):
+        if self.abi:
+            from numpower_amd._lib import check
+            check(load().np_comm_barrier())
+            D.sync()
+            return
         if self.use_torch:
             self.dist.barrier()
             if not DRYRUN:
@@ -152,6 +177,11 @@ class Dist:
             D.sync()
 
     def max_over_ranks(self, x: float) -> float:
+        if self.abi:
+            from numpower_amd._lib import check
+            m = C.c_float(0.0)
+            check(load().np_comm_max(float(x), C.byref(m)))
+            return float(m.value)
         if not self.use_torch:
             return x
         t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if DRYRUN else "cuda")
@@ -159,6 +189,9 @@ class Dist:
         return float(t.item())
 
     def close(self):
+        if self.abi:
+            with _stdout_to_devnull():
+                load().np_comm_destroy()
         if self.use_torch:
             with _stdout_to_devnull():
                 self.dist.destroy_process_group()
@@ -261,6 +294,16 @@ def bench_matmul(dist: Dist, steps, warmup, do_cpu):
     dA, dB, dC = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B), D.DeviceArray((n, n))
     wall, ev_ms = timed(dist, lambda: D.sgemm(dA, dB, out=dC), steps, warmup)
     flop = 2.0 * n ** 3
+    # the spread behind the average (941-1228 us inside one run): the same K launches
+    # again, each bracketed by its own event pair on the kernel's stream (after, not inside, the timed region)
+    timers = [Timer() for _ in range(steps)]
+    for t in timers:
+        t.start()
+        D.sgemm(dA, dB, out=dC)
+        t.stop()
+    per = sorted(t.elapsed_ms() for t in timers)
+    launch_ms = {"min": per[0], "median": per[len(per) // 2], "max": per[-1],
+                 "note": "%d individually timed launches after the timed region" % steps}
     # parity: sampled rows against an fp64 product (1e-5 relative to |A|.|B|)
     rows = [0, 1, 1234, 4095]
     got = dC.to_host()[rows].astype(np.float64)
@@ -268,7 +311,7 @@ def bench_matmul(dist: Dist, steps, warmup, do_cpu):
     scale = np.abs(A[rows]).astype(np.float64) @ np.abs(B).astype(np.float64)
     err = float((np.abs(got - ref) / scale).max())
     out = {
-        "wall_s": wall, "event_ms": ev_ms, "flop_per_step": flop,
+        "wall_s": wall, "event_ms": ev_ms, "flop_per_step": flop, "launch_ms": launch_ms,
         "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6),
     }
     if do_cpu:
@@ -306,8 +349,33 @@ def bench_extras(dist: Dist, steps, warmup):
     a = synth.uniform((N,), 5, 0.0, 1.0)
     b = synth.uniform((N,), 6, 0.0, 1.0)
     da, db, do = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b), D.DeviceArray((N,))
+    # What THIS box's HBM gives the three access mixes, measured in the same run through the library's own
+    # streaming kernels on the same buffers ("measure achievable with a copy kernel and
+    # report both"): a float4 copy (np_memcpy_d2d, 8 B/elem), a read-only stream (np_reduce_all_dev: 4 B/elem)
+    # and a write-only stream (np_fill: 4 B/elem).  `frac` stays against the 8 TB/s spec; frac_of_copy says how
+    # the add kernel (2 reads + 1 write) compares with the copy (1 read + 1 write) on this box.
+    lib0 = load()
+    from numpower_amd._lib import check as _check
+    sink = D.DeviceArray((4,))
+    ceil = {}
+    for key, nbytes, fn in (
+            ("copy", 8.0 * N, lambda: _check(lib0.np_memcpy_d2d(do.ptr, da.ptr, 4 * N))),
+            ("read", 4.0 * N, lambda: _check(lib0.np_reduce_all_dev(0, da.ptr, N, sink.ptr))),
+            ("write", 4.0 * N, lambda: _check(lib0.np_fill(do.ptr, 1.5, N)))):
+        c = hbm_case(key, nbytes, fn, steps, warmup, dist)
+        ceil[key + "_GBps"] = c["GBps"]
+    sink.free()
     r = hbm_case("add 1e8 fp32 (C3a)", 12.0 * N, lambda: D.binary("add", da, "full", db, "full", 1, N, out=do),
                  steps, warmup, dist)
+    if os.environ.get("NP_BENCH_DIAG") == "1":
+        again = [hbm_case("add", 12.0 * N, lambda: D.binary("add", da, "full", db, "full", 1, N, out=do), steps, warmup, dist)["GBps"]
+                 for _ in range(4)]
+        log("[diag] add 1e8 (bench buffers, random data) %s then %s GB/s  a=%#x b=%#x o=%#x" % (
+            "%.0f" % r["GBps"], " ".join("%.0f" % x for x in again), da.ptr, db.ptr, do.ptr))
+    ceil["frac_of_copy"] = r["GBps"] / ceil["copy_GBps"]
+    ceil["note"] = ("same run, same buffers: np_memcpy_d2d (float4 copy), np_reduce_all_dev sum (read-only), "
+                    "np_fill (write-only); MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy")
+    r["roofline"]["ceiling"] = ceil
     got = do.to_host()
     t, it = cpu_time(lambda: oracle.binary("add", a, b), budget_s=6.0, max_iters=3)
     ref = oracle.binary("add", a, b)
@@ -333,8 +401,6 @@ def bench_extras(dist: Dist, steps, warmup):
     ex["greater_1e8"] = r
     # §8(f) row 1: NDArray_ArrayEqual / AllClose as one streaming reduction, 8 B/elem, result on the host
     flag = C.c_int(0)
-    lib0 = load()
-    from numpower_amd._lib import check as _check
     r = hbm_case("allclose(a, a') 1e8 fp32 (logic.c:719-772, §8f)", 8.0 * N,
                  lambda: _check(lib0.np_count_mismatch(1, da.ptr, db.ptr, N, 1e-5, 1e-8, C.byref(flag))),
                  steps, warmup, dist)
@@ -555,6 +621,75 @@ def bench_config5(dist: Dist, steps, warmup):
             "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6)}
 
 
+def bench_config5_abi(dist: Dist, steps, warmup, own_comm_port=None):
+    """BASELINE config 5 the way a C / PHP host writes it — no torch tensor, no torch collective: the rank's
+    slab of the batch is one np_sgemm_strided_batched launch written in place into the full result buffer,
+    then ONE np_allgather (RCCL over xGMI behind the C ABI) on the same stream.  own_comm_port: bring up a
+    communicator just for this leg (torch mode: the job's collectives belong to torch.distributed)."""
+    from numpower_amd._lib import check
+    lib = load()
+    total, n = 512, 1024
+    per = total // dist.n
+    lo = dist.rank * per
+    if own_comm_port is not None:
+        with _stdout_to_devnull():
+            check(lib.np_comm_init(dist.rank, dist.n, ("tcp://127.0.0.1:%d" % own_comm_port).encode()))
+    try:
+        A, B = D.DeviceArray((per, n, n)), D.DeviceArray((per, n, n))
+        for i in range(per):
+            ha = synth.uniform((n, n), 12_000 + lo + i, -1.0, 1.0)     # named: the buffer must outlive the copy call
+            hb = synth.uniform((n, n), 13_000 + lo + i, -1.0, 1.0)
+            check(lib.np_memcpy_h2d(A.ptr + i * n * n * 4, ha.ctypes.data, n * n * 4))
+            check(lib.np_memcpy_h2d(B.ptr + i * n * n * 4, hb.ctypes.data, n * n * 4))
+        full = D.DeviceArray((total, n, n))
+        mine = full.ptr + lo * n * n * 4
+        slab_bytes = per * n * n * 4
+
+        def compute():
+            check(lib.np_sgemm_strided_batched(per, n, n, n, A.ptr, n * n, B.ptr, n * n, mine, n * n))
+
+        def compute_and_gather():
+            compute()
+            check(lib.np_allgather(mine, full.ptr, slab_bytes))
+
+        flop = 2.0 * total * n ** 3
+        wall_c, _ = timed(dist, compute, steps, warmup)
+        wall_g, _ = timed(dist, compute_and_gather, steps, warmup)
+        j = ((dist.rank + 1) % dist.n) * per           # one matrix of a PEER's slab, after the gather, against fp64
+        got = np.empty((n, n), dtype=np.float32)
+        check(lib.np_memcpy_d2h(got.ctypes.data, full.ptr + j * n * n * 4, n * n * 4))
+        Ah = synth.uniform((n, n), 12_000 + j, -1.0, 1.0).astype(np.float64)
+        Bh = synth.uniform((n, n), 13_000 + j, -1.0, 1.0).astype(np.float64)
+        err = float((np.abs(got.astype(np.float64) - Ah @ Bh) / (np.abs(Ah) @ np.abs(Bh))).max())
+        for d in (A, B, full):
+            d.free()
+    finally:
+        if own_comm_port is not None:
+            with _stdout_to_devnull():
+                lib.np_comm_destroy()
+    return {"workload": "512 x (1024x1024) fp32 batched matmul, %d slab(s) of %d, gathered with np_allgather (C ABI)" % (dist.n, per),
+            "scaling": "strong", "compute_only_GFLOPs": flop * steps / wall_c / 1e9,
+            "gathered_GFLOPs": flop * steps / wall_g / 1e9, "allgather_bytes_per_rank": slab_bytes,
+            "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6)}
+
+
+def _diag_add(dist, label):
+    """NP_BENCH_DIAG=1: the add-1e8 rate at different points of the run (is it the kernel or the context?)."""
+    if os.environ.get("NP_BENCH_DIAG") != "1":
+        return
+    N = 100_000_000
+    a, b, o = D.DeviceArray((N,)), D.DeviceArray((N,)), D.DeviceArray((N,))
+    D.fill(a, 0.25)
+    D.fill(b, 0.5)
+    rates = []
+    for _ in range(4):
+        _, ev_ms = timed(dist, lambda: D.binary("add", a, "full", b, "full", 1, N, out=o), 25, 5)
+        rates.append(12.0 * N / (ev_ms / 25) / 1e6)
+    log("[diag] add 1e8 (constant data) %-28s %s GB/s  a=%#x b=%#x o=%#x" % (label, " ".join("%.0f" % r for r in rates), a.ptr, b.ptr, o.ptr))
+    for d in (a, b, o):
+        d.free()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -581,7 +716,9 @@ def main():
                               "dry_run": True, "ranks_seen": ranks_seen}), flush=True)
         dist.close()
         return
-    mm = bench_matmul(dist, args.steps, args.warmup, do_cpu=rank0 and args.gpus == 1)
+    _diag_add(dist, "before anything")
+    mm = bench_matmul(dist, args.steps, args.warmup, do_cpu=rank0 and args.gpus == 1 and os.environ.get("NP_BENCH_DIAG_NOCPU") != "1")
+    _diag_add(dist, "after matmul + cpu baseline")
     flop = mm["flop_per_step"]
     value = flop * args.steps * args.gpus / mm["wall_s"] / 1e9            # GFLOP/s, whole job
     kernel_tflops = flop / (mm["event_ms"] / args.steps) / 1e9             # this rank's kernel
@@ -595,7 +732,8 @@ def main():
         "roofline": {"bound": "mfma", "achieved": kernel_tflops, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": kernel_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                      "kernel": "sgemm_dma_kernel 256x128x16 (v_mfma_f32_32x32x2_f32, LDS-DMA staging)",
-                     "algorithmic_flop_per_launch": flop},
+                     "algorithmic_flop_per_launch": flop, "launch_ms": mm["launch_ms"],
+                     "frac_best_launch": flop / mm["launch_ms"]["min"] / 1e9 / PEAK_FP32_MFMA_TFLOPS},
         "parity": {"matmul_max_norm_err_vs_fp64": mm["parity_max_norm_err_vs_fp64"], "ok": mm["parity_ok"]},
     }
     if "cpu" in mm:
@@ -603,7 +741,12 @@ def main():
         result["parity"]["gpu_vs_cpu_reference_max_norm_err"] = mm["gpu_vs_cpu_max_norm_err"]
     extras = {}
     if not args.no_extras:
-        if not dist.use_torch:
+        if dist.abi:
+            try:
+                extras = {"config5_batched_matmul_allgather_c_abi": bench_config5_abi(dist, max(3, args.steps // 10), 2)}
+            except Exception as e:
+                extras = {"error": repr(e)}
+        elif not dist.use_torch:
             try:
                 extras = bench_extras(dist, max(10, args.steps // 2), args.warmup)
                 add = extras["add_1e8"]
@@ -627,7 +770,24 @@ def main():
                 extras = {"config5_batched_matmul_allgather": bench_config5(dist, max(3, args.steps // 10), 2)}
             except Exception as e:
                 extras = {"error": repr(e)}
+            # the same workload with the collective issued through the C ABI (np_allgather) on its own communicator
+            try:
+                port = int(os.environ.get("MASTER_PORT", "29531")) + 23
+                extras["config5_batched_matmul_allgather_c_abi"] = bench_config5_abi(dist, max(3, args.steps // 10), 2,
+                                                                                      own_comm_port=port)
+            except Exception as e:
+                extras["config5_batched_matmul_allgather_c_abi"] = {"error": repr(e)}
             watchdog.cancel()
+    # MFMA utilisation of the headline kernel from the committed rocprofv3 SQ counter pass
+    # (profiles/rNN/gemm_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES over 4 SIMDs x SQ_BUSY_CU_CYCLES)
+    pmc_files = sorted((ROOT / "profiles").glob("r*/gemm_pmc.json"))
+    if pmc_files:
+        try:
+            g = json.loads(pmc_files[-1].read_text())
+            result["roofline"]["mfma_busy"] = g.get("mfma_busy")
+            result["roofline"]["mfma_busy_source"] = str(pmc_files[-1].relative_to(ROOT))
+        except Exception:
+            pass
     # HBM traffic per launch from the committed PMC passes (profiles/rNN/pmc_traffic.json)
     traffic, src = pmc_traffic()
     if traffic:

@@ -350,6 +350,29 @@ int np_copy2d(float *dst, size_t dst_pitch, const float *src, size_t src_pitch, 
 int np_identity(float *out, size_t n);
 int np_arange(float *out, double start, double step, size_t n);
 
+/* ---- the path's one collective (BASELINE config 5) --------------------------------------
+ * One process per GPU (the reference's device model: NDArray::setDevice, numpower.c:615-635; it has no
+ * multi-device code).  A batch-parallel workload keeps contiguous slabs per rank — e.g. batch b of a batched
+ * matmul on rank b / (batch / world) — computes them with np_sgemm_strided_batched, and replicates the
+ * result with ONE all-gather over xGMI (RCCL, loaded on demand).  All calls are enqueued on the library stream,
+ * ordered with the kernels; nothing here is needed — or loaded — by a single-GPU process.
+ *
+ * np_comm_init   rank in [0, world); endpoint = "tcp://host:port" (rank 0 serves the RCCL id on that port;
+ *                use 127.0.0.1 and a free port on one node) or a file path that does not exist yet (rank 0
+ *                publishes the id there, peers poll for it; removed by np_comm_destroy).  Blocks until every
+ *                rank has joined (120 s limit).  The device is the one np_init selected.
+ * np_allgather   recv[r * bytes_per_rank ...] = rank r's send buffer, for every r; in place when
+ *                send == recv + rank * bytes_per_rank.  Asynchronous (np_sync / a read-back waits for it).
+ * np_comm_max    max of one host float over the ranks (timing: the slowest rank); blocks.
+ * np_comm_barrier returns once every rank's stream has reached the call. */
+int np_comm_init(int rank, int world, const char *endpoint);
+int np_comm_rank(void);    /* -1 without a communicator */
+int np_comm_world(void);   /*  0 without a communicator */
+int np_allgather(const void *dev_send, void *dev_recv, size_t bytes_per_rank);
+int np_comm_max(float value, float *host_max);
+int np_comm_barrier(void);
+int np_comm_destroy(void);
+
 /* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 = whole-K plans only,
  * -2 = default planner again, -3 = default planner + always pad unaligned operands). */
 int np_sgemm_set_variant(int variant);

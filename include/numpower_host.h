@@ -212,6 +212,9 @@ NDArray *NDArray_Abs(NDArray *nda);
 /* float_rsqrt (double_math.c:111-126) on the device; numpower.c:1791 passes cuda_float_arccos to the
  * driver for GPU arrays by mistake (no cuda_float_rsqrt exists), so rsqrt gets its own entry point */
 NDArray *NDArray_Rsqrt(NDArray *nda);
+/* float_exp2 (double_math.c:31-33) on the device: the reference has no GPU exp2 at all (numpower.c:3153 maps
+ * the CPU kernel over whatever pointer the array holds; cuda_math.h declares no cuda_float_exp2) */
+NDArray *NDArray_Exp2(NDArray *nda);
 
 /* ---- reductions ---- */
 float NDArray_Sum_Float(NDArray *a);

@@ -77,6 +77,13 @@ PROTOTYPES = {
                                         C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]),
     "np_fused_chain_reduce_axis": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(FusedOp),
                                              C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, _f32p]),
+    "np_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
+    "np_comm_rank": (C.c_int, []),
+    "np_comm_world": (C.c_int, []),
+    "np_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "np_comm_max": (C.c_int, [C.c_float, C.POINTER(C.c_float)]),
+    "np_comm_barrier": (C.c_int, []),
+    "np_comm_destroy": (C.c_int, []),
     "np_reduce_all": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.POINTER(C.c_float)]),
     "np_reduce_all_dev": (C.c_int, [C.c_int, _f32p, C.c_size_t, _f32p]),
     "np_all": (C.c_int, [_f32p, C.c_size_t, C.c_uint, C.POINTER(C.c_int)]),

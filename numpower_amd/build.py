@@ -27,7 +27,8 @@ INCLUDE = ROOT / "include"
 LIBDIR = ROOT / "numpower_amd" / "lib"
 OBJDIR = ROOT / "build" / "obj"
 
-HIP_SOURCES = ["np_runtime.hip", "np_elementwise.hip", "np_reduce.hip", "np_sgemm.hip", "np_layout.hip", "np_select.hip"]
+HIP_SOURCES = ["np_runtime.hip", "np_elementwise.hip", "np_reduce.hip", "np_sgemm.hip", "np_layout.hip", "np_select.hip",
+               "np_comm.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
@@ -80,7 +81,7 @@ def build_hip(force: bool = False, verbose: bool = False, tuning: bool = False) 
             list(ex.map(_run, jobs))
     lib = LIBDIR / ("libnp_hip_tuning.so" if tuning else "libnp_hip.so")
     if force or jobs or _newer(lib, objs):
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(lib)])
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(lib), "-ldl"])
     return lib
 
 

@@ -12,6 +12,7 @@
 #include <math.h>
 
 #include "np_internal.h"
+#include "np_pow_tables.h"
 
 // Bit-level parity with the reference's CPU results needs every multiply, add and divide rounded
 // on its own: no implicit FMA contraction anywhere in this file (the two places where the
@@ -28,61 +29,164 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // scalar op bodies
 // ------------------------------------------------------------------------------------------
 
-// pow for the common case — x finite and normal, y finite — as 2^(y log2 x) in fp64: fp64 FMAs
-// are cheap next to HBM on this part (~30 per element against 12 B of traffic), and the double
-// carries y log2(x) accurately enough (<= 1e-10 relative on log2 x) that the result is the correctly
-// rounded fp32 power in all but ~3e-4 of cases (glibc's powf, which the reference calls per element,
-// arithmetics.c:912-914, is itself < 0.52 ulp).  log2 via the atanh series of (m - 1) / (m + 1) on
-// m in [0.7071, 1.4143]; the quotient from the fp32 reciprocal plus one Newton step; 2^f by a degree-8
-// Taylor series on |f| <= 0.5 (the hardware exp2 on (float)f instead: 0.201 vs 0.220 ms at 10^8, but only
-// 93.7 % instead of 99.97 % of results equal to the correctly rounded power, profiles/r01/pow_ab.log).
-// A negative base is NaN unless y is an integer.  Everything else (zeros, denormals, inf, NaN) takes
-// the library's powf with its C99 special cases.
-// One out-of-line copy of the library routine: inlined at each of a thread's 16 elements it made the
+// pow for the common case — x finite and normal, y finite — as 2^(y log2 x) in fp64 (an fp64 FMA issues at the
+// fp32 rate on this part: every VALU instruction of a wave64 takes 4 cycles, so one fp64 op does the work of a
+// handful of double-float fp32 ops).  glibc's powf, which the reference calls per element (arithmetics.c:912-914),
+// is < 0.52 ulp; this is the correctly rounded fp32 power in all but ~2.5e-4 of cases and never more than 1 ulp off.
+//
+//   log2 x   x = 2^e m, m in [sqrt(1/2), sqrt(2)) (offset split of the bit pattern); the top 5 mantissa bits pick
+//            one of 32 intervals with centre c_i: z = m / c_i - 1 (one FMA against the tabulated 1 / c_i, |z| <=
+//            0.0153), log2 x = (e + log2 c_i) + z (b1 + z (b2 + ... + z b6)).  The table (np_pow_tables.h, 512
+//            bytes, made by tools/gen_pow_tables.py) sits in global memory and is read with a per-lane index: it
+//            lives in the L1 / L2 of every CU, and a vector load costs no VALU issue slot — which is what this kernel
+//            is short of.  The interval around 1.0 has c = 1 exactly, so powers of numbers next to 1 lose nothing.
+//   2^t      t = y log2 x = n + f, |f| <= 1/2: degree-8 polynomial; its tail c4 + ... + c8 f^4 enters scaled by
+//            f^4 c4 <= 6e-4 and runs in fp32, two elements per instruction (v_pk_fma_f32); no clamp — rint, the
+//            saturating v_cvt_i32_f64 and v_ldexp_f64 turn an out-of-range t into inf / 0 by themselves.
+// A negative base is NaN unless y is an integer; zeros, denormals, inf, NaN take the library's powf with its C99
+// special cases: both behind wave-uniform branches (a ballot per float4), so positive normal data runs the core
+// and nothing else.
+//
+// How it got here (profiles/r02/pow_r02.log).  Round 1: 2^(y log2 x) with log2 from the atanh series of
+// (m - 1) / (m + 1) (fp32 reciprocal + Newton step), all fp64, branch-free sign handling: 67 VALU instructions per
+// element, SQ_ACTIVE_INST_VALU = 99 % of the CU-busy cycles, the fp64-saturated chip clocked down to ~1.5 GHz:
+// 202-325 us per 1e8 elements.  A quarter of the instructions were v_mov: each polynomial constant was copied to
+// a VGPR pair per element so that v_fmac_f64 (dst == addend) could consume it -> the FMAs below are VOP3 v_fma_f64
+// with the constant read from an SGPR pair (one constant-bus operand).  With the uniform branches: 48 / element.
+// The table instead of the division + series, no clamp: 38 / element, 15 of them fp64 arithmetic (were 29).
+
+// a * b + c with c (resp. a) a uniform constant in an SGPR pair
+__device__ __forceinline__ double fma_vvs(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+// (int)x with the instruction's own saturation (C++'s conversion is undefined out of range)
+__device__ __forceinline__ int cvt_i32_sat(double x) {
+    int n;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(x));
+    return n;
+}
+
+// One out-of-line copy of the library routine: inlined at each of a thread's elements it made the
 // kernel 4800 instructions long and the hot path a walk across the instruction cache.
 __device__ __attribute__((noinline)) float pow_slow(float x, float y) { return powf(x, y); }
 
-__device__ __forceinline__ float fast_pow(float x, float y) {
-    const unsigned xs = __float_as_uint(x), xb = xs & 0x7fffffffu, yb = __float_as_uint(y);
-    const bool fast = (xb - 0x00800000u) < 0x7f000000u && (yb & 0x7f800000u) != 0x7f800000u;
-    // negative base: NaN unless y is an integer, whose parity picks the sign (C99 7.12.7.4); kept
-    // branch-free — an early return here cost 15 % on all-positive inputs
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// r = c[0] + x (c[1] + x (... c[NC - 1])) in fp32, element pairs packed
+template <int N, int NC>
+__device__ __forceinline__ void horner32(const float (&x)[N], float (&r)[N], const float (&c)[NC]) {
+    if constexpr (N % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < N; j += 2) {
+            const v2f xv = {x[j], x[j + 1]};
+            v2f acc = {c[NC - 1], c[NC - 1]};
+#pragma unroll
+            for (int i = NC - 2; i >= 0; --i) acc = __builtin_elementwise_fma(acc, xv, (v2f){c[i], c[i]});
+            r[j] = acc[0];
+            r[j + 1] = acc[1];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float acc = c[NC - 1];
+#pragma unroll
+            for (int i = NC - 2; i >= 0; --i) acc = __builtin_fmaf(acc, x[j], c[i]);
+            r[j] = acc;
+        }
+    }
+}
+
+// |x|^y for N elements, |x| normal and finite (xb = its bits), y finite; garbage (never a trap, never an
+// out-of-bounds table index) otherwise.
+// `tab`: the 32-entry table — a wave-private copy in LDS in the streaming kernel (ds_read_b128 per element;
+// read straight from global memory the per-lane gathers made the kernel wait on the vector cache:
+// SQ_WAIT_ANY doubled and 213 us became 232, profiles/r02/pow_r02.log), kPowLogTab itself elsewhere.
+typedef const __attribute__((address_space(3))) PowLogEntry *PowTabLds;
+
+template <int N, typename Tab>
+__device__ __forceinline__ void pow_core_n(const unsigned (&xb)[N], const float *y, float *out, Tab tab) {
+    double f[N];
+    float f32[N], q32[N];
+    int n[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const unsigned t0 = xb[k] - 0x3f3504f3u;                     // bits of sqrt(1/2): moves the exponent split there
+        const int e = (int)t0 >> 23;
+        const float m = __uint_as_float((t0 & 0x007fffffu) + 0x3f3504f3u);
+        const PowLogEntry tc = tab[(t0 >> 18) & 31u];
+        const double z = fma((double)m, tc[0], -1.0);
+        double q = fma_vvs(z, NP_POW_LOG2_B6, NP_POW_LOG2_B5);
+        q = fma_vvs(q, z, NP_POW_LOG2_B4);
+        q = fma_vvs(q, z, NP_POW_LOG2_B3);
+        q = fma_vvs(q, z, NP_POW_LOG2_B2);
+        q = fma_vvs(q, z, NP_POW_LOG2_B1);
+        const double L = fma(q, z, tc[1] + (double)e);
+        const double t = (double)y[k] * L;
+        const double nd = rint(t);
+        f[k] = t - nd;
+        n[k] = cvt_i32_sat(nd);
+        f32[k] = (float)f[k];
+    }
+    const float kExpTail[5] = {9.61812910762847688e-03f, 1.33335581464284411e-03f, 1.54035303933816061e-04f,
+                               1.52527338040598377e-05f, 1.32154867901443053e-06f};
+    horner32<N, 5>(f32, q32, kExpTail);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double q = fma_vvs((double)q32[k], f[k], 5.55041086648215762e-02);
+        q = fma_vvs(q, f[k], 2.40226506959100694e-01);
+        q = fma_vvs(q, f[k], 6.93147180559945286e-01);
+        q = fma(q, f[k], 1.0);
+        out[k] = (float)ldexp(q, n[k]);
+    }
+}
+
+// the fp64 path applies: base finite, normal and non-zero; exponent finite
+__device__ __forceinline__ bool pow_fast_ok(unsigned xb, float y) {
+    return (xb - 0x00800000u) < 0x7f000000u && (__float_as_uint(y) & 0x7f800000u) != 0x7f800000u;
+}
+// negative base: NaN unless y is an integer, whose parity picks the sign (C99 7.12.7.4); OR-ed into the bits
+__device__ __forceinline__ unsigned pow_neg_fix(float y) {
     const float ay = fabsf(y);
-    const bool neg = xs != xb;
     const unsigned odd = (ay < 16777216.0f) ? ((unsigned)(int)ay << 31) : 0u;
-    const unsigned fix = !neg ? 0u : (truncf(ay) != ay) ? 0x7fc00000u : odd;   // OR-ed into the result bits
-    int e = (int)(xb >> 23) - 127;
-    float m = __uint_as_float((xb & 0x007fffffu) | 0x3f800000u);   // [1, 2)
-    if (m > 1.41421356f) { m *= 0.5f; e += 1; }
-    const double md = (double)m, d = md + 1.0;
-    double r = (double)__builtin_amdgcn_rcpf((float)d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    const double s = (md - 1.0) * r, s2 = s * s;
-    double p = 1.0 / 11.0;
-    p = fma(p, s2, 1.0 / 9.0);
-    p = fma(p, s2, 1.0 / 7.0);
-    p = fma(p, s2, 1.0 / 5.0);
-    p = fma(p, s2, 1.0 / 3.0);
-    const double L = fma(2.88539008177792677e+00, fma(s * s2, p, s), (double)e);   // e + (2 / ln 2) atanh(s)
-    double t = (double)y * L;
-    t = fmin(fmax(t, -2000.0), 2000.0);
-    const double n = rint(t), f = t - n;
-#ifdef NP_POW_EXP_HW
-    float res = __uint_as_float(__float_as_uint(ldexpf(__builtin_amdgcn_exp2f((float)f), (int)n)) | fix);
-#else
-    double q = 1.32154867901443053e-06;
-    q = fma(q, f, 1.52527338040598377e-05);
-    q = fma(q, f, 1.54035303933816061e-04);
-    q = fma(q, f, 1.33335581464284411e-03);
-    q = fma(q, f, 9.61812910762847688e-03);
-    q = fma(q, f, 5.55041086648215762e-02);
-    q = fma(q, f, 2.40226506959100694e-01);
-    q = fma(q, f, 6.93147180559945286e-01);
-    q = fma(q, f, 1.00000000000000000e+00);
-    float res = __uint_as_float(__float_as_uint((float)ldexp(q, (int)n)) | fix);
-#endif
-    if (__builtin_expect(!fast, 0)) res = pow_slow(x, y);
-    return res;
+    return (truncf(ay) != ay) ? 0x7fc00000u : odd;
+}
+
+// N powers per call (a float4, or the elements a fused-chain trip holds): the rare cases — a negative base
+// anywhere in the wave, an operand outside the fp64 path — are taken by scalar (wave-uniform) branches, so a
+// wave of positive normal data runs pow_core and nothing else.
+template <int N, typename Tab>
+__device__ __forceinline__ void pow_n(const float *x, const float *y, float *out, Tab tab) {
+    // rare-case census in 4 integer ops per element: OR of the sign bits; unsigned max of (|x| bits - min
+    // normal) — zero / denormal bases wrap to huge values, inf / NaN stay >= 0x7f000000 — and of the |y| bits
+    unsigned sign_or = 0u, x_span = 0u, y_top = 0u;
+    unsigned xb[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const unsigned xs = __float_as_uint(x[k]);
+        xb[k] = xs & 0x7fffffffu;
+        sign_or |= xs;
+        x_span = max(x_span, xb[k] - 0x00800000u);
+        y_top = max(y_top, __float_as_uint(y[k]) & 0x7fffffffu);
+    }
+    pow_core_n<N>(xb, y, out, tab);
+    if (__builtin_amdgcn_ballot_w64((int)sign_or < 0) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if ((int)__float_as_uint(x[k]) < 0) out[k] = __uint_as_float(__float_as_uint(out[k]) | pow_neg_fix(y[k]));
+    }
+    if (__builtin_amdgcn_ballot_w64(x_span >= 0x7f000000u || y_top >= 0x7f800000u) != 0ull) {
+#pragma unroll 1
+        for (int k = 0; k < N; ++k)
+            if (!pow_fast_ok(__float_as_uint(x[k]) & 0x7fffffffu, y[k])) out[k] = pow_slow(x[k], y[k]);
+    }
+}
+
+__device__ __forceinline__ float fast_pow(float x, float y) {
+    float r;
+    pow_n<1>(&x, &y, &r, (const PowLogEntry *)kPowLogTab);
+    return r;
 }
 
 // `body` = element lies in the range the reference's AVX2 loop covers (only meaningful when the
@@ -362,6 +466,16 @@ __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict
     float sa = 0.0f, sb = 0.0f;
     if constexpr (AK == NP_SCALAR) sa = a ? a[0] : ha;
     if constexpr (BK == NP_SCALAR) sb = b ? b[0] : hb;
+    // pow: every wave stages its own copy of the log2 table (512 B) in LDS — no workgroup barrier: a wave's
+    // LDS operations complete in order, so its reads below see its own writes
+    __shared__ PowLogEntry pow_tab_lds[OP == NP_POW ? 4 : 1][OP == NP_POW ? 32 : 1];
+    PowTabLds pow_tab = (PowTabLds)&pow_tab_lds[OP == NP_POW ? (threadIdx.x >> 6) : 0][0];
+    if constexpr (OP == NP_POW) {
+        const unsigned lane = threadIdx.x & 63u;
+        if (lane < 32u) pow_tab_lds[threadIdx.x >> 6][lane] = kPowLogTab[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     for (I base = tid; base < nvec; base += stride * UNROLL) {
         v4f va[UNROLL], vb[UNROLL];
@@ -379,9 +493,17 @@ __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict
             if (v < nvec) {
                 v4f r;
                 const I e = v * 4;
+                if constexpr (OP == NP_POW) {
+                    const float px[4] = {va[u][0], va[u][1], va[u][2], va[u][3]};
+                    const float py[4] = {vb[u][0], vb[u][1], vb[u][2], vb[u][3]};
+                    float pr[4];
+                    pow_n<4>(px, py, pr, pow_tab);
+                    r = v4f{pr[0], pr[1], pr[2], pr[3]};
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    r[k] = binary_apply<OP, QUIRK>(va[u][k], vb[u][k], (e + k) < body_end);
+                    for (int k = 0; k < 4; ++k)
+                        r[k] = binary_apply<OP, QUIRK>(va[u][k], vb[u][k], (e + k) < body_end);
+                }
                 st4<NT>(out + (size_t)v * 4, r);
             }
         }
@@ -531,6 +653,8 @@ __global__ __launch_bounds__(256) void outer_kernel(const float *__restrict__ a,
 }
 
 int g_variant = 0;   // see np_elementwise_set_variant
+constexpr bool kColsWideDefault = false;      // fused_chain_cols_kernel: column-block width / residency (A/B: tools/fused_cols_ab.py)
+constexpr size_t kColsWgPerCuDefault = 8;
 
 struct LaunchCfg {
     int unroll;          // float4 per lane per trip
@@ -600,6 +724,8 @@ int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size
     // tools/explore/add_bw.hip): UNROLL 2 (default) and 4, non-temporal
     if (c.unroll == 4)
         NP_BV(4, true);
+    else if (c.unroll == 1)
+        NP_BV(1, true);
     else
         NP_BV(2, true);
 #undef NP_BV
@@ -679,6 +805,8 @@ int launch_unary(const float *in, float *out, size_t n, float p0, float p1) {
     unary_vec_kernel<OP, U, NT, I><<<grid, 256, 0, s>>>(in, out, nvec, tail, (I)n, p0, p1)
         if (c.unroll == 4)
             NP_UV(4, true);
+        else if (c.unroll == 1)
+            NP_UV(1, true);
         else
             NP_UV(2, true);
 #undef NP_UV
@@ -963,12 +1091,22 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
             binary_dispatch<N, LIGHT>(o.op, acc, oth, o.swap != 0, o.quirk != 0, body);
         }
         if constexpr (VACC) {
+            // dead slots (past the end of the span) are skipped under the exec mask: one branch per float4
+            // slot instead of a select per element
             if (sink == NP_SUM) {
 #pragma unroll
-                for (int e = 0; e < N; ++e) rv[e] += live[e / G] ? acc[e] : 0.0f;
+                for (int u = 0; u < U; ++u)
+                    if (live[u]) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) rv[u * G + g] += acc[u * G + g];
+                    }
             } else if (sink == NP_PROD) {
 #pragma unroll
-                for (int e = 0; e < N; ++e) rv[e] *= live[e / G] ? acc[e] : 1.0f;
+                for (int u = 0; u < U; ++u)
+                    if (live[u]) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) rv[u * G + g] *= acc[u * G + g];
+                    }
             } else if (sink == NP_MIN) {
 #pragma unroll
                 for (int e = 0; e < N; ++e)
@@ -985,10 +1123,18 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
             // same combine rules as np_reduce_all: NaN never replaces in min / max)
             if (sink == NP_SUM) {
 #pragma unroll
-                for (int e = 0; e < N; ++e) racc += live[e / G] ? acc[e] : 0.0f;
+                for (int u = 0; u < U; ++u)
+                    if (live[u]) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) racc += acc[u * G + g];
+                    }
             } else if (sink == NP_PROD) {
 #pragma unroll
-                for (int e = 0; e < N; ++e) racc *= live[e / G] ? acc[e] : 1.0f;
+                for (int u = 0; u < U; ++u)
+                    if (live[u]) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) racc *= acc[u * G + g];
+                    }
             } else if (sink == NP_MIN) {
 #pragma unroll
                 for (int e = 0; e < N; ++e)
@@ -1078,7 +1224,7 @@ __global__ __launch_bounds__(256) void fused_chain_rows_kernel(FusedArgs by_valu
 // A workgroup owns 64 slots of G columns; its four waves take every fourth row of the block's row chunk
 // (blockIdx.y), each lane accumulating its own G columns (VACC), and are combined through LDS.  With
 // more than one row chunk the partials [chunk][cols] are folded by np_reduce_axis.
-template <int G, bool LIGHT, typename I>
+template <int G, bool LIGHT, bool WIDE, typename I>
 __global__ __launch_bounds__(256) void fused_chain_cols_kernel(FusedArgs by_value, float *__restrict__ out, I rows, I cols,
                                                                I rows_per_chunk, float mean_div) {
     (void)by_value;
@@ -1086,12 +1232,27 @@ __global__ __launch_bounds__(256) void fused_chain_cols_kernel(FusedArgs by_valu
     const int sink = f->sink;
     const I lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const I slots_per_row = cols / G;             // cols % G == 0
-    const I slot = (I)blockIdx.x * 64 + lane;
     const I r0 = (I)blockIdx.y * rows_per_chunk;
     const I r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
     float rv[2 * G], racc = 0.0f;
 #pragma unroll
     for (int e = 0; e < 2 * G; ++e) rv[e] = sink_identity(sink);
+    if constexpr (WIDE) {
+        // the whole workgroup walks down the chunk row by row: 256 slots = 4 KiB of one row per step (one
+        // DRAM-friendly contiguous segment instead of four 1 KiB segments of four different rows), every
+        // thread owns its G columns for the whole chunk, so nothing has to be combined across waves
+        const I slot = (I)blockIdx.x * 256 + threadIdx.x;
+        if (slot < slots_per_row) {
+            fused_span_impl<2, G, LIGHT, I, true>(f, out, r0 * cols, (r1 - r0) * slots_per_row, slot, slots_per_row, racc, rv);
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const float v = sink_combine(sink, rv[e], rv[G + e]);
+                out[(size_t)blockIdx.y * cols + (size_t)slot * G + e] = mean_div != 0.0f ? v / mean_div : v;
+            }
+        }
+        return;
+    }
+    const I slot = (I)blockIdx.x * 64 + lane;
     // slot index v of the span <-> (row r0 + v / slots_per_row, slot v % slots_per_row): this thread's
     // slots are v = (wave + 4 i) * slots_per_row + slot
     if (slot < slots_per_row)
@@ -1301,8 +1462,13 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     }
     if (axis_mode == 0) {
         const size_t g = cols % 4 == 0 ? 4 : 1;
-        const size_t col_blocks = (cols / g + 63) / 64;
-        size_t chunks = ((size_t)np::num_cus() * 8 + col_blocks - 1) / col_blocks;
+        // tuning knobs (np_elementwise_set_variant): 1000 + k = k workgroups per CU, 64-slot column blocks;
+        // 2000 + k = the same with 256-slot (whole-workgroup) column blocks
+        const bool wide = g_variant >= 2000 && g_variant < 3000 ? true : g_variant >= 1000 && g_variant < 2000 ? false : kColsWideDefault;
+        const size_t wg_per_cu = g_variant >= 1000 && g_variant < 3000 && g_variant % 1000 ? (size_t)(g_variant % 1000) : kColsWgPerCuDefault;
+        const size_t block_slots = wide ? 256 : 64;
+        const size_t col_blocks = (cols / g + block_slots - 1) / block_slots;
+        size_t chunks = ((size_t)np::num_cus() * wg_per_cu + col_blocks - 1) / col_blocks;
         const size_t max_chunks = rows / 32 ? rows / 32 : 1;
         if (chunks > max_chunks) chunks = max_chunks;
         if (chunks > 65535) chunks = 65535;
@@ -1316,9 +1482,14 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         }
         const float div = chunks > 1 ? 0.0f : mean_div;
         const dim3 grid((unsigned)col_blocks, (unsigned)chunks);
-#define NP_FCOL(G_, LIGHT_) fused_chain_cols_kernel<G_, LIGHT_, uint32_t><<<grid, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, (uint32_t)rows_per_chunk, div)
-        if (g == 4) { if (light) NP_FCOL(4, true); else NP_FCOL(4, false); }
-        else { if (light) NP_FCOL(1, true); else NP_FCOL(1, false); }
+#define NP_FCOL(G_, LIGHT_, WIDE_) fused_chain_cols_kernel<G_, LIGHT_, WIDE_, uint32_t><<<grid, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, (uint32_t)rows_per_chunk, div)
+        if (wide) {
+            if (g == 4) { if (light) NP_FCOL(4, true, true); else NP_FCOL(4, false, true); }
+            else { if (light) NP_FCOL(1, true, true); else NP_FCOL(1, false, true); }
+        } else {
+            if (g == 4) { if (light) NP_FCOL(4, true, false); else NP_FCOL(4, false, false); }
+            else { if (light) NP_FCOL(1, true, false); else NP_FCOL(1, false, false); }
+        }
 #undef NP_FCOL
         NP_LAUNCH_CHECK("fused_chain_cols_kernel");
         if (chunks > 1) {

@@ -1470,6 +1470,10 @@ extern "C" int np_ext_count_device_alloc(int delta) {
 // (numpower.c:1791, a slip — there is no cuda_float_rsqrt); this is float_rsqrt's definition
 // (double_math.c:111-126: 0x5f3759df + one Newton step) as its own entry point.
 NDArray *NDArray_Rsqrt(NDArray *nda) { return unary_op(nda, NP_RSQRT, 0.0f, 0.0f); }
+// exp2 on the device: PHP_METHOD(NDArray, exp2) calls NDArray_Map(nda, float_exp2) whatever the device
+// (numpower.c:3153 — a GPU array's device pointer would be dereferenced on the host) and cuda_math.h has no
+// cuda_float_exp2; float_exp2 (double_math.c:31-33) as its own entry point.
+NDArray *NDArray_Exp2(NDArray *nda) { return unary_op(nda, NP_EXP2, 0.0f, 0.0f); }
 NDArray *NDArray_Abs(NDArray *nda) { return unary_op(nda, NP_ABS, 0.0f, 0.0f); }   // arithmetics.c:934-947
 
 /* ---- reductions ---- */

@@ -93,6 +93,7 @@ def _load_host():
         "NDArrayMathGPU_ElementWise1N": (_P, [_P, C.c_void_p, _P]),
         "NDArray_Abs": (_P, [_P]),
         "NDArray_Rsqrt": (_P, [_P]),
+        "NDArray_Exp2": (_P, [_P]),
         "NDArray_Sum_Float": (C.c_float, [_P]),
         "NDArray_Float_Prod": (C.c_float, [_P]),
         "NDArray_Mean_Float": (C.c_float, [_P]),
@@ -378,6 +379,8 @@ class NDArray:
             # no cuda_float_rsqrt); the stand-in asks for the CPU definition (float_rsqrt, double_math.c:111-126)
             # through NDArray_Rsqrt instead of reproducing the slip.
             return NDArray._wrap(h.NDArray_Rsqrt(x._p))
+        if name == "exp2":    # no cuda_float_exp2 in the reference (numpower.c:3153 is CPU-only): own entry point
+            return NDArray._wrap(h.NDArray_Exp2(x._p))
         if name == "abs":     # PHP_METHOD(NDArray, abs) calls NDArray_Abs (numpower.c:1619)
             return NDArray._wrap(h.NDArray_Abs(x._p))
         return NDArray._wrap(h.NDArrayMathGPU_ElementWise(x._p, _fn(h, "cuda_float_" + name)))

@@ -5,13 +5,20 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np
 from numpower_amd import device as D, synth
 from numpower_amd._lib import load, Timer
-variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [104, 101, 102, 108]
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 and sys.argv[1][0] != "-" else [104, 101, 102, 108]
 D.init(0); lib = load()
 N = 100_000_000
 a = D.DeviceArray.from_host(synth.uniform((N,), 5)); b = D.DeviceArray.from_host(synth.uniform((N,), 6)); o = D.DeviceArray((N,))
+PER_LAUNCH = "--per-launch" in sys.argv   # median of individually timed launches (how tools/explore/add_bw times)
 def t(fn, n=20):
     for _ in range(3): fn()
-    D.sync(); tm = Timer(); tm.start()
+    D.sync()
+    if PER_LAUNCH:
+        ts = []
+        for _ in range(n):
+            tm = Timer(); tm.start(); fn(); tm.stop(); ts.append(tm.elapsed_ms())
+        return float(np.median(ts))
+    tm = Timer(); tm.start()
     for _ in range(n): fn()
     tm.stop(); return tm.elapsed_ms() / n
 res = {}

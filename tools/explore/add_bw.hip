@@ -39,13 +39,38 @@ __global__ __launch_bounds__(T) void k_chunk(const v4f* a, const v4f* b, v4f* o,
   if(MODE==2 && accs[0]+accs[1]+accs[2]+accs[3]==12345.678f) sink[0]=1;
 }
 
+// LDS-DMA read side: both operands travel global -> LDS by global_load_lds_dwordx4
+// (no destination VGPRs while the loads are in flight), come back with ds_read_b128, the sum leaves by a plain /
+// nt store.  Every wave owns its LDS slots (2 x U KiB), so no barrier: s_waitcnt vmcnt(0) orders a wave's own DMA.
+template<int U, bool NTS, int AUX, int T>
+__global__ __launch_bounds__(T) void k_ldsdma(const v4f* a, const v4f* b, v4f* o, unsigned nvec){
+  extern __shared__ float lds[];
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* wa = lds + wave*(2*U*256); float* wb = wa + U*256;
+  const unsigned stride = gridDim.x*T; const unsigned tid = blockIdx.x*T+threadIdx.x;
+  for(unsigned base=tid; base<nvec; base+=stride*U){
+    #pragma unroll
+    for(int u=0;u<U;++u){ unsigned v=base+u*stride; if(v<nvec){
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a+v), (__attribute__((address_space(3))) void*)(wa+u*256), 16, 0, AUX);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b+v), (__attribute__((address_space(3))) void*)(wb+u*256), 16, 0, AUX); } }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    #pragma unroll
+    for(int u=0;u<U;++u){ unsigned v=base+u*stride; if(v<nvec){
+      v4f va = *(const v4f*)(wa+u*256+lane*4), vb = *(const v4f*)(wb+u*256+lane*4);
+      st<NTS>(o+v, va+vb); } }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slots are re-filled by the next trip
+  }
+}
+
 float *A,*B,*O,*S; unsigned nvec; hipStream_t st_;
 template<typename F> void bench(const char* name, double bytes, F launch){
   for(int i=0;i<3;++i) launch(); CK(hipStreamSynchronize(st_));
   std::vector<float> ts; hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for(int i=0;i<15;++i){ CK(hipEventRecord(e0,st_)); launch(); CK(hipEventRecord(e1,st_)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms,e0,e1)); ts.push_back(ms);} 
   std::sort(ts.begin(), ts.end());
-  printf("%-44s med %.4f ms  %.0f GB/s   min %.4f ms %.0f GB/s\n", name, ts[7], bytes/ts[7]/1e6, ts[0], bytes/ts[0]/1e6); fflush(stdout);
+  // the same kernel as bench.py times it: 25 launches back to back between one event pair (no host sync in between)
+  CK(hipEventRecord(e0,st_)); for(int i=0;i<25;++i) launch(); CK(hipEventRecord(e1,st_)); CK(hipEventSynchronize(e1)); float bms; CK(hipEventElapsedTime(&bms,e0,e1)); bms/=25;
+  printf("%-44s med %.4f ms  %.0f GB/s   min %.4f ms %.0f GB/s   back-to-back x25 %.4f ms %.0f GB/s\n", name, ts[7], bytes/ts[7]/1e6, ts[0], bytes/ts[0]/1e6, bms, bytes/bms/1e6); fflush(stdout);
 }
 template<int U,bool NTL,bool NTS,int MODE,int T> void run_cfg(int kind, int bpc){
   double bytes = (MODE==0?12.0:MODE==1?8.0:4.0)*nvec*4;
@@ -63,7 +88,38 @@ template<int U,bool NTL,bool NTS,int T> void run_off(size_t offb, size_t offo){
   char name[128]; snprintf(name,128,"offset U%d T%d offB=%zuB offO=%zuB", U,T,offb,offo);
   bench(name, bytes, [&]{ k_grid<U,NTL,NTS,0,T><<<grid,T,0,st_>>>((v4f*)A,(v4f*)((char*)B+offb),(v4f*)((char*)O+offo),nvec,S); });
 }
-int main(int argc, char** argv){ if(argc>2){
+template<int U,bool NTS,int AUX,int T> void run_lds(int bpc){
+  double bytes = 12.0*nvec*4; size_t need=((size_t)nvec+(size_t)U*T-1)/((size_t)U*T); unsigned grid = bpc? std::min<size_t>(need,(size_t)256*bpc):need;
+  char name[128]; snprintf(name,128,"ldsdma U%d T%d nts%d aux%d bpc%d grid%u", U,T,(int)NTS,AUX,bpc,grid);
+  size_t shm = (size_t)(T/64)*2*U*1024;
+  bench(name, bytes, [&]{ k_ldsdma<U,NTS,AUX,T><<<grid,T,shm,st_>>>((v4f*)A,(v4f*)B,(v4f*)O,nvec); });
+}
+__global__ void k_check(const float* a, const float* b, const float* o, size_t n, unsigned* bad){ size_t i = blockIdx.x*(size_t)blockDim.x+threadIdx.x; size_t st=(size_t)gridDim.x*blockDim.x; for(; i<n; i+=st) if(o[i]!=a[i]+b[i]) atomicAdd(bad,1u); }
+int main(int argc, char** argv){ if(argc>1 && argv[1][0]=='l'){
+  // ./add_bw lds : LDS-DMA read side vs the library's structure (grid U2 T256 nt/nt, uncapped), random data
+  size_t n=100000000; nvec=n/4; CK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  CK(hipMalloc(&A,n*4)); CK(hipMalloc(&B,n*4)); CK(hipMalloc(&O,n*4)); CK(hipMalloc(&S,4));
+  printf("A=%p B=%p O=%p (hipMalloc: 2 MiB aligned = %d %d %d)\n",A,B,O,(int)(((size_t)A&0x1fffff)==0),(int)(((size_t)B&0x1fffff)==0),(int)(((size_t)O&0x1fffff)==0));
+  k_rand<<<2048,256,0,st_>>>(A,n,1); k_rand<<<2048,256,0,st_>>>(B,n,2); CK(hipStreamSynchronize(st_));
+  // correctness of the DMA kernel first
+  CK(hipMemsetAsync(O,0,n*4,st_)); CK(hipMemsetAsync(S,0,4,st_));
+  { const int U=2,T=256; size_t need=((size_t)nvec+(size_t)U*T-1)/((size_t)U*T); k_ldsdma<U,true,0,T><<<need,T,(T/64)*2*U*1024,st_>>>((v4f*)A,(v4f*)B,(v4f*)O,nvec); }
+  k_check<<<4096,256,0,st_>>>(A,B,O,n,(unsigned*)S); unsigned bad=1; CK(hipMemcpyAsync(&bad,S,4,hipMemcpyDeviceToHost,st_)); CK(hipStreamSynchronize(st_));
+  printf("ldsdma U2 correctness: %u mismatches of %zu\n", bad, n);
+  for(int rep=0; rep<3; ++rep){
+    printf("-- round %d\n", rep);
+    run_cfg<2,true,true,0,256>(0,0);            // the library's add structure
+    run_cfg<4,true,true,1,256>(0,0); run_cfg<4,true,true,2,256>(0,0); run_cfg<4,true,true,3,256>(0,0);   // copy / read / write ceilings
+    run_lds<1,true,0,256>(0); run_lds<2,true,0,256>(0); run_lds<4,true,0,256>(0); run_lds<8,true,0,256>(0);
+    run_lds<2,true,2,256>(0); run_lds<4,true,2,256>(0); run_lds<2,false,0,256>(0); run_lds<2,true,0,512>(0); run_lds<4,true,0,128>(0);
+    run_lds<4,true,0,256>(8); run_lds<4,true,0,256>(16); run_lds<8,true,0,256>(4);
+    // second sweep (the nt hint on the DMA was the only variant ahead of the plain kernel in the first)
+    run_lds<1,true,2,256>(0); run_lds<3,true,2,256>(0); run_lds<6,true,2,256>(0); run_lds<4,true,2,512>(0); run_lds<4,true,2,128>(0);
+    run_lds<4,true,3,256>(0); run_lds<4,true,18,256>(0); run_lds<4,true,19,256>(0); run_lds<4,false,2,256>(0);
+    run_cfg<4,true,true,0,256>(0,0); run_cfg<1,true,true,0,256>(0,0);
+  }
+  return 0; }
+  if(argc>2){
   size_t n=100000000; nvec=n/4; CK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   CK(hipMalloc(&A,n*4+(8<<20))); CK(hipMalloc(&B,n*4+(8<<20))); CK(hipMalloc(&O,n*4+(8<<20))); CK(hipMalloc(&S,4));
   printf("A=%p B=%p O=%p\n",A,B,O);
