@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void outer_kernel(const float *__restrict__ a,
 
 int g_variant = 0;   // see np_elementwise_set_variant
 constexpr bool kColsWideDefault = false;      // fused_chain_cols_kernel: column-block width / residency (A/B: tools/fused_cols_ab.py)
-constexpr size_t kColsWgPerCuDefault = 8;
+constexpr size_t kColsWgPerCuDefault = 4;   // 92.5 us vs 94-108 at 8 (profiles/r02/fused_cols_ab.log)
 
 struct LaunchCfg {
     int unroll;          // float4 per lane per trip
@@ -1091,22 +1091,12 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
             binary_dispatch<N, LIGHT>(o.op, acc, oth, o.swap != 0, o.quirk != 0, body);
         }
         if constexpr (VACC) {
-            // dead slots (past the end of the span) are skipped under the exec mask: one branch per float4
-            // slot instead of a select per element
             if (sink == NP_SUM) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (live[u]) {
-#pragma unroll
-                        for (int g = 0; g < G; ++g) rv[u * G + g] += acc[u * G + g];
-                    }
+                for (int e = 0; e < N; ++e) rv[e] += live[e / G] ? acc[e] : 0.0f;
             } else if (sink == NP_PROD) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (live[u]) {
-#pragma unroll
-                        for (int g = 0; g < G; ++g) rv[u * G + g] *= acc[u * G + g];
-                    }
+                for (int e = 0; e < N; ++e) rv[e] *= live[e / G] ? acc[e] : 1.0f;
             } else if (sink == NP_MIN) {
 #pragma unroll
                 for (int e = 0; e < N; ++e)
@@ -1123,18 +1113,10 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
             // same combine rules as np_reduce_all: NaN never replaces in min / max)
             if (sink == NP_SUM) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (live[u]) {
-#pragma unroll
-                        for (int g = 0; g < G; ++g) racc += acc[u * G + g];
-                    }
+                for (int e = 0; e < N; ++e) racc += live[e / G] ? acc[e] : 0.0f;
             } else if (sink == NP_PROD) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (live[u]) {
-#pragma unroll
-                        for (int g = 0; g < G; ++g) racc *= acc[u * G + g];
-                    }
+                for (int e = 0; e < N; ++e) racc *= live[e / G] ? acc[e] : 1.0f;
             } else if (sink == NP_MIN) {
 #pragma unroll
                 for (int e = 0; e < N; ++e)

@@ -44,6 +44,7 @@ struct GemmArgs {
     size_t stride_a, stride_b, stride_c;   // batch strides (elements)
     unsigned tiles_m, tiles_n;
     unsigned swizzle;                       // 0 = row-major tile order, else XCD-aware grouping
+    unsigned prio_period;                   // sgemm_dma_kernel<.., PRIO>: K-tiles between priority flips (see there)
     unsigned long long *probe;              // optional per-workgroup timing record (debug), else null
 };
 
@@ -464,7 +465,15 @@ __global__ __launch_bounds__(256, 2) void sgemm_pipe_kernel(GemmArgs g) {
 // columns >= N, which the guarded epilogue does not store — no zero fill, no extra work in the loop.
 // KTAIL = K % 16 != 0 (its own instantiation: the tail bookkeeping costs the aligned case 0.5-1 %
 // when it is merely a run-time flag, profiles/r01/gemm_ktail_ab.log).
-template <bool EDGE, bool KTAIL>
+//
+// PRIO = alternate the wave priority between the two workgroups that share a CU.  Each SIMD holds one wave of
+// each; at equal priority the SIMD's issue arbitration favours the OLDER wave, so the first-dispatched workgroup
+// runs ahead, finishes early and leaves its neighbour alone on the CU for the rest of its tile, where one wave
+// per SIMD cannot keep the matrix pipe full (tools/gemm_probe.py: co-resident workgroups ending 1.63 M and
+// 2.39 M cycles after their start).  With PRIO every wave reads its slot in the SIMD (HW_ID.WAVE_ID bit 0: the
+// two resident waves differ in it) and raises / drops s_setprio every g.prio_period K-tiles in opposite phase to
+// its neighbour: each workgroup is the favoured one half of the time, both finish together.
+template <bool EDGE, bool KTAIL, bool PRIO = false>
 __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     if (g.K_last && blockIdx.z + 1 == gridDim.z) g.K = g.K_last;   // uniform: split-K remainder chunk
     constexpr int BM = 256, BN = 128, BK = 16;
@@ -657,7 +666,23 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     // (a compile-time "tail DMA" variant of k_tile, peeled into its own iteration, pushed the kernel
     // to 256 VGPRs + 600 B/lane of scratch and 4096^3 from 144 to 130 TFLOP/s: the flag stays uniform
     // run-time state)
-    for (; kt + 2 < nk; ++kt) k_tile(T{}, T{});
+    if constexpr (PRIO) {
+        // hwreg(HW_REG_HW_ID = 4, offset 0, size 4) = WAVE_ID: this wave's slot among the SIMD's resident waves
+        unsigned phase = (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u;
+        while (kt + 2 < nk) {
+            if (phase)
+                __builtin_amdgcn_s_setprio(1);
+            else
+                __builtin_amdgcn_s_setprio(0);
+            const unsigned left = nk - 2 - kt;
+            const unsigned stop = kt + (left < g.prio_period ? left : g.prio_period);
+            for (; kt < stop; ++kt) k_tile(T{}, T{});
+            phase ^= 1u;
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else {
+        for (; kt + 2 < nk; ++kt) k_tile(T{}, T{});
+    }
     if (kt + 1 < nk) k_tile(F{}, T{});
     k_tile(F{}, F{});
 
@@ -1084,6 +1109,9 @@ __global__ __launch_bounds__(256) void sgemm_thin_chunks_kernel(const float *__r
 }
 
 int g_variant = 0;
+// sgemm_dma_kernel<.., PRIO>: K-tiles per priority phase; np_sgemm_set_variant(-(100 + p)) sets it (p = 0: off).
+// 16: 145.4 -> 146.4 TFLOP/s at 4096^3 (tools/gemm_prio_ab.py, profiles/r02/gemm_prio_ab.log; 2...64 all within 0.3 %)
+unsigned g_prio_period = 16;
 unsigned long long *g_probe = nullptr;
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
@@ -1151,7 +1179,10 @@ int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
             sgemm_dma_kernel<true, false><<<grid, 256, 0, np::stream()>>>(g);
         else if (ktail)
             sgemm_dma_kernel<false, true><<<grid, 256, 0, np::stream()>>>(g);
-        else
+        else if (g_prio_period) {
+            g.prio_period = g_prio_period;
+            sgemm_dma_kernel<false, false, true><<<grid, 256, 0, np::stream()>>>(g);
+        } else
             sgemm_dma_kernel<false, false><<<grid, 256, 0, np::stream()>>>(g);
         NP_LAUNCH_CHECK("sgemm_dma_kernel");
         return NP_OK;
@@ -1341,6 +1372,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
     g.lda = (unsigned)lda; g.ldb = (unsigned)N; g.ldc = (unsigned)N;
     g.stride_a = sa; g.stride_b = sb; g.stride_c = sc;
     g.tiles_m = g.tiles_n = 0;
+    g.prio_period = 0;
     g.probe = g_probe;
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(B) &&
                      (sa % 4 == 0) && (sb % 4 == 0);
@@ -1494,6 +1526,10 @@ int np_debug_sgemm_probe(void *dev_buf) {
 }
 
 int np_sgemm_set_variant(int variant) {
+    if (variant <= -100) {   // -(100 + p): priority alternation between co-resident workgroups, p K-tiles per phase (p = 0: off)
+        g_prio_period = (unsigned)(-variant - 100);
+        return NP_OK;
+    }
     if (variant < 0) {   // -1: whole-K plans only, -2: default planner, -3: default + forced operand padding
         g_splitk = variant != -1;
         g_force_pad = variant == -3;

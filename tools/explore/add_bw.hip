@@ -62,6 +62,20 @@ __global__ __launch_bounds__(T) void k_ldsdma(const v4f* a, const v4f* b, v4f* o
   }
 }
 
+// U accesses per lane, `span` float4 apart (instead of one grid apart): span = ceil(nvec / U) rounded up to a block
+// multiple PLUS a stagger, so that a lane's U accesses to one operand do not share their low address bits.
+template<int U, int T>
+__global__ __launch_bounds__(T) void k_span(const v4f* a, const v4f* b, v4f* o, unsigned nvec, unsigned span){
+  const unsigned stride = gridDim.x*T;
+  for(unsigned base=blockIdx.x*T+threadIdx.x; base<span; base+=stride){
+    v4f va[U], vb[U];
+    #pragma unroll
+    for(int u=0;u<U;++u){ unsigned v=base+u*span; if(v<nvec){ va[u]=ld<true>(a+v); vb[u]=ld<true>(b+v);} }
+    #pragma unroll
+    for(int u=0;u<U;++u){ unsigned v=base+u*span; if(v<nvec) st<true>(o+v, va[u]+vb[u]); }
+  }
+}
+
 float *A,*B,*O,*S; unsigned nvec; hipStream_t st_;
 template<typename F> void bench(const char* name, double bytes, F launch){
   for(int i=0;i<3;++i) launch(); CK(hipStreamSynchronize(st_));
@@ -94,6 +108,11 @@ template<int U,bool NTS,int AUX,int T> void run_lds(int bpc){
   size_t shm = (size_t)(T/64)*2*U*1024;
   bench(name, bytes, [&]{ k_ldsdma<U,NTS,AUX,T><<<grid,T,shm,st_>>>((v4f*)A,(v4f*)B,(v4f*)O,nvec); });
 }
+template<int U,int T> void run_span(unsigned stagger){
+  double bytes = 12.0*nvec*4; unsigned span = ((nvec + U - 1)/U + T - 1)/T*T + stagger; unsigned grid = (span + T - 1)/T;
+  char name[128]; snprintf(name,128,"span  U%d T%d stagger %u float4 (%u B)", U,T,stagger,stagger*16);
+  bench(name, bytes, [&]{ k_span<U,T><<<grid,T,0,st_>>>((v4f*)A,(v4f*)B,(v4f*)O,nvec,span); });
+}
 __global__ void k_check(const float* a, const float* b, const float* o, size_t n, unsigned* bad){ size_t i = blockIdx.x*(size_t)blockDim.x+threadIdx.x; size_t st=(size_t)gridDim.x*blockDim.x; for(; i<n; i+=st) if(o[i]!=a[i]+b[i]) atomicAdd(bad,1u); }
 int main(int argc, char** argv){ if(argc>1 && argv[1][0]=='l'){
   // ./add_bw lds : LDS-DMA read side vs the library's structure (grid U2 T256 nt/nt, uncapped), random data
@@ -117,6 +136,9 @@ int main(int argc, char** argv){ if(argc>1 && argv[1][0]=='l'){
     run_lds<1,true,2,256>(0); run_lds<3,true,2,256>(0); run_lds<6,true,2,256>(0); run_lds<4,true,2,512>(0); run_lds<4,true,2,128>(0);
     run_lds<4,true,3,256>(0); run_lds<4,true,18,256>(0); run_lds<4,true,19,256>(0); run_lds<4,false,2,256>(0);
     run_cfg<4,true,true,0,256>(0,0); run_cfg<1,true,true,0,256>(0,0);
+    // third sweep: U accesses per lane `span` apart with a stagger between them
+    run_span<2,256>(0); run_span<2,256>(16); run_span<2,256>(64); run_span<2,256>(128); run_span<2,256>(192); run_span<2,256>(1024+64);
+    run_span<4,256>(0); run_span<4,256>(64); run_span<3,256>(64); run_span<1,256>(0);
   }
   return 0; }
   if(argc>2){
