@@ -378,6 +378,7 @@ int np_comm_destroy(void);
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);
 int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128 */
+int np_reduce_set_variant(int variant);   /* streaming reductions, first pass: workgroups per CU (0 = default) */
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,7 @@ PROTOTYPES = {
     "np_sgemm_set_variant": (C.c_int, [C.c_int]),
     "np_elementwise_set_variant": (C.c_int, [C.c_int]),
     "np_layout_set_variant": (C.c_int, [C.c_int]),
+    "np_reduce_set_variant": (C.c_int, [C.c_int]),
 }
 
 

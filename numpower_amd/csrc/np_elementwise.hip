@@ -691,6 +691,9 @@ unsigned grid_for(size_t work_items, int per_thread, int blocks_per_cu) {
     }
     if (blocks > 0x7fffffffu) blocks = 0x7fffffffu;
     if (blocks < 1) blocks = 1;
+    // a lane's UNROLL accesses are one grid apart: keep that distance off the powers of two (2^27 elements would
+    // put them exactly 256 MiB apart, on the same HBM channel — np::capped_grid has the measurement)
+    if (blocks >= 64) blocks |= 1;
     return (unsigned)blocks;
 }
 
@@ -1344,7 +1347,7 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         // long-lived blocks (NP_FUSED_RBPC blocks per CU for tools/fused_ab.py)
         static const int rbpc = getenv("NP_FUSED_RBPC") ? atoi(getenv("NP_FUSED_RBPC")) : 16;
         const size_t want = (n / 4 + 255) / 256 + 1, cap = (size_t)np::num_cus() * (size_t)rbpc;
-        reduce_blocks = (unsigned)(want < cap ? want : cap);
+        reduce_blocks = (unsigned)np::capped_grid(want, cap);
         if (int rc = partials.alloc(reduce_blocks * sizeof(float))) return rc;
         out = (float *)partials.ptr;
     }

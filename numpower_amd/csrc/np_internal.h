@@ -19,6 +19,14 @@ hipStream_t stream();
 int ensure_init();
 // Device properties cached at init.
 int num_cus();
+// Block count of a capped grid-stride kernel.  With `cap` a power of two (CUs x 8 ...) every lane's accesses
+// sit a power-of-two number of bytes apart — 2048 workgroups x 4 KiB = 8 MiB — and land on the same HBM channel:
+// the full sum of 1e8 floats ran 5.66 TB/s on 2048 workgroups and 6.39 on 2049 (profiles/r02/reduce_cap_ab_2.log).
+// A capped grid is therefore made odd.
+inline size_t capped_grid(size_t wanted, size_t cap) {
+    if (wanted <= cap) return wanted < 1 ? 1 : wanted;
+    return cap | 1;
+}
 // Copy kernel for large word-aligned device-to-device copies (np_elementwise.hip); bytes % 4 == 0.
 int device_copy(void *dst, const void *src, size_t bytes);
 

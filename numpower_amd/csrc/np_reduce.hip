@@ -25,6 +25,15 @@ typedef v4f v4f_u __attribute__((aligned(4)));   // float4 access that only assu
 
 using namespace np::dev;   // r_identity / r_combine / wave_reduce / block_reduce (np_internal.h)
 
+// Workgroups per CU of the streaming reductions' first pass (np_reduce_set_variant; tools/reduce_cap_ab.py).
+// One partial per workgroup, so more workgroups = more partials for the one-block second pass to fold.
+int g_wg_per_cu = 0;   // 0 = the default below
+constexpr int kStreamWgPerCu = 8;
+inline size_t stream_cap() {
+    if (g_wg_per_cu >= 1000) return (size_t)g_wg_per_cu;   // tuning: an exact workgroup count
+    return (size_t)np::num_cus() * (size_t)(g_wg_per_cu > 0 ? g_wg_per_cu : kStreamWgPerCu);
+}
+
 // ------------------------------------------------------------------------------------------
 // full reduction
 // ------------------------------------------------------------------------------------------
@@ -745,10 +754,7 @@ int launch_reduce_all(const float *in, size_t n, float *dev_out) {
     if (head > n) head = n;
     const size_t nvec = (n - head) / 4;
     // enough workgroups to fill the chip (8 per CU), but never more than one per 4 KiB of input
-    size_t blocks = (nvec + 255) / 256;
-    const size_t cap = (size_t)np::num_cus() * 8;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
+    const size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
     np::Scratch partials;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
     reduce_all_pass1<OP, I><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (I)n,
@@ -770,14 +776,21 @@ int dispatch_reduce_all(const float *in, size_t n, float *dev_out) {
 size_t choose_splits(size_t outer, size_t axis_len, size_t inner4) {
     const size_t col_tiles = (inner4 + 63) / 64;
     const size_t base = col_tiles * outer;
-    const size_t target = (size_t)np::num_cus() * 8;
+    // 12 workgroups per CU (tuning: stream_cap() x 3/2), and an ODD number of rows per chunk: chunks that start a
+    // power-of-two number of rows apart (65536 x 4096 in 128 chunks: 512 rows = 8 MiB) put every workgroup's
+    // current row on the same HBM channels — 6.19 TB/s against 6.45-6.50 (profiles/r02/reduce_cap_ab_2.log)
+    const size_t target = stream_cap() * 3 / 2;
     if (base >= target) return 1;
     size_t s = (target + base - 1) / base;
     // keep at least 64 rows per chunk so the per-workgroup epilogue stays negligible
     const size_t max_s = axis_len / 64 > 0 ? axis_len / 64 : 1;
     if (s > max_s) s = max_s;
     if (s > 65535) s = 65535;
-    return s < 1 ? 1 : s;
+    if (s < 1) s = 1;
+    // the kernels derive rows per chunk as ceil(axis_len / splits): step to the nearest split count that makes it odd
+    for (size_t t = s; t > 1 && t + 16 > s; --t)
+        if (((axis_len + t - 1) / t) % 2 == 1) return t;
+    return s;
 }
 
 // mean_div_override != 0: this call folds the partials of an earlier pass — MEAN divides by the
@@ -973,10 +986,7 @@ static int xform_sum(const float *in, const float *in2, size_t n, float p0, floa
     hipStream_t s = np::stream();
     const bool vec = true;   // dword-aligned float4 loads: views may start anywhere
     const size_t nvec = n / 4;
-    size_t blocks = ((vec ? nvec : n / 4) + 255) / 256;
-    const size_t cap = (size_t)np::num_cus() * 8;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
+    const size_t blocks = np::capped_grid(((vec ? nvec : n / 4) + 255) / 256, stream_cap());
     np::Scratch partials;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
     if (vec)
@@ -1248,10 +1258,7 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
     size_t head = ((16 - ((uintptr_t)in & 15u)) & 15u) / 4;
     if (head > n) head = n;
     const size_t nvec = (n - head) / 4;
-    size_t blocks = (nvec + 255) / 256;
-    const size_t cap = (size_t)np::num_cus() * 8;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
+    const size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
     np::Scratch partials, out;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
     if (int rc = out.alloc(sizeof(float))) return rc;
@@ -1268,6 +1275,12 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
     float v = 0.0f;
     if (int rc = np_memcpy_d2h(&v, out.ptr, sizeof(float))) return rc;
     *host_out = (v != 0.0f) ? 1 : 0;
+    return NP_OK;
+}
+
+int np_reduce_set_variant(int variant) {
+    if (variant < 0 || variant > 1000000) return np::fail(NP_ERR_INVALID, "np_reduce_set_variant: workgroups per CU out of range");
+    g_wg_per_cu = variant;
     return NP_OK;
 }
 

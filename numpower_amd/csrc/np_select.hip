@@ -210,7 +210,7 @@ int run_select(const float *in, size_t n, size_t k, float *dev_out2) {
     unsigned long long *hist = (unsigned long long *)((char *)buf.ptr + 256);
     size_t blocks = (n / 4 + 255) / 256;
     const size_t cap = (size_t)np::num_cus() * 4;   // 32 KB of LDS histograms per workgroup
-    if (blocks > cap) blocks = cap;
+    if (blocks > cap) blocks = cap;                 // (LDS-atomic bound: an odd count, np::capped_grid, buys nothing here)
     if (blocks < 1) blocks = 1;
     select_init_kernel<<<1, 256, 0, s>>>(st, hist, (unsigned long long)k);
     NP_LAUNCH_CHECK("select_init_kernel");
