@@ -238,6 +238,24 @@ __device__ __forceinline__ float binary_apply(float a, float b, bool body) {
     return 0.0f;
 }
 
+// exp(x) = 2^n 2^f with n = rint(x log2 e) and f = x log2 e - n from two FMAs (log2 e split hi + lo, so f is good
+// to 2^-30 whatever n is), 2^f from the hardware v_exp_f32 (1 ulp), the scaling by v_ldexp_f32 (denormal results
+// included): 8 VALU instructions where the device library's expf spends 14 — the same argument reduction, but it
+// adds compare / select pairs for the overflow and underflow ends.  Here the argument is clamped into
+// [-104, 88.8] (one v_med3: beyond those the result is 0 / inf anyway and n stays a small integer), and the LAST
+// fma takes the UNclamped x: a NaN or an infinity comes out of it as NaN / +-inf, v_exp_f32 turns that into
+// NaN / inf / 0, v_ldexp_f32 keeps it — no special-case instructions at all.  <= 1.2 ulp against fp64 over the
+// whole range (tests/test_gpu_libm_domain.py holds it to the 1e-5 bar against the oracle's glibc; special values
+// bit for bit).  The fused chains that end in a reduction are VALU-bound, and exp is their commonest step.
+__device__ __forceinline__ float fast_exp(float x) {
+    const float log2e_hi = 0x1.715476p+0f, log2e_lo = __uint_as_float(0x32a57060u);   // 1.9259630335e-08
+    const float xc = __builtin_amdgcn_fmed3f(x, -104.0f, 88.8f);
+    const float n = __builtin_rintf(xc * log2e_hi);
+    float f = __builtin_fmaf(xc, log2e_hi, -n);
+    f = __builtin_fmaf(x, log2e_lo, f);
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
 // log1p and the hyperbolic family: the device library's versions are 3-4x too slow to stay under
 // the HBM roofline (tools/op_sweep.py: log1pf 2.5, sinhf 2.3, asinhf 1.9 TB/s against 6.4 for expf).
 // These are a handful of VALU instructions around expf / logf / sqrtf, accurate to a few ulp over
@@ -315,7 +333,7 @@ __device__ __forceinline__ float unary_apply(float x, float p0, float p1) {
     // sqrtf is correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt;
     // __fsqrt_rn is NOT (it lowers to the native approximation unless OCML_BASIC_ROUNDED_OPERATIONS)
     if constexpr (OP == NP_SQRT) return sqrtf(x);
-    if constexpr (OP == NP_EXP) return expf(x);
+    if constexpr (OP == NP_EXP) return fast_exp(x);
     if constexpr (OP == NP_EXP2) return exp2f(x);
     if constexpr (OP == NP_EXPM1) return expm1f(x);
     if constexpr (OP == NP_LOG) return logf(x);

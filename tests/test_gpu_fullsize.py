@@ -99,24 +99,29 @@ def test_matmul_4096(hip, oracle):
     B = synth.uniform((n, n), 4, -1.0, 1.0)
     dA, dB = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B)
     C = D.sgemm(dA, dB).to_host()
-    rows = np.array([0, 1, 31, 32, 255, 256, 1234, 2047, 2048, 4095])
-    ref = A[rows].astype(np.float64) @ B.astype(np.float64)
-    scale = np.abs(A[rows]).astype(np.float64) @ np.abs(B).astype(np.float64)
-    assert (np.abs(C[rows] - ref) <= 1e-6 * scale).all()
-    cols = np.array([0, 63, 64, 127, 128, 4095])
-    refc = A.astype(np.float64) @ B[:, cols].astype(np.float64)
-    scalec = np.abs(A).astype(np.float64) @ np.abs(B[:, cols]).astype(np.float64)
-    assert (np.abs(C[:, cols] - refc) <= 1e-6 * scalec).all()
-    # the reference's CPU back end (OpenBLAS) on the same inputs, all elements
+    # EVERY element against the fp64 product of the same fp32 inputs, bound scaled per element by |A|.|B|
+    # (two 4096^3 dgemms on the host: a few seconds); 1e-6 is 10x inside the north star's 1e-5
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    err = np.abs(C - ref) / scale
+    assert err.max() <= 1e-6, "max error %.3g |A|.|B| at %s" % (err.max(), np.unravel_index(err.argmax(), err.shape))
+    # the reference's CPU back end (OpenBLAS sgemm) on the same inputs: every element, same per-element scale
     Cref = oracle.matmul(A, B)
-    norm = np.sqrt(n) * 1.0   # |row| . |col| magnitude for U(-1,1) operands ~ n/3; loose global bound
-    assert np.abs(C - Cref).max() <= 1e-5 * (n / 3.0)
+    assert (np.abs(C - Cref) <= 1e-5 * scale).all()
+    err_ref = np.abs(Cref - ref) / scale
+    assert err_ref.max() <= 1e-6                            # ... and OpenBLAS itself sits where we do:
+    assert err.max() <= 2.0 * err_ref.max() and err.mean() <= 2.0 * err_ref.mean()
+    # (relative to the RESULT the 1e-5 of the north star cannot hold for a K = 4096 fp32 dot product whose terms
+    # cancel — for the reference's OpenBLAS no more than for us — hence the |A|.|B| scale; where nothing cancels,
+    # |c| >= |A|.|B| / 4, both are inside 1e-5 of the fp64 value)
+    big = np.abs(ref) >= 0.25 * scale
+    if big.any():
+        assert (np.abs(C - ref)[big] <= 1e-5 * np.abs(ref)[big]).all()
     # exact identities: A . I == A bit for bit, (2A) . B == 2 (A . B) bit for bit
     I = np.eye(n, dtype=np.float32)
     assert (_u32(D.sgemm(dA, D.DeviceArray.from_host(I)).to_host()) == _u32(A)).all()
     C2 = D.sgemm(D.DeviceArray.from_host(A * np.float32(2.0)), dB).to_host()
     assert (_u32(C2) == _u32(C * np.float32(2.0))).all()
-    del norm
 
 
 def test_batched_matmul_slab_64x1024(hip):

@@ -224,3 +224,37 @@ def test_chain_axis_reduction_errors(hip):
         g.lazy().exp().sum(axis=2)
     with pytest.raises(Error, match="axis -1 is out of bounds for array of dimension 2"):
         g.lazy().exp().sum(axis=-1)
+
+
+def test_chains_are_persistent_values(hip):
+    """A chain continued in two directions gives two different expressions (`_unary` / `_binary`
+    used to append to the one shared object, so `y1 = base + 1; y2 = base * 2` both became (exp(a)+1)*2)."""
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    from numpower_amd.ndarray import NDArray
+    a = synth.uniform((513, 129), 97, -2.0, 2.0)
+    ga = NDArray.array(a).gpu()
+    base = ga.lazy().exp()
+    y1 = base + 1.0
+    y2 = base * 2.0
+    y3 = (base - 0.5).abs()
+    assert len(base.ops) == 1 and len(y1.ops) == 2 and len(y2.ops) == 2 and len(y3.ops) == 3
+    e = NDArray.exp(ga)
+    assert _same(base.eval().cpu().numpy(), e.cpu().numpy())
+    assert _same(y1.eval().cpu().numpy(), (e + 1.0).cpu().numpy())
+    assert _same(y2.eval().cpu().numpy(), (e * 2.0).cpu().numpy())
+    assert _same(y3.eval().cpu().numpy(), NDArray.abs(e - 0.5).cpu().numpy())
+    assert _same(base.eval().cpu().numpy(), e.cpu().numpy())          # still exp(a) after its continuations ran
+    # a full chain (12 ops; the one operand array is bound once) continued twice: each continuation evaluates
+    # the full prefix and starts afresh, the 12-op chain itself stays what it was
+    b = synth.uniform((513, 129), 98, 0.0, 0.25)
+    gb = NDArray.array(b).gpu()
+    long = ga.lazy()
+    for _ in range(12):
+        long = long + gb
+    assert len(long.ops) == 12 and len(long.inputs) == 2
+    p, q = long * 3.0, long - 1.0
+    ref = a.copy()
+    for _ in range(12):
+        ref = ref + b
+    assert _same(p.eval().cpu().numpy(), ref * np.float32(3.0)) and _same(q.eval().cpu().numpy(), ref - np.float32(1.0))
+    assert len(long.ops) == 12 and len(p.ops) == 1 and len(q.ops) == 1
