@@ -1363,7 +1363,11 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         if (n >= (size_t(1) << 31)) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: array too large");
         // grid-stride loop over a capped grid: one workgroup-reduce + partial per block, so few,
         // long-lived blocks (NP_FUSED_RBPC blocks per CU for tools/fused_ab.py)
+#ifdef NP_TUNING   // tools/fused_ab.py; the shipped library reads no environment variable
         static const int rbpc = getenv("NP_FUSED_RBPC") ? atoi(getenv("NP_FUSED_RBPC")) : 16;
+#else
+        constexpr int rbpc = 16;
+#endif
         const size_t want = (n / 4 + 255) / 256 + 1, cap = (size_t)np::num_cus() * (size_t)rbpc;
         reduce_blocks = (unsigned)np::capped_grid(want, cap);
         if (int rc = partials.alloc(reduce_blocks * sizeof(float))) return rc;
@@ -1416,8 +1420,13 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     // float4 slots per thread-trip: measured (tools/fused_ab.py, profiles/r01/fused_ab.log) — the
     // LIGHT interpreter is best at 1 slot (49 VGPRs, 8 waves/SIMD), the full one at 2.
     // NP_FUSED_U / NP_FUSED_FULL override for that A/B.
+#ifdef NP_TUNING
     static const int fu_env = getenv("NP_FUSED_U") ? atoi(getenv("NP_FUSED_U")) : 0;
     static const bool force_full = getenv("NP_FUSED_FULL") != nullptr;
+#else
+    constexpr int fu_env = 0;
+    constexpr bool force_full = false;
+#endif
     hipStream_t s = np::stream();
     if (force_full) light = false;
     if (axis_mode == 1) {

@@ -3,6 +3,7 @@ each configuration runs in its own subprocess).  Usage: python tools/fused_ab.py
 import ctypes as C
 import json
 import os
+os.environ.setdefault("NP_HIP_USE_TUNING_BUILD", "1")   # needs `python -m numpower_amd.build --tuning`
 import subprocess
 import sys
 from pathlib import Path
