@@ -120,7 +120,8 @@ class Dist:
                 raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (n, world))
             D.init(self.local_rank)
             from numpower_amd._lib import check
-            endpoint = "tcp://%s:%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29531"))
+            # not MASTER_PORT itself: under torch.distributed.run the launcher's own store is listening there
+            endpoint = "tcp://%s:%d" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29531")) + 29)
             with _stdout_to_devnull():      # RCCL's banner
                 check(load().np_comm_init(self.rank, n, endpoint.encode()))
                 check(load().np_comm_barrier())

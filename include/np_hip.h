@@ -372,6 +372,8 @@ int np_allgather(const void *dev_send, void *dev_recv, size_t bytes_per_rank);
 int np_comm_max(float value, float *host_max);
 int np_comm_barrier(void);
 int np_comm_destroy(void);
+/* testing: the rendezvous of np_comm_init alone (no device, no RCCL) — rank 0's 128 bytes reach every peer */
+int np_comm_debug_exchange(int rank, int world, const char *endpoint, void *bytes128, double timeout_s);
 
 /* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 = whole-K plans only,
  * -2 = default planner again, -3 = default planner + always pad unaligned operands). */

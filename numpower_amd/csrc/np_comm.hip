@@ -236,9 +236,33 @@ int np_comm_init(int rank, int world, const char *endpoint) {
     g_comm.rank = rank;
     g_comm.world = world;
     void *p = nullptr;
-    if (int rc = np_malloc(&p, sizeof(float) * (size_t)(world + 1))) return rc;
+    if (int rc = np_malloc(&p, sizeof(float) * (size_t)(world + 1))) {
+        (void)g_comm.api.CommDestroy(g_comm.comm);   // no half-made communicator: np_last_error() keeps the allocation message
+        g_comm.comm = nullptr;
+        return rc;
+    }
     g_comm.scratch = (float *)p;
     return NP_OK;
+}
+
+// The rendezvous alone (no device, no RCCL): rank 0 hands `bytes128` to the peers, who receive it into theirs.
+// Exists so that the multi-process hand-over can be tested on a machine without GPUs (tests/test_comm_rendezvous_cpu.py).
+int np_comm_debug_exchange(int rank, int world, const char *endpoint, void *bytes128, double timeout_s) {
+    if (world < 1 || rank < 0 || rank >= world || !endpoint || !*endpoint || !bytes128)
+        return np::fail(NP_ERR_INVALID, "np_comm_debug_exchange: bad arguments");
+    if (world == 1) return NP_OK;
+    ncclUniqueId id;
+    memcpy(&id, bytes128, sizeof(id));
+    std::string host;
+    int port = 0;
+    int rc;
+    if (parse_tcp(endpoint, host, port)) {
+        rc = exchange_tcp(host, port, rank, world, id, timeout_s);
+    } else {
+        rc = exchange_file(endpoint, rank, id, timeout_s);
+    }
+    if (rc == NP_OK) memcpy(bytes128, &id, sizeof(id));
+    return rc;
 }
 
 int np_comm_rank(void) { return g_comm.comm ? g_comm.rank : -1; }

@@ -1,0 +1,80 @@
+"""The hand-over of the RCCL id in np_comm_init (rank 0 -> peers, over a loopback TCP socket or a file), run as
+real separate processes without a GPU through np_comm_debug_exchange: world 2 and 4, both endpoint forms, peers
+that start BEFORE rank 0 is listening, and the time-out when rank 0 never shows up."""
+import ctypes as C
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+WORKER = textwrap.dedent("""
+    import ctypes as C, sys, time
+    sys.path.insert(0, %r)
+    from numpower_amd._lib import load
+    rank, world, endpoint, delay, timeout = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], float(sys.argv[4]), float(sys.argv[5])
+    lib = load()
+    time.sleep(delay)
+    buf = (C.c_ubyte * 128)(*([(7 * i + 3) %% 251 for i in range(128)] if rank == 0 else [0] * 128))
+    rc = lib.np_comm_debug_exchange(rank, world, endpoint.encode(), buf, timeout)
+    if rc != 0:
+        print("ERR", lib.np_last_error().decode()); sys.exit(3)
+    print("OK", bytes(buf).hex())
+""") % str(ROOT)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_world(world, endpoint, rank0_delay=0.0, skip_rank0=False, timeout=20.0):
+    procs = []
+    for r in range(world):
+        if r == 0 and skip_rank0:
+            continue
+        delay = rank0_delay if r == 0 else 0.0
+        procs.append((r, subprocess.Popen([sys.executable, "-c", WORKER, str(r), str(world), endpoint, str(delay), str(timeout)],
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    out = {}
+    for r, p in procs:
+        so, se = p.communicate(timeout=90)
+        out[r] = (p.returncode, so.strip(), se[-500:])
+    return out
+
+
+EXPECT = bytes((7 * i + 3) % 251 for i in range(128)).hex()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("form", ["tcp", "file"])
+def test_every_peer_receives_rank0s_bytes(world, form, tmp_path):
+    endpoint = "tcp://127.0.0.1:%d" % free_port() if form == "tcp" else str(tmp_path / "id")
+    out = run_world(world, endpoint, rank0_delay=0.6)          # peers are up first and have to retry / poll
+    for r in range(world):
+        rc, so, se = out[r]
+        assert rc == 0, (r, so, se)
+        assert so == "OK " + EXPECT, (r, so)
+
+
+def test_peers_time_out_when_rank0_never_comes():
+    out = run_world(2, "tcp://127.0.0.1:%d" % free_port(), skip_rank0=True, timeout=1.5)
+    rc, so, _ = out[1]
+    assert rc == 3 and "could not fetch the id" in so
+
+
+def test_rank0_times_out_when_a_peer_is_missing():
+    import time
+    from numpower_amd._lib import load
+    lib = load()
+    buf = (C.c_ubyte * 128)()
+    t0 = time.time()
+    rc = lib.np_comm_debug_exchange(0, 3, ("tcp://127.0.0.1:%d" % free_port()).encode(), buf, 1.5)
+    assert rc != 0 and b"peers fetched the id" in lib.np_last_error()
+    assert time.time() - t0 < 10
