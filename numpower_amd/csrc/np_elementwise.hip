@@ -1519,7 +1519,11 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         else                                                                                             \
             fused_chain_kernel<VEC_, U_, LIGHT_, uint64_t><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);    \
     } while (0)
-    const int fu = fu_env ? fu_env : (light ? 1 : 2);
+    // two float4 slots per lane for both interpreters: with the 8-instruction exp a wave's fixed cost (launch, kernarg
+    // and descriptor loads, one scalar branch per step) weighs more than its registers — exp(X) + row 0.161 -> 0.139-0.143
+    // ms, exp(a)*b+2 0.204-0.213 -> 0.197-0.203 (round 1, with the 14-instruction expf, one slot was ahead for the
+    // light interpreter; tools/fused_ab.py with FUSED_AB_BCAST=1, profiles/r02/fused_u_ab.log)
+    const int fu = fu_env ? fu_env : 2;
     if (!vec) {
         if (light) NP_FC(false, 2, true); else NP_FC(false, 2, false);
     } else if (fu == 1) {
@@ -1529,7 +1533,7 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     }
 #undef NP_FC
     NP_LAUNCH_CHECK("fused_chain_kernel");
-    if (sink >= 0) return np_reduce_all_dev(sink, (const float *)partials.ptr, reduce_blocks, result);
+    if (sink >= 0) return np::fold_partials(sink, (const float *)partials.ptr, reduce_blocks, result);
     return NP_OK;
 }
 

@@ -27,6 +27,8 @@ inline size_t capped_grid(size_t wanted, size_t cap) {
     if (wanted <= cap) return wanted < 1 ? 1 : wanted;
     return cap | 1;
 }
+// One-block fold of per-workgroup partials into one device float (np_reduce.hip); op = NP_SUM / PROD / MIN / MAX.
+int fold_partials(int op, const float *partials, size_t n, float *dev_out);
 // Copy kernel for large word-aligned device-to-device copies (np_elementwise.hip); bytes % 4 == 0.
 int device_copy(void *dst, const void *src, size_t bytes);
 

@@ -766,6 +766,29 @@ int launch_reduce_all(const float *in, size_t n, float *dev_out) {
     return NP_OK;
 }
 
+}  // namespace
+
+namespace np {
+// Fold `n` per-workgroup partials (a few thousand at most) into one device float with ONE one-block launch — what a
+// first pass that already reduced per workgroup needs behind it (np_reduce_all_dev on the partials would be a
+// first pass of its own plus this: two launches, ~10 us, for 16 KB).
+int fold_partials(int op, const float *partials, size_t n, float *dev_out) {
+    if (n > 0x7fffffffu) return np::fail(NP_ERR_INVALID, "fold_partials: too many partials");
+    hipStream_t s = np::stream();
+    switch (op) {
+        case NP_SUM: reduce_all_pass2<NP_SUM><<<1, 256, 0, s>>>(partials, (int)n, dev_out, 1.0f); break;
+        case NP_PROD: reduce_all_pass2<NP_PROD><<<1, 256, 0, s>>>(partials, (int)n, dev_out, 1.0f); break;
+        case NP_MIN: reduce_all_pass2<NP_MIN><<<1, 256, 0, s>>>(partials, (int)n, dev_out, 1.0f); break;
+        case NP_MAX: reduce_all_pass2<NP_MAX><<<1, 256, 0, s>>>(partials, (int)n, dev_out, 1.0f); break;
+        default: return np::fail(NP_ERR_INVALID, "fold_partials: unknown reduction %d", op);
+    }
+    NP_LAUNCH_CHECK("reduce_all_pass2");
+    return NP_OK;
+}
+}  // namespace np
+
+namespace {
+
 template <int OP>
 int dispatch_reduce_all(const float *in, size_t n, float *dev_out) {
     if (n < (size_t(1) << 31)) return launch_reduce_all<OP, uint32_t>(in, n, dev_out);

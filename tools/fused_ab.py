@@ -30,6 +30,11 @@ def one(chain):
         ops = [FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0), FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 1, n // 8 * 8),
                FusedOp(1, BINARY_OPS["add"], 2, 0, 0, 0, 0, 0)]
         nbytes = 12 * n
+    elif chain in ("exp_row", "exp_col"):     # exp(X) + r on 25000 x 4000 (BASELINE C3c in one pass): 8 B/elem
+        inputs = [bufs[0].ptr, bufs[1].ptr]
+        kinds = [0, 2 if chain == "exp_row" else 3]
+        ops = [FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0), FusedOp(1, BINARY_OPS["add"], 1, 0, 0, 0, 0, 0)]
+        nbytes = 8 * n
     elif chain in ("fma3", "fma3_sum"):       # a*b+c : 3 arrays in, 1 out
         inputs = [bufs[0].ptr, bufs[1].ptr, bufs[2].ptr]
         kinds = [0, 0, 0]
@@ -53,7 +58,8 @@ def one(chain):
         if reduce:
             _lib.check(lib.np_fused_chain_reduce(arr, k, len(inputs), o, len(ops), 0, 1, n, C.byref(res)))
         else:
-            _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, 1, n))
+            rows, cols = (25000, 4000) if chain in ("exp_row", "exp_col") else (1, n)
+            _lib.check(lib.np_fused_chain(arr, k, len(inputs), o, len(ops), bufs[3].ptr, rows, cols))
     for _ in range(5):
         launch()
     t.start()
@@ -71,6 +77,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         one(sys.argv[1])
     else:
+        if os.environ.get("FUSED_AB_BCAST"):
+            for rnd in range(2):
+                for chain in ("exp_row", "exp_col", "exp_mul_add"):
+                    for u in ("1", "2"):
+                        subprocess.run([sys.executable, __file__, chain], env=dict(os.environ, NP_FUSED_U=u), check=False)
+            sys.exit(0)
         if os.environ.get("FUSED_AB_REDUCE"):
             for chain in ("exp_mul_add_sum", "fma3_sum"):
                 for u in ("1", "2"):
