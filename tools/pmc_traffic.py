@@ -8,6 +8,7 @@ import collections, csv, json, sys
 KEYS = [  # bench key, substring(s) identifying the kernel
     ("sgemm_dma_kernel", ["sgemm_dma_kernel"]),
     ("add_1e8", ["binary_vec_kernel<0, 0, 0,"]),
+    ("pow_1e8", ["binary_vec_kernel<5, 0, 0,"]),
     ("exp_1e8", ["unary_vec_kernel<2,"]),
     ("log_1e8", ["unary_vec_kernel<5,"]),
     ("add_row_broadcast", ["binary_vec_kernel<0, 0, 2,"]),

@@ -16,6 +16,7 @@ D.sync()
 N = 100_000_000
 a = D.DeviceArray.from_host(synth.uniform((N,), 5)); b = D.DeviceArray.from_host(synth.uniform((N,), 6)); o = D.DeviceArray((N,))
 for _ in range(iters): D.binary("add", a, "full", b, "full", 1, N, out=o)
+for _ in range(iters): D.binary("pow", a, "full", b, "full", 1, N, out=o)
 for _ in range(iters): D.unary("exp", a, out=o)
 for _ in range(iters): D.unary("log", b, out=o)
 row = D.DeviceArray.from_host(synth.uniform((4000,), 9)); col = D.DeviceArray.from_host(synth.uniform((25000,), 10))
