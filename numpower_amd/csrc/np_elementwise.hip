@@ -1566,13 +1566,13 @@ int np_fused_chain_reduce(const float *const *inputs, const int *input_kinds, in
         return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: unknown reduction %d", reduce_op);
     if (rows * cols == 0) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: empty input");
     if (int rc = np::ensure_init()) return rc;
-    np::Scratch dev;
-    if (int rc = dev.alloc(sizeof(float))) return rc;
+    float *slot = np::result_slots();
+    if (!slot) return NP_ERR_ALLOC;
     const int sink = reduce_op == NP_MEAN ? NP_SUM : reduce_op;
-    if (int rc = fused_chain_impl(inputs, input_kinds, n_inputs, ops, n_ops, (float *)dev.ptr, rows, cols, sink))
+    if (int rc = fused_chain_impl(inputs, input_kinds, n_inputs, ops, n_ops, slot, rows, cols, sink))
         return rc;
-    float v = 0.0f;
-    if (int rc = np_memcpy_d2h(&v, dev.ptr, sizeof(float))) return rc;
+    if (int rc = np::result_wait()) return rc;
+    const float v = slot[0];
     *host_out = reduce_op == NP_MEAN ? v / (float)(rows * cols) : v;
     return NP_OK;
 }

@@ -19,6 +19,13 @@ hipStream_t stream();
 int ensure_init();
 // Device properties cached at init.
 int num_cus();
+// Host-result slots: 64 floats of pinned, device-visible host memory.  A reduction's last kernel writes its value
+// straight into a slot and the caller only waits for the stream (result_wait) and reads it — no 4-byte D2H copy call
+// behind every nd::sum() / allclose() / median() (that call alone is ~10 us of host + driver time).  One set per
+// process: host-result entry points are synchronous, so a slot is free again when the call returns.
+float *result_slots();   // nullptr + error set on failure
+int result_wait();       // = synchronise the library stream
+
 // Block count of a capped grid-stride kernel.  With `cap` a power of two (CUs x 8 ...) every lane's accesses
 // sit a power-of-two number of bytes apart — 2048 workgroups x 4 KiB = 8 MiB — and land on the same HBM channel:
 // the full sum of 1e8 floats ran 5.66 TB/s on 2048 workgroups and 6.39 on 2049 (profiles/r02/reduce_cap_ab_2.log).

@@ -994,10 +994,13 @@ int np_reduce_all_dev(int op, const float *in, size_t n, float *dev_out) {
 
 int np_reduce_all(int op, const float *in, size_t n, float *host_out) {
     if (!host_out) return np::fail(NP_ERR_INVALID, "np_reduce_all: null output");
-    np::Scratch out;
-    if (int rc = out.alloc(sizeof(float))) return rc;
-    if (int rc = np_reduce_all_dev(op, in, n, (float *)out.ptr)) return rc;
-    return np_memcpy_d2h(host_out, out.ptr, sizeof(float));
+    if (int rc = np::ensure_init()) return rc;
+    float *slot = np::result_slots();
+    if (!slot) return NP_ERR_ALLOC;
+    if (int rc = np_reduce_all_dev(op, in, n, slot)) return rc;
+    if (int rc = np::result_wait()) return rc;
+    *host_out = slot[0];
+    return NP_OK;
 }
 
 }  // extern "C" (the template below cannot have C linkage)
@@ -1229,22 +1232,27 @@ int np_moments(const float *in, size_t n, float *host_mean, float *host_m2) {
     float sum = 0.0f;
     if (int rc = np_reduce_all(NP_SUM, in, n, &sum)) return rc;
     const float mean = sum / (float)n;   // NDArray_Sum_Float(a) / NDArray_NUMELEMENTS(a), statistics.c:95,119
-    np::Scratch out;
-    if (int rc = out.alloc(sizeof(float))) return rc;
-    if (int rc = xform_sum<1>(in, nullptr, n, mean, 0.0f, (float *)out.ptr)) return rc;
+    float *slot = np::result_slots();
+    if (!slot) return NP_ERR_ALLOC;
+    if (int rc = xform_sum<1>(in, nullptr, n, mean, 0.0f, slot)) return rc;
+    if (int rc = np::result_wait()) return rc;
     *host_mean = mean;
-    return np_memcpy_d2h(host_m2, out.ptr, sizeof(float));
+    *host_m2 = slot[0];
+    return NP_OK;
 }
 
 int np_weighted_sums(const float *a, const float *w, size_t n, float *host_sum_aw, float *host_sum_w) {
     if (!host_sum_aw || !host_sum_w) return np::fail(NP_ERR_INVALID, "np_weighted_sums: null output");
     if (n == 0 || !a || !w) return np::fail(NP_ERR_INVALID, "np_weighted_sums: empty input");
     if (int rc = np::ensure_init()) return rc;
-    np::Scratch out;
-    if (int rc = out.alloc(sizeof(float))) return rc;
-    if (int rc = xform_sum<2>(a, w, n, 0.0f, 0.0f, (float *)out.ptr)) return rc;
-    if (int rc = np_memcpy_d2h(host_sum_aw, out.ptr, sizeof(float))) return rc;
-    return np_reduce_all(NP_SUM, w, n, host_sum_w);
+    float *slot = np::result_slots();
+    if (!slot) return NP_ERR_ALLOC;
+    if (int rc = xform_sum<2>(a, w, n, 0.0f, 0.0f, slot)) return rc;
+    if (int rc = np_reduce_all_dev(NP_SUM, w, n, slot + 1)) return rc;   // both values behind ONE wait
+    if (int rc = np::result_wait()) return rc;
+    *host_sum_aw = slot[0];
+    *host_sum_w = slot[1];
+    return NP_OK;
 }
 
 int np_count_mismatch(int mode, const float *a, const float *b, size_t n, float rtol, float atol,
@@ -1256,17 +1264,16 @@ int np_count_mismatch(int mode, const float *a, const float *b, size_t n, float 
     if (n == 0) return NP_OK;
     if (!a || !b) return np::fail(NP_ERR_INVALID, "np_count_mismatch: null input");
     if (int rc = np::ensure_init()) return rc;
-    np::Scratch out;
-    if (int rc = out.alloc(sizeof(float))) return rc;
+    float *slot = np::result_slots();
+    if (!slot) return NP_ERR_ALLOC;
     // a sum of 0/1 terms: inexact above 2^24 but zero exactly when every term is zero
     if (mode == NP_MISMATCH_EXACT) {
-        if (int rc = xform_sum<3>(a, b, n, 0.0f, 0.0f, (float *)out.ptr)) return rc;
+        if (int rc = xform_sum<3>(a, b, n, 0.0f, 0.0f, slot)) return rc;
     } else {
-        if (int rc = xform_sum<4>(a, b, n, rtol, atol, (float *)out.ptr)) return rc;
+        if (int rc = xform_sum<4>(a, b, n, rtol, atol, slot)) return rc;
     }
-    float v = 0.0f;
-    if (int rc = np_memcpy_d2h(&v, out.ptr, sizeof(float))) return rc;
-    *host_any = (v != 0.0f) ? 1 : 0;
+    if (int rc = np::result_wait()) return rc;
+    *host_any = (slot[0] != 0.0f) ? 1 : 0;
     return NP_OK;
 }
 
@@ -1282,9 +1289,10 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
     if (head > n) head = n;
     const size_t nvec = (n - head) / 4;
     const size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
-    np::Scratch partials, out;
+    np::Scratch partials;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
-    if (int rc = out.alloc(sizeof(float))) return rc;
+    float *slot = np::result_slots();
+    if (!slot) return NP_ERR_ALLOC;
     const uint32_t body_end = (uint32_t)np_avx_body_end(n);
     if (flags & NP_QUIRK_AVX_BODY)
         all_pass1<true, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n,
@@ -1293,11 +1301,10 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
         all_pass1<false, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n,
                                                                     (uint32_t)head, (uint32_t)nvec, 0u);
     NP_LAUNCH_CHECK("all_pass1");
-    reduce_all_pass2<NP_MIN><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, (float *)out.ptr, 1.0f);
+    reduce_all_pass2<NP_MIN><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, slot, 1.0f);
     NP_LAUNCH_CHECK("reduce_all_pass2");
-    float v = 0.0f;
-    if (int rc = np_memcpy_d2h(&v, out.ptr, sizeof(float))) return rc;
-    *host_out = (v != 0.0f) ? 1 : 0;
+    if (int rc = np::result_wait()) return rc;
+    *host_out = (slot[0] != 0.0f) ? 1 : 0;
     return NP_OK;
 }
 

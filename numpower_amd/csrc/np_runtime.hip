@@ -37,6 +37,7 @@ struct Runtime {
     struct Block { size_t size; int device; unsigned stagger; };
     std::unordered_map<void *, Block> live;              // ptr -> rounded size, owning device, offset from the hipMalloc base
     unsigned large_seq = 0;                              // running count of large blocks obtained from the driver
+    float *slots = nullptr;                              // pinned host-result slots (np::result_slots)
     size_t reserved = 0;                                 // bytes held (live + cached)
     long live_count = 0;
 };
@@ -111,6 +112,26 @@ int ensure_init() {
         return np_init(cur);
     }
     if (hipGetDevice(&cur) == hipSuccess && cur != r.device) NP_HIP_CHECK(hipSetDevice(r.device));
+    return NP_OK;
+}
+
+float *result_slots() {
+    Runtime &r = rt();
+    if (!r.slots) {
+        void *p = nullptr;
+        const hipError_t e = hipHostMalloc(&p, 64 * sizeof(float), hipHostMallocMapped);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            fail(NP_ERR_ALLOC, "pinned result slots: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+        r.slots = (float *)p;
+    }
+    return r.slots;
+}
+
+int result_wait() {
+    NP_HIP_CHECK(hipStreamSynchronize(rt().cur_stream));
     return NP_OK;
 }
 

@@ -239,10 +239,14 @@ int np_order_stat_dev(const float *in, size_t n, size_t k, float *dev_out2) {
 
 int np_order_stat(const float *in, size_t n, size_t k, float *host_out2) {
     if (!host_out2) return np::fail(NP_ERR_INVALID, "np_order_stat: null output");
-    np::Scratch out;
-    if (int rc = out.alloc(2 * sizeof(float))) return rc;
-    if (int rc = np_order_stat_dev(in, n, k, (float *)out.ptr)) return rc;
-    return np_memcpy_d2h(host_out2, out.ptr, 2 * sizeof(float));
+    if (int rc = np::ensure_init()) return rc;
+    float *slot = np::result_slots();
+    if (!slot) return NP_ERR_ALLOC;
+    if (int rc = np_order_stat_dev(in, n, k, slot)) return rc;
+    if (int rc = np::result_wait()) return rc;
+    host_out2[0] = slot[0];
+    host_out2[1] = slot[1];
+    return NP_OK;
 }
 
 }  // extern "C"
