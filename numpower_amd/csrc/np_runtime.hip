@@ -119,7 +119,7 @@ float *result_slots() {
     Runtime &r = rt();
     if (!r.slots) {
         void *p = nullptr;
-        const hipError_t e = hipHostMalloc(&p, 64 * sizeof(float), hipHostMallocMapped);
+        const hipError_t e = hipHostMalloc(&p, 64 * sizeof(float), hipHostMallocMapped | hipHostMallocPortable);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             fail(NP_ERR_ALLOC, "pinned result slots: %s", hipGetErrorString(e));
