@@ -114,7 +114,25 @@ template<int U,int T> void run_span(unsigned stagger){
   bench(name, bytes, [&]{ k_span<U,T><<<grid,T,0,st_>>>((v4f*)A,(v4f*)B,(v4f*)O,nvec,span); });
 }
 __global__ void k_check(const float* a, const float* b, const float* o, size_t n, unsigned* bad){ size_t i = blockIdx.x*(size_t)blockDim.x+threadIdx.x; size_t st=(size_t)gridDim.x*blockDim.x; for(; i<n; i+=st) if(o[i]!=a[i]+b[i]) atomicAdd(bad,1u); }
-int main(int argc, char** argv){ if(argc>1 && argv[1][0]=='l'){
+int main(int argc, char** argv){ if(argc>1 && argv[1][0]=='s'){
+  // ./add_bw slab : the three operands carved out of ONE hipMalloc at chosen distances (is the run-to-run spread of
+  // separately allocated buffers physical placement?  does a fixed relative layout remove it?)
+  size_t n=100000000; nvec=n/4; CK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  const size_t MiB = 1u<<20; char* slab; CK(hipMalloc(&slab, (size_t)1600*MiB)); CK(hipMalloc(&S,4));
+  printf("slab=%p\n", slab);
+  const size_t base_sp = 384*MiB;   // 400,000,000 B rounded up to 2 MiB
+  size_t spacings[] = {base_sp, base_sp+1024, base_sp+4096, base_sp+65536, base_sp+2*MiB, base_sp+2*MiB+1024, base_sp+8*MiB, base_sp+8*MiB+1024, base_sp+32*MiB+1024, 400*MiB+1024, 448*MiB+1024, 512*MiB, 512*MiB+1024};
+  for(int rep=0; rep<2; ++rep) for(size_t sp: spacings){
+    for(int order=0; order<2; ++order){
+      A=(float*)(slab + (order? 2*sp:0)); B=(float*)(slab+sp); O=(float*)(slab + (order? 0:2*sp));
+      if(rep==0 && order==0){ k_rand<<<2048,256,0,st_>>>((float*)slab,(size_t)1600*MiB/4,1); CK(hipStreamSynchronize(st_)); }
+      char name[128]; snprintf(name,128,"slab spacing %4zu MiB + %6zu B  %s", sp/MiB, sp%MiB, order? "o<b<a":"a<b<o");
+      double bytes = 12.0*nvec*4; size_t need=((size_t)nvec+511)/512; unsigned grid=need|1;
+      bench(name, bytes, [&]{ k_grid<2,true,true,0,256><<<grid,256,0,st_>>>((v4f*)A,(v4f*)B,(v4f*)O,nvec,S); });
+    }
+  }
+  return 0; }
+  if(argc>1 && argv[1][0]=='l'){
   // ./add_bw lds : LDS-DMA read side vs the library's structure (grid U2 T256 nt/nt, uncapped), random data
   size_t n=100000000; nvec=n/4; CK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   CK(hipMalloc(&A,n*4)); CK(hipMalloc(&B,n*4)); CK(hipMalloc(&O,n*4)); CK(hipMalloc(&S,4));

@@ -86,7 +86,7 @@ if __name__ == "__main__":
         if os.environ.get("FUSED_AB_REDUCE"):
             for chain in ("exp_mul_add_sum", "fma3_sum"):
                 for u in ("1", "2"):
-                    for rbpc in ("4", "8", "16", "32", "64"):
+                    for rbpc in os.environ.get("FUSED_AB_RBPCS", "4,8,16,32,64").split(","):
                         env = dict(os.environ, NP_FUSED_U=u, NP_FUSED_RBPC=rbpc)
                         subprocess.run([sys.executable, __file__, chain], env=env, check=False)
             sys.exit(0)
