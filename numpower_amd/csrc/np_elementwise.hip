@@ -1060,12 +1060,15 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
                 col[u] = first[u] - row[u] * cols;
             }
         }
-        float x0[N], acc[N], nxt[N];
+        // the chain value starts as input 0 and lives in acc from the first load on: input 0 is not kept in a second
+        // set of registers for the rare step that names it again (x * x ...) — that step re-reads it (an L2 hit), and
+        // every other chain saves N registers and N moves per trip
+        float acc[N], nxt[N];
         if (in0) {
-            fused_fetch<U, G, I>(x0, in0, FUSED_IDX_FULL, first, row, col, live);
+            fused_fetch<U, G, I>(acc, in0, FUSED_IDX_FULL, first, row, col, live);
         } else {
 #pragma unroll
-            for (int e = 0; e < N; ++e) x0[e] = scalar0;
+            for (int e = 0; e < N; ++e) acc[e] = scalar0;
         }
         if (first_prefetch) {
             fused_fetch<U, G, I>(nxt, first_prefetch, first_prefetch_idx, first, row, col, live);
@@ -1073,8 +1076,6 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
 #pragma unroll
             for (int e = 0; e < N; ++e) nxt[e] = 0.0f;
         }
-#pragma unroll
-        for (int e = 0; e < N; ++e) acc[e] = x0[e];
         for (int k = 0; k < n_ops; ++k) {
             struct {
                 int kind, op, swap, quirk, src_kind, prefetch_idx;
@@ -1096,8 +1097,12 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
 #pragma unroll
                 for (int e = 0; e < N; ++e) oth[e] = nxt[e];
             } else if (o.src_kind == FUSED_SRC_INPUT0) {
+                if (in0) {
+                    fused_fetch<U, G, I>(oth, in0, FUSED_IDX_FULL, first, row, col, live);
+                } else {
 #pragma unroll
-                for (int e = 0; e < N; ++e) oth[e] = x0[e];
+                    for (int e = 0; e < N; ++e) oth[e] = scalar0;
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < N; ++e) oth[e] = o.scalar;
