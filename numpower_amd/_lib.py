@@ -129,6 +129,8 @@ def lib_path() -> Path:
     import os
     if os.environ.get("NP_HIP_USE_TUNING_BUILD") == "1":
         return LIBDIR / "libnp_hip_tuning.so"
+    if os.environ.get("NP_HIP_LIB"):            # dev A/B of two builds on one box (tools/ only)
+        return Path(os.environ["NP_HIP_LIB"])
     return LIBDIR / "libnp_hip.so"
 
 
