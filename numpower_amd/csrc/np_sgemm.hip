@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
                 const unsigned row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const unsigned col = n0 + wn0 + j * 32 + li;
                 if (!EDGE || (row < g.M && col < (g.n_store ? g.n_store : g.N)))
-                    C[(size_t)row * g.ldc + col] = acc[i][j][r];
+                    __builtin_nontemporal_store(acc[i][j][r], &C[(size_t)row * g.ldc + col]);   // C is never re-read here
             }
     probe_end(g, probe_c0, probe_w0);
 }
