@@ -380,6 +380,8 @@ int np_comm_debug_exchange(int rank, int world, const char *endpoint, void *byte
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);
 int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128 */
+int np_select_set_variant(int variant);   /* order statistics: 0 = no bracket path, 1 = default (n >= 2^23), else the smallest n that takes it */
+int np_select_last_path(int *path);       /* tests / tools: 1 if the last selection ran over the bracket's copied keys, 0 if over the array (synchronises) */
 int np_reduce_set_variant(int variant);   /* streaming reductions, first pass: workgroups per CU (0 = default) */
 
 #ifdef __cplusplus

@@ -113,6 +113,8 @@ PROTOTYPES = {
     "np_elementwise_set_variant": (C.c_int, [C.c_int]),
     "np_layout_set_variant": (C.c_int, [C.c_int]),
     "np_reduce_set_variant": (C.c_int, [C.c_int]),
+    "np_select_set_variant": (C.c_int, [C.c_int]),
+    "np_select_last_path": (C.c_int, [C.POINTER(C.c_int)]),
 }
 
 

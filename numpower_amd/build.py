@@ -142,6 +142,23 @@ def build_host(force: bool = False, verbose: bool = False) -> Path:
     return lib
 
 
+def build_method_bodies(force: bool = False, verbose: bool = False) -> Path:
+    """ext/method_bodies.c -> numpower_amd/lib/method_bodies: the device branch of the reference's
+    PHP_METHODs as a C99 program over numpower_host.h + hip_math.h (-Wall -Wextra -Werror: a
+    signature that drifts from the reference's call sites fails here)."""
+    exe = LIBDIR / "method_bodies"
+    src = EXT / "method_bodies.c"
+    deps = [src, LIBDIR / "libnumpower_host.so"] + list(INCLUDE.glob("*.h")) + list(EXT.glob("*.h"))
+    if force or _newer(exe, deps):
+        if verbose:
+            print("[build] compiling ext/method_bodies.c", flush=True)
+        cc = shutil.which("gcc") or "gcc"
+        flags = [f for f in EXT_CFLAGS if f != "-fPIC"]
+        _run([cc, *flags, str(src), "-o", str(exe), f"-L{LIBDIR}", "-lnumpower_host", "-lnp_hip",
+              "-Wl,-rpath,$ORIGIN"])
+    return exe
+
+
 def build_oracle(force: bool = False, verbose: bool = False) -> Path:
     """Compile oracle/'s C restatement (test infrastructure; never loaded by the product)."""
     odir = ROOT / "oracle"
@@ -166,6 +183,7 @@ def build_all(force: bool = False, verbose: bool = False):
     hip = build_hip(force, verbose)
     host = build_host(force, verbose)
     build_ext_glue(force, verbose)
+    build_method_bodies(force, verbose)
     oracle = build_oracle(force, verbose)
     return hip, host, oracle
 

@@ -120,3 +120,90 @@ def test_quantile_errors(hip):
     with pytest.raises(Error, match="Q must be a scalar"):
         NDArray.quantile(g, [0.5, 0.6])
     assert NDArray.quantile(g, 0.5) == 2.0 and NDArray.median(g) == 2.0
+
+
+@pytest.fixture
+def bracket_everywhere():
+    """Send every array of >= 2048 elements down the bracket path (sample -> bracket -> filter -> verdict),
+    which by default only arrays of >= 2^23 elements take."""
+    from numpower_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.np_select_set_variant(2048))
+    yield lib
+    _lib.check(lib.np_select_set_variant(1))
+
+
+def _path():
+    from numpower_amd import _lib
+    path = C.c_int(-1)
+    _lib.check(_lib.load().np_select_last_path(C.byref(path)))
+    return path.value
+
+
+def test_bracket_is_refused_or_dropped_when_it_cannot_help(hip, bracket_everywhere):
+    n = 1_500_000
+    relu = np.maximum(synth.uniform((n,), 95, -1.0, 1.0), np.float32(0.0))
+    want = np.sort(_keys(relu))
+    got = _order_stat(relu, n // 4)                     # inside the 50 % of zeros: no bracket can be tighter
+    assert got.view(np.uint32).tolist() == _from_keys([want[n // 4], want[n // 4 + 1]]).view(np.uint32).tolist()
+    assert _path() == 0
+    got = _order_stat(relu, n * 9 // 10)                # among the positive half: bracketed
+    assert got.view(np.uint32).tolist() == _from_keys([want[n * 9 // 10], want[n * 9 // 10 + 1]]).view(np.uint32).tolist()
+    assert _path() == 1
+
+
+def _bracket_cases():
+    for name, x in _cases():
+        if x.size >= 2048:
+            yield name, x
+    n = 1_500_000
+    u = synth.uniform((n,), 91, 0.0, 1.0)
+    yield "normalish", (synth.uniform((n,), 92, -1.0, 1.0) + synth.uniform((n,), 93, -1.0, 1.0) + u).astype(np.float32)
+    # the sample lies: 1024 evenly spaced runs of 1024 floats see only the planted value
+    lying = synth.uniform((n,), 94, 0.0, 1.0)
+    nvec = n // 4
+    for b in range(1024):
+        start = (b * (nvec - 256) // 1023) * 4
+        lying[start:start + 1024] = np.float32(1000.0)
+    yield "sample_lies", lying
+    yield "half_zero", np.maximum(synth.uniform((n,), 95, -1.0, 1.0), np.float32(0.0))       # a ReLU output: the bracket is refused
+    yield "two_clusters", np.where(u < 0.5, np.float32(1e-3), np.float32(1e3)) * synth.uniform((n,), 96, 1.0, 1.001)
+    with_nan = synth.uniform((n,), 97, -4.0, 4.0)
+    with_nan[::1001] = np.nan
+    with_nan[5::2003] = -np.nan
+    yield "with_nan", with_nan
+
+
+@pytest.mark.parametrize("name,x", list(_bracket_cases()), ids=[c[0] for c in _bracket_cases()])
+def test_order_stat_bracket_path_matches_a_sort(name, x, hip, bracket_everywhere):
+    x = np.ascontiguousarray(x, np.float32)
+    n = x.size
+    want = np.sort(_keys(x))
+    ranks = sorted({0, 1, n - 1, n - 2, n // 2, n // 2 - 1, n // 3, (7 * n) // 8, n // 1000, n - n // 1000})
+    # ranks whose successor sits in another top-level bin (where the bracket ends, if it ends there)
+    top = want >> 21
+    edges = np.flatnonzero(top[1:] != top[:-1])
+    ranks = sorted(set(ranks) | {int(e) for e in edges[:3]} | {int(e) + 1 for e in edges[:3]} | {int(e) for e in edges[-2:]})
+    for k in ranks:
+        got = _order_stat(x, k)
+        exp = _from_keys([want[k], want[min(k + 1, n - 1)]])
+        assert got.view(np.uint32).tolist() == exp.view(np.uint32).tolist(), (name, k)
+
+
+def test_bracket_path_is_taken_and_agrees_with_the_plain_passes(hip):
+    """2.5 * 10^7 elements (default threshold 2^23): same answers with the path on and off, for every decile."""
+    from numpower_amd import _lib
+    lib = _lib.load()
+    x = (synth.uniform((25_000_000,), 98, -1.0, 1.0) * np.exp(synth.uniform((25_000_000,), 99, -3.0, 3.0))).astype(np.float32)
+    want = np.sort(_keys(x))
+    for k in [0, x.size - 1] + [x.size * d // 10 for d in range(1, 10)]:
+        exp = _from_keys([want[k], want[min(k + 1, x.size - 1)]]).view(np.uint32).tolist()
+        _lib.check(lib.np_select_set_variant(0))
+        plain = _order_stat(x, k)
+        _lib.check(lib.np_select_set_variant(1))
+        fast = _order_stat(x, k)
+        path = C.c_int(-1)
+        _lib.check(lib.np_select_last_path(C.byref(path)))
+        assert plain.view(np.uint32).tolist() == exp, k
+        assert fast.view(np.uint32).tolist() == exp, k
+        assert path.value == 1, "rank %d fell back to the plain passes" % k
