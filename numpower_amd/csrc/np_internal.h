@@ -78,6 +78,37 @@ __device__ __forceinline__ float wave_reduce(float v) {
     return v;   // lane 0 holds the wave's result
 }
 
+// ---- handing a workgroup's result to the LAST workgroup of the same kernel ----
+// A second, one-workgroup kernel behind a streaming pass costs 4-5 us however little it folds.  Instead every workgroup
+// stores its partial, takes a ticket, and the one that draws the last ticket folds them all.  Everything that crosses
+// workgroups travels by device-scope atomics (store, RMW, load): these are performed at the memory side, past the
+// eight XCD L2s, which are not coherent with each other.  A wave takes its ticket only after its own stores have been
+// acknowledged (s_waitcnt 0).  Device-scope FENCES are deliberately not used: each writes back / invalidates an L2,
+// and a thousand workgroups doing that tripled the time of the streaming pass they ended (np_select.hip: 73 -> 240 us).
+// Worth it only where the step replaced is more than a fold: the ticket is one address, ~20 ns per workgroup at the
+// memory side, and every workgroup waits a round trip for its own before it retires.  The full reductions, with 2049
+// workgroups and a second kernel that only adds up 2049 floats, lost 5 us to it (sum of 10^8: 63 -> 68 us) and keep
+// their one-workgroup second kernel; the selection passes (np_select.hip), whose second step walks a histogram, use it.
+template <typename T>
+__device__ __forceinline__ T coherent_load(const T *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void coherent_store(T *p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// true in every thread of the last of `participants` workgroups to get here (all threads of a workgroup must call it)
+__device__ __forceinline__ bool last_workgroup_done(unsigned *ticket, unsigned participants) {
+    __shared__ unsigned s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == participants - 1 ? 1u : 0u;
+    __syncthreads();
+    return s_last != 0;
+}
+
 // Workgroup reduce of one value per thread (256 threads = 4 waves).  Result valid in thread 0.
 template <int OP>
 __device__ __forceinline__ float block_reduce(float v, float *lds4) {
