@@ -157,6 +157,53 @@ def test_fuzz_order_statistics(hip, oracle):
         assert np.float32(nd.quantile(g, q)).view(np.uint32) == oracle.quantile(x, q).view(np.uint32), (n, style, q)
 
 
+def test_fuzz_order_statistics_bracket_path(hip):
+    """np_order_stat with the bracket path forced on every array >= 2048 elements: random length, rank and
+    distribution (incl. ones whose bracket is refused or missed), against a sort of the keys."""
+    import ctypes as C
+    from numpower_amd import _lib
+    from tests.test_gpu_order_stats import _from_keys, _keys
+    lib = _lib.load()
+    rng = np.random.default_rng(23 + SEED)
+    _lib.check(lib.np_select_set_variant(2048))
+    try:
+        taken = 0
+        for case in range(CASES):
+            n = int(rng.integers(2048, 3_000_000))
+            u = synth.uniform((n,), 9000 + case + 100_000 * SEED, 0.0, 1.0)
+            style = case % 6
+            if style == 0:
+                x = u
+            elif style == 1:      # many binades, both signs
+                x = ((u - np.float32(0.5)) * np.exp(synth.uniform((n,), 9500 + case, -30.0, 30.0))).astype(np.float32)
+            elif style == 2:      # a big lump of one value among random ones
+                x = np.where(u < rng.uniform(0.05, 0.6), np.float32(rng.uniform(-1, 1)), u - np.float32(0.5)).astype(np.float32)
+            elif style == 3:      # sorted / reversed
+                x = np.sort(u)[::(1 if case % 12 < 6 else -1)].copy()
+            elif style == 4:      # few distinct values
+                x = np.rint(u * np.float32(rng.integers(2, 200))).astype(np.float32)
+            else:                 # one binade, dense keys
+                x = (u * np.float32(1e-3) + np.float32(rng.uniform(0.5, 4.0))).astype(np.float32)
+            x = np.ascontiguousarray(x, np.float32)
+            want = np.sort(_keys(x))
+            buf = _lib.DeviceBuffer(4 * n)
+            _lib.check(lib.np_memcpy_h2d(buf.ptr, x.ctypes.data, 4 * n))
+            out = (C.c_float * 2)()
+            ranks = {0, n - 1, int(rng.integers(0, n)), int(rng.integers(0, n)), int(rng.integers(0, min(n, 5000))),
+                     n - 1 - int(rng.integers(0, min(n, 5000)))}
+            for k in sorted(ranks):
+                _lib.check(lib.np_order_stat(buf.ptr, n, k, out))
+                exp = _from_keys([want[k], want[min(k + 1, n - 1)]]).view(np.uint32).tolist()
+                assert np.float32([out[0], out[1]]).view(np.uint32).tolist() == exp, (case, style, n, k)
+                path = C.c_int(-1)
+                _lib.check(lib.np_select_last_path(C.byref(path)))
+                taken += path.value
+            buf.free()
+        assert taken > 0          # the sweep did exercise the copied-keys passes, not only the fallback
+    finally:
+        _lib.check(lib.np_select_set_variant(1))
+
+
 def test_fuzz_fused_chains(hip):
     """Random linear chains (<= 10 steps, row / column / 0-d / python-scalar operands on either side)
     through the one-kernel interpreter vs the same ops issued one by one: bit-identical."""
