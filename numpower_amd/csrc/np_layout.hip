@@ -27,15 +27,19 @@ struct __attribute__((packed, aligned(4))) U4 { v4f v; };
 // in: [batch][rows][cols] -> out: [batch][cols][rows].  TILE x TILE floats per workgroup; the LDS
 // tile is padded to TILE+1 floats per row.  Global reads and writes are float4 per lane along
 // rows: TILE*4 contiguous bytes per row segment on both sides (256 B at TILE 64, 512 B at 128).
-template <int TILE, bool VEC>
+template <int TR, int TC, bool VEC>
 __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__restrict__ in,
                                                              float *__restrict__ out, unsigned rows,
                                                              unsigned cols, unsigned tiles_x,
                                                              unsigned tiles_y) {
-    constexpr int LDT = TILE + 1;
-    constexpr int C4 = TILE / 4;     // float4 columns per tile row
-    constexpr int RPP = 256 / C4;    // tile rows covered per pass of the 256 threads
-    constexpr int PASSES = TILE / RPP;
+    // a TR x TC tile of the input (TR rows, TC columns) becomes a TC x TR tile of the output
+    constexpr int LDT = TR + 1;           // tile[c][r]
+    constexpr int C4 = TC / 4;            // float4 columns per input tile row
+    constexpr int RPP = 256 / C4;         // input tile rows covered per pass of the 256 threads
+    constexpr int PASSES = TR / RPP;
+    constexpr int OC4 = TR / 4;           // float4 columns per output tile row
+    constexpr int ORPP = 256 / OC4;
+    constexpr int OPASSES = TC / ORPP;
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const size_t plane = (size_t)rows * cols;
     const float *src = in + (size_t)blockIdx.z * plane;
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
     // (the grid is linear in x: a 10^7 x 3 matrix has more tile rows than gridDim.y allows)
     const unsigned bx = blockIdx.x % tiles_x;
     const unsigned by = (blockIdx.x / tiles_x + bx) % tiles_y;
-    const unsigned r0 = by * TILE, c0 = bx * TILE;
+    const unsigned r0 = by * TR, c0 = bx * TC;
     const unsigned tx4 = threadIdx.x % C4, ty = threadIdx.x / C4;
 
     // load: rows of the input tile; all PASSES loads are issued before the first LDS store
@@ -71,13 +75,14 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
         for (int k = 0; k < 4; ++k) tile[(4 * tx4 + k) * LDT + ty + RPP * j] = v[j][k];
     __syncthreads();
     // store: rows of the output tile (= columns of the input tile)
+    const unsigned otx4 = threadIdx.x % OC4, oty = threadIdx.x / OC4;
 #pragma unroll
-    for (int j = 0; j < PASSES; ++j) {
-        const unsigned oc = ty + RPP * j;   // output row inside the tile (input column)
-        const unsigned orow = c0 + oc, ocol = r0 + 4 * tx4;
+    for (int j = 0; j < OPASSES; ++j) {
+        const unsigned oc = oty + ORPP * j;   // output row inside the tile (input column)
+        const unsigned orow = c0 + oc, ocol = r0 + 4 * otx4;
         v4f w;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = tile[oc * LDT + 4 * tx4 + k];
+        for (int k = 0; k < 4; ++k) w[k] = tile[oc * LDT + 4 * otx4 + k];
         if constexpr (VEC) {
             if (orow < cols && ocol < rows) __builtin_nontemporal_store(w, (v4f *)(dst + (size_t)orow * rows + ocol));
         } else if (orow < cols && ocol + 3 < rows) {
@@ -275,18 +280,28 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 int g_tile = 0;   // 0 = default, else 64 / 128 (np_layout_set_variant)
 
-template <int TILE>
+template <int TR, int TC>
 int launch_transpose(const float *in, float *out, size_t batch, size_t rows, size_t cols, bool vec) {
-    const size_t tiles_x = (cols + TILE - 1) / TILE, tiles_y = (rows + TILE - 1) / TILE;
+    const size_t tiles_x = (cols + TC - 1) / TC, tiles_y = (rows + TR - 1) / TR;
     if (tiles_x * tiles_y > 0x7fffffffu) return np::fail(NP_ERR_INVALID, "np_transpose2d: too many tiles");
     const dim3 grid((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch);
-    const size_t lds = (size_t)TILE * (TILE + 1) * sizeof(float);
+    constexpr size_t lds = (size_t)TC * (TR + 1) * sizeof(float);
+    if (lds > 64 * 1024) {   // above the 64 KB default limit of dynamic LDS
+        static bool attr_set = false;
+        if (!attr_set) {
+            NP_HIP_CHECK(hipFuncSetAttribute((const void *)transpose_tile_kernel<TR, TC, true>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            NP_HIP_CHECK(hipFuncSetAttribute((const void *)transpose_tile_kernel<TR, TC, false>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+    }
     if (vec)
-        transpose_tile_kernel<TILE, true><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols,
-                                                                           (unsigned)tiles_x, (unsigned)tiles_y);
+        transpose_tile_kernel<TR, TC, true><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols,
+                                                                             (unsigned)tiles_x, (unsigned)tiles_y);
     else
-        transpose_tile_kernel<TILE, false><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols,
-                                                                            (unsigned)tiles_x, (unsigned)tiles_y);
+        transpose_tile_kernel<TR, TC, false><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols,
+                                                                              (unsigned)tiles_x, (unsigned)tiles_y);
     NP_LAUNCH_CHECK("transpose_tile_kernel");
     return NP_OK;
 }
@@ -347,18 +362,12 @@ int np_transpose2d(const float *in, float *out, size_t batch, size_t rows, size_
     int tile = g_tile;
     if (tile == 0)
         tile = (((rows + 127) / 128) * ((cols + 127) / 128) * batch >= (size_t)np::num_cus() * 4) ? 128 : 64;
-    if (tile == 128) {
-        static bool attr_set = false;
-        if (!attr_set) {   // 66 KB of dynamic LDS is above the 64 KB default limit
-            NP_HIP_CHECK(hipFuncSetAttribute((const void *)transpose_tile_kernel<128, true>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 4));
-            NP_HIP_CHECK(hipFuncSetAttribute((const void *)transpose_tile_kernel<128, false>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 4));
-            attr_set = true;
-        }
-        return launch_transpose<128>(in, out, batch, rows, cols, vec);
-    }
-    return launch_transpose<64>(in, out, batch, rows, cols, vec);
+    // Rectangular tiles (the kernel takes any TR x TC) were measured in round 2 — 256x64, 64x256, 128x64, 64x128, 256x32,
+    // 32x256 (profiles/r02/transpose_rect_ab.log): none beats 128 x 128.  What counts is the length of the READ
+    // segments (64x256: 1 KiB reads, 256 B writes = 128x128's 5.74 TB/s at 65536 x 4096; 256x64: 256 B reads, 1 KiB
+    // writes = 5.16), so only the two square tiles are instantiated.
+    if (tile == 128) return launch_transpose<128, 128>(in, out, batch, rows, cols, vec);
+    return launch_transpose<64, 64>(in, out, batch, rows, cols, vec);
 }
 
 int np_permute(const float *in, float *out, int ndim, const int *host_shape, const int *host_perm) {
