@@ -377,10 +377,11 @@ int np_comm_debug_exchange(int rank, int world, const char *endpoint, void *byte
 
 /* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 = whole-K plans only,
  * -2 = default planner again, -3 = default planner + always pad unaligned operands). */
+int np_runtime_set_variant(int variant);   /* how host-result calls wait: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag (default) */
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);
 int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128 */
-int np_select_set_variant(int variant);   /* order statistics: 0 = no bracket path, 1 = default (n >= 2^23), else the smallest n that takes it */
+int np_select_set_variant(int variant);   /* order statistics: 0 = no bracket path, 1 = default (n >= 2^26), else the smallest n that takes it */
 int np_select_last_path(int *path);       /* tests / tools: 1 if the last selection ran over the bracket's copied keys, 0 if over the array (synchronises) */
 int np_reduce_set_variant(int variant);   /* streaming reductions, first pass: workgroups per CU (0 = default) */
 

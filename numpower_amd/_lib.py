@@ -114,6 +114,7 @@ PROTOTYPES = {
     "np_layout_set_variant": (C.c_int, [C.c_int]),
     "np_reduce_set_variant": (C.c_int, [C.c_int]),
     "np_select_set_variant": (C.c_int, [C.c_int]),
+    "np_runtime_set_variant": (C.c_int, [C.c_int]),
     "np_select_last_path": (C.c_int, [C.POINTER(C.c_int)]),
 }
 

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -38,6 +39,8 @@ struct Runtime {
     std::unordered_map<void *, Block> live;              // ptr -> rounded size, owning device, offset from the hipMalloc base
     unsigned large_seq = 0;                              // running count of large blocks obtained from the driver
     float *slots = nullptr;                              // pinned host-result slots (np::result_slots)
+    int wait_mode = 1;                                   // np_runtime_set_variant: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag
+    uint32_t wait_seq = 0;
     size_t reserved = 0;                                 // bytes held (live + cached)
     long live_count = 0;
 };
@@ -130,8 +133,31 @@ float *result_slots() {
     return r.slots;
 }
 
+// Waiting for a host result.  hipStreamSynchronize costs 10-20 us of driver time per call on top of the kernels — as
+// much as a reduction over a million floats takes.  Instead the command processor is asked to write a sequence
+// number into the last of the pinned slots once the stream gets there (hipStreamWriteValue32: no kernel launch) and
+// the host spins on it; the result itself was written by the last kernel, which has completed (and released its
+// system-scope writes) before the stream reaches the flag write.  A wait that lasts longer than 2 ms, or a runtime that
+// refuses the stream operation, goes to hipStreamSynchronize.
 int result_wait() {
-    NP_HIP_CHECK(hipStreamSynchronize(rt().cur_stream));
+    Runtime &r = rt();
+    if (r.wait_mode == 1 && r.slots) {
+        volatile uint32_t *flag = (volatile uint32_t *)(r.slots + 63);
+        const uint32_t want = ++r.wait_seq;
+        const hipError_t e = hipStreamWriteValue32(r.cur_stream, (void *)flag, want, 0);
+        if (e == hipSuccess) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0;; ++spins) {
+                if (*flag == want) return NP_OK;
+                __builtin_ia32_pause();
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+            }
+        } else {
+            (void)hipGetLastError();
+            r.wait_mode = 0;   // not supported here: never try again
+        }
+    }
+    NP_HIP_CHECK(hipStreamSynchronize(r.cur_stream));
     return NP_OK;
 }
 
@@ -189,6 +215,12 @@ int np_init(int device) {
 }
 
 int np_set_device(int device) { return np_init(device); }
+
+int np_runtime_set_variant(int variant) {
+    if (variant != 0 && variant != 1) return np::fail(NP_ERR_INVALID, "np_runtime_set_variant: 0 = wait with hipStreamSynchronize, 1 = spin on a stream-written flag (default)");
+    rt().wait_mode = variant;
+    return NP_OK;
+}
 
 int np_sync(void) {
     if (int rc = np::ensure_init()) return rc;

@@ -18,7 +18,8 @@
 // level where the two ranks part, which the following pass finds with one compare + min per element
 // (or names directly, at the last level).  12 B/elem of HBM reads in total; no sort, no copy.
 //
-// Large arrays (>= 2^23 elements) take a shortcut first, the "bracket" path: the 11-bit histogram of an
+// Large arrays (>= 2^26 elements: the path's seven launches cost ~125 us before the first byte, against ~35 us + 12 B/elem
+// for the plain passes — measured crossover 5-6 * 10^7, profiles/r02/select_threshold.log) take a shortcut first, the "bracket" path: the 11-bit histogram of an
 // evenly spaced 2^20-element SAMPLE (1024 runs of 4 KiB), taken at two levels (22 key bits), names the
 // narrow key range that can hold rank k (the sample ranks k*m/n -+ 4096, eight standard deviations of a
 // binomial rank: about 1 % of the data); ONE pass over
@@ -580,7 +581,7 @@ __global__ void select_init_kernel(SelectState *st, unsigned long long *hist, un
 }
 
 size_t g_filter_blocks = 0;                 // np_select_set_variant(2..2047): workgroups of the streaming passes (0 = 4 per CU)
-size_t g_bracket_min_n = size_t(1) << 23;   // np_select_set_variant: 0 switches the bracket path off
+size_t g_bracket_min_n = size_t(1) << 26;   // np_select_set_variant: 0 switches the bracket path off
 
 template <typename I>
 int run_select(const float *in, size_t n, size_t k, float *dev_out2) {
@@ -651,7 +652,7 @@ int np_select_set_variant(int variant) {
         return NP_OK;
     }
     if (variant == 1) g_filter_blocks = 0;
-    g_bracket_min_n = variant == 0 ? 0 : variant == 1 ? size_t(1) << 23 : (size_t)variant;
+    g_bracket_min_n = variant == 0 ? 0 : variant == 1 ? size_t(1) << 26 : (size_t)variant;
     if (g_bracket_min_n && g_bracket_min_n < 2048) g_bracket_min_n = 2048;   // a sample run is 1024 floats
     return NP_OK;
 }

@@ -125,7 +125,7 @@ def test_quantile_errors(hip):
 @pytest.fixture
 def bracket_everywhere():
     """Send every array of >= 2048 elements down the bracket path (sample -> bracket -> filter -> verdict),
-    which by default only arrays of >= 2^23 elements take."""
+    which by default only arrays of >= 2^26 elements take."""
     from numpower_amd import _lib
     lib = _lib.load()
     _lib.check(lib.np_select_set_variant(2048))
@@ -191,10 +191,10 @@ def test_order_stat_bracket_path_matches_a_sort(name, x, hip, bracket_everywhere
 
 
 def test_bracket_path_is_taken_and_agrees_with_the_plain_passes(hip):
-    """2.5 * 10^7 elements (default threshold 2^23): same answers with the path on and off, for every decile."""
+    """7 * 10^7 elements (default threshold 2^26): same answers with the path on and off, for every decile."""
     from numpower_amd import _lib
     lib = _lib.load()
-    x = (synth.uniform((25_000_000,), 98, -1.0, 1.0) * np.exp(synth.uniform((25_000_000,), 99, -3.0, 3.0))).astype(np.float32)
+    x = (synth.uniform((70_000_000,), 98, -1.0, 1.0) * np.exp(synth.uniform((70_000_000,), 99, -3.0, 3.0))).astype(np.float32)
     want = np.sort(_keys(x))
     for k in [0, x.size - 1] + [x.size * d // 10 for d in range(1, 10)]:
         exp = _from_keys([want[k], want[min(k + 1, x.size - 1)]]).view(np.uint32).tolist()

@@ -12,7 +12,8 @@ from numpower_amd import _lib, synth
 
 lib = _lib.load()
 _lib.check(lib.np_init(0))
-n = 100_000_000
+import os
+n = int(os.environ.get("SELECT_AB_N", "100000000"))
 cases = {
     "uniform01": lambda: synth.uniform((n,), 5, 0.0, 1.0),
     "signed_wide": lambda: (synth.uniform((n,), 6, -1.0, 1.0) * np.exp(synth.uniform((n,), 7, -8.0, 8.0))).astype(np.float32),
@@ -29,10 +30,10 @@ for name, make in cases.items():
     h = make()
     _lib.check(lib.np_memcpy_h2d(buf.ptr, h.ctypes.data, 4 * n))
     for k_name, k in (("median", n // 2), ("p99", n * 99 // 100), ("min", 0)):
-        row = {"data": name, "rank": k_name}
+        row = {"n": n, "data": name, "rank": k_name}
         for variant, label in variants:
             _lib.check(lib.np_select_set_variant(1))
-            _lib.check(lib.np_select_set_variant(variant))
+            _lib.check(lib.np_select_set_variant(variant if variant != 1 else 2048))
             for _ in range(3):
                 _lib.check(lib.np_order_stat_dev(buf.ptr, n, k, out2.ptr))
             t = _lib.Timer()
