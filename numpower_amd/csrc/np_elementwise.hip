@@ -880,6 +880,8 @@ struct FusedArgs {
     size_t cols;                   // row length of the result; 0 when no operand is broadcast
     int first_prefetch_idx;
     int sink;                      // -1: store the chain value; NP_SUM / NP_PROD / NP_MIN / NP_MAX: reduce it
+    unsigned *ticket;              // full reduction on a small grid: the last workgroup folds the partials (np_internal.h) ...
+    float *result;                 // ... into this device float; null ticket: np::fold_partials does, in a second launch
     unsigned div_m, div_s1, div_s2;   // e / cols for 32-bit e without a division (see fast_div)
     FusedStep ops[FUSED_MAX_OPS];
 };
@@ -1295,14 +1297,16 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, fl
     } else {
         fused_span<U, 1, LIGHT, I>(f, out, (I)0, n, tid, stride, racc);   // 4-byte aligned views
     }
-    if (sink >= 0) {   // one partial per workgroup; np_reduce_all_dev folds them (deterministic)
+    if (sink >= 0) {   // one partial per workgroup, folded in a fixed order (deterministic) by the last workgroup or a second launch
         __shared__ float lds4[4];
-        float r;
-        if (sink == NP_SUM) r = np::dev::block_reduce<NP_SUM>(racc, lds4);
-        else if (sink == NP_PROD) r = np::dev::block_reduce<NP_PROD>(racc, lds4);
-        else if (sink == NP_MIN) r = np::dev::block_reduce<NP_MIN>(racc, lds4);
-        else r = np::dev::block_reduce<NP_MAX>(racc, lds4);
-        if (threadIdx.x == 0) out[blockIdx.x] = r;
+        unsigned *ticket = f->ticket;
+        float *result = f->result;
+#define NP_FOLD(OP_) np::dev::fold_in_last_workgroup<OP_>(np::dev::block_reduce<OP_>(racc, lds4), out, ticket, result, 1.0f, lds4)
+        if (sink == NP_SUM) NP_FOLD(NP_SUM);
+        else if (sink == NP_PROD) NP_FOLD(NP_PROD);
+        else if (sink == NP_MIN) NP_FOLD(NP_MIN);
+        else NP_FOLD(NP_MAX);
+#undef NP_FOLD
     }
 }
 
@@ -1353,6 +1357,8 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     f.first_prefetch_idx = FUSED_IDX_FULL;
     f.cols = broadcast ? cols : 0;
     f.sink = sink;
+    f.ticket = nullptr;
+    f.result = nullptr;
     f.div_m = f.div_s1 = f.div_s2 = 0;   // cols == 1: q = n
     if (broadcast && cols > 1 && cols <= 0xffffffffull) {
         unsigned l = 0;
@@ -1377,6 +1383,10 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         reduce_blocks = (unsigned)np::capped_grid(want, cap);
         if (int rc = partials.alloc(reduce_blocks * sizeof(float))) return rc;
         out = (float *)partials.ptr;
+        if (reduce_blocks <= np::kFoldInKernelMaxBlocks) {
+            f.ticket = np::next_ticket();
+            f.result = result;
+        }
     }
     FusedStep *last_stream = nullptr;
     bool light = true;
@@ -1538,7 +1548,7 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     }
 #undef NP_FC
     NP_LAUNCH_CHECK("fused_chain_kernel");
-    if (sink >= 0) return np::fold_partials(sink, (const float *)partials.ptr, reduce_blocks, result);
+    if (sink >= 0 && !f.ticket) return np::fold_partials(sink, (const float *)partials.ptr, reduce_blocks, result);
     return NP_OK;
 }
 

@@ -24,7 +24,17 @@ int num_cus();
 // behind every nd::sum() / allclose() / median() (that call alone is ~10 us of host + driver time).  One set per
 // process: host-result entry points are synchronous, so a slot is free again when the call returns.
 float *result_slots();   // nullptr + error set on failure
-int result_wait();       // = synchronise the library stream
+int result_wait();       // = wait for the library stream (spinning on a stream-written flag, np_runtime.hip)
+// A zeroed device counter for one launch of a "last workgroup folds" kernel (np::dev::fold_in_last_workgroup): taken
+// from a ring of 1024, and put back to zero by the workgroup that used it up, so a slot is clean again long before
+// the ring comes round (nullptr + error set on failure).
+unsigned *next_ticket();
+// Largest first-pass grid whose partials are folded by its own last workgroup rather than by a second kernel.  The
+// ticket is one hot address (~20 ns per workgroup at the memory side) and every workgroup waits a round trip for its
+// own: with 2049 workgroups the in-kernel fold LOST 5 us on a 63 us sum of 10^8 floats; on small grids it saves the
+// second launch — nd::sum() of 1024 floats 13.2 -> 10.3 us, of 10^5 (98 workgroups) 15.9 -> 13.0 (tools/latency_ab.py).
+// (Cutting mid-size grids down to 511 fatter workgroups so that they qualify was tried: 10^6 floats 17.0 -> 18.1 us.)
+constexpr size_t kFoldInKernelMaxBlocks = 256;
 
 // Block count of a capped grid-stride kernel.  With `cap` a power of two (CUs x 8 ...) every lane's accesses
 // sit a power-of-two number of bytes apart — 2048 workgroups x 4 KiB = 8 MiB — and land on the same HBM channel:
@@ -85,10 +95,10 @@ __device__ __forceinline__ float wave_reduce(float v) {
 // eight XCD L2s, which are not coherent with each other.  A wave takes its ticket only after its own stores have been
 // acknowledged (s_waitcnt 0).  Device-scope FENCES are deliberately not used: each writes back / invalidates an L2,
 // and a thousand workgroups doing that tripled the time of the streaming pass they ended (np_select.hip: 73 -> 240 us).
-// Worth it only where the step replaced is more than a fold: the ticket is one address, ~20 ns per workgroup at the
-// memory side, and every workgroup waits a round trip for its own before it retires.  The full reductions, with 2049
-// workgroups and a second kernel that only adds up 2049 floats, lost 5 us to it (sum of 10^8: 63 -> 68 us) and keep
-// their one-workgroup second kernel; the selection passes (np_select.hip), whose second step walks a histogram, use it.
+// The ticket is one address, ~20 ns per workgroup at the memory side, and every workgroup waits a round trip for its own
+// before it retires: the full reductions with their 2049 workgroups lost 5 us to it (sum of 10^8: 63 -> 68 us) and keep
+// the one-workgroup second kernel at that size; up to kFoldInKernelMaxBlocks workgroups they fold in-kernel, as do
+// the selection passes (np_select.hip), whose second step walks a histogram.
 template <typename T>
 __device__ __forceinline__ T coherent_load(const T *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -122,6 +132,37 @@ __device__ __forceinline__ float block_reduce(float v, float *lds4) {
         for (int w = 1; w < nw; ++w) v = r_combine<OP>(v, lds4[w]);
     }
     return v;
+}
+
+// The end of a streaming first pass: `r` is this workgroup's partial (valid in thread 0).  With a ticket, the last
+// workgroup to finish folds all gridDim.x partials — thread t takes partials t, t + blockDim, ... and block_reduce joins
+// them, the order the separate one-workgroup kernel uses, whichever workgroup happens to be last — and writes out[0]
+// (divided by mean_count for NP_MEAN).  Without one (ticket == nullptr) the partial is just stored for that kernel.
+// All threads of every workgroup call it.
+template <int OP>
+__device__ __forceinline__ void fold_in_last_workgroup(float r, float *partials, unsigned *ticket, float *out,
+                                                       float mean_count, float *lds4) {
+    if (!ticket) {
+        if (threadIdx.x == 0) partials[blockIdx.x] = r;
+        return;
+    }
+    if (gridDim.x == 1) {
+        if (threadIdx.x == 0) {
+            if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, mean_count);
+            out[0] = r;
+        }
+        return;
+    }
+    if (threadIdx.x == 0) coherent_store(&partials[blockIdx.x], r);
+    if (!last_workgroup_done(ticket, gridDim.x)) return;
+    float f = r_identity<OP>();
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) f = r_combine<OP>(f, coherent_load(&partials[i]));
+    f = block_reduce<OP>(f, lds4);
+    if (threadIdx.x == 0) {
+        if constexpr (OP == NP_MEAN) f = __fdiv_rn(f, mean_count);
+        out[0] = f;
+        coherent_store(ticket, 0u);   // clean for the launch that draws this slot next
+    }
 }
 
 }  // namespace dev

@@ -43,7 +43,8 @@ inline size_t stream_cap() {
 template <int OP, typename I>
 __global__ __launch_bounds__(256) void reduce_all_pass1(const float *__restrict__ in,
                                                         float *__restrict__ partials, I n, I head,
-                                                        I nvec) {
+                                                        I nvec, unsigned *__restrict__ ticket,
+                                                        float *__restrict__ out, float mean_count) {
     __shared__ float lds4[4];
     const I stride = (I)gridDim.x * blockDim.x;
     const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void reduce_all_pass1(const float *__restrict_
         if (t < n) r = r_combine<OP>(r, in[t]);
     }
     r = block_reduce<OP>(r, lds4);
-    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+    fold_in_last_workgroup<OP>(r, partials, ticket, out, mean_count, lds4);   // ticket == nullptr: pass 2 folds
 }
 
 // pass 2: one workgroup folds the partials; MEAN divides by the element count at the end
@@ -129,7 +130,8 @@ template <int XFORM, typename I>
 __global__ __launch_bounds__(256) void reduce_xform_pass1(const float *__restrict__ in,
                                                           const float *__restrict__ in2,
                                                           float *__restrict__ partials, I n, I nvec,
-                                                          float p0, float p1) {
+                                                          float p0, float p1, unsigned *__restrict__ ticket,
+                                                          float *__restrict__ out) {
     __shared__ float lds4[4];
     const I stride = (I)gridDim.x * blockDim.x;
     const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void reduce_xform_pass1(const float *__restric
         if (t < n) r += xf(in[t], XFORM >= 2 ? in2[t] : 0.0f);
     }
     r = block_reduce<NP_SUM>(r, lds4);
-    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+    fold_in_last_workgroup<NP_SUM>(r, partials, ticket, out, 1.0f, lds4);
 }
 
 // generic (misaligned views): one thread per element stride, scalar loads
@@ -171,14 +173,15 @@ template <int XFORM, typename I>
 __global__ __launch_bounds__(256) void reduce_xform_scalar(const float *__restrict__ in,
                                                            const float *__restrict__ in2,
                                                            float *__restrict__ partials, I n, float p0,
-                                                           float p1) {
+                                                           float p1, unsigned *__restrict__ ticket,
+                                                           float *__restrict__ out) {
     __shared__ float lds4[4];
     const I stride = (I)gridDim.x * blockDim.x;
     float r = 0.0f;
     for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         r += xform_term<XFORM>(in[i], XFORM >= 2 ? in2[i] : 0.0f, p0, p1);
     r = block_reduce<NP_SUM>(r, lds4);
-    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+    fold_in_last_workgroup<NP_SUM>(r, partials, ticket, out, 1.0f, lds4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -433,7 +436,8 @@ __device__ __forceinline__ float all_verdict(float x, I index, I body_end) {
 template <bool QUIRK, typename I>
 __global__ __launch_bounds__(256) void all_pass1(const float *__restrict__ in,
                                                  float *__restrict__ partials, I n, I head, I nvec,
-                                                 I body_end) {
+                                                 I body_end, unsigned *__restrict__ ticket,
+                                                 float *__restrict__ out) {
     __shared__ float lds4[4];
     const I stride = (I)gridDim.x * blockDim.x;
     float r = 1.0f;
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(256) void all_pass1(const float *__restrict__ in,
         if (t < n) r = fminf(r, all_verdict<QUIRK, I>(in[t], t, body_end));
     }
     r = block_reduce<NP_MIN>(r, lds4);
-    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+    fold_in_last_workgroup<NP_MIN>(r, partials, ticket, out, 1.0f, lds4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -757,9 +761,12 @@ int launch_reduce_all(const float *in, size_t n, float *dev_out) {
     const size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
     np::Scratch partials;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
-    reduce_all_pass1<OP, I><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (I)n,
-                                                           (I)head, (I)nvec);
+    // small grids: the last workgroup to finish folds the partials, no second launch (np_internal.h)
+    unsigned *ticket = blocks <= np::kFoldInKernelMaxBlocks ? np::next_ticket() : nullptr;
+    reduce_all_pass1<OP, I><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (I)n, (I)head, (I)nvec,
+                                                           ticket, dev_out, (float)n);
     NP_LAUNCH_CHECK("reduce_all_pass1");
+    if (ticket) return NP_OK;
     reduce_all_pass2<OP><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, dev_out,
                                            (float)n);
     NP_LAUNCH_CHECK("reduce_all_pass2");
@@ -1015,13 +1022,15 @@ static int xform_sum(const float *in, const float *in2, size_t n, float p0, floa
     const size_t blocks = np::capped_grid(((vec ? nvec : n / 4) + 255) / 256, stream_cap());
     np::Scratch partials;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
+    unsigned *ticket = blocks <= np::kFoldInKernelMaxBlocks ? np::next_ticket() : nullptr;
     if (vec)
-        reduce_xform_pass1<XFORM, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, in2, (float *)partials.ptr,
-                                                                         (uint32_t)n, (uint32_t)nvec, p0, p1);
+        reduce_xform_pass1<XFORM, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, in2, (float *)partials.ptr, (uint32_t)n,
+                                                                         (uint32_t)nvec, p0, p1, ticket, dev_out);
     else
-        reduce_xform_scalar<XFORM, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, in2, (float *)partials.ptr,
-                                                                          (uint32_t)n, p0, p1);
+        reduce_xform_scalar<XFORM, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, in2, (float *)partials.ptr, (uint32_t)n,
+                                                                          p0, p1, ticket, dev_out);
     NP_LAUNCH_CHECK("reduce_xform");
+    if (ticket) return NP_OK;
     reduce_all_pass2<NP_SUM><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, dev_out, 1.0f);
     NP_LAUNCH_CHECK("reduce_all_pass2");
     return NP_OK;
@@ -1294,15 +1303,18 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
     float *slot = np::result_slots();
     if (!slot) return NP_ERR_ALLOC;
     const uint32_t body_end = (uint32_t)np_avx_body_end(n);
+    unsigned *ticket = blocks <= np::kFoldInKernelMaxBlocks ? np::next_ticket() : nullptr;
     if (flags & NP_QUIRK_AVX_BODY)
-        all_pass1<true, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n,
-                                                                   (uint32_t)head, (uint32_t)nvec, body_end);
+        all_pass1<true, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n, (uint32_t)head,
+                                                                   (uint32_t)nvec, body_end, ticket, slot);
     else
-        all_pass1<false, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n,
-                                                                    (uint32_t)head, (uint32_t)nvec, 0u);
+        all_pass1<false, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n, (uint32_t)head,
+                                                                    (uint32_t)nvec, 0u, ticket, slot);
     NP_LAUNCH_CHECK("all_pass1");
-    reduce_all_pass2<NP_MIN><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, slot, 1.0f);
-    NP_LAUNCH_CHECK("reduce_all_pass2");
+    if (!ticket) {
+        reduce_all_pass2<NP_MIN><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, slot, 1.0f);
+        NP_LAUNCH_CHECK("reduce_all_pass2");
+    }
     if (int rc = np::result_wait()) return rc;
     *host_out = (slot[0] != 0.0f) ? 1 : 0;
     return NP_OK;

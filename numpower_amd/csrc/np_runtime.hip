@@ -39,6 +39,9 @@ struct Runtime {
     std::unordered_map<void *, Block> live;              // ptr -> rounded size, owning device, offset from the hipMalloc base
     unsigned large_seq = 0;                              // running count of large blocks obtained from the driver
     float *slots = nullptr;                              // pinned host-result slots (np::result_slots)
+    unsigned *tickets = nullptr;                         // ring of zeroed device counters (np::next_ticket)
+    int tickets_device = -1;
+    unsigned ticket_seq = 0;
     int wait_mode = 1;                                   // np_runtime_set_variant: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag
     uint32_t wait_seq = 0;
     size_t reserved = 0;                                 // bytes held (live + cached)
@@ -133,6 +136,30 @@ float *result_slots() {
     return r.slots;
 }
 
+constexpr unsigned kTicketRing = 1024;
+
+// np_init allocates the ring (not the first reduction: that one may be inside a stream capture)
+static int alloc_tickets_locked(Runtime &r) {
+    if (r.tickets && r.tickets_device == r.device) return NP_OK;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, kTicketRing * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(p, 0, kTicketRing * sizeof(unsigned));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(NP_ERR_ALLOC, "ticket ring: %s", hipGetErrorString(e));
+    }
+    r.tickets = (unsigned *)p;   // a ring per device this process has used; the old one is left to the driver
+    r.tickets_device = r.device;
+    return NP_OK;
+}
+
+unsigned *next_ticket() {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (alloc_tickets_locked(r) != NP_OK) return nullptr;
+    return r.tickets + (r.ticket_seq++ % kTicketRing);
+}
+
 // Waiting for a host result.  hipStreamSynchronize costs 10-20 us of driver time per call on top of the kernels — as
 // much as a reduction over a million floats takes.  Instead the command processor is asked to write a sequence
 // number into the last of the pinned slots once the stream gets there (hipStreamWriteValue32: no kernel launch) and
@@ -211,7 +238,7 @@ int np_init(int device) {
     r.cur_stream = r.own_stream;
     r.device = device;
     r.inited = true;
-    return NP_OK;
+    return np::alloc_tickets_locked(r);
 }
 
 int np_set_device(int device) { return np_init(device); }
