@@ -381,8 +381,8 @@ int np_runtime_set_variant(int variant);   /* how host-result calls wait: 0 = hi
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);
 int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128 */
-int np_select_set_variant(int variant);   /* order statistics: 0 = no bracket path, 1 = default (n >= 2^26), else the smallest n that takes it */
-int np_select_last_path(int *path);       /* tests / tools: 1 if the last selection ran over the bracket's copied keys, 0 if over the array (synchronises) */
+int np_select_set_variant(int variant);   /* order statistics: 0 = plain three passes only (no bracket path, no one-workgroup kernel), 1 = default (n >= 2^26), else the smallest n that takes it */
+int np_select_last_path(int *path);       /* tests / tools: 1 if the last selection ran over the bracket's copied keys, 0 if over the array, 2 if in the one-workgroup kernel (synchronises) */
 int np_reduce_set_variant(int variant);   /* streaming reductions, first pass: workgroups per CU (0 = default) */
 
 #ifdef __cplusplus

@@ -36,6 +36,7 @@
 namespace {
 
 constexpr int BINS = 2048;
+constexpr unsigned SMALL_MAX = 32768;   // arrays up to here: select_small_kernel, one workgroup, one launch
 constexpr int COPIES = 4;
 // Threads per workgroup of the histogram passes: one 16-wave workgroup per CU keeps as many waves resident as four
 // 4-wave ones but adds a quarter as many LDS histograms to the global one — up to 2048 device-scope atomics per
@@ -580,8 +581,85 @@ __global__ void select_init_kernel(SelectState *st, unsigned long long *hist, un
     }
 }
 
+size_t g_small_max = SMALL_MAX;             // np_select_set_variant(0) also switches the one-workgroup kernel off
 size_t g_filter_blocks = 0;                 // np_select_set_variant(2..2047): workgroups of the streaming passes (0 = 4 per CU)
 size_t g_bracket_min_n = size_t(1) << 26;   // np_select_set_variant: 0 switches the bracket path off
+
+
+// ---- small arrays: one workgroup, one launch ---------------------------------------------------------
+// Up to 32768 elements the selection is a chain of launches and round trips, not of bytes (four launches: 36 us for
+// 1024 floats).  One workgroup of 1024 threads reads the array ONCE into registers (<= 32 keys per thread), then
+// selects byte by byte, most significant first: a 256-bin LDS histogram of the keys that match the prefix so far, one
+// wave scans it (4 bins per lane + a shuffle scan).  After four bytes the prefix IS the k-th key; its successor is the
+// same key again if the last bin holds rank k+1 too, else the smallest key above it (one min-reduce over the
+// registers), else — k is the maximum — the key itself, as on the large path.
+
+__global__ __launch_bounds__(1024) void select_small_kernel(const float *__restrict__ in, unsigned n, unsigned k,
+                                                            float *__restrict__ out2) {
+    constexpr unsigned PER = SMALL_MAX / 1024;
+    __shared__ unsigned h[256];
+    __shared__ unsigned s_bin, s_below, s_in_bin, s_min[16];
+    unsigned key[PER];
+#pragma unroll
+    for (unsigned j = 0; j < PER; ++j) {
+        const unsigned i = j * 1024 + threadIdx.x;
+        key[j] = i < n ? to_key(in[i]) : 0u;
+    }
+    const unsigned lane = threadIdx.x & 63;
+    unsigned prefix = 0, mask = 0, rank = k, in_bin = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) h[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (unsigned j = 0; j < PER; ++j)
+            if (j * 1024 + threadIdx.x < n && (key[j] & mask) == prefix) atomicAdd(&h[(key[j] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64) {   // wave 0: lane l owns bins 4l .. 4l+3
+            const unsigned c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
+            const unsigned sum = c0 + c1 + c2 + c3;
+            unsigned incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned up = (unsigned)__shfl_up((int)incl, off, 64);
+                if ((int)lane >= off) incl += up;
+            }
+            const unsigned excl = incl - sum;
+            if (excl <= rank && rank < incl) {   // exactly one lane
+                unsigned below = excl, b = 0, c = c0;
+                if (below + c0 <= rank) { below += c0; b = 1; c = c1;
+                    if (below + c1 <= rank) { below += c1; b = 2; c = c2;
+                        if (below + c2 <= rank) { below += c2; b = 3; c = c3; } } }
+                s_bin = 4 * lane + b;
+                s_below = below;
+                s_in_bin = c;
+            }
+        }
+        __syncthreads();
+        prefix |= s_bin << shift;
+        mask |= 0xffu << shift;
+        rank -= s_below;
+        in_bin = s_in_bin;
+    }
+    // prefix = the k-th key; `rank` = its index among the in_bin keys equal to it; k - rank keys are smaller
+    unsigned succ = prefix;   // the same key again (duplicates), or no successor at all (k is the maximum)
+    if (rank + 1 >= in_bin && (k - rank) + in_bin < n) {   // wave-uniform: the successor is the smallest key above
+        unsigned m = 0xffffffffu;
+#pragma unroll
+        for (unsigned j = 0; j < PER; ++j)
+            if (j * 1024 + threadIdx.x < n && key[j] > prefix) m = min(m, key[j]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_down((int)m, off, 64));
+        if (lane == 0) s_min[threadIdx.x >> 6] = m;
+        __syncthreads();
+        succ = s_min[0];
+        for (int w = 1; w < 16; ++w) succ = min(succ, s_min[w]);
+    }
+    if (threadIdx.x == 0) {
+        g_last_path = 2;
+        out2[0] = from_key(prefix);
+        out2[1] = from_key(succ);
+    }
+}
 
 template <typename I>
 int run_select(const float *in, size_t n, size_t k, float *dev_out2) {
@@ -641,6 +719,11 @@ int np_order_stat_dev(const float *in, size_t n, size_t k, float *dev_out2) {
     if (k >= n) return np::fail(NP_ERR_INVALID, "np_order_stat: rank %zu out of range for %zu elements", k, n);
     if (!in || !dev_out2) return np::fail(NP_ERR_INVALID, "np_order_stat: null pointer");
     if (int rc = np::ensure_init()) return rc;
+    if (n <= g_small_max) {
+        select_small_kernel<<<1, 1024, 0, np::stream()>>>(in, (unsigned)n, (unsigned)k, dev_out2);
+        NP_LAUNCH_CHECK("select_small_kernel");
+        return NP_OK;
+    }
     if (n < (size_t(1) << 31)) return run_select<uint32_t>(in, n, k, dev_out2);
     return run_select<uint64_t>(in, n, k, dev_out2);
 }
@@ -652,6 +735,7 @@ int np_select_set_variant(int variant) {
         return NP_OK;
     }
     if (variant == 1) g_filter_blocks = 0;
+    g_small_max = variant == 0 ? 0 : SMALL_MAX;
     g_bracket_min_n = variant == 0 ? 0 : variant == 1 ? size_t(1) << 26 : (size_t)variant;
     if (g_bracket_min_n && g_bracket_min_n < 2048) g_bracket_min_n = 2048;   // a sample run is 1024 floats
     return NP_OK;

@@ -207,3 +207,56 @@ def test_bracket_path_is_taken_and_agrees_with_the_plain_passes(hip):
         assert plain.view(np.uint32).tolist() == exp, k
         assert fast.view(np.uint32).tolist() == exp, k
         assert path.value == 1, "rank %d fell back to the plain passes" % k
+
+
+def test_small_arrays_take_the_one_workgroup_kernel_every_rank(hip):
+    """n <= 32768: select_small_kernel (one launch).  Every rank of small arrays, incl. duplicates, -0 / +0, +-inf and
+    NaNs of both signs (the all-ones NaN is the largest key there is: the 'no successor' sentinel must not eat it)."""
+    rng = np.random.default_rng(5)
+    specials = np.array([0.0, -0.0, np.inf, -np.inf], np.float32)
+    allones_nan = np.array([0x7fffffff, 0xffffffff, 0x7fc00000], np.uint32).view(np.float32)
+    for n in (1, 2, 3, 5, 64, 65, 255, 256, 257, 300):
+        for style in range(4):
+            x = synth.uniform((n,), 700 + n + style, -2.0, 2.0)
+            if style == 1:
+                x = np.rint(x).astype(np.float32)
+            elif style == 2:
+                x[rng.integers(0, n, max(1, n // 4))] = specials[rng.integers(0, 4, max(1, n // 4))]
+            elif style == 3:
+                x[rng.integers(0, n, max(1, n // 3))] = allones_nan[rng.integers(0, 3, max(1, n // 3))]
+            want = np.sort(_keys(x))
+            for k in range(n):
+                got = _order_stat(x, k)
+                exp = _from_keys([want[k], want[min(k + 1, n - 1)]])
+                assert got.view(np.uint32).tolist() == exp.view(np.uint32).tolist(), (n, style, k)
+            assert _path() == 2
+    for n in (1023, 1024, 1025, 4097, 32767, 32768):
+        x = synth.uniform((n,), 800 + n, -1.0, 1.0) * np.float32(1e-3) + np.float32(1.0)   # one binade: low bytes decide
+        want = np.sort(_keys(x))
+        for k in sorted({0, 1, n // 2, n - 2, n - 1, int(rng.integers(0, n)), int(rng.integers(0, n))}):
+            got = _order_stat(x, k)
+            exp = _from_keys([want[k], want[min(k + 1, n - 1)]])
+            assert got.view(np.uint32).tolist() == exp.view(np.uint32).tolist(), (n, k)
+        assert _path() == 2
+    x = synth.uniform((32769,), 9, -1.0, 1.0)
+    _order_stat(x, 5)
+    assert _path() == 0
+
+
+@pytest.mark.parametrize("name,x", [c for c in _cases() if c[1].size <= 32768], ids=[c[0] for c in _cases() if c[1].size <= 32768])
+def test_plain_passes_still_serve_small_arrays(name, x, hip):
+    """np_select_set_variant(0): the three-pass kernels on the sizes the one-workgroup kernel normally takes."""
+    from numpower_amd import _lib
+    lib = _lib.load()
+    x = np.ascontiguousarray(x, np.float32)
+    n = x.size
+    want = np.sort(_keys(x))
+    _lib.check(lib.np_select_set_variant(0))
+    try:
+        for k in sorted({0, n - 1, n // 2, max(n // 2 - 1, 0), n // 3, min(n - 1, 1), max(n - 2, 0)}):
+            got = _order_stat(x, k)
+            exp = _from_keys([want[k], want[min(k + 1, n - 1)]])
+            assert got.view(np.uint32).tolist() == exp.view(np.uint32).tolist(), (name, k)
+        assert _path() == 0
+    finally:
+        _lib.check(lib.np_select_set_variant(1))
