@@ -23,7 +23,7 @@ int num_cus();
 // straight into a slot and the caller only waits for the stream (result_wait) and reads it — no 4-byte D2H copy call
 // behind every nd::sum() / allclose() / median() (that call alone is ~10 us of host + driver time).  One set per
 // process: host-result entry points are synchronous, so a slot is free again when the call returns.
-float *result_slots();   // nullptr + error set on failure
+float *result_slots(int count = 1);   // nullptr + error set on failure; `count` = how many slots the call's kernels will write
 int result_wait();       // = wait for the library stream (spinning on a stream-written flag, np_runtime.hip)
 // A zeroed device counter for one launch of a "last workgroup folds" kernel (np::dev::fold_in_last_workgroup): taken
 // from a ring of 1024, and put back to zero by the workgroup that used it up, so a slot is clean again long before

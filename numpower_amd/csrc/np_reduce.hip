@@ -1254,7 +1254,7 @@ int np_weighted_sums(const float *a, const float *w, size_t n, float *host_sum_a
     if (!host_sum_aw || !host_sum_w) return np::fail(NP_ERR_INVALID, "np_weighted_sums: null output");
     if (n == 0 || !a || !w) return np::fail(NP_ERR_INVALID, "np_weighted_sums: empty input");
     if (int rc = np::ensure_init()) return rc;
-    float *slot = np::result_slots();
+    float *slot = np::result_slots(2);
     if (!slot) return NP_ERR_ALLOC;
     if (int rc = xform_sum<2>(a, w, n, 0.0f, 0.0f, slot)) return rc;
     if (int rc = np_reduce_all_dev(NP_SUM, w, n, slot + 1)) return rc;   // both values behind ONE wait

@@ -42,8 +42,11 @@ struct Runtime {
     unsigned *tickets = nullptr;                         // ring of zeroed device counters (np::next_ticket)
     int tickets_device = -1;
     unsigned ticket_seq = 0;
-    int wait_mode = 1;                                   // np_runtime_set_variant: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag
+    int wait_mode = 2;                                   // np_runtime_set_variant: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag,
+                                                         // 2 = spin on the result slots themselves (armed with a sentinel)
     uint32_t wait_seq = 0;
+    int armed = 0;                                       // slots [0, armed) hold `sentinel` until the kernel writes them
+    uint32_t sentinel = 0;
     size_t reserved = 0;                                 // bytes held (live + cached)
     long live_count = 0;
 };
@@ -121,7 +124,7 @@ int ensure_init() {
     return NP_OK;
 }
 
-float *result_slots() {
+float *result_slots(int count) {
     Runtime &r = rt();
     if (!r.slots) {
         void *p = nullptr;
@@ -132,6 +135,15 @@ float *result_slots() {
             return nullptr;
         }
         r.slots = (float *)p;
+    }
+    // Arm the slots the coming kernels will write: a signalling-NaN bit pattern that changes with every call.  The
+    // host then only has to watch them change (result_wait) — no flag, no stream operation behind the kernels.
+    r.armed = 0;
+    if (r.wait_mode == 2 && count > 0 && count <= 32) {
+        r.sentinel = 0x7f800001u + (++r.wait_seq & 0x3fffffu);
+        volatile uint32_t *w = (volatile uint32_t *)r.slots;
+        for (int i = 0; i < count; ++i) w[i] = r.sentinel;
+        r.armed = count;
     }
     return r.slots;
 }
@@ -160,24 +172,39 @@ unsigned *next_ticket() {
     return r.tickets + (r.ticket_seq++ % kTicketRing);
 }
 
-// Waiting for a host result.  hipStreamSynchronize costs 10-20 us of driver time per call on top of the kernels — as
-// much as a reduction over a million floats takes.  Instead the command processor is asked to write a sequence
-// number into the last of the pinned slots once the stream gets there (hipStreamWriteValue32: no kernel launch) and
-// the host spins on it; the result itself was written by the last kernel, which has completed (and released its
-// system-scope writes) before the stream reaches the flag write.  A wait that lasts longer than 2 ms, or a runtime that
-// refuses the stream operation, goes to hipStreamSynchronize.
+// Waiting for a host result.  hipStreamSynchronize costs 5-6 us of driver time per call on top of the kernels, a
+// third of what nd::sum() of a small array takes.  The result lives in pinned, device-visible host memory, so the host
+// can simply watch it arrive: result_slots(count) filled the slots with a sentinel (a signalling NaN whose payload
+// changes from call to call), the last kernel overwrites them, and result_wait spins until none of them holds the
+// sentinel any more.  (Mode 1, the round's first version, spins on a flag the command processor writes behind the
+// kernels — hipStreamWriteValue32 — which turned out to be a 3.4 us kernel of its own.)  A result that happens to BE
+// the sentinel (a NaN with exactly that payload carried through from the input), a wait longer than 2 ms, or a runtime
+// that refuses the stream operation all end in hipStreamSynchronize: slower, never wrong.
 int result_wait() {
     Runtime &r = rt();
-    if (r.wait_mode == 1 && r.slots) {
+    const auto expired = [t0 = std::chrono::steady_clock::now()](unsigned spins) {
+        return (spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2);
+    };
+    if (r.wait_mode == 2 && r.armed > 0 && r.slots) {
+        volatile uint32_t *w = (volatile uint32_t *)r.slots;
+        const int armed = r.armed;
+        r.armed = 0;
+        for (unsigned spins = 0;; ++spins) {
+            bool pending = false;
+            for (int i = 0; i < armed; ++i) pending |= w[i] == r.sentinel;
+            if (!pending) return NP_OK;
+            __builtin_ia32_pause();
+            if (expired(spins)) break;
+        }
+    } else if (r.wait_mode == 1 && r.slots) {
         volatile uint32_t *flag = (volatile uint32_t *)(r.slots + 63);
         const uint32_t want = ++r.wait_seq;
         const hipError_t e = hipStreamWriteValue32(r.cur_stream, (void *)flag, want, 0);
         if (e == hipSuccess) {
-            const auto t0 = std::chrono::steady_clock::now();
             for (unsigned spins = 0;; ++spins) {
                 if (*flag == want) return NP_OK;
                 __builtin_ia32_pause();
-                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                if (expired(spins)) break;
             }
         } else {
             (void)hipGetLastError();
@@ -244,7 +271,8 @@ int np_init(int device) {
 int np_set_device(int device) { return np_init(device); }
 
 int np_runtime_set_variant(int variant) {
-    if (variant != 0 && variant != 1) return np::fail(NP_ERR_INVALID, "np_runtime_set_variant: 0 = wait with hipStreamSynchronize, 1 = spin on a stream-written flag (default)");
+    if (variant < 0 || variant > 2)
+        return np::fail(NP_ERR_INVALID, "np_runtime_set_variant: 0 = wait with hipStreamSynchronize, 1 = spin on a stream-written flag, 2 = spin on the result itself (default)");
     rt().wait_mode = variant;
     return NP_OK;
 }

@@ -752,7 +752,7 @@ int np_select_last_path(int *path) {
 int np_order_stat(const float *in, size_t n, size_t k, float *host_out2) {
     if (!host_out2) return np::fail(NP_ERR_INVALID, "np_order_stat: null output");
     if (int rc = np::ensure_init()) return rc;
-    float *slot = np::result_slots();
+    float *slot = np::result_slots(2);
     if (!slot) return NP_ERR_ALLOC;
     if (int rc = np_order_stat_dev(in, n, k, slot)) return rc;
     if (int rc = np::result_wait()) return rc;

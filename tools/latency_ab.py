@@ -22,7 +22,7 @@ for n in (1024, 100_000, 1_000_000, 10_000_000, 100_000_000):
     _lib.check(lib.np_memcpy_h2d(b.ptr, h.ctypes.data, 4 * n))
     row = {"n": n}
     for rnd in range(2):
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             _lib.check(lib.np_runtime_set_variant(variant))
             calls = {
                 "sum": lambda: _lib.check(lib.np_reduce_all(0, a.ptr, n, C.byref(out))),
@@ -37,8 +37,8 @@ for n in (1024, 100_000, 1_000_000, 10_000_000, 100_000_000):
                 for _ in range(reps):
                     fn()
                 us = (time.perf_counter() - t0) / reps * 1e6
-                key = "%s_%s_us" % (name, "sync" if variant == 0 else "spin")
+                key = "%s_%s_us" % (name, ("sync", "flag", "watch")[variant])
                 row[key] = round(min(us, row.get(key, 1e9)), 2)
-    _lib.check(lib.np_runtime_set_variant(1))
+    _lib.check(lib.np_runtime_set_variant(2))
     print(json.dumps(row), flush=True)
     a.free(); b.free()
