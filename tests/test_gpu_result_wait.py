@@ -1,0 +1,48 @@
+"""The three ways a host-result call can wait (np_runtime_set_variant: 0 hipStreamSynchronize, 1 a stream-written flag,
+2 watching the pinned result slots change — the default) return the same values, back to back and interleaved with
+asynchronous work, for one-slot (sum / allclose / all) and two-slot (order statistics, weighted sums) results."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from numpower_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_wait_modes_agree(hip):
+    from numpower_amd import _lib
+    lib = _lib.load()
+    n = 300_007
+    h = synth.uniform((n,), 11, -1.0, 1.0)
+    w = synth.uniform((n,), 12, 0.0, 1.0)
+    a, b, o = _lib.DeviceBuffer(4 * n), _lib.DeviceBuffer(4 * n), _lib.DeviceBuffer(4 * n)
+    _lib.check(lib.np_memcpy_h2d(a.ptr, h.ctypes.data, 4 * n))
+    _lib.check(lib.np_memcpy_h2d(b.ptr, w.ctypes.data, 4 * n))
+    want = None
+    try:
+        for variant in (0, 1, 2, 2, 1, 0):
+            _lib.check(lib.np_runtime_set_variant(variant))
+            got = []
+            for rep in range(20):
+                s = C.c_float(0.0)
+                _lib.check(lib.np_unary(_lib.UNARY_OPS["exp"], a.ptr, o.ptr, n, 0.0, 0.0))     # asynchronous work in front
+                _lib.check(lib.np_reduce_all(0, o.ptr, n, C.byref(s)))
+                two = (C.c_float * 2)()
+                _lib.check(lib.np_order_stat(a.ptr, n, (rep * 7919) % n, two))
+                flag = C.c_int(-1)
+                _lib.check(lib.np_count_mismatch(1, a.ptr, b.ptr, n, 1e-5, 1e-8, C.byref(flag)))
+                saw, sw = C.c_float(0.0), C.c_float(0.0)
+                _lib.check(lib.np_weighted_sums(a.ptr, b.ptr, n, C.byref(saw), C.byref(sw)))
+                mn = C.c_float(0.0)
+                _lib.check(lib.np_reduce_all(2, a.ptr, 1000 + rep, C.byref(mn)))              # tiny: one launch
+                got.append((s.value, two[0], two[1], flag.value, saw.value, sw.value, mn.value))
+            if want is None:
+                want = got
+                assert abs(got[0][0] - float(np.exp(h.astype(np.float64)).sum())) <= 1e-5 * float(np.exp(h.astype(np.float64)).sum())
+                assert got[0][6] == h[:1000].min()
+            assert got == want, variant
+    finally:
+        _lib.check(lib.np_runtime_set_variant(2))
+        a.free(); b.free(); o.free()
