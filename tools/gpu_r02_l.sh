@@ -1,3 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out/r02l
-timeout 600 python -m pytest tests/test_gpu_result_wait.py -x -q -m gpu 2>&1 | tail -15
+for seed in 3 4; do
+timeout 1400 python tools/fuzz_parity.py 600 $seed > gpurun_out/r02l/fuzz_$seed.log 2>&1; echo "seed $seed rc=$?"; tail -2 gpurun_out/r02l/fuzz_$seed.log
+done
