@@ -167,3 +167,34 @@ def test_elementwise_beyond_2p31_elements(hip):
     assert ex.view(n - 2, (2,)).to_host().tolist() == [1.75, 1.75]
     for d in (a, b, out, ex):
         d.free()
+
+
+def test_order_stat_beyond_2p31_elements(hip):
+    """np_order_stat with 64-bit indices (bracket path and plain passes): 2^31 + 2^24 floats built on the device from
+    129 copies of a shuffled 0 .. 2^24-1 pattern, so the k-th smallest is k // 129 exactly."""
+    import ctypes as C
+    from numpower_amd import _lib
+    lib = _lib.load()
+    D = hip
+    m, copies = 1 << 24, 129
+    n = m * copies                                             # 2 164 260 864 > 2^31
+    rng = np.random.default_rng(12)
+    pattern = rng.permutation(m).astype(np.float32)            # every integer below 2^24 is a float
+    chunk = D.DeviceArray.from_host(pattern)
+    big = D.DeviceArray((n,))
+    for c in range(copies):
+        _lib.check(lib.np_memcpy_d2d(big.view(c * m, (m,)).ptr, chunk.ptr, 4 * m))
+    two = (C.c_float * 2)()
+    path = C.c_int(-1)
+    try:
+        for variant in (1, 0):                                 # bracket path, then the plain three passes
+            _lib.check(lib.np_select_set_variant(variant))
+            for k in (0, 1, n // 2, n // 2 + 64, (1 << 31) + 5, n - 2, n - 1, 129 * 4_000_000 - 1):
+                _lib.check(lib.np_order_stat(big.ptr, n, k, two))
+                want = [float(k // copies), float(min(k + 1, n - 1) // copies)]
+                assert [two[0], two[1]] == want, (variant, k)
+                _lib.check(lib.np_select_last_path(C.byref(path)))
+                assert path.value == variant, (variant, k)
+    finally:
+        _lib.check(lib.np_select_set_variant(1))
+        chunk.free(); big.free()

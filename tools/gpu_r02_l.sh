@@ -1,5 +1,2 @@
 #!/bin/bash
-mkdir -p gpurun_out/r02l
-for seed in 3 4; do
-timeout 1400 python tools/fuzz_parity.py 600 $seed > gpurun_out/r02l/fuzz_$seed.log 2>&1; echo "seed $seed rc=$?"; tail -2 gpurun_out/r02l/fuzz_$seed.log
-done
+timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "beyond" 2>&1 | tail -15
