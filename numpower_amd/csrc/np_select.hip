@@ -18,19 +18,22 @@
 // level where the two ranks part, which the following pass finds with one compare + min per element
 // (or names directly, at the last level).  12 B/elem of HBM reads in total; no sort, no copy.
 //
-// Large arrays (>= 2^26 elements: the path's seven launches cost ~125 us before the first byte, against ~35 us + 12 B/elem
-// for the plain passes — measured crossover 5-6 * 10^7, profiles/r02/select_threshold.log) take a shortcut first, the "bracket" path: the 11-bit histogram of an
-// evenly spaced 2^20-element SAMPLE (1024 runs of 4 KiB), taken at two levels (22 key bits), names the
-// narrow key range that can hold rank k (the sample ranks k*m/n -+ 4096, eight standard deviations of a
-// binomial rank: about 1 % of the data); ONE pass over
-// the array then counts the keys below that bracket and copies the keys inside it into per-workgroup
-// segments of a scratch buffer (no histogram, no per-element atomics: one LDS atomic per wave per 1024
-// elements).  If rank k and its successor did land inside the bracket — checked exactly, on the device —
-// the three radix passes run over the copied keys instead of the array: 4 B/elem + small instead of
-// 12 B/elem.  If
-// not (adversarial order, or a bin so full of duplicates that the bracket would be more than a quarter
-// of the data, in which case the copy is skipped altogether), the three passes read the array as
-// before: the result never depends on the sample, only the time does.
+// Three paths, by size:
+//   n <= 32768      select_small_kernel: one workgroup, one launch, the array read once into registers.
+//   n <  2^26       the three passes above (each pass's bin-picking step runs in the pass's last workgroup, so a
+//                   selection is an init kernel + three launches).
+//   n >= 2^26       the "bracket" path in front of them.  An evenly spaced 2^20-element SAMPLE (1024 runs of 4 KiB) is
+//                   histogrammed at two levels (22 key bits) and names the narrow key range that can hold rank k (the
+//                   sample ranks k*m/n -+ 4096, eight standard deviations of a binomial rank: about 1 % of the data).
+//                   ONE pass over the array then counts the keys below that bracket and copies the keys inside it into
+//                   per-WAVE segments of a scratch buffer (fill count in a scalar register: no atomics, no LDS).  If
+//                   rank k and its successor did land inside the bracket — checked exactly, on the device — the radix
+//                   passes run over the copied keys instead of the array: 4 B/elem + small instead of 12 B/elem.  If
+//                   not (adversarial order, or a value so often repeated that the bracket would be more than a quarter
+//                   of the data, in which case the copy is skipped altogether), the three passes read the array as
+//                   before: the result never depends on the sample, only the time does.  The path's launches cost
+//                   ~125 us before the first byte, against ~35 us + 12 B/elem for the plain passes: measured crossover
+//                   5-6 * 10^7 elements (profiles/r02/select_threshold.log).
 #include "np_internal.h"
 
 namespace {
@@ -49,7 +52,7 @@ constexpr int HT = 1024;
 // (the sample pass, the passes over a thin bracket) now run on few workgroups instead.
 constexpr int HCOPIES = 1;
 
-__device__ int g_last_path;   // 1: the last selection read the bracket's copied keys, 0: the array (np_select_last_path)
+__device__ int g_last_path;   // the last selection: 0 read the array, 1 the bracket's copied keys, 2 ran in select_small_kernel (np_select_last_path)
 
 struct SelectState {
     unsigned long long k;        // rank still to find inside the current prefix group
@@ -62,8 +65,8 @@ struct SelectState {
     unsigned lo_key;             // bracket = keys with key - lo_key <= width
     unsigned width;
     int bracket;                 // the sample produced a usable bracket: the filter pass runs
-    int overflow;                // a workgroup's segment filled up: the copy is incomplete
-    int use_compact;             // verdict of select_decide_kernel: the radix passes read the segments
+    int overflow;                // a wave's segment filled up: the copy is incomplete
+    int use_compact;             // verdict of decide(): the radix passes read the segments
     unsigned group;              // radix passes over the copied keys: segments per wave
     unsigned nbits;              // ... which are ranked by (key - lo_key) << (32 - nbits), nbits = bit length of width:
                                  //     pass p is needed only while nbits > 11 * p (32 and a plain key when reading the array)
