@@ -365,7 +365,9 @@ int np_transpose2d(const float *in, float *out, size_t batch, size_t rows, size_
     // Rectangular tiles (the kernel takes any TR x TC) were measured in round 2 — 256x64, 64x256, 128x64, 64x128, 256x32,
     // 32x256 (profiles/r02/transpose_rect_ab.log): none beats 128 x 128.  What counts is the length of the READ
     // segments (64x256: 1 KiB reads, 256 B writes = 128x128's 5.74 TB/s at 65536 x 4096; 256x64: 256 B reads, 1 KiB
-    // writes = 5.16), so only the two square tiles are instantiated.
+    // writes = 5.16), so only the two square tiles are instantiated.  A probe with the LDS round trip taken out (same
+    // loads and stores, wrong values) runs at the same 5.65 TB/s: the LDS transpose is hidden, the rate is what 512-byte
+    // segments at two tiles per CU get from HBM — and with no LDS allocated (more tiles in flight) it drops to 5.35.
     if (tile == 128) return launch_transpose<128, 128>(in, out, batch, rows, cols, vec);
     return launch_transpose<64, 64>(in, out, batch, rows, cols, vec);
 }
