@@ -345,12 +345,12 @@ __device__ void bracket_level(SelectState *__restrict__ st, unsigned long long *
     const unsigned long long skip = LEVEL ? st->sample_below : 0ull;   // ranks are counted from the first bracket's start
     const unsigned long long r_lo = (ks > SAMPLE_DELTA ? ks - SAMPLE_DELTA : 0) - skip;
     const unsigned long long r_hi = (ks + SAMPLE_DELTA < SAMPLE_M ? ks + SAMPLE_DELTA : SAMPLE_M - 1) - skip;
-    // a rank within delta of either end of the sample: the array may hold keys beyond the sample's extremes
+    // A rank within delta of either end of the sample: the array may hold keys beyond the sample's extremes.  The two
+    // levels still narrow the bracket down inside the sample's range (sample rank 0 / m-1 = its first / last occupied
+    // bin); the finished bracket is then opened to key 0 / 0xffffffff, which adds only what the sample never saw.
     const bool lo_open = ks <= SAMPLE_DELTA, hi_open = ks + SAMPLE_DELTA >= SAMPLE_M - 1;
     const unsigned long long incl = part[cur][threadIdx.x], excl = incl - sum;
-    if (threadIdx.x == 0 && lo_open) { edge[0] = 0; edge[1] = 0; }
-    if (threadIdx.x == 255 && hi_open) { edge[2] = BINS - 1; edge[3] = incl; }
-    if (!lo_open && excl <= r_lo && r_lo < incl) {
+    if (excl <= r_lo && r_lo < incl) {
         unsigned long long below = excl;
         unsigned j = 0;
 #pragma unroll
@@ -359,7 +359,7 @@ __device__ void bracket_level(SelectState *__restrict__ st, unsigned long long *
         edge[0] = threadIdx.x * per + j;
         edge[1] = below;
     }
-    if (!hi_open && excl <= r_hi && r_hi < incl) {
+    if (excl <= r_hi && r_hi < incl) {
         unsigned long long upto = excl;
         unsigned j = 0;
 #pragma unroll
@@ -389,8 +389,9 @@ __device__ void bracket_level(SelectState *__restrict__ st, unsigned long long *
             const unsigned long long new_lo = old_lo + ((unsigned long long)b_lo << shift);
             unsigned long long new_end = new_lo + ((unsigned long long)span << shift) - 1ull;
             if (new_end > old_end) new_end = old_end;
-            st->lo_key = (unsigned)new_lo;
-            st->width = (unsigned)(new_end - new_lo);
+            const unsigned long long open_lo = lo_open ? 0ull : new_lo, open_end = hi_open ? 0xffffffffull : new_end;
+            st->lo_key = (unsigned)open_lo;
+            st->width = (unsigned)(open_end - open_lo);
             // the copy pays only while the bracket is a small part of the data (one value repeated over a quarter
             // of the array cannot be bracketed any tighter: the plain passes take over)
             st->bracket = inside * 4 <= SAMPLE_M ? 1 : 0;
