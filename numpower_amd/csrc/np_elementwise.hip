@@ -445,11 +445,16 @@ __device__ __forceinline__ v4f fetch4(const float *p, I v, I cols4, float splat,
     if constexpr (KIND == NP_SCALAR) return v4f{splat, splat, splat, splat};
     if constexpr (KIND == NP_ROW) {
         if (rg.cols == 0) return *(const v4f_u *)(p + (size_t)(v % cols4) * 4);
+        // ragged: ONE division per float4 (the position of its first element), then a dword-aligned float4 load when the
+        // four elements stay in one row — all but one float4 in cols / 4 — and a walk with wrap-around for the others
+        const I e0 = v * 4;
+        I c = e0 - ragged_row(rg, e0) * rg.cols;
+        if (c + 3 < rg.cols) return *(const v4f_u *)(p + (size_t)c);
         v4f r;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const I e = v * 4 + k;
-            r[k] = p[(size_t)(e - ragged_row(rg, e) * rg.cols)];
+            r[k] = p[(size_t)c];
+            c = c + 1 == rg.cols ? (I)0 : c + 1;
         }
         return r;
     }
@@ -458,6 +463,8 @@ __device__ __forceinline__ v4f fetch4(const float *p, I v, I cols4, float splat,
             const float s = p[(size_t)(v / cols4)];
             return v4f{s, s, s, s};
         }
+        // (one division per float4 + a walk, as for ROW above, measured 2 % slower here than four divisions: the column
+        // operand needs no second load in the common case either way — tools/ragged_ab.py)
         v4f r;
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[k] = p[(size_t)ragged_row(rg, (I)(v * 4 + k))];
