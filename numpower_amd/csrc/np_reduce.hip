@@ -457,10 +457,12 @@ __global__ __launch_bounds__(256) void all_pass1(const float *__restrict__ in,
 }
 
 // ------------------------------------------------------------------------------------------
-// axis reduction, inner >= 4 and inner % 4 == 0: "column" reduce
+// axis reduction, inner >= 4: "column" reduce
 // ------------------------------------------------------------------------------------------
 //
-// View: in[outer][axis_len][inner].  A workgroup owns a tile of 64 float4 columns (256 floats of
+// View: in[outer][axis_len][inner] — any inner: rows need not start on a 16-byte boundary (dword-aligned float4
+// accesses), and the last group of a row with inner % 4 != 0 handles its 1-3 columns one by one.
+// A workgroup owns a tile of 64 float4 columns (256 floats of
 // the inner dimension) and one of `splits` contiguous chunks of the axis; its 4 waves walk
 // interleaved rows of the chunk (each wave-level load is one contiguous 1 KiB segment of a row),
 // keep ROWS_IN_FLIGHT independent loads in flight, and combine through LDS at the end.
@@ -472,9 +474,10 @@ __global__ __launch_bounds__(256) void all_pass1(const float *__restrict__ in,
 template <int OP, bool FINAL, typename I>
 __global__ __launch_bounds__(256) void reduce_axis_cols(const float *__restrict__ in,
                                                         float *__restrict__ out, I axis_len,
-                                                        I inner4, I splits, float mean_div,
+                                                        I inner, I splits, float mean_div,
                                                         int prod_quirk, I body_end) {
     __shared__ v4f lds[3][64];
+    const I inner4 = (inner + 3) / 4;   // column groups per row; the last one may hold fewer than 4 columns
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const I col4 = (I)blockIdx.x * 64 + lane;
     const I split = blockIdx.y;
@@ -485,11 +488,17 @@ __global__ __launch_bounds__(256) void reduce_axis_cols(const float *__restrict_
     if (r1 > axis_len) r1 = axis_len;
     const float id = r_identity<OP>();
     v4f acc0{id, id, id, id}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    if (col4 < inner4) {
-        const size_t row_stride = (size_t)inner4 * 4;
+    const I valid = col4 < inner4 ? (inner - col4 * 4 < 4 ? inner - col4 * 4 : (I)4) : (I)0;   // columns this lane owns
+    if (valid > 0) {
+        // A ragged last group (valid < 4) loads whole float4s like everyone else — the 1-3 extra floats are the start
+        // of the next row and are never stored — except on the very last row of the array, where they would lie past
+        // the buffer: that one row it reads element by element.
+        const bool past_end = valid < 4 && o == (I)gridDim.z - 1 && r1 == axis_len;
+        const I r1v = past_end ? r1 - 1 : r1;
+        const size_t row_stride = (size_t)inner;
         const float *p = in + (size_t)o * axis_len * row_stride + (size_t)col4 * 4;
         I r = r0 + wave;
-        for (; r + 12 < r1; r += 16) {
+        for (; r + 12 < r1v; r += 16) {
             const v4f x0 = __builtin_nontemporal_load((const v4f_u *)(p + (size_t)r * row_stride));
             const v4f x1 = __builtin_nontemporal_load((const v4f_u *)(p + (size_t)(r + 4) * row_stride));
             const v4f x2 = __builtin_nontemporal_load((const v4f_u *)(p + (size_t)(r + 8) * row_stride));
@@ -502,10 +511,15 @@ __global__ __launch_bounds__(256) void reduce_axis_cols(const float *__restrict_
                 acc3[k] = r_combine<OP>(acc3[k], x3[k]);
             }
         }
-        for (; r < r1; r += 4) {
+        for (; r < r1v; r += 4) {
             const v4f x0 = *(const v4f_u *)(p + (size_t)r * row_stride);
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc0[k] = r_combine<OP>(acc0[k], x0[k]);
+        }
+        if (past_end && r == r1v) {   // this wave's turn in the interleave falls on the last row
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if ((I)k < valid) acc0[k] = r_combine<OP>(acc0[k], p[(size_t)r * row_stride + k]);
         }
     }
     v4f acc;
@@ -514,7 +528,7 @@ __global__ __launch_bounds__(256) void reduce_axis_cols(const float *__restrict_
         acc[k] = r_combine<OP>(r_combine<OP>(acc0[k], acc1[k]), r_combine<OP>(acc2[k], acc3[k]));
     if (wave > 0) lds[wave - 1][lane] = acc;
     __syncthreads();
-    if (wave == 0 && col4 < inner4) {
+    if (wave == 0 && valid > 0) {
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
             const v4f t = lds[w][lane];
@@ -534,8 +548,14 @@ __global__ __launch_bounds__(256) void reduce_axis_cols(const float *__restrict_
                 }
             }
         }
-        float *q = out + ((size_t)o * splits + split) * (size_t)inner4 * 4 + (size_t)col4 * 4;
-        *(v4f_u *)q = acc;
+        float *q = out + ((size_t)o * splits + split) * (size_t)inner + (size_t)col4 * 4;
+        if (valid == 4) {
+            *(v4f_u *)q = acc;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if ((I)k < valid) q[k] = acc[k];
+        }
     }
 }
 
@@ -895,15 +915,18 @@ int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t in
             NP_LAUNCH_CHECK("reduce_rows_wave");
             return NP_OK;
         }
-    } else if (inner % 4 == 0 && outer <= 65535 &&
+    } else if ((inner % 4 == 0 || inner >= 4000) && outer <= 65535 &&
                !(inner <= 128 && axis_len >= 512 && outer * inner < target_wg * 64)) {
         // (a handful of float4 columns would use a fraction of the 64-column tile: those go to the
-        // flat small-inner kernel below; any pointer alignment: dword-aligned float4 accesses)
-        const size_t inner4 = inner / 4;
+        // flat small-inner kernel below; any pointer alignment.  Ragged rows (inner % 4 != 0: every row starts
+        // on a different 4-byte boundary) come here from 4000 columns up — 10007 x 10007 axis-0 sum 4.4 -> 5.4
+        // TB/s, 5000 x 20001 4.55 -> 5.58, 25000 x 4001 4.8 -> 5.15; at 2502 columns it is a tie with the
+        // generic kernel and at 1001 it loses 12 %: tools/ragged_reduce_ab.py)
+        const size_t inner4 = (inner + 3) / 4;
         const size_t splits = choose_splits(outer, axis_len, inner4);
         const dim3 grid((unsigned)((inner4 + 63) / 64), (unsigned)splits, (unsigned)outer);
         if (splits == 1) {
-            reduce_axis_cols<OP, true, I><<<grid, 256, 0, s>>>(in, out, (I)axis_len, (I)inner4, (I)1,
+            reduce_axis_cols<OP, true, I><<<grid, 256, 0, s>>>(in, out, (I)axis_len, (I)inner, (I)1,
                                                             mean_div, quirk, (I)body_end);
             NP_LAUNCH_CHECK("reduce_axis_cols");
             return NP_OK;
@@ -911,13 +934,13 @@ int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t in
         np::Scratch partials;
         if (int rc = partials.alloc(outer * splits * inner * sizeof(float))) return rc;
         reduce_axis_cols<OP, false, I><<<grid, 256, 0, s>>>(in, (float *)partials.ptr, (I)axis_len,
-                                                         (I)inner4, (I)splits, mean_div, 0, (I)0);
+                                                         (I)inner, (I)splits, mean_div, 0, (I)0);
         NP_LAUNCH_CHECK("reduce_axis_cols(pass 1)");
         // pass 2: the partials are an outer x splits x inner array; MEAN must divide by the real
         // axis length, not by `splits`.
         const dim3 grid2((unsigned)((inner4 + 63) / 64), 1, (unsigned)outer);
         reduce_axis_cols<OP, true, I><<<grid2, 256, 0, s>>>((const float *)partials.ptr, out,
-                                                         (I)splits, (I)inner4, (I)1, mean_div,
+                                                         (I)splits, (I)inner, (I)1, mean_div,
                                                          quirk, (I)body_end);
         NP_LAUNCH_CHECK("reduce_axis_cols(pass 2)");
         return NP_OK;
