@@ -808,6 +808,54 @@ __global__ __launch_bounds__(256) void sgemv_short_rows_kernel(const float *__re
     if (l == 0 && row < M) y[row] = acc;
 }
 
+
+// Many short rows, staged: lanes of sgemv_short_rows_kernel read 4 bytes each at a row's stride, so a wave needs N
+// load instructions for what is one contiguous span of memory (10^7 x 10: 3.5 TB/s).  Here a workgroup copies a
+// contiguous slab of R rows into LDS with coalesced float4 loads — the matrix is read as the flat stream it is — and
+// then every thread forms the inner products of its rows out of LDS (row pitch N | 1 words: an even N would put all
+// lanes of a wave on a few banks).  x sits in LDS too.  Needs a 16-byte aligned A and R * N % 4 == 0.
+__global__ __launch_bounds__(256) void sgemv_staged_rows_kernel(const float *__restrict__ A,
+                                                                const float *__restrict__ x,
+                                                                float *__restrict__ y, size_t M, unsigned N,
+                                                                unsigned R, unsigned magic) {
+    extern __shared__ __attribute__((aligned(16))) float slab[];   // R * pitch floats, then N floats of x
+    const unsigned pitch = N | 1u;
+    float *xs = slab + (size_t)R * pitch;
+    const size_t row0 = (size_t)blockIdx.x * R;
+    const unsigned rows = (unsigned)(M - row0 < R ? M - row0 : R);
+    const unsigned total = rows * N;                 // floats of this slab
+    const float *src = A + row0 * N;                 // 16-byte aligned: row0 * N is a multiple of 4
+    for (unsigned c = threadIdx.x; c < N; c += 256) xs[c] = x[c];
+    const unsigned nvec = total / 4;
+    for (unsigned v = threadIdx.x; v < nvec; v += 256) {
+        const v4f a = __builtin_nontemporal_load((const v4f *)(src + (size_t)v * 4));
+        const unsigned e = v * 4;
+        unsigned r = __umulhi(e, magic);             // e / N  (magic = ceil(2^32 / N), exact for e < 2^16)
+        unsigned c = e - r * N;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            slab[r * pitch + c] = a[k];
+            if (++c == N) { c = 0; ++r; }
+        }
+    }
+    for (unsigned e = nvec * 4 + threadIdx.x; e < total; e += 256) {   // last slab of a matrix with M * N % 4 != 0
+        const unsigned r = __umulhi(e, magic);
+        slab[r * pitch + (e - r * N)] = src[e];
+    }
+    __syncthreads();
+    for (unsigned r = threadIdx.x; r < rows; r += 256) {
+        const float *a = slab + r * pitch;
+        float acc0 = 0.0f, acc1 = 0.0f;
+        unsigned c = 0;
+        for (; c + 1 < N; c += 2) {
+            acc0 = fmaf(a[c], xs[c], acc0);
+            acc1 = fmaf(a[c + 1], xs[c + 1], acc1);
+        }
+        if (c < N) acc0 = fmaf(a[c], xs[c], acc0);
+        y[row0 + r] = acc0 + acc1;
+    }
+}
+
 // ---- thin products: C = A (M x K) . B (K x N) with N <= 32 --------------------------------------
 // (points x 3) . (3 x 3), (samples x 784) . (784 x 10): these are HBM-bound reads of A — a 64 x 64
 // MFMA tile would be 90 % padding (10^7 x 3 x 3 ran at 0.46 TB/s).  They are GEMVs with NV right-hand
@@ -1601,6 +1649,20 @@ int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y) {
         return np::fail(NP_ERR_INVALID, "np_sgemv: dimension too large");
     if (int rc = np::ensure_init()) return rc;
     const size_t target = (size_t)np::num_cus() * 8;
+    if (N >= 4 && N <= 63 && M >= 262144 && aligned16(A)) {   // (N = 3 and small M: the lane-group kernel below is ahead)
+        // slabs of R rows, R a multiple of 256 (so that R * N % 4 == 0 and every thread has whole rows), ~32 KB of LDS
+        const unsigned pitch = (unsigned)N | 1u;
+        unsigned R = (8192u / pitch) / 256u * 256u;
+        if (R < 256) R = 256;
+        const size_t blocks = (M + R - 1) / R;
+        const size_t lds = ((size_t)R * pitch + N) * sizeof(float);
+        if (blocks <= 0x7fffffffu && lds <= 64 * 1024) {
+            const unsigned magic = (unsigned)((0x100000000ull + N - 1) / N);
+            sgemv_staged_rows_kernel<<<(unsigned)blocks, 256, lds, np::stream()>>>(A, x, y, M, (unsigned)N, R, magic);
+            NP_LAUNCH_CHECK("sgemv_staged_rows_kernel");
+            return NP_OK;
+        }
+    }
     if (N <= 256 && M >= 1024) {
         size_t L = 1;
         while (L * 8 < N) L *= 2;          // ~8 elements per lane

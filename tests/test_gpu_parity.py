@@ -675,7 +675,9 @@ def test_axis_reduce_few_outputs_long_axis(shape, axis, hip, oracle):
 
 
 @pytest.mark.parametrize("mn", [(1, 3_000_001), (1, 65536), (10, 500_000), (7, 16385), (200_000, 10), (5000, 1), (4096, 33),
-                                (300, 70_001), (50_000, 100), (20_000, 256), (20_000, 257), (100_000, 8), (100_000, 9)])
+                                (300, 70_001), (50_000, 100), (20_000, 256), (20_000, 257), (100_000, 8), (100_000, 9),
+                                # LDS-staged slabs of short rows (M >= 262144, 4 <= N <= 63), incl. a ragged last slab and M * N % 4 != 0
+                                (300_000, 10), (262_144, 4), (262_145, 63), (400_003, 7), (1_000_000, 16), (270_001, 33)])
 def test_sgemv_shapes(mn, hip, oracle):
     """np_sgemv / NDArray_Dot outside the square case: inner products and few long rows (chunked:
     sgemv_chunks_kernel + fold), many short rows (thread per row), against fp64 and the oracle's
