@@ -719,6 +719,57 @@ __global__ __launch_bounds__(256) void reduce_rows_group(const float *__restrict
     }
 }
 
+
+// Short rows, very many of them (a 10^7 x 10 matrix summed along axis 1 — softmax denominators): the lanes of
+// reduce_rows_group read 4 bytes each at the row stride, N load instructions per wave for what is one contiguous span.
+// Here a workgroup copies a contiguous slab of R rows into LDS with coalesced float4 loads and every thread folds its
+// rows out of LDS (row pitch len | 1 words: an even pitch would put a wave's lanes on a few banks).  Needs a 16-byte
+// aligned input and R * len % 4 == 0 (R is a multiple of 256).  Same technique as sgemv_staged_rows_kernel (np_sgemm.hip).
+template <int OP>
+__global__ __launch_bounds__(256) void reduce_rows_staged(const float *__restrict__ in, float *__restrict__ out,
+                                                          size_t rows_total, unsigned len, unsigned R, unsigned magic,
+                                                          float mean_div, int prod_quirk) {
+    extern __shared__ __attribute__((aligned(16))) float slab[];
+    const unsigned pitch = len | 1u;
+    const size_t row0 = (size_t)blockIdx.x * R;
+    const unsigned rows = (unsigned)(rows_total - row0 < R ? rows_total - row0 : R);
+    const unsigned total = rows * len;
+    const float *src = in + row0 * len;
+    const unsigned nvec = total / 4;
+    for (unsigned v = threadIdx.x; v < nvec; v += 256) {
+        const v4f a = __builtin_nontemporal_load((const v4f *)(src + (size_t)v * 4));
+        const unsigned e = v * 4;
+        unsigned r = __umulhi(e, magic);   // e / len (magic = ceil(2^32 / len), exact for e < 2^16)
+        unsigned c = e - r * len;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            slab[r * pitch + c] = a[k];
+            if (++c == len) { c = 0; ++r; }
+        }
+    }
+    for (unsigned e = nvec * 4 + threadIdx.x; e < total; e += 256) {
+        const unsigned r = __umulhi(e, magic);
+        slab[r * pitch + (e - r * len)] = src[e];
+    }
+    __syncthreads();
+    for (unsigned r = threadIdx.x; r < rows; r += 256) {
+        const float *p = slab + r * pitch;
+        float a0 = r_identity<OP>(), a1 = a0;
+        unsigned c = 0;
+        for (; c + 1 < len; c += 2) {
+            a0 = r_combine<OP>(a0, p[c]);
+            a1 = r_combine<OP>(a1, p[c + 1]);
+        }
+        if (c < len) a0 = r_combine<OP>(a0, p[c]);
+        float v = r_combine<OP>(a0, a1);
+        if constexpr (OP == NP_MEAN) v = __fdiv_rn(v, mean_div);
+        if constexpr (OP == NP_PROD) {
+            if (prod_quirk && v == 0.0f) v = 0.0f;   // see reduce_rows_wave
+        }
+        out[row0 + r] = v;
+    }
+}
+
 // blockIdx.y = chunk of the row (chunks > 1: few rows, long rows — out[row][chunk], a later pass
 // folds the chunks; the MEAN division then happens there).
 template <int OP, typename I>
@@ -885,6 +936,23 @@ int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t in
                 in, (float *)partials.ptr, (I)outer, (I)axis_len, 1.0f, (I)chunk_len, 0);
             NP_LAUNCH_CHECK("reduce_rows_block(chunks)");
             return launch_reduce_axis<OP, I>((const float *)partials.ptr, outer, chunks, 1, out, flags, mean_div);
+        }
+        if (axis_len > 4 && axis_len <= 48 && outer * axis_len >= (size_t(8) << 20) && ((uintptr_t)in & 15u) == 0) {
+            // slabs of R rows (a multiple of 256) staged through ~32 KB of LDS: 10^7 x 10 4.5 -> 5.95 TB/s, 5 * 10^6 x 16
+            // 2.4 -> 6.4, 2 * 10^7 x 5 3.8 -> 5.35 (tools/short_rows_reduce_ab.py); rows of 63 floats lose (two slabs per CU)
+            // and so do small arrays (300001 x 7: 3.5 -> 4.2 us), which stay with the lane-group kernel below
+            const unsigned pitch = (unsigned)axis_len | 1u;
+            unsigned R = (8192u / pitch) / 256u * 256u;
+            if (R < 256) R = 256;
+            const size_t blocks = (outer + R - 1) / R;
+            const size_t lds = (size_t)R * pitch * sizeof(float);
+            if (blocks <= 0x7fffffffu && lds <= 64 * 1024) {
+                const unsigned magic = (unsigned)((0x100000000ull + axis_len - 1) / axis_len);
+                reduce_rows_staged<OP><<<(unsigned)blocks, 256, lds, s>>>(in, out, outer, (unsigned)axis_len, R, magic,
+                                                                       mean_div, quirk);
+                NP_LAUNCH_CHECK("reduce_rows_staged");
+                return NP_OK;
+            }
         }
         if (axis_len > 4 && axis_len <= 256) {
             // L lanes per row with at most ~8 elements per lane

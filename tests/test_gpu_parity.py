@@ -641,7 +641,11 @@ def test_fast_hyperbolic_accuracy(op, hip, oracle):
 
 @pytest.mark.parametrize("shape,axis", [((3, 300_000), 1), ((300_000, 3), 0), ((1_000_003, 1), 0), ((1, 1_000_003), 1),
                                         ((5, 70_000, 3), 1), ((2, 40_000, 17), 1), ((1001, 1003), 0), ((4001, 250), 0),
-                                        ((9, 20_011), 1), ((200_000, 2), 0), ((64, 5000, 64), 1), ((7, 600, 1), 1)])
+                                        ((9, 20_011), 1), ((200_000, 2), 0), ((64, 5000, 64), 1), ((7, 600, 1), 1),
+                                        # very many short rows: slabs staged through LDS (reduce_rows_staged), incl. a ragged
+                                        # last slab and rows * len % 4 != 0; ragged wide rows through the float4 column kernel
+                                        ((900_001, 10), 1), ((1_700_000, 5), 1), ((530_003, 16), 1), ((180_001, 47), 1),
+                                        ((3000, 4001), 0), ((2100, 10_007), 0)])
 def test_axis_reduce_few_outputs_long_axis(shape, axis, hip, oracle):
     """Shapes where the outputs alone cannot fill the machine — a few long rows, column sums of an
     N x 3 array, ragged inner sizes: the axis is cut into chunks / flat slabs (reduce_rows_block
