@@ -1319,9 +1319,143 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, fl
 
 }  // namespace
 
-// whether the axis-sink kernels take this shape (otherwise: materialise the chain, then np_reduce_axis)
+
+// Chain ending in a reduction over the LAST axis of a matrix with very many SHORT rows (sum(exp(X), 1) over 10 classes):
+// the row kernels above give a lane group to each row and load 4 bytes per lane at the row stride.  Here — as in
+// reduce_rows_staged (np_reduce.hip), whose fold order this repeats, so that the fused result stays bit-identical to the
+// op-by-op one — a workgroup walks a contiguous slab of R rows as the flat float4 stream it is, runs the chain on each
+// float4 (every operand kind can be fetched there: the element's row and column are known), parks the chain values in
+// LDS (row pitch len | 1 words) and then every thread folds its rows.  R is a multiple of 256, so slabs start on 16 bytes.
+struct StagedCtx {
+    FusedArgsK f;
+    float *slab;          // LDS
+    size_t base, row0;    // flat index / row index of the slab's first element
+    unsigned len, pitch, magic;
+};
+
+// N values (one float4 or one element) of the slab through the chain; e = slab-relative flat index of the first.
+// (Out of line — one copy of the interpreter, called once per float4 with all eight loads of a thread issued first —
+// it cost 2.3x: register save / restore around every call, 0.129 -> 0.29 ms on 10^7 x 10.)
+template <int N>
+__device__ __forceinline__ void staged_run(const StagedCtx &cx, unsigned e, v4f x) {
+    FusedArgsK f = cx.f;
+    const float *in0 = f->in0;
+    const unsigned len = cx.len;
+    float acc[N];
+    unsigned r[N], c[N];
+    r[0] = __umulhi(e, cx.magic);                // e / len (magic = ceil(2^32 / len), exact for e < 2^16)
+    c[0] = e - r[0] * len;
+#pragma unroll
+    for (int j = 1; j < N; ++j) {
+        const bool wrap = c[j - 1] + 1 == len;
+        c[j] = wrap ? 0u : c[j - 1] + 1;
+        r[j] = r[j - 1] + (wrap ? 1u : 0u);
+    }
+    const size_t ge = cx.base + e;
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = x[j];
+    auto fetch = [&](const float *p, int idx, float (&dst)[N]) {
+        if (idx == FUSED_IDX_FULL) {
+            if constexpr (N == 4) {
+                const v4f t = *(const v4f_u *)(p + ge);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[j] = t[j];
+            } else {
+                dst[0] = p[ge];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                dst[j] = p[idx == FUSED_IDX_ROW ? (size_t)c[j] : idx == FUSED_IDX_COL ? cx.row0 + r[j] : (size_t)0];
+        }
+    };
+    const float *stream = f->first_prefetch;
+    int stream_idx = f->first_prefetch_idx;
+    const int n_ops = f->n_ops;
+    for (int k = 0; k < n_ops; ++k) {
+        const int kind = f->ops[k].kind, op = f->ops[k].op;
+        if (kind == NP_FUSED_UNARY) {
+            unary_dispatch<N, false>(op, acc, f->ops[k].p0, f->ops[k].p1);
+            continue;
+        }
+        float oth[N];
+        bool body[N];
+        const int src = f->ops[k].src_kind;
+        if (src == FUSED_SRC_STREAM) {
+            fetch(stream, stream_idx, oth);
+            stream = f->ops[k].prefetch;
+            stream_idx = f->ops[k].prefetch_idx;
+        } else if (src == FUSED_SRC_INPUT0) {
+            fetch(in0, FUSED_IDX_FULL, oth);
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) oth[j] = f->ops[k].scalar;
+        }
+        const size_t body_end = f->ops[k].body_end;
+#pragma unroll
+        for (int j = 0; j < N; ++j) body[j] = ge + j < body_end;
+        binary_dispatch<N, false>(op, acc, oth, f->ops[k].swap != 0, f->ops[k].quirk != 0, body);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) cx.slab[r[j] * cx.pitch + c[j]] = acc[j];
+}
+
+template <int SINK>
+__global__ __launch_bounds__(256) void fused_chain_rows_staged_kernel(FusedArgs by_value, float *__restrict__ out,
+                                                                      size_t rows_total, unsigned len, unsigned R,
+                                                                      unsigned magic, float mean_div) {
+    (void)by_value;
+    extern __shared__ __attribute__((aligned(16))) float slab[];
+    StagedCtx cx;
+    cx.f = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    cx.slab = slab;
+    cx.len = len;
+    cx.pitch = len | 1u;
+    cx.magic = magic;
+    cx.row0 = (size_t)blockIdx.x * R;
+    cx.base = cx.row0 * len;
+    const unsigned pitch = cx.pitch;
+    const size_t row0 = cx.row0;
+    const unsigned rows = (unsigned)(rows_total - row0 < R ? rows_total - row0 : R);
+    const unsigned total = rows * len;
+    const float *in0 = cx.f->in0;
+    // two float4s of input 0 in flight per trip (the chain is a long stretch of code the compiler does not move loads
+    // across): sum(exp(X), 1) on 10^7 x 10 0.129 ms with one, 0.109 with two, 0.123 with four (four inlined copies of the
+    // interpreter)
+    const unsigned nvec = total / 4;
+    for (unsigned v = threadIdx.x; v < nvec; v += 512) {
+        const bool two = v + 256 < nvec;
+        const v4f x0 = __builtin_nontemporal_load((const v4f *)(in0 + cx.base + (size_t)v * 4));
+        const v4f x1 = two ? __builtin_nontemporal_load((const v4f *)(in0 + cx.base + (size_t)(v + 256) * 4)) : v4f{0, 0, 0, 0};
+        staged_run<4>(cx, v * 4, x0);
+        if (two) staged_run<4>(cx, (v + 256) * 4, x1);
+    }
+    for (unsigned e = nvec * 4 + threadIdx.x; e < total; e += 256) staged_run<1>(cx, e, v4f{in0[cx.base + e], 0, 0, 0});
+    __syncthreads();
+    for (unsigned r = threadIdx.x; r < rows; r += 256) {
+        const float *p = slab + r * pitch;
+        float a0 = np::dev::r_identity<SINK>(), a1 = a0;
+        unsigned c = 0;
+        for (; c + 1 < len; c += 2) {
+            a0 = np::dev::r_combine<SINK>(a0, p[c]);
+            a1 = np::dev::r_combine<SINK>(a1, p[c + 1]);
+        }
+        if (c < len) a0 = np::dev::r_combine<SINK>(a0, p[c]);
+        float v = np::dev::r_combine<SINK>(a0, a1);
+        if (mean_div != 0.0f) v = __fdiv_rn(v, mean_div);
+        out[row0 + r] = v;
+    }
+}
+
+// very many short rows: the staged kernel (the same window as reduce_rows_staged in np_reduce.hip, which the op-by-op
+// path takes for these shapes — the two must agree for the fused result to stay bit-identical)
+static bool fused_rows_staged_shape(size_t rows, size_t cols) {
+    return cols > 4 && cols <= 48 && rows * cols >= (size_t(8) << 20);
+}
+
 static bool fused_axis_shape_ok(size_t rows, size_t cols, int axis) {
     if (rows * cols >= (size_t(1) << 32)) return false;
+    if (axis == 1 && fused_rows_staged_shape(rows, cols)) return true;
     if (axis == 1) return cols >= 16 && (rows >= 128 || rows * cols >= (size_t(1) << 20));   // a lane group / wave / workgroup (or several) per row
     return rows >= 32 && cols / (cols % 4 == 0 ? 4 : 1) >= 32;   // first axis: a lane per column slot, waves interleaved over rows
 }
@@ -1451,6 +1585,31 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
 #endif
     hipStream_t s = np::stream();
     if (force_full) light = false;
+    if (axis_mode == 1 && fused_rows_staged_shape(rows, cols)) {
+        // (needs input 0 as a 16-byte aligned full array; anything else — a chain that starts from a scalar, a view at an
+        // odd offset — is materialised and handed to np_reduce_axis like the shapes fused_axis_shape_ok turns away)
+        if (!f.in0 || ((uintptr_t)f.in0 & 15u) != 0) {
+            np::Scratch tmp;
+            if (int rc = tmp.alloc(n * sizeof(float))) return rc;
+            if (int rc = fused_chain_impl(inputs, input_kinds, n_inputs, ops, n_ops, (float *)tmp.ptr, rows, cols, -1)) return rc;
+            const int rop = mean_div != 0.0f ? NP_MEAN : sink;
+            return np_reduce_axis(rop, (const float *)tmp.ptr, rows, cols, 1, out, 0);
+        }
+        const unsigned pitch = (unsigned)cols | 1u;
+        unsigned R = (8192u / pitch) / 256u * 256u;
+        if (R < 256) R = 256;
+        const size_t blocks = (rows + R - 1) / R;
+        const size_t lds = (size_t)R * pitch * sizeof(float);
+        const unsigned magic = (unsigned)((0x100000000ull + cols - 1) / cols);
+#define NP_FRS(SINK_) fused_chain_rows_staged_kernel<SINK_><<<(unsigned)blocks, 256, lds, s>>>(f, out, rows, (unsigned)cols, R, magic, mean_div)
+        if (sink == NP_SUM) NP_FRS(NP_SUM);
+        else if (sink == NP_PROD) NP_FRS(NP_PROD);
+        else if (sink == NP_MIN) NP_FRS(NP_MIN);
+        else NP_FRS(NP_MAX);
+#undef NP_FRS
+        NP_LAUNCH_CHECK("fused_chain_rows_staged_kernel");
+        return NP_OK;
+    }
     if (axis_mode == 1) {
         // last axis: a wave per row while rows are plentiful and short enough to leave a wave busy, else a workgroup
         const bool block = cols >= 16384 || rows < (size_t)np::num_cus() * 16;

@@ -164,7 +164,9 @@ def test_fused_broadcast_index_arithmetic(cols, hip):
 
 
 @pytest.mark.parametrize("shape", [(25000, 4000), (4096, 1000), (300, 70_000), (5000, 257), (1000, 66), (129, 64), (2000, 48), (50, 1000),
-                                   (100_000, 12), (7, 5), (3, 1_000_000), (64, 128, 96), (1000,)])
+                                   (100_000, 12), (7, 5), (3, 1_000_000), (64, 128, 96), (1000,),
+                                   # very many short rows: fused_chain_rows_staged_kernel (slabs through LDS), ragged last slab
+                                   (900_001, 10), (530_003, 16), (180_001, 47)])
 def test_chain_ending_in_an_axis_reduction(shape, hip):
     """sum / max / min / mean / prod over the last axis (any rank) and the first axis (2-d) as the chain's
     last step (np_fused_chain_reduce_axis: row-sink and column-sink kernels, or the temporary + reduce
@@ -204,6 +206,10 @@ def test_chain_ending_in_an_axis_reduction(shape, hip):
                 got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
                 assert got.shape == np.asarray(ref).shape, (label, shape, axis, op)
                 assert (np.abs(got - ref) <= 1e-5 * np.maximum(scale, 1e-30)).all(), (label, shape, axis, op)
+                if nd == 2 and axis == 1 and 4 < last <= 48 and a.size >= (8 << 20):
+                    # the staged kernel repeats reduce_rows_staged's fold order: bit-identical to the op-by-op sums
+                    stepwise = getattr(NDArray, op)(eager(ga), axis)
+                    assert _same(got, stepwise.cpu().numpy()), (label, shape, axis, op, "fused vs op-by-op")
     # prod: values near 1 so that long rows neither overflow nor vanish.  Factors this close to 1 are the
     # worst case for any fp32 product TREE: a pairwise fp32 product of 10^6 of them is 9e-4 off fp64 on the
     # CPU as well (the rounding of products straddling 1.0 does not average out), ~1e-9 per factor

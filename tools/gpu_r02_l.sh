@@ -1,4 +1,5 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_statistics.py tests/test_gpu_argreduce.py -x -q -m gpu 2>&1 | tail -3
-NP_FUZZ_CASES=500 NP_FUZZ_SEED=41 timeout 900 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu -k "axis" 2>&1 | tail -2
-timeout 300 python tools/short_rows_reduce_ab.py 2>&1 | tail -8
+mkdir -p gpurun_out/r02l
+for v in new; do echo "== $v"; NP_HIP_LIB=$PWD/build/ab/libnp_hip_$v.so timeout 600 python tools/fused_short_rows_ab.py; done > gpurun_out/r02l/fused_short_rows_ab2.log 2>&1
+cat gpurun_out/r02l/fused_short_rows_ab2.log
+timeout 900 python -m pytest tests/test_gpu_fusion.py -x -q -m gpu 2>&1 | tail -2
