@@ -999,9 +999,10 @@ __device__ __forceinline__ void binary_dispatch(int op, float (&acc)[N], const f
 // load of the next array operand is issued as soon as the previous one has been consumed, so it is
 // in flight while the steps in between compute; with input 0 that keeps two loads outstanding per
 // thread without holding every input in registers (which cost occupancy: 6 inputs x 8 values).
-template <int U, int G, typename I>
+template <int U, int G, typename I, bool RAGGED = false>
 __device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p, int idx, const I (&first)[U],
-                                            const I (&row)[U], const I (&col)[U], const bool (&live)[U]) {
+                                            const I (&row)[U], const I (&col)[U], const bool (&live)[U],
+                                            I ragged_cols = 0) {
     if (idx == FUSED_IDX_FULL) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1015,13 +1016,24 @@ __device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p,
             }
         }
     } else if (idx == FUSED_IDX_ROW) {
-        // one row of `cols` floats, re-read by every result row: cache-resident, plain loads.  The
-        // float4 path is only taken when cols % 4 == 0 (a slot never straddles two rows).
+        // one row of `cols` floats, re-read by every result row: cache-resident, plain loads.  With cols % 4 != 0
+        // (ragged_cols = cols, else 0) a slot may straddle two rows: those few slots walk the row with wrap-around.
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (G == 4) {
                 v4f t = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-                if (live[u]) t = *(const v4f_u *)(p + (size_t)col[u]);
+                if (live[u]) {
+                    if (!RAGGED || col[u] + 3 < ragged_cols) {
+                        t = *(const v4f_u *)(p + (size_t)col[u]);
+                    } else {
+                        I c = col[u];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            t[e] = p[(size_t)c];
+                            c = c + 1 == ragged_cols ? (I)0 : c + 1;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dst[u * 4 + e] = t[e];
             } else {
@@ -1030,6 +1042,17 @@ __device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p,
         }
     } else {
         // one value per result row (column operand) or one value in all (0-d device scalar)
+        if (RAGGED && G == 4 && idx == FUSED_IDX_COL) {   // uniform: a slot that runs into the next row takes that row's value for its tail
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool straddles = live[u] && col[u] + 3 >= ragged_cols;
+                const float t0 = live[u] ? p[(size_t)row[u]] : 0.0f;
+                const float t1 = straddles ? p[(size_t)row[u] + 1] : t0;
+#pragma unroll
+                for (int e = 0; e < G; ++e) dst[u * G + e] = (straddles && col[u] + e >= ragged_cols) ? t1 : t0;
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float t = live[u] ? p[idx == FUSED_IDX_COL ? (size_t)row[u] : (size_t)0] : 0.0f;
@@ -1041,7 +1064,7 @@ __device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p,
 
 // VACC: the sink accumulates per register element (rv[u * G + e], for column reductions where every
 // element of a slot belongs to a different result) instead of into the one scalar racc.
-template <int U, int G, bool LIGHT, typename I, bool VACC>
+template <int U, int G, bool LIGHT, typename I, bool VACC, bool RAGGED = false>
 __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict__ out, I elem0, I nslots, I tid,
                                                 I stride, float &racc, float (&rv)[U * G]) {
     constexpr int N = U * G;
@@ -1051,6 +1074,8 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
     const float scalar0 = f->scalar0;
     const int first_prefetch_idx = f->first_prefetch_idx;
     const I cols = (I)f->cols;
+    const I ragged_cols = RAGGED ? cols : (I)0;   // float4 slots of a broadcast with cols % 4 != 0 may straddle rows (a kernel variant of its own:
+                                                  // with the extra code in the common kernel, aligned exp(X) + col lost 9 %)
     const unsigned div_m = f->div_m, div_s1 = f->div_s1, div_s2 = f->div_s2;
     for (I base = 0; base < nslots; base += stride * U) {
         I first[U], row[U], col[U];
@@ -1080,7 +1105,7 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
             for (int e = 0; e < N; ++e) acc[e] = scalar0;
         }
         if (first_prefetch) {
-            fused_fetch<U, G, I>(nxt, first_prefetch, first_prefetch_idx, first, row, col, live);
+            fused_fetch<U, G, I, RAGGED>(nxt, first_prefetch, first_prefetch_idx, first, row, col, live, ragged_cols);
         } else {
 #pragma unroll
             for (int e = 0; e < N; ++e) nxt[e] = 0.0f;
@@ -1122,7 +1147,7 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
                 body[e] = (size_t)first[e / G] < o.body_end;
             }
             if (o.src_kind == FUSED_SRC_STREAM && o.prefetch)
-                fused_fetch<U, G, I>(nxt, o.prefetch, o.prefetch_idx, first, row, col, live);
+                fused_fetch<U, G, I, RAGGED>(nxt, o.prefetch, o.prefetch_idx, first, row, col, live, ragged_cols);
             binary_dispatch<N, LIGHT>(o.op, acc, oth, o.swap != 0, o.quirk != 0, body);
         }
         if constexpr (VACC) {
@@ -1175,11 +1200,11 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
     }
 }
 
-template <int U, int G, bool LIGHT, typename I>
+template <int U, int G, bool LIGHT, typename I, bool RAGGED = false>
 __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out, I elem0, I nslots, I tid,
                                            I stride, float &racc) {
     float unused[U * G];
-    fused_span_impl<U, G, LIGHT, I, false>(f, out, elem0, nslots, tid, stride, racc, unused);
+    fused_span_impl<U, G, LIGHT, I, false, RAGGED>(f, out, elem0, nslots, tid, stride, racc, unused);
 }
 
 __device__ __forceinline__ float sink_identity(int sink) {
@@ -1289,7 +1314,7 @@ __global__ __launch_bounds__(256) void fused_chain_cols_kernel(FusedArgs by_valu
     }
 }
 
-template <bool VEC, int U, bool LIGHT, typename I>
+template <bool VEC, int U, bool LIGHT, typename I, bool RAGGED = false>
 __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, float *__restrict__ out, I n) {
     (void)by_value;   // first kernel argument: lives at offset 0 of the kernarg segment
     FusedArgsK f = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1299,7 +1324,7 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, fl
     float racc = sink == NP_SUM ? 0.0f : sink == NP_PROD ? 1.0f : sink == NP_MIN ? INFINITY : -INFINITY;
     if constexpr (VEC) {
         const I nvec = n / 4;
-        fused_span<U, 4, LIGHT, I>(f, out, (I)0, nvec, tid, stride, racc);
+        fused_span<U, 4, LIGHT, I, RAGGED>(f, out, (I)0, nvec, tid, stride, racc);
         fused_span<1, 1, LIGHT, I>(f, out, nvec * 4, n - nvec * 4, tid, stride, racc);   // ragged tail (< 4 elements)
     } else {
         fused_span<U, 1, LIGHT, I>(f, out, (I)0, n, tid, stride, racc);   // 4-byte aligned views
@@ -1483,8 +1508,9 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         if (!inputs[i]) return np::fail(NP_ERR_INVALID, "np_fused_chain: null input %d", i);
         switch (input_kinds[i]) {
             case NP_FULL: break;
-            case NP_ROW: vec = vec && cols % 4 == 0; broadcast = true; break;
-            case NP_COL: vec = vec && cols % 4 == 0; broadcast = true; break;
+            // (float4 slots also when cols % 4 != 0, from 4 columns up: a slot then straddles at most two rows — fused_fetch)
+            case NP_ROW: vec = vec && (cols % 4 == 0 || (cols >= 4 && axis_mode < 0)); broadcast = true; break;
+            case NP_COL: vec = vec && (cols % 4 == 0 || (cols >= 4 && axis_mode < 0)); broadcast = true; break;
             case NP_SCALAR:
             case NP_HOST_SCALAR: break;
             default: return np::fail(NP_ERR_INVALID, "np_fused_chain: unknown operand kind %d", input_kinds[i]);
@@ -1705,7 +1731,16 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     // ms, exp(a)*b+2 0.204-0.213 -> 0.197-0.203 (round 1, with the 14-instruction expf, one slot was ahead for the
     // light interpreter; tools/fused_ab.py with FUSED_AB_BCAST=1, profiles/r02/fused_u_ab.log)
     const int fu = fu_env ? fu_env : 2;
-    if (!vec) {
+    if (vec && broadcast && cols % 4 != 0) {   // float4 slots that may straddle rows: the RAGGED variant of the two-slot kernels
+        const unsigned grid = reduce_blocks ? reduce_blocks : grid_for(n / 4 + 1, 2, 0);
+        if (small) {
+            if (light) fused_chain_kernel<true, 2, true, uint32_t, true><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);
+            else fused_chain_kernel<true, 2, false, uint32_t, true><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);
+        } else {
+            if (light) fused_chain_kernel<true, 2, true, uint64_t, true><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);
+            else fused_chain_kernel<true, 2, false, uint64_t, true><<<grid, 256, 0, s>>>(f, out, (uint64_t)n);
+        }
+    } else if (!vec) {
         if (light) NP_FC(false, 2, true); else NP_FC(false, 2, false);
     } else if (fu == 1) {
         if (light) NP_FC(true, 1, true); else NP_FC(true, 1, false);
