@@ -1241,6 +1241,11 @@ __global__ __launch_bounds__(256) void fused_chain_rows_kernel(FusedArgs by_valu
     for (I r = first_row; r < rows; r += row_stride) {
         float racc = sink_identity(sink);
         fused_span<2, G, LIGHT, I>(f, out, r * cols + slot0 * G, nslots, lane, width, racc);
+        if constexpr (G == 4) {   // a row of cols % 4 != 0 floats: its last 1-3 elements, one per lane, behind the float4 slots
+            const I tail = cols - (cols / 4) * 4;
+            if (tail != 0 && (!BLOCK || blockIdx.y == gridDim.y - 1))
+                fused_span<1, 1, LIGHT, I>(f, out, r * cols + (cols / 4) * 4, tail, lane, width, racc);
+        }
         if constexpr (BLOCK) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) racc = sink_combine(sink, racc, __shfl_down(racc, off, 64));
@@ -1639,7 +1644,9 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     if (axis_mode == 1) {
         // last axis: a wave per row while rows are plentiful and short enough to leave a wave busy, else a workgroup
         const bool block = cols >= 16384 || rows < (size_t)np::num_cus() * 16;
-        const size_t slots = cols / (cols % 4 == 0 ? 4 : 1);
+        // float4 slots also for rows of cols % 4 != 0 floats (dword-aligned accesses; the kernel takes the 1-3 leftover
+        // elements of each row one per lane): such rows used to run one ELEMENT per slot
+        const size_t slots = cols / 4;
         unsigned L = 64;                                   // ~2 slots per lane per trip
         while (L > 4 && (size_t)L >= slots) L >>= 1;
         size_t grid = block ? rows : (rows + 4 * (64 / L) - 1) / (4 * (64 / L));
@@ -1664,13 +1671,8 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         const float div = chunks > 1 ? 0.0f : mean_div;
         const dim3 grid2((unsigned)grid, (unsigned)chunks);
 #define NP_FR(G_, LIGHT_, BLOCK_) fused_chain_rows_kernel<G_, LIGHT_, BLOCK_, uint32_t><<<grid2, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, L, (uint32_t)chunk_slots, div)
-        if (cols % 4 == 0) {
-            if (light) { if (block) NP_FR(4, true, true); else NP_FR(4, true, false); }
-            else { if (block) NP_FR(4, false, true); else NP_FR(4, false, false); }
-        } else {
-            if (light) { if (block) NP_FR(1, true, true); else NP_FR(1, true, false); }
-            else { if (block) NP_FR(1, false, true); else NP_FR(1, false, false); }
-        }
+        if (light) { if (block) NP_FR(4, true, true); else NP_FR(4, true, false); }
+        else { if (block) NP_FR(4, false, true); else NP_FR(4, false, false); }
 #undef NP_FR
         NP_LAUNCH_CHECK("fused_chain_rows_kernel");
         if (chunks > 1) {
