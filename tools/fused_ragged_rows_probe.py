@@ -12,7 +12,7 @@ from numpower_amd.ndarray import NDArray
 
 lib = _lib.load()
 _lib.check(lib.np_init(0))
-for rows, cols in ((25000, 4000), (25000, 4001), (33333, 3001), (400_000, 250), (400_000, 251), (5000, 20_001), (300, 333_335)):
+for rows, cols in ((25000, 4000), (25000, 4001), (33333, 3001), (400_000, 250), (400_000, 256), (1_000_000, 100), (1_600_000, 64), (100_000, 1000), (50_000, 2000), (5000, 20_001), (300, 333_335)):
     x = synth.uniform((rows, cols), 3, -1.0, 1.0)
     gx = NDArray.array(x).gpu()
     build = lambda: gx.lazy().exp().sum(axis=1)
