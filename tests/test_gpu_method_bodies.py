@@ -121,3 +121,36 @@ def test_method_bodies_builds_and_refuses_to_run_without_a_device(tmp_path):
     proc = subprocess.run([str(EXE), str(tmp_path / "o.bin")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert proc.returncode == 1
     assert "gpu() failed" in proc.stderr
+
+
+# The unary PHP_METHODs whose device branch is `rtn = NDArrayMathGPU_ElementWise(nda, cuda_float_<name>);` in the reference's
+# numpower.c.  Data: the call sites a drop-in has to serve (abs goes through NDArray_Abs, rsqrt / exp2 have no working GPU
+# branch there).  test_method_table_matches_the_reference_call_sites re-derives it from the reference when that is present.
+REFERENCE_UNARY_CALL_SITES = sorted(
+    "arccos arccosh arcsin arcsinh arctan arctanh ceil cos cosh degrees exp expm1 fix floor log log10 log1p log2 logb negate "
+    "positive radians reciprocal rint sign sin sinc sinh sqrt tan tanh trunc".split())
+
+
+def _method_table_names():
+    import re
+    src = (ROOT / "ext" / "method_bodies.c").read_text()
+    table = src[src.index("static const UnaryMethod kUnary[]"):]
+    table = table[:table.index("};")]
+    return sorted(re.findall(r'\{"(\w+)",\s*cuda_float_(\w+),', table))
+
+
+def test_method_table_covers_every_unary_call_site():
+    """CPU tier: ext/method_bodies.c hands the driver the same cuda_float_* pointer under every name the reference does."""
+    pairs = _method_table_names()
+    assert all(label == sym for label, sym in pairs)
+    assert [label for label, _ in pairs] == REFERENCE_UNARY_CALL_SITES
+    assert [u[0] for u in sorted(UNARY)] == REFERENCE_UNARY_CALL_SITES          # and the GPU test checks every one of them
+
+
+def test_method_table_matches_the_reference_call_sites():
+    import re
+    ref = Path("/root/reference/numpower.c")
+    if not ref.exists():
+        pytest.skip("reference tree not present on this box")
+    names = set(re.findall(r"NDArrayMathGPU_ElementWise\(\s*nda\s*,\s*cuda_float_(\w+)\s*\)", ref.read_text(errors="ignore")))
+    assert sorted(names) == REFERENCE_UNARY_CALL_SITES
