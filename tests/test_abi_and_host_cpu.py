@@ -185,3 +185,20 @@ def test_manipulation_and_order_stat_argument_checks_on_cpu_arrays():
                lambda: NDArray.diag(v), lambda: NDArray.median(v), lambda: NDArray.quantile(v, 0.5)):
         with pytest.raises(Error, match="only computes on the GPU"):
             fn()
+
+
+def test_tuning_knobs_validate_their_argument_without_a_device():
+    """np_*_set_variant are plain setters (no device work): a bad code is an error with a message, a good one is accepted,
+    and the defaults are restored — on a box without a GPU too."""
+    import ctypes as C
+    from numpower_amd import _lib
+    lib = _lib.load()
+    lib.np_last_error.restype = C.c_char_p
+    assert lib.np_select_set_variant(-1) != 0 and b"np_select_set_variant" in lib.np_last_error()
+    for ok in (0, 2048, 767, 1):
+        assert lib.np_select_set_variant(ok) == 0
+    assert lib.np_runtime_set_variant(3) != 0 and b"np_runtime_set_variant" in lib.np_last_error()
+    assert lib.np_runtime_set_variant(-1) != 0
+    for ok in (0, 1, 2):
+        assert lib.np_runtime_set_variant(ok) == 0
+    assert lib.np_select_last_path(None) != 0      # null output: refused before any device call
