@@ -590,10 +590,42 @@ def bench_extras(dist: Dist, steps, warmup):
     return ex
 
 
+XGMI_LINK_GBPS = 153.0   # MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU; a peer's slab arrives over that peer's own link
+
+
+def _config5_report(dist, per, n, legs, slab_bytes, err, how):
+    """The common shape of config 5's two reports.  legs: {name: wall seconds per step (max over ranks)}."""
+    total = per * dist.n
+    flop = 2.0 * total * n ** 3
+    out = {"workload": "512 x (1024x1024) fp32 batched matmul, %d slab(s) of %d, %s" % (dist.n, per, how),
+           "scaling": "strong", "allgather_bytes_per_rank": slab_bytes,
+           "ms_per_step": {k: v * 1e3 for k, v in legs.items()},
+           "compute_only_GFLOPs": flop / legs["compute_only"] / 1e9,
+           "gathered_GFLOPs": flop / legs["gathered"] / 1e9,
+           "overlapped_GFLOPs": {k: flop / v / 1e9 for k, v in legs.items() if k.startswith("overlapped")},
+           "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6)}
+    best = min((v, k) for k, v in legs.items() if k != "compute_only")
+    out["best_gathered_form"] = best[1]
+    out["best_gathered_GFLOPs"] = flop / best[0] / 1e9
+    out["best_gathered_vs_compute_only"] = legs["compute_only"] / best[0]
+    if dist.n > 1:
+        # every rank receives (n - 1) slabs, each over its own link: the rate one link has to sustain
+        exposed = max(legs["gathered"] - legs["compute_only"], 1e-9)
+        out["xgmi"] = {"model_link_GBps": XGMI_LINK_GBPS,
+                       "model_gather_ms": slab_bytes / XGMI_LINK_GBPS / 1e6,
+                       "gather_alone_ms": exposed * 1e3,
+                       "link_GBps_gather_alone": slab_bytes / exposed / 1e9,
+                       "link_GBps_best_form_whole_step": slab_bytes / best[0] / 1e9,
+                       "note": "per-link rate = one slab / time; 'gather alone' = gathered - compute_only"}
+    return out
+
+
 def bench_config5(dist: Dist, steps, warmup):
-    """BASELINE config 5: 512 x (1024 x 1024) batched matmul, batch sharded over the ranks in
-    contiguous slabs, one RCCL all-gather of the result slabs (strong scaling; compute-only and
-    gathered throughput)."""
+    """BASELINE config 5 with torch.distributed as the plumbing: 512 x (1024 x 1024) batched matmul, batch sharded
+    over the ranks in contiguous slabs (strong scaling).  Legs: compute only; compute + ONE all-gather of the result
+    slabs behind it; and the overlapped pipeline of numpower_amd.parallel (slab in 2 / 4 / 8 pieces, each piece's
+    point-to-point exchange on the process group's stream while the next piece computes)."""
+    from numpower_amd import parallel
     torch = dist.torch
     total, n = 512, 1024
     per = total // dist.n
@@ -610,37 +642,56 @@ def bench_config5(dist: Dist, steps, warmup):
     lib = load()
     from numpower_amd._lib import check
 
+    def gemm(a, b, out):
+        check(lib.np_sgemm_strided_batched(a.shape[0], n, n, n, a.data_ptr(), n * n, b.data_ptr(), n * n,
+                                           out.data_ptr(), n * n))
+
     def compute():
-        check(lib.np_sgemm_strided_batched(per, n, n, n, A.data_ptr(), n * n, B.data_ptr(), n * n,
-                                           mine.data_ptr(), n * n))
+        gemm(A, B, mine)
 
     def compute_and_gather():
         compute()
         dist.dist.all_gather_into_tensor(Cfull.view(-1), mine.reshape(-1))
 
-    flop = 2.0 * total * n ** 3
-    wall_c, _ = timed(dist, compute, steps, warmup)
-    wall_g, _ = timed(dist, compute_and_gather, steps, warmup)
-    # parity: one matrix of a peer's slab, after the gather, against fp64
+    def overlapped(chunks):
+        def step():
+            handles = []
+            for plo, cnt in parallel.pieces_of(per, chunks):
+                gemm(A[plo:plo + cnt], B[plo:plo + cnt], mine[plo:plo + cnt])
+                handles.extend(parallel.exchange_piece(dist.dist, Cfull, per, plo, cnt))
+            for h in handles:
+                h.wait()
+        return step
+
+    legs = {"compute_only": timed(dist, compute, steps, warmup)[0] / steps,
+            "gathered": timed(dist, compute_and_gather, steps, warmup)[0] / steps}
+    for chunks in (2, 4, 8):
+        if chunks <= per:
+            Cfull.zero_()
+            legs["overlapped_%d" % chunks] = timed(dist, overlapped(chunks), steps, warmup)[0] / steps
+    # parity: one matrix of a peer's slab, as the LAST (overlapped) leg left it, against fp64
     peer = (dist.rank + 1) % dist.n
-    j = peer * per
+    j = peer * per + per - 1
     Ah = synth.uniform((n, n), 12_000 + j, -1.0, 1.0).astype(np.float64)
     Bh = synth.uniform((n, n), 13_000 + j, -1.0, 1.0).astype(np.float64)
     err = float((np.abs(Cfull[j].cpu().numpy().astype(np.float64) - Ah @ Bh) / (np.abs(Ah) @ np.abs(Bh))).max())
-    return {"workload": "512 x (1024x1024) fp32 batched matmul, %d slab(s) of %d" % (dist.n, per),
-            "scaling": "strong", "compute_only_GFLOPs": flop * steps / wall_c / 1e9,
-            "gathered_GFLOPs": flop * steps / wall_g / 1e9, "allgather_bytes_per_rank": per * n * n * 4,
-            "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6)}
+    return _config5_report(dist, per, n, legs, per * n * n * 4, err, "torch.distributed (RCCL) collectives")
 
 
-def bench_config5_abi(dist: Dist, steps, warmup, own_comm_port=None):
+def bench_config5_abi(dist: Dist, steps, warmup, own_comm_port=None, world1=False):
     """BASELINE config 5 the way a C / PHP host writes it — no torch tensor, no torch collective: the rank's
-    slab of the batch is one np_sgemm_strided_batched launch written in place into the full result buffer,
-    then ONE np_allgather (RCCL over xGMI behind the C ABI) on the same stream.  own_comm_port: bring up a
-    communicator just for this leg (torch mode: the job's collectives belong to torch.distributed)."""
+    slab of the batch is written in place into the full result buffer by np_sgemm_strided_batched, and
+      gathered       ONE np_allgather behind it on the same stream (no overlap possible)
+      two_stream     np_sgemm_strided_batched_allgather(chunks = 1): the same all-gather on the communication stream
+      p2p_1          ... chunks = 1, moved as one grouped send/recv exchange instead of ncclAllGather
+      overlapped_k   ... the slab in k pieces, piece c's exchange travelling while piece c + 1 is computed
+    own_comm_port: bring up a communicator just for this leg (torch mode: the job's collectives belong to
+    torch.distributed).  world1: a one-rank communicator on a single GPU — nothing travels, but the whole mechanism
+    (second stream, events, chunked launches) runs, so `overlapped_k` ~ `compute_only` shows what the pipeline
+    itself costs."""
     from numpower_amd._lib import check
     lib = load()
-    total, n = 512, 1024
+    total, n = (64, 1024) if world1 else (512, 1024)
     per = total // dist.n
     lo = dist.rank * per
     if own_comm_port is not None:
@@ -664,10 +715,19 @@ def bench_config5_abi(dist: Dist, steps, warmup, own_comm_port=None):
             compute()
             check(lib.np_allgather(mine, full.ptr, slab_bytes))
 
-        flop = 2.0 * total * n ** 3
-        wall_c, _ = timed(dist, compute, steps, warmup)
-        wall_g, _ = timed(dist, compute_and_gather, steps, warmup)
-        j = ((dist.rank + 1) % dist.n) * per           # one matrix of a PEER's slab, after the gather, against fp64
+        def pipelined(chunks, mode):
+            return lambda: check(lib.np_sgemm_strided_batched_allgather(per, n, n, n, A.ptr, n * n, B.ptr, n * n,
+                                                                        full.ptr, chunks, mode))
+
+        legs = {"compute_only": timed(dist, compute, steps, warmup)[0] / steps,
+                "gathered": timed(dist, compute_and_gather, steps, warmup)[0] / steps,
+                "two_stream": timed(dist, pipelined(1, 1), steps, warmup)[0] / steps,
+                "p2p_1": timed(dist, pipelined(1, 2), steps, warmup)[0] / steps}
+        for chunks in (2, 4, 8):
+            if chunks <= per:
+                check(lib.np_memset0(full.ptr, total * n * n * 4))
+                legs["overlapped_%d" % chunks] = timed(dist, pipelined(chunks, 0), steps, warmup)[0] / steps
+        j = ((dist.rank + 1) % dist.n) * per + per - 1  # one matrix of a PEER's slab, as the last overlapped leg left it
         got = np.empty((n, n), dtype=np.float32)
         check(lib.np_memcpy_d2h(got.ctypes.data, full.ptr + j * n * n * 4, n * n * 4))
         Ah = synth.uniform((n, n), 12_000 + j, -1.0, 1.0).astype(np.float64)
@@ -679,10 +739,11 @@ def bench_config5_abi(dist: Dist, steps, warmup, own_comm_port=None):
         if own_comm_port is not None:
             with _stdout_to_devnull():
                 lib.np_comm_destroy()
-    return {"workload": "512 x (1024x1024) fp32 batched matmul, %d slab(s) of %d, gathered with np_allgather (C ABI)" % (dist.n, per),
-            "scaling": "strong", "compute_only_GFLOPs": flop * steps / wall_c / 1e9,
-            "gathered_GFLOPs": flop * steps / wall_g / 1e9, "allgather_bytes_per_rank": slab_bytes,
-            "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6)}
+    rep = _config5_report(dist, per, n, legs, slab_bytes, err, "np_comm_* (RCCL behind the C ABI)")
+    if world1:
+        rep["workload"] = ("64 x (1024x1024) fp32 batched matmul = ONE rank's slab of config 5 on a one-rank communicator: "
+                           "nothing travels, the two-stream pipeline itself is what is measured")
+    return rep
 
 
 def _diag_add(dist, label):
@@ -761,6 +822,11 @@ def main():
         elif not dist.use_torch:
             try:
                 extras = bench_extras(dist, max(10, args.steps // 2), args.warmup)
+                try:
+                    extras["config5_one_rank_slab_c_abi"] = bench_config5_abi(dist, max(5, args.steps // 5), 2,
+                                                                                own_comm_port=_free_port(), world1=True)
+                except Exception as e:
+                    extras["config5_one_rank_slab_c_abi"] = {"error": repr(e)}
                 add = extras["add_1e8"]
                 result["secondary"] = {"metric": "GB/s elementwise add 10^8 fp32", "value": add["GBps"],
                                        "unit": "GB/s", "roofline": add["roofline"],

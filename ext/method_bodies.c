@@ -14,6 +14,9 @@
  *                                                                                    numpower.c:3364-3389
  *   sum / prod           reduce(nda, &axis_i, NDArray_Add_Float) | NDArray_Sum_Float numpower.c:4620-4645
  *   matmul / dot         NDArray_Matmul(nda, ndb), NDArray_Dot(nda, ndb)
+ *   sharded batched matmul  NDArray_CommInit(rank, world, endpoint); NDArray_ShardedBatchedMatmul(a, b, batch, mode)
+ *                        (this project's own extension, SURVEY.md section 8e: the reference has no multi-device
+ *                        code; run here as a world of one rank — kept, gathered and in 3 overlapped pieces)
  *   gpu() / cpu()        NDArray_ToGPU / NDArray_ToCPU
  *
  * Zend argument parsing (zval -> NDArray*) and RETURN_NDARRAY are the only parts of a method that are
@@ -23,11 +26,13 @@
  *
  * Usage: method_bodies <output file>
  */
+#define _POSIX_C_SOURCE 200809L   /* getpid() under -std=c99 */
 #include <stdbool.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "numpower_host.h"
 #include "hip_math.h"
@@ -234,6 +239,37 @@ int main(int argc, char **argv) {
     r = NDArray_Dot(x, b);
     dump("dot", r);
     if (r) NDArray_FREE(r);
+
+    /* the sharded batched matmul as a PHP method would issue it (world of one: the communicator, the second stream
+     * and the chunk pipeline all run; the transfers have no peer to go to) */
+    {
+        int shape3[3] = {6, 33, 47}, shape3b[3] = {6, 47, 29};
+        NDArray *h3a = input(6 * 33, 47, 106, -1, 1), *h3b = input(6 * 47, 29, 107, -1, 1);
+        NDArray *ha3 = NDArray_FromHostBuffer(NDArray_FDATA(h3a), shape3, 3), *hb3 = NDArray_FromHostBuffer(NDArray_FDATA(h3b), shape3b, 3);
+        NDArray *a3 = to_gpu(ha3), *b3 = to_gpu(hb3);
+        char endpoint[64];
+        snprintf(endpoint, sizeof endpoint, "/tmp/np_method_bodies_%ld.id", (long) getpid());
+        if (NDArray_CommInit(0, 1, endpoint) != 0) {
+            fprintf(stderr, "method_bodies: NDArray_CommInit failed: %s\n", numpower_host_last_error());
+            g_failed = 1;
+        } else {
+            static const struct { const char *name; int mode; } kShard[] = {
+                {"sharded_keep", NP_SHARD_KEEP}, {"sharded_gather", NP_SHARD_GATHER}, {"sharded_overlap3", 3}};
+            for (size_t i = 0; i < sizeof kShard / sizeof kShard[0]; i++) {
+                r = NDArray_ShardedBatchedMatmul(a3, b3, 6 * NDArray_CommWorld(), kShard[i].mode);
+                dump(kShard[i].name, r);
+                if (r) NDArray_FREE(r);
+            }
+            r = NDArray_ShardedBatchedMatmul(a3, b3, 7, NP_SHARD_GATHER);   /* shares that do not add up: thrown, NULL */
+            if (r != NULL || strstr(numpower_host_last_error(), "Batch of 7 is not 1 slab(s) of 6") == NULL) {
+                fprintf(stderr, "method_bodies: bad batch was not refused (%s)\n", numpower_host_last_error());
+                g_failed = 1;
+            }
+            if (NDArray_CommDestroy() != 0) g_failed = 1;
+        }
+        NDArray_FREE(a3);  NDArray_FREE(ha3);  NDArray_FREE(h3a);
+        NDArray_FREE(b3);  NDArray_FREE(hb3);  NDArray_FREE(h3b);
+    }
 
     /* $r->cpu(): a device result brought back as a host NDArray */
     r = method_unary(x, cuda_float_exp);

@@ -21,6 +21,13 @@
  *     (The reference synchronises after every launch, cuda_math.cu:1104-1109; results are
  *     identical, only the blocking point moves to the read-back.)
  *   - no torch / PHP / Zend types anywhere in this file.
+ *   - threads: the library is one device + one stream per process, like the reference (PHP NTS, one
+ *     request = one thread).  Calls may come from several host threads: the pool and the host-result
+ *     entry points (np_reduce_all, np_all, np_count_mismatch, np_moments, np_weighted_sums,
+ *     np_order_stat, np_fused_chain_reduce) serialise internally, np_last_error() is per thread.
+ *     Every np_* call leaves the CALLING THREAD's current HIP device set to the library's device
+ *     (np_init / np_set_device) — the effect cudaSetDevice has in the reference (numpower.c:633);
+ *     a host that keeps another device current for its own work must re-select it afterwards.
  */
 #ifndef NUMPOWER_AMD_NP_HIP_H
 #define NUMPOWER_AMD_NP_HIP_H
@@ -44,7 +51,9 @@ typedef enum np_status {
 
 /* Select the device and create the library stream.  Replaces the implicit CUDA context
  * creation of the reference; np_set_device mirrors NDArray::setDevice -> cudaSetDevice
- * (numpower.c:615-635). */
+ * (numpower.c:615-635): it changes where NEW buffers and NEW work go and tears nothing down — the
+ * device used before keeps its stream (work in flight completes), its cached blocks and its live
+ * buffers, which can be freed at any time and used again after switching back. */
 int np_init(int device);
 int np_set_device(int device);
 int np_device_count(int *host_count);
@@ -357,14 +366,16 @@ int np_arange(float *out, double start, double step, size_t n);
  * result with ONE all-gather over xGMI (RCCL, loaded on demand).  All calls are enqueued on the library stream,
  * ordered with the kernels; nothing here is needed — or loaded — by a single-GPU process.
  *
- * np_comm_init   rank in [0, world); endpoint = "tcp://host:port" (rank 0 serves the RCCL id on that port;
- *                use 127.0.0.1 and a free port on one node) or a file path that does not exist yet (rank 0
- *                publishes the id there, peers poll for it; removed by np_comm_destroy).  Blocks until every
- *                rank has joined (120 s limit).  The device is the one np_init selected.
+ * np_comm_init   rank in [0, world); endpoint = "tcp://host:port" (rank 0 serves the RCCL id on that port
+ *                to peers that introduce themselves; use 127.0.0.1 and a free port on one node) or a file path
+ *                (rank 0 publishes the id there — replacing a stale file — peers poll for it; removed by
+ *                np_comm_destroy and on a failed init).  Blocks until every rank has joined (120 s limit).  The
+ *                device is the one np_init selected.
  * np_allgather   recv[r * bytes_per_rank ...] = rank r's send buffer, for every r; in place when
- *                send == recv + rank * bytes_per_rank.  Asynchronous (np_sync / a read-back waits for it).
+ *                send == recv + rank * bytes_per_rank.  Enqueued on the LIBRARY stream: ordered behind the kernels,
+ *                no overlap with them.  Asynchronous for the host (np_sync / a read-back waits for it).
  * np_comm_max    max of one host float over the ranks (timing: the slowest rank); blocks.
- * np_comm_barrier returns once every rank's stream has reached the call. */
+ * np_comm_barrier returns once every rank's streams (library and communication) have reached the call. */
 int np_comm_init(int rank, int world, const char *endpoint);
 int np_comm_rank(void);    /* -1 without a communicator */
 int np_comm_world(void);   /*  0 without a communicator */
@@ -372,8 +383,46 @@ int np_allgather(const void *dev_send, void *dev_recv, size_t bytes_per_rank);
 int np_comm_max(float value, float *host_max);
 int np_comm_barrier(void);
 int np_comm_destroy(void);
+
+/* The overlapped form.  The communicator owns a second, high-priority stream.  np_allgather_async makes that stream
+ * wait (an event, on the device) for everything the library stream has been given so far, then enqueues the gather
+ * THERE and returns: kernels launched afterwards on the library stream run while the data travels.
+ *   dev_recv_base + r * recv_stride_bytes  <-  rank r's `bytes` at dev_send, for every r  (recv_stride_bytes >= bytes;
+ *   in place when dev_send is this rank's destination).
+ * How the bytes travel:
+ *   NP_GATHER_COLLECTIVE  one ncclAllGather; needs recv_stride_bytes == bytes
+ *   NP_GATHER_P2P         one grouped exchange of ncclSend / ncclRecv pairs: each peer's piece crosses that peer's own
+ *                         xGMI link straight into place (any stride; no staging buffer, no scatter copy)
+ *   NP_GATHER_AUTO        COLLECTIVE when the destinations are contiguous, else P2P
+ * np_comm_wait makes the library stream wait (on the device; the host does not block) for everything given to the
+ * communication stream so far: call it before the gathered data is read by a kernel, np_sync or a copy.  Until then
+ * the send region must not be rewritten and the destination not read. */
+typedef enum np_gather_mode { NP_GATHER_AUTO = 0, NP_GATHER_COLLECTIVE = 1, NP_GATHER_P2P = 2 } np_gather_mode;
+int np_allgather_async(const void *dev_send, void *dev_recv_base, size_t bytes, size_t recv_stride_bytes, int mode);
+int np_comm_wait(void);
+void *np_comm_stream(void);   /* the communication stream as a raw hipStream_t (NULL without a communicator) */
+
+/* BASELINE config 5 as one call: C_full is the replicated result, world * slab matrices of M x N, contiguous.  This
+ * rank multiplies its slab (A, B: `slab` matrices, strides in elements) straight into its window
+ * C_full + rank * slab * M * N, in `chunks` pieces (as equal as they come; clipped to slab); the gather of piece c is
+ * handed to the communication stream as soon as piece c's GEMM is enqueued and travels while piece c + 1 computes.
+ * Ends with np_comm_wait(), so the next call on the library stream (or np_sync) sees the whole result.  chunks = 1
+ * is "compute, then one all-gather" on two streams (mode picks the transport); chunks > 1 always travels P2P (the
+ * pieces of a slab are one slab apart across ranks) and mode NP_GATHER_COLLECTIVE is refused.  The result is
+ * bit-identical for every chunks / mode: the same GEMM kernel computes every matrix.  The reference has no batched
+ * or multi-device matmul (linalg.c:239-242 rejects ndim > 2, numpower.c:615-635): the oracle for this call is the
+ * loop of 2-D NDArray_Matmul over the batch. */
+/* How the call above cuts a slab: piece c of `chunks` starts at item *host_lo and holds *host_count items (the first
+ * slab % chunks pieces hold one more).  Pure arithmetic; needs no device and no communicator. */
+int np_comm_piece(size_t slab, int chunks, int c, size_t *host_lo, size_t *host_count);
+int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K, const float *A, size_t stride_a,
+                                       const float *B, size_t stride_b, float *C_full, int chunks, int mode);
+
 /* testing: the rendezvous of np_comm_init alone (no device, no RCCL) — rank 0's 128 bytes reach every peer */
 int np_comm_debug_exchange(int rank, int world, const char *endpoint, void *bytes128, double timeout_s);
+/* testing: dst <- src through one grouped ncclSend / ncclRecv pair from this rank to itself on the communication
+ * stream, then np_comm_wait() — the P2P transport on a box with a single GPU */
+int np_comm_debug_sendrecv_self(const void *dev_src, void *dev_dst, size_t bytes);
 
 /* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 = whole-K plans only,
  * -2 = default planner again, -3 = default planner + always pad unaligned operands). */

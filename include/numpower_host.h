@@ -274,6 +274,27 @@ NDArray *NDArray_Inner(NDArray *nda, NDArray *ndb);   /* linalg.c:310-345: sum o
  * point: linalg.c:239-242 rejects ndim > 2 with "Stack of matrices not allowed") */
 NDArray *NDArray_BatchedMatmul(NDArray *a, NDArray *b);
 
+/* ---- the sharded form of the batched matmul (BASELINE config 5) ----
+ * One PHP process per GPU (NDArray::setDevice, numpower.c:615-635, picks the process's device; the reference has
+ * no multi-device code).  NDArray_CommInit joins the node's ranks (np_comm_init: endpoint "tcp://127.0.0.1:port"
+ * or a file path); 0 on success, -1 + a thrown Error otherwise.
+ * NDArray_ShardedBatchedMatmul: a_slab [slab x M x K] and b_slab [slab x K x N] are THIS rank's contiguous share of
+ * a batch of `batch` = slab * world products (rank r holds matrices r*slab ... (r+1)*slab - 1).
+ *   gather_mode  NP_SHARD_KEEP (0)      -> [slab x M x N], this rank's products only: no collective at all
+ *                NP_SHARD_GATHER (1)    -> [batch x M x N] replicated on every rank: the GEMM, then ONE all-gather
+ *                k >= 2                 -> the same result, slab computed in k pieces, each piece's transfer
+ *                                          overlapped with the next piece's GEMM (np_sgemm_strided_batched_allgather)
+ * Without a communicator the process is a world of one: batch must equal slab.  Errors (thrown like every other
+ * method's): device mismatch / shape mismatch with NDArray_Matmul's messages (linalg.c:219-237),
+ * "Batch of %d is not %d slab(s) of %d" when the shares do not add up. */
+#define NP_SHARD_KEEP 0
+#define NP_SHARD_GATHER 1
+int NDArray_CommInit(int rank, int world, const char *endpoint);
+int NDArray_CommDestroy(void);
+int NDArray_CommRank(void);
+int NDArray_CommWorld(void);
+NDArray *NDArray_ShardedBatchedMatmul(NDArray *a_slab, NDArray *b_slab, int batch, int gather_mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,14 +6,23 @@
 // numpower.c:615-635; it has no multi-device code at all).  RCCL does the transport; it is loaded at
 // np_comm_init() with dlopen — librccl.so is 0.5 GB and nothing else in this library needs it, so a process that
 // never shards never maps it (and a process that already has torch's copy loaded gets that one: same SONAME).
-// Collectives are enqueued on the library stream (np_get_stream), i.e. ordered with the kernels: a GEMM writing a
-// slab followed by np_allgather of that slab needs no synchronisation in between.
+// The handful of RCCL declarations used are restated below, so building libnp_hip.so needs no RCCL header either.
+//
+// Two streams.  np_allgather() enqueues on the library stream (np_get_stream), i.e. strictly behind the kernels:
+// a GEMM writing a slab followed by np_allgather of that slab needs no synchronisation in between — and gets no
+// overlap.  The *_async entry points and np_sgemm_strided_batched_allgather() put the collective on the
+// communicator's OWN stream behind an event recorded on the library stream: the GEMM of piece c+1 runs while piece c
+// travels.  At 8 GPUs config 5 moves 1.75 GiB into every GPU (>= 1.75 ms even at the 7 x 153 GB/s the xGMI mesh
+// offers) against ~1 ms of GEMM per rank, so hiding the shorter leg behind the longer one is the one multi-GPU
+// optimisation the cost model says matters.  np_comm_wait() orders the library stream behind
+// whatever the communication stream has been given (a device-side wait; the host does not block).
 //
 // Rendezvous: rank 0 creates the ncclUniqueId and hands it to the other ranks
-//   "tcp://host:port"  rank 0 listens on host:port and serves the 128 bytes to world - 1 connections (peers retry
-//                      until it is up); nothing is left behind, a port is fresh by construction
-//   any other string   a file path: rank 0 writes <path>.tmp and renames it to <path>, peers poll for <path>;
-//                      the caller must pass a path that does not exist yet (rank 0 removes it at destroy)
+//   "tcp://host:port"  rank 0 listens on host:port; a peer connects, says who it is (magic + rank), and gets the
+//                      128 bytes back; a connection that does not introduce itself as a rank not yet served is
+//                      dropped and does not count (peers retry until rank 0 is up); nothing is left behind
+//   any other string   a file path: rank 0 removes a stale <path>, writes <path>.tmp and renames it to <path>, peers
+//                      poll for <path>; rank 0 removes it at destroy and on every failure after publishing
 #include <arpa/inet.h>
 #include <dlfcn.h>
 #include <errno.h>
@@ -27,22 +36,33 @@
 #include <time.h>
 #include <unistd.h>
 
-#include <rccl/rccl.h>
-
 #include <string>
+#include <vector>
 
 #include "np_internal.h"
 
 namespace {
 
+// ---- the slice of RCCL's C API this file uses (rccl.h of ROCm 7.2 = NCCL 2.27 API; values are ABI) ----
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr int ncclChar = 0, ncclFloat = 7;   // ncclDataType_t
+constexpr int ncclMax = 2;                   // ncclRedOp_t
+
 struct Rccl {
     void *handle = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclAllGather) AllGather = nullptr;
-    decltype(&ncclAllReduce) AllReduce = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
 struct Comm {
@@ -51,6 +71,13 @@ struct Comm {
     int rank = 0, world = 0;
     std::string file_to_remove;
     float *scratch = nullptr;   // world floats on the device (np_comm_max / barrier)
+    // the communication stream and its events (created at np_comm_init on the communicator's device)
+    hipStream_t stream = nullptr;
+    static constexpr int kEvents = 32;
+    hipEvent_t produced[kEvents] = {};   // ring: "the library stream has produced this piece"
+    unsigned next_event = 0;
+    hipEvent_t drained = nullptr;        // "the communication stream has delivered everything given to it so far"
+    bool pending = false;                // something was enqueued on the communication stream since the last np_comm_wait
 };
 
 Comm g_comm;
@@ -71,6 +98,10 @@ int load_rccl(Rccl &r) {
     NP_SYM(CommDestroy, "ncclCommDestroy");
     NP_SYM(AllGather, "ncclAllGather");
     NP_SYM(AllReduce, "ncclAllReduce");
+    NP_SYM(Send, "ncclSend");
+    NP_SYM(Recv, "ncclRecv");
+    NP_SYM(GroupStart, "ncclGroupStart");
+    NP_SYM(GroupEnd, "ncclGroupEnd");
     NP_SYM(GetErrorString, "ncclGetErrorString");
 #undef NP_SYM
     return NP_OK;
@@ -127,6 +158,14 @@ int resolve(const std::string &host, int port, sockaddr_in &addr) {
     return NP_OK;
 }
 
+// What a peer says before it is handed the id: rank 0 must not count a stray local connection (a port scanner, a
+// health check, a second job reusing the port) as a served rank.
+struct Hello {
+    uint32_t magic;
+    int32_t rank, world;
+};
+constexpr uint32_t kHelloMagic = 0x4e50434dU;   // "NPCM"
+
 // rank 0: serve `id` to world - 1 peers; peers: fetch it.  timeout_s bounds both sides.
 int exchange_tcp(const std::string &host, int port, int rank, int world, ncclUniqueId &id, double timeout_s) {
     sockaddr_in addr;
@@ -144,6 +183,7 @@ int exchange_tcp(const std::string &host, int port, int rank, int world, ncclUni
         }
         timeval tv{1, 0};
         setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));   // accept() wakes up once a second
+        std::vector<char> served_rank((size_t)world, 0);
         for (int served = 0; served < world - 1;) {
             const int c = accept(ls, nullptr, nullptr);
             if (c < 0) {
@@ -154,9 +194,17 @@ int exchange_tcp(const std::string &host, int port, int rank, int world, ncclUni
                 }
                 continue;
             }
-            const bool ok = io_all(c, &id, sizeof(id), true);
+            timeval ctv{2, 0};   // a connection that says nothing is dropped after 2 s
+            setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &ctv, sizeof(ctv));
+            Hello h{};
+            const bool known = io_all(c, &h, sizeof(h), false) && h.magic == kHelloMagic && h.world == world &&
+                               h.rank > 0 && h.rank < world && !served_rank[(size_t)h.rank];
+            const bool ok = known && io_all(c, &id, sizeof(id), true);
             close(c);
-            if (ok) ++served;
+            if (ok) {
+                served_rank[(size_t)h.rank] = 1;
+                ++served;
+            }
         }
         close(ls);
         return NP_OK;
@@ -167,7 +215,8 @@ int exchange_tcp(const std::string &host, int port, int rank, int world, ncclUni
         if (connect(c, (sockaddr *)&addr, sizeof(addr)) == 0) {
             timeval tv{(time_t)timeout_s, 0};
             setsockopt(c, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-            const bool ok = io_all(c, &id, sizeof(id), false);
+            Hello h{kHelloMagic, rank, world};
+            const bool ok = io_all(c, &h, sizeof(h), true) && io_all(c, &id, sizeof(id), false);
             close(c);
             if (ok) return NP_OK;
         } else {
@@ -183,12 +232,17 @@ int exchange_tcp(const std::string &host, int port, int rank, int world, ncclUni
 int exchange_file(const std::string &path, int rank, ncclUniqueId &id, double timeout_s) {
     if (rank == 0) {
         const std::string tmp = path + ".tmp";
+        // a file left by a run that died after publishing would hand its peers a dead id: rank 0 owns the path
+        (void)unlink(path.c_str());
         FILE *fp = fopen(tmp.c_str(), "wb");
         if (!fp) return np::fail(NP_ERR_INVALID, "np_comm_init: cannot write %s: %s", tmp.c_str(), strerror(errno));
         const bool ok = fwrite(&id, sizeof(id), 1, fp) == 1;
         fclose(fp);
-        if (!ok || rename(tmp.c_str(), path.c_str()) != 0)
-            return np::fail(NP_ERR_INVALID, "np_comm_init: cannot publish %s: %s", path.c_str(), strerror(errno));
+        if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
+            const int e = errno;
+            (void)unlink(tmp.c_str());
+            return np::fail(NP_ERR_INVALID, "np_comm_init: cannot publish %s: %s", path.c_str(), strerror(e));
+        }
         return NP_OK;
     }
     const double deadline = now_s() + timeout_s;
@@ -208,6 +262,76 @@ int exchange_file(const std::string &path, int rank, ncclUniqueId &id, double ti
     }
 }
 
+// ---- the communication stream ----
+
+void destroy_stream_objects() {
+    for (hipEvent_t &e : g_comm.produced) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    if (g_comm.drained) (void)hipEventDestroy(g_comm.drained);
+    g_comm.drained = nullptr;
+    if (g_comm.stream) (void)hipStreamDestroy(g_comm.stream);
+    g_comm.stream = nullptr;
+    g_comm.pending = false;
+}
+
+int create_stream_objects() {
+    // highest priority: while a GEMM fills every CU, the collective's few workgroups must still get scheduled promptly
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        least = greatest = 0;
+    }
+    NP_HIP_CHECK(hipStreamCreateWithPriority(&g_comm.stream, hipStreamNonBlocking, greatest));
+    for (hipEvent_t &e : g_comm.produced) NP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    NP_HIP_CHECK(hipEventCreateWithFlags(&g_comm.drained, hipEventDisableTiming));
+    return NP_OK;
+}
+
+// The communication stream picks up everything the library stream has been given so far.
+int comm_stream_follows_compute() {
+    hipEvent_t e = g_comm.produced[g_comm.next_event++ % Comm::kEvents];
+    NP_HIP_CHECK(hipEventRecord(e, np::stream()));
+    NP_HIP_CHECK(hipStreamWaitEvent(g_comm.stream, e, 0));
+    return NP_OK;
+}
+
+// recv_base + r * recv_stride <- rank r's `bytes` at send, for every r, on stream s.  Contiguous destinations
+// (recv_stride == bytes) are ONE ncclAllGather unless p2p is asked for; anything else is one grouped exchange of
+// ncclSend / ncclRecv pairs — every peer's piece travels over that peer's own xGMI link straight into place, no
+// staging buffer, no scatter copy.  The own piece is copied only when it is not already in place.
+int gather_on(hipStream_t s, const void *send, void *recv_base, size_t bytes, size_t recv_stride, bool p2p) {
+    Comm &c = g_comm;
+    char *base = (char *)recv_base;
+    if (recv_stride == bytes && !p2p) {
+        // bytes travel as ncclChar: any slab size, no alignment demand beyond the buffers' own
+        NP_RCCL_CHECK(c.api.AllGather(send, recv_base, bytes, ncclChar, c.comm, s));
+        return NP_OK;
+    }
+    char *own = base + (size_t)c.rank * recv_stride;
+    if ((const void *)own != send) NP_HIP_CHECK(hipMemcpyAsync(own, send, bytes, hipMemcpyDeviceToDevice, s));
+    if (c.world == 1) return NP_OK;
+    NP_RCCL_CHECK(c.api.GroupStart());
+    for (int step = 1; step < c.world; ++step) {
+        // rank r sends to r + step while it receives from r - step: every step is a perfect matching of the mesh
+        const int to = (c.rank + step) % c.world, from = (c.rank - step + c.world) % c.world;
+        ncclResult_t rc = c.api.Send(send, bytes, ncclChar, to, c.comm, s);
+        if (rc == ncclSuccess) rc = c.api.Recv(base + (size_t)from * recv_stride, bytes, ncclChar, from, c.comm, s);
+        if (rc != ncclSuccess) {
+            (void)c.api.GroupEnd();
+            return np::fail(NP_ERR_DEVICE, "ncclSend/ncclRecv failed: %s", c.api.GetErrorString(rc));
+        }
+    }
+    NP_RCCL_CHECK(c.api.GroupEnd());
+    return NP_OK;
+}
+
+int need_comm(const char *who) {
+    if (!g_comm.comm) return np::fail(NP_ERR_INVALID, "%s: no communicator (np_comm_init first)", who);
+    return np::ensure_init();
+}
+
 }  // namespace
 
 extern "C" {
@@ -221,6 +345,7 @@ int np_comm_init(int rank, int world, const char *endpoint) {
     ncclUniqueId id;
     memset(&id, 0, sizeof(id));
     if (rank == 0) NP_RCCL_CHECK(g_comm.api.GetUniqueId(&id));
+    std::string published;   // rank 0, file mode: the path peers poll; removed on every failure from here on
     if (world > 1) {
         std::string host;
         int port = 0;
@@ -229,19 +354,32 @@ int np_comm_init(int rank, int world, const char *endpoint) {
             if (int rc = exchange_tcp(host, port, rank, world, id, timeout_s)) return rc;
         } else {
             if (int rc = exchange_file(endpoint, rank, id, timeout_s)) return rc;
-            if (rank == 0) g_comm.file_to_remove = endpoint;
+            if (rank == 0) published = endpoint;
         }
     }
-    NP_RCCL_CHECK(g_comm.api.CommInitRank(&g_comm.comm, world, id, rank));
+    // from here on a failure must leave nothing behind: no published id (a later init with the same path would hand
+    // its peers a dead one and they would hang in ncclCommInitRank), no half-made communicator, no stream
+    const auto undo = [&](int rc) {
+        if (g_comm.comm) (void)g_comm.api.CommDestroy(g_comm.comm);
+        g_comm.comm = nullptr;
+        destroy_stream_objects();
+        if (!published.empty()) (void)unlink(published.c_str());
+        return rc;
+    };
+    {
+        const ncclResult_t rc = g_comm.api.CommInitRank(&g_comm.comm, world, id, rank);
+        if (rc != ncclSuccess) {
+            g_comm.comm = nullptr;
+            return undo(np::fail(NP_ERR_DEVICE, "ncclCommInitRank failed: %s", g_comm.api.GetErrorString(rc)));
+        }
+    }
     g_comm.rank = rank;
     g_comm.world = world;
+    if (int rc = create_stream_objects()) return undo(rc);
     void *p = nullptr;
-    if (int rc = np_malloc(&p, sizeof(float) * (size_t)(world + 1))) {
-        (void)g_comm.api.CommDestroy(g_comm.comm);   // no half-made communicator: np_last_error() keeps the allocation message
-        g_comm.comm = nullptr;
-        return rc;
-    }
+    if (int rc = np_malloc(&p, sizeof(float) * (size_t)(world + 1))) return undo(rc);   // np_last_error() keeps the allocation message
     g_comm.scratch = (float *)p;
+    g_comm.file_to_remove = published;
     return NP_OK;
 }
 
@@ -269,19 +407,102 @@ int np_comm_rank(void) { return g_comm.comm ? g_comm.rank : -1; }
 int np_comm_world(void) { return g_comm.comm ? g_comm.world : 0; }
 
 int np_allgather(const void *dev_send, void *dev_recv, size_t bytes_per_rank) {
-    if (!g_comm.comm) return np::fail(NP_ERR_INVALID, "np_allgather: no communicator (np_comm_init first)");
+    if (int rc = need_comm("np_allgather")) return rc;
     if (bytes_per_rank == 0) return NP_OK;
     if (!dev_send || !dev_recv) return np::fail(NP_ERR_INVALID, "np_allgather: null pointer");
-    if (int rc = np::ensure_init()) return rc;
-    // bytes travel as ncclChar: any slab size, no alignment demand beyond the buffers' own
-    NP_RCCL_CHECK(g_comm.api.AllGather(dev_send, dev_recv, bytes_per_rank, ncclChar, g_comm.comm, np::stream()));
+    return gather_on(np::stream(), dev_send, dev_recv, bytes_per_rank, bytes_per_rank, false);
+}
+
+int np_allgather_async(const void *dev_send, void *dev_recv_base, size_t bytes, size_t recv_stride_bytes, int mode) {
+    if (int rc = need_comm("np_allgather_async")) return rc;
+    if (mode != NP_GATHER_AUTO && mode != NP_GATHER_COLLECTIVE && mode != NP_GATHER_P2P)
+        return np::fail(NP_ERR_INVALID, "np_allgather_async: unknown mode %d", mode);
+    if (bytes == 0) return NP_OK;
+    if (!dev_send || !dev_recv_base) return np::fail(NP_ERR_INVALID, "np_allgather_async: null pointer");
+    if (recv_stride_bytes < bytes)
+        return np::fail(NP_ERR_INVALID, "np_allgather_async: destinations %zu bytes apart would overlap (%zu bytes each)",
+                        recv_stride_bytes, bytes);
+    if (mode == NP_GATHER_COLLECTIVE && recv_stride_bytes != bytes)
+        return np::fail(NP_ERR_INVALID, "np_allgather_async: NP_GATHER_COLLECTIVE needs contiguous destinations (stride == bytes)");
+    if (int rc = comm_stream_follows_compute()) return rc;
+    g_comm.pending = true;
+    return gather_on(g_comm.stream, dev_send, dev_recv_base, bytes, recv_stride_bytes, mode == NP_GATHER_P2P);
+}
+
+int np_comm_wait(void) {
+    if (int rc = need_comm("np_comm_wait")) return rc;
+    if (!g_comm.pending) return NP_OK;
+    NP_HIP_CHECK(hipEventRecord(g_comm.drained, g_comm.stream));
+    NP_HIP_CHECK(hipStreamWaitEvent(np::stream(), g_comm.drained, 0));
+    g_comm.pending = false;
     return NP_OK;
 }
 
+// Piece c of a slab cut into `chunks` pieces: as equal as they come, the first slab % chunks pieces hold one item
+// more.  Pure arithmetic (no device, no communicator): every rank cuts its slab the same way, which is what makes
+// piece c of rank r land at r * slab + lo of the replicated result.
+int np_comm_piece(size_t slab, int chunks, int c, size_t *host_lo, size_t *host_count) {
+    if (!host_lo || !host_count) return np::fail(NP_ERR_INVALID, "np_comm_piece: null output");
+    if (chunks < 1 || c < 0 || c >= chunks) return np::fail(NP_ERR_INVALID, "np_comm_piece: piece %d of %d", c, chunks);
+    const size_t base = slab / (size_t)chunks, extra = slab % (size_t)chunks, i = (size_t)c;
+    *host_lo = i * base + (i < extra ? i : extra);
+    *host_count = base + (i < extra ? 1 : 0);
+    return NP_OK;
+}
+
+void *np_comm_stream(void) { return g_comm.comm ? (void *)g_comm.stream : nullptr; }
+
+// The sharded batched matmul of BASELINE config 5 as ONE call: this rank's slab of `slab` products, written in
+// place into its window of the replicated result, in `chunks` pieces — piece c's gather is given to the
+// communication stream the moment piece c's GEMM has been enqueued, and travels while piece c + 1 is computed.
+int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K, const float *A, size_t stride_a,
+                                       const float *B, size_t stride_b, float *C_full, int chunks, int mode) {
+    if (int rc = need_comm("np_sgemm_strided_batched_allgather")) return rc;
+    if (mode != NP_GATHER_AUTO && mode != NP_GATHER_COLLECTIVE && mode != NP_GATHER_P2P)
+        return np::fail(NP_ERR_INVALID, "np_sgemm_strided_batched_allgather: unknown mode %d", mode);
+    if (chunks < 1) return np::fail(NP_ERR_INVALID, "np_sgemm_strided_batched_allgather: chunks = %d", chunks);
+    if (slab == 0 || M == 0 || N == 0) return NP_OK;
+    if (!A || !B || !C_full) return np::fail(NP_ERR_INVALID, "np_sgemm_strided_batched_allgather: null pointer");
+    if ((size_t)chunks > slab) chunks = (int)slab;
+    if (mode == NP_GATHER_COLLECTIVE && chunks > 1)
+        return np::fail(NP_ERR_INVALID, "np_sgemm_strided_batched_allgather: NP_GATHER_COLLECTIVE moves whole slabs "
+                                        "(chunks = 1); pieces of a slab are not contiguous across ranks");
+    const size_t mat = M * N, slab_elems = slab * mat;
+    float *mine = C_full + (size_t)g_comm.rank * slab_elems;
+    for (int c = 0; c < chunks; ++c) {
+        size_t lo = 0, count = 0;
+        if (int rc = np_comm_piece(slab, chunks, c, &lo, &count)) return rc;
+        if (int rc = np_sgemm_strided_batched(count, M, N, K, A + lo * stride_a, stride_a, B + lo * stride_b, stride_b,
+                                              mine + lo * mat, mat))
+            return rc;
+        // piece c of rank r belongs at C_full + r * slab + lo: destinations one slab apart
+        if (int rc = np_allgather_async(mine + lo * mat, C_full + lo * mat, count * mat * sizeof(float),
+                                        slab_elems * sizeof(float), chunks == 1 ? mode : NP_GATHER_P2P))
+            return rc;
+    }
+    return np_comm_wait();   // whatever the caller enqueues next (or np_sync) sees the gathered result
+}
+
+// testing: one grouped ncclSend / ncclRecv pair from this rank to itself on the communication stream (the only way
+// to run the p2p transport on a box with one GPU); dst <- src, then np_comm_wait().
+int np_comm_debug_sendrecv_self(const void *dev_src, void *dev_dst, size_t bytes) {
+    if (int rc = need_comm("np_comm_debug_sendrecv_self")) return rc;
+    if (!dev_src || !dev_dst || bytes == 0) return np::fail(NP_ERR_INVALID, "np_comm_debug_sendrecv_self: bad arguments");
+    if (int rc = comm_stream_follows_compute()) return rc;
+    g_comm.pending = true;
+    NP_RCCL_CHECK(g_comm.api.GroupStart());
+    ncclResult_t rc = g_comm.api.Send(dev_src, bytes, ncclChar, g_comm.rank, g_comm.comm, g_comm.stream);
+    if (rc == ncclSuccess) rc = g_comm.api.Recv(dev_dst, bytes, ncclChar, g_comm.rank, g_comm.comm, g_comm.stream);
+    const ncclResult_t rc2 = g_comm.api.GroupEnd();
+    if (rc != ncclSuccess || rc2 != ncclSuccess)
+        return np::fail(NP_ERR_DEVICE, "self ncclSend/ncclRecv failed: %s", g_comm.api.GetErrorString(rc != ncclSuccess ? rc : rc2));
+    return np_comm_wait();
+}
+
 int np_comm_max(float value, float *host_max) {
-    if (!g_comm.comm) return np::fail(NP_ERR_INVALID, "np_comm_max: no communicator (np_comm_init first)");
     if (!host_max) return np::fail(NP_ERR_INVALID, "np_comm_max: null output");
-    if (int rc = np::ensure_init()) return rc;
+    if (int rc = need_comm("np_comm_max")) return rc;
+    if (int rc = np_comm_wait()) return rc;   // "every rank's stream has reached this point" includes its gathers
     NP_HIP_CHECK(hipMemcpyAsync(g_comm.scratch, &value, sizeof(float), hipMemcpyHostToDevice, np::stream()));
     NP_RCCL_CHECK(g_comm.api.AllReduce(g_comm.scratch, g_comm.scratch + 1, 1, ncclFloat, ncclMax, g_comm.comm, np::stream()));
     NP_HIP_CHECK(hipMemcpyAsync(host_max, g_comm.scratch + 1, sizeof(float), hipMemcpyDeviceToHost, np::stream()));
@@ -296,9 +517,11 @@ int np_comm_barrier(void) {
 
 int np_comm_destroy(void) {
     if (!g_comm.comm) return NP_OK;
+    if (g_comm.stream) (void)hipStreamSynchronize(g_comm.stream);
     (void)hipStreamSynchronize(np::stream());
     const ncclResult_t rc = g_comm.api.CommDestroy(g_comm.comm);
     g_comm.comm = nullptr;
+    destroy_stream_objects();
     if (g_comm.scratch) np_free(g_comm.scratch);
     g_comm.scratch = nullptr;
     if (!g_comm.file_to_remove.empty()) {

@@ -1784,12 +1784,13 @@ int np_fused_chain_reduce(const float *const *inputs, const int *input_kinds, in
         return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: unknown reduction %d", reduce_op);
     if (rows * cols == 0) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: empty input");
     if (int rc = np::ensure_init()) return rc;
-    float *slot = np::result_slots();
+    np::ResultCall call;
+    float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
     const int sink = reduce_op == NP_MEAN ? NP_SUM : reduce_op;
     if (int rc = fused_chain_impl(inputs, input_kinds, n_inputs, ops, n_ops, slot, rows, cols, sink))
         return rc;
-    if (int rc = np::result_wait()) return rc;
+    if (int rc = call.wait()) return rc;
     const float v = slot[0];
     *host_out = reduce_op == NP_MEAN ? v / (float)(rows * cols) : v;
     return NP_OK;

@@ -20,11 +20,19 @@ int ensure_init();
 // Device properties cached at init.
 int num_cus();
 // Host-result slots: 64 floats of pinned, device-visible host memory.  A reduction's last kernel writes its value
-// straight into a slot and the caller only waits for the stream (result_wait) and reads it — no 4-byte D2H copy call
+// straight into a slot and the caller only waits for the stream (wait()) and reads it — no 4-byte D2H copy call
 // behind every nd::sum() / allclose() / median() (that call alone is ~10 us of host + driver time).  One set per
-// process: host-result entry points are synchronous, so a slot is free again when the call returns.
-float *result_slots(int count = 1);   // nullptr + error set on failure; `count` = how many slots the call's kernels will write
-int result_wait();       // = wait for the library stream (spinning on a stream-written flag, np_runtime.hip)
+// process, handed out to ONE host-result call at a time: the guard holds a process-wide mutex from arming the slots
+// to the end of the call, so concurrent callers (threads of a ctypes host, ZTS PHP) queue up instead of re-arming
+// and reading each other's slots.  Do not nest two guards in one scope.
+struct ResultCall {
+    explicit ResultCall(int count = 1);   // `count` = how many slots the call's kernels will write
+    ~ResultCall();
+    ResultCall(const ResultCall &) = delete;
+    ResultCall &operator=(const ResultCall &) = delete;
+    float *slot = nullptr;                // nullptr + error set on failure
+    int wait();                           // wait for the library stream (spinning on the slots, np_runtime.hip)
+};
 // A zeroed device counter for one launch of a "last workgroup folds" kernel (np::dev::fold_in_last_workgroup): taken
 // from a ring of 1024, and put back to zero by the workgroup that used it up, so a slot is clean again long before
 // the ring comes round (nullptr + error set on failure).

@@ -1093,10 +1093,11 @@ int np_reduce_all_dev(int op, const float *in, size_t n, float *dev_out) {
 int np_reduce_all(int op, const float *in, size_t n, float *host_out) {
     if (!host_out) return np::fail(NP_ERR_INVALID, "np_reduce_all: null output");
     if (int rc = np::ensure_init()) return rc;
-    float *slot = np::result_slots();
+    np::ResultCall call;
+    float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
     if (int rc = np_reduce_all_dev(op, in, n, slot)) return rc;
-    if (int rc = np::result_wait()) return rc;
+    if (int rc = call.wait()) return rc;
     *host_out = slot[0];
     return NP_OK;
 }
@@ -1332,10 +1333,11 @@ int np_moments(const float *in, size_t n, float *host_mean, float *host_m2) {
     float sum = 0.0f;
     if (int rc = np_reduce_all(NP_SUM, in, n, &sum)) return rc;
     const float mean = sum / (float)n;   // NDArray_Sum_Float(a) / NDArray_NUMELEMENTS(a), statistics.c:95,119
-    float *slot = np::result_slots();
+    np::ResultCall call;
+    float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
     if (int rc = xform_sum<1>(in, nullptr, n, mean, 0.0f, slot)) return rc;
-    if (int rc = np::result_wait()) return rc;
+    if (int rc = call.wait()) return rc;
     *host_mean = mean;
     *host_m2 = slot[0];
     return NP_OK;
@@ -1345,11 +1347,12 @@ int np_weighted_sums(const float *a, const float *w, size_t n, float *host_sum_a
     if (!host_sum_aw || !host_sum_w) return np::fail(NP_ERR_INVALID, "np_weighted_sums: null output");
     if (n == 0 || !a || !w) return np::fail(NP_ERR_INVALID, "np_weighted_sums: empty input");
     if (int rc = np::ensure_init()) return rc;
-    float *slot = np::result_slots(2);
+    np::ResultCall call(2);
+    float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
     if (int rc = xform_sum<2>(a, w, n, 0.0f, 0.0f, slot)) return rc;
     if (int rc = np_reduce_all_dev(NP_SUM, w, n, slot + 1)) return rc;   // both values behind ONE wait
-    if (int rc = np::result_wait()) return rc;
+    if (int rc = call.wait()) return rc;
     *host_sum_aw = slot[0];
     *host_sum_w = slot[1];
     return NP_OK;
@@ -1364,7 +1367,8 @@ int np_count_mismatch(int mode, const float *a, const float *b, size_t n, float 
     if (n == 0) return NP_OK;
     if (!a || !b) return np::fail(NP_ERR_INVALID, "np_count_mismatch: null input");
     if (int rc = np::ensure_init()) return rc;
-    float *slot = np::result_slots();
+    np::ResultCall call;
+    float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
     // a sum of 0/1 terms: inexact above 2^24 but zero exactly when every term is zero
     if (mode == NP_MISMATCH_EXACT) {
@@ -1372,7 +1376,7 @@ int np_count_mismatch(int mode, const float *a, const float *b, size_t n, float 
     } else {
         if (int rc = xform_sum<4>(a, b, n, rtol, atol, slot)) return rc;
     }
-    if (int rc = np::result_wait()) return rc;
+    if (int rc = call.wait()) return rc;
     *host_any = (slot[0] != 0.0f) ? 1 : 0;
     return NP_OK;
 }
@@ -1391,7 +1395,8 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
     const size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
     np::Scratch partials;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
-    float *slot = np::result_slots();
+    np::ResultCall call;
+    float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
     const uint32_t body_end = (uint32_t)np_avx_body_end(n);
     unsigned *ticket = blocks <= np::kFoldInKernelMaxBlocks ? np::next_ticket() : nullptr;
@@ -1406,7 +1411,7 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
         reduce_all_pass2<NP_MIN><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, slot, 1.0f);
         NP_LAUNCH_CHECK("reduce_all_pass2");
     }
-    if (int rc = np::result_wait()) return rc;
+    if (int rc = call.wait()) return rc;
     *host_out = (slot[0] != 0.0f) ? 1 : 0;
     return NP_OK;
 }

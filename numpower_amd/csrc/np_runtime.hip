@@ -25,30 +25,41 @@ namespace {
 
 thread_local char g_err[512] = "";
 
-struct Runtime {
-    std::mutex mu;
+constexpr int kMaxDevices = 16;
+
+// What belongs to ONE device: its stream, its cached blocks, its ticket ring.  NDArray::setDevice
+// (numpower.c:615-635 -> cudaSetDevice) only changes which device NEW work and NEW arrays go to; arrays
+// of the device the process used before stay alive and usable, so nothing of the old device is torn down
+// when the current device changes.
+struct DeviceState {
     bool inited = false;
-    int device = 0;
     int cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t cur_stream = nullptr;
-    // caching pool
     struct FreeBlock { void *ptr; unsigned stagger; };
-    std::map<size_t, std::vector<FreeBlock>> free_blocks;   // rounded size -> cached blocks
+    std::map<size_t, std::vector<FreeBlock>> free_blocks;   // rounded size -> cached blocks of this device
+    unsigned *tickets = nullptr;                         // ring of zeroed device counters (np::next_ticket)
+    unsigned ticket_seq = 0;
+};
+
+struct Runtime {
+    std::mutex mu;
+    std::mutex result_mu;                                // one host-result call at a time (np::ResultCall)
+    bool inited = false;
+    int device = 0;                                      // the CURRENT device: new blocks, launches, np_sync
+    DeviceState dev[kMaxDevices];
     struct Block { size_t size; int device; unsigned stagger; };
     std::unordered_map<void *, Block> live;              // ptr -> rounded size, owning device, offset from the hipMalloc base
     unsigned large_seq = 0;                              // running count of large blocks obtained from the driver
-    float *slots = nullptr;                              // pinned host-result slots (np::result_slots)
-    unsigned *tickets = nullptr;                         // ring of zeroed device counters (np::next_ticket)
-    int tickets_device = -1;
-    unsigned ticket_seq = 0;
+    float *slots = nullptr;                              // pinned host-result slots (np::ResultCall)
     int wait_mode = 2;                                   // np_runtime_set_variant: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag,
                                                          // 2 = spin on the result slots themselves (armed with a sentinel)
     uint32_t wait_seq = 0;
     int armed = 0;                                       // slots [0, armed) hold `sentinel` until the kernel writes them
     uint32_t sentinel = 0;
-    size_t reserved = 0;                                 // bytes held (live + cached)
+    size_t reserved = 0;                                 // bytes held (live + cached), all devices
     long live_count = 0;
+    DeviceState &cur() { return dev[device]; }
 };
 
 Runtime &rt() {
@@ -75,16 +86,19 @@ size_t round_size(size_t bytes) {
 constexpr size_t kStaggerFrom = size_t(1) << 20;   // blocks of at least 1 MiB
 constexpr size_t kStaggerStep = 1024, kStaggerSlots = 4;
 
+// Gives every cached block (of every device this process has used) back to the driver.
 size_t trim_locked(Runtime &r) {
     size_t released = 0;
-    for (auto &kv : r.free_blocks) {
-        for (const Runtime::FreeBlock &b : kv.second) {
-            (void)hipFree((char *)b.ptr - b.stagger);
-            released += kv.first;
+    for (DeviceState &d : r.dev) {
+        for (auto &kv : d.free_blocks) {
+            for (const DeviceState::FreeBlock &b : kv.second) {
+                (void)hipFree((char *)b.ptr - b.stagger);
+                released += kv.first;
+            }
+            kv.second.clear();
         }
-        kv.second.clear();
+        d.free_blocks.clear();
     }
-    r.free_blocks.clear();
     r.reserved -= released;
     return released;
 }
@@ -105,14 +119,16 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
-hipStream_t stream() { return rt().cur_stream; }
-int num_cus() { return rt().cus; }
+hipStream_t stream() { return rt().cur().cur_stream; }
+int num_cus() { return rt().cur().cus; }
 
 // Entry-point guard.  First use: bind the library to the calling thread's CURRENT HIP device (whatever
 // the caller — PHP's setDevice, torch.cuda.set_device — selected; device 0 only if nothing did).  Later:
 // the HIP current device is per host thread, so a thread that never selected one would allocate on and
 // launch from device 0 while the pool and the stream belong to r.device — re-select r.device whenever
 // the thread's current device differs (a thread-local read; no driver call in the steady state).
+// SIDE EFFECT (stated in np_hip.h): every np_* entry point leaves the calling thread's current HIP device
+// set to the library's device — the same thing the reference's cudaSetDevice does to its process.
 int ensure_init() {
     Runtime &r = rt();
     int cur = 0;
@@ -123,6 +139,24 @@ int ensure_init() {
     if (hipGetDevice(&cur) == hipSuccess && cur != r.device) NP_HIP_CHECK(hipSetDevice(r.device));
     return NP_OK;
 }
+
+float *result_slots(int count);
+int result_wait();
+
+// One host-result call at a time.  The pinned slots, the sentinel and the armed count are process-wide,
+// so two threads inside np_reduce_all / np_all / np_moments / np_order_stat ... at once would re-arm each
+// other's slots and read each other's values (ctypes drops the GIL; a ZTS PHP has real threads).  The guard
+// holds result_mu from the moment the slots are armed until the value has been read back; an uncontended
+// lock is ~20 ns against the ~8 us such a call costs.
+ResultCall::ResultCall(int count) {
+    rt().result_mu.lock();
+    slot = result_slots(count);
+}
+ResultCall::~ResultCall() {
+    rt().armed = 0;
+    rt().result_mu.unlock();
+}
+int ResultCall::wait() { return result_wait(); }
 
 float *result_slots(int count) {
     Runtime &r = rt();
@@ -140,7 +174,9 @@ float *result_slots(int count) {
     // host then only has to watch them change (result_wait) — no flag, no stream operation behind the kernels.
     r.armed = 0;
     if (r.wait_mode == 2 && count > 0 && count <= 32) {
-        r.sentinel = 0x7f800001u + (++r.wait_seq & 0x3fffffu);
+        // payload in [0x7f800001, 0x7fbfffff): always a SIGNALLING NaN, never 0x7fc00000 — the default quiet NaN a
+        // reduction may legitimately produce (which would read as "still pending" and cost the 2 ms fallback)
+        r.sentinel = 0x7f800001u + (++r.wait_seq % 0x3ffffeu);
         volatile uint32_t *w = (volatile uint32_t *)r.slots;
         for (int i = 0; i < count; ++i) w[i] = r.sentinel;
         r.armed = count;
@@ -151,8 +187,8 @@ float *result_slots(int count) {
 constexpr unsigned kTicketRing = 1024;
 
 // np_init allocates the ring (not the first reduction: that one may be inside a stream capture)
-static int alloc_tickets_locked(Runtime &r) {
-    if (r.tickets && r.tickets_device == r.device) return NP_OK;
+static int alloc_tickets_locked(DeviceState &d) {
+    if (d.tickets) return NP_OK;
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, kTicketRing * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(p, 0, kTicketRing * sizeof(unsigned));
@@ -160,16 +196,16 @@ static int alloc_tickets_locked(Runtime &r) {
         (void)hipGetLastError();
         return fail(NP_ERR_ALLOC, "ticket ring: %s", hipGetErrorString(e));
     }
-    r.tickets = (unsigned *)p;   // a ring per device this process has used; the old one is left to the driver
-    r.tickets_device = r.device;
+    d.tickets = (unsigned *)p;   // one ring per device this process has used
     return NP_OK;
 }
 
 unsigned *next_ticket() {
     Runtime &r = rt();
     std::lock_guard<std::mutex> lk(r.mu);
-    if (alloc_tickets_locked(r) != NP_OK) return nullptr;
-    return r.tickets + (r.ticket_seq++ % kTicketRing);
+    DeviceState &d = r.cur();
+    if (alloc_tickets_locked(d) != NP_OK) return nullptr;
+    return d.tickets + (d.ticket_seq++ % kTicketRing);
 }
 
 // Waiting for a host result.  hipStreamSynchronize costs 5-6 us of driver time per call on top of the kernels, a
@@ -180,6 +216,10 @@ unsigned *next_ticket() {
 // kernels — hipStreamWriteValue32 — which turned out to be a 3.4 us kernel of its own.)  A result that happens to BE
 // the sentinel (a NaN with exactly that payload carried through from the input), a wait longer than 2 ms, or a runtime
 // that refuses the stream operation all end in hipStreamSynchronize: slower, never wrong.
+// NOTE the mode-2 wait returns as soon as the slots have changed, i.e. possibly BEFORE the writing kernel has retired
+// (its ticket reset, np_internal.h fold_in_last_workgroup, may still be in flight).  That is safe because everything
+// that could observe the difference — the next launch drawing the same ticket, a pool block handed out again — is
+// enqueued on the same stream and therefore ordered behind the kernel.
 int result_wait() {
     Runtime &r = rt();
     const auto expired = [t0 = std::chrono::steady_clock::now()](unsigned spins) {
@@ -199,7 +239,7 @@ int result_wait() {
     } else if (r.wait_mode == 1 && r.slots) {
         volatile uint32_t *flag = (volatile uint32_t *)(r.slots + 63);
         const uint32_t want = ++r.wait_seq;
-        const hipError_t e = hipStreamWriteValue32(r.cur_stream, (void *)flag, want, 0);
+        const hipError_t e = hipStreamWriteValue32(r.cur().cur_stream, (void *)flag, want, 0);
         if (e == hipSuccess) {
             for (unsigned spins = 0;; ++spins) {
                 if (*flag == want) return NP_OK;
@@ -211,7 +251,7 @@ int result_wait() {
             r.wait_mode = 0;   // not supported here: never try again
         }
     }
-    NP_HIP_CHECK(hipStreamSynchronize(r.cur_stream));
+    NP_HIP_CHECK(hipStreamSynchronize(r.cur().cur_stream));
     return NP_OK;
 }
 
@@ -246,26 +286,26 @@ int np_init(int device) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
         return np::fail(NP_ERR_NODEVICE, "No GPU device available or HIP not enabled");
-    if (device < 0 || device >= n)
-        return np::fail(NP_ERR_INVALID, "np_init: device %d out of range (0..%d)", device, n - 1);
+    if (device < 0 || device >= n || device >= kMaxDevices)
+        return np::fail(NP_ERR_INVALID, "np_init: device %d out of range (0..%d)", device, (n < kMaxDevices ? n : kMaxDevices) - 1);
     NP_HIP_CHECK(hipSetDevice(device));
-    if (r.inited && r.device == device) return NP_OK;
-    if (r.inited) {
-        // moving to another device: drop cached blocks of the old one
-        (void)hipSetDevice(r.device);
-        trim_locked(r);
-        if (r.own_stream) (void)hipStreamDestroy(r.own_stream);
-        r.own_stream = nullptr;
-        NP_HIP_CHECK(hipSetDevice(device));
+    DeviceState &d = r.dev[device];
+    if (!d.inited) {
+        hipDeviceProp_t prop;
+        NP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        d.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        NP_HIP_CHECK(hipStreamCreateWithFlags(&d.own_stream, hipStreamNonBlocking));
+        d.cur_stream = d.own_stream;
+        if (int rc = np::alloc_tickets_locked(d)) return rc;
+        d.inited = true;
     }
-    hipDeviceProp_t prop;
-    NP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
-    r.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    NP_HIP_CHECK(hipStreamCreateWithFlags(&r.own_stream, hipStreamNonBlocking));
-    r.cur_stream = r.own_stream;
+    // Switching devices tears nothing down: the old device keeps its stream (work in flight there completes), its
+    // cached blocks and its live arrays — cudaSetDevice semantics (numpower.c:633).  Work enqueued from now on goes to
+    // `device`; an array of the old device is usable again after switching back (or from the new device wherever the
+    // platform gives peers access to each other's memory, as the reference's kernels would assume).
     r.device = device;
     r.inited = true;
-    return np::alloc_tickets_locked(r);
+    return NP_OK;
 }
 
 int np_set_device(int device) { return np_init(device); }
@@ -279,24 +319,24 @@ int np_runtime_set_variant(int variant) {
 
 int np_sync(void) {
     if (int rc = np::ensure_init()) return rc;
-    NP_HIP_CHECK(hipStreamSynchronize(rt().cur_stream));
+    NP_HIP_CHECK(hipStreamSynchronize(rt().cur().cur_stream));
     return NP_OK;
 }
 
 int np_set_stream(void *hip_stream) {
     if (int rc = np::ensure_init()) return rc;
-    Runtime &r = rt();
-    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : r.own_stream;
-    if (next == r.cur_stream) return NP_OK;   // per-chunk callers (parallel.hip_compute) must not block here
+    DeviceState &d = rt().cur();
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : d.own_stream;
+    if (next == d.cur_stream) return NP_OK;   // per-chunk callers (parallel.hip_compute) must not block here
     // drain the stream we are leaving so pool reuse stays ordered
-    NP_HIP_CHECK(hipStreamSynchronize(r.cur_stream));
-    r.cur_stream = next;
+    NP_HIP_CHECK(hipStreamSynchronize(d.cur_stream));
+    d.cur_stream = next;
     return NP_OK;
 }
 
 void *np_get_stream(void) {
     if (np::ensure_init()) return nullptr;
-    return (void *)rt().cur_stream;
+    return (void *)rt().cur().cur_stream;
 }
 
 /* ---- timers ---- */
@@ -312,12 +352,12 @@ int np_timer_create(void **timer) {
 }
 int np_timer_start(void *timer) {
     if (!timer) return np::fail(NP_ERR_INVALID, "np_timer_start: null timer");
-    NP_HIP_CHECK(hipEventRecord(((Timer *)timer)->start, rt().cur_stream));
+    NP_HIP_CHECK(hipEventRecord(((Timer *)timer)->start, rt().cur().cur_stream));
     return NP_OK;
 }
 int np_timer_stop(void *timer) {
     if (!timer) return np::fail(NP_ERR_INVALID, "np_timer_stop: null timer");
-    NP_HIP_CHECK(hipEventRecord(((Timer *)timer)->stop, rt().cur_stream));
+    NP_HIP_CHECK(hipEventRecord(((Timer *)timer)->stop, rt().cur().cur_stream));
     return NP_OK;
 }
 int np_timer_elapsed_ms(void *timer, float *host_ms) {
@@ -346,7 +386,7 @@ int np_timer_destroy(void *timer) {
 // captured).
 int np_graph_begin(void) {
     if (int rc = np::ensure_init()) return rc;
-    NP_HIP_CHECK(hipStreamBeginCapture(rt().cur_stream, hipStreamCaptureModeThreadLocal));
+    NP_HIP_CHECK(hipStreamBeginCapture(rt().cur().cur_stream, hipStreamCaptureModeThreadLocal));
     return NP_OK;
 }
 
@@ -354,7 +394,7 @@ int np_graph_end(void **graph_exec) {
     if (!graph_exec) return np::fail(NP_ERR_INVALID, "np_graph_end: null output");
     *graph_exec = nullptr;
     hipGraph_t graph = nullptr;
-    NP_HIP_CHECK(hipStreamEndCapture(rt().cur_stream, &graph));
+    NP_HIP_CHECK(hipStreamEndCapture(rt().cur().cur_stream, &graph));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
@@ -365,7 +405,7 @@ int np_graph_end(void **graph_exec) {
 
 int np_graph_launch(void *graph_exec) {
     if (!graph_exec) return np::fail(NP_ERR_INVALID, "np_graph_launch: null graph");
-    NP_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, rt().cur_stream));
+    NP_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, rt().cur().cur_stream));
     return NP_OK;
 }
 
@@ -385,8 +425,9 @@ int np_malloc(void **dev_ptr, size_t bytes) {
     const size_t sz = round_size(bytes);
     void *p = nullptr;
     unsigned stagger = 0;
-    auto it = r.free_blocks.find(sz);
-    if (it != r.free_blocks.end() && !it->second.empty()) {
+    DeviceState &d = r.cur();
+    auto it = d.free_blocks.find(sz);
+    if (it != d.free_blocks.end() && !it->second.empty()) {
         p = it->second.back().ptr;
         stagger = it->second.back().stagger;
         it->second.pop_back();
@@ -396,7 +437,8 @@ int np_malloc(void **dev_ptr, size_t bytes) {
         if (e != hipSuccess) {
             (void)hipGetLastError();
             // give cached blocks back to the driver and retry once
-            NP_HIP_CHECK(hipStreamSynchronize(r.cur_stream));
+            for (DeviceState &o : r.dev)
+                if (o.inited) NP_HIP_CHECK(hipStreamSynchronize(o.cur_stream));
             trim_locked(r);
             e = hipMalloc(&p, sz + pad);
             if (e != hipSuccess) {
@@ -424,14 +466,9 @@ int np_free(void *dev_ptr) {
     auto it = r.live.find(dev_ptr);
     if (it == r.live.end())
         return np::fail(NP_ERR_INVALID, "np_free: pointer %p was not allocated by np_malloc", dev_ptr);
-    if (it->second.device == r.device) {
-        r.free_blocks[it->second.size].push_back(Runtime::FreeBlock{dev_ptr, it->second.stagger});
-    } else {
-        // allocated before an NDArray::setDevice to another GPU: the cache only holds blocks of the
-        // current device, so this one goes straight back to the driver
-        (void)hipFree((char *)dev_ptr - it->second.stagger);
-        r.reserved -= it->second.size;
-    }
+    // back into the cache of the device that owns it — which need not be the current one after an
+    // NDArray::setDevice: the block is reused the next time that device is current
+    r.dev[it->second.device].free_blocks[it->second.size].push_back(DeviceState::FreeBlock{dev_ptr, it->second.stagger});
     r.live.erase(it);
     r.live_count--;
     return NP_OK;
@@ -443,7 +480,8 @@ int np_pool_trim(size_t *host_bytes) {
     if (int rc = np::ensure_init()) return rc;
     Runtime &r = rt();
     std::lock_guard<std::mutex> lk(r.mu);
-    NP_HIP_CHECK(hipStreamSynchronize(r.cur_stream));
+    for (DeviceState &o : r.dev)
+        if (o.inited) NP_HIP_CHECK(hipStreamSynchronize(o.cur_stream));
     size_t released = trim_locked(r);
     if (host_bytes) *host_bytes = released;
     return NP_OK;
@@ -457,8 +495,8 @@ int np_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes) {
     if (int rc = np::ensure_init()) return rc;
     // Pageable source: hipMemcpyAsync stages it and returns once the host buffer is reusable,
     // which is the semantic NDArray_ToGPU needs (ndarray.c:1054-1055).
-    NP_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, rt().cur_stream));
-    NP_HIP_CHECK(hipStreamSynchronize(rt().cur_stream));
+    NP_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, np::stream()));
+    NP_HIP_CHECK(hipStreamSynchronize(np::stream()));
     return NP_OK;
 }
 
@@ -466,8 +504,8 @@ int np_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes) {
     if (bytes == 0) return NP_OK;
     if (!host_dst || !dev_src) return np::fail(NP_ERR_INVALID, "np_memcpy_d2h: null pointer");
     if (int rc = np::ensure_init()) return rc;
-    NP_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, rt().cur_stream));
-    NP_HIP_CHECK(hipStreamSynchronize(rt().cur_stream));
+    NP_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, np::stream()));
+    NP_HIP_CHECK(hipStreamSynchronize(np::stream()));
     return NP_OK;
 }
 
@@ -478,7 +516,7 @@ int np_memcpy_d2d(void *dev_dst, const void *dev_src, size_t bytes) {
     // large word-aligned copies: the library's own float4 stream beats the runtime's blit by ~20 %
     if (bytes >= (size_t(8) << 20) && bytes % 4 == 0 && ((uintptr_t)dev_dst & 3u) == 0 && ((uintptr_t)dev_src & 3u) == 0)
         return np::device_copy(dev_dst, dev_src, bytes);
-    NP_HIP_CHECK(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, rt().cur_stream));
+    NP_HIP_CHECK(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, np::stream()));
     return NP_OK;
 }
 
@@ -486,7 +524,7 @@ int np_memset0(void *dev_ptr, size_t bytes) {
     if (bytes == 0) return NP_OK;
     if (!dev_ptr) return np::fail(NP_ERR_INVALID, "np_memset0: null pointer");
     if (int rc = np::ensure_init()) return rc;
-    NP_HIP_CHECK(hipMemsetAsync(dev_ptr, 0, bytes, rt().cur_stream));
+    NP_HIP_CHECK(hipMemsetAsync(dev_ptr, 0, bytes, np::stream()));
     return NP_OK;
 }
 

@@ -756,10 +756,11 @@ int np_select_last_path(int *path) {
 int np_order_stat(const float *in, size_t n, size_t k, float *host_out2) {
     if (!host_out2) return np::fail(NP_ERR_INVALID, "np_order_stat: null output");
     if (int rc = np::ensure_init()) return rc;
-    float *slot = np::result_slots(2);
+    np::ResultCall call(2);
+    float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
     if (int rc = np_order_stat_dev(in, n, k, slot)) return rc;
-    if (int rc = np::result_wait()) return rc;
+    if (int rc = call.wait()) return rc;
     host_out2[0] = slot[0];
     host_out2[1] = slot[1];
     return NP_OK;

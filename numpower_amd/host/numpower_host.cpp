@@ -1716,4 +1716,49 @@ NDArray *NDArray_BatchedMatmul(NDArray *a, NDArray *b) {
     return result;
 }
 
+// ---- the sharded form: one call per PHP method, like every other row of the path ----
+
+int NDArray_CommInit(int rank, int world, const char *endpoint) { return dev_ok(np_comm_init(rank, world, endpoint)) ? 0 : -1; }
+int NDArray_CommDestroy(void) { return dev_ok(np_comm_destroy()) ? 0 : -1; }
+int NDArray_CommRank(void) { return np_comm_world() > 0 ? np_comm_rank() : 0; }
+int NDArray_CommWorld(void) { return np_comm_world() > 0 ? np_comm_world() : 1; }
+
+NDArray *NDArray_ShardedBatchedMatmul(NDArray *a, NDArray *b, int batch, int gather_mode) {
+    if (!a || !b) return nullptr;
+    if (NDArray_DEVICE(a) != NDArray_DEVICE(b)) {
+        throw_error("Device mismatch, both NDArray MUST be in the same device.");
+        return nullptr;
+    }
+    if (NDArray_NDIM(a) != 3 || NDArray_NDIM(b) != 3 || a->dimensions[0] != b->dimensions[0]) {
+        throw_error("Arrays must have the same shape. Broadcasting not implemented.");
+        return nullptr;
+    }
+    if (a->dimensions[2] != b->dimensions[1]) {
+        throw_error("Shape mismatch for matmul. cols(a) != rows(b)");
+        return nullptr;
+    }
+    if (gather_mode < 0) {
+        throw_error("gather mode must be 0 (keep sharded), 1 (gather) or a number of overlapped pieces");
+        return nullptr;
+    }
+    const int world = NDArray_CommWorld(), slab = a->dimensions[0];
+    if (batch < 0 || (long)slab * world != (long)batch) {
+        throw_error("Batch of %d is not %d slab(s) of %d", batch, world, slab);
+        return nullptr;
+    }
+    if (gather_mode == NP_SHARD_KEEP || np_comm_world() == 0) return NDArray_BatchedMatmul(a, b);   // no collective on the path
+    if (!require_gpu(a, "matmul")) return nullptr;
+    const size_t M = (size_t)a->dimensions[1], K = (size_t)a->dimensions[2], N = (size_t)b->dimensions[2];
+    int shape[3] = {batch, (int)M, (int)N};
+    NDArray *result = new_array(shape, 3, NDARRAY_DEVICE_GPU, false);   // every rank's window is written by its owner
+    if (!result) return nullptr;
+    if (!dev_ok(np_sgemm_strided_batched_allgather((size_t)slab, M, N, K, NDArray_FDATA(a), M * K, NDArray_FDATA(b), K * N,
+                                                   NDArray_FDATA(result), gather_mode == NP_SHARD_GATHER ? 1 : gather_mode,
+                                                   NP_GATHER_AUTO))) {
+        NDArray_FREE(result);
+        return nullptr;
+    }
+    return result;
+}
+
 }  // extern "C"

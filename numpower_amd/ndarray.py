@@ -108,6 +108,11 @@ def _load_host():
         "NDArray_Outer": (_P, [_P, _P]),
         "NDArray_Inner": (_P, [_P, _P]),
         "NDArray_BatchedMatmul": (_P, [_P, _P]),
+        "NDArray_ShardedBatchedMatmul": (_P, [_P, _P, C.c_int, C.c_int]),
+        "NDArray_CommInit": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
+        "NDArray_CommDestroy": (C.c_int, []),
+        "NDArray_CommRank": (C.c_int, []),
+        "NDArray_CommWorld": (C.c_int, []),
     }
     for name in ("Add", "Subtract", "Multiply", "Divide", "Mod", "Pow"):
         sig[f"NDArray_{name}_Float"] = (_P, [_P, _P])
@@ -667,6 +672,24 @@ class NDArray:
     def batched_matmul(a, b):
         h = _load_host()
         return NDArray._wrap(h.NDArray_BatchedMatmul(a._p, b._p))
+
+    @staticmethod
+    def comm_init(rank: int, world: int, endpoint: str):
+        """Join the node's ranks (one process per GPU); endpoint "tcp://127.0.0.1:port" or a file path."""
+        if _load_host().NDArray_CommInit(int(rank), int(world), endpoint.encode()) != 0:
+            _raise_pending(_load_host())
+
+    @staticmethod
+    def comm_destroy():
+        if _load_host().NDArray_CommDestroy() != 0:
+            _raise_pending(_load_host())
+
+    @staticmethod
+    def sharded_batched_matmul(a_slab, b_slab, batch: int, gather_mode: int = 1):
+        """This rank's slab of a batch of `batch` products; gather_mode 0 keeps the result sharded, 1 gathers it
+        with one all-gather, k >= 2 overlaps the gather of k pieces with the GEMM (include/numpower_host.h)."""
+        h = _load_host()
+        return NDArray._wrap(h.NDArray_ShardedBatchedMatmul(a_slab._p, b_slab._p, int(batch), int(gather_mode)))
 
     @staticmethod
     def live_device_allocations() -> int:

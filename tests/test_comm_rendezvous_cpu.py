@@ -78,3 +78,54 @@ def test_rank0_times_out_when_a_peer_is_missing():
     rc = lib.np_comm_debug_exchange(0, 3, ("tcp://127.0.0.1:%d" % free_port()).encode(), buf, 1.5)
     assert rc != 0 and b"peers fetched the id" in lib.np_last_error()
     assert time.time() - t0 < 10
+
+
+def test_a_stray_connection_is_not_counted_as_a_rank():
+    """Something that is not a rank connects to rank 0's port first (and says nothing useful): it is dropped and the
+    real peer is still served (rank 0 used to hand the id to any connector and count it)."""
+    import threading
+    import time
+    port = free_port()
+    endpoint = "tcp://127.0.0.1:%d" % port
+    stop = threading.Event()
+
+    def stray():
+        # keeps knocking with garbage / silence until the exchange is over
+        while not stop.is_set():
+            try:
+                with socket.create_connection(("127.0.0.1", port), timeout=0.2) as s:
+                    s.sendall(b"GET / HTTP/1.0\r\n\r\n")
+                    s.settimeout(0.2)
+                    try:
+                        s.recv(256)
+                    except OSError:
+                        pass
+            except OSError:
+                pass
+            time.sleep(0.02)
+
+    t = threading.Thread(target=stray, daemon=True)
+    t.start()
+    try:
+        out = run_world(2, endpoint, rank0_delay=0.3, timeout=20.0)
+    finally:
+        stop.set()
+        t.join(timeout=5)
+    for r in range(2):
+        rc, so, se = out[r]
+        assert rc == 0, (r, so, se)
+        assert so == "OK " + EXPECT
+
+
+def test_a_stale_id_file_is_replaced_by_rank0(tmp_path):
+    """A file left behind by a run that died after publishing must not reach the peers of the next run."""
+    path = tmp_path / "id"
+    path.write_bytes(bytes(128))          # a dead id of the right size
+    out = run_world(2, str(path), rank0_delay=0.0)
+    rc0, so0, se0 = out[0]
+    assert rc0 == 0, (so0, se0)
+    # the peer may have started polling before rank 0 replaced the file: what it must never do is hang; and a peer
+    # that starts after rank 0 sees the fresh bytes
+    out2 = run_world(2, str(path), rank0_delay=0.0, skip_rank0=True, timeout=5.0)
+    rc1, so1, _ = out2[1]
+    assert rc1 == 0 and so1 == "OK " + EXPECT

@@ -74,6 +74,132 @@ def test_sharded_batched_matmul_through_the_c_abi(hip):
     assert (np.abs(got - want) <= 1e-6 * scale).all()
 
 
+@pytest.mark.parametrize("chunks,mode", [(1, 0), (1, 1), (1, 2), (2, 0), (4, 2), (5, 0), (8, 0), (64, 0)])
+def test_overlapped_sharded_matmul_is_bit_identical(chunks, mode, hip, oracle):
+    """np_sgemm_strided_batched_allgather (GEMM pieces on the library stream, each piece's gather on the communication
+    stream) against the plain form — np_sgemm_strided_batched + np_allgather on one stream — bit for bit, for every
+    chunk count / transport, and against the oracle's loop of 2-D matmuls (the reference has no batched entry point,
+    linalg.c:239-242)."""
+    lib = load()
+    batch, m, k, n = 8, 96, 160, 64
+    A = synth.uniform((batch, m, k), 12, -1.0, 1.0)
+    B = synth.uniform((batch, k, n), 13, -1.0, 1.0)
+    check(lib.np_comm_init(0, 1, ("tcp://127.0.0.1:%d" % free_port()).encode()))
+    try:
+        assert lib.np_comm_stream() and lib.np_comm_stream() != lib.np_get_stream()
+        dA, dB = hip.DeviceArray.from_host(A), hip.DeviceArray.from_host(B)
+        plain, over = hip.DeviceArray((batch, m, n)), hip.DeviceArray((batch, m, n))
+        check(lib.np_sgemm_strided_batched(batch, m, n, k, dA.ptr, m * k, dB.ptr, k * n, plain.ptr, m * n))
+        check(lib.np_allgather(plain.ptr, plain.ptr, batch * m * n * 4))
+        hip.fill(over, float("nan"))
+        check(lib.np_sgemm_strided_batched_allgather(batch, m, n, k, dA.ptr, m * k, dB.ptr, k * n, over.ptr, chunks, mode))
+        want, got = plain.to_host(), over.to_host()      # to_host() is on the library stream: ordered behind np_comm_wait
+    finally:
+        check(lib.np_comm_destroy())
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    for i in range(batch):
+        ref = oracle.matmul(A[i], B[i])
+        scale = np.abs(A[i]).astype(np.float64) @ np.abs(B[i]).astype(np.float64)
+        assert (np.abs(got[i] - ref) / scale).max() <= 1e-5
+
+
+def test_async_gather_out_of_place_and_strided(hip):
+    """np_allgather_async: the copy lands on the communication stream behind what the library stream produced, and
+    np_comm_wait orders the library stream behind it — out of place (world 1: the own piece is copied into place),
+    with a destination stride, both transports."""
+    lib = load()
+    check(lib.np_comm_init(0, 1, ("tcp://127.0.0.1:%d" % free_port()).encode()))
+    try:
+        n = 1 << 20
+        src, dst = hip.DeviceArray((n,)), hip.DeviceArray((2 * n,))
+        for mode in (0, 1, 2):
+            hip.fill(src, 1.5 + mode)         # produced on the library stream ...
+            hip.fill(dst, -1.0)
+            check(lib.np_allgather_async(src.ptr, dst.ptr, n * 4, n * 4, mode))      # ... picked up by the other stream
+            check(lib.np_comm_wait())
+            out = dst.to_host()
+            assert (out[:n] == 1.5 + mode).all() and (out[n:] == -1.0).all()
+        hip.fill(dst, -1.0)
+        check(lib.np_allgather_async(src.ptr, dst.ptr + 4 * 100, n * 4, 2 * n * 4, 0))   # strided: p2p path, own piece copied
+        check(lib.np_comm_wait())
+        out = dst.to_host()
+        assert (out[100:100 + n] == 3.5).all() and (out[:100] == -1.0).all()
+        with pytest.raises(NumPowerError, match="contiguous destinations"):
+            check(lib.np_allgather_async(src.ptr, dst.ptr, n * 4, 2 * n * 4, 1))
+        with pytest.raises(NumPowerError, match="overlap"):
+            check(lib.np_allgather_async(src.ptr, dst.ptr, n * 4, n * 2, 0))
+        with pytest.raises(NumPowerError, match="NP_GATHER_COLLECTIVE"):
+            check(lib.np_sgemm_strided_batched_allgather(4, 8, 8, 8, src.ptr, 64, src.ptr, 64, dst.ptr, 2, 1))
+    finally:
+        check(lib.np_comm_destroy())
+
+
+def test_p2p_transport_to_self(hip):
+    """The grouped ncclSend / ncclRecv pair the chunked gather is made of, run on the only peer a one-GPU box has:
+    the rank itself."""
+    lib = load()
+    check(lib.np_comm_init(0, 1, ("tcp://127.0.0.1:%d" % free_port()).encode()))
+    try:
+        x = synth.uniform((1 << 18,), 21, -1.0, 1.0)
+        src, dst = hip.DeviceArray.from_host(x), hip.DeviceArray((1 << 18,))
+        hip.fill(dst, 0.0)
+        check(lib.np_comm_debug_sendrecv_self(src.ptr, dst.ptr, x.nbytes))
+        assert (dst.to_host() == x).all()
+    finally:
+        check(lib.np_comm_destroy())
+
+
+def test_gather_overlaps_the_gemm(hip):
+    """The point of the second stream: a gather given to the communication stream runs WHILE a later GEMM on the library
+    stream does.  Timed with events on both streams: [GEMM_1 ; gather(out of place, 256 MiB) ‖ GEMM_2] must finish
+    well before the serial sum of the three."""
+    lib = load()
+    from numpower_amd._lib import Timer
+    check(lib.np_comm_init(0, 1, ("tcp://127.0.0.1:%d" % free_port()).encode()))
+    try:
+        n, batch = 1024, 64
+        A, B = hip.DeviceArray((batch, n, n)), hip.DeviceArray((batch, n, n))
+        hip.fill(A, 0.5)
+        hip.fill(B, 0.25)
+        c1, c2, full = hip.DeviceArray((batch, n, n)), hip.DeviceArray((batch, n, n)), hip.DeviceArray((batch, n, n))
+        nbytes = batch * n * n * 4
+
+        def gemm(out):
+            check(lib.np_sgemm_strided_batched(batch, n, n, n, A.ptr, n * n, B.ptr, n * n, out.ptr, n * n))
+
+        def timed(fn, reps=5):
+            best = 1e9
+            for _ in range(reps + 2):
+                t = Timer()
+                t.start()
+                fn()
+                t.stop()
+                best = min(best, t.elapsed_ms())
+            return best
+
+        t_gemm = timed(lambda: gemm(c1))
+        t_copy = timed(lambda: (check(lib.np_allgather_async(c1.ptr, full.ptr, nbytes, nbytes, 0)), check(lib.np_comm_wait())))
+
+        def serial():
+            gemm(c1)
+            check(lib.np_allgather(c1.ptr, full.ptr, nbytes))      # library stream: strictly behind, GEMM_2 behind it
+            gemm(c2)
+
+        def overlapped():
+            gemm(c1)
+            check(lib.np_allgather_async(c1.ptr, full.ptr, nbytes, nbytes, 0))
+            gemm(c2)
+            check(lib.np_comm_wait())
+
+        t_serial, t_over = timed(serial), timed(overlapped)
+        print("gemm %.3f ms  copy %.3f ms  serial %.3f ms  overlapped %.3f ms" % (t_gemm, t_copy, t_serial, t_over))
+        assert (full.to_host()[0] == c1.to_host()[0]).all()
+        # the copy (~0.1 ms of HBM time) hides behind GEMM_2 (~1 ms): at least half of it must be gone
+        assert t_over <= t_serial - 0.5 * t_copy + 0.05, (t_gemm, t_copy, t_serial, t_over)
+    finally:
+        check(lib.np_comm_destroy())
+
+
 def test_bad_arguments(hip):
     lib = load()
     for args in ((1, 1, b"tcp://127.0.0.1:1"), (-1, 2, b"x"), (0, 0, b"x"), (0, 1, b"")):

@@ -2,8 +2,10 @@
 oracle to chew through the whole input:
 
   C3a add 1e8          bit-exact against IEEE fp32 addition (= the reference's AVX2 add) + linearity
-  C3b exp / log 1e8    sampled against the oracle, exp(log(x)) round trip on the full array
-  C3c broadcast        bit-exact, row and column forms on 25000 x 4000
+  C3b exp / log 1e8    ALL 10^8 elements against the oracle (exp on U[-10,10) seed 7, log on U[1e-3,1e3) seed 8:
+                       SURVEY.md section 8d's inputs), + the exp(log(x)) round trip
+  C3c broadcast        bit-exact, row and column forms on 25000 x 4000; the fused exp(X)+row / exp(X)+col chain at
+                       the same size against the oracle's composition
   C4  sum(axis 0)      65536 x 4096 against an fp64 accumulation, checksum-of-checksums vs sum()
   C2  matmul 4096^2    sampled rows against fp64, associativity-free identities (A.I, scaling)
   C5  batched matmul   64 x (1024 x 1024) slab (one rank's share of 512) against per-matrix np_sgemm
@@ -42,18 +44,85 @@ def test_add_1e8_bit_exact_and_linear(hip):
         d.free()
 
 
+def _worst_rel(got, ref, floor):
+    """max |got - ref| / max(|ref|, floor) over two fp32 arrays, in fp64, in chunks (no 10^8-element fp64 temporaries
+    beyond one chunk)."""
+    worst, step = 0.0, 1 << 24
+    for i in range(0, got.size, step):
+        g, r = got[i:i + step].astype(np.float64), ref[i:i + step].astype(np.float64)
+        assert (np.isfinite(g) == np.isfinite(r)).all()
+        worst = max(worst, float((np.abs(g - r) / np.maximum(np.abs(r), floor)).max()))
+    return worst
+
+
 def test_exp_log_1e8(hip, oracle):
+    """BASELINE config 3 at full size, EVERY element against the oracle (glibc expf / logf through float_exp /
+    float_log, double_math.c:27-57) — the oracle maps 10^8 floats in well under a second, there is nothing to sample."""
     D = hip
-    x = synth.uniform((N8,), 8, 1e-3, 1e3)
+    x = synth.uniform((N8,), 7, -10.0, 10.0)               # SURVEY.md section 8d, C3b: exp on U[-10, 10), seed 7
+    dx = D.DeviceArray.from_host(x)
+    de = D.unary("exp", dx)
+    got = de.to_host().reshape(-1)
+    ref = oracle.unary("exp", x).reshape(-1)
+    assert _worst_rel(got, ref, 1e-30) <= 1e-5
+    de.free()
+    dx.free()
+    del got, ref
+    x = synth.uniform((N8,), 8, 1e-3, 1e3)                 # ... log on U[1e-3, 1e3), seed 8
     dx = D.DeviceArray.from_host(x)
     dl = D.unary("log", dx)
-    got = dl.to_host()
-    idx = np.concatenate([np.arange(0, 200_000), np.arange(N8 - 200_000, N8), np.arange(0, N8, 997)])
-    ref = oracle.unary("log", x[idx]).astype(np.float64)
-    assert (np.abs(got[idx] - ref) <= 1e-5 * np.abs(ref) + 1e-11).all()
-    back = D.unary("exp", dl).to_host().astype(np.float64)
-    assert (np.abs(back - x) <= 5e-6 * np.abs(x) * (1.0 + np.abs(np.log(x.astype(np.float64))))).all()
+    got = dl.to_host().reshape(-1)
+    ref = oracle.unary("log", x).reshape(-1)
+    # log crosses zero at x = 1: 1e-5 relative with an absolute floor of 1e-6 * 1e-5 (as assert_close, test_gpu_parity.py)
+    assert _worst_rel(got, ref, 1e-6) <= 1e-5
+    del ref
+    back = D.unary("exp", dl).to_host().reshape(-1)
+    step = 1 << 24
+    for i in range(0, N8, step):
+        xs = x[i:i + step].astype(np.float64)
+        assert (np.abs(back[i:i + step] - xs) <= 5e-6 * xs * (1.0 + np.abs(np.log(xs)))).all()
     for d in (dx, dl):
+        d.free()
+
+
+def test_fused_exp_plus_broadcast_25000x4000_vs_oracle(hip, oracle):
+    """BASELINE config 3c as ONE fused launch (np_fused_chain: exp(X) + r with r a row / a column, no temporary) at
+    full size against the oracle's composition NDArray_Add_Float(NDArray_Map(X, float_exp), r) — all 10^8 elements."""
+    import ctypes as C
+
+    from numpower_amd._lib import BINARY_OPS, NP_FUSED_BINARY, NP_FUSED_UNARY, UNARY_OPS, FusedOp, check, load
+    D, lib = hip, load()
+    R, Cc = 25000, 4000
+    X = synth.uniform((R, Cc), 5, -10.0, 10.0)
+    row = synth.uniform((Cc,), 9, -1.0, 1.0)
+    col = synth.uniform((R, 1), 10, -1.0, 1.0)
+    dX, drow, dcol, out = D.DeviceArray.from_host(X), D.DeviceArray.from_host(row), D.DeviceArray.from_host(col), D.DeviceArray((R, Cc))
+    eX = oracle.unary("exp", X)
+    for name, small, dsmall, kind in (("row", row, drow, 2), ("col", col, dcol, 3)):
+        ptrs = (C.c_void_p * 2)(dX.ptr, dsmall.ptr)
+        kinds = (C.c_int * 2)(0, kind)
+        prog = (FusedOp * 2)()
+        prog[0].kind, prog[0].op = NP_FUSED_UNARY, UNARY_OPS["exp"]
+        prog[1].kind, prog[1].op, prog[1].operand, prog[1].swap = NP_FUSED_BINARY, BINARY_OPS["add"], 1, 0
+        check(lib.np_fused_chain(ptrs, kinds, 2, prog, 2, out.ptr, R, Cc))
+        got = out.to_host().reshape(-1)
+        ref = oracle.binary("add", eX, small).reshape(-1)
+        # the sum can cancel (exp(x) ~ -r): bound relative to |exp(x)| + |r|, which is >= |ref|
+        worst, step = 0.0, 1 << 24
+        mag = (np.abs(eX) + np.abs(small)).reshape(-1)      # row (C,) and column (R, 1) both broadcast against R x C
+        for i in range(0, got.size, step):
+            g, r = got[i:i + step].astype(np.float64), ref[i:i + step].astype(np.float64)
+            worst = max(worst, float((np.abs(g - r) / mag[i:i + step]).max()))
+        assert worst <= 1e-5, (name, worst)
+        # and bit-identical to the two-launch form on the GPU (exp, then the broadcast add)
+        dE = D.unary("exp", dX)
+        dTwo = D.binary("add", dE, "full", dsmall, name, R, Cc)
+        two = dTwo.to_host().reshape(-1)
+        dE.free()
+        dTwo.free()
+        assert (_u32(two) == _u32(got)).all(), name
+        del two, ref, mag, got
+    for d in (dX, drow, dcol, out):
         d.free()
 
 

@@ -1,6 +1,12 @@
-"""SURVEY.md §8(f) row 4 on the GPU: fused elementwise chains are bit-identical to the same ops
-issued one by one through the stand-alone entry points (and therefore to the oracle wherever those
-are), for every op kind incl. the quirk-carrying ones, at aligned, ragged and view shapes."""
+"""SURVEY.md §8(f) row 4 on the GPU: fused elementwise chains
+
+  1. against the ORACLE's composition of the same ops (oracle.binary(oracle.unary(...)): the reference's CPU
+     functions applied one after the other, arithmetics.c / double_math.c) — bit for bit where every op of the chain
+     is exact arithmetic (incl. the multiply / mod AVX-body quirks), within 1e-5 relative where a libm-class
+     function is involved;
+  2. and, second, against the same ops issued one by one through the stand-alone GPU entry points (bit-identical:
+     fusion must not change a single bit),
+for every op kind incl. the quirk-carrying ones, at aligned, ragged and view shapes."""
 import numpy as np
 import pytest
 
@@ -18,8 +24,22 @@ def _same(a, b):
     return a.shape == b.shape and ((_bits(a) == _bits(b)) | (np.isnan(a) & np.isnan(b))).all()
 
 
+def _close(got, want, scale=None, rel=1e-5):
+    """|got - want| <= rel * scale (scale defaults to |want|, floor 1e-30); NaN / inf patterns must agree.  `scale` is
+    the magnitude of the operands of the chain's last additive step where that step can cancel."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    if got.shape != want.shape:
+        return False
+    fin = np.isfinite(want)
+    if not (np.isfinite(got) == fin).all() or not (got[~fin] == want[~fin])[~np.isnan(want[~fin])].all():
+        return False
+    s = np.abs(want) if scale is None else np.asarray(scale, dtype=np.float64)
+    s = np.broadcast_to(s, want.shape)
+    return bool((np.abs(got[fin] - want[fin]) <= rel * np.maximum(s[fin], 1e-30)).all())
+
+
 @pytest.mark.parametrize("shape", [(1000, 1000), (257, 1001), (3, 5), (64, 4096)])
-def test_fused_equals_unfused(shape, hip):
+def test_fused_equals_unfused(shape, hip, oracle):
     from numpower_amd.lazy import Lazy   # noqa: F401  (installs NDArray.lazy)
     from numpower_amd.ndarray import NDArray
     a = synth.uniform(shape, 91, -2.0, 2.0)
@@ -28,30 +48,41 @@ def test_fused_equals_unfused(shape, hip):
     a.reshape(-1)[::7] = 0.0          # zero products: multiply's -0.0 / +0.0 quirk must survive fusion
     ga, gb, gc = NDArray.array(a).gpu(), NDArray.array(b).gpu(), NDArray.array(c).gpu()
 
-    fused = (ga.lazy().exp() * gb + 2.0).eval()
+    O, f32 = oracle, np.float32
+    fused = (ga.lazy().exp() * gb + 2.0).eval().cpu().numpy()
+    want = O.binary("add", O.binary("multiply", O.unary("exp", a), b), f32(2.0))       # libm inside: 1e-5
+    assert _close(fused, want), "exp(a)*b+2 vs the oracle's composition"
     plain = (NDArray.exp(ga) * gb) + 2.0
-    assert _same(fused.cpu().numpy(), plain.cpu().numpy())
+    assert _same(fused, plain.cpu().numpy())
 
-    fused = ((ga.lazy() * gc) % gb).abs().sqrt().eval()
+    fused = ((ga.lazy() * gc) % gb).abs().sqrt().eval().cpu().numpy()
+    want = O.unary("sqrt", O.unary("abs", O.binary("mod", O.binary("multiply", a, c), b)))   # exact ops + both quirks
+    assert _same(fused, want), "sqrt(abs((a*c) % b)) vs the oracle's composition"
     plain = NDArray.sqrt(NDArray.abs((ga * gc) % gb))
-    assert _same(fused.cpu().numpy(), plain.cpu().numpy())
+    assert _same(fused, plain.cpu().numpy())
 
-    fused = (1.5 - ga.lazy()).clip(-1.0, 2.0).round(2).eval()
+    fused = (1.5 - ga.lazy()).clip(-1.0, 2.0).round(2).eval().cpu().numpy()
+    want = O.unary("round", O.unary("clip", O.binary("subtract", f32(1.5), a), -1.0, 2.0), 2.0)
+    assert _same(fused, want), "round(clip(1.5-a)) vs the oracle's composition"
     plain = NDArray.round(NDArray.clip(1.5 - ga, -1.0, 2.0), 2)
-    assert _same(fused.cpu().numpy(), plain.cpu().numpy())
+    assert _same(fused, plain.cpu().numpy())
 
-    fused = (ga.lazy().equal(gc) + ga.lazy().greater(gb).eval()).eval()
+    fused = (ga.lazy().equal(gc) + ga.lazy().greater(gb).eval()).eval().cpu().numpy()
+    want = O.binary("add", O.binary("equal", a, c), O.binary("greater", a, b))
+    assert _same(fused, want), "equal + greater vs the oracle's composition"
     plain = NDArray.equal(ga, gc) + NDArray.greater(ga, gb)
-    assert _same(fused.cpu().numpy(), plain.cpu().numpy())
+    assert _same(fused, plain.cpu().numpy())
 
     # the same array bound twice is loaded once
     lz = ga.lazy() * ga + ga
     assert len(lz.inputs) == 1
-    assert _same(lz.eval().cpu().numpy(), ((ga * ga) + ga).cpu().numpy())
+    got = lz.eval().cpu().numpy()
+    assert _same(got, O.binary("add", O.binary("multiply", a, a), a)), "a*a+a vs the oracle's composition"
+    assert _same(got, ((ga * ga) + ga).cpu().numpy())
 
 
 @pytest.mark.parametrize("shape", [(250, 400), (33, 1001), (7, 3)])
-def test_fused_broadcast_operands(shape, hip):
+def test_fused_broadcast_operands(shape, hip, oracle):
     """Row / column / 0-d device operands inside a chain (ndarray.c:1196-1291 resolved in-kernel):
     bit-identical to the op-by-op path, incl. the AVX-body bound that depends on WHICH side the
     small operand is on (arithmetics.c:251)."""
@@ -66,22 +97,32 @@ def test_fused_broadcast_operands(shape, hip):
     row[::3] = 0.0
     gx, grow, gcol, grow1 = (NDArray.array(v).gpu() for v in (x, row, col, row1))
 
-    fused = (gx.lazy().exp() + grow).eval()
-    assert _same(fused.cpu().numpy(), (NDArray.exp(gx) + grow).cpu().numpy())
-    fused = (gx.lazy().exp() + gcol).eval()
-    assert _same(fused.cpu().numpy(), (NDArray.exp(gx) + gcol).cpu().numpy())
+    O = oracle
+    ex = O.unary("exp", x)
+    fused = (gx.lazy().exp() + grow).eval().cpu().numpy()
+    assert _close(fused, O.binary("add", ex, row), np.abs(ex) + np.abs(row)[None, :]), "exp(x)+row vs the oracle"
+    assert _same(fused, (NDArray.exp(gx) + grow).cpu().numpy())
+    fused = (gx.lazy().exp() + gcol).eval().cpu().numpy()
+    assert _close(fused, O.binary("add", ex, col), np.abs(ex) + np.abs(col)), "exp(x)+col vs the oracle"
+    assert _same(fused, (NDArray.exp(gx) + gcol).cpu().numpy())
 
-    # quirk-carrying ops with the small operand on either side
-    fused = ((gx.lazy() * grow) % gcol).eval()
-    assert _same(fused.cpu().numpy(), ((gx * grow) % gcol).cpu().numpy())
-    fused = (grow * gx.lazy()).eval()
-    assert _same(fused.cpu().numpy(), (grow * gx).cpu().numpy())
-    fused = (gcol % gx.lazy().abs() + grow1).eval()
-    assert _same(fused.cpu().numpy(), ((gcol % NDArray.abs(gx)) + grow1).cpu().numpy())
-    fused = gx.lazy().equal(grow1).eval()
-    assert _same(fused.cpu().numpy(), NDArray.equal(gx, grow1).cpu().numpy())
-    fused = gx.lazy().not_equal(gcol).eval()
-    assert _same(fused.cpu().numpy(), NDArray.not_equal(gx, gcol).cpu().numpy())
+    # quirk-carrying ops with the small operand on either side: exact arithmetic, so the oracle's composition
+    # (NDArray_Multiply_Float / NDArray_Mod_Float with their broadcast + AVX-body bound, arithmetics.c:251) bit for bit
+    fused = ((gx.lazy() * grow) % gcol).eval().cpu().numpy()
+    assert _same(fused, O.binary("mod", O.binary("multiply", x, row), col)), "(x*row) % col vs the oracle"
+    assert _same(fused, ((gx * grow) % gcol).cpu().numpy())
+    fused = (grow * gx.lazy()).eval().cpu().numpy()
+    assert _same(fused, O.binary("multiply", row, x)), "row*x vs the oracle"
+    assert _same(fused, (grow * gx).cpu().numpy())
+    fused = (gcol % gx.lazy().abs() + grow1).eval().cpu().numpy()
+    assert _same(fused, O.binary("add", O.binary("mod", col, O.unary("abs", x)), row1)), "col % |x| + row1 vs the oracle"
+    assert _same(fused, ((gcol % NDArray.abs(gx)) + grow1).cpu().numpy())
+    fused = gx.lazy().equal(grow1).eval().cpu().numpy()
+    assert _same(fused, O.binary("equal", x, row1)), "equal(x, row1) vs the oracle"
+    assert _same(fused, NDArray.equal(gx, grow1).cpu().numpy())
+    fused = gx.lazy().not_equal(gcol).eval().cpu().numpy()
+    assert _same(fused, O.binary("not_equal", x, col)), "not_equal(x, col) vs the oracle"
+    assert _same(fused, NDArray.not_equal(gx, gcol).cpu().numpy())
 
     # numpy meaning as an independent check
     got = (gx.lazy().exp() + grow).eval().cpu().numpy()
@@ -89,7 +130,7 @@ def test_fused_broadcast_operands(shape, hip):
     assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
 
 
-def test_long_chain_splits_and_views(hip):
+def test_long_chain_splits_and_views(hip, oracle):
     from numpower_amd.lazy import Lazy   # noqa: F401
     from numpower_amd.ndarray import NDArray
     x = synth.uniform((6, 1001), 3, 0.5, 1.5)
@@ -97,10 +138,14 @@ def test_long_chain_splits_and_views(hip):
     row, other = g[1], g[2]                      # 4-byte aligned views: scalar path of the kernel
     lz = row.lazy()
     plain = row
+    want = x[1]
     for k in range(20):                          # longer than one chain: flushes in between
         lz = (lz * other + 0.25).sqrt()
         plain = NDArray.sqrt(plain * other + 0.25)
-    assert _same(lz.eval().cpu().numpy(), plain.cpu().numpy())
+        want = oracle.unary("sqrt", oracle.binary("add", oracle.binary("multiply", want, x[2]), np.float32(0.25)))
+    got = lz.eval().cpu().numpy()
+    assert _same(got, want), "60 exact steps vs the oracle's composition"
+    assert _same(got, plain.cpu().numpy())
 
 
 def test_fused_errors(hip):
@@ -118,7 +163,7 @@ def test_fused_errors(hip):
 
 
 @pytest.mark.parametrize("shape", [(1000, 1000), (257, 1001), (3, 5), (1,)])
-def test_chain_ending_in_a_reduction(shape, hip):
+def test_chain_ending_in_a_reduction(shape, hip, oracle):
     """sum / prod / min / max / mean of an expression without materialising it
     (np_fused_chain_reduce): min / max are exact; sum / mean within 1e-5 of an fp64 accumulation of
     the SAME fp32 chain values (the reference's own order is sequential fp32); deterministic."""
@@ -128,13 +173,19 @@ def test_chain_ending_in_a_reduction(shape, hip):
     b = synth.uniform(shape, 95, 0.5, 2.0)
     ga, gb = NDArray.array(a).gpu(), NDArray.array(b).gpu()
     vals = (NDArray.exp(ga) * gb + 2.0).cpu().numpy()          # the chain's fp32 values, op by op
+    ovals = oracle.binary("add", oracle.binary("multiply", oracle.unary("exp", a), b), np.float32(2.0))   # ... and the oracle's
     chain = lambda: ga.lazy().exp() * gb + 2.0                 # noqa: E731
     assert chain().max() == float(vals.max()) and chain().min() == float(vals.min())
+    assert abs(chain().max() - float(ovals.max())) <= 1e-5 * abs(float(ovals.max()))
+    assert abs(chain().min() - float(ovals.min())) <= 1e-5 * abs(float(ovals.min()))
     s = chain().sum()
     assert s == chain().sum()
     want = float(vals.astype(np.float64).sum())
     assert abs(s - want) <= 1e-5 * abs(want)
+    owant = float(ovals.astype(np.float64).sum())              # fp64 sum of the ORACLE's chain values
+    assert abs(s - owant) <= 1e-5 * abs(owant)
     assert abs(chain().mean() - want / vals.size) <= 1e-5 * abs(want / vals.size)
+    assert abs(chain().mean() - owant / vals.size) <= 1e-5 * abs(owant / vals.size)
     # a chain of length 0 is a plain reduction
     assert abs(ga.lazy().sum() - float(a.astype(np.float64).sum())) <= 1e-5 * np.abs(a).sum()
     # prod over a short vector; broadcast operand in a reduced chain
@@ -167,7 +218,7 @@ def test_fused_broadcast_index_arithmetic(cols, hip):
                                    (100_000, 12), (7, 5), (3, 1_000_000), (64, 128, 96), (1000,),
                                    # very many short rows: fused_chain_rows_staged_kernel (slabs through LDS), ragged last slab
                                    (900_001, 10), (530_003, 16), (180_001, 47)])
-def test_chain_ending_in_an_axis_reduction(shape, hip):
+def test_chain_ending_in_an_axis_reduction(shape, hip, oracle):
     """sum / max / min / mean / prod over the last axis (any rank) and the first axis (2-d) as the chain's
     last step (np_fused_chain_reduce_axis: row-sink and column-sink kernels, or the temporary + reduce
     fallback for shapes they would idle on) against the op-by-op path: min / max bit-identical, sums within
@@ -182,29 +233,47 @@ def test_chain_ending_in_an_axis_reduction(shape, hip):
     col = NDArray.array(synth.uniform((shape[0], 1), 303, 0.5, 1.5)).gpu() if nd == 2 else None
     axes = [nd - 1] + ([0] if nd == 2 else []) + ([1] if nd == 3 else [])
 
-    def chains():
-        yield "exp", lambda x: x.exp(), lambda x: NDArray.exp(x)
-        yield "x*row+0.5", lambda x: x * row + 0.5, lambda x: (x * row) + 0.5
-        if col is not None:
-            yield "(x-col)^2", lambda x: (x - col) * (x - col).eval() if False else ((x - col).abs() * 2.0), lambda x: NDArray.abs(x - col) * 2.0
-        yield "tanh(x)+x", lambda x: x.tanh() + ga, lambda x: NDArray.tanh(x) + ga      # full interpreter + input 0 reused
+    O, f32 = oracle, np.float32
+    h_row = row.cpu().numpy()
+    h_col = col.cpu().numpy() if col is not None else None
 
-    for label, build, eager in chains():
+    # (label, lazy chain, op-by-op GPU chain, the ORACLE's composition on the host, every op exact?)
+    def chains():
+        yield "exp", lambda x: x.exp(), lambda x: NDArray.exp(x), lambda: O.unary("exp", a), False
+        yield ("x*row+0.5", lambda x: x * row + 0.5, lambda x: (x * row) + 0.5,
+               lambda: O.binary("add", O.binary("multiply", a, h_row), f32(0.5)), True)
+        if col is not None:
+            yield ("|x-col|*2", lambda x: (x - col).abs() * 2.0, lambda x: NDArray.abs(x - col) * 2.0,
+                   lambda: O.binary("multiply", O.unary("abs", O.binary("subtract", a, h_col)), f32(2.0)), True)
+        yield ("tanh(x)+x", lambda x: x.tanh() + ga, lambda x: NDArray.tanh(x) + ga,      # full interpreter + input 0 reused
+               lambda: O.binary("add", O.unary("tanh", a), a), False)
+
+    for label, build, eager, by_oracle, exact in chains():
         value = eager(ga).cpu().numpy()
         v64 = value.astype(np.float64)
+        ovalue = by_oracle()                      # what the reference's CPU functions give for the same chain
+        o64 = ovalue.astype(np.float64)
+        if exact:
+            assert _same(value, ovalue), (label, shape, "op-by-op GPU chain vs the oracle's composition")
         for axis in axes:
             n_axis = shape[axis]
-            got = build(ga.lazy()).max(axis=axis)
-            got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
-            assert _same(got, value.max(axis=axis)), (label, shape, axis, "max")
-            got = build(ga.lazy()).min(axis=axis)
-            got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
-            assert _same(got, value.min(axis=axis)), (label, shape, axis, "min")
-            for op, ref, scale in (("sum", v64.sum(axis=axis), np.abs(v64).sum(axis=axis)),
-                                   ("mean", v64.sum(axis=axis) / n_axis, np.abs(v64).sum(axis=axis) / n_axis)):
+            for mm in ("max", "min"):
+                got = getattr(build(ga.lazy()), mm)(axis=axis)
+                got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
+                oref = getattr(ovalue, mm)(axis=axis)
+                if exact:
+                    assert _same(got, oref), (label, shape, axis, mm, "vs the oracle")
+                else:
+                    assert _close(got, oref, np.abs(oref) + 1e-3), (label, shape, axis, mm, "vs the oracle")
+                assert _same(got, getattr(value, mm)(axis=axis)), (label, shape, axis, mm)
+            for op, ref, scale, oref, oscale in (
+                    ("sum", v64.sum(axis=axis), np.abs(v64).sum(axis=axis), o64.sum(axis=axis), np.abs(o64).sum(axis=axis)),
+                    ("mean", v64.sum(axis=axis) / n_axis, np.abs(v64).sum(axis=axis) / n_axis,
+                     o64.sum(axis=axis) / n_axis, np.abs(o64).sum(axis=axis) / n_axis)):
                 got = getattr(build(ga.lazy()), op)(axis=axis)
                 got = got.cpu().numpy() if hasattr(got, "cpu") else np.float32(got)
                 assert got.shape == np.asarray(ref).shape, (label, shape, axis, op)
+                assert (np.abs(got - oref) <= 1e-5 * np.maximum(oscale, 1e-30)).all(), (label, shape, axis, op, "vs the oracle")
                 assert (np.abs(got - ref) <= 1e-5 * np.maximum(scale, 1e-30)).all(), (label, shape, axis, op)
                 if nd == 2 and axis == 1 and 4 < last <= 48 and a.size >= (8 << 20):
                     # the staged kernel repeats reduce_rows_staged's fold order: bit-identical to the op-by-op sums

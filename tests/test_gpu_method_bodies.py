@@ -111,6 +111,24 @@ def test_pow_reduce_matmul_methods(records, oracle):
     assert_close(records["exp_cpu"], oracle.unary("exp", np.clip(x, -50, 50)), "exp -> cpu()")
 
 
+@pytest.mark.gpu
+def test_sharded_batched_matmul_method(records, oracle):
+    """NDArray_ShardedBatchedMatmul from C, a world of one rank: kept / gathered / 3 overlapped pieces are the same
+    bits, and every matrix equals the oracle's loop of 2-D matmuls (linalg.c:239-242 rejects ndim > 2: the loop IS
+    the reference form)."""
+    a = c_input(6 * 33, 47, 106, -1, 1).reshape(6, 33, 47)
+    b = c_input(6 * 47, 29, 107, -1, 1).reshape(6, 47, 29)
+    keep = records["sharded_keep"]
+    assert keep.shape == (6, 33, 29)
+    for name in ("sharded_gather", "sharded_overlap3"):
+        assert_bit_equal(records[name], keep, name)
+    for i in range(6):
+        ref = oracle.matmul(a[i], b[i])
+        scale = np.abs(a[i]).astype(np.float64) @ np.abs(b[i]).astype(np.float64)
+        assert (np.abs(keep[i] - ref) / scale).max() <= REL_TOL
+        assert (np.abs(keep[i] - a[i].astype(np.float64) @ b[i].astype(np.float64)) / scale).max() <= 1e-6
+
+
 def test_method_bodies_builds_and_refuses_to_run_without_a_device(tmp_path):
     """CPU tier: the program exists (the build compiled the reference's call expressions with -Werror)
     and, with no GPU, stops at gpu() with the reference's message instead of computing anywhere else."""

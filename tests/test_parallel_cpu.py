@@ -57,7 +57,7 @@ def _worker(rank, world, port, batch, gather, q, kind="matmul"):
             torch.bmm(x, y, out=out)
 
         res = parallel.sharded_batched_matmul(a, b, batch, compute, dist=dist, gather=gather,
-                                              overlap_chunks=2 if kind == "overlap" else 1)
+                                              overlap_chunks=int(kind[len("overlap"):] or 2) if kind.startswith("overlap") else 1)
         q.put((rank, res.numpy()))
     finally:
         dist.destroy_process_group()
@@ -112,10 +112,26 @@ def test_sharded_elementwise(world, batch, gather):
             np.testing.assert_array_equal(out[rank], want[slab.start:slab.stop])
 
 
-def test_sharded_batched_matmul_overlapped_gather():
-    """overlap_chunks: per-piece compute + asynchronous all-gather into the right windows of the
-    replicated result (world 2, slabs of 4 in 2 pieces)."""
-    out = _run(2, 8, gather=True, kind="overlap")
-    want = _expected(8)
-    for rank in range(2):
+@pytest.mark.parametrize("world,batch,chunks", [(2, 8, 2), (2, 10, 3), (3, 12, 2), (3, 15, 4), (2, 4, 8)])
+def test_sharded_batched_matmul_overlapped_gather(world, batch, chunks):
+    """overlap_chunks: per-piece compute + asynchronous point-to-point exchange straight into the right windows of
+    the replicated result — the chunk index arithmetic of np_sgemm_strided_batched_allgather (np_comm_piece), with
+    real peers: world 2 and 3, pieces that divide the slab and pieces that do not, more pieces than matrices."""
+    out = _run(world, batch, gather=True, kind="overlap%d" % chunks)
+    want = _expected(batch)
+    for rank in range(world):
         np.testing.assert_allclose(out[rank], want, rtol=1e-6, atol=1e-6)
+
+
+def test_piece_arithmetic_matches_the_c_abi():
+    """np_comm_piece: contiguous, covering, as equal as they come, first pieces larger; clipped to the slab."""
+    for slab in (1, 5, 8, 64, 65):
+        for chunks in (1, 2, 3, 4, 8, 100):
+            pcs = parallel.pieces_of(slab, chunks)
+            assert len(pcs) == min(chunks, slab)
+            assert pcs[0][0] == 0 and sum(c for _, c in pcs) == slab
+            for (lo, c), (lo2, _) in zip(pcs, pcs[1:]):
+                assert lo + c == lo2
+            sizes = [c for _, c in pcs]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert parallel.pieces_of(64, 4) == [(0, 16), (16, 16), (32, 16), (48, 16)]
