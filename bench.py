@@ -816,14 +816,14 @@ def main():
     if not args.no_extras:
         if dist.abi:
             try:
-                extras = {"config5_batched_matmul_allgather_c_abi": bench_config5_abi(dist, max(3, args.steps // 10), 2)}
+                extras = {"config5_batched_matmul_allgather_c_abi": bench_config5_abi(dist, max(5, args.steps // 5), 5)}
             except Exception as e:
                 extras = {"error": repr(e)}
         elif not dist.use_torch:
             try:
                 extras = bench_extras(dist, max(10, args.steps // 2), args.warmup)
                 try:
-                    extras["config5_one_rank_slab_c_abi"] = bench_config5_abi(dist, max(5, args.steps // 5), 2,
+                    extras["config5_one_rank_slab_c_abi"] = bench_config5_abi(dist, max(10, args.steps // 2), 10,
                                                                                 own_comm_port=_free_port(), world1=True)
                 except Exception as e:
                     extras["config5_one_rank_slab_c_abi"] = {"error": repr(e)}
@@ -845,13 +845,13 @@ def main():
             watchdog.daemon = True
             watchdog.start()
             try:
-                extras = {"config5_batched_matmul_allgather": bench_config5(dist, max(3, args.steps // 10), 2)}
+                extras = {"config5_batched_matmul_allgather": bench_config5(dist, max(5, args.steps // 5), 5)}
             except Exception as e:
                 extras = {"error": repr(e)}
             # the same workload with the collective issued through the C ABI (np_allgather) on its own communicator
             try:
                 port = int(os.environ.get("MASTER_PORT", "29531")) + 23
-                extras["config5_batched_matmul_allgather_c_abi"] = bench_config5_abi(dist, max(3, args.steps // 10), 2,
+                extras["config5_batched_matmul_allgather_c_abi"] = bench_config5_abi(dist, max(5, args.steps // 5), 5,
                                                                                       own_comm_port=port)
             except Exception as e:
                 extras["config5_batched_matmul_allgather_c_abi"] = {"error": repr(e)}

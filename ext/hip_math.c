@@ -39,6 +39,7 @@ static size_t count(int n) { return n > 0 ? (size_t)n : 0; }
         raise_if(np_unary(code, d_array, d_array, count(nblocks), 0.0f, 0.0f));                    \
     }
 NP_HIP_MATH_UNARY_LIST(NP_HIP_MATH_DEFINE_UNARY)
+NP_HIP_MATH_EXTRA_UNARY_LIST(NP_HIP_MATH_DEFINE_UNARY)   /* rsqrt, exp2: see hip_math.h */
 #undef NP_HIP_MATH_DEFINE_UNARY
 
 /* numpower.c:2487 (clip), :2959 (round) */
@@ -57,6 +58,7 @@ void cuda_float_arctan2(int nblocks, float *d_array, float *y_array) {
 int np_hip_math_unary_code(ElementWiseFloatGPUOperation op) {
 #define NP_HIP_MATH_MATCH_UNARY(name, code) if (op == cuda_float_##name) return code;
     NP_HIP_MATH_UNARY_LIST(NP_HIP_MATH_MATCH_UNARY)
+    NP_HIP_MATH_EXTRA_UNARY_LIST(NP_HIP_MATH_MATCH_UNARY)
 #undef NP_HIP_MATH_MATCH_UNARY
     return -1;
 }

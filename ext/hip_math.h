@@ -36,8 +36,14 @@ typedef void (*ElementWiseFloatGPUOperation1N)(int, float *, float *);
     X(rint, NP_RINT) X(fix, NP_FIX) X(ceil, NP_CEIL) X(floor, NP_FLOOR) X(sinc, NP_SINC)          \
     X(trunc, NP_TRUNC) X(negate, NP_NEGATE) X(sign, NP_SIGN) X(positive, NP_POSITIVE)             \
     X(reciprocal, NP_RECIPROCAL)
+/* Two unary methods have no usable device function in the reference: PHP_METHOD(rsqrt) hands
+ * cuda_float_arccos to the driver (numpower.c:1791, a slip) and PHP_METHOD(exp2) has no device branch at
+ * all (numpower.c:3153 maps the CPU kernel over whatever pointer the array holds).  These two names are
+ * NOT in cuda_math.h; tools/apply_with_hip.py declares them in numpower.c and points the two methods at them. */
+#define NP_HIP_MATH_EXTRA_UNARY_LIST(X) X(rsqrt, NP_RSQRT) X(exp2, NP_EXP2)
 #define NP_HIP_MATH_DECLARE_UNARY(name, code) void cuda_float_##name(int nblocks, float *d_array);
 NP_HIP_MATH_UNARY_LIST(NP_HIP_MATH_DECLARE_UNARY)
+NP_HIP_MATH_EXTRA_UNARY_LIST(NP_HIP_MATH_DECLARE_UNARY)
 #undef NP_HIP_MATH_DECLARE_UNARY
 void cuda_float_clip(int nblocks, float *d_array, float minVal, float maxVal);
 void cuda_float_round(int nblocks, float *d_array, float decimals);

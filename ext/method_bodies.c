@@ -130,6 +130,9 @@ static const UnaryMethod kUnary[] = {
     {"trunc", cuda_float_trunc, -10, 10},      {"fix", cuda_float_fix, -10, 10},
     {"rint", cuda_float_rint, -10, 10},        {"radians", cuda_float_radians, -360, 360},
     {"degrees", cuda_float_degrees, -7, 7},    {"sinc", cuda_float_sinc, -5, 5},
+    /* the two methods tools/apply_with_hip.py re-points (numpower.c:1791 passes cuda_float_arccos for rsqrt,
+     * :3153 has no device branch for exp2) */
+    {"rsqrt", cuda_float_rsqrt, 0.01f, 100},   {"exp2", cuda_float_exp2, -10, 10},
 };
 
 static NDArray *method_unary(NDArray *nda, ElementWiseFloatGPUOperation op) {

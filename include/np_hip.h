@@ -418,11 +418,25 @@ int np_comm_piece(size_t slab, int chunks, int c, size_t *host_lo, size_t *host_
 int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K, const float *A, size_t stride_a,
                                        const float *B, size_t stride_b, float *C_full, int chunks, int mode);
 
+/* How the communicator orders its two streams and issues the sharded GEMM (tuning / A-B; np_comm.hip):
+ *   0  default: device-side flags (a one-lane kernel publishes a sequence number on the producing stream, a one-lane
+ *      kernel on the consuming stream waits for it) and ONE progress-reporting GEMM launch per slab — the transfer of
+ *      piece c is released by the GEMM's own tile counter.  Falls back to HIP events by itself if the self-test at
+ *      np_comm_init finds that flags do not get through (both streams on one hardware queue).
+ *   1  HIP events (hipEventRecord + hipStreamWaitEvent) and one GEMM launch per piece
+ *   2  device-side flags, one GEMM launch per piece
+ * np_comm_sync_mode: 1 = flags in use, 0 = events, -1 = no communicator. */
+int np_comm_set_variant(int variant);
+int np_comm_sync_mode(void);
+
 /* testing: the rendezvous of np_comm_init alone (no device, no RCCL) — rank 0's 128 bytes reach every peer */
 int np_comm_debug_exchange(int rank, int world, const char *endpoint, void *bytes128, double timeout_s);
 /* testing: dst <- src through one grouped ncclSend / ncclRecv pair from this rank to itself on the communication
  * stream, then np_comm_wait() — the P2P transport on a box with a single GPU */
 int np_comm_debug_sendrecv_self(const void *dev_src, void *dev_dst, size_t bytes);
+/* testing: every piece gathered point-to-point is from now on ALSO sent from this rank to itself into dev_scratch
+ * (pieces larger than `bytes` are not): real RCCL traffic next to the GEMM on a box without a peer.  (NULL, 0) = off. */
+int np_comm_debug_loopback(void *dev_scratch, size_t bytes);
 
 /* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 = whole-K plans only,
  * -2 = default planner again, -3 = default planner + always pad unaligned operands). */

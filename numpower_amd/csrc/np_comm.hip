@@ -17,6 +17,18 @@
 // optimisation the cost model says matters.  np_comm_wait() orders the library stream behind
 // whatever the communication stream has been given (a device-side wait; the host does not block).
 //
+// How the two streams are ordered.  hipStreamWaitEvent across two streams costs the LAUNCHING THREAD 60-80 us per call
+// on this platform (profiles/r03/chunk_overhead.log: 8 pieces 1.05 -> 1.51 ms per slab, GPU idle in between) — more
+// than the transfer it is supposed to hide.  So the order is kept on the device instead: a one-lane kernel on the
+// producing stream publishes a sequence number (flag_set_kernel), a one-lane kernel on the consuming stream spins on it
+// (flag_wait_kernel: s_sleep between device-scope acquire loads, gives up after a time-out and raises a host-visible
+// error word instead of hanging the queue).  The sharded GEMM goes one step further: ONE launch computes the whole
+// slab and its workgroups count finished tiles per piece (GemmArgs::progress, np_sgemm.hip); the wait kernel in front
+// of piece c's transfer releases it when the count is complete — no launch per piece, no host in the loop.  Both
+// need the two streams to sit on different hardware queues (they do: the communication stream is created at high
+// priority); np_comm_init proves it with a self-test and falls back to HIP events if the flag does not come through
+// (np_comm_set_variant(1) forces the event form, for A/B).
+//
 // Rendezvous: rank 0 creates the ncclUniqueId and hands it to the other ranks
 //   "tcp://host:port"  rank 0 listens on host:port; a peer connects, says who it is (magic + rank), and gets the
 //                      128 bytes back; a connection that does not introduce itself as a rank not yet served is
@@ -78,7 +90,20 @@ struct Comm {
     unsigned next_event = 0;
     hipEvent_t drained = nullptr;        // "the communication stream has delivered everything given to it so far"
     bool pending = false;                // something was enqueued on the communication stream since the last np_comm_wait
+    // device-side ordering (see the header comment)
+    static constexpr int kMaxPieces = 64;
+    unsigned *flags = nullptr;           // device: [0] produced sequence, [1] drained sequence, [8 .. 8 + kMaxPieces) tile counters (zero between calls)
+    unsigned *host_error = nullptr;      // pinned, device-visible: set by a wait kernel that gave up
+    unsigned produced_seq = 0, drained_seq = 0;
+    bool use_flags = false;              // false: HIP events (np_comm_set_variant(1), or the self-test failed)
+    hipStream_t flags_ok_for = nullptr;  // the library stream the self-test passed for
+    // testing (np_comm_debug_loopback): every gathered piece is ALSO sent from this rank to itself into this scratch
+    // buffer — real RCCL p2p traffic on the communication stream of a box that has no peer
+    char *loopback = nullptr;
+    size_t loopback_bytes = 0;
 };
+
+int g_sync_variant = 0;   // np_comm_set_variant: 0 = device-side flags where they work, 1 = HIP events only, 2 = flags but one GEMM launch per piece
 
 Comm g_comm;
 
@@ -264,6 +289,77 @@ int exchange_file(const std::string &path, int rank, ncclUniqueId &id, double ti
 
 // ---- the communication stream ----
 
+constexpr unsigned long long kWaitTimeoutTicks = 60ull * 100000000ull;   // 60 s of the 100 MHz wall clock
+constexpr unsigned long long kSelfTestTicks = 2000000ull;                // 20 ms
+
+__global__ void flag_set_kernel(unsigned *flag, unsigned value) {
+    // everything earlier on this stream is complete and visible (kernel boundary): a memory-side store publishes it
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Spins until *flag has reached `target` (sequence numbers: compared as a signed difference, so wrap-around is fine;
+// tile counters: plain >=).  One lane; s_sleep keeps it off the issue ports of the CU it sits on.
+__global__ void flag_wait_kernel(const unsigned *flag, unsigned target, unsigned long long timeout_ticks, unsigned *host_error) {
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // memory-side; the next kernel on this stream starts with an acquire
+        if ((int)(v - target) >= 0) return;
+        __builtin_amdgcn_s_sleep(16);
+        if ((spins & 63u) == 63u && wall_clock64() - t0 > timeout_ticks) {
+            __hip_atomic_store(host_error, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;   // give up rather than hang the queue: the host reports it at its next np_comm_* call
+        }
+    }
+}
+
+// The last act of a pipelined call on the communication stream: the tile counters go back to zero (the next call's GEMM
+// counts from there) and the "drained" sequence number is published — one kernel, one hop, instead of a memset + a set.
+__global__ void finish_kernel(unsigned *counters, int n, unsigned *flag, unsigned value) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) __hip_atomic_store(counters + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int stream_follows(hipStream_t consumer, hipStream_t producer, unsigned *flag, unsigned &seq, hipEvent_t event) {
+    Comm &c = g_comm;
+    if (c.use_flags) {
+        ++seq;
+        flag_set_kernel<<<1, 1, 0, producer>>>(flag, seq);
+        NP_LAUNCH_CHECK("flag_set_kernel");
+        flag_wait_kernel<<<1, 1, 0, consumer>>>(flag, seq, kWaitTimeoutTicks, c.host_error);
+        NP_LAUNCH_CHECK("flag_wait_kernel");
+        return NP_OK;
+    }
+    NP_HIP_CHECK(hipEventRecord(event, producer));
+    NP_HIP_CHECK(hipStreamWaitEvent(consumer, event, 0));
+    return NP_OK;
+}
+
+// Do device-side flags work between the communication stream and `compute`?  The wait goes in FIRST: were the two
+// streams multiplexed onto one hardware queue, the set kernel would queue up behind the spinning wait and never run —
+// the wait then gives up after 20 ms, raises the error word, and this communicator uses HIP events instead.
+int flags_self_test(hipStream_t compute) {
+    Comm &c = g_comm;
+    c.use_flags = false;
+    c.flags_ok_for = compute;
+    if (g_sync_variant == 1 || !c.flags || !c.host_error) return NP_OK;
+    NP_HIP_CHECK(hipStreamSynchronize(compute));
+    NP_HIP_CHECK(hipStreamSynchronize(c.stream));
+    *(volatile unsigned *)c.host_error = 0;
+    const unsigned seq = ++c.produced_seq;
+    flag_wait_kernel<<<1, 1, 0, c.stream>>>(c.flags, seq, kSelfTestTicks, c.host_error);
+    NP_LAUNCH_CHECK("flag_wait_kernel");
+    flag_set_kernel<<<1, 1, 0, compute>>>(c.flags, seq);
+    NP_LAUNCH_CHECK("flag_set_kernel");
+    NP_HIP_CHECK(hipStreamSynchronize(c.stream));
+    NP_HIP_CHECK(hipStreamSynchronize(compute));
+    c.use_flags = *(volatile unsigned *)c.host_error == 0;
+    *(volatile unsigned *)c.host_error = 0;
+    return NP_OK;
+}
+
 void destroy_stream_objects() {
     for (hipEvent_t &e : g_comm.produced) {
         if (e) (void)hipEventDestroy(e);
@@ -274,6 +370,14 @@ void destroy_stream_objects() {
     if (g_comm.stream) (void)hipStreamDestroy(g_comm.stream);
     g_comm.stream = nullptr;
     g_comm.pending = false;
+    if (g_comm.flags) (void)hipFree(g_comm.flags);
+    g_comm.flags = nullptr;
+    if (g_comm.host_error) (void)hipHostFree(g_comm.host_error);
+    g_comm.host_error = nullptr;
+    g_comm.use_flags = false;
+    g_comm.flags_ok_for = nullptr;
+    g_comm.loopback = nullptr;
+    g_comm.loopback_bytes = 0;
 }
 
 int create_stream_objects() {
@@ -286,15 +390,19 @@ int create_stream_objects() {
     NP_HIP_CHECK(hipStreamCreateWithPriority(&g_comm.stream, hipStreamNonBlocking, greatest));
     for (hipEvent_t &e : g_comm.produced) NP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     NP_HIP_CHECK(hipEventCreateWithFlags(&g_comm.drained, hipEventDisableTiming));
-    return NP_OK;
+    const size_t flag_bytes = sizeof(unsigned) * (8 + Comm::kMaxPieces);
+    NP_HIP_CHECK(hipMalloc((void **)&g_comm.flags, flag_bytes));
+    NP_HIP_CHECK(hipMemset(g_comm.flags, 0, flag_bytes));
+    NP_HIP_CHECK(hipHostMalloc((void **)&g_comm.host_error, sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable));
+    *g_comm.host_error = 0;
+    g_comm.produced_seq = g_comm.drained_seq = 0;
+    return flags_self_test(np::stream());
 }
 
 // The communication stream picks up everything the library stream has been given so far.
 int comm_stream_follows_compute() {
-    hipEvent_t e = g_comm.produced[g_comm.next_event++ % Comm::kEvents];
-    NP_HIP_CHECK(hipEventRecord(e, np::stream()));
-    NP_HIP_CHECK(hipStreamWaitEvent(g_comm.stream, e, 0));
-    return NP_OK;
+    Comm &c = g_comm;
+    return stream_follows(c.stream, np::stream(), c.flags + 0, c.produced_seq, c.produced[c.next_event++ % Comm::kEvents]);
 }
 
 // recv_base + r * recv_stride <- rank r's `bytes` at send, for every r, on stream s.  Contiguous destinations
@@ -311,6 +419,14 @@ int gather_on(hipStream_t s, const void *send, void *recv_base, size_t bytes, si
     }
     char *own = base + (size_t)c.rank * recv_stride;
     if ((const void *)own != send) NP_HIP_CHECK(hipMemcpyAsync(own, send, bytes, hipMemcpyDeviceToDevice, s));
+    if (c.loopback && bytes <= c.loopback_bytes) {
+        NP_RCCL_CHECK(c.api.GroupStart());
+        ncclResult_t rc = c.api.Send(send, bytes, ncclChar, c.rank, c.comm, s);
+        if (rc == ncclSuccess) rc = c.api.Recv(c.loopback, bytes, ncclChar, c.rank, c.comm, s);
+        const ncclResult_t rc2 = c.api.GroupEnd();
+        if (rc != ncclSuccess || rc2 != ncclSuccess)
+            return np::fail(NP_ERR_DEVICE, "loopback ncclSend/ncclRecv failed: %s", c.api.GetErrorString(rc != ncclSuccess ? rc : rc2));
+    }
     if (c.world == 1) return NP_OK;
     NP_RCCL_CHECK(c.api.GroupStart());
     for (int step = 1; step < c.world; ++step) {
@@ -329,7 +445,15 @@ int gather_on(hipStream_t s, const void *send, void *recv_base, size_t bytes, si
 
 int need_comm(const char *who) {
     if (!g_comm.comm) return np::fail(NP_ERR_INVALID, "%s: no communicator (np_comm_init first)", who);
-    return np::ensure_init();
+    if (int rc = np::ensure_init()) return rc;
+    if (g_comm.host_error && *(volatile unsigned *)g_comm.host_error) {
+        *(volatile unsigned *)g_comm.host_error = 0;
+        return np::fail(NP_ERR_DEVICE, "%s: an earlier device-side wait between the library and the communication stream "
+                                       "timed out (its producer never ran); results since then are incomplete", who);
+    }
+    // the caller may have moved the library onto another stream (np_set_stream): prove the flags again for that one
+    if (g_comm.flags_ok_for != np::stream()) return flags_self_test(np::stream());
+    return NP_OK;
 }
 
 }  // namespace
@@ -432,11 +556,31 @@ int np_allgather_async(const void *dev_send, void *dev_recv_base, size_t bytes, 
 int np_comm_wait(void) {
     if (int rc = need_comm("np_comm_wait")) return rc;
     if (!g_comm.pending) return NP_OK;
-    NP_HIP_CHECK(hipEventRecord(g_comm.drained, g_comm.stream));
-    NP_HIP_CHECK(hipStreamWaitEvent(np::stream(), g_comm.drained, 0));
+    if (int rc = stream_follows(np::stream(), g_comm.stream, g_comm.flags + 1, g_comm.drained_seq, g_comm.drained)) return rc;
     g_comm.pending = false;
     return NP_OK;
 }
+
+int np_comm_set_variant(int variant) {
+    if (variant < 0 || variant > 2)
+        return np::fail(NP_ERR_INVALID, "np_comm_set_variant: 0 = device-side flags + one progress-reporting GEMM launch (default), "
+                                        "1 = HIP events, one GEMM launch per piece, 2 = device-side flags, one GEMM launch per piece");
+    g_sync_variant = variant;
+    if (g_comm.comm) return flags_self_test(np::stream());
+    return NP_OK;
+}
+
+// testing: from now on every piece gathered through the p2p path is also sent from this rank to itself into
+// dev_scratch (pieces larger than `bytes` are not) — the only RCCL transfer a one-GPU box can run next to the GEMM.
+// (nullptr, 0) switches it off.
+int np_comm_debug_loopback(void *dev_scratch, size_t bytes) {
+    if (int rc = need_comm("np_comm_debug_loopback")) return rc;
+    g_comm.loopback = (char *)dev_scratch;
+    g_comm.loopback_bytes = dev_scratch ? bytes : 0;
+    return NP_OK;
+}
+
+int np_comm_sync_mode(void) { return g_comm.comm ? (g_comm.use_flags ? 1 : 0) : -1; }
 
 // Piece c of a slab cut into `chunks` pieces: as equal as they come, the first slab % chunks pieces hold one item
 // more.  Pure arithmetic (no device, no communicator): every rank cuts its slab the same way, which is what makes
@@ -469,6 +613,38 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
                                         "(chunks = 1); pieces of a slab are not contiguous across ranks");
     const size_t mat = M * N, slab_elems = slab * mat;
     float *mine = C_full + (size_t)g_comm.rank * slab_elems;
+    Comm &cm = g_comm;
+    if (cm.use_flags && g_sync_variant == 0 && chunks <= Comm::kMaxPieces) {
+        // ONE launch for the whole slab; its workgroups count finished tiles per piece in cm.flags[8 + c] (zero here:
+        // the previous call's last act on the communication stream was to clear them, and np_comm_wait ordered this
+        // call's GEMM behind that)
+        unsigned tiles = 0;
+        unsigned *counters = cm.flags + 8;
+        if (int rc = np::sgemm_batched_with_progress(slab, M, N, K, A, stride_a, B, stride_b, mine, mat, counters, chunks, &tiles))
+            return rc;
+        if (tiles) {
+            cm.pending = true;
+            for (int c = 0; c < chunks; ++c) {
+                size_t lo = 0, count = 0;
+                if (int rc = np_comm_piece(slab, chunks, c, &lo, &count)) return rc;
+                flag_wait_kernel<<<1, 1, 0, cm.stream>>>(counters + c, (unsigned)(count * tiles), kWaitTimeoutTicks, cm.host_error);
+                NP_LAUNCH_CHECK("flag_wait_kernel");
+                if (int rc = gather_on(cm.stream, mine + lo * mat, C_full + lo * mat, count * mat * sizeof(float),
+                                       slab_elems * sizeof(float), chunks == 1 ? mode == NP_GATHER_P2P : true))
+                    return rc;
+            }
+            // counters back to zero + "drained" published in one kernel; the library stream then waits for that number:
+            // whatever the caller enqueues next (or np_sync) sees the gathered result
+            ++cm.drained_seq;
+            finish_kernel<<<1, 64, 0, cm.stream>>>(counters, chunks, cm.flags + 1, cm.drained_seq);
+            NP_LAUNCH_CHECK("finish_kernel");
+            flag_wait_kernel<<<1, 1, 0, np::stream()>>>(cm.flags + 1, cm.drained_seq, kWaitTimeoutTicks, cm.host_error);
+            NP_LAUNCH_CHECK("flag_wait_kernel");
+            cm.pending = false;
+            return NP_OK;
+        }
+        // (a shape whose plan is not a single tiled launch: nothing was launched, take the per-piece form)
+    }
     for (int c = 0; c < chunks; ++c) {
         size_t lo = 0, count = 0;
         if (int rc = np_comm_piece(slab, chunks, c, &lo, &count)) return rc;

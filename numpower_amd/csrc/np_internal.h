@@ -54,6 +54,10 @@ inline size_t capped_grid(size_t wanted, size_t cap) {
 }
 // One-block fold of per-workgroup partials into one device float (np_reduce.hip); op = NP_SUM / PROD / MIN / MAX.
 int fold_partials(int op, const float *partials, size_t n, float *dev_out);
+// Batched GEMM in one launch with per-piece progress counters (np_sgemm.hip; used by np_comm.hip's overlapped pipeline).
+int sgemm_batched_with_progress(size_t batch, size_t M, size_t N, size_t K, const float *A, size_t stride_a, const float *B,
+                                size_t stride_b, float *C, size_t stride_c, unsigned *counters, int chunks,
+                                unsigned *tiles_per_matrix);
 // Copy kernel for large word-aligned device-to-device copies (np_elementwise.hip); bytes % 4 == 0.
 int device_copy(void *dst, const void *src, size_t bytes);
 

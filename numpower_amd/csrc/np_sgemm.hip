@@ -46,7 +46,30 @@ struct GemmArgs {
     unsigned swizzle;                       // 0 = row-major tile order, else XCD-aware grouping
     unsigned prio_period;                   // sgemm_dma_kernel<.., PRIO>: K-tiles between priority flips (see there)
     unsigned long long *probe;              // optional per-workgroup timing record (debug), else null
+    // Progress reporting (np::sgemm_batched_with_progress): when non-null, every workgroup adds 1 to progress[c] once its
+    // C tile is visible device-wide, c = the piece (np_comm_piece split: piece_extra pieces of piece_base + 1 batch
+    // entries, then pieces of piece_base) its batch entry belongs to.  A wait kernel on another stream releases the
+    // transfer of piece c the moment its last tile has landed — no second launch, no host round trip.
+    unsigned *progress;
+    unsigned piece_base, piece_extra;
 };
+
+// Last statement of sgemm_dma_kernel (all threads of the workgroup call it).  In progress mode the kernel stores C with
+// device-scope (memory-side) stores, so a tile is visible to every XCD once its stores are acknowledged: each wave
+// waits for its own (s_waitcnt 0), the barrier collects the four waves, one memory-side atomic reports the tile.  No
+// device-scope FENCE: that is an L2 write-back per workgroup, and 2048 of them cost the 64 x 1024^3 slab half its rate
+// (0.96 -> 1.43 ms, profiles/r03/chunk_overhead.log, first version) — the same lesson as np_internal.h's ticket.
+__device__ __forceinline__ void progress_signal(const GemmArgs &g) {
+    if (!g.progress) return;   // uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned b = blockIdx.z, big = g.piece_extra * (g.piece_base + 1);
+        const unsigned c = b < big ? b / (g.piece_base + 1) : g.piece_extra + (b - big) / g.piece_base;
+        __hip_atomic_fetch_add(g.progress + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // Debug instrumentation: per workgroup {shader-clock start, end, 100 MHz wall start, end, XCC id}.
 // Used by tools/gemm_probe.py to separate "cycles lost to stalls" from "clock lowered by DVFS".
@@ -686,18 +709,29 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     if (kt + 1 < nk) k_tile(F{}, T{});
     k_tile(F{}, F{});
 
+    const auto store_tile = [&](auto coherent) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const unsigned col = n0 + wn0 + j * 32 + li;
-                if (!EDGE || (row < g.M && col < (g.n_store ? g.n_store : g.N)))
-                    __builtin_nontemporal_store(acc[i][j][r], &C[(size_t)row * g.ldc + col]);   // C is never re-read here
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const unsigned col = n0 + wn0 + j * 32 + li;
+                    if (!EDGE || (row < g.M && col < (g.n_store ? g.n_store : g.N))) {
+                        if constexpr (decltype(coherent)::value)   // progress mode: performed at the memory side, past this XCD's L2
+                            __hip_atomic_store(&C[(size_t)row * g.ldc + col], acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else
+                            __builtin_nontemporal_store(acc[i][j][r], &C[(size_t)row * g.ldc + col]);   // C is never re-read here
+                    }
+                }
+    };
+    if (g.progress)
+        store_tile(std::true_type{});
+    else
+        store_tile(std::false_type{});
     probe_end(g, probe_c0, probe_w0);
+    progress_signal(g);
 }
 
 // Zero-padded copy of a row-major matrix: out (rows_out x ld_out, ld_out % 4 == 0, 16-byte aligned)
@@ -1164,6 +1198,21 @@ unsigned long long *g_probe = nullptr;
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
+// What np::sgemm_batched_with_progress asks of the ONE launch it makes (host-side plumbing; the entry points are not
+// re-entrant across threads for this request, like the communicator that is its only caller).
+struct ProgressRequest {
+    unsigned *counters = nullptr;
+    unsigned base = 0, extra = 0;
+    unsigned tiles_per_matrix = 0;   // out: written by the launcher that took the request
+    unsigned launches = 0;           // out: kernel launches made while the request was active
+};
+ProgressRequest g_progress;
+inline void note_progress_launch(const GemmArgs &g) {
+    if (!g.progress) return;
+    g_progress.tiles_per_matrix = g.tiles_m * g.tiles_n;
+    ++g_progress.launches;
+}
+
 template <int BM, int BN, int BK, int MINW>
 int launch_sgemm_tile(GemmArgs g, unsigned batch, bool vec) {
     g.tiles_m = (g.M + BM - 1) / BM;
@@ -1233,6 +1282,7 @@ int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
         } else
             sgemm_dma_kernel<false, false><<<grid, 256, 0, np::stream()>>>(g);
         NP_LAUNCH_CHECK("sgemm_dma_kernel");
+        note_progress_launch(g);
         return NP_OK;
     }
     if (cfg == 1) return launch_sgemm_tile<128, 128, 16, 4>(g, batch, vec);
@@ -1422,6 +1472,9 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
     g.tiles_m = g.tiles_n = 0;
     g.prio_period = 0;
     g.probe = g_probe;
+    g.progress = g_progress.counters;
+    g.piece_base = g_progress.base;
+    g.piece_extra = g_progress.extra;
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(B) &&
                      (sa % 4 == 0) && (sb % 4 == 0);
     // variant = tile_code + 10 * swizzle_group ; 0 = default
@@ -1564,6 +1617,43 @@ int launch_thin(size_t M, size_t N, size_t K, const float *A, const float *B, fl
 }
 
 }  // namespace
+
+namespace np {
+
+// The batched GEMM as ONE launch whose workgroups report progress (GemmArgs::progress): counters[c] += 1 for every
+// finished tile of piece c, the np_comm_piece split of `batch` into `chunks`.  *tiles_per_matrix = how many tiles one
+// batch entry contributes (piece c is complete at count(c) * tiles_per_matrix), or 0 when this shape's plan is not a
+// single launch of the LDS-DMA kernel (small or unaligned matrices) — nothing has been launched then and the caller
+// issues one launch per piece instead.
+int sgemm_batched_with_progress(size_t batch, size_t M, size_t N, size_t K, const float *A, size_t stride_a, const float *B,
+                                size_t stride_b, float *C, size_t stride_c, unsigned *counters, int chunks,
+                                unsigned *tiles_per_matrix) {
+    *tiles_per_matrix = 0;
+    // batch >= 2: the planner never splits K or pads there, the plan is one launch_cfg (plan_sgemm / launch_planned)
+    if (batch < 2 || batch > 65535 || M == 0 || N == 0 || K == 0 || chunks < 1 || (size_t)chunks > batch || g_variant != 0 ||
+        !A || !B || !C || !counters)
+        return NP_OK;
+    if (int rc = np::ensure_init()) return rc;
+    // only the LDS-DMA kernel reports progress: ask the planner BEFORE anything is launched
+    const size_t lda = K;
+    const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(B) && (stride_a % 4 == 0) &&
+                     (stride_b % 4 == 0);
+    const bool dma_ok = vec && N >= 4;
+    if (!dma_ok) return NP_OK;
+    const Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec);
+    if (p.cfg != 0 || p.tail_rows != 0) return NP_OK;
+    g_progress = ProgressRequest{counters, (unsigned)(batch / (size_t)chunks), (unsigned)(batch % (size_t)chunks), 0, 0};
+    const int rc = launch_sgemm(batch, M, N, K, A, lda, stride_a, B, stride_b, C, stride_c);
+    const ProgressRequest done = g_progress;
+    g_progress = ProgressRequest{};
+    if (rc) return rc;
+    if (done.launches != 1)
+        return np::fail(NP_ERR_DEVICE, "np_sgemm: internal error: a progress-reporting GEMM made %u launches", done.launches);
+    *tiles_per_matrix = done.tiles_per_matrix;
+    return NP_OK;
+}
+
+}  // namespace np
 
 extern "C" {
 

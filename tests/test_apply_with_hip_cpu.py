@@ -1,0 +1,117 @@
+"""tools/apply_with_hip.py — INTEGRATION.md section 2a as a mechanically checkable artefact.
+
+Runs the tool on a scratch copy of the reference checkout (this container only: /root/reference does not exist on
+the GPU box, where these tests skip; nothing of the reference is committed or shipped) and asserts that
+  * every edit's anchor is found exactly as many times as the tool expects (no anchor missing or ambiguous),
+  * each replaced statement is kept on the #else side, so the tree still builds --with-cuda,
+  * with HAVE_NP_HIP + HAVE_CUBLAS defined, no preprocessor-visible line of the extension's C sources names the
+    CUDA runtime or cuBLAS any more,
+  * the glue travels with the tree (src/hip/),
+and that the tool fails loudly — not silently — when an anchor has moved."""
+import re
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(ROOT / "tools"))
+
+pytestmark = pytest.mark.skipif(not (REF / "numpower.c").exists(), reason="reference checkout not present on this box")
+
+
+@pytest.fixture(scope="module")
+def patched(tmp_path_factory):
+    import apply_with_hip as tool
+    out = tmp_path_factory.mktemp("with_hip") / "numpower"
+    applied = tool.apply(REF, out)
+    return tool, out, applied
+
+
+def test_every_edit_applies_exactly_as_often_as_expected(patched):
+    tool, out, applied = patched
+    assert len(applied) == len(tool.EDITS)
+    for e in tool.EDITS:
+        assert applied[e.what] == e.expect, e.what
+    # 7 header swaps + the call sites of INTEGRATION.md section 2a
+    assert sum(1 for e in tool.EDITS if "CUDA headers" in e.what) == 7
+
+
+def test_no_cuda_runtime_name_is_visible_to_a_hip_build(patched):
+    tool, out, _ = patched
+    assert tool.check_tree(out) == []
+    # the checker is not vacuous: the UNPATCHED tree fails it, at the very call sites the table lists
+    problems = []
+    for rel in ("numpower.c", "src/ndarray.c", "src/initializers.c", "src/ndmath/arithmetics.c", "src/ndmath/linalg.c", "src/debug.c"):
+        problems += ["%s:%d" % (rel, no) for no, _ in tool.hip_visible_cuda_names((REF / rel).read_text())]
+    for site in ("src/ndarray.c:1055", "src/ndarray.c:1090", "src/initializers.c:439", "src/initializers.c:443",
+                 "src/initializers.c:758", "src/ndmath/arithmetics.c:218", "src/ndmath/arithmetics.c:883",
+                 "src/ndmath/linalg.c:68", "numpower.c:623", "numpower.c:633"):
+        assert site in problems, site
+
+
+def test_the_cuda_side_is_kept_verbatim(patched):
+    """Each wrapped edit leaves the reference's statement on the #else side: with HAVE_NP_HIP undefined the patched
+    file preprocesses back to the reference's text."""
+    tool, out, _ = patched
+
+    def without_hip(text):
+        keep, stack = [], []          # stack entries: True = inside the HAVE_NP_HIP side of one of OUR blocks, False = its #else side
+        for line in text.split("\n"):
+            s = line.strip()
+            if s == "#ifdef HAVE_NP_HIP":
+                stack.append(True)
+                continue
+            if stack and s == "#else" and stack[-1] is True:
+                stack[-1] = False
+                continue
+            if stack and s == "#endif" and stack[-1] is False:
+                stack.pop()
+                continue
+            if stack and stack[-1] is True:
+                continue
+            keep.append(line)
+        return "\n".join(keep)
+
+    for rel in sorted({e.file for e in tool.EDITS if e.wrap}):
+        assert without_hip((out / rel).read_text()) == (REF / rel).read_text(), rel
+
+
+def test_the_glue_and_the_configure_option_travel_with_the_tree(patched):
+    tool, out, _ = patched
+    for g in tool.GLUE_FILES:
+        assert (out / "src" / "hip" / Path(g).name).read_bytes() == (ROOT / g).read_bytes()
+    m4 = (out / "config.m4").read_text()
+    assert "PHP_ARG_WITH([hip]" in m4 and "$NP_GPU_ALLOC_SOURCES \\" in m4 and "src/gpu_alloc.c \\" not in m4
+    assert 'NP_GPU_ALLOC_SOURCES="src/gpu_alloc.c"' in m4          # the default keeps the CUDA / CPU builds as they were
+    for src in re.search(r'NP_GPU_ALLOC_SOURCES="(src/hip/[^"]+)"', m4).group(1).split():
+        assert (out / src).exists(), src
+    numpower = (out / "numpower.c").read_text()
+    assert "NDArrayMathGPU_ElementWise(nda, cuda_float_rsqrt)" in numpower and "NDArrayMathGPU_ElementWise(nda, cuda_float_exp2)" in numpower
+
+
+def test_a_moved_anchor_is_a_hard_error(tmp_path):
+    import apply_with_hip as tool
+    broken = tmp_path / "broken"
+    shutil.copytree(REF, broken, ignore=shutil.ignore_patterns(".git"))
+    text = (broken / "src" / "ndarray.c").read_text()
+    assert "cudaMemcpyDeviceToHost);" in text
+    (broken / "src" / "ndarray.c").write_text(text.replace("cudaMemcpy(rtn->data, NDArray_FDATA(target)", "cudaMemcpy(rtn->data , NDArray_FDATA(target)"))
+    with pytest.raises(tool.PatchError, match=r"ndarray\.c:1090 .* matched 0 time"):
+        tool.apply(broken, tmp_path / "out1")
+    # ... and so is an ambiguous one (the same statement twice)
+    twice = tmp_path / "twice"
+    shutil.copytree(REF, twice, ignore=shutil.ignore_patterns(".git"))
+    t = (twice / "src" / "initializers.c").read_text()
+    line = "            cudaMemset(rtn->data, 0, rtn->descriptor->numElements * sizeof(float));\n"
+    assert t.count(line) == 1
+    (twice / "src" / "initializers.c").write_text(t.replace(line, line + line))
+    with pytest.raises(tool.PatchError, match="matched 2 time"):
+        tool.apply(twice, tmp_path / "out2")
+    # the command line reports it with exit status 2
+    proc = subprocess.run([sys.executable, str(ROOT / "tools" / "apply_with_hip.py"), str(broken), str(tmp_path / "out3")],
+                          capture_output=True, text=True)
+    assert proc.returncode == 2 and "matched 0 time" in proc.stderr

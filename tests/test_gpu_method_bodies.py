@@ -47,7 +47,7 @@ UNARY = [("sin", -10, 10), ("cos", -10, 10), ("tan", -1.4, 1.4), ("arcsin", -1, 
          ("log2", 0.01, 100), ("log10", 0.01, 100), ("log1p", -0.9, 50), ("logb", 0.01, 100), ("sqrt", 0, 100),
          ("reciprocal", 0.1, 10), ("negate", -10, 10), ("positive", -10, 10), ("sign", -10, 10),
          ("floor", -10, 10), ("ceil", -10, 10), ("trunc", -10, 10), ("fix", -10, 10), ("rint", -10, 10),
-         ("radians", -360, 360), ("degrees", -7, 7), ("sinc", -5, 5)]
+         ("radians", -360, 360), ("degrees", -7, 7), ("sinc", -5, 5), ("rsqrt", 0.01, 100), ("exp2", -10, 10)]
 
 
 @pytest.fixture(scope="module")
