@@ -438,8 +438,9 @@ int np_comm_debug_sendrecv_self(const void *dev_src, void *dev_dst, size_t bytes
  * (pieces larger than `bytes` are not): real RCCL traffic next to the GEMM on a box without a peer.  (NULL, 0) = off. */
 int np_comm_debug_loopback(void *dev_scratch, size_t bytes);
 
-/* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 = whole-K plans only,
- * -2 = default planner again, -3 = default planner + always pad unaligned operands). */
+/* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 = whole-K plans only (no split-K, no
+ * stream-K), -2 = default planner again, -3 = default planner + always pad unaligned operands, -4 = stream-K wherever
+ * the kernel can run it, -5 = default planner without stream-K). */
 int np_runtime_set_variant(int variant);   /* how host-result calls wait: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag, 2 = spin on the result itself (default) */
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);

@@ -100,10 +100,17 @@ __device__ __forceinline__ void horner32(const float (&x)[N], float (&r)[N], con
 
 // |x|^y for N elements, |x| normal and finite (xb = its bits), y finite; garbage (never a trap, never an
 // out-of-bounds table index) otherwise.
-// `tab`: the 32-entry table — a wave-private copy in LDS in the streaming kernel (ds_read_b128 per element;
-// read straight from global memory the per-lane gathers made the kernel wait on the vector cache:
-// SQ_WAIT_ANY doubled and 213 us became 232, profiles/r02/pow_r02.log), kPowLogTab itself elsewhere.
+// `tab`: the 32-entry table — in LDS in the streaming kernel (ds_read_b128 per element; read straight from global
+// memory the per-lane gathers made the kernel wait on the vector cache: SQ_WAIT_ANY doubled and 213 us became 232,
+// profiles/r02/pow_r02.log), kPowLogTab itself elsewhere.
 typedef const __attribute__((address_space(3))) PowLogEntry *PowTabLds;
+// One 512-byte copy per wave.  Entries e and e + 16 share banks, and with a random entry per lane 44 % of the lookup's
+// LDS cycles are bank conflicts (SQ_LDS_BANK_CONFLICT 6.1e6 of SQ_LDS_IDX_ACTIVE 1.39e7, profiles/r02/pmc_sq_final.txt)
+// — but they are not on the critical path: the kernel is bound by its fp64 arithmetic.  Round 3 tried the
+// conflict-free layout (16 replicas, entry-major, lane l reads replica l & 15: SQ_LDS_BANK_CONFLICT = 0 of 9.4e6,
+// profiles/r03/pmc_sq_pow_replicated.txt): staging 8 KB per workgroup made the uncapped grid's 49 000 workgroups
+// read 400 MB of table from L2 (218 us against 205), and a grid capped at 8-18 workgroups per CU to amortise it ran
+// 220-233 us (profiles/r03/pow_ab.log) — every form slower than the conflicting one, which therefore stays.
 
 template <int N, typename Tab>
 __device__ __forceinline__ void pow_core_n(const unsigned (&xb)[N], const float *y, float *out, Tab tab) {
@@ -1305,17 +1312,25 @@ __global__ __launch_bounds__(256) void fused_chain_cols_kernel(FusedArgs by_valu
     if (slot < slots_per_row)
         fused_span_impl<2, G, LIGHT, I, true>(f, out, r0 * cols, (r1 - r0) * slots_per_row, wave * slots_per_row + slot,
                                               4 * slots_per_row, racc, rv);
-    __shared__ float part[4][64][G];
+    // cross-wave combine through LDS, lane fastest: a wave's 64 stores / loads of one element land on 64 different banks
+    // (lane-major [lane][e] put lanes l and l + 16 on one bank: 74 % of this kernel's LDS cycles were conflicts)
+    __shared__ float part[4][G][64];
 #pragma unroll
-    for (int e = 0; e < G; ++e) part[wave][lane][e] = sink_combine(sink, rv[e], rv[G + e]);
+    for (int e = 0; e < G; ++e) part[wave][e][lane] = sink_combine(sink, rv[e], rv[G + e]);
     __syncthreads();
+    float v[G];
+#pragma unroll
+    for (int e = 0; e < G; ++e) {
+        v[e] = part[0][e][lane];
+        for (int w = 1; w < 4; ++w) v[e] = sink_combine(sink, v[e], part[w][e][lane]);
+    }
+    // One row of results per chunk of rows; with several chunks np_reduce_axis folds them in a second launch.  (Round 3
+    // folded them here, in the last workgroup of each column block to finish — memory-side partials, a ticket per block,
+    // profiles/r03/fused_cols_ab.log: 96 us against 75 + the ~9 us second launch.  The 64 partial rows arrive one
+    // memory round trip after the other at the end of a kernel that has nothing left to hide them behind.)
     if (wave == 0 && slot < slots_per_row) {
 #pragma unroll
-        for (int e = 0; e < G; ++e) {
-            float v = part[0][lane][e];
-            for (int w = 1; w < 4; ++w) v = sink_combine(sink, v, part[w][lane][e]);
-            out[(size_t)blockIdx.y * cols + (size_t)slot * G + e] = mean_div != 0.0f ? v / mean_div : v;
-        }
+        for (int e = 0; e < G; ++e) out[(size_t)blockIdx.y * cols + (size_t)slot * G + e] = mean_div != 0.0f ? v[e] / mean_div : v[e];
     }
 }
 

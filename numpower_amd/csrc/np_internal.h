@@ -37,6 +37,8 @@ struct ResultCall {
 // from a ring of 1024, and put back to zero by the workgroup that used it up, so a slot is clean again long before
 // the ring comes round (nullptr + error set on failure).
 unsigned *next_ticket();
+// `count` consecutive zeroed counters (count <= 256), one per independent fold of the same launch
+unsigned *next_tickets(unsigned count);
 // Largest first-pass grid whose partials are folded by its own last workgroup rather than by a second kernel.  The
 // ticket is one hot address (~20 ns per workgroup at the memory side) and every workgroup waits a round trip for its
 // own: with 2049 workgroups the in-kernel fold LOST 5 us on a 63 us sum of 10^8 floats; on small grids it saves the

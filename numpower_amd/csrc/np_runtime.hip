@@ -185,6 +185,7 @@ float *result_slots(int count) {
 }
 
 constexpr unsigned kTicketRing = 1024;
+unsigned *next_tickets(unsigned count);
 
 // np_init allocates the ring (not the first reduction: that one may be inside a stream capture)
 static int alloc_tickets_locked(DeviceState &d) {
@@ -200,12 +201,22 @@ static int alloc_tickets_locked(DeviceState &d) {
     return NP_OK;
 }
 
-unsigned *next_ticket() {
+unsigned *next_ticket() { return next_tickets(1); }
+
+// `count` consecutive tickets (count <= kTicketRing / 4): a run that would cross the end of the ring starts over at slot 0
+unsigned *next_tickets(unsigned count) {
     Runtime &r = rt();
     std::lock_guard<std::mutex> lk(r.mu);
     DeviceState &d = r.cur();
+    if (count == 0 || count > kTicketRing / 4) {
+        fail(NP_ERR_INVALID, "internal: %u tickets asked of a ring of %u", count, kTicketRing);
+        return nullptr;
+    }
     if (alloc_tickets_locked(d) != NP_OK) return nullptr;
-    return d.tickets + (d.ticket_seq++ % kTicketRing);
+    unsigned at = d.ticket_seq % kTicketRing;
+    if (at + count > kTicketRing) at = 0;
+    d.ticket_seq = at + count;
+    return d.tickets + at;
 }
 
 // Waiting for a host result.  hipStreamSynchronize costs 5-6 us of driver time per call on top of the kernels, a

@@ -496,11 +496,19 @@ __global__ __launch_bounds__(256, 2) void sgemm_pipe_kernel(GemmArgs g) {
 // 2.39 M cycles after their start).  With PRIO every wave reads its slot in the SIMD (HW_ID.WAVE_ID bit 0: the
 // two resident waves differ in it) and raises / drops s_setprio every g.prio_period K-tiles in opposite phase to
 // its neighbour: each workgroup is the favoured one half of the time, both finish together.
-template <bool EDGE, bool KTAIL, bool PRIO = false>
-__global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
-    if (g.K_last && blockIdx.z + 1 == gridDim.z) g.K = g.K_last;   // uniform: split-K remainder chunk
-    constexpr int BM = 256, BN = 128, BK = 16;
-    constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
+// The body of the LDS-DMA GEMM: one 256 x 128 tile of A . B over `K` inner elements starting at the pointers given
+// (A: the tile's first k column of the matrix, B: its first k row), accumulators handed to `epilogue(acc)`.  A device
+// function so that two kernels share it: sgemm_dma_kernel (one whole tile per workgroup) and sgemm_streamk_kernel
+// (a workgroup walks a contiguous range of (tile, k) iterations, i.e. a few SEGMENTS of tiles).  `K` is this
+// segment's inner length: a K tail (K % 16) exists only in the segment that holds the tile's last k.
+constexpr int kDmaBM = 256, kDmaBN = 128, kDmaBK = 16, kDmaTM = 4, kDmaTN = 2;
+typedef v16f DmaAcc[kDmaTM][kDmaTN];
+
+template <bool EDGE, bool KTAIL, bool PRIO>
+__device__ __forceinline__ void dma_gemm_segment(const GemmArgs &g, const float *A, const float *B, const unsigned m0,
+                                                 const unsigned n0, const unsigned K, DmaAcc &acc) {
+    constexpr int BM = kDmaBM, BN = kDmaBN, BK = kDmaBK;
+    constexpr int WM = 128, WN = 64, TM = kDmaTM, TN = kDmaTN;
     constexpr int A_SZ = BM * BK, B_SZ = BK * BN;   // floats per buffer: 4096 + 2048
 
     __shared__ __attribute__((aligned(16))) float smem[3 * (A_SZ + B_SZ)];
@@ -512,16 +520,6 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     const unsigned li = lane & 31, lh = lane >> 5;
     const unsigned wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
 
-    unsigned tile_m, tile_n;
-    tile_coords(g, blockIdx.x, tile_m, tile_n);
-    const unsigned m0 = tile_m * BM, n0 = tile_n * BN;
-    unsigned long long probe_c0 = 0, probe_w0 = 0;
-    probe_begin(g, probe_c0, probe_w0);
-
-    const float *A = g.A + (size_t)blockIdx.z * g.stride_a;
-    const float *B = g.B + (size_t)blockIdx.z * g.stride_b;
-    float *C = g.C + (size_t)blockIdx.z * g.stride_c;
-
     // DMA source pointers of this lane for K-tile 0 (advanced by BK / BK rows per tile).
     // A: the wave moves 4 chunks of 16 rows x 64 B; lane = (row_in_chunk, slot); slot p of row r
     //    fetches k-chunk p ^ ((r >> 2) & 3).
@@ -530,8 +528,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     // K % 4 == 0).  Its out-of-range slots are fetched from clamped addresses (k-chunk 0 / B row
     // kr-1: valid memory) and overwritten with zeros by the lane that DMA'd them, after they have
     // landed and before the barrier that publishes the tile — the loop itself is unchanged.
-    const unsigned nk = (g.K + BK - 1) / BK;
-    const unsigned kr = g.K - (nk - 1) * BK;          // 16 = no tail
+    const unsigned nk = (K + BK - 1) / BK;
+    const unsigned kr = K - (nk - 1) * BK;          // 16 = no tail
     const float *a_src[4];
     unsigned a_q[4];                                   // k-chunk (0..3) this lane fetches for chunk c
 #pragma unroll
@@ -588,7 +586,6 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     };
     const bool has_tail = KTAIL && kr < BK;
 
-    v16f acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -709,29 +706,165 @@ __global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
     if (kt + 1 < nk) k_tile(F{}, T{});
     k_tile(F{}, F{});
 
-    const auto store_tile = [&](auto coherent) {
+}
+
+// element (i, j, r) of a lane's accumulators <-> row / column inside the 256 x 128 tile
+__device__ __forceinline__ void dma_acc_coords(unsigned &row0, unsigned &col0) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    row0 = (wave >> 1) * 128 + 4 * (lane >> 5);   // + i * 32 + (r & 3) + 8 * (r >> 2)
+    col0 = (wave & 1) * 64 + (lane & 31);         // + j * 32
+}
+
+template <bool EDGE, bool COHERENT>
+__device__ __forceinline__ void dma_store_tile(const GemmArgs &g, float *C, unsigned m0, unsigned n0, const DmaAcc &acc) {
+    unsigned row0, col0;
+    dma_acc_coords(row0, col0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < kDmaTM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < kDmaTN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const unsigned col = n0 + wn0 + j * 32 + li;
-                    if (!EDGE || (row < g.M && col < (g.n_store ? g.n_store : g.N))) {
-                        if constexpr (decltype(coherent)::value)   // progress mode: performed at the memory side, past this XCD's L2
-                            __hip_atomic_store(&C[(size_t)row * g.ldc + col], acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        else
-                            __builtin_nontemporal_store(acc[i][j][r], &C[(size_t)row * g.ldc + col]);   // C is never re-read here
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const unsigned row = m0 + row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                const unsigned col = n0 + col0 + j * 32;
+                if (!EDGE || (row < g.M && col < (g.n_store ? g.n_store : g.N))) {
+                    if constexpr (COHERENT)   // performed at the memory side, past this XCD's L2
+                        __hip_atomic_store(&C[(size_t)row * g.ldc + col], acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        __builtin_nontemporal_store(acc[i][j][r], &C[(size_t)row * g.ldc + col]);   // C is never re-read here
                 }
-    };
+            }
+}
+
+template <bool EDGE, bool KTAIL, bool PRIO = false>
+__global__ __launch_bounds__(256, 2) void sgemm_dma_kernel(GemmArgs g) {
+    if (g.K_last && blockIdx.z + 1 == gridDim.z) g.K = g.K_last;   // uniform: split-K remainder chunk
+    unsigned tile_m, tile_n;
+    tile_coords(g, blockIdx.x, tile_m, tile_n);
+    const unsigned m0 = tile_m * kDmaBM, n0 = tile_n * kDmaBN;
+    unsigned long long probe_c0 = 0, probe_w0 = 0;
+    probe_begin(g, probe_c0, probe_w0);
+    const float *A = g.A + (size_t)blockIdx.z * g.stride_a;
+    const float *B = g.B + (size_t)blockIdx.z * g.stride_b;
+    float *C = g.C + (size_t)blockIdx.z * g.stride_c;
+    DmaAcc acc;
+    dma_gemm_segment<EDGE, KTAIL, PRIO>(g, A, B, m0, n0, g.K, acc);
     if (g.progress)
-        store_tile(std::true_type{});
+        dma_store_tile<EDGE, true>(g, C, m0, n0, acc);
     else
-        store_tile(std::false_type{});
+        dma_store_tile<EDGE, false>(g, C, m0, n0, acc);
     probe_end(g, probe_c0, probe_w0);
     progress_signal(g);
+}
+
+// ---- stream-K ------------------------------------------------------------------------------------------------
+// One tile per workgroup wastes the machine whenever the number of tiles is not a multiple of what is resident
+// (512 workgroups): 3000^3 is 288 tiles, 2048^3 is 128, 4097^3 (padded) 561 — a third wave of 49 tiles behind two
+// full ones.  Here the unit of work is the K-TILE: the T x nk iterations of the product, tile-major, are cut into
+// gridDim.x equal contiguous ranges, one per workgroup (Osama et al., "Stream-K", arXiv 2301.03598).  A range is at
+// most: the tail of one tile (its k from kb > 0 on), some whole tiles, the head of one more (k from 0 up to ke < nk).
+//   whole tile            stored straight to C
+//   segment with kb > 0   its accumulators go to this workgroup's slot of the workspace, then flag[w] = seq
+//   head segment (kb = 0, ke < nk)   the tile's FINISHER: it waits for the workgroups holding the rest of the tile —
+//                         w + 1, w + 2, ... which each met that tile FIRST in their range and so posted long ago —
+//                         adds their partials in that order and stores C.
+// The sum order of every element is fixed by the schedule: run to run the result is bit-identical.  Deadlock-free
+// even if not all workgroups are resident at once: a workgroup only ever waits for HIGHER-numbered ones, whose
+// contribution is the first thing they compute; the lower-numbered residents therefore finish and make room.
+// Partials and flags travel by memory-side stores / loads (np_internal.h: the XCD L2s are not coherent).
+struct StreamKArgs {
+    float *workspace;       // gridDim.x slots of 256 x 128 floats: a workgroup's partial tile, row-major
+    unsigned *flags;        // gridDim.x words; flag[w] == seq <=> workgroup w's partial of THIS launch is in its slot
+    unsigned seq;
+    unsigned nk;            // k-tiles per tile
+    unsigned long long iters_total;   // tiles * nk
+};
+
+template <bool EDGE, bool KTAIL, bool PRIO = false>
+__global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, StreamKArgs sk) {
+    const unsigned long long G = gridDim.x, w = blockIdx.x;
+    const unsigned long long it0 = sk.iters_total * w / G, it1 = sk.iters_total * (w + 1) / G;
+    bool first = true;
+    for (unsigned long long it = it0; it < it1;) {
+        const unsigned t = (unsigned)(it / sk.nk), kb = (unsigned)(it - (unsigned long long)t * sk.nk);
+        const unsigned long long tile_end = (unsigned long long)(t + 1) * sk.nk;
+        const unsigned ke = (unsigned)((it1 < tile_end ? it1 : tile_end) - (unsigned long long)t * sk.nk);
+        unsigned tile_m, tile_n;
+        tile_coords(g, t, tile_m, tile_n);
+        const unsigned m0 = tile_m * kDmaBM, n0 = tile_n * kDmaBN;
+        const unsigned K = ke == sk.nk ? g.K - kb * kDmaBK : (ke - kb) * kDmaBK;
+        if (!first) __syncthreads();   // the previous segment's last LDS reads are done before this one's DMAs land
+        first = false;
+        DmaAcc acc;
+        dma_gemm_segment<EDGE, KTAIL, PRIO>(g, g.A + (size_t)kb * kDmaBK, g.B + (size_t)kb * kDmaBK * g.ldb, m0, n0, K, acc);
+        const unsigned long long next_it = it1 < tile_end ? it1 : tile_end;
+        unsigned row0, col0;
+        dma_acc_coords(row0, col0);
+        // the epilogue's addresses all derive from these two: made opaque HERE so that none of that arithmetic is hoisted
+        // above the K loop, where it lived in (and spilled from) registers the loop needs — 282 VGPRs spilled, and the
+        // scratch allocation throttled wave dispatch (2048^3: 222 us against 139 for the tile form)
+        asm volatile("" : "+v"(row0), "+v"(col0));
+        // finisher (this segment is the HEAD of a tile that ends in other workgroups): the rest of the tile is in
+        // workgroups w + 1 ... w_last, the one holding its last k-tile.  All their flags first — no data yet —
+        unsigned long long w_last = w;
+        if (kb == 0 && ke != sk.nk) {
+            w_last = (tile_end - 1) * G / sk.iters_total;                         // candidate owner of iteration tile_end - 1 ...
+            while (sk.iters_total * (w_last + 1) / G < tile_end) ++w_last;        // ... exact under the floor()s above
+            while (sk.iters_total * w_last / G >= tile_end) --w_last;
+            if (threadIdx.x == 0) {
+                for (unsigned long long p = w + 1; p <= w_last; ++p)
+                    while (np::dev::coherent_load(sk.flags + p) != sk.seq) __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        }
+        const unsigned n_partials = (unsigned)(w_last - w);
+        // ... then ONE store loop for every case — the tile of C, or (kb != 0: the tile's k = 0 lives in a lower-numbered
+        // workgroup) this workgroup's slot of the workspace seen as a 256 x 128 matrix of its own — with the finisher's
+        // partial sums folded in block by block on the way out (workgroup order = k order: the same sum every run).
+        // Separate loops for the cases cost 600-1200 B of scratch per lane and, through the scratch allocation, half the
+        // kernel's wave dispatch rate (2048^3: 222 us against 139 for the tile form).
+        const bool to_slot = kb != 0;
+        float *dst = to_slot ? sk.workspace + (size_t)w * (kDmaBM * kDmaBN) : g.C;
+        const unsigned ld = to_slot ? kDmaBN : g.ldc, r_base = to_slot ? 0u : m0, c_base = to_slot ? 0u : n0;
+        const unsigned lim_m = to_slot ? kDmaBM : g.M, lim_n = to_slot ? kDmaBN : (g.n_store ? g.n_store : g.N);
+        const float *peers = sk.workspace + (size_t)(w + 1) * (kDmaBM * kDmaBN);
+#pragma unroll
+        for (int i = 0; i < kDmaTM; ++i)
+#pragma unroll
+            for (int j = 0; j < kDmaTN; ++j) {
+                for (unsigned q = 0; q < n_partials; ++q) {
+                    const float *slot = peers + (size_t)q * (kDmaBM * kDmaBN);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {   // 8 loads in flight: the ragged instantiations have no more registers than that to spare
+                        float part[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r)
+                            part[r] = np::dev::coherent_load(slot + (row0 + i * 32 + (r & 3) + 8 * (2 * h + (r >> 2))) * kDmaBN + col0 + j * 32);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) acc[i][j][8 * h + r] += part[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned row = r_base + row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const unsigned col = c_base + col0 + j * 32;
+                    if (!EDGE || (row < lim_m && col < lim_n)) np::dev::coherent_store(&dst[(size_t)row * ld + col], acc[i][j][r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if (n_partials) {   // consumed: the flags end the launch as they began it
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (unsigned long long p = w + 1; p <= w_last; ++p) np::dev::coherent_store(sk.flags + p, 0u);
+        }
+        if (to_slot) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (threadIdx.x == 0) np::dev::coherent_store(sk.flags + w, sk.seq);
+        }
+        it = next_it;
+    }
 }
 
 // Zero-padded copy of a row-major matrix: out (rows_out x ld_out, ld_out % 4 == 0, 16-byte aligned)
@@ -1291,6 +1424,7 @@ int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
 
 bool g_force_pad = false;   // np_sgemm_set_variant(-3): always take launch_padded when it applies (tests)
 bool g_splitk = true;   // np_sgemm_set_variant(-1) turns the K-splitting plans off (A/B in tools/)
+int g_streamk = 0;      // np_sgemm_set_variant(-4): stream-K wherever the kernel can run it, (-5): never, (-2): back to the model
 
 // A plan = tile configuration + how many trailing tile-ROWS of C are computed split-K.
 //   tail_rows == 0        : one launch, every workgroup walks the whole K (the classic grid)
@@ -1353,6 +1487,8 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
 }
 
 int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec);
+int launch_streamk(GemmArgs g, unsigned G);
+double streamk_model(size_t M, size_t N, size_t K, unsigned *grid_out);
 
 // Operands the LDS-DMA kernel cannot take as they are — K % 16 != 0, rows that are not 16-byte
 // aligned (K % 4 or N % 4 != 0), odd base addresses — are copied once into zero-padded, aligned
@@ -1380,7 +1516,97 @@ int launch_padded(const GemmArgs &g, const Plan &p, size_t Kp, size_t Np) {
     q.ldb = (unsigned)Np;
     q.n_store = g.N;          // C keeps its real row length (ldc = N)
     q.N = (unsigned)Np;
+    if (g_streamk >= 0 && !q.progress) {   // the padded product is as ragged as they come (4097^3: 17 x 33 tiles, 49 of them in a third wave)
+        unsigned G = 0;
+        const double t_sk = streamk_model(q.M, Np, Kp, &G);
+        if (t_sk < 1e299 && (g_streamk > 0 || t_sk < 0.99 * p.t)) return launch_streamk(q, G);
+    }
     return launch_plan(p, q, 1, true);
+}
+
+// ---- stream-K launch (sgemm_streamk_kernel) ----
+// Flags live for the life of the process, one array per device, zero between launches: the finisher that consumes
+// workgroup p's partial puts flag[p] back to 0, so a launch leaves them as it found them (and a captured graph can be
+// replayed: nothing in the launch depends on a per-launch sequence number).
+constexpr unsigned kStreamKMaxGrid = 1024;
+unsigned *g_streamk_flags[16] = {};
+
+int streamk_flags(unsigned **flags) {
+    int dev = 0;
+    NP_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return np::fail(NP_ERR_INVALID, "np_sgemm: device %d out of range", dev);
+    if (!g_streamk_flags[dev]) {
+        void *p = nullptr;
+        NP_HIP_CHECK(hipMalloc(&p, kStreamKMaxGrid * sizeof(unsigned)));
+        NP_HIP_CHECK(hipMemset(p, 0, kStreamKMaxGrid * sizeof(unsigned)));
+        g_streamk_flags[dev] = (unsigned *)p;
+    }
+    *flags = g_streamk_flags[dev];
+    return NP_OK;
+}
+
+// Modelled time of the stream-K form of an M x N x K product (one matrix; rows float4-loadable), or a huge number
+// where it does not apply, and the grid to run it on: two workgroups per CU (they share the matrix pipe at the rate
+// the tile kernel reaches with two resident tiles, kCfg[0].eff) or one (eff1; for few tiles: half as many partials).
+// Calibrated on profiles/r03/gemm_sweep_streamk.log: on top of the K-tiles themselves a launch pays ~8 us (pipeline
+// fills of up to three segments, the flag round trip) and ~5 us for every partial tile its busiest finisher folds in —
+// those reads come at the very end, when nothing is left to hide them behind (2048^3 on 512 workgroups: 3 partials per
+// tile, 118 us of K-tiles, 149 us measured; 1280 x 1280 x 8192: 10 partials, 184 -> 236 us and the tile form wins).
+// Ragged tiles (M % 256, N % 128, K % 16) run the guarded instantiations: ~4 % slower.
+double streamk_model(size_t M, size_t N, size_t K, unsigned *grid_out) {
+    const double cus = (double)np::num_cus(), cu_flops = 157.3e12 / 256.0;
+    const size_t tm = (M + 255) / 256, tn = (N + 127) / 128, nk = (K + 15) / 16;
+    *grid_out = 0;
+    if (tm * tn * nk >= (1ull << 40)) return 1e300;
+    const double iters = (double)(tm * tn) * (double)nk;
+    const double ragged = (M % 256 || N % 128 || K % 16) ? 1.04 : 1.0;
+    double best = 1e300;
+    for (int per_cu = 2; per_cu >= 1; --per_cu) {
+        unsigned G = (unsigned)(per_cu * cus);
+        if (G > kStreamKMaxGrid) G = kStreamKMaxGrid;
+        const double per_wg = ceil(iters / G);
+        if (per_wg < 24.0) continue;   // ranges too short to amortise the pipeline fill
+        const double eff = per_cu == 2 ? kCfg[0].eff / 2.0 : kCfg[0].eff1;
+        const double t_kt = 2.0 * 256.0 * 128.0 * 16.0 / (eff * cu_flops);   // one k-tile of one workgroup
+        const double folds = per_wg >= (double)nk ? 1.0 : ceil((double)nk / per_wg) - 1.0;
+        const double t = per_wg * t_kt * ragged + 8e-6 + 5e-6 * folds;
+        if (t < best) {
+            best = t;
+            *grid_out = G;
+        }
+    }
+    return best;
+}
+
+int launch_streamk(GemmArgs g, unsigned G) {
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 127) / 128;
+    g.swizzle = 0;   // tile-major ranges: a workgroup's consecutive tiles (and its neighbours') share an A panel
+    StreamKArgs sk;
+    sk.nk = (g.K + 15) / 16;
+    sk.iters_total = (unsigned long long)g.tiles_m * g.tiles_n * sk.nk;
+    sk.seq = 1;
+    if (sk.iters_total < G) G = (unsigned)sk.iters_total;
+    if (int rc = streamk_flags(&sk.flags)) return rc;
+    np::Scratch ws;
+    if (int rc = ws.alloc((size_t)G * 256 * 128 * sizeof(float))) return rc;
+    sk.workspace = (float *)ws.ptr;
+    const bool edge = g.M % 256 || g.N % 128 || g.n_store;
+    const bool ktail = g.K % 16;
+    hipStream_t s = np::stream();
+    if (edge && ktail)
+        sgemm_streamk_kernel<true, true><<<G, 256, 0, s>>>(g, sk);
+    else if (edge)
+        sgemm_streamk_kernel<true, false><<<G, 256, 0, s>>>(g, sk);
+    else if (ktail)
+        sgemm_streamk_kernel<false, true><<<G, 256, 0, s>>>(g, sk);
+    else if (g_prio_period) {
+        g.prio_period = g_prio_period;
+        sgemm_streamk_kernel<false, false, true><<<G, 256, 0, s>>>(g, sk);
+    } else
+        sgemm_streamk_kernel<false, false><<<G, 256, 0, s>>>(g, sk);
+    NP_LAUNCH_CHECK("sgemm_streamk_kernel");
+    return NP_OK;
 }
 
 int launch_planned(GemmArgs g, size_t batch, bool vec) {
@@ -1425,6 +1651,15 @@ int launch_planned(GemmArgs g, size_t batch, bool vec) {
     if (debug)
         fprintf(stderr, "[np_sgemm] %zux%zux%zu batch %zu -> cfg %d tail_rows %u S %u Kc %zu model %.1f us\n", M, N, K,
                 batch, p.cfg, p.tail_rows, p.S, p.Kc, p.t * 1e6);
+    // stream-K: equal shares of K-TILES instead of whole tiles, when the tile count does not fill the machine evenly
+    // (K % 16 and ragged M / N included; needs float4-loadable rows like every use of the LDS-DMA kernel).  Not under
+    // a progress request (np_comm's pipeline counts whole tiles) and not for batches (blockIdx.z is the batch there).
+    if (batch == 1 && dma_ok && g_streamk >= 0 && !g.progress && g.K_last == 0) {
+        unsigned G = 0;
+        const double t_sk = streamk_model(M, N, K, &G);
+        if (debug) fprintf(stderr, "[np_sgemm] %zux%zux%zu stream-K model %.1f us on %u workgroups\n", M, N, K, t_sk * 1e6, G);
+        if (t_sk < 1e299 && (g_streamk > 0 || t_sk < 0.99 * p.t)) return launch_streamk(g, G);
+    }
     return launch_plan(p, g, batch, vec);
 }
 
@@ -1668,9 +1903,10 @@ int np_sgemm_set_variant(int variant) {
         g_prio_period = (unsigned)(-variant - 100);
         return NP_OK;
     }
-    if (variant < 0) {   // -1: whole-K plans only, -2: default planner, -3: default + forced operand padding
+    if (variant < 0) {   // -1: whole-K plans only, -2: default planner, -3: default + forced operand padding, -4 / -5: stream-K always / never
         g_splitk = variant != -1;
         g_force_pad = variant == -3;
+        g_streamk = variant == -4 ? 1 : (variant == -5 || variant == -1) ? -1 : 0;   // -1: one whole tile per workgroup, nothing else
         return NP_OK;
     }
     // variants >= 1000 switch parts of the pipelined kernel OFF to time them (tools/gemm_ab.py): the
