@@ -81,6 +81,7 @@ struct Comm {
     Rccl api;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 0;
+    int device = -1;            // the communicator, its stream and its flags belong to the device current at np_comm_init
     std::string file_to_remove;
     float *scratch = nullptr;   // world floats on the device (np_comm_max / barrier)
     // the communication stream and its events (created at np_comm_init on the communicator's device)
@@ -446,6 +447,10 @@ int gather_on(hipStream_t s, const void *send, void *recv_base, size_t bytes, si
 int need_comm(const char *who) {
     if (!g_comm.comm) return np::fail(NP_ERR_INVALID, "%s: no communicator (np_comm_init first)", who);
     if (int rc = np::ensure_init()) return rc;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != g_comm.device)
+        return np::fail(NP_ERR_INVALID, "%s: the communicator belongs to device %d but the library is on device %d "
+                                        "(np_set_device back, or np_comm_destroy and np_comm_init again)", who, g_comm.device, cur);
     if (g_comm.host_error && *(volatile unsigned *)g_comm.host_error) {
         *(volatile unsigned *)g_comm.host_error = 0;
         return np::fail(NP_ERR_DEVICE, "%s: an earlier device-side wait between the library and the communication stream "
@@ -499,6 +504,7 @@ int np_comm_init(int rank, int world, const char *endpoint) {
     }
     g_comm.rank = rank;
     g_comm.world = world;
+    if (hipGetDevice(&g_comm.device) != hipSuccess) g_comm.device = 0;
     if (int rc = create_stream_objects()) return undo(rc);
     void *p = nullptr;
     if (int rc = np_malloc(&p, sizeof(float) * (size_t)(world + 1))) return undo(rc);   // np_last_error() keeps the allocation message
@@ -624,14 +630,23 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
             return rc;
         if (tiles) {
             cm.pending = true;
-            for (int c = 0; c < chunks; ++c) {
+            int failed = NP_OK;
+            for (int c = 0; c < chunks && failed == NP_OK; ++c) {
                 size_t lo = 0, count = 0;
-                if (int rc = np_comm_piece(slab, chunks, c, &lo, &count)) return rc;
+                if ((failed = np_comm_piece(slab, chunks, c, &lo, &count)) != NP_OK) break;
                 flag_wait_kernel<<<1, 1, 0, cm.stream>>>(counters + c, (unsigned)(count * tiles), kWaitTimeoutTicks, cm.host_error);
-                NP_LAUNCH_CHECK("flag_wait_kernel");
-                if (int rc = gather_on(cm.stream, mine + lo * mat, C_full + lo * mat, count * mat * sizeof(float),
-                                       slab_elems * sizeof(float), chunks == 1 ? mode == NP_GATHER_P2P : true))
-                    return rc;
+                if (hipGetLastError() != hipSuccess) {
+                    failed = np::fail(NP_ERR_DEVICE, "launch of flag_wait_kernel failed");
+                    break;
+                }
+                failed = gather_on(cm.stream, mine + lo * mat, C_full + lo * mat, count * mat * sizeof(float),
+                                   slab_elems * sizeof(float), chunks == 1 ? mode == NP_GATHER_P2P : true);
+            }
+            if (failed != NP_OK) {
+                // the GEMM is counting tiles: whatever went wrong above, the counters must be zero again before the next
+                // call (its waits would otherwise be released by THIS call's counts) — behind the GEMM, on its own stream
+                (void)hipMemsetAsync(counters, 0, sizeof(unsigned) * Comm::kMaxPieces, np::stream());
+                return failed;
             }
             // counters back to zero + "drained" published in one kernel; the library stream then waits for that number:
             // whatever the caller enqueues next (or np_sync) sees the gathered result
