@@ -1381,7 +1381,7 @@ struct StagedCtx {
 // N values (one float4 or one element) of the slab through the chain; e = slab-relative flat index of the first.
 // (Out of line — one copy of the interpreter, called once per float4 with all eight loads of a thread issued first —
 // it cost 2.3x: register save / restore around every call, 0.129 -> 0.29 ms on 10^7 x 10.)
-template <int N>
+template <int N, bool LIGHT>
 __device__ __forceinline__ void staged_run(const StagedCtx &cx, unsigned e, v4f x) {
     FusedArgsK f = cx.f;
     const float *in0 = f->in0;
@@ -1420,7 +1420,7 @@ __device__ __forceinline__ void staged_run(const StagedCtx &cx, unsigned e, v4f 
     for (int k = 0; k < n_ops; ++k) {
         const int kind = f->ops[k].kind, op = f->ops[k].op;
         if (kind == NP_FUSED_UNARY) {
-            unary_dispatch<N, false>(op, acc, f->ops[k].p0, f->ops[k].p1);
+            unary_dispatch<N, LIGHT>(op, acc, f->ops[k].p0, f->ops[k].p1);
             continue;
         }
         float oth[N];
@@ -1439,16 +1439,16 @@ __device__ __forceinline__ void staged_run(const StagedCtx &cx, unsigned e, v4f 
         const size_t body_end = f->ops[k].body_end;
 #pragma unroll
         for (int j = 0; j < N; ++j) body[j] = ge + j < body_end;
-        binary_dispatch<N, false>(op, acc, oth, f->ops[k].swap != 0, f->ops[k].quirk != 0, body);
+        binary_dispatch<N, LIGHT>(op, acc, oth, f->ops[k].swap != 0, f->ops[k].quirk != 0, body);
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) cx.slab[r[j] * cx.pitch + c[j]] = acc[j];
 }
 
-template <int SINK>
+template <int SINK, bool LIGHT>
 __global__ __launch_bounds__(256) void fused_chain_rows_staged_kernel(FusedArgs by_value, float *__restrict__ out,
                                                                       size_t rows_total, unsigned len, unsigned R,
-                                                                      unsigned magic, float mean_div) {
+                                                                      unsigned magic, float mean_div, unsigned T) {
     (void)by_value;
     extern __shared__ __attribute__((aligned(16))) float slab[];
     StagedCtx cx;
@@ -1472,11 +1472,24 @@ __global__ __launch_bounds__(256) void fused_chain_rows_staged_kernel(FusedArgs 
         const bool two = v + 256 < nvec;
         const v4f x0 = __builtin_nontemporal_load((const v4f *)(in0 + cx.base + (size_t)v * 4));
         const v4f x1 = two ? __builtin_nontemporal_load((const v4f *)(in0 + cx.base + (size_t)(v + 256) * 4)) : v4f{0, 0, 0, 0};
-        staged_run<4>(cx, v * 4, x0);
-        if (two) staged_run<4>(cx, (v + 256) * 4, x1);
+        staged_run<4, LIGHT>(cx, v * 4, x0);
+        if (two) staged_run<4, LIGHT>(cx, (v + 256) * 4, x1);
     }
-    for (unsigned e = nvec * 4 + threadIdx.x; e < total; e += 256) staged_run<1>(cx, e, v4f{in0[cx.base + e], 0, 0, 0});
+    for (unsigned e = nvec * 4 + threadIdx.x; e < total; e += 256) staged_run<1, LIGHT>(cx, e, v4f{in0[cx.base + e], 0, 0, 0});
     __syncthreads();
+    if (T > 1) {
+        // rows of 49 ... 1024 floats: only a few rows fit a slab, so a group of T lanes (a power of two <= 64) folds each
+        // row — lane t takes elements t, t + T, ... (consecutive lanes, consecutive LDS words), then an xor-shuffle tree
+        const unsigned g = threadIdx.x / T, t = threadIdx.x & (T - 1), per_pass = 256u / T;
+        for (unsigned r = g; r < rows; r += per_pass) {
+            const float *p = slab + r * pitch;
+            float a = np::dev::r_identity<SINK>();
+            for (unsigned c = t; c < len; c += T) a = np::dev::r_combine<SINK>(a, p[c]);
+            for (unsigned off = T >> 1; off > 0; off >>= 1) a = np::dev::r_combine<SINK>(a, __shfl_xor(a, (int)off, 64));
+            if (t == 0) out[row0 + r] = mean_div != 0.0f ? __fdiv_rn(a, mean_div) : a;
+        }
+        return;
+    }
     for (unsigned r = threadIdx.x; r < rows; r += 256) {
         const float *p = slab + r * pitch;
         float a0 = np::dev::r_identity<SINK>(), a1 = a0;
@@ -1497,10 +1510,26 @@ __global__ __launch_bounds__(256) void fused_chain_rows_staged_kernel(FusedArgs 
 static bool fused_rows_staged_shape(size_t rows, size_t cols) {
     return cols > 4 && cols <= 48 && rows * cols >= (size_t(8) << 20);
 }
+// Rows of 49 ... 512 floats of a large array that the lane-group kernel packs badly take the same staged kernel, a lane
+// group folding each row of the slab: rows whose length is not a multiple of 4 (the lane-group kernel walks their last
+// 1-3 elements in a pass of their own) and rows whose float4 slots do not fill the lane groups (100 floats = 25 slots on
+// 16 lanes).  Measured, same box (profiles/r03/fused_mid_rows_ab.log): 2e6 x 50 2.5 -> 4.3 TB/s, 400000 x 250 2.9 -> 3.8,
+// 800000 x 127 3.0 -> 3.9, 1e6 x 100 3.2 -> 3.6; well-packed rows stay where they are (64 / 256 / 1000 / 1024 floats:
+// 3.8-4.8 TB/s there against 3.3-3.8 staged).  np_elementwise_set_variant(4000) switches the window off (A/B).
+constexpr size_t kStagedMidMax = 512;
+static bool fused_rows_staged_mid_shape(size_t rows, size_t cols) {
+    if (g_variant == 4000 || cols <= 48 || cols > kStagedMidMax || rows < 4096 || rows * cols < (size_t(8) << 20)) return false;
+    if (cols % 4 != 0) return true;
+    const size_t slots = cols / 4;
+    size_t L = 64;                                   // the lane-group kernel's choice (fused_chain_impl, axis_mode 1)
+    while (L > 4 && L >= slots) L >>= 1;
+    const size_t trips = (slots + 2 * L - 1) / (2 * L);
+    return (double)slots / (double)(trips * 2 * L) < 0.9;
+}
 
 static bool fused_axis_shape_ok(size_t rows, size_t cols, int axis) {
     if (rows * cols >= (size_t(1) << 32)) return false;
-    if (axis == 1 && fused_rows_staged_shape(rows, cols)) return true;
+    if (axis == 1 && (fused_rows_staged_shape(rows, cols) || fused_rows_staged_mid_shape(rows, cols))) return true;
     if (axis == 1) return cols >= 16 && (rows >= 128 || rows * cols >= (size_t(1) << 20));   // a lane group / wave / workgroup (or several) per row
     return rows >= 32 && cols / (cols % 4 == 0 ? 4 : 1) >= 32;   // first axis: a lane per column slot, waves interleaved over rows
 }
@@ -1631,7 +1660,8 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
 #endif
     hipStream_t s = np::stream();
     if (force_full) light = false;
-    if (axis_mode == 1 && fused_rows_staged_shape(rows, cols)) {
+    const bool staged_mid = axis_mode == 1 && fused_rows_staged_mid_shape(rows, cols) && f.in0 && ((uintptr_t)f.in0 & 15u) == 0;
+    if (axis_mode == 1 && (fused_rows_staged_shape(rows, cols) || staged_mid)) {
         // (needs input 0 as a 16-byte aligned full array; anything else — a chain that starts from a scalar, a view at an
         // odd offset — is materialised and handed to np_reduce_axis like the shapes fused_axis_shape_ok turns away)
         if (!f.in0 || ((uintptr_t)f.in0 & 15u) != 0) {
@@ -1642,12 +1672,29 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
             return np_reduce_axis(rop, (const float *)tmp.ptr, rows, cols, 1, out, 0);
         }
         const unsigned pitch = (unsigned)cols | 1u;
-        unsigned R = (8192u / pitch) / 256u * 256u;
+        unsigned R = (8192u / pitch) / 256u * 256u, T = 1;
         if (R < 256) R = 256;
+        if (staged_mid) {
+            // ~32 KB of LDS per workgroup (4-5 resident per CU keep the streaming phase's loads in flight); R % 4 == 0 keeps
+            // every slab's first element 16-byte aligned; T lanes per row, the largest power of two that R rows leave
+            R = (8192u / pitch) / 4u * 4u;
+            if (R < 4) R = 4;
+            T = 64;
+            while (T > 1 && T * R > 256u) T >>= 1;
+        }
         const size_t blocks = (rows + R - 1) / R;
+        if (blocks > 0x7fffffffu) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce_axis: too many rows");
         const size_t lds = (size_t)R * pitch * sizeof(float);
         const unsigned magic = (unsigned)((0x100000000ull + cols - 1) / cols);
-#define NP_FRS(SINK_) fused_chain_rows_staged_kernel<SINK_><<<(unsigned)blocks, 256, lds, s>>>(f, out, rows, (unsigned)cols, R, magic, mean_div)
+        // (the LIGHT interpreter — only ops whose bodies are a handful of instructions — where the chain allows: fewer
+        // registers, more waves, more loads in flight; variant 4001 keeps the full one for the A/B)
+#define NP_FRS(SINK_)                                                                                                                        \
+    do {                                                                                                                                     \
+        if (light && g_variant != 4001)                                                                                                      \
+            fused_chain_rows_staged_kernel<SINK_, true><<<(unsigned)blocks, 256, lds, s>>>(f, out, rows, (unsigned)cols, R, magic, mean_div, T);  \
+        else                                                                                                                                 \
+            fused_chain_rows_staged_kernel<SINK_, false><<<(unsigned)blocks, 256, lds, s>>>(f, out, rows, (unsigned)cols, R, magic, mean_div, T); \
+    } while (0)
         if (sink == NP_SUM) NP_FRS(NP_SUM);
         else if (sink == NP_PROD) NP_FRS(NP_PROD);
         else if (sink == NP_MIN) NP_FRS(NP_MIN);

@@ -12,18 +12,25 @@ from numpower_amd.ndarray import NDArray
 
 lib = _lib.load()
 _lib.check(lib.np_init(0))
-for rows, cols in ((25000, 4000), (25000, 4001), (33333, 3001), (400_000, 250), (400_000, 256), (1_000_000, 100), (1_600_000, 64), (100_000, 1000), (50_000, 2000), (5000, 20_001), (300, 333_335)):
-    x = synth.uniform((rows, cols), 3, -1.0, 1.0)
-    gx = NDArray.array(x).gpu()
-    build = lambda: gx.lazy().exp().sum(axis=1)
-    for _ in range(3):
-        y = build()
-    _lib.check(lib.np_sync())
-    t = _lib.Timer(); t.start()
-    for _ in range(10):
-        y = build()
-    t.stop(); _lib.check(lib.np_sync())
-    ms = t.elapsed_ms() / 10
-    want = np.exp(x.astype(np.float64)).sum(1)
-    ok = bool((np.abs(y.cpu().numpy() - want) <= 1e-5 * want).all())
-    print("%7d x %-7d  sum(exp(X),1) %.4f ms %5.0f GB/s %s" % (rows, cols, ms, 4.0 * rows * cols / ms / 1e6, "ok" if ok else "WRONG"), flush=True)
+import os
+variants = [int(v) for v in os.environ.get("NP_PROBE_VARIANTS", "0").split(",")]
+shapes = ((25000, 4000), (25000, 4001), (33333, 3001), (400_000, 250), (400_000, 256), (1_000_000, 100), (1_600_000, 64), (2_000_000, 50), (800_000, 127),
+          (200_000, 500), (100_000, 1000), (100_000, 1001), (98_000, 1024), (50_000, 2000), (5000, 20_001), (300, 333_335))
+for variant in variants:
+  _lib.check(lib.np_elementwise_set_variant(variant))
+  print("== np_elementwise_set_variant(%d)" % variant)
+  for rows, cols in shapes:
+      x = synth.uniform((rows, cols), 3, -1.0, 1.0)
+      gx = NDArray.array(x).gpu()
+      build = lambda: gx.lazy().exp().sum(axis=1)
+      for _ in range(3):
+          y = build()
+      _lib.check(lib.np_sync())
+      t = _lib.Timer(); t.start()
+      for _ in range(10):
+          y = build()
+      t.stop(); _lib.check(lib.np_sync())
+      ms = t.elapsed_ms() / 10
+      want = np.exp(x.astype(np.float64)).sum(1)
+      ok = bool((np.abs(y.cpu().numpy() - want) <= 1e-5 * want).all())
+      print("%7d x %-7d  sum(exp(X),1) %.4f ms %5.0f GB/s %s" % (rows, cols, ms, 4.0 * rows * cols / ms / 1e6, "ok" if ok else "WRONG"), flush=True)
