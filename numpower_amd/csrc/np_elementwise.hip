@@ -1227,7 +1227,7 @@ __device__ __forceinline__ float sink_combine(int sink, float a, float b) {   //
 // Chain ending in a reduction over the LAST axis: out[r] = reduce_c chain(r, c).  One wave per row
 // (BLOCK = false; rows of up to a few thousand elements, no barrier anywhere) or one workgroup per
 // row (BLOCK = true).  scale = 1 / cols for a mean (applied as a division, like NDArray::mean).
-template <int G, bool LIGHT, bool BLOCK, typename I>
+template <int G, bool LIGHT, bool BLOCK, typename I, int UU = 2>
 __global__ __launch_bounds__(256) void fused_chain_rows_kernel(FusedArgs by_value, float *__restrict__ out, I rows, I cols,
                                                                unsigned L, I chunk_slots, float mean_div) {
     (void)by_value;
@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(256) void fused_chain_rows_kernel(FusedArgs by_valu
     const I out_stride = BLOCK ? (I)gridDim.y : 1, out_off = BLOCK ? (I)blockIdx.y : 0;
     for (I r = first_row; r < rows; r += row_stride) {
         float racc = sink_identity(sink);
-        fused_span<2, G, LIGHT, I>(f, out, r * cols + slot0 * G, nslots, lane, width, racc);
+        fused_span<UU, G, LIGHT, I>(f, out, r * cols + slot0 * G, nslots, lane, width, racc);
         if constexpr (G == 4) {   // a row of cols % 4 != 0 floats: its last 1-3 elements, one per lane, behind the float4 slots
             const I tail = cols - (cols / 4) * 4;
             if (tail != 0 && (!BLOCK || blockIdx.y == gridDim.y - 1))
@@ -1709,8 +1709,15 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         // float4 slots also for rows of cols % 4 != 0 floats (dword-aligned accesses; the kernel takes the 1-3 leftover
         // elements of each row one per lane): such rows used to run one ELEMENT per slot
         const size_t slots = cols / 4;
-        unsigned L = 64;                                   // ~2 slots per lane per trip
-        while (L > 4 && (size_t)L >= slots) L >>= 1;
+        // The lane-group (wave) mode is bound by instruction issue, not by HBM (profiles/r03/rows_pmc.txt: SALU + VALU
+        // activity scales with the time; rows of 64 floats issue 50 % more instructions per element than rows of 4000).
+        // For LIGHT chains over rows of 128 ... 512 floats the interpreter's per-trip dispatch is amortised over 4 float4
+        // slots per lane instead of 2, the lane group sized to ~4 slots per lane: 128 / 256 / 500 / 512 floats +7-12 %
+        // (192, 384: neutral); shorter and longer rows lose 3-18 % to the extra registers and keep 2
+        // (profiles/r03/fused_rows_u4_ab.log; variant 5000 = 2 everywhere).
+        const bool four = light && !block && cols >= 128 && cols <= 512 && g_variant != 5000;
+        unsigned L = 64;                                   // ~2 (or ~4) slots per lane per trip
+        while (L > 4 && (size_t)L * (four ? 2 : 1) >= slots) L >>= 1;
         size_t grid = block ? rows : (rows + 4 * (64 / L) - 1) / (4 * (64 / L));
         const size_t cap = (size_t)np::num_cus() * 16;
         if (grid > cap) grid = cap;
@@ -1733,7 +1740,8 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         const float div = chunks > 1 ? 0.0f : mean_div;
         const dim3 grid2((unsigned)grid, (unsigned)chunks);
 #define NP_FR(G_, LIGHT_, BLOCK_) fused_chain_rows_kernel<G_, LIGHT_, BLOCK_, uint32_t><<<grid2, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, L, (uint32_t)chunk_slots, div)
-        if (light) { if (block) NP_FR(4, true, true); else NP_FR(4, true, false); }
+        if (four) fused_chain_rows_kernel<4, true, false, uint32_t, 4><<<grid2, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, L, (uint32_t)chunk_slots, div);
+        else if (light) { if (block) NP_FR(4, true, true); else NP_FR(4, true, false); }
         else { if (block) NP_FR(4, false, true); else NP_FR(4, false, false); }
 #undef NP_FR
         NP_LAUNCH_CHECK("fused_chain_rows_kernel");

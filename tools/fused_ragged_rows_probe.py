@@ -15,7 +15,7 @@ _lib.check(lib.np_init(0))
 import os
 variants = [int(v) for v in os.environ.get("NP_PROBE_VARIANTS", "0").split(",")]
 shapes = ((25000, 4000), (25000, 4001), (33333, 3001), (400_000, 250), (400_000, 256), (1_000_000, 100), (1_600_000, 64), (2_000_000, 50), (800_000, 127),
-          (200_000, 500), (100_000, 1000), (100_000, 1001), (98_000, 1024), (50_000, 2000), (5000, 20_001), (300, 333_335))
+          (800_000, 128), (500_000, 192), (260_000, 384), (200_000, 500), (200_000, 512), (160_000, 640), (130_000, 768), (100_000, 1000), (100_000, 1001), (98_000, 1024), (50_000, 2000), (5000, 20_001), (300, 333_335))
 for variant in variants:
   _lib.check(lib.np_elementwise_set_variant(variant))
   print("== np_elementwise_set_variant(%d)" % variant)
