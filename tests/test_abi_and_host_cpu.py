@@ -202,3 +202,30 @@ def test_tuning_knobs_validate_their_argument_without_a_device():
     for ok in (0, 1, 2):
         assert lib.np_runtime_set_variant(ok) == 0
     assert lib.np_select_last_path(None) != 0      # null output: refused before any device call
+
+
+def test_comm_entry_points_without_a_communicator_or_device():
+    """The overlapped-gather entry points refuse politely before any device work when no communicator exists, the piece
+    arithmetic is pure, and the communicator's tuning knob validates its argument — on a box without a GPU too."""
+    import ctypes as C
+    from numpower_amd import _lib
+    lib = _lib.load()
+    lib.np_last_error.restype = C.c_char_p
+    assert lib.np_comm_world() == 0 and lib.np_comm_rank() == -1 and lib.np_comm_sync_mode() == -1
+    assert not lib.np_comm_stream()
+    for call in (lambda: lib.np_allgather_async(1, 2, 4, 4, 0), lambda: lib.np_comm_wait(),
+                 lambda: lib.np_sgemm_strided_batched_allgather(4, 8, 8, 8, 1, 64, 2, 64, 3, 2, 0),
+                 lambda: lib.np_comm_debug_sendrecv_self(1, 2, 4), lambda: lib.np_comm_debug_loopback(None, 0)):
+        assert call() != 0 and b"no communicator" in lib.np_last_error()
+    lo, count = C.c_size_t(0), C.c_size_t(0)
+    got = []
+    for c in range(3):
+        assert lib.np_comm_piece(64, 3, c, C.byref(lo), C.byref(count)) == 0
+        got.append((lo.value, count.value))
+    assert got == [(0, 22), (22, 21), (43, 21)]
+    assert lib.np_comm_piece(64, 0, 0, C.byref(lo), C.byref(count)) != 0 and b"np_comm_piece" in lib.np_last_error()
+    assert lib.np_comm_piece(64, 3, 3, C.byref(lo), C.byref(count)) != 0
+    assert lib.np_comm_piece(64, 3, 0, None, C.byref(count)) != 0
+    assert lib.np_comm_set_variant(3) != 0 and b"np_comm_set_variant" in lib.np_last_error()
+    for ok in (1, 2, 0):
+        assert lib.np_comm_set_variant(ok) == 0
