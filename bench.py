@@ -333,13 +333,27 @@ def bench_matmul(dist: Dist, steps, warmup, do_cpu):
 
 
 def hbm_case(name, bytes_per_launch, launch, steps, warmup, dist):
+    """`ms_per_launch` / `frac` = the timed region (K launches back to back behind W warm-ups).  The same K launches
+    again, each bracketed by its own event pair (after, not inside, the timed region), give the spread behind that
+    average (`launch_ms`: min / median / max; an individually bracketed launch includes its launch gap, so its median
+    sits a few per cent ABOVE the back-to-back average for these 70-400 us kernels — unlike the GEMM, the HBM-bound
+    kernels show no ramp: profiles/r03/bench_r03.json)."""
     wall, ev_ms = timed(dist, launch, steps, warmup)
     per_launch_ms = ev_ms / steps
     gbps = bytes_per_launch / per_launch_ms / 1e6
-    return {"name": name, "ms_per_launch": per_launch_ms, "GBps": gbps,
-            "algorithmic_bytes": bytes_per_launch,
-            "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": gbps / PEAK_HBM_GBPS, "traffic": None}}
+    out = {"name": name, "ms_per_launch": per_launch_ms, "GBps": gbps,
+           "algorithmic_bytes": bytes_per_launch,
+           "roofline": {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": gbps / PEAK_HBM_GBPS, "traffic": None}}
+    timers = [Timer() for _ in range(steps)]
+    for t in timers:
+        t.start()
+        launch()
+        t.stop()
+    per = sorted(t.elapsed_ms() for t in timers)
+    out["launch_ms"] = {"min": per[0], "median": per[len(per) // 2], "max": per[-1]}
+    out["roofline"]["frac_median_launch"] = bytes_per_launch / per[len(per) // 2] / 1e6 / PEAK_HBM_GBPS
+    return out
 
 
 def bench_extras(dist: Dist, steps, warmup):

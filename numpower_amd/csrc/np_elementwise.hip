@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(256) void fused_chain_rows_kernel(FusedArgs by_valu
 // A workgroup owns 64 slots of G columns; its four waves take every fourth row of the block's row chunk
 // (blockIdx.y), each lane accumulating its own G columns (VACC), and are combined through LDS.  With
 // more than one row chunk the partials [chunk][cols] are folded by np_reduce_axis.
-template <int G, bool LIGHT, bool WIDE, typename I>
+template <int G, bool LIGHT, bool WIDE, typename I, int CU = 2>
 __global__ __launch_bounds__(256) void fused_chain_cols_kernel(FusedArgs by_value, float *__restrict__ out, I rows, I cols,
                                                                I rows_per_chunk, float mean_div) {
     (void)by_value;
@@ -1288,19 +1288,20 @@ __global__ __launch_bounds__(256) void fused_chain_cols_kernel(FusedArgs by_valu
     const I slots_per_row = cols / G;             // cols % G == 0
     const I r0 = (I)blockIdx.y * rows_per_chunk;
     const I r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
-    float rv[2 * G], racc = 0.0f;
+    float rv[CU * G], racc = 0.0f;   // CU rows in flight per lane, one accumulator set per row slot
 #pragma unroll
-    for (int e = 0; e < 2 * G; ++e) rv[e] = sink_identity(sink);
+    for (int e = 0; e < CU * G; ++e) rv[e] = sink_identity(sink);
     if constexpr (WIDE) {
         // the whole workgroup walks down the chunk row by row: 256 slots = 4 KiB of one row per step (one
         // DRAM-friendly contiguous segment instead of four 1 KiB segments of four different rows), every
         // thread owns its G columns for the whole chunk, so nothing has to be combined across waves
         const I slot = (I)blockIdx.x * 256 + threadIdx.x;
         if (slot < slots_per_row) {
-            fused_span_impl<2, G, LIGHT, I, true>(f, out, r0 * cols, (r1 - r0) * slots_per_row, slot, slots_per_row, racc, rv);
+            fused_span_impl<CU, G, LIGHT, I, true>(f, out, r0 * cols, (r1 - r0) * slots_per_row, slot, slots_per_row, racc, rv);
 #pragma unroll
             for (int e = 0; e < G; ++e) {
-                const float v = sink_combine(sink, rv[e], rv[G + e]);
+                float v = rv[e];
+                for (int u = 1; u < CU; ++u) v = sink_combine(sink, v, rv[u * G + e]);
                 out[(size_t)blockIdx.y * cols + (size_t)slot * G + e] = mean_div != 0.0f ? v / mean_div : v;
             }
         }
@@ -1310,13 +1311,17 @@ __global__ __launch_bounds__(256) void fused_chain_cols_kernel(FusedArgs by_valu
     // slot index v of the span <-> (row r0 + v / slots_per_row, slot v % slots_per_row): this thread's
     // slots are v = (wave + 4 i) * slots_per_row + slot
     if (slot < slots_per_row)
-        fused_span_impl<2, G, LIGHT, I, true>(f, out, r0 * cols, (r1 - r0) * slots_per_row, wave * slots_per_row + slot,
+        fused_span_impl<CU, G, LIGHT, I, true>(f, out, r0 * cols, (r1 - r0) * slots_per_row, wave * slots_per_row + slot,
                                               4 * slots_per_row, racc, rv);
     // cross-wave combine through LDS, lane fastest: a wave's 64 stores / loads of one element land on 64 different banks
     // (lane-major [lane][e] put lanes l and l + 16 on one bank: 74 % of this kernel's LDS cycles were conflicts)
     __shared__ float part[4][G][64];
 #pragma unroll
-    for (int e = 0; e < G; ++e) part[wave][e][lane] = sink_combine(sink, rv[e], rv[G + e]);
+    for (int e = 0; e < G; ++e) {
+        float v = rv[e];
+        for (int u = 1; u < CU; ++u) v = sink_combine(sink, v, rv[u * G + e]);
+        part[wave][e][lane] = v;
+    }
     __syncthreads();
     float v[G];
 #pragma unroll
@@ -1774,7 +1779,14 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         const float div = chunks > 1 ? 0.0f : mean_div;
         const dim3 grid((unsigned)col_blocks, (unsigned)chunks);
 #define NP_FCOL(G_, LIGHT_, WIDE_) fused_chain_cols_kernel<G_, LIGHT_, WIDE_, uint32_t><<<grid, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, (uint32_t)rows_per_chunk, div)
-        if (wide) {
+        // variants 6004 / 6001 / 6003: the LIGHT float4 kernel with 4 / 1 / 3 rows in flight per lane (A/B, tools/fused_cols_ab.py)
+        if (g == 4 && light && !wide && g_variant == 6004)
+            fused_chain_cols_kernel<4, true, false, uint32_t, 4><<<grid, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, (uint32_t)rows_per_chunk, div);
+        else if (g == 4 && light && !wide && g_variant == 6003)
+            fused_chain_cols_kernel<4, true, false, uint32_t, 3><<<grid, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, (uint32_t)rows_per_chunk, div);
+        else if (g == 4 && light && !wide && g_variant == 6001)
+            fused_chain_cols_kernel<4, true, false, uint32_t, 1><<<grid, 256, 0, s>>>(f, dst, (uint32_t)rows, (uint32_t)cols, (uint32_t)rows_per_chunk, div);
+        else if (wide) {
             if (g == 4) { if (light) NP_FCOL(4, true, true); else NP_FCOL(4, false, true); }
             else { if (light) NP_FCOL(1, true, true); else NP_FCOL(1, false, true); }
         } else {

@@ -35,7 +35,7 @@ def run(axis, out, iters=30):
     return t.elapsed_ms() / iters * 1e3
 
 
-variants = [0, 3000, 1002, 1003, 1004, 1006, 1008, 1016, 2004, 2008]   # 3000 = the two-kernel form (chunk fold by np_reduce_axis)
+variants = [0, 1004, 1007, 1008, 1009, 1010, 1012, 0, 1008]   # 100k = k workgroups per CU; 600k = k rows in flight per lane (default 2: 6001 / 6003 / 6004 measured 97 / 93 / 86 us)
 for rnd in range(3):
     print("-- round", rnd, flush=True)
     print("   axis 1 (rows kernel)            %6.1f us" % run(1, out1))
