@@ -812,8 +812,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, Strea
             while (sk.iters_total * (w_last + 1) / G < tile_end) ++w_last;        // ... exact under the floor()s above
             while (sk.iters_total * w_last / G >= tile_end) --w_last;
             if (threadIdx.x == 0) {
+                // (bounded: the schedule guarantees the flags — 2^26 polls, s_sleep between them, are tens of seconds: a wait
+                // that long can only be a fault elsewhere, and a wrong tile is a lesser evil than a queue that never drains)
                 for (unsigned long long p = w + 1; p <= w_last; ++p)
-                    while (np::dev::coherent_load(sk.flags + p) != sk.seq) __builtin_amdgcn_s_sleep(8);
+                    for (unsigned spins = 0; np::dev::coherent_load(sk.flags + p) != sk.seq && spins < (1u << 26); ++spins)
+                        __builtin_amdgcn_s_sleep(8);
             }
             __syncthreads();
         }
