@@ -93,6 +93,28 @@ def test_the_glue_and_the_configure_option_travel_with_the_tree(patched):
     assert "NDArrayMathGPU_ElementWise(nda, cuda_float_rsqrt)" in numpower and "NDArrayMathGPU_ElementWise(nda, cuda_float_exp2)" in numpower
 
 
+def test_the_new_statements_compile_against_the_c_abi(tmp_path):
+    """The HAVE_NP_HIP side of every statement-level edit, each with the locals it uses declared as in the reference,
+    compiled on its own with -Wall -Wextra -Werror against include/np_hip.h, include/numpower_host.h and ext/hip_math.h:
+    the replacement text is well-typed C against the ABI it calls (needs no reference checkout)."""
+    import apply_with_hip as tool
+    src = tmp_path / "snippets.c"
+    src.write_text(tool.snippet_check_source())
+    n = sum(1 for e in tool.EDITS if e.context)
+    assert n >= 14
+    proc = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
+                           "-I", str(ROOT / "include"), "-I", str(ROOT / "ext"), str(src)], capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    # and the check is not vacuous: a wrong argument order in one snippet is refused
+    bad = src.read_text().replace("np_memset0(rtn->data, rtn->descriptor->numElements * sizeof(float));",
+                                  "np_memset0(rtn->descriptor->numElements * sizeof(float), rtn->data);")
+    assert bad != src.read_text()
+    (tmp_path / "bad.c").write_text(bad)
+    proc = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
+                           "-I", str(ROOT / "include"), "-I", str(ROOT / "ext"), str(tmp_path / "bad.c")], capture_output=True, text=True)
+    assert proc.returncode != 0
+
+
 def test_a_moved_anchor_is_a_hard_error(tmp_path):
     import apply_with_hip as tool
     broken = tmp_path / "broken"

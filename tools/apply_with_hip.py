@@ -49,6 +49,9 @@ class Edit:
     new: str           # the HAVE_NP_HIP side (same indentation as the old text is applied automatically)
     expect: int = 1    # how many times the anchor must match
     wrap: bool = True  # True: #ifdef HAVE_NP_HIP new #else old #endif;  False: plain substitution by `new`
+    context: str = ""  # C declarations of the locals of the surrounding reference function that `new` uses (CONTEXTS
+                       # below): with them the new text is compiled on its own — snippet_check_source() — against
+                       # include/np_hip.h, include/numpower_host.h and ext/hip_math.h; "" = nothing to compile
 
 
 def _cuda_includes(file: str, line: str) -> Edit:
@@ -100,14 +103,15 @@ EDITS = [
     Edit("src/initializers.c", "initializers.c:443 NDArray_Zeros (float)",
          r"^(?P<old>[ \t]*cudaMemset\(rtn->data, 0, rtn->descriptor->numElements \* sizeof\(float\)\);)$",
          "np_memset0(rtn->data, rtn->descriptor->numElements * sizeof(float));"),
-    # ---- device -> device copies: vmemcpyd2d(src, dst, bytes) is already declared in gpu_alloc.h:10 ----
+    # ---- device -> device copies: np_memcpy_d2d(dst, src, bytes) with size_t bytes (vmemcpyd2d of gpu_alloc.h:10 takes
+    #      the reference's `unsigned int`: 4 GiB) ----
     Edit("src/initializers.c", "initializers.c:758 NDArray_Copy: D2D copy",
          r"^(?P<old>[ \t]*cudaMemcpy\(NDArray_FDATA\(rtn\), NDArray_FDATA\(a\), NDArray_NUMELEMENTS\(a\) \* sizeof\(float\), cudaMemcpyDeviceToDevice\);)$",
-         "vmemcpyd2d((char *) NDArray_FDATA(a), (char *) NDArray_FDATA(rtn), NDArray_NUMELEMENTS(a) * sizeof(float));"),
+         "np_memcpy_d2d(NDArray_FDATA(rtn), NDArray_FDATA(a), NDArray_NUMELEMENTS(a) * sizeof(float));"),
     Edit("src/ndmath/linalg.c", "linalg.c:145-146 NDArray_SVD: D2D copy + sync",
          r"^(?P<old>[ \t]*cudaMemcpy\(output_data, NDArray_FDATA\(target_ptr\), sizeof\(float\) \* NDArray_NUMELEMENTS\(target\), cudaMemcpyDeviceToDevice\);\n"
          r"[ \t]*cudaDeviceSynchronize\(\);)$",
-         "vmemcpyd2d((char *) NDArray_FDATA(target_ptr), (char *) output_data, sizeof(float) * NDArray_NUMELEMENTS(target));"),
+         "np_memcpy_d2d(output_data, NDArray_FDATA(target_ptr), sizeof(float) * NDArray_NUMELEMENTS(target));"),
     # ---- the per-op cudaDeviceSynchronize() after the result allocation: arithmetics.c:218,497,633,758,883 ----
     Edit("src/ndmath/arithmetics.c", "arithmetics.c:218,497,633,758,883: sync after vmalloc (add, subtract, divide, mod, pow)",
          _SYNC, "/* nothing: the back end's stream orders the allocation with the kernels; read-backs block */", expect=5),
@@ -193,6 +197,24 @@ EDITS = [
          "      $NP_GPU_ALLOC_SOURCES \\", wrap=False),
 ]
 
+# What each compiled snippet needs from the reference function around it (names and types as in the reference).
+CONTEXTS = {
+    "ndarray.c:1055-1060 NDArray_ToGPU: H2D copy": "float *tmp_gpu = 0; NDArray *target = 0;",
+    "ndarray.c:1090 NDArray_ToCPU: D2H copy": "NDArray *rtn = 0, *target = 0;",
+    "ndarray.c:1021 NDArray_ToIntVector: one float back": "double *tmp_val = 0; NDArray *nda = 0; int i = 0;",
+    "debug.c:201 print_matrix_float: D2H copy": "float *tmp_buffer = 0, *buffer = 0; int num_elements = 0;",
+    "linalg.c:680 singular values back to the host": "float *singular_values = 0; NDArray *svd[3] = {0, 0, 0};",
+    "initializers.c:439 NDArray_Zeros (double)": "NDArray *rtn = 0;",
+    "initializers.c:443 NDArray_Zeros (float)": "NDArray *rtn = 0;",
+    "initializers.c:758 NDArray_Copy: D2D copy": "NDArray *rtn = 0, *a = 0;",
+    "linalg.c:145-146 NDArray_SVD: D2D copy + sync": "float *output_data = 0; NDArray *target_ptr = 0, *target = 0;",
+    "linalg.c:55-71 NDArray_FMatmul: cuBLAS -> np_sgemm": "NDArray *a = 0, *b = 0, *result = 0;",
+    "numpower.c:623-633 NDArray::setDevice": "int numDevices = 0; long deviceId = 0;",
+    "debug.c:220-254 NDArray_DumpDevices": " ",
+    "numpower.c:1791 PHP_METHOD(rsqrt): the right device function": "NDArray *rtn = 0, *nda = 0;",
+    "numpower.c:3153 PHP_METHOD(exp2): a device branch": "NDArray *rtn = 0, *nda = 0;",
+}
+
 HIP_M4_BLOCK = '''dnl ---- MI355X (gfx950) through numpower_amd: added by numpower_amd/tools/apply_with_hip.py ----
 dnl No device compiler step: the kernels live in a prebuilt libnp_hip.so, everything compiled here is plain C
 dnl (src/hip/*.c), so the stock phpize / libtool flow builds it (no Makefile.frag, no nvcc).
@@ -229,6 +251,38 @@ GLUE_FILES = ["ext/gpu_alloc_hip.c", "ext/hip_math.c", "ext/hip_math.h", "ext/hi
               "ext/np_ext_hooks.h", "include/np_hip.h"]
 # not compiled in a --with-hip build: replaced wholesale by the glue
 REPLACED_BY_GLUE = ("src/gpu_alloc.c", "src/ndmath/cuda/")
+
+
+for _e in EDITS:
+    _e.context = CONTEXTS.get(_e.what, "")
+assert all(k in {e.what for e in EDITS} for k in CONTEXTS), "CONTEXTS names an edit that does not exist"
+
+
+def snippet_check_source() -> str:
+    """One C translation unit holding the HAVE_NP_HIP side of every statement-level edit, each in a function of its own
+    with the locals it uses declared as in the reference.  `gcc -fsyntax-only -Wall -Werror` on it (tests/
+    test_apply_with_hip_cpu.py) proves that the new statements are well-typed against the C ABI and the glue headers —
+    a wrong argument order, a missing status check's type, a misspelt entry point fail THERE, not in a maintainer's
+    PHP build.  The only foreign declarations are the three reference symbols the new text itself calls."""
+    out = ["/* generated by tools/apply_with_hip.py: snippet_check_source() */",
+           "#include <stdio.h>", "#include <stddef.h>",
+           '#include "np_hip.h"', '#include "numpower_host.h"', '#include "hip_math.h"',
+           "void zend_throw_error(void *exception_ce, const char *format, ...);   /* Zend/zend_exceptions.h */",
+           "NDArray *NDArray_Map(NDArray *array, float (*op)(float));                /* src/ndarray.h */",
+           "float float_exp2(float val);                                             /* src/ndmath/double_math.h */", ""]
+    for k, e in enumerate(EDITS):
+        if not e.context:
+            continue
+        ret = "void *" if "return NULL;" in e.new else "void "
+        out.append("/* %s */" % e.what)
+        out.append("%ssnippet_%d(void) {" % (ret, k))
+        out.append("    " + e.context)
+        out.append(_indent(e.new, "    "))
+        if ret == "void *":
+            out.append("    return (void *) 0;")
+        out.append("}")
+        out.append("")
+    return "\n".join(out)
 
 
 def _indent(text: str, pad: str) -> str:
