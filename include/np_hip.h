@@ -431,6 +431,12 @@ int np_comm_sync_mode(void);
 
 /* testing: the rendezvous of np_comm_init alone (no device, no RCCL) — rank 0's 128 bytes reach every peer */
 int np_comm_debug_exchange(int rank, int world, const char *endpoint, void *bytes128, double timeout_s);
+/* testing: the exchange np_sgemm_strided_batched_allgather makes rank `rank` of `world` issue for a slab of `slab` items
+ * of item_bytes in `chunks` pieces (point to point), computed by the same functions as the real path, without a device or
+ * a communicator: records {piece, send to, send offset, bytes, receive from, receive offset} (byte offsets into the
+ * replicated result); *host_count = number of records (also when max_records is smaller). */
+int np_comm_debug_plan(int rank, int world, size_t slab, size_t item_bytes, int chunks, unsigned long long *host_out,
+                       size_t max_records, size_t *host_count);
 /* testing: dst <- src through one grouped ncclSend / ncclRecv pair from this rank to itself on the communication
  * stream, then np_comm_wait() — the P2P transport on a box with a single GPU */
 int np_comm_debug_sendrecv_self(const void *dev_src, void *dev_dst, size_t bytes);

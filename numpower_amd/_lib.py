@@ -95,6 +95,8 @@ PROTOTYPES = {
                                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]),
     "np_comm_debug_sendrecv_self": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "np_comm_debug_loopback": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "np_comm_debug_plan": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_ulonglong), C.c_size_t,
+                                     C.POINTER(C.c_size_t)]),
     "np_reduce_all": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.POINTER(C.c_float)]),
     "np_reduce_all_dev": (C.c_int, [C.c_int, _f32p, C.c_size_t, _f32p]),
     "np_all": (C.c_int, [_f32p, C.c_size_t, C.c_uint, C.POINTER(C.c_int)]),

@@ -406,6 +406,26 @@ int comm_stream_follows_compute() {
     return stream_follows(c.stream, np::stream(), c.flags + 0, c.produced_seq, c.produced[c.next_event++ % Comm::kEvents]);
 }
 
+// ---- the addressing of the exchange, as pure functions (shared by the real path and by np_comm_debug_plan, which lets a
+// test run the arithmetic for any rank / world without a device) ----
+
+// step s of the grouped exchange: rank r sends to r + s while it receives from r - s — every step is a perfect matching
+// of the fully connected mesh, every pair of GPUs meets exactly once per direction
+inline void p2p_peers(int rank, int world, int step, int *to, int *from) {
+    *to = (rank + step) % world;
+    *from = (rank - step + world) % world;
+}
+
+// piece [lo, lo + count) of this rank's slab inside the replicated result of world * slab items of item_bytes each:
+// where it is sent FROM, the base every rank's copy of that piece is received relative to, and how far apart the ranks'
+// copies lie (one slab)
+inline void piece_addresses(int rank, size_t slab, size_t item_bytes, size_t lo, size_t *send_off, size_t *recv_base_off,
+                            size_t *recv_stride) {
+    *send_off = ((size_t)rank * slab + lo) * item_bytes;
+    *recv_base_off = lo * item_bytes;
+    *recv_stride = slab * item_bytes;
+}
+
 // recv_base + r * recv_stride <- rank r's `bytes` at send, for every r, on stream s.  Contiguous destinations
 // (recv_stride == bytes) are ONE ncclAllGather unless p2p is asked for; anything else is one grouped exchange of
 // ncclSend / ncclRecv pairs — every peer's piece travels over that peer's own xGMI link straight into place, no
@@ -431,8 +451,8 @@ int gather_on(hipStream_t s, const void *send, void *recv_base, size_t bytes, si
     if (c.world == 1) return NP_OK;
     NP_RCCL_CHECK(c.api.GroupStart());
     for (int step = 1; step < c.world; ++step) {
-        // rank r sends to r + step while it receives from r - step: every step is a perfect matching of the mesh
-        const int to = (c.rank + step) % c.world, from = (c.rank - step + c.world) % c.world;
+        int to = 0, from = 0;
+        p2p_peers(c.rank, c.world, step, &to, &from);
         ncclResult_t rc = c.api.Send(send, bytes, ncclChar, to, c.comm, s);
         if (rc == ncclSuccess) rc = c.api.Recv(base + (size_t)from * recv_stride, bytes, ncclChar, from, c.comm, s);
         if (rc != ncclSuccess) {
@@ -639,8 +659,10 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
                     failed = np::fail(NP_ERR_DEVICE, "launch of flag_wait_kernel failed");
                     break;
                 }
-                failed = gather_on(cm.stream, mine + lo * mat, C_full + lo * mat, count * mat * sizeof(float),
-                                   slab_elems * sizeof(float), chunks == 1 ? mode == NP_GATHER_P2P : true);
+                size_t send_off = 0, recv_off = 0, stride = 0;
+                piece_addresses(cm.rank, slab, mat * sizeof(float), lo, &send_off, &recv_off, &stride);
+                failed = gather_on(cm.stream, (const char *)C_full + send_off, (char *)C_full + recv_off, count * mat * sizeof(float),
+                                   stride, chunks == 1 ? mode == NP_GATHER_P2P : true);
             }
             if (failed != NP_OK) {
                 // the GEMM is counting tiles: whatever went wrong above, the counters must be zero again before the next
@@ -667,11 +689,47 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
                                               mine + lo * mat, mat))
             return rc;
         // piece c of rank r belongs at C_full + r * slab + lo: destinations one slab apart
-        if (int rc = np_allgather_async(mine + lo * mat, C_full + lo * mat, count * mat * sizeof(float),
-                                        slab_elems * sizeof(float), chunks == 1 ? mode : NP_GATHER_P2P))
+        size_t send_off = 0, recv_off = 0, stride = 0;
+        piece_addresses(g_comm.rank, slab, mat * sizeof(float), lo, &send_off, &recv_off, &stride);
+        if (int rc = np_allgather_async((const char *)C_full + send_off, (char *)C_full + recv_off, count * mat * sizeof(float),
+                                        stride, chunks == 1 ? mode : NP_GATHER_P2P))
             return rc;
     }
     return np_comm_wait();   // whatever the caller enqueues next (or np_sync) sees the gathered result
+}
+
+// testing: what np_sgemm_strided_batched_allgather(slab items of item_bytes, `chunks` pieces, point to point) makes rank
+// `rank` of `world` send and receive — computed by the SAME functions the real path uses (np_comm_piece, piece_addresses,
+// p2p_peers), no device, no communicator.  host_out receives records of 6 values {piece, send to, send offset, bytes,
+// receive from, receive offset} (offsets in bytes from the start of the replicated result), *host_count how many.
+int np_comm_debug_plan(int rank, int world, size_t slab, size_t item_bytes, int chunks, unsigned long long *host_out,
+                       size_t max_records, size_t *host_count) {
+    if (world < 1 || rank < 0 || rank >= world || chunks < 1 || !host_count || (!host_out && max_records))
+        return np::fail(NP_ERR_INVALID, "np_comm_debug_plan: bad arguments");
+    if ((size_t)chunks > slab) chunks = slab ? (int)slab : 1;
+    size_t n = 0;
+    for (int c = 0; c < chunks; ++c) {
+        size_t lo = 0, count = 0;
+        if (int rc = np_comm_piece(slab, chunks, c, &lo, &count)) return rc;
+        size_t send_off = 0, recv_base = 0, stride = 0;
+        piece_addresses(rank, slab, item_bytes, lo, &send_off, &recv_base, &stride);
+        for (int step = 1; step < world; ++step) {
+            int to = 0, from = 0;
+            p2p_peers(rank, world, step, &to, &from);
+            if (n < max_records) {
+                unsigned long long *r = host_out + 6 * n;
+                r[0] = (unsigned long long)c;
+                r[1] = (unsigned long long)to;
+                r[2] = send_off;
+                r[3] = count * item_bytes;
+                r[4] = (unsigned long long)from;
+                r[5] = recv_base + (size_t)from * stride;
+            }
+            ++n;
+        }
+    }
+    *host_count = n;
+    return NP_OK;
 }
 
 // testing: one grouped ncclSend / ncclRecv pair from this rank to itself on the communication stream (the only way

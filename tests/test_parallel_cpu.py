@@ -135,3 +135,49 @@ def test_piece_arithmetic_matches_the_c_abi():
             sizes = [c for _, c in pcs]
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
     assert parallel.pieces_of(64, 4) == [(0, 16), (16, 16), (32, 16), (48, 16)]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("chunks", [1, 2, 3, 8])
+def test_c_abi_exchange_plan_replicates_the_result(world, chunks):
+    """np_comm_debug_plan: the sends / receives np_sgemm_strided_batched_allgather issues on every rank, from the same
+    functions as the real path (np_comm_piece, piece_addresses, p2p_peers) — played out on numpy buffers for worlds of
+    2, 3 and 8 ranks: every send has exactly one matching receive of the same piece and size, every byte of every peer's
+    slab arrives exactly once in the right place, nothing lands in a rank's own slab."""
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    lib = load()
+    slab, item = 5, 12           # 5 items of 12 bytes per rank: pieces that do not divide evenly
+    total = world * slab * item
+    truth = np.arange(total, dtype=np.int64) % 251 + 1                      # the replicated result every rank must end with
+    bufs = []
+    for r in range(world):
+        b = np.zeros(total, dtype=np.int64)
+        b[r * slab * item:(r + 1) * slab * item] = truth[r * slab * item:(r + 1) * slab * item]   # its own slab, computed in place
+        bufs.append(b)
+    plans = []
+    for r in range(world):
+        n = C.c_size_t(0)
+        check(lib.np_comm_debug_plan(r, world, slab, item, chunks, None, 0, C.byref(n)))
+        assert n.value == min(chunks, slab) * (world - 1)
+        rec = (C.c_ulonglong * (6 * n.value))()
+        check(lib.np_comm_debug_plan(r, world, slab, item, chunks, rec, n.value, C.byref(n)))
+        plans.append([tuple(rec[6 * i + k] for k in range(6)) for i in range(n.value)])
+    written = [np.zeros(total, dtype=np.int64) for _ in range(world)]
+    for r in range(world):
+        for piece, to, send_off, nbytes, frm, recv_off in plans[r]:
+            # the matching receive on the destination rank: same piece, same size, from this rank, into this rank's window
+            match = [q for q in plans[to] if q[0] == piece and q[4] == r]
+            assert len(match) == 1 and match[0][3] == nbytes, (r, to, piece)
+            dst_off = match[0][5]
+            assert dst_off == send_off                                      # a replicated result: same place on every rank
+            assert r * slab * item <= send_off and send_off + nbytes <= (r + 1) * slab * item   # sent from its own slab only
+            bufs[to][dst_off:dst_off + nbytes] = bufs[r][send_off:send_off + nbytes]
+            written[to][dst_off:dst_off + nbytes] += 1
+    for r in range(world):
+        assert (bufs[r] == truth).all(), r
+        own = slice(r * slab * item, (r + 1) * slab * item)
+        assert (written[r][own] == 0).all()
+        others = np.ones(total, dtype=bool)
+        others[own] = False
+        assert (written[r][others] == 1).all()
