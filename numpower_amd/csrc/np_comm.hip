@@ -291,7 +291,7 @@ int exchange_file(const std::string &path, int rank, ncclUniqueId &id, double ti
 // ---- the communication stream ----
 
 constexpr unsigned long long kWaitTimeoutTicks = 60ull * 100000000ull;   // 60 s of the 100 MHz wall clock
-constexpr unsigned long long kSelfTestTicks = 2000000ull;                // 20 ms
+constexpr unsigned long long kSelfTestTicks = 20000000ull;               // 200 ms (only ever spent when the test FAILS)
 
 __global__ void flag_set_kernel(unsigned *flag, unsigned value) {
     // everything earlier on this stream is complete and visible (kernel boundary): a memory-side store publishes it
@@ -340,12 +340,18 @@ int stream_follows(hipStream_t consumer, hipStream_t producer, unsigned *flag, u
 
 // Do device-side flags work between the communication stream and `compute`?  The wait goes in FIRST: were the two
 // streams multiplexed onto one hardware queue, the set kernel would queue up behind the spinning wait and never run —
-// the wait then gives up after 20 ms, raises the error word, and this communicator uses HIP events instead.
+// the wait then gives up after 200 ms, raises the error word, and this communicator uses HIP events instead.
 int flags_self_test(hipStream_t compute) {
     Comm &c = g_comm;
     c.use_flags = false;
     c.flags_ok_for = compute;
     if (g_sync_variant == 1 || !c.flags || !c.host_error) return NP_OK;
+    // both kernels once with nothing to wait for: their first launch loads code on the host side, and that must not eat
+    // into the budget of the wait that is about to spin on the device
+    flag_set_kernel<<<1, 1, 0, compute>>>(c.flags + 2, 1u);
+    NP_LAUNCH_CHECK("flag_set_kernel");
+    flag_wait_kernel<<<1, 1, 0, c.stream>>>(c.flags + 3, 0u, kSelfTestTicks, c.host_error);
+    NP_LAUNCH_CHECK("flag_wait_kernel");
     NP_HIP_CHECK(hipStreamSynchronize(compute));
     NP_HIP_CHECK(hipStreamSynchronize(c.stream));
     *(volatile unsigned *)c.host_error = 0;
