@@ -1,0 +1,92 @@
+"""The sharded batched matmul with REAL peers: one process per GPU, np_comm_init over loopback, every form of
+np_sgemm_strided_batched_allgather (one all-gather, point to point, 2 / 3 / 4 overlapped pieces; device-side flags and HIP
+events) — each rank's replicated result bit-identical to a single-GPU batched product of the whole batch and within
+1e-5 of the oracle's loop of 2-D matmuls.
+
+Needs at least two GPUs in one box: it SKIPS on the usual one-GPU lease (RCCL refuses two ranks on one device) and is
+written so that it runs the day a multi-GPU box does — like tests/test_gpu_devices_threads.py::test_set_device_switches_with_live_arrays."""
+import ctypes as C
+import socket
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from numpower_amd import synth
+from numpower_amd._lib import check, load
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+WORKER = textwrap.dedent("""
+    import ctypes as C, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from numpower_amd import device as D, synth
+    from numpower_amd._lib import check, load
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    batch, m, k, n = 4 * world, 96, 160, 64
+    slab = batch // world
+    D.init(rank)
+    lib = load()
+    check(lib.np_comm_init(rank, world, ("tcp://127.0.0.1:%%d" %% port).encode()))
+    A = np.stack([synth.uniform((m, k), 700 + i, -1.0, 1.0) for i in range(rank * slab, (rank + 1) * slab)])
+    B = np.stack([synth.uniform((k, n), 800 + i, -1.0, 1.0) for i in range(rank * slab, (rank + 1) * slab)])
+    dA, dB = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B)
+    results = {}
+    for variant in (0, 1, 2):
+        check(lib.np_comm_set_variant(variant))
+        for chunks, mode in ((1, 1), (1, 2), (2, 0), (3, 0), (4, 0)):
+            full = D.DeviceArray((batch, m, n))
+            D.fill(full, float("nan"))
+            check(lib.np_sgemm_strided_batched_allgather(slab, m, n, k, dA.ptr, m * k, dB.ptr, k * n, full.ptr, chunks, mode))
+            results["v%%d_c%%d_m%%d" %% (variant, chunks, mode)] = full.to_host()
+            full.free()
+    check(lib.np_comm_barrier())
+    check(lib.np_comm_destroy())
+    np.savez(out, **results)
+    print("OK")
+""") % str(ROOT)
+
+
+def _device_count():
+    n = C.c_int(0)
+    check(load().np_device_count(C.byref(n)))
+    return n.value
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_sharded_matmul_across_real_ranks(tmp_path, oracle):
+    devices = _device_count()
+    if devices < 2:
+        pytest.skip("needs two GPUs in one box (RCCL refuses two ranks on one device)")
+    world = 4 if devices >= 4 else 2
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, "-c", WORKER, str(r), str(world), str(port), str(tmp_path / ("rank%d.npz" % r))],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and so.strip().endswith("OK"), (r, so[-300:], se[-1500:])
+    batch, m, k, n = 4 * world, 96, 160, 64
+    A = np.stack([synth.uniform((m, k), 700 + i, -1.0, 1.0) for i in range(batch)])
+    B = np.stack([synth.uniform((k, n), 800 + i, -1.0, 1.0) for i in range(batch)])
+    ref = np.stack([oracle.matmul(A[i], B[i]) for i in range(batch)])          # the reference form: a loop of 2-D matmuls
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    first = None
+    for r in range(world):
+        got = np.load(tmp_path / ("rank%d.npz" % r))
+        for key in got.files:
+            x = got[key]
+            assert not np.isnan(x).any(), (r, key)
+            assert (np.abs(x - ref) <= 1e-5 * scale).all(), (r, key)
+            if first is None:
+                first = x
+            assert (x.view(np.uint32) == first.view(np.uint32)).all(), (r, key)   # every rank, every form: the same bits
