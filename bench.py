@@ -827,12 +827,28 @@ def main():
         result["cpu_baseline"] = mm["cpu"]
         result["parity"]["gpu_vs_cpu_reference_max_norm_err"] = mm["gpu_vs_cpu_max_norm_err"]
     extras = {}
+
+    def sharded_watchdog():
+        # the sharded extra has collectives in it: if a peer dies or a transfer never completes there, the headline
+        # measured above must still be reported — after 200 s rank 0 prints it without the extra and every rank leaves
+        def bail():
+            if rank0:
+                result["extras"] = {"error": "config 5 (sharded batched matmul + all-gather) did not finish in 200 s"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        t = threading.Timer(200.0, bail)
+        t.daemon = True
+        t.start()
+        return t
+
     if not args.no_extras:
         if dist.abi:
+            watchdog = sharded_watchdog()
             try:
                 extras = {"config5_batched_matmul_allgather_c_abi": bench_config5_abi(dist, max(5, args.steps // 5), 5)}
             except Exception as e:
                 extras = {"error": repr(e)}
+            watchdog.cancel()
         elif not dist.use_torch:
             try:
                 extras = bench_extras(dist, max(10, args.steps // 2), args.warmup)
@@ -848,16 +864,7 @@ def main():
             except Exception as e:   # extras must never take the headline down
                 extras = {"error": repr(e)}
         else:
-            # the sharded extra has collectives in it: if a peer dies there, the headline measured above
-            # must still be reported — after 200 s rank 0 prints it without the extra and every rank leaves
-            def bail():
-                if rank0:
-                    result["extras"] = {"error": "config 5 (sharded batched matmul + all-gather) did not finish in 200 s"}
-                    print(json.dumps(result), flush=True)
-                os._exit(0)
-            watchdog = threading.Timer(200.0, bail)
-            watchdog.daemon = True
-            watchdog.start()
+            watchdog = sharded_watchdog()
             try:
                 extras = {"config5_batched_matmul_allgather": bench_config5(dist, max(5, args.steps // 5), 5)}
             except Exception as e:
