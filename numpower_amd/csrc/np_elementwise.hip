@@ -104,13 +104,37 @@ __device__ __forceinline__ void horner32(const float (&x)[N], float (&r)[N], con
 // memory the per-lane gathers made the kernel wait on the vector cache: SQ_WAIT_ANY doubled and 213 us became 232,
 // profiles/r02/pow_r02.log), kPowLogTab itself elsewhere.
 typedef const __attribute__((address_space(3))) PowLogEntry *PowTabLds;
-// One 512-byte copy per wave.  Entries e and e + 16 share banks, and with a random entry per lane 44 % of the lookup's
-// LDS cycles are bank conflicts (SQ_LDS_BANK_CONFLICT 6.1e6 of SQ_LDS_IDX_ACTIVE 1.39e7, profiles/r02/pmc_sq_final.txt)
-// — but they are not on the critical path: the kernel is bound by its fp64 arithmetic.  Round 3 tried the
-// conflict-free layout (16 replicas, entry-major, lane l reads replica l & 15: SQ_LDS_BANK_CONFLICT = 0 of 9.4e6,
-// profiles/r03/pmc_sq_pow_replicated.txt): staging 8 KB per workgroup made the uncapped grid's 49 000 workgroups
-// read 400 MB of table from L2 (218 us against 205), and a grid capped at 8-18 workgroups per CU to amortise it ran
-// 220-233 us (profiles/r03/pow_ab.log) — every form slower than the conflicting one, which therefore stays.
+// In LDS: one 512-byte copy per wave.  Entries e and e + 16 share banks, and with a random entry per lane 44 % of the
+// lookup's LDS cycles are bank conflicts (SQ_LDS_BANK_CONFLICT 6.1e6 of SQ_LDS_IDX_ACTIVE 1.39e7,
+// profiles/r03/pmc_sq_pow_tables.txt) — not on the critical path: the kernel is bound by its fp64 arithmetic on a slow
+// box and by HBM on a fast one.  Round 3 first tried a conflict-free LDS layout (16 replicas, entry-major, lane l reads
+// replica l & 15: 0 conflicts, profiles/r03/pmc_sq_pow_replicated.txt): staging 8 KB per workgroup made the uncapped
+// grid's 49 000 workgroups read 400 MB of table from L2 (218 us against 205), and a grid capped at 8-18 workgroups per CU
+// to amortise it ran 220-233 us (profiles/r03/pow_ab.log).  What ships is the register form below: no banks, nothing
+// staged, 3 % fewer VALU instructions, and in every back-to-back pair a little faster: 184.7-190.9 us against 184.9-194.3
+// on a box where add takes 185-186 (profiles/r03/pow_regtab_ab.log; under the counters 3.18e6 against 3.35e6 GPU cycles for
+// five launches, pmc_sq_pow_tables.txt) — pow now runs at add's rate there.  The LDS copy stays as the A/B partner
+// (variant 9000).
+
+// The same table held in two VGPRs across the wave and read with ds_bpermute_b32 (the LDS crossbar, no banks involved:
+// no conflicts by construction, nothing staged).  `invc`: lanes 0..31 hold the low word of invc[lane], lanes 32..63 the
+// high word of invc[lane - 32]; `logc`: the same for logc.  A lookup is four bpermutes (byte address 4 e, + 128 for the high
+// words).  bpermute returns 0 for a source lane that is not executing: every lane of the wave must be active at a lookup
+// (binary_vec_kernel<..., POWREG = true> keeps them so).
+struct PowTabRegs {
+    int invc, logc;
+    __device__ __forceinline__ void load(unsigned lane) {
+        const int *w = (const int *)kPowLogTab;
+        invc = w[4 * (lane & 31u) + (lane >> 5)];
+        logc = w[4 * (lane & 31u) + 2 + (lane >> 5)];
+    }
+    __device__ __forceinline__ PowLogEntry operator[](unsigned e) const {
+        const int at = (int)(e * 4u);
+        const int i_lo = __builtin_amdgcn_ds_bpermute(at, invc), i_hi = __builtin_amdgcn_ds_bpermute(at + 128, invc);
+        const int l_lo = __builtin_amdgcn_ds_bpermute(at, logc), l_hi = __builtin_amdgcn_ds_bpermute(at + 128, logc);
+        return PowLogEntry{__hiloint2double(i_hi, i_lo), __hiloint2double(l_hi, l_lo)};
+    }
+};
 
 template <int N, typename Tab>
 __device__ __forceinline__ void pow_core_n(const unsigned (&xb)[N], const float *y, float *out, Tab tab) {
@@ -486,7 +510,7 @@ __device__ __forceinline__ v4f fetch4(const float *p, I v, I cols4, float splat,
 
 // Vector path: each lane handles UNROLL float4 per trip, spaced one grid apart so that every
 // wave-level access is a contiguous 1 KiB segment.
-template <int OP, int AK, int BK, bool QUIRK, int UNROLL, bool NT, typename I>
+template <int OP, int AK, int BK, bool QUIRK, int UNROLL, bool NT, typename I, bool POWREG = false>
 __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict__ a,
                                                          const float *__restrict__ b,
                                                          float *__restrict__ out, I nvec, I cols4,
@@ -500,20 +524,27 @@ __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict
     if constexpr (BK == NP_SCALAR) sb = b ? b[0] : hb;
     // pow: every wave stages its own copy of the log2 table (512 B) in LDS — no workgroup barrier: a wave's
     // LDS operations complete in order, so its reads below see its own writes
-    __shared__ PowLogEntry pow_tab_lds[OP == NP_POW ? 4 : 1][OP == NP_POW ? 32 : 1];
-    PowTabLds pow_tab = (PowTabLds)&pow_tab_lds[OP == NP_POW ? (threadIdx.x >> 6) : 0][0];
-    if constexpr (OP == NP_POW) {
+    constexpr bool LDSTAB = OP == NP_POW && !POWREG;
+    __shared__ PowLogEntry pow_tab_lds[LDSTAB ? 4 : 1][LDSTAB ? 32 : 1];
+    PowTabLds pow_tab = (PowTabLds)&pow_tab_lds[LDSTAB ? (threadIdx.x >> 6) : 0][0];
+    PowTabRegs pow_regs{0, 0};
+    if constexpr (LDSTAB) {
         const unsigned lane = threadIdx.x & 63u;
         if (lane < 32u) pow_tab_lds[threadIdx.x >> 6][lane] = kPowLogTab[lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (POWREG) pow_regs.load(threadIdx.x & 63u);
 
-    for (I base = tid; base < nvec; base += stride * UNROLL) {
+    // POWREG: the loop and the arithmetic run with the whole wave active (the table lives in its lanes); lanes past
+    // the end compute 1^1 and store nothing
+    auto more = [&](I base) { return POWREG ? __builtin_amdgcn_ballot_w64(base < nvec) != 0ull : base < nvec; };
+    for (I base = tid; more(base); base += stride * UNROLL) {
         v4f va[UNROLL], vb[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const I v = base + (I)u * stride;
+            if constexpr (POWREG) va[u] = vb[u] = v4f{1.0f, 1.0f, 1.0f, 1.0f};
             if (v < nvec) {
                 va[u] = fetch4<AK, NT, I>(a, v, cols4, sa, rg);
                 vb[u] = fetch4<BK, NT, I>(b, v, cols4, sb, rg);
@@ -522,7 +553,13 @@ __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const I v = base + (I)u * stride;
-            if (v < nvec) {
+            if constexpr (POWREG) {
+                const float px[4] = {va[u][0], va[u][1], va[u][2], va[u][3]};
+                const float py[4] = {vb[u][0], vb[u][1], vb[u][2], vb[u][3]};
+                float pr[4];
+                pow_n<4>(px, py, pr, pow_regs);
+                if (v < nvec) st4<NT>(out + (size_t)v * 4, v4f{pr[0], pr[1], pr[2], pr[3]});
+            } else if (v < nvec) {
                 v4f r;
                 const I e = v * 4;
                 if constexpr (OP == NP_POW) {
@@ -757,7 +794,11 @@ int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size
                                                                          (I)body_end, ha, hb, rg)
     // only the measured-useful variants are instantiated (the full unroll x nt sweep lives in
     // tools/explore/add_bw.hip): UNROLL 2 (default) and 4, non-temporal
-    if (c.unroll == 4)
+    if (OP == NP_POW && g_variant != 9000 && c.unroll == 2) {   // the log2 table in registers (9000: the per-wave LDS copy, tools/pow_grid_ab.py)
+        if constexpr (OP == NP_POW)
+            binary_vec_kernel<OP, AK, BK, QUIRK, 2, true, I, true><<<grid, 256, 0, s>>>(a, b, out, nvec, cols4, tail, (I)n,
+                                                                                       (I)body_end, ha, hb, rg);
+    } else if (c.unroll == 4)
         NP_BV(4, true);
     else if (c.unroll == 1)
         NP_BV(1, true);

@@ -212,6 +212,49 @@ def test_pow_special_cases_and_range(hip, oracle):
     assert (ulp == 0).mean() > 0.995
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 63, 255, 256, 257, 1000, 4099, 65536 + 5, 1_000_003])
+def test_pow_partial_last_waves(n, hip, oracle):
+    """The log2 table of the pow kernel lives in the lanes of each wave (ds_bpermute): sizes that leave the last wave
+    partly past the end, with the rare cases (negative base, zero, inf, NaN) sprinkled in, against glibc's powf and bit
+    for bit against the LDS-table form of the same kernel (variant 9000); row / column / scalar exponents too."""
+    from numpower_amd import device as D
+    from numpower_amd._lib import check, load
+    lib = load()
+    x = synth.uniform((n,), 11, 0.01, 4.0)
+    y = synth.uniform((n,), 12, -3.0, 3.0)
+    if n > 256:
+        x[5], x[77], x[200] = -2.0, 0.0, np.inf
+        y[5], y[78], y[201] = 3.0, np.nan, -np.inf
+    da, db = D.DeviceArray.from_host(x), D.DeviceArray.from_host(y)
+    got = D.binary("pow", da, "full", db, "full", 1, n).to_host().reshape(-1)
+    check(lib.np_elementwise_set_variant(9000))
+    try:
+        lds = D.binary("pow", da, "full", db, "full", 1, n).to_host().reshape(-1)
+    finally:
+        check(lib.np_elementwise_set_variant(0))
+    assert_bit_equal(got, lds, "register table vs LDS table, n = %d" % n)
+    with np.errstate(all="ignore"):
+        want = oracle.binary("pow", x, y)
+    assert (np.isnan(got) == np.isnan(want)).all()
+    ok = ~np.isnan(want)
+    ulp = np.abs(got[ok].view(np.int32).astype(np.int64) - want[ok].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1
+    if n >= 1000:   # broadcast kinds of the same kernel: rows x cols with cols % 4 == 0 (vector path)
+        rows, cols = n // 8, 8
+        X = np.ascontiguousarray(x[:rows * cols].reshape(rows, cols))
+        dX = D.DeviceArray.from_host(X)
+        for kind, operand in (("row", y[:cols].copy()), ("col", y[:rows].copy()), ("scalar", y[:1].copy())):
+            dy = D.DeviceArray.from_host(operand)
+            got = D.binary("pow", dX, "full", dy, kind, rows, cols).to_host().reshape(rows, cols)
+            full = {"row": operand[None, :], "col": operand[:, None], "scalar": operand[0]}[kind]
+            with np.errstate(all="ignore"):
+                want = oracle.binary("pow", X, np.ascontiguousarray(np.broadcast_to(full, X.shape)).astype(np.float32))
+            assert (np.isnan(got) == np.isnan(want)).all(), kind
+            ok = ~np.isnan(want)
+            ulp = np.abs(got[ok].view(np.int32).astype(np.int64) - want[ok].view(np.int32).astype(np.int64))
+            assert ulp.max() <= 1, kind
+
+
 def test_pow_scalar_two_is_a_square(hip, oracle):
     """`$a ** 2` takes the multiply kernel: same values as glibc's powf(x, 2) up to its own rounding slack
     (<= 1 ulp), same zeros / infinities / NaNs."""

@@ -29,8 +29,11 @@ if "add" in which:
     for _ in range(iters):
         D.binary("add", a, "full", b, "full", 1, N, out=o)
 if "pow" in which:
+    import os
+    check(lib.np_elementwise_set_variant(int(os.environ.get("NP_PROF_POW_VARIANT", "0"))))   # 9000: the log2 table in LDS instead of registers
     for _ in range(iters):
         D.binary("pow", a, "full", b, "full", 1, N, out=o)
+    check(lib.np_elementwise_set_variant(0))
 R, Cc = 25000, 4000
 prog1 = (FusedOp * 1)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0))
 ptrs1 = (C.c_void_p * 1)(a.ptr)
