@@ -482,12 +482,18 @@ __global__ __launch_bounds__(256, 2) void sgemm_pipe_kernel(GemmArgs g) {
 // a full tile earlier; hipcc's vmcnt(0) in front of the barrier is then already satisfied);
 // right after it the DMAs of tile t+2 go into the buffer tile t-1 just vacated.
 //
-// EDGE = the tile may stick out of C (M % 256 or N % 128 != 0; K % 16 == 0 and float4-aligned rows
-// are still required).  Out-of-range A rows and B columns are fetched from CLAMPED addresses (row
-// M-1, columns N-4..N-1): whatever lands in those LDS slots only ever reaches C rows >= M or
-// columns >= N, which the guarded epilogue does not store — no zero fill, no extra work in the loop.
-// KTAIL = K % 16 != 0 (its own instantiation: the tail bookkeeping costs the aligned case 0.5-1 %
-// when it is merely a run-time flag, profiles/r01/gemm_ktail_ab.log).
+// EDGE = the tile may stick out of C (M % 256 or N % 128 != 0).  Out-of-range A rows and B columns are
+// fetched from CLAMPED addresses (row M-1, columns 0..3): whatever lands in those LDS slots only ever
+// reaches C rows >= M or columns >= N, which the guarded epilogue does not store — no zero fill, no
+// extra work in the loop.
+// KTAIL = K % 16 != 0 or N % 4 != 0 (its own instantiation: the tail bookkeeping costs the aligned case
+// 0.5-1 % when it is merely a run-time flag, profiles/r01/gemm_ktail_ab.log).
+// Nothing has to be 16-byte aligned: global_load_lds_dwordx4 takes 4-byte-aligned global addresses at
+// the aligned rate (tools/explore/dma_unaligned.hip, profiles/r03/dma_unaligned.log), so odd K, N, row
+// strides and base addresses run here as they are (round 3; before, such operands were first copied
+// into padded workspaces).  What K % 4 and N % 4 leave over is handled in the LAST K-tile only: a
+// 4-float chunk cut by the end of a row is fetched so that it ENDS with the row and moved into place
+// in LDS (zero_tail) — A's K tail must hold zeros, and B's last row must not be read past the matrix.
 //
 // PRIO = alternate the wave priority between the two workgroups that share a CU.  Each SIMD holds one wave of
 // each; at equal priority the SIMD's issue arbitration favours the OLDER wave, so the first-dispatched workgroup
@@ -524,10 +530,10 @@ __device__ __forceinline__ void dma_gemm_segment(const GemmArgs &g, const float 
     // A: the wave moves 4 chunks of 16 rows x 64 B; lane = (row_in_chunk, slot); slot p of row r
     //    fetches k-chunk p ^ ((r >> 2) & 3).
     // B: the wave moves 2 chunks of 2 k-rows x 512 B, straight row-major.
-    // K tail: the last K-tile may hold only kr = 4, 8 or 12 valid k (K % 16, rows are float4-aligned so
-    // K % 4 == 0).  Its out-of-range slots are fetched from clamped addresses (k-chunk 0 / B row
-    // kr-1: valid memory) and overwritten with zeros by the lane that DMA'd them, after they have
-    // landed and before the barrier that publishes the tile — the loop itself is unchanged.
+    // K tail: the last K-tile may hold only kr = 1..15 valid k.  Its out-of-range slots are fetched from
+    // clamped addresses (k-chunk 0 / B row kr-1: valid memory) and overwritten with zeros by the lane
+    // that DMA'd them, after they have landed and before the barrier that publishes the tile — the loop
+    // itself is unchanged.
     const unsigned nk = (K + BK - 1) / BK;
     const unsigned kr = K - (nk - 1) * BK;          // 16 = no tail
     const float *a_src[4];
@@ -543,11 +549,15 @@ __device__ __forceinline__ void dma_gemm_segment(const GemmArgs &g, const float 
     }
     const float *b_src[2];
     unsigned b_k[2];                                   // k row (0..15) this lane fetches for chunk c
+    unsigned b_cut = 0;                                // N % 4 != 0 and this lane's 4 columns straddle N: how many are inside (1..3)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const unsigned krow = (wave * 2 + c) * 2 + (lane >> 5);
         unsigned gcol = n0 + (lane & 31) * 4;
-        if (EDGE && gcol + 4 > g.N) gcol = g.N - 4;
+        if (EDGE && gcol + 4 > g.N) {
+            if (gcol >= g.N) gcol = 0;                 // wholly outside: any valid address (N >= 4)
+            else b_cut = g.N - gcol;                   // straddling: fetched as it is — the floats past N are the next row's
+        }                                              // first ones (the very last row of B: see dma_tile), C columns >= N
         b_src[c] = B + (size_t)krow * g.ldb + gcol;
         b_k[c] = krow;
     }
@@ -559,7 +569,11 @@ __device__ __forceinline__ void dma_gemm_segment(const GemmArgs &g, const float 
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float *src = a_src[c];
-            if (KTAIL && tail && a_q[c] * 4 >= kr) src -= a_q[c] * 4;
+            if (KTAIL && tail) {
+                const unsigned k0 = a_q[c] * 4;
+                if (k0 + 4 > kr) src -= k0 + 4 - kr;           // cut by K (K % 4 != 0), or wholly past it: the 4 floats that END
+            }                                                  // with the row instead (never past the end of A); zero_tail moves
+                                                               // the valid ones into place / zeroes the slot
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(as + c * 256), 16, 0, 0);
             a_src[c] += BK;
@@ -567,24 +581,39 @@ __device__ __forceinline__ void dma_gemm_segment(const GemmArgs &g, const float 
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float *src = b_src[c];
-            if (KTAIL && tail && b_k[c] >= kr) src -= (size_t)(b_k[c] - (kr - 1)) * g.ldb;
+            if (KTAIL && tail && b_k[c] + 1 >= kr) {           // B's last row (k = K - 1) or below it
+                if (b_k[c] >= kr) src -= (size_t)(b_k[c] - (kr - 1)) * g.ldb;
+                src -= b_cut ? 4 - b_cut : 0;                  // a straddling chunk of the LAST row ends with the matrix instead
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(bs + c * 256), 16, 0, 0);
             b_src[c] += b_step;
         }
     };
-    // after the tail tile has landed (vmcnt(0)): zero the slots this lane fetched from clamped addresses
+    // after the tail tile has landed (vmcnt(0)): zero the slots this lane fetched from clamped addresses; a slot that was
+    // fetched `s` floats early (cut by K, or by N in B's last row) has its floats moved down by s and zeros behind them
+    auto shifted = [](v4f v, unsigned s) {   // s = 1..3
+        return v4f{s == 1 ? v[1] : s == 2 ? v[2] : v[3], s == 1 ? v[2] : s == 2 ? v[3] : 0.0f, s == 1 ? v[3] : 0.0f, 0.0f};
+    };
     auto zero_tail = [&](unsigned buf) {
         float *as = As + buf * A_SZ + wave * 1024 + lane * 4;
         float *bs = Bs + buf * B_SZ + wave * 512 + lane * 4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (a_q[c] * 4 >= kr) *(v4f *)(as + c * 256) = v4f{0, 0, 0, 0};
+        for (int c = 0; c < 4; ++c) {
+            const unsigned k0 = a_q[c] * 4;
+            v4f *slot = (v4f *)(as + c * 256);
+            if (k0 >= kr) *slot = v4f{0, 0, 0, 0};
+            else if (k0 + 4 > kr) *slot = shifted(*slot, k0 + 4 - kr);
+        }
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-            if (b_k[c] >= kr) *(v4f *)(bs + c * 256) = v4f{0, 0, 0, 0};
+        for (int c = 0; c < 2; ++c) {
+            v4f *slot = (v4f *)(bs + c * 256);
+            if (b_k[c] >= kr) *slot = v4f{0, 0, 0, 0};
+            else if (b_cut && b_k[c] + 1 == kr) *slot = shifted(*slot, 4 - b_cut);
+        }
     };
-    const bool has_tail = KTAIL && kr < BK;
+    // the last K-tile needs the fix-up when K % 16 != 0, and when N % 4 != 0 (B's last row must not be read past its end)
+    const bool has_tail = KTAIL && (kr < BK || (g.N & 3u) != 0);
 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -655,7 +684,7 @@ __device__ __forceinline__ void dma_gemm_segment(const GemmArgs &g, const float 
             // tile kt+1 (DMA issued one tile ago) must have landed for every wave before anyone
             // reads it; the same barrier tells everyone that tile kt-1's buffer is free
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (has_tail && kt + 2 == nk) zero_tail(nxt);   // tile kt+1 is the ragged last one
+            if (has_tail && kt + 2 == nk && nk > 2) zero_tail(nxt);   // tile kt+1 is the ragged last one (nk <= 2: the prologue fixed it — moving a slot's floats twice would be wrong)
             __syncthreads();
         }
         // second half: MFMAs of k group 1 with 6 LDS-DMA issues (tile kt+2 -> the buffer tile kt-1
@@ -1405,7 +1434,7 @@ int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
         // reads 944 -> 691 MB per launch (tools/gemm_swizzle_pmc.py, profiles/r01/gemm_swizzle_pmc.log)
         if (g_variant == 0 && g.tiles_m >= 8) g.swizzle = 4;
         const bool edge = g.M % 256 || g.N % 128 || g.n_store;
-        const bool ktail = g.K % 16 || g.K_last % 16;
+        const bool ktail = g.K % 16 || g.K_last % 16 || g.N % 4;   // N % 4: B's last row needs the tail tile's fix-up
         if (edge && ktail)
             sgemm_dma_kernel<true, true><<<grid, 256, 0, np::stream()>>>(g);
         else if (edge)
@@ -1426,8 +1455,23 @@ int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
 }
 
 bool g_force_pad = false;   // np_sgemm_set_variant(-3): always take launch_padded when it applies (tests)
-bool g_splitk = true;   // np_sgemm_set_variant(-1) turns the K-splitting plans off (A/B in tools/)
+int g_dma_any_alignment = 1;   // np_sgemm_set_variant(-6) = 0: the LDS-DMA kernel only for float4-loadable operands, as before round 3; (-8) = 2: for unaligned ones of any size (A/B); (-7) = 1: default
+
 int g_streamk = 0;      // np_sgemm_set_variant(-4): stream-K wherever the kernel can run it, (-5): never, (-2): back to the model
+
+// Shapes the LDS-DMA kernel (and its stream-K form) takes: a row holds at least one whole 4-float chunk.  `vec` =
+// every row of both operands is float4-loadable — no longer a requirement (sgemm_dma_kernel's comment), but small
+// products whose rows are not are left to the forms they took before (one matrix: padded copies; batches: the
+// register-staged kernels): measured faster there (profiles/r03/gemm_unaligned.log: 1001^3 38 us against 42, 64 x 513^3
+// 238 against 263; from 1537^3 / 16 x 1001^3 up the LDS-DMA kernel on the operands as they are wins by 3-20 %).
+inline bool dma_takes(size_t M, size_t N, size_t K, size_t batch, bool vec) {
+    if (N < 4 || K < 4) return false;
+    if (vec) return true;
+    if (!g_dma_any_alignment) return false;
+    const double flop = 2.0 * (double)M * (double)N * (double)K;
+    return g_dma_any_alignment == 2 || g_streamk > 0 || flop >= (batch == 1 ? 4e9 : 1e9);
+}
+bool g_splitk = true;   // np_sgemm_set_variant(-1) turns the K-splitting plans off (A/B in tools/)
 
 // A plan = tile configuration + how many trailing tile-ROWS of C are computed split-K.
 //   tail_rows == 0        : one launch, every workgroup walks the whole K (the classic grid)
@@ -1457,8 +1501,9 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
             if (units <= 0) return 0.0;
             const double waves = units / cus;
             const double blend = waves <= 1.0 ? 0.0 : waves >= 2.0 ? 1.0 : waves - 1.0;
-            // the register-staged kernels lose ~1/4 when rows are not float4-loadable (4097^3: 97 vs 132)
-            const double eff = (T.eff1 + (T.eff - T.eff1) * blend) * (vec || c == 0 ? 1.0 : 0.78);
+            // the register-staged kernels lose ~1/4 when rows are not float4-loadable (4097^3: 97 vs 132), the LDS-DMA
+            // kernel 5-9 % (16-byte fetches that straddle cache lines: profiles/r03/gemm_unaligned.log)
+            const double eff = (T.eff1 + (T.eff - T.eff1) * blend) * (vec ? 1.0 : c == 0 ? 0.93 : 0.78);
             return ceil(waves) * (2.0 * T.bm * T.bn * (double)k / (eff * cu_flops) + unit_fixed);
         };
         const double whole = span((double)(tm * tn * batch), K);
@@ -1493,8 +1538,10 @@ int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec);
 int launch_streamk(GemmArgs g, unsigned G);
 double streamk_model(size_t M, size_t N, size_t K, unsigned *grid_out);
 
-// Operands the LDS-DMA kernel cannot take as they are — K % 16 != 0, rows that are not 16-byte
-// aligned (K % 4 or N % 4 != 0), odd base addresses — are copied once into zero-padded, aligned
+// Until round 3 the LDS-DMA kernel wanted float4-loadable rows, and operands that were not — K % 4 or
+// N % 4 != 0, odd base addresses — were first copied into padded workspaces; it now takes them as they
+// are (4097^3: 124 -> see profiles/r03/gemm_unaligned.log), so this path is left for rows shorter than
+// one 4-float chunk and for A/B (np_sgemm_set_variant(-6), (-3)).  The operands are copied once into zero-padded, aligned
 // workspaces: A' (M x K'), B' (K' x N'), K' = K rounded up to 16, N' = N rounded up to 4.  The
 // zeros contribute nothing, C is written in place with its real row length (n_store), and the
 // copies cost O(M K + K N) bytes against O(M N K) flops: 4097^3 pays ~70 us of copies to run at the
@@ -1595,7 +1642,7 @@ int launch_streamk(GemmArgs g, unsigned G) {
     if (int rc = ws.alloc((size_t)G * 256 * 128 * sizeof(float))) return rc;
     sk.workspace = (float *)ws.ptr;
     const bool edge = g.M % 256 || g.N % 128 || g.n_store;
-    const bool ktail = g.K % 16;
+    const bool ktail = g.K % 16 || g.N % 4;
     hipStream_t s = np::stream();
     if (edge && ktail)
         sgemm_streamk_kernel<true, true><<<G, 256, 0, s>>>(g, sk);
@@ -1614,22 +1661,40 @@ int launch_streamk(GemmArgs g, unsigned G) {
 
 int launch_planned(GemmArgs g, size_t batch, bool vec) {
     const size_t M = g.M, N = g.N, K = g.K;
-    const bool dma_ok = vec && N >= 4;   // M, N edges: sgemm_dma_kernel<EDGE>; K % 16: zeroed tail slots
+    const bool dma_ok = dma_takes(M, N, K, batch, vec);   // M, N edges: sgemm_dma_kernel<EDGE>; K % 16, odd K / N: fixed up in the last K-tile
     Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec);
 #ifdef NP_TUNING   // tuning builds only (python -m numpower_amd.build --tuning): plan tracing
     static const bool debug = getenv("NP_SGEMM_PLAN_DEBUG") != nullptr;
 #else
     constexpr bool debug = false;
 #endif
-    if (!dma_ok && batch == 1 && g_splitk && N >= 1) {
+    // stream-K: equal shares of K-TILES instead of whole tiles, when the tile count does not fill the machine evenly
+    // (K % 16, ragged M / N and operands of any alignment included, like every use of the LDS-DMA kernel).  Not under
+    // a progress request (np_comm's pipeline counts whole tiles) and not for batches (blockIdx.z is the batch there).
+    const bool sk_allowed = batch == 1 && g_streamk >= 0 && !g.progress && g.K_last == 0;
+    unsigned sk_grid = 0;
+    double t_sk = 1e300;
+    if (sk_allowed && dma_ok) {
+        t_sk = streamk_model(M, N, K, &sk_grid) / (vec ? 1.0 : 0.93);
+        if (debug && t_sk < 1e299) fprintf(stderr, "[np_sgemm] %zux%zux%zu stream-K model %.1f us on %u workgroups\n", M, N, K, t_sk * 1e6, sk_grid);
+    }
+    const bool take_sk = t_sk < 1e299 && (g_streamk > 0 || t_sk < 0.99 * p.t);
+    if (!vec && batch == 1 && g_splitk && N >= 1) {   // padded copies + the aligned kernel: still the faster form for the largest products
         const size_t Kp = (K + 15) / 16 * 16, Np = (N + 3) / 4 * 4;
         Plan pp = plan_sgemm(M, Np, Kp, 1, true, true);
+        double t_pad = pp.t;
+        if (sk_allowed) {
+            unsigned G = 0;
+            const double t = streamk_model(M, Np, Kp, &G);
+            if (t < 0.99 * t_pad) t_pad = t;
+        }
         // two pad launches: read + write of both operands
-        pp.t += 2.0 * (double)((M * Kp + Kp * Np) * sizeof(float)) / 4e12 + 2 * 3e-6;
+        t_pad += 2.0 * (double)((M * Kp + Kp * Np) * sizeof(float)) / 4e12 + 2 * 3e-6;
+        const double t_as_is = take_sk ? t_sk : p.t;
         if (debug)
             fprintf(stderr, "[np_sgemm] %zux%zux%zu pad candidate: cfg %d tail_rows %u S %u model %.1f us vs unpadded cfg %d tail %u S %u %.1f us\n",
-                    M, N, K, pp.cfg, pp.tail_rows, pp.S, pp.t * 1e6, p.cfg, p.tail_rows, p.S, p.t * 1e6);
-        if (pp.t < p.t || g_force_pad) {
+                    M, N, K, pp.cfg, pp.tail_rows, pp.S, t_pad * 1e6, p.cfg, p.tail_rows, p.S, t_as_is * 1e6);
+        if (t_pad < t_as_is || g_force_pad) {
             if (debug)
                 fprintf(stderr, "[np_sgemm] %zux%zux%zu -> padded to K %zu N %zu: cfg %d tail_rows %u S %u model %.1f us (unpadded %.1f)\n",
                         M, N, K, Kp, Np, pp.cfg, pp.tail_rows, pp.S, pp.t * 1e6, p.t * 1e6);
@@ -1654,15 +1719,7 @@ int launch_planned(GemmArgs g, size_t batch, bool vec) {
     if (debug)
         fprintf(stderr, "[np_sgemm] %zux%zux%zu batch %zu -> cfg %d tail_rows %u S %u Kc %zu model %.1f us\n", M, N, K,
                 batch, p.cfg, p.tail_rows, p.S, p.Kc, p.t * 1e6);
-    // stream-K: equal shares of K-TILES instead of whole tiles, when the tile count does not fill the machine evenly
-    // (K % 16 and ragged M / N included; needs float4-loadable rows like every use of the LDS-DMA kernel).  Not under
-    // a progress request (np_comm's pipeline counts whole tiles) and not for batches (blockIdx.z is the batch there).
-    if (batch == 1 && dma_ok && g_streamk >= 0 && !g.progress && g.K_last == 0) {
-        unsigned G = 0;
-        const double t_sk = streamk_model(M, N, K, &G);
-        if (debug) fprintf(stderr, "[np_sgemm] %zux%zux%zu stream-K model %.1f us on %u workgroups\n", M, N, K, t_sk * 1e6, G);
-        if (t_sk < 1e299 && (g_streamk > 0 || t_sk < 0.99 * p.t)) return launch_streamk(g, G);
-    }
+    if (take_sk) return launch_streamk(g, sk_grid);
     return launch_plan(p, g, batch, vec);
 }
 
@@ -1739,7 +1796,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
         case 5: return launch_sgemm_pipe<128, 128, 0>(g, (unsigned)batch, vec);
         case 6: return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
         case 7:
-            if (vec && N >= 4) return launch_cfg(0, g, (unsigned)batch, vec);
+            if (N >= 4 && K >= 4 && (vec || g_dma_any_alignment)) return launch_cfg(0, g, (unsigned)batch, vec);   // any size: tests
             return launch_sgemm_pipe<128, 128, 1>(g, (unsigned)batch, vec);
         default: break;
     }
@@ -1876,7 +1933,7 @@ int sgemm_batched_with_progress(size_t batch, size_t M, size_t N, size_t K, cons
     const size_t lda = K;
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(B) && (stride_a % 4 == 0) &&
                      (stride_b % 4 == 0);
-    const bool dma_ok = vec && N >= 4;
+    const bool dma_ok = dma_takes(M, N, K, batch, vec);
     if (!dma_ok) return NP_OK;
     const Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec);
     if (p.cfg != 0 || p.tail_rows != 0) return NP_OK;
@@ -1907,6 +1964,10 @@ int np_sgemm_set_variant(int variant) {
         return NP_OK;
     }
     if (variant < 0) {   // -1: whole-K plans only, -2: default planner, -3: default + forced operand padding, -4 / -5: stream-K always / never
+        if (variant <= -6 && variant >= -8) {   // -6: LDS-DMA kernel for float4-loadable operands only (the pad-copy path for the rest), -8: for any operands of any size, -7: back to the default
+            g_dma_any_alignment = variant == -6 ? 0 : variant == -8 ? 2 : 1;
+            return NP_OK;
+        }
         g_splitk = variant != -1;
         g_force_pad = variant == -3;
         g_streamk = variant == -4 ? 1 : (variant == -5 || variant == -1) ? -1 : 0;   // -1: one whole tile per workgroup, nothing else

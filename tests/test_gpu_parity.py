@@ -626,6 +626,82 @@ def test_matmul_padded_operands(mnk, hip):
     assert (np.abs(plain.astype(np.float64) - got) / scale).max() <= 2e-6
 
 
+UNALIGNED_SHAPES = [(300, 5, 5), (300, 6, 7), (257, 7, 6), (1, 4, 4), (255, 129, 17), (256, 131, 18), (513, 258, 19),
+                    (300, 1001, 21), (64, 7, 33), (700, 133, 47), (1000, 1001, 1001), (1001, 1003, 1005), (130, 4097, 31),
+                    (2049, 2051, 2053), (3001, 2999, 1003), (512, 256, 1001), (512, 257, 1024), (4097, 4097, 4097)]
+
+
+@pytest.mark.parametrize("form", ["tile", "streamk", "default"])
+@pytest.mark.parametrize("mnk", UNALIGNED_SHAPES, ids=["%dx%dx%d" % s for s in UNALIGNED_SHAPES])
+def test_matmul_dma_unaligned_operands(mnk, form, hip):
+    """K % 4, N % 4 != 0, odd base addresses: the LDS-DMA kernel takes the operands as they are (4-byte-aligned
+    global_load_lds; a chunk cut by the end of a row is fetched so that it ends WITH the row and moved into place in LDS
+    in the last K-tile).  A and B sit at odd float offsets inside NaN-filled allocations — a K tail that was not zeroed,
+    or anything read from outside the operands and used, turns up as NaN — C inside a canary frame; the tile form
+    (variant 7), stream-K (-4) and the default planner; fp64 bar, and agreement with the pad-copy path (-6)."""
+    from numpower_amd import _lib
+    from numpower_amd import device as D
+    lib = _lib.load()
+    m, n, k = mnk
+    a = synth.uniform((m, k), 37, -1.0, 1.0)
+    b = synth.uniform((k, n), 38, -1.0, 1.0)
+    pad = 1024
+    frames = []
+    ptrs = []
+    for off, mat in ((1, a), (3, b)):
+        frame = D.DeviceArray((mat.size + 2 * pad + 4,))
+        D.fill(frame, float("nan"))
+        where = frame.ptr + 4 * (pad + off)
+        _lib.check(lib.np_memcpy_h2d(where, mat.ctypes.data, mat.nbytes))
+        frames.append(frame)
+        ptrs.append(where)
+    out = D.DeviceArray((m * n + 2 * pad,))
+    D.fill(out, -777.0)
+    variant = {"tile": 7, "streamk": -4, "default": None}[form]
+    if variant is not None:
+        _lib.check(lib.np_sgemm_set_variant(variant))
+    try:
+        _lib.check(lib.np_sgemm(m, n, k, ptrs[0], ptrs[1], out.ptr + 4 * pad))
+    finally:
+        _lib.check(lib.np_sgemm_set_variant(0))
+        _lib.check(lib.np_sgemm_set_variant(-2))
+    host = out.to_host().reshape(-1)
+    assert (host[:pad] == -777.0).all() and (host[pad + m * n:] == -777.0).all()
+    got = host[pad:pad + m * n].reshape(m, n)
+    assert not np.isnan(got).any()
+    ref64 = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(got - ref64) / scale).max() <= 1e-6
+    if form == "default":
+        _lib.check(lib.np_sgemm_set_variant(-6))      # as before round 3: such operands go through padded copies
+        try:
+            _lib.check(lib.np_sgemm(m, n, k, ptrs[0], ptrs[1], out.ptr + 4 * pad))
+        finally:
+            _lib.check(lib.np_sgemm_set_variant(-7))
+        padded = out.to_host().reshape(-1)[pad:pad + m * n].reshape(m, n)
+        assert (np.abs(padded.astype(np.float64) - got) / scale).max() <= 2e-6
+    for f in frames + [out]:
+        f.free()
+
+
+def test_batched_matmul_unaligned_strides(hip):
+    """The batched entry with odd matrix sizes (every matrix starts at an odd float offset) — one launch of the LDS-DMA
+    kernel over blockIdx.z — and the progress-reporting form np_comm's pipeline uses."""
+    from numpower_amd import _lib
+    from numpower_amd import device as D
+    lib = _lib.load()
+    batch, m, n, k = 5, 259, 131, 77
+    a = synth.uniform((batch, m, k), 39, -1.0, 1.0)
+    b = synth.uniform((batch, k, n), 40, -1.0, 1.0)
+    da, db = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b)
+    out = D.DeviceArray((batch, m, n))
+    _lib.check(lib.np_sgemm_strided_batched(batch, m, n, k, da.ptr, m * k, db.ptr, k * n, out.ptr, m * n))
+    got = out.to_host().reshape(batch, m, n)
+    ref64 = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(got - ref64) / scale).max() <= 1e-6
+
+
 def _log_sweep(lo, hi, n, seed):
     """n values log-uniform in [lo, hi]."""
     u = synth.uniform((n,), seed, 0.0, 1.0).astype(np.float64)
