@@ -1318,6 +1318,74 @@ __global__ __launch_bounds__(256) void sgemm_thin_left_kernel(const float *__res
     }
 }
 
+// Few rows of A (M <= 8) against a large B (a vector . matrix product, the row edge of a peeled product): an
+// HBM-bound read of B — a 64-row MFMA tile would be 90 % padding and the tiled kernels reach 1.8 TB/s (1 x 4097 x 4097:
+// 37 us).  A wave owns 256 columns (one float4 per lane, dword-aligned: rows of B start anywhere) and every fourth row
+// of a chunk of K; a lane keeps MV float4 accumulators; A's elements are wave-uniform (scalar loads).  The four waves
+// of a workgroup take interleaved rows of the same chunk and are summed through LDS; (column block, chunk) workgroups
+// write partial[chunk][M][N], folded by np_reduce_axis in chunk order (deterministic) — or C directly when one chunk
+// covers K.  B is read once, 1 KiB per wave per row.
+template <int MV>
+__global__ __launch_bounds__(256) void sgemm_fewrows_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                            float *__restrict__ out, unsigned M, unsigned N, unsigned K,
+                                                            unsigned chunk_len) {
+    typedef v4f v4f_u __attribute__((aligned(4)));
+    __shared__ v4f part[3][MV][64];
+    const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned col = blockIdx.x * 256 + lane * 4;
+    const unsigned k0 = blockIdx.y * chunk_len;
+    const unsigned k1 = (K - k0 < chunk_len) ? K : k0 + chunk_len;
+    const bool whole = col + 4 <= N;   // this lane's four columns are all inside
+    v4f acc[MV];
+#pragma unroll
+    for (int i = 0; i < MV; ++i) acc[i] = v4f{0, 0, 0, 0};
+    auto load_b = [&](unsigned k) {
+        v4f b{0, 0, 0, 0};
+        const float *src = B + (size_t)k * N + col;
+        if (whole) b = __builtin_nontemporal_load((const v4f_u *)src);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < N) b[e] = src[e];
+        }
+        return b;
+    };
+    auto rank1 = [&](unsigned k, const v4f &b) {
+#pragma unroll
+        for (int i = 0; i < MV; ++i)
+            if (i < (int)M) {
+                const float a = A[(size_t)i * K + k];   // k is wave-uniform
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(a, b[e], acc[i][e]);
+            }
+    };
+    unsigned k = k0 + wave;
+    for (; k + 12 < k1; k += 16) {   // four rows in flight
+        const v4f b0 = load_b(k), b1 = load_b(k + 4), b2 = load_b(k + 8), b3 = load_b(k + 12);
+        rank1(k, b0); rank1(k + 4, b1); rank1(k + 8, b2); rank1(k + 12, b3);
+    }
+    for (; k < k1; k += 4) rank1(k, load_b(k));
+    if (wave) {
+#pragma unroll
+        for (int i = 0; i < MV; ++i) part[wave - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *dst = out + (size_t)blockIdx.y * M * N;
+#pragma unroll
+        for (int i = 0; i < MV; ++i)
+            if (i < (int)M) {
+                const v4f sum = (acc[i] + part[0][i][lane]) + (part[1][i][lane] + part[2][i][lane]);
+                if (whole) *(v4f_u *)(dst + (size_t)i * N + col) = sum;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < N) dst[(size_t)i * N + col + e] = sum[e];
+                }
+            }
+    }
+}
+
 // Few rows of A, a long K, N <= 32 (X^T X of a 10^7 x 3 array): (chunk, row) workgroups as in
 // sgemv_chunks_kernel, with NV accumulators; partial[row][chunk][N], folded by np_reduce_axis.
 template <int NV>
@@ -1487,7 +1555,7 @@ bool g_splitk = true;   // np_sgemm_set_variant(-1) turns the K-splitting plans 
 // 2*bm*bn*k / (eff * peak per CU) + a fixed prologue/epilogue, the reduce costs its HBM traffic.
 struct Plan { int cfg; unsigned tail_rows, S; size_t Kc; double t; };
 
-Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool only_dma = false, bool vec = true) {
+Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool only_dma = false, bool vec = true, bool splitk = true) {
     const double cus = (double)np::num_cus();
     const double cu_flops = 157.3e12 / 256.0, unit_fixed = 1.5e-6, launch = 3e-6, hbm = 4e12;
     Plan best{2, 0, 1, K, 1e300};
@@ -1508,7 +1576,7 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
         };
         const double whole = span((double)(tm * tn * batch), K);
         if (whole < best.t) best = Plan{c, 0, 1, K, whole};
-        if (!g_splitk || batch != 1 || K < 512) continue;
+        if (!g_splitk || !splitk || batch != 1 || K < 512) continue;
         // candidate tails: up to one machine-wave worth of tile rows, or everything
         size_t max_tail = (size_t)(cus / (double)tn) + 1;
         if (max_tail > tm) max_tail = tm;
@@ -1662,7 +1730,10 @@ int launch_streamk(GemmArgs g, unsigned G) {
 int launch_planned(GemmArgs g, size_t batch, bool vec) {
     const size_t M = g.M, N = g.N, K = g.K;
     const bool dma_ok = dma_takes(M, N, K, batch, vec);   // M, N edges: sgemm_dma_kernel<EDGE>; K % 16, odd K / N: fixed up in the last K-tile
-    Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec);
+    // C as a window of a wider matrix (the main block of a peeled product, launch_peeled): the split-K plans fold their
+    // partials into a dense C, so they — and the pad path, which may take one — are left out
+    const bool dense_c = g.ldc == g.N && g.ldb == g.N;
+    Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec, dense_c);
 #ifdef NP_TUNING   // tuning builds only (python -m numpower_amd.build --tuning): plan tracing
     static const bool debug = getenv("NP_SGEMM_PLAN_DEBUG") != nullptr;
 #else
@@ -1679,7 +1750,7 @@ int launch_planned(GemmArgs g, size_t batch, bool vec) {
         if (debug && t_sk < 1e299) fprintf(stderr, "[np_sgemm] %zux%zux%zu stream-K model %.1f us on %u workgroups\n", M, N, K, t_sk * 1e6, sk_grid);
     }
     const bool take_sk = t_sk < 1e299 && (g_streamk > 0 || t_sk < 0.99 * p.t);
-    if (!vec && batch == 1 && g_splitk && N >= 1) {   // padded copies + the aligned kernel: still the faster form for the largest products
+    if (!vec && batch == 1 && g_splitk && dense_c && N >= 1) {   // padded copies + the aligned kernel: still the faster form for the largest products
         const size_t Kp = (K + 15) / 16 * 16, Np = (N + 3) / 4 * 4;
         Plan pp = plan_sgemm(M, Np, Kp, 1, true, true);
         double t_pad = pp.t;
@@ -1754,15 +1825,16 @@ int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec) {
     return np_reduce_axis(NP_SUM, W, 1, chunks, m2 * N, g.C + m1 * N, 0);
 }
 
-// C[b] (M x N, row stride N) = A[b] (M x K, row stride lda) * B[b] (K x N, row stride N)
-int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, size_t lda, size_t sa,
-                 const float *B, size_t sb, float *C, size_t sc) {
-    if (M > 0x7fffffffu || N > 0x7fffffffu || K > 0x7fffffffu || lda > 0x7fffffffu || batch > 65535)
+// C[b] (M x N, row stride ldc) = A[b] (M x K, row stride lda) * B[b] (K x N, row stride ldb)
+int launch_sgemm_ld(size_t batch, size_t M, size_t N, size_t K, const float *A, size_t lda, size_t sa,
+                    const float *B, size_t ldb, size_t sb, float *C, size_t ldc, size_t sc) {
+    if (M > 0x7fffffffu || N > 0x7fffffffu || K > 0x7fffffffu || lda > 0x7fffffffu || ldb > 0x7fffffffu || ldc > 0x7fffffffu ||
+        batch > 65535)
         return np::fail(NP_ERR_INVALID, "np_sgemm: dimension too large");
     GemmArgs g;
     g.A = A; g.B = B; g.C = C;
     g.M = (unsigned)M; g.N = (unsigned)N; g.K = (unsigned)K; g.K_last = 0; g.n_store = 0;
-    g.lda = (unsigned)lda; g.ldb = (unsigned)N; g.ldc = (unsigned)N;
+    g.lda = (unsigned)lda; g.ldb = (unsigned)ldb; g.ldc = (unsigned)ldc;
     g.stride_a = sa; g.stride_b = sb; g.stride_c = sc;
     g.tiles_m = g.tiles_n = 0;
     g.prio_period = 0;
@@ -1770,7 +1842,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
     g.progress = g_progress.counters;
     g.piece_base = g_progress.base;
     g.piece_extra = g_progress.extra;
-    const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(B) &&
+    const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (N % 4 == 0) && (ldb % 4 == 0) && aligned16(A) && aligned16(B) &&
                      (sa % 4 == 0) && (sb % 4 == 0);
     // variant = tile_code + 10 * swizzle_group ; 0 = default
 #ifdef NP_TUNING
@@ -1801,6 +1873,84 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
         default: break;
     }
     return launch_planned(g, batch, vec);
+}
+
+int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, size_t lda, size_t sa,
+                 const float *B, size_t sb, float *C, size_t sc) {
+    return launch_sgemm_ld(batch, M, N, K, A, lda, sa, B, N, sb, C, N, sc);
+}
+
+// ---- peeling a thin ragged edge ----
+// 4097^3 is 17 x 33 tiles of 256 x 128 of which a whole tile row holds ONE row of C and a whole tile column one
+// column: 9 % of the matrix-core work is spent on padding, whatever the schedule.  When M % 256 (<= 8 rows) or N % 128
+// (<= 2 columns) is that thin and the product large, the edge is peeled off instead:
+//   main block   C[0:M0, 0:N0] = A[0:M0, :] . B[:, 0:N0]   whole tiles, C and B addressed as windows of the full
+//                matrices (ldb = ldc = N; the LDS-DMA kernel reads rows of any alignment)
+//   row edge     C[M0:M, :]    = A[M0:M, :] . B             an (M - M0) x K by K x N product: reads B once
+//   column edge  C[0:M0, N0:N] = A[0:M0, :] . B[:, N0:N]    the columns gathered into a K x c matrix, the thin product
+//                (reads A once), the result scattered into C's columns (np_copy2d both ways)
+// taken when the planner's model of main + edges beats the whole product by 3 %: the edges are HBM-bound reads of one
+// operand each (the row edge on sgemm_fewrows_kernel: 3.7 TB/s at 4097^2, 5.9 at 8192^2; the column edge on the thin
+// kernels: 2.6 TB/s — profiles/r03/gemm_fringe_probe.log).
+bool g_fewrows = true;   // np_sgemm_set_variant(-12): M <= 8 products go to the tiled kernels as before (A/B), (-13): back
+int g_peel = 1;   // np_sgemm_set_variant(-9) = 0: never peel, (-10) = 1: when the model says so (default), (-11) = 2: whenever an edge is thin enough (tests)
+
+// the planner's estimate for one product, whichever form launch_planned would pick
+double estimate_product(size_t M, size_t N, size_t K, bool vec, bool dense_c) {
+    const bool dma_ok = dma_takes(M, N, K, 1, vec);
+    double t = plan_sgemm(M, N, K, 1, dma_ok, false, vec, dense_c).t;
+    if (dma_ok && g_streamk >= 0) {
+        unsigned G = 0;
+        const double t_sk = streamk_model(M, N, K, &G) / (vec ? 1.0 : 0.93);
+        if (t_sk < 0.99 * t) t = t_sk;
+    }
+    if (!vec && g_splitk && dense_c) {
+        const size_t Kp = (K + 15) / 16 * 16, Np = (N + 3) / 4 * 4;
+        double t_pad = plan_sgemm(M, Np, Kp, 1, true, true).t;
+        if (g_streamk >= 0) {
+            unsigned G = 0;
+            const double t_sk = streamk_model(M, Np, Kp, &G);
+            if (t_sk < 0.99 * t_pad) t_pad = t_sk;
+        }
+        t_pad += 2.0 * (double)((M * Kp + Kp * Np) * sizeof(float)) / 4e12 + 2 * 3e-6;
+        if (t_pad < t) t = t_pad;
+    }
+    return t;
+}
+
+// 1 = not peeled (the caller carries on), else the status of the peeled product
+int try_peeled(size_t M, size_t N, size_t K, const float *A, const float *B, float *C) {
+    if (!g_peel || g_variant != 0 || g_progress.counters || (g_peel == 1 && 2.0 * (double)M * (double)N * (double)K < 2e10)) return 1;
+    const size_t r = M % 256, c = N % 128;
+    const size_t m_cut = (r && r <= 8 && M > 2048) ? M - r : M, n_cut = (c && c <= 2 && N > 2048) ? N - c : N;
+    if (m_cut == M && n_cut == N) return 1;
+    const bool aligned = aligned16(A) && aligned16(B);
+    const bool vec_full = K % 4 == 0 && N % 4 == 0 && aligned;
+    const double t_full = estimate_product(M, N, K, vec_full, true);
+    double best = g_peel == 2 ? 1e300 : 0.97 * t_full;
+    size_t M0 = M, N0 = N;
+    for (int pick = 1; pick < 4; ++pick) {   // rows only, columns only, both
+        const size_t m0 = (pick & 1) ? m_cut : M, n0 = (pick & 2) ? n_cut : N;
+        if ((m0 == M && (pick & 1)) || (n0 == N && (pick & 2))) continue;
+        double t = estimate_product(m0, n0, K, vec_full, n0 == N);
+        if (m0 != M) t += (double)K * (double)N * 4.0 / 4.5e12 + 6e-6;   // sgemm_fewrows_kernel + its fold
+        if (n0 != N) t += (double)m0 * (double)K * 4.0 / 2.6e12 * (N - n0 == 1 ? 1.0 : 1.4) + 10e-6;
+        if (t < best) { best = t; M0 = m0; N0 = n0; }
+    }
+    if (M0 == M && N0 == N) return 1;
+    if (int rc = launch_sgemm_ld(1, M0, N0, K, A, K, 0, B, N, 0, C, N, 0)) return rc;
+    if (M0 != M)
+        if (int rc = np_sgemm_strided_batched(1, M - M0, N, K, A + M0 * K, 0, B, 0, C + M0 * N, 0)) return rc;
+    if (N0 != N) {
+        const size_t cw = N - N0;
+        np::Scratch tb, tc;
+        if (int rc = tb.alloc(K * cw * sizeof(float))) return rc;
+        if (int rc = tc.alloc(M0 * cw * sizeof(float))) return rc;
+        if (int rc = np_copy2d((float *)tb.ptr, cw, B + N0, N, cw, K)) return rc;
+        if (int rc = np_sgemm_strided_batched(1, M0, cw, K, A, 0, (const float *)tb.ptr, 0, (float *)tc.ptr, 0)) return rc;
+        if (int rc = np_copy2d(C + N0, N, (const float *)tc.ptr, cw, cw, M0)) return rc;
+    }
+    return NP_OK;
 }
 
 // N <= 32: the GEMV-with-several-right-hand-sides kernels.  Returns 1 when the shape is left to the
@@ -1904,6 +2054,37 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
     return 1;
 }
 
+// M <= 8 rows against a B of at least a few MB: sgemm_fewrows_kernel.  Returns 1 when the shape is left to the tiled kernels.
+int launch_fewrows(size_t M, size_t N, size_t K, const float *A, const float *B, float *C) {
+    // (B below ~24 MB: the tiled kernels are level or ahead — 1 x 2049 x 2049 14 us against 16, profiles/r03/gemm_fringe_probe.log)
+    if (M > 8 || N < 256 || K < 256 || (double)K * (double)N < 6e6 || N > 0x7fffffffu || K > 0x7fffffffu) return 1;
+    const size_t col_blocks = (N + 255) / 256;
+    // ~6 workgroups per CU; a chunk is at least 16 rows (four per wave) and a multiple of 4
+    size_t chunks = ((size_t)np::num_cus() * 6 + col_blocks - 1) / col_blocks;
+    if (chunks > K / 16) chunks = K / 16;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 65535) chunks = 65535;
+    size_t chunk_len = ((K + chunks - 1) / chunks + 3) / 4 * 4;
+    chunks = (K + chunk_len - 1) / chunk_len;
+    np::Scratch partial;
+    float *out = C;
+    if (chunks > 1) {
+        if (int rc = partial.alloc(chunks * M * N * sizeof(float))) return rc;
+        out = (float *)partial.ptr;
+    }
+    const dim3 grid((unsigned)col_blocks, (unsigned)chunks);
+    hipStream_t s = np::stream();
+#define NP_FR(MV_) sgemm_fewrows_kernel<MV_><<<grid, 256, 0, s>>>(A, B, out, (unsigned)M, (unsigned)N, (unsigned)K, (unsigned)chunk_len)
+    if (M == 1) NP_FR(1);
+    else if (M == 2) NP_FR(2);
+    else if (M <= 4) NP_FR(4);
+    else NP_FR(8);
+#undef NP_FR
+    NP_LAUNCH_CHECK("sgemm_fewrows_kernel");
+    if (chunks > 1) return np_reduce_axis(NP_SUM, out, 1, chunks, M * N, C, 0);
+    return NP_OK;
+}
+
 int launch_thin(size_t M, size_t N, size_t K, const float *A, const float *B, float *C) {
     if (N <= 4) return launch_thin_nv<4>(M, N, K, A, B, C);
     if (N <= 8) return launch_thin_nv<8>(M, N, K, A, B, C);
@@ -1964,6 +2145,14 @@ int np_sgemm_set_variant(int variant) {
         return NP_OK;
     }
     if (variant < 0) {   // -1: whole-K plans only, -2: default planner, -3: default + forced operand padding, -4 / -5: stream-K always / never
+        if (variant == -12 || variant == -13) {   // -12: no sgemm_fewrows_kernel (M <= 8 on the tiled kernels, as before), -13: back
+            g_fewrows = variant == -13;
+            return NP_OK;
+        }
+        if (variant <= -9 && variant >= -11) {   // -9: never peel a thin ragged edge off a large product, -11: always when one is thin enough, -10: back to the default (the model decides)
+            g_peel = variant == -9 ? 0 : variant == -11 ? 2 : 1;
+            return NP_OK;
+        }
         if (variant <= -6 && variant >= -8) {   // -6: LDS-DMA kernel for float4-loadable operands only (the pad-copy path for the rest), -8: for any operands of any size, -7: back to the default
             g_dma_any_alignment = variant == -6 ? 0 : variant == -8 ? 2 : 1;
             return NP_OK;
@@ -2003,9 +2192,17 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K, const f
         return NP_OK;
     }
     if (!A || !B) return np::fail(NP_ERR_INVALID, "np_sgemm: null input");
+    if (batch == 1 && M <= 0x7fffffffu && N <= 0x7fffffffu && K <= 0x7fffffffu) {
+        const int rc = try_peeled(M, N, K, A, B, C);
+        if (rc != 1) return rc;   // 1 = not peeled
+    }
     // (N up to 64 for the split-K thin path only: a few hundred rows x a very long K, two 32-column blocks)
     if (batch == 1 && (N <= 32 || (N <= 64 && M < 2048 && K >= 16384)) && g_variant == 0 && K <= 0x7fffffffu) {
         const int rc = launch_thin(M, N, K, A, B, C);
+        if (rc != 1) return rc;   // 1 = shape not taken
+    }
+    if (batch == 1 && M <= 8 && g_variant == 0 && g_fewrows) {
+        const int rc = launch_fewrows(M, N, K, A, B, C);
         if (rc != 1) return rc;   // 1 = shape not taken
     }
     if (batch == 1 && M <= 16 && K <= 64 && N >= 65536 && g_variant == 0) {

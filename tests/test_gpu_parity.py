@@ -684,6 +684,80 @@ def test_matmul_dma_unaligned_operands(mnk, form, hip):
         f.free()
 
 
+@pytest.mark.parametrize("mnk", [(1, 4097, 4097), (2, 1000, 3000), (3, 257, 5000), (5, 4099, 300), (8, 8192, 1024), (7, 300, 100000),
+                                 (4, 1024, 1024), (1, 256, 4000), (6, 70001, 256), (8, 1031, 1031)])
+def test_matmul_few_rows(mnk, hip, oracle):
+    """M <= 8 rows against a large B (vector . matrix, the row edge of a peeled product): sgemm_fewrows_kernel — B read
+    once, K cut into chunks whose partial sums are folded in chunk order.  fp64 bar, the oracle's OpenBLAS product at
+    1e-5 |A|.|B|, a canary frame around C, bit-identical when repeated, and the tiled kernels (variant -12) agree."""
+    from numpower_amd import _lib
+    from numpower_amd import device as D
+    lib = _lib.load()
+    m, n, k = mnk
+    a = synth.uniform((m, k), 43, -1.0, 1.0)
+    b = synth.uniform((k, n), 44, -1.0, 1.0)
+    da, db = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b)
+    pad = 1024
+    frame = D.DeviceArray((m * n + 2 * pad,))
+    outs = []
+    for _ in range(2):
+        D.fill(frame, -777.0)
+        _lib.check(lib.np_sgemm(m, n, k, da.ptr, db.ptr, frame.ptr + 4 * pad))
+        host = frame.to_host().reshape(-1)
+        assert (host[:pad] == -777.0).all() and (host[pad + m * n:] == -777.0).all()
+        outs.append(host[pad:pad + m * n].reshape(m, n).copy())
+    assert (outs[0].view(np.uint32) == outs[1].view(np.uint32)).all()
+    got = outs[0]
+    ref64 = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(got - ref64) / scale).max() <= 1e-6
+    assert (np.abs(got - oracle.matmul(a, b)) <= 1e-5 * scale).all()
+    _lib.check(lib.np_sgemm_set_variant(-12))
+    try:
+        tiled = D.sgemm(da, db).to_host()
+    finally:
+        _lib.check(lib.np_sgemm_set_variant(-13))
+    assert (np.abs(tiled.astype(np.float64) - got) / scale).max() <= 2e-6
+
+
+@pytest.mark.parametrize("mnk", [(2305, 2178, 77), (2049, 2304, 100), (2304, 2049, 64), (2312, 2050, 33), (4097, 4097, 600)])
+@pytest.mark.parametrize("mode", ["forced", "default"])
+def test_matmul_peeled_edges(mnk, mode, hip):
+    """A thin ragged edge (M % 256 <= 8 rows, N % 128 <= 2 columns) of a large product is peeled off: whole tiles for
+    the main block — C and B addressed as windows of the full matrices — and thin products for the edges (try_peeled,
+    np_sgemm.hip).  Forced (variant -11) on shapes the model would leave alone, and the default on one it takes;
+    fp64 bar, a canary frame around C, agreement with the unpeeled product (-9)."""
+    from numpower_amd import _lib
+    from numpower_amd import device as D
+    lib = _lib.load()
+    m, n, k = mnk
+    a = synth.uniform((m, k), 41, -1.0, 1.0)
+    b = synth.uniform((k, n), 42, -1.0, 1.0)
+    da, db = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b)
+    pad = 4096
+    frame = D.DeviceArray((m * n + 2 * pad,))
+    D.fill(frame, -777.0)
+    _lib.check(lib.np_sgemm_set_variant(-11 if mode == "forced" else -10))
+    try:
+        _lib.check(lib.np_sgemm(m, n, k, da.ptr, db.ptr, frame.ptr + 4 * pad))
+    finally:
+        _lib.check(lib.np_sgemm_set_variant(-10))
+    host = frame.to_host().reshape(-1)
+    assert (host[:pad] == -777.0).all() and (host[pad + m * n:] == -777.0).all()
+    got = host[pad:pad + m * n].reshape(m, n)
+    ref64 = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(got - ref64) / scale).max() <= 1e-6
+    _lib.check(lib.np_sgemm_set_variant(-9))
+    try:
+        whole = D.sgemm(da, db).to_host()
+    finally:
+        _lib.check(lib.np_sgemm_set_variant(-10))
+    assert (np.abs(whole.astype(np.float64) - got) / scale).max() <= 2e-6
+    for x in (da, db, frame):
+        x.free()
+
+
 def test_batched_matmul_unaligned_strides(hip):
     """The batched entry with odd matrix sizes (every matrix starts at an odd float offset) — one launch of the LDS-DMA
     kernel over blockIdx.z — and the progress-reporting form np_comm's pipeline uses."""

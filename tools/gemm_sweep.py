@@ -20,7 +20,7 @@ odd = bool(os.environ.get('NP_SWEEP_ODD'))
 if odd:
     shapes = [(1001,)*3, (1537,)*3, (2001,)*3, (2049,)*3, (3001,)*3, (4097,)*3, (5001,)*3, (4096, 4096, 4097), (4096, 4097, 4096), (4097, 4096, 4096),
               (2049, 1003, 3001), (8191,)*3, (1000, 1002, 1000), (3000, 3001, 3000)]
-for (m, n, k) in shapes:
+for (m, n, k) in ([] if os.environ.get('NP_SWEEP_PEEL') else shapes):
     a = D.DeviceArray((m, k)); b = D.DeviceArray((k, n)); c = D.DeviceArray((m, n))
     D.fill(a, 0.5); D.fill(b, 0.25)
     D.unary("sin", a, out=a); D.unary("cos", b, out=b)   # non-constant data
@@ -37,6 +37,25 @@ for (m, n, k) in shapes:
     check(lib.np_sgemm_set_variant(-2))
     print(line, flush=True)
     a.free(); b.free(); c.free()
+if os.environ.get('NP_SWEEP_PEEL'):   # thin ragged edges: the whole product (-9) / the edges peeled off whenever thin enough (-11) / default (-10)
+    for (m, n, k) in [(4097,)*3, (4097, 4096, 4096), (4096, 4097, 4096), (4098, 4098, 4098), (4104, 4097, 4097), (2049,)*3, (3073,)*3, (5121,)*3, (6145,)*3,
+                      (8193,)*3, (8200, 8193, 8192), (4097, 4097, 1024), (2305, 8193, 4096)]:
+        a = D.DeviceArray((m, k)); b = D.DeviceArray((k, n)); c = D.DeviceArray((m, n))
+        D.fill(a, 0.5); D.fill(b, 0.25)
+        D.unary("sin", a, out=a); D.unary("cos", b, out=b)
+        reps = max(3, min(50, int(2e11 / (2.0 * m * n * k))))
+        line = "%6d x %6d x %6d :" % (m, n, k)
+        for variant, label in ((-9, "whole"), (-11, "peeled"), (-10, "default")):
+            check(lib.np_sgemm_set_variant(variant))
+            for _ in range(3): D.sgemm(a, b, out=c)
+            D.sync(); t = Timer(); t.start()
+            for _ in range(reps): D.sgemm(a, b, out=c)
+            t.stop(); ms = t.elapsed_ms() / reps
+            line += "  %s %7.3f ms %5.1f TF" % (label, ms, 2.0 * m * n * k / ms / 1e9)
+        check(lib.np_sgemm_set_variant(-10))
+        print(line, flush=True)
+        a.free(); b.free(); c.free()
+    sys.exit(0)
 if odd:   # batched, every matrix at an odd offset: before, these ran on the register-staged kernels (no pad path for batches)
     for (batch, m, n, k) in ((16, 1001, 1001, 1001), (64, 513, 515, 517), (8, 2049, 2049, 2049), (32, 1000, 1002, 1000)):
         a = D.DeviceArray((batch, m, k)); b = D.DeviceArray((batch, k, n)); c = D.DeviceArray((batch, m, n))
