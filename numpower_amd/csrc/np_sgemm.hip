@@ -941,7 +941,28 @@ __global__ __launch_bounds__(256) void sgemv_kernel(const float *__restrict__ A,
             acc = fmaf(av[3], xv[3], acc);
         }
     } else {
-        for (unsigned k = lane; k < N; k += 64) acc = fmaf(a[k], x[k], acc);
+        // rows that are not 16-byte aligned (odd N): dword-aligned float4 loads, two in flight per lane, instead of one
+        // float per lane per load (4096 x 4097: 25 us -> see profiles/r03/gemm_fringe_probe.log), then the N % 4 tail
+        typedef v4f v4f_u __attribute__((aligned(4)));
+        const unsigned n4 = N / 4;
+        float acc1 = 0.0f;
+        unsigned v = lane;
+        for (; v + 64 < n4; v += 128) {
+            const v4f a0 = *(const v4f_u *)(a + (size_t)v * 4), x0 = *(const v4f_u *)(x + (size_t)v * 4);
+            const v4f a1 = *(const v4f_u *)(a + (size_t)(v + 64) * 4), x1 = *(const v4f_u *)(x + (size_t)(v + 64) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = fmaf(a0[e], x0[e], acc);
+                acc1 = fmaf(a1[e], x1[e], acc1);
+            }
+        }
+        for (; v < n4; v += 64) {
+            const v4f a0 = *(const v4f_u *)(a + (size_t)v * 4), x0 = *(const v4f_u *)(x + (size_t)v * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = fmaf(a0[e], x0[e], acc);
+        }
+        for (unsigned k = n4 * 4 + lane; k < N; k += 64) acc = fmaf(a[k], x[k], acc);
+        acc += acc1;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -1891,7 +1912,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
 //                (reads A once), the result scattered into C's columns (np_copy2d both ways)
 // taken when the planner's model of main + edges beats the whole product by 3 %: the edges are HBM-bound reads of one
 // operand each (the row edge on sgemm_fewrows_kernel: 3.7 TB/s at 4097^2, 5.9 at 8192^2; the column edge on the thin
-// kernels: 2.6 TB/s — profiles/r03/gemm_fringe_probe.log).
+// kernels: 5.9 TB/s for one column, ~3 for two — profiles/r03/gemm_fringe_probe.log).
 bool g_fewrows = true;   // np_sgemm_set_variant(-12): M <= 8 products go to the tiled kernels as before (A/B), (-13): back
 int g_peel = 1;   // np_sgemm_set_variant(-9) = 0: never peel, (-10) = 1: when the model says so (default), (-11) = 2: whenever an edge is thin enough (tests)
 
@@ -1934,7 +1955,7 @@ int try_peeled(size_t M, size_t N, size_t K, const float *A, const float *B, flo
         if ((m0 == M && (pick & 1)) || (n0 == N && (pick & 2))) continue;
         double t = estimate_product(m0, n0, K, vec_full, n0 == N);
         if (m0 != M) t += (double)K * (double)N * 4.0 / 4.5e12 + 6e-6;   // sgemm_fewrows_kernel + its fold
-        if (n0 != N) t += (double)m0 * (double)K * 4.0 / 2.6e12 * (N - n0 == 1 ? 1.0 : 1.4) + 10e-6;
+        if (n0 != N) t += (double)m0 * (double)K * 4.0 / (N - n0 == 1 ? 5e12 : 3e12) + 10e-6;   // sgemv_kernel / the MFMA thin kernel, + the two column copies
         if (t < best) { best = t; M0 = m0; N0 = n0; }
     }
     if (M0 == M && N0 == N) return 1;
@@ -1962,7 +1983,9 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
     // measured (profiles/r01/skinny_gemm.log): with N <= 4 the per-k loads of B are few enough that the
     // kernel stays HBM-bound (10^7 x 3 x 3: 0.53 -> 0.045 ms); with 8-32 accumulators it turns
     // load-issue-bound and loses to the tiled kernels, so those shapes are left to the planner
-    if (M >= 2048 && N <= 4 && K * N <= 16384) {   // B stays in the vector L1 / L2 while every row streams past it
+    if (N == 1 && M >= 2048 && K >= 256) return np_sgemv(M, K, A, B, C);   // a matrix . vector product: a wave per row, float4 loads
+    // (a long K on few rows: the MFMA kernel over K-chunks below reads A at 3.3 TB/s where this one's 4-byte loads reach 2)
+    if (M >= 2048 && N <= 4 && K * N <= 16384 && (K < 1024 || M >= 65536)) {   // B stays in the vector L1 / L2 while every row streams past it
         size_t L = 1;
         while (L * 8 < K && L < 64) L *= 2;    // ~8 k per lane
         const size_t blocks = (M * L + 255) / 256;
@@ -1981,10 +2004,29 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
         NP_LAUNCH_CHECK("sgemm_thin_kernel");
         return NP_OK;
     }
-    if (M >= 2048 && N > 4 && N <= 32 && K >= 4) {
+    if (M >= 2048 && (N > 4 || (K >= 1024 && M < 65536)) && N <= 32 && K >= 4) {
         const size_t rows_per_block = N <= 16 ? 64 : 128;
         const size_t blocks = (M + rows_per_block - 1) / rows_per_block;
         if (blocks > 0x7fffffffu) return 1;
+        // Not enough rows to fill the machine with one workgroup per 64 / 128 rows (4096 x 8 x 4097: 64 workgroups, 90 us
+        // for 67 MB): K is cut into chunks as for M < 2048 below, partials [chunk][M][N] folded by np_reduce_axis.
+        if (blocks < target && K >= 1024) {
+            size_t chunks = (target + blocks - 1) / blocks;
+            if (chunks > K / 512) chunks = K / 512;
+            if (chunks > 65535) chunks = 65535;
+            if (chunks >= 2) {
+                size_t kc = (K + chunks - 1) / chunks;
+                kc = (kc + 63) / 64 * 64;
+                chunks = (K + kc - 1) / kc;
+                np::Scratch partial;
+                if (int rc = partial.alloc(chunks * M * N * sizeof(float))) return rc;
+                const dim3 grid((unsigned)blocks, (unsigned)chunks);
+                if (N <= 16) sgemm_thin_mfma_kernel<16><<<grid, 256, 0, s>>>(A, B, (float *)partial.ptr, M, (unsigned)N, (unsigned)K, (unsigned)kc);
+                else sgemm_thin_mfma_kernel<32><<<grid, 256, 0, s>>>(A, B, (float *)partial.ptr, M, (unsigned)N, (unsigned)K, (unsigned)kc);
+                NP_LAUNCH_CHECK("sgemm_thin_mfma_kernel");
+                return np_reduce_axis(NP_SUM, (const float *)partial.ptr, 1, chunks, M * N, C, 0);
+            }
+        }
         if (N <= 16) sgemm_thin_mfma_kernel<16><<<(unsigned)blocks, 256, 0, s>>>(A, B, C, M, (unsigned)N, (unsigned)K, (unsigned)K);
         else sgemm_thin_mfma_kernel<32><<<(unsigned)blocks, 256, 0, s>>>(A, B, C, M, (unsigned)N, (unsigned)K, (unsigned)K);
         NP_LAUNCH_CHECK("sgemm_thin_mfma_kernel");

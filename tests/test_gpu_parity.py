@@ -943,7 +943,11 @@ def test_row_reductions_short_rows(cols, hip, oracle):
                                  # ... and N = 33..64 there (two 32-column blocks): cluster sums H^T . X, Gram matrices of <= 64 features
                                  (32, 64, 300_000), (64, 64, 100_001), (100, 33, 20_000), (2047, 50, 16_384), (40, 63, 70_000),
                                  # fewer row tiles than four waves: 128- and 64-thread workgroups
-                                 (20, 8, 50_000), (30, 16, 20_000), (32, 32, 65_536), (33, 20, 40_000), (48, 12, 30_000)])
+                                 (20, 8, 50_000), (30, 16, 20_000), (32, 32, 65_536), (33, 20, 40_000), (48, 12, 30_000),
+                                 # 2048 <= M, too few rows to fill the machine, a long K: the MFMA thin kernel over K-chunks + a fold;
+                                 # N = 1 there: the matrix . vector kernel (rows of any alignment)
+                                 (4096, 8, 4097), (4096, 2, 4097), (8192, 16, 8192), (3000, 31, 5001), (2048, 5, 1024), (20_000, 24, 3000),
+                                 (4096, 1, 4097), (2048, 1, 2049), (5000, 1, 1001), (3000, 1, 256), (2500, 1, 4098)])
 def test_matmul_thin(mnk, hip, oracle):
     """N <= 32: GEMV-with-several-right-hand-sides kernels (sgemm_thin_kernel: lane groups per row of A;
     sgemm_thin_mfma_kernel: one wave = 16 / 32 rows on the MFMA with B through LDS; sgemm_thin_chunks_kernel:

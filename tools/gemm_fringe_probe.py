@@ -8,7 +8,7 @@ from numpower_amd._lib import Timer, check, load
 D.init(0); lib = load()
 shapes = [(4097, 4097, 4097), (4096, 4096, 4097), (1, 4097, 4097), (2, 4097, 4097), (8, 4097, 4097), (4096, 1, 4097), (4096, 2, 4097),
           (4096, 8, 4097), (2049, 2049, 2049), (2048, 2048, 2049), (1, 2049, 2049), (2048, 1, 2049), (3001, 3001, 3001), (2816, 2944, 3001),
-          (185, 3001, 3001), (2816, 57, 3001), (1, 8192, 8192), (4, 8192, 8192), (8, 8192, 8192), (8, 1024, 1024), (1, 1024, 16384), (1, 100000, 1000), (3, 300, 100000)]
+          (185, 3001, 3001), (2816, 57, 3001), (8192, 16, 8192), (8192, 1, 8192), (20000, 24, 3000), (1, 8192, 8192), (4, 8192, 8192), (8, 8192, 8192), (8, 1024, 1024), (1, 1024, 16384), (1, 100000, 1000), (3, 300, 100000)]
 for (m, n, k) in shapes:
     a = D.DeviceArray((m, k)); b = D.DeviceArray((k, n)); c = D.DeviceArray((m, n))
     D.fill(a, 0.5); D.fill(b, 0.25)
