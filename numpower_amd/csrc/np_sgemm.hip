@@ -512,7 +512,7 @@ typedef v16f DmaAcc[kDmaTM][kDmaTN];
 
 template <bool EDGE, bool KTAIL, bool PRIO>
 __device__ __forceinline__ void dma_gemm_segment(const GemmArgs &g, const float *A, const float *B, const unsigned m0,
-                                                 const unsigned n0, const unsigned K, DmaAcc &acc) {
+                                                 const unsigned n0, const unsigned K, DmaAcc &acc, float **lds_out = nullptr) {
     constexpr int BM = kDmaBM, BN = kDmaBN, BK = kDmaBK;
     constexpr int WM = 128, WN = 64, TM = kDmaTM, TN = kDmaTN;
     constexpr int A_SZ = BM * BK, B_SZ = BK * BN;   // floats per buffer: 4096 + 2048
@@ -520,6 +520,7 @@ __device__ __forceinline__ void dma_gemm_segment(const GemmArgs &g, const float 
     __shared__ __attribute__((aligned(16))) float smem[3 * (A_SZ + B_SZ)];
     float *const As = smem;
     float *const Bs = smem + 3 * A_SZ;
+    if (lds_out) *lds_out = smem;   // stream-K folds its partial tiles through the same 72 KiB once the K loop is over
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -825,7 +826,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, Strea
         if (!first) __syncthreads();   // the previous segment's last LDS reads are done before this one's DMAs land
         first = false;
         DmaAcc acc;
-        dma_gemm_segment<EDGE, KTAIL, PRIO>(g, g.A + (size_t)kb * kDmaBK, g.B + (size_t)kb * kDmaBK * g.ldb, m0, n0, K, acc);
+        float *lds = nullptr;
+        dma_gemm_segment<EDGE, KTAIL, PRIO>(g, g.A + (size_t)kb * kDmaBK, g.B + (size_t)kb * kDmaBK * g.ldb, m0, n0, K, acc, &lds);
         const unsigned long long next_it = it1 < tile_end ? it1 : tile_end;
         unsigned row0, col0;
         dma_acc_coords(row0, col0);
@@ -847,43 +849,71 @@ __global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, Strea
                     for (unsigned spins = 0; np::dev::coherent_load(sk.flags + p) != sk.seq && spins < (1u << 26); ++spins)
                         __builtin_amdgcn_s_sleep(8);
             }
-            __syncthreads();
+            __syncthreads();   // (also: every wave is done with the K loop's LDS before the fold's DMAs land in it)
         }
         const unsigned n_partials = (unsigned)(w_last - w);
-        // ... then ONE store loop for every case — the tile of C, or (kb != 0: the tile's k = 0 lives in a lower-numbered
-        // workgroup) this workgroup's slot of the workspace seen as a 256 x 128 matrix of its own — with the finisher's
-        // partial sums folded in block by block on the way out (workgroup order = k order: the same sum every run).
-        // Separate loops for the cases cost 600-1200 B of scratch per lane and, through the scratch allocation, half the
-        // kernel's wave dispatch rate (2048^3: 222 us against 139 for the tile form).
+        // A partial tile travels LANE-MAJOR: group G = (i * 2 + j) * 4 + q holds acc[i][j][4q .. 4q + 3] of all 256 lanes,
+        // lane t's four floats at slot[(G * 256 + t) * 4].  The writer stores a float4 per lane per group, coalesced; the
+        // finisher fetches half a partial (16 groups = 64 KiB) with 16 LDS-DMA loads per lane — no registers, all in
+        // flight at once — and every lane then reads back exactly the 16-byte slots it fetched itself (no barrier).
+        // Fetching the partials into registers eight floats at a time (all the ragged instantiations have to spare) cost
+        // ~5 us per partial at the very end of the launch, where nothing is left to hide it behind.
         const bool to_slot = kb != 0;
-        float *dst = to_slot ? sk.workspace + (size_t)w * (kDmaBM * kDmaBN) : g.C;
-        const unsigned ld = to_slot ? kDmaBN : g.ldc, r_base = to_slot ? 0u : m0, c_base = to_slot ? 0u : n0;
-        const unsigned lim_m = to_slot ? kDmaBM : g.M, lim_n = to_slot ? kDmaBN : (g.n_store ? g.n_store : g.N);
-        const float *peers = sk.workspace + (size_t)(w + 1) * (kDmaBM * kDmaBN);
+        if (to_slot) {
+            // (ONE running pointer, kept opaque: 32 precomputed addresses were 64 VGPRs the K loop had to spill around)
+            float *dst = sk.workspace + (size_t)w * (kDmaBM * kDmaBN) + (size_t)threadIdx.x * 4;
 #pragma unroll
-        for (int i = 0; i < kDmaTM; ++i)
+            for (int i = 0; i < kDmaTM; ++i)
 #pragma unroll
-            for (int j = 0; j < kDmaTN; ++j) {
-                for (unsigned q = 0; q < n_partials; ++q) {
-                    const float *slot = peers + (size_t)q * (kDmaBM * kDmaBN);
+                for (int j = 0; j < kDmaTN; ++j)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {   // 8 loads in flight: the ragged instantiations have no more registers than that to spare
-                        float part[8];
+                    for (int q = 0; q < 4; ++q) {
+                        const v4f v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");   // memory-side, as coherent_store
+                        dst += 256 * 4;
+                        asm volatile("" : "+v"(dst));
+                    }
+        } else {
+            const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            for (unsigned q = 0; q < n_partials; ++q) {   // workgroup order = k order: the same sum every run
+                const float *peer = sk.workspace + (size_t)(w + 1 + q) * (kDmaBM * kDmaBN) + (size_t)threadIdx.x * 4;
 #pragma unroll
-                        for (int r = 0; r < 8; ++r)
-                            part[r] = np::dev::coherent_load(slot + (row0 + i * 32 + (r & 3) + 8 * (2 * h + (r >> 2))) * kDmaBN + col0 + j * 32);
+                for (int half = 0; half < 2; ++half) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous half's LDS reads are complete
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) acc[i][j][8 * h + r] += part[r];
+                    for (int gi = 0; gi < 16; ++gi) {
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)peer,
+                                                         (__attribute__((address_space(3))) void *)(lds + (gi * 256 + wave * 64) * 4), 16, 0,
+                                                         16 /* sc1: performed at the memory side, as coherent_load */);
+                        peer += 256 * 4;
+                        asm volatile("" : "+v"(peer));
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int gi = 0; gi < 16; ++gi) {
+                        const v4f p = *(const v4f *)(lds + (gi * 256 + threadIdx.x) * 4);
+                        const int grp = half * 16 + gi, i = grp / (kDmaTN * 4), j = (grp / 4) % kDmaTN, qq = grp % 4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * qq + e] += p[e];
+                        if (gi % 2 == 1) __builtin_amdgcn_sched_barrier(0);   // two 16-byte reads in flight: the ragged instantiations have no more registers to spare
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned row = r_base + row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    const unsigned col = c_base + col0 + j * 32;
-                    if (!EDGE || (row < lim_m && col < lim_n)) np::dev::coherent_store(&dst[(size_t)row * ld + col], acc[i][j][r]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
+            // the tile of C
+            const unsigned lim_n = g.n_store ? g.n_store : g.N;
+#pragma unroll
+            for (int i = 0; i < kDmaTM; ++i)
+#pragma unroll
+                for (int j = 0; j < kDmaTN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned row = m0 + row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                        const unsigned col = n0 + col0 + j * 32;
+                        if (!EDGE || (row < g.M && col < lim_n)) np::dev::coherent_store(&g.C[(size_t)row * g.ldc + col], acc[i][j][r]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
         if (n_partials) {   // consumed: the flags end the launch as they began it
             __syncthreads();
             if (threadIdx.x == 0)
@@ -1688,17 +1718,18 @@ int streamk_flags(unsigned **flags) {
 // where it does not apply, and the grid to run it on: two workgroups per CU (they share the matrix pipe at the rate
 // the tile kernel reaches with two resident tiles, kCfg[0].eff) or one (eff1; for few tiles: half as many partials).
 // Calibrated on profiles/r03/gemm_sweep_streamk.log: on top of the K-tiles themselves a launch pays ~8 us (pipeline
-// fills of up to three segments, the flag round trip) and ~5 us for every partial tile its busiest finisher folds in —
-// those reads come at the very end, when nothing is left to hide them behind (2048^3 on 512 workgroups: 3 partials per
-// tile, 118 us of K-tiles, 149 us measured; 1280 x 1280 x 8192: 10 partials, 184 -> 236 us and the tile form wins).
-// Ragged tiles (M % 256, N % 128, K % 16) run the guarded instantiations: ~4 % slower.
+// fills of up to three segments, the flag round trip) and ~3 us for every partial tile its busiest finisher folds in —
+// those reads come at the very end, when nothing is left to hide them behind (5 us before the fold went through LDS-DMA:
+// 2048^3 on 512 workgroups, 3 partials per tile, 118 us of K-tiles, 149 us measured then, 131 now; 1280 x 1280 x 8192:
+// 10 partials, level with the tile form).
+// Ragged tiles (M % 256, N % 128, K % 16) run the guarded instantiations: ~2 % slower.
 double streamk_model(size_t M, size_t N, size_t K, unsigned *grid_out) {
     const double cus = (double)np::num_cus(), cu_flops = 157.3e12 / 256.0;
     const size_t tm = (M + 255) / 256, tn = (N + 127) / 128, nk = (K + 15) / 16;
     *grid_out = 0;
     if (tm * tn * nk >= (1ull << 40)) return 1e300;
     const double iters = (double)(tm * tn) * (double)nk;
-    const double ragged = (M % 256 || N % 128 || K % 16) ? 1.04 : 1.0;
+    const double ragged = (M % 256 || N % 128 || K % 16) ? 1.02 : 1.0;
     double best = 1e300;
     for (int per_cu = 2; per_cu >= 1; --per_cu) {
         unsigned G = (unsigned)(per_cu * cus);
@@ -1708,7 +1739,7 @@ double streamk_model(size_t M, size_t N, size_t K, unsigned *grid_out) {
         const double eff = per_cu == 2 ? kCfg[0].eff / 2.0 : kCfg[0].eff1;
         const double t_kt = 2.0 * 256.0 * 128.0 * 16.0 / (eff * cu_flops);   // one k-tile of one workgroup
         const double folds = per_wg >= (double)nk ? 1.0 : ceil((double)nk / per_wg) - 1.0;
-        const double t = per_wg * t_kt * ragged + 8e-6 + 5e-6 * folds;
+        const double t = per_wg * t_kt * ragged + 8e-6 + 3e-6 * folds;
         if (t < best) {
             best = t;
             *grid_out = G;
