@@ -842,13 +842,12 @@ __global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, Strea
             w_last = (tile_end - 1) * G / sk.iters_total;                         // candidate owner of iteration tile_end - 1 ...
             while (sk.iters_total * (w_last + 1) / G < tile_end) ++w_last;        // ... exact under the floor()s above
             while (sk.iters_total * w_last / G >= tile_end) --w_last;
-            if (threadIdx.x == 0) {
-                // (bounded: the schedule guarantees the flags — 2^26 polls, s_sleep between them, are tens of seconds: a wait
-                // that long can only be a fault elsewhere, and a wrong tile is a lesser evil than a queue that never drains)
-                for (unsigned long long p = w + 1; p <= w_last; ++p)
-                    for (unsigned spins = 0; np::dev::coherent_load(sk.flags + p) != sk.seq && spins < (1u << 26); ++spins)
-                        __builtin_amdgcn_s_sleep(8);
-            }
+            // one lane per flag (they were posted long ago: polled one after the other, each costs a round trip to memory)
+            // (bounded: the schedule guarantees the flags — 2^26 polls, s_sleep between them, are tens of seconds: a wait
+            // that long can only be a fault elsewhere, and a wrong tile is a lesser evil than a queue that never drains)
+            for (unsigned p = (unsigned)w + 1 + threadIdx.x; p <= (unsigned)w_last; p += 256)
+                for (unsigned spins = 0; np::dev::coherent_load(sk.flags + p) != sk.seq && spins < (1u << 26); ++spins)
+                    __builtin_amdgcn_s_sleep(8);
             __syncthreads();   // (also: every wave is done with the K loop's LDS before the fold's DMAs land in it)
         }
         const unsigned n_partials = (unsigned)(w_last - w);
@@ -909,7 +908,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, Strea
                     for (int r = 0; r < 16; ++r) {
                         const unsigned row = m0 + row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                         const unsigned col = n0 + col0 + j * 32;
-                        if (!EDGE || (row < g.M && col < lim_n)) np::dev::coherent_store(&g.C[(size_t)row * g.ldc + col], acc[i][j][r]);
+                        if (!EDGE || (row < g.M && col < lim_n)) __builtin_nontemporal_store(acc[i][j][r], &g.C[(size_t)row * g.ldc + col]);   // as the tile kernel: no other workgroup reads C
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
