@@ -691,8 +691,8 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
     for (int c = 0; c < chunks; ++c) {
         size_t lo = 0, count = 0;
         if (int rc = np_comm_piece(slab, chunks, c, &lo, &count)) return rc;
-        if (int rc = np_sgemm_strided_batched(count, M, N, K, A + lo * stride_a, stride_a, B + lo * stride_b, stride_b,
-                                              mine + lo * mat, mat))
+        if (int rc = np::sgemm_batched_piece(count, slab, M, N, K, A + lo * stride_a, stride_a, B + lo * stride_b, stride_b,
+                                             mine + lo * mat, mat))   // planned as the whole slab: same kernels as the one-call form
             return rc;
         // piece c of rank r belongs at C_full + r * slab + lo: destinations one slab apart
         size_t send_off = 0, recv_off = 0, stride = 0;

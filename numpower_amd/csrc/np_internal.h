@@ -60,6 +60,9 @@ int fold_partials(int op, const float *partials, size_t n, float *dev_out);
 int sgemm_batched_with_progress(size_t batch, size_t M, size_t N, size_t K, const float *A, size_t stride_a, const float *B,
                                 size_t stride_b, float *C, size_t stride_c, unsigned *counters, int chunks,
                                 unsigned *tiles_per_matrix);
+// np_sgemm_strided_batched for `count` matrices that are a piece of a batch of `whole`: planned as the whole batch (np_sgemm.hip)
+int sgemm_batched_piece(size_t count, size_t whole, size_t M, size_t N, size_t K, const float *A, size_t stride_a, const float *B,
+                        size_t stride_b, float *C, size_t stride_c);
 // Copy kernel for large word-aligned device-to-device copies (np_elementwise.hip); bytes % 4 == 0.
 int device_copy(void *dst, const void *src, size_t bytes);
 

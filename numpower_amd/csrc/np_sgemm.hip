@@ -1778,8 +1778,14 @@ int launch_streamk(GemmArgs g, unsigned G) {
     return NP_OK;
 }
 
-int launch_planned(GemmArgs g, size_t batch, bool vec) {
+// != 0: the matrices being launched are a PIECE of a batch of this many (np_comm's per-piece pipeline): planned as that
+// batch, so that every piece — a single matrix included — runs the kernel configuration the whole batch would have
+// run, and the pipelined result is bit-identical to the one-call form (np::sgemm_batched_piece)
+size_t g_plan_batch = 0;
+
+int launch_planned(GemmArgs g, size_t launch_batch, bool vec) {
     const size_t M = g.M, N = g.N, K = g.K;
+    const size_t batch = g_plan_batch > launch_batch ? g_plan_batch : launch_batch;   // what the plan is made for
     const bool dma_ok = dma_takes(M, N, K, batch, vec);   // M, N edges: sgemm_dma_kernel<EDGE>; K % 16, odd K / N: fixed up in the last K-tile
     // C as a window of a wider matrix (the main block of a peeled product, launch_peeled): the split-K plans fold their
     // partials into a dense C, so they — and the pad path, which may take one — are left out
@@ -1842,7 +1848,7 @@ int launch_planned(GemmArgs g, size_t batch, bool vec) {
         fprintf(stderr, "[np_sgemm] %zux%zux%zu batch %zu -> cfg %d tail_rows %u S %u Kc %zu model %.1f us\n", M, N, K,
                 batch, p.cfg, p.tail_rows, p.S, p.Kc, p.t * 1e6);
     if (take_sk) return launch_streamk(g, sk_grid);
-    return launch_plan(p, g, batch, vec);
+    return launch_plan(p, g, launch_batch, vec);
 }
 
 int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec) {
@@ -2201,6 +2207,17 @@ int sgemm_batched_with_progress(size_t batch, size_t M, size_t N, size_t K, cons
     return NP_OK;
 }
 
+// `count` matrices that are a piece of a batch of `whole`: the kernels and tile configuration np_sgemm_strided_batched
+// would pick for the whole batch — a one-matrix piece must not wander off to the single-product planner (split-K,
+// stream-K, peeled edges ...), or the pipelined result would differ from the one-call form in its last bits.
+int sgemm_batched_piece(size_t count, size_t whole, size_t M, size_t N, size_t K, const float *A, size_t stride_a, const float *B,
+                        size_t stride_b, float *C, size_t stride_c) {
+    g_plan_batch = whole;
+    const int rc = np_sgemm_strided_batched(count, M, N, K, A, stride_a, B, stride_b, C, stride_c);
+    g_plan_batch = 0;
+    return rc;
+}
+
 }  // namespace np
 
 extern "C" {
@@ -2264,6 +2281,14 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K, const f
         return NP_OK;
     }
     if (!A || !B) return np::fail(NP_ERR_INVALID, "np_sgemm: null input");
+    if (g_plan_batch > 1) {   // a piece of a larger batch: straight to the tiled kernels, planned as that batch (launch_planned)
+        for (size_t b0 = 0; b0 < batch; b0 += 65535) {
+            const size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+            if (int rc = launch_sgemm(nb, M, N, K, A + b0 * stride_a, K, stride_a, B + b0 * stride_b, stride_b, C + b0 * stride_c, stride_c))
+                return rc;
+        }
+        return NP_OK;
+    }
     if (batch == 1 && M <= 0x7fffffffu && N <= 0x7fffffffu && K <= 0x7fffffffu) {
         const int rc = try_peeled(M, N, K, A, B, C);
         if (rc != 1) return rc;   // 1 = not peeled

@@ -111,6 +111,38 @@ def test_overlapped_sharded_matmul_is_bit_identical(chunks, mode, variant, hip, 
         assert (np.abs(got[i] - ref) / scale).max() <= 1e-5
 
 
+@pytest.mark.parametrize("shape", [(12, 1001, 1003, 1001), (4, 1024, 1024, 1024), (5, 1000, 1002, 1000)],
+                         ids=["odd rows", "aligned", "N % 4 = 2"])
+def test_overlapped_sharded_matmul_progress_launch_any_alignment(shape, hip):
+    """Matrices large enough for the ONE progress-reporting launch of the LDS-DMA kernel (its workgroups count finished
+    tiles per piece), including operands whose rows are not float4-loadable (the kernel reads them as they are and
+    runs its ragged instantiation; twelve odd matrices fill the machine well enough for the planner to pick it), and
+    shapes whose plan is not that launch (five 1000 x 1002 matrices: 64 x 64 tiles) and fall back to one launch per piece —
+    where a piece of ONE matrix must still run the whole batch's configuration (np::sgemm_batched_piece), not the
+    single-product planner's.  Bit-identical to the plain form, within 1e-6 |A|.|B| of fp64, three pieces."""
+    lib = load()
+    batch, m, k, n = shape
+    A = synth.uniform((batch, m, k), 14, -1.0, 1.0)
+    B = synth.uniform((batch, k, n), 15, -1.0, 1.0)
+    check(lib.np_comm_init(0, 1, ("tcp://127.0.0.1:%d" % free_port()).encode()))
+    try:
+        dA, dB = hip.DeviceArray.from_host(A), hip.DeviceArray.from_host(B)
+        plain, over = hip.DeviceArray((batch, m, n)), hip.DeviceArray((batch, m, n))
+        check(lib.np_sgemm_strided_batched(batch, m, n, k, dA.ptr, m * k, dB.ptr, k * n, plain.ptr, m * n))
+        for rep in range(2):
+            hip.fill(over, float("nan"))
+            check(lib.np_sgemm_strided_batched_allgather(batch, m, n, k, dA.ptr, m * k, dB.ptr, k * n, over.ptr, 3, 0))
+            got = over.to_host()
+            assert not np.isnan(got).any(), rep
+        want = plain.to_host()
+    finally:
+        check(lib.np_comm_destroy())
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    assert (np.abs(got.reshape(ref.shape) - ref) / scale).max() <= 1e-6
+
+
 def test_async_gather_out_of_place_and_strided(hip):
     """np_allgather_async: the copy lands on the communication stream behind what the library stream produced, and
     np_comm_wait orders the library stream behind it — out of place (world 1: the own piece is copied into place),
