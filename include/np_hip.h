@@ -321,6 +321,13 @@ int np_sgemm(size_t M, size_t N, size_t K, const float *A, const float *B, float
 int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K,
                              const float *A, size_t stride_a, const float *B, size_t stride_b,
                              float *C, size_t stride_c);
+/* The same for `count` matrices that are a PIECE of a batch of `whole` (a caller that pipelines a batch piece by piece,
+ * numpower_amd/parallel.py): the piece runs the kernel configuration np_sgemm_strided_batched would pick for the whole
+ * batch, so that the pieces together are bit-identical to the one call — a piece of one matrix would otherwise go to
+ * the single-product planner (split-K, stream-K ...), which sums in a different order.  whole >= count. */
+int np_sgemm_strided_batched_piece(size_t count, size_t whole, size_t M, size_t N, size_t K,
+                                   const float *A, size_t stride_a, const float *B, size_t stride_b,
+                                   float *C, size_t stride_c);
 /* y[M] = A[MxN] . x[N]; replaces cblas_sgemv / matrixVectorMultiplyFloatKernel
  * (linalg.c:367-386, cuda_math.cu:228,1417). */
 int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y);

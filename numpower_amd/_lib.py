@@ -114,6 +114,8 @@ PROTOTYPES = {
     "np_sgemm_strided_batched": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
                                            _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p,
                                            C.c_size_t]),
+    "np_sgemm_strided_batched_piece": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                                 _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p, C.c_size_t]),
     "np_sgemv": (C.c_int, [C.c_size_t, C.c_size_t, _f32p, _f32p, _f32p]),
     "np_outer": (C.c_int, [_f32p, C.c_size_t, _f32p, C.c_size_t, _f32p]),
     "np_transpose2d": (C.c_int, [_f32p, _f32p, C.c_size_t, C.c_size_t, C.c_size_t]),

@@ -2326,6 +2326,12 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K, const f
     return NP_OK;
 }
 
+int np_sgemm_strided_batched_piece(size_t count, size_t whole, size_t M, size_t N, size_t K, const float *A, size_t stride_a,
+                                   const float *B, size_t stride_b, float *C, size_t stride_c) {
+    if (whole < count) return np::fail(NP_ERR_INVALID, "np_sgemm_strided_batched_piece: a piece of %zu matrices of a batch of %zu", count, whole);
+    return np::sgemm_batched_piece(count, whole, M, N, K, A, stride_a, B, stride_b, C, stride_c);
+}
+
 int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y) {
     if (M == 0) return NP_OK;
     if (!A || !x || !y) return np::fail(NP_ERR_INVALID, "np_sgemv: null pointer");

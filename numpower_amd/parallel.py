@@ -103,8 +103,11 @@ def _sharded(slabs_in, batch: int, item_shape, compute, dist, gather: bool, over
     mine = full[slab.start:slab.stop]
     if world > 1 and batch % world == 0 and overlap_chunks > 1:
         handles = []
+        # a compute that knows how (hip_compute) is told the piece belongs to a slab of slab.size items: it then runs the
+        # kernels the whole slab would have run, and the pipelined result is bit-identical to the one-call form
+        extra = {"whole": slab.size} if getattr(compute, "accepts_whole", False) else {}
         for lo, count in pieces_of(slab.size, overlap_chunks):
-            compute(*[x[lo:lo + count] for x in slabs_in], mine[lo:lo + count])
+            compute(*[x[lo:lo + count] for x in slabs_in], mine[lo:lo + count], **extra)
             # piece c of every rank's slab lands at rank * slab + lo of the result
             handles.extend(exchange_piece(dist, full, slab.size, lo, count))
         for h in handles:
@@ -192,8 +195,9 @@ def hip_elementwise(op: str):
     return compute
 
 
-def hip_compute(a, b, out):
-    """compute() for GPU ranks: one np_sgemm_strided_batched launch, ordered with torch's work.
+def hip_compute(a, b, out, whole=None):
+    """compute() for GPU ranks: one np_sgemm_strided_batched launch, ordered with torch's work (whole: the operands are
+    a piece of a slab of that many matrices — np_sgemm_strided_batched_piece).
 
     If torch's current stream is a real stream the library is switched onto it (RCCL then sees the
     GEMM in stream order).  The legacy default stream has handle 0, which np_set_stream reads as
@@ -211,7 +215,14 @@ def hip_compute(a, b, out):
         check(lib.np_set_stream(handle))
     else:
         torch.cuda.synchronize(a.device)      # inputs produced on the null stream are complete
-    check(lib.np_sgemm_strided_batched(s, m, n, k, a.data_ptr(), m * k, b.data_ptr(), k * n,
-                                       out.data_ptr(), m * n))
+    if whole is not None and whole > s:
+        check(lib.np_sgemm_strided_batched_piece(s, whole, m, n, k, a.data_ptr(), m * k, b.data_ptr(), k * n,
+                                                 out.data_ptr(), m * n))
+    else:
+        check(lib.np_sgemm_strided_batched(s, m, n, k, a.data_ptr(), m * k, b.data_ptr(), k * n,
+                                           out.data_ptr(), m * n))
     if not handle:
         check(lib.np_sync())                  # result complete before the collective is enqueued
+
+
+hip_compute.accepts_whole = True

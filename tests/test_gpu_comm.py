@@ -143,6 +143,25 @@ def test_overlapped_sharded_matmul_progress_launch_any_alignment(shape, hip):
     assert (np.abs(got.reshape(ref.shape) - ref) / scale).max() <= 1e-6
 
 
+def test_pieces_of_a_batch_run_the_batch_s_kernels(hip):
+    """np_sgemm_strided_batched_piece: five 1000 x 1002 x 1000 products as pieces of 2, 2 and 1 matrices are bit for bit
+    the one call over all five (a one-matrix piece through np_sgemm_strided_batched itself is planned as a single
+    product — split-K here — and differs in its last bits: the reason the entry point exists)."""
+    lib = load()
+    batch, m, n, k = 5, 1000, 1002, 1000
+    A = synth.uniform((batch, m, k), 16, -1.0, 1.0)
+    B = synth.uniform((batch, k, n), 17, -1.0, 1.0)
+    dA, dB = hip.DeviceArray.from_host(A), hip.DeviceArray.from_host(B)
+    one, pieces = hip.DeviceArray((batch, m, n)), hip.DeviceArray((batch, m, n))
+    check(lib.np_sgemm_strided_batched(batch, m, n, k, dA.ptr, m * k, dB.ptr, k * n, one.ptr, m * n))
+    for lo, count in ((0, 2), (2, 2), (4, 1)):
+        check(lib.np_sgemm_strided_batched_piece(count, batch, m, n, k, dA.ptr + 4 * lo * m * k, m * k, dB.ptr + 4 * lo * k * n, k * n,
+                                                 pieces.ptr + 4 * lo * m * n, m * n))
+    assert (one.to_host().view(np.uint32) == pieces.to_host().view(np.uint32)).all()
+    with pytest.raises(NumPowerError, match="a piece of 3 matrices of a batch of 2"):
+        check(lib.np_sgemm_strided_batched_piece(3, 2, m, n, k, dA.ptr, m * k, dB.ptr, k * n, pieces.ptr, m * n))
+
+
 def test_async_gather_out_of_place_and_strided(hip):
     """np_allgather_async: the copy lands on the communication stream behind what the library stream produced, and
     np_comm_wait orders the library stream behind it — out of place (world 1: the own piece is copied into place),
