@@ -456,8 +456,8 @@ int np_comm_debug_loopback(void *dev_scratch, size_t bytes);
  * the kernel can run it, -5 = default planner without stream-K, -6 = operands whose rows are not float4-loadable never
  * go to the LDS-DMA kernel as they are (padded copies / register-staged kernels, as before round 3), -8 = they always do, whatever the size, -7 = back to the
  * default: from a size threshold up), -9 = never peel a thin ragged edge (M % 256 <= 8 rows, N % 128 <= 2 columns) off a
- * large product, -11 = always when there is one, -10 = back to the default: when the planner's model says it pays), -12 = products with M <= 8 rows go to the tiled
- * kernels instead of sgemm_fewrows_kernel (as before round 3), -13 = back). */
+ * large product, -11 = always when there is one, -10 = back to the default: when the planner's model says it pays), -12 = products with M <= 64 rows go to the tiled
+ * kernels instead of sgemm_fewrows_kernel / sgemm_skinny_kernel (as before round 3), -13 = back). */
 int np_runtime_set_variant(int variant);   /* how host-result calls wait: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag, 2 = spin on the result itself (default) */
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);   /* launch shape of the streaming kernels (np_elementwise.hip cfg_from_variant) and A/B switches of single kernels, e.g. 9000 = np_binary(pow) with its log2 table in LDS instead of registers (same bits) */

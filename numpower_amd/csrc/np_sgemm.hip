@@ -1436,6 +1436,144 @@ __global__ __launch_bounds__(256) void sgemm_fewrows_kernel(const float *__restr
     }
 }
 
+// 9 ... 64 rows of A against a large B (a small batch against a weight matrix): still an HBM-bound read of B — the
+// 256 x 128 tiles are three quarters padding there and the 64 x 64 ones reach 2.8 TB/s (16 ... 64 x 8192 x 8192: 93-96 us
+// for 268 MB) — but too many rows for a lane to keep in registers (sgemm_fewrows_kernel).  Here the rows go to the
+// matrix cores.  A workgroup owns 128 columns and a chunk of K; its four waves take every fourth 16-row tile of the
+// chunk.  Per tile a lane fetches eight float4s of B — lane (jl = lane & 31, kh = lane >> 5) reads rows kt + 8 kh + s,
+// s = 0..7, at columns n0 + 4 jl .. + 3: a wave covers two rows x 512 bytes per load — and component c of those float4s
+// is the B operand of MFMA (s, c): v_mfma_f32_32x32x2_f32 pairs k = kt + s (kh = 0) with k = kt + 8 + s (kh = 1), and
+// MFMA c produces the output columns n0 + 4 j + c — the four MFMAs of a step interleave to 128 consecutive columns, so a
+// lane stores float4s.  A's 16-column tile (<= 64 rows: 4 KiB) is staged by the wave itself in its own LDS slice (rows
+// padded to 20 floats) and read back as the A operands: lane (i, kh) takes A[rb * 32 + i][kt + 8 kh .. + 7].  Rows >= M
+// and k >= the chunk's end are zeros.  The four waves' accumulators are summed through LDS block by block; (column
+// block, chunk) partials [chunk][M][N] are folded by np_reduce_axis in chunk order (deterministic).
+template <int RB>   // 32-row blocks: 1 (M <= 32) or 2 (M <= 64)
+__global__ __launch_bounds__(256, 2) void sgemm_skinny_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                              float *__restrict__ out, unsigned M, unsigned N, unsigned K,
+                                                              unsigned chunk_len) {
+    typedef v4f v4f_u __attribute__((aligned(4)));
+    constexpr int PITCH = 20;                                   // floats per staged row of A (16 + 4: 16-byte aligned, off the bank period)
+    __shared__ __attribute__((aligned(16))) float lds[4 * RB * 32 * PITCH > 3 * 64 * 16 ? 4 * RB * 32 * PITCH : 3 * 64 * 16];
+    const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned jl = lane & 31, kh = lane >> 5;
+    const unsigned n0 = blockIdx.x * 128, col = n0 + 4 * jl;
+    const unsigned k0 = blockIdx.y * chunk_len;
+    const unsigned k1 = (K - k0 < chunk_len) ? K : k0 + chunk_len;
+    const bool whole = col + 4 <= N;
+    float *as = lds + wave * (RB * 32 * PITCH);
+    v16f acc[RB][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][c][r] = 0.0f;
+
+    // (issuing the next tile's loads before this tile's MFMAs costs 70 more registers and half the resident waves:
+    // 16 x 8192 x 8192 64 -> 83 us; the other waves of the SIMD are the prefetch)
+    for (unsigned kt = k0 + wave * 16; kt < k1; kt += 64) {
+        // B: eight rows per lane group
+        v4f b[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const unsigned k = kt + 8 * kh + s;
+            b[s] = v4f{0, 0, 0, 0};
+            if (k < k1) {
+                const float *src = B + (size_t)k * N + col;
+                if (whole) b[s] = __builtin_nontemporal_load((const v4f_u *)src);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < N) b[s][e] = src[e];
+                }
+            }
+        }
+        // A: the wave stages rows 0 .. RB * 32 - 1 of its 16 k-columns in its own LDS slice (lane: row lane / 4 + 16 p,
+        // k-columns 4 (lane % 4) .. + 3) and reads the operands back
+#pragma unroll
+        for (int p = 0; p < RB * 2; ++p) {
+            const unsigned row = (lane >> 2) + 16 * p, kq = kt + 4 * (lane & 3);
+            v4f x{0, 0, 0, 0};
+            if (row < M) {
+                const float *src = A + (size_t)row * K + kq;
+                if (kq + 4 <= k1) x = *(const v4f_u *)src;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (kq + e < k1) x[e] = src[e];
+                }
+            }
+            *(v4f *)(as + row * PITCH + 4 * (lane & 3)) = x;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // a wave's LDS operations complete in order: its reads below see its writes
+        __builtin_amdgcn_wave_barrier();
+        float a[RB][8];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const v4f lo = *(const v4f *)(as + (rb * 32 + jl) * PITCH + 8 * kh), hi = *(const v4f *)(as + (rb * 32 + jl) * PITCH + 8 * kh + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[rb][e] = lo[e];
+                a[rb][4 + e] = hi[e];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the operands are in registers before the next tile is staged over them
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[rb][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], b[s][c], acc[rb][c], 0, 0, 0);
+    }
+
+    // the four waves' sums, one (row block, column phase) block of 16 floats per lane at a time: waves 1..3 -> LDS -> wave 0
+    __syncthreads();
+    float *red = lds;   // [3][64 lanes][16]
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (wave) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(v4f *)(red + ((wave - 1) * 64 + lane) * 16 + 4 * q) =
+                        v4f{acc[rb][c][4 * q], acc[rb][c][4 * q + 1], acc[rb][c][4 * q + 2], acc[rb][c][4 * q + 3]};
+            }
+            __syncthreads();
+            if (!wave) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4f t = *(const v4f *)(red + (w * 64 + lane) * 16 + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[rb][c][4 * q + e] += t[e];
+                    }
+            }
+            __syncthreads();
+        }
+    if (wave) return;
+    float *dst = out + (size_t)blockIdx.y * M * N;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < M) {
+                const v4f v{acc[rb][0][r], acc[rb][1][r], acc[rb][2][r], acc[rb][3][r]};
+                float *d = dst + (size_t)row * N + col;
+                if (whole) *(v4f_u *)d = v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < N) d[e] = v[e];
+                }
+            }
+        }
+}
+
 // Few rows of A, a long K, N <= 32 (X^T X of a 10^7 x 3 array): (chunk, row) workgroups as in
 // sgemv_chunks_kernel, with NV accumulators; partial[row][chunk][N], folded by np_reduce_axis.
 template <int NV>
@@ -1949,7 +2087,7 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
 // taken when the planner's model of main + edges beats the whole product by 3 %: the edges are HBM-bound reads of one
 // operand each (the row edge on sgemm_fewrows_kernel: 3.7 TB/s at 4097^2, 5.9 at 8192^2; the column edge on the thin
 // kernels: 5.9 TB/s for one column, ~3 for two — profiles/r03/gemm_fringe_probe.log).
-bool g_fewrows = true;   // np_sgemm_set_variant(-12): M <= 8 products go to the tiled kernels as before (A/B), (-13): back
+bool g_fewrows = true;   // np_sgemm_set_variant(-12): M <= 64 products against a large B go to the tiled kernels as before — no sgemm_fewrows_kernel / sgemm_skinny_kernel (A/B), (-13): back
 int g_peel = 1;   // np_sgemm_set_variant(-9) = 0: never peel, (-10) = 1: when the model says so (default), (-11) = 2: whenever an edge is thin enough (tests)
 
 // the planner's estimate for one product, whichever form launch_planned would pick
@@ -2163,6 +2301,39 @@ int launch_fewrows(size_t M, size_t N, size_t K, const float *A, const float *B,
     return NP_OK;
 }
 
+// 9 <= M <= 32 rows against a large B: sgemm_skinny_kernel.  Returns 1 when the shape is left to the tiled kernels.
+int launch_skinny(size_t M, size_t N, size_t K, const float *A, const float *B, float *C) {
+    // (33 ... 64 rows — two 32-row blocks, 200 registers, two waves per SIMD — measured 134 us against the tiles' 93 on
+    // 64 x 8192 x 8192: left to them; the RB = 2 instantiation stays for the day that is worth tuning)
+    if (M < 9 || M > 32 || N < 512 || K < 512 || (double)K * (double)N < 16e6 || N > 0x7fffffffu || K > 0x7fffffffu) return 1;
+    const size_t col_blocks = (N + 127) / 128;
+    // ~3 workgroups per CU, as long as the partials stay under ~15 % of the bytes of B; chunks are multiples of 64 rows
+    // (four waves x 16-row tiles)
+    size_t chunks = ((size_t)np::num_cus() * 3 + col_blocks - 1) / col_blocks;
+    const size_t cap = (size_t)(0.075 * (double)K / (double)M);
+    if (chunks > cap) chunks = cap;
+    if (chunks > K / 64) chunks = K / 64;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 65535) chunks = 65535;
+    size_t chunk_len = ((K + chunks - 1) / chunks + 63) / 64 * 64;
+    chunks = (K + chunk_len - 1) / chunk_len;
+    np::Scratch partial;
+    float *out = C;
+    if (chunks > 1) {
+        if (int rc = partial.alloc(chunks * M * N * sizeof(float))) return rc;
+        out = (float *)partial.ptr;
+    }
+    const dim3 grid((unsigned)col_blocks, (unsigned)chunks);
+    hipStream_t s = np::stream();
+    if (M <= 32)
+        sgemm_skinny_kernel<1><<<grid, 256, 0, s>>>(A, B, out, (unsigned)M, (unsigned)N, (unsigned)K, (unsigned)chunk_len);
+    else
+        sgemm_skinny_kernel<2><<<grid, 256, 0, s>>>(A, B, out, (unsigned)M, (unsigned)N, (unsigned)K, (unsigned)chunk_len);
+    NP_LAUNCH_CHECK("sgemm_skinny_kernel");
+    if (chunks > 1) return np_reduce_axis(NP_SUM, out, 1, chunks, M * N, C, 0);
+    return NP_OK;
+}
+
 int launch_thin(size_t M, size_t N, size_t K, const float *A, const float *B, float *C) {
     if (N <= 4) return launch_thin_nv<4>(M, N, K, A, B, C);
     if (N <= 8) return launch_thin_nv<8>(M, N, K, A, B, C);
@@ -2300,6 +2471,10 @@ int np_sgemm_strided_batched(size_t batch, size_t M, size_t N, size_t K, const f
     }
     if (batch == 1 && M <= 8 && g_variant == 0 && g_fewrows) {
         const int rc = launch_fewrows(M, N, K, A, B, C);
+        if (rc != 1) return rc;   // 1 = shape not taken
+    }
+    if (batch == 1 && M >= 9 && M <= 32 && g_variant == 0 && g_fewrows) {
+        const int rc = launch_skinny(M, N, K, A, B, C);
         if (rc != 1) return rc;   // 1 = shape not taken
     }
     if (batch == 1 && M <= 16 && K <= 64 && N >= 65536 && g_variant == 0) {

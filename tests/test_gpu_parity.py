@@ -685,10 +685,14 @@ def test_matmul_dma_unaligned_operands(mnk, form, hip):
 
 
 @pytest.mark.parametrize("mnk", [(1, 4097, 4097), (2, 1000, 3000), (3, 257, 5000), (5, 4099, 300), (8, 8192, 1024), (7, 300, 100000),
-                                 (4, 1024, 1024), (1, 256, 4000), (6, 70001, 256), (8, 1031, 1031)])
+                                 (4, 1024, 1024), (1, 256, 4000), (6, 70001, 256), (8, 1031, 1031),
+                                 # 9 ... 64 rows: sgemm_skinny_kernel (the rows on the matrix cores, B read once)
+                                 (9, 4097, 4097), (16, 8192, 2048), (31, 4099, 4001), (32, 5000, 3333), (33, 4096, 4096), (64, 4097, 4100),
+                                 (50, 70001, 513), (64, 512, 40000), (17, 100003, 600)])
 def test_matmul_few_rows(mnk, hip, oracle):
-    """M <= 8 rows against a large B (vector . matrix, the row edge of a peeled product): sgemm_fewrows_kernel — B read
-    once, K cut into chunks whose partial sums are folded in chunk order.  fp64 bar, the oracle's OpenBLAS product at
+    """M <= 64 rows against a large B (vector . matrix, the row edge of a peeled product, a small batch against a weight
+    matrix): sgemm_fewrows_kernel (M <= 8) / sgemm_skinny_kernel (MFMA, M <= 64) — B read once, K cut into chunks whose
+    partial sums are folded in chunk order.  fp64 bar, the oracle's OpenBLAS product at
     1e-5 |A|.|B|, a canary frame around C, bit-identical when repeated, and the tiled kernels (variant -12) agree."""
     from numpower_amd import _lib
     from numpower_amd import device as D
