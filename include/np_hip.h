@@ -455,7 +455,7 @@ int np_comm_debug_loopback(void *dev_scratch, size_t bytes);
  * stream-K), -2 = default planner again, -3 = default planner + always pad unaligned operands, -4 = stream-K wherever
  * the kernel can run it, -5 = default planner without stream-K, -6 = operands whose rows are not float4-loadable never
  * go to the LDS-DMA kernel as they are (padded copies / register-staged kernels, as before round 3), -8 = they always do, whatever the size, -7 = back to the
- * default: from a size threshold up), -9 = never peel a thin ragged edge (M % 256 <= 8 rows, N % 128 <= 2 columns) off a
+ * default: from a size threshold up), -9 = never peel a thin ragged edge (M % 256 <= 32 rows, N % 128 <= 2 columns) off a
  * large product, -11 = always when there is one, -10 = back to the default: when the planner's model says it pays), -12 = products with M <= 64 rows go to the tiled
  * kernels instead of sgemm_fewrows_kernel / sgemm_skinny_kernel (as before round 3), -13 = back). */
 int np_runtime_set_variant(int variant);   /* how host-result calls wait: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag, 2 = spin on the result itself (default) */

@@ -2077,14 +2077,14 @@ int launch_sgemm(size_t batch, size_t M, size_t N, size_t K, const float *A, siz
 
 // ---- peeling a thin ragged edge ----
 // 4097^3 is 17 x 33 tiles of 256 x 128 of which a whole tile row holds ONE row of C and a whole tile column one
-// column: 9 % of the matrix-core work is spent on padding, whatever the schedule.  When M % 256 (<= 8 rows) or N % 128
+// column: 9 % of the matrix-core work is spent on padding, whatever the schedule.  When M % 256 (<= 32 rows) or N % 128
 // (<= 2 columns) is that thin and the product large, the edge is peeled off instead:
 //   main block   C[0:M0, 0:N0] = A[0:M0, :] . B[:, 0:N0]   whole tiles, C and B addressed as windows of the full
 //                matrices (ldb = ldc = N; the LDS-DMA kernel reads rows of any alignment)
 //   row edge     C[M0:M, :]    = A[M0:M, :] . B             an (M - M0) x K by K x N product: reads B once
 //   column edge  C[0:M0, N0:N] = A[0:M0, :] . B[:, N0:N]    the columns gathered into a K x c matrix, the thin product
 //                (reads A once), the result scattered into C's columns (np_copy2d both ways)
-// taken when the planner's model of main + edges beats the whole product by 3 %: the edges are HBM-bound reads of one
+// taken when the planner's model of main + edges beats the whole product by 1.5 %: the edges are HBM-bound reads of one
 // operand each (the row edge on sgemm_fewrows_kernel: 3.7 TB/s at 4097^2, 5.9 at 8192^2; the column edge on the thin
 // kernels: 5.9 TB/s for one column, ~3 for two — profiles/r03/gemm_fringe_probe.log).
 bool g_fewrows = true;   // np_sgemm_set_variant(-12): M <= 64 products against a large B go to the tiled kernels as before — no sgemm_fewrows_kernel / sgemm_skinny_kernel (A/B), (-13): back
@@ -2117,18 +2117,18 @@ double estimate_product(size_t M, size_t N, size_t K, bool vec, bool dense_c) {
 int try_peeled(size_t M, size_t N, size_t K, const float *A, const float *B, float *C) {
     if (!g_peel || g_variant != 0 || g_progress.counters || (g_peel == 1 && 2.0 * (double)M * (double)N * (double)K < 2e10)) return 1;
     const size_t r = M % 256, c = N % 128;
-    const size_t m_cut = (r && r <= 8 && M > 2048) ? M - r : M, n_cut = (c && c <= 2 && N > 2048) ? N - c : N;
+    const size_t m_cut = (r && r <= 32 && M > 2048) ? M - r : M, n_cut = (c && c <= 2 && N > 2048) ? N - c : N;
     if (m_cut == M && n_cut == N) return 1;
     const bool aligned = aligned16(A) && aligned16(B);
     const bool vec_full = K % 4 == 0 && N % 4 == 0 && aligned;
     const double t_full = estimate_product(M, N, K, vec_full, true);
-    double best = g_peel == 2 ? 1e300 : 0.97 * t_full;
+    double best = g_peel == 2 ? 1e300 : 0.985 * t_full;   // (the model is ~5 % pessimistic about the peeled form: 5121^3 modelled 0.967, measured 0.93)
     size_t M0 = M, N0 = N;
     for (int pick = 1; pick < 4; ++pick) {   // rows only, columns only, both
         const size_t m0 = (pick & 1) ? m_cut : M, n0 = (pick & 2) ? n_cut : N;
         if ((m0 == M && (pick & 1)) || (n0 == N && (pick & 2))) continue;
         double t = estimate_product(m0, n0, K, vec_full, n0 == N);
-        if (m0 != M) t += (double)K * (double)N * 4.0 / 4.5e12 + 6e-6;   // sgemm_fewrows_kernel + its fold
+        if (m0 != M) t += (double)K * (double)N * 4.0 / (M - m0 <= 8 ? 4.5e12 : 3.6e12) + 6e-6;   // sgemm_fewrows_kernel (<= 8 rows) / sgemm_skinny_kernel + the fold
         if (n0 != N) t += (double)m0 * (double)K * 4.0 / (N - n0 == 1 ? 5e12 : 3e12) + 10e-6;   // sgemv_kernel / the MFMA thin kernel, + the two column copies
         if (t < best) { best = t; M0 = m0; N0 = n0; }
     }

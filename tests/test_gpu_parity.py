@@ -724,10 +724,11 @@ def test_matmul_few_rows(mnk, hip, oracle):
     assert (np.abs(tiled.astype(np.float64) - got) / scale).max() <= 2e-6
 
 
-@pytest.mark.parametrize("mnk", [(2305, 2178, 77), (2049, 2304, 100), (2304, 2049, 64), (2312, 2050, 33), (4097, 4097, 600)])
+@pytest.mark.parametrize("mnk", [(2305, 2178, 77), (2049, 2304, 100), (2304, 2049, 64), (2312, 2050, 33), (4097, 4097, 600),
+                                 (2320, 4100, 4100), (2336, 4096, 4097)])
 @pytest.mark.parametrize("mode", ["forced", "default"])
 def test_matmul_peeled_edges(mnk, mode, hip):
-    """A thin ragged edge (M % 256 <= 8 rows, N % 128 <= 2 columns) of a large product is peeled off: whole tiles for
+    """A thin ragged edge (M % 256 <= 32 rows, N % 128 <= 2 columns) of a large product is peeled off: whole tiles for
     the main block — C and B addressed as windows of the full matrices — and thin products for the edges (try_peeled,
     np_sgemm.hip).  Forced (variant -11) on shapes the model would leave alone, and the default on one it takes;
     fp64 bar, a canary frame around C, agreement with the unpeeled product (-9)."""

@@ -39,7 +39,7 @@ for (m, n, k) in ([] if os.environ.get('NP_SWEEP_PEEL') else shapes):
     a.free(); b.free(); c.free()
 if os.environ.get('NP_SWEEP_PEEL'):   # thin ragged edges: the whole product (-9) / the edges peeled off whenever thin enough (-11) / default (-10)
     for (m, n, k) in [(4097,)*3, (4097, 4096, 4096), (4096, 4097, 4096), (4098, 4098, 4098), (4104, 4097, 4097), (2049,)*3, (3073,)*3, (5121,)*3, (6145,)*3,
-                      (8193,)*3, (8200, 8193, 8192), (4097, 4097, 1024), (2305, 8193, 4096)]:
+                      (8193,)*3, (8200, 8193, 8192), (4097, 4097, 1024), (2305, 8193, 4096), (4112, 4096, 4096), (4128, 4097, 4097), (4120, 8192, 4096)]:
         a = D.DeviceArray((m, k)); b = D.DeviceArray((k, n)); c = D.DeviceArray((m, n))
         D.fill(a, 0.5); D.fill(b, 0.25)
         D.unary("sin", a, out=a); D.unary("cos", b, out=b)
