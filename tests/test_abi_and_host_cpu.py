@@ -202,6 +202,15 @@ def test_tuning_knobs_validate_their_argument_without_a_device():
     for ok in (0, 1, 2):
         assert lib.np_runtime_set_variant(ok) == 0
     assert lib.np_select_last_path(None) != 0      # null output: refused before any device call
+    # the GEMM planner's switches are setters too (A/B partners of the default forms): accepted and restored
+    for code in (-4, -5, -2, -6, -8, -7, -9, -11, -10, -12, -13, -3, -2, 0):
+        assert lib.np_sgemm_set_variant(code) == 0
+    assert lib.np_sgemm_set_variant(1000) != 0 and b"tuning builds" in lib.np_last_error()      # ablations: tuning builds only
+    for code in (9000, 0):
+        assert lib.np_elementwise_set_variant(code) == 0
+    # a piece larger than the batch it claims to belong to: refused before any device call
+    assert lib.np_sgemm_strided_batched_piece(3, 2, 8, 8, 8, None, 64, None, 64, None, 64) != 0
+    assert b"a piece of 3 matrices of a batch of 2" in lib.np_last_error()
 
 
 def test_comm_entry_points_without_a_communicator_or_device():
