@@ -427,11 +427,17 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
 
 /* How the communicator orders its two streams and issues the sharded GEMM (tuning / A-B; np_comm.hip):
  *   0  default: device-side flags (a one-lane kernel publishes a sequence number on the producing stream, a one-lane
- *      kernel on the consuming stream waits for it) and ONE progress-reporting GEMM launch per slab — the transfer of
- *      piece c is released by the GEMM's own tile counter.  Falls back to HIP events by itself if the self-test at
- *      np_comm_init finds that flags do not get through (both streams on one hardware queue).
+ *      kernel on the consuming stream waits for it).  On a one-rank communicator the slab is ONE progress-reporting
+ *      GEMM launch (piece c's transfer is released by the GEMM's own tile counter); with peers it is one GEMM launch
+ *      per piece, a kernel boundary behind every piece — the single launch has only ever run on one GPU, so with
+ *      world > 1 it is opt-in (3).  Falls back to HIP events by itself if the self-test at np_comm_init finds that
+ *      flags do not get through (both streams on one hardware queue).
  *   1  HIP events (hipEventRecord + hipStreamWaitEvent) and one GEMM launch per piece
  *   2  device-side flags, one GEMM launch per piece
+ *   3  device-side flags, ONE progress-reporting GEMM launch per slab at any world size
+ * A device-side wait for this GPU's own work gives up after 60 s and raises the process's device-error word: the next
+ * np_sync / np_memcpy_d2h / host-result call / np_comm_* call returns NP_ERR_DEVICE.  A wait for transfers (which depend on
+ * other ranks) never gives up by itself — same as the RCCL kernel it waits for; np_comm_destroy releases it after 30 s.
  * np_comm_sync_mode: 1 = flags in use, 0 = events, -1 = no communicator. */
 int np_comm_set_variant(int variant);
 int np_comm_sync_mode(void);
@@ -465,6 +471,10 @@ int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 12
 int np_select_set_variant(int variant);   /* order statistics: 0 = plain three passes only (no bracket path, no one-workgroup kernel), 1 = default (n >= 2^26), else the smallest n that takes it */
 int np_select_last_path(int *path);       /* tests / tools: 1 if the last selection ran over the bracket's copied keys, 0 if over the array, 2 if in the one-workgroup kernel (synchronises) */
 int np_reduce_set_variant(int variant);   /* streaming reductions, first pass: workgroups per CU (0 = default) */
+/* testing: a one-lane kernel on the library stream raises `bits` in the process's device-error word — what a device-side wait
+ * that gives up does (1 = a stream-ordering wait of np_comm, 2 = a stream-K finisher).  The next np_sync / np_memcpy_d2h /
+ * host-result call / np_comm_* call returns NP_ERR_DEVICE once, and clears the word. */
+int np_debug_raise_device_error(unsigned bits);
 
 #ifdef __cplusplus
 }

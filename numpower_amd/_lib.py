@@ -130,6 +130,7 @@ PROTOTYPES = {
     "np_select_set_variant": (C.c_int, [C.c_int]),
     "np_runtime_set_variant": (C.c_int, [C.c_int]),
     "np_select_last_path": (C.c_int, [C.POINTER(C.c_int)]),
+    "np_debug_raise_device_error": (C.c_int, [C.c_uint]),
 }
 
 

@@ -21,13 +21,26 @@
 // on this platform (profiles/r03/chunk_overhead.log: 8 pieces 1.05 -> 1.51 ms per slab, GPU idle in between) — more
 // than the transfer it is supposed to hide.  So the order is kept on the device instead: a one-lane kernel on the
 // producing stream publishes a sequence number (flag_set_kernel), a one-lane kernel on the consuming stream spins on it
-// (flag_wait_kernel: s_sleep between device-scope acquire loads, gives up after a time-out and raises a host-visible
-// error word instead of hanging the queue).  The sharded GEMM goes one step further: ONE launch computes the whole
+// (flag_wait_kernel: s_sleep between device-scope acquire loads).  Which waits may give up: a wait whose producer is THIS
+// GPU's own work (the communication stream waiting for the library stream's GEMM) is bounded — it gives up after a
+// time-out and raises the process's device-error word (np_internal.h), which np_sync, np_memcpy_d2h, the host-result
+// calls and every np_comm_* entry point turn into NP_ERR_DEVICE.  The opposite direction — the library stream waiting
+// for transfers to be delivered — depends on OTHER ranks (skew, RCCL's lazy connect, a peer that is minutes late) and
+// is NOT bounded, exactly like the RCCL kernel it waits for and like the hipStreamWaitEvent it replaces: a result that
+// has not been gathered is never handed to the caller as if it had.  The host can still release such a wait
+// (np_comm_destroy raises the abort word it polls).  The sharded GEMM goes one step further: ONE launch computes the whole
 // slab and its workgroups count finished tiles per piece (GemmArgs::progress, np_sgemm.hip); the wait kernel in front
 // of piece c's transfer releases it when the count is complete — no launch per piece, no host in the loop.  Both
 // need the two streams to sit on different hardware queues (they do: the communication stream is created at high
 // priority); np_comm_init proves it with a self-test and falls back to HIP events if the flag does not come through
 // (np_comm_set_variant(1) forces the event form, for A/B).
+//
+// What has and has not run on hardware.  Everything here has run on ONE GPU (world 1, plus RCCL loopback send/recv).  The
+// progress-reporting single launch relies on memory-side (sc1) stores of C being visible to the RCCL kernel that the
+// wait kernel releases, without a kernel boundary in between; that is proven on one device only, so with world > 1 the
+// default is the form with a kernel boundary behind every piece (one GEMM launch per piece + flag_set_kernel, variant
+// 2's behaviour).  np_comm_set_variant(3) asks for the single launch at any world size (bench.py times it as its own
+// leg, with a parity check behind it, so the first multi-GPU run validates or refutes it).
 //
 // Rendezvous: rank 0 creates the ncclUniqueId and hands it to the other ranks
 //   "tcp://host:port"  rank 0 listens on host:port; a peer connects, says who it is (magic + rank), and gets the
@@ -94,7 +107,7 @@ struct Comm {
     // device-side ordering (see the header comment)
     static constexpr int kMaxPieces = 64;
     unsigned *flags = nullptr;           // device: [0] produced sequence, [1] drained sequence, [8 .. 8 + kMaxPieces) tile counters (zero between calls)
-    unsigned *host_error = nullptr;      // pinned, device-visible: set by a wait kernel that gave up
+    unsigned *host_error = nullptr;      // pinned, device-visible, 2 words: the SELF-TEST's error / abort words (real waits use np::device_error_word())
     unsigned produced_seq = 0, drained_seq = 0;
     bool use_flags = false;              // false: HIP events (np_comm_set_variant(1), or the self-test failed)
     hipStream_t flags_ok_for = nullptr;  // the library stream the self-test passed for
@@ -104,7 +117,10 @@ struct Comm {
     size_t loopback_bytes = 0;
 };
 
-int g_sync_variant = 0;   // np_comm_set_variant: 0 = device-side flags where they work, 1 = HIP events only, 2 = flags but one GEMM launch per piece
+// np_comm_set_variant: 0 = device-side flags where they work; ONE progress-reporting GEMM launch on a one-rank communicator,
+// one launch per piece when there are peers (see the header), 1 = HIP events only, 2 = flags, one GEMM launch per piece,
+// 3 = flags, one progress-reporting launch whatever the world size
+int g_sync_variant = 0;
 
 Comm g_comm;
 
@@ -290,7 +306,8 @@ int exchange_file(const std::string &path, int rank, ncclUniqueId &id, double ti
 
 // ---- the communication stream ----
 
-constexpr unsigned long long kWaitTimeoutTicks = 60ull * 100000000ull;   // 60 s of the 100 MHz wall clock
+constexpr unsigned long long kWaitTimeoutTicks = 60ull * 100000000ull;   // 60 s of the 100 MHz wall clock: waits for THIS GPU's own work
+constexpr unsigned long long kWaitForPeers = 0ull;                       // no time-out: waits for transfers (other ranks decide when they end)
 constexpr unsigned long long kSelfTestTicks = 20000000ull;               // 200 ms (only ever spent when the test FAILS)
 
 __global__ void flag_set_kernel(unsigned *flag, unsigned value) {
@@ -299,16 +316,25 @@ __global__ void flag_set_kernel(unsigned *flag, unsigned value) {
 }
 
 // Spins until *flag has reached `target` (sequence numbers: compared as a signed difference, so wrap-around is fine;
-// tile counters: plain >=).  One lane; s_sleep keeps it off the issue ports of the CU it sits on.
-__global__ void flag_wait_kernel(const unsigned *flag, unsigned target, unsigned long long timeout_ticks, unsigned *host_error) {
+// tile counters: plain >=).  One lane; s_sleep keeps it off the issue ports of the CU it sits on.  timeout_ticks != 0:
+// gives up after that long, ORs error_bit into error_word[0] (reported by the host, np::check_device_error) and lets the
+// queue drain.  timeout_ticks == 0: never gives up by itself — only when the host raises error_word[1] (abort).
+__global__ void flag_wait_kernel(const unsigned *flag, unsigned target, unsigned long long timeout_ticks, unsigned *error_word,
+                                 unsigned error_bit) {
     const unsigned long long t0 = wall_clock64();
     for (unsigned spins = 0;; ++spins) {
         const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // memory-side; the next kernel on this stream starts with an acquire
         if ((int)(v - target) >= 0) return;
         __builtin_amdgcn_s_sleep(16);
-        if ((spins & 63u) == 63u && wall_clock64() - t0 > timeout_ticks) {
-            __hip_atomic_store(host_error, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;   // give up rather than hang the queue: the host reports it at its next np_comm_* call
+        if (timeout_ticks) {
+            if ((spins & 63u) == 63u && wall_clock64() - t0 > timeout_ticks) {
+                __hip_atomic_fetch_or(error_word, error_bit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;   // give up rather than hang the queue: the host reports it (np_sync, np_memcpy_d2h, np_comm_*)
+            }
+        } else if ((spins & 4095u) == 4095u &&   // one read over the host link every few milliseconds
+                   __hip_atomic_load(error_word + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+            __hip_atomic_fetch_or(error_word, error_bit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;   // the host asked every wait to end (np_comm_destroy): what it guarded is incomplete, and reported as such
         }
     }
 }
@@ -323,13 +349,14 @@ __global__ void finish_kernel(unsigned *counters, int n, unsigned *flag, unsigne
     if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-int stream_follows(hipStream_t consumer, hipStream_t producer, unsigned *flag, unsigned &seq, hipEvent_t event) {
+int stream_follows(hipStream_t consumer, hipStream_t producer, unsigned *flag, unsigned &seq, hipEvent_t event,
+                   unsigned long long timeout_ticks) {
     Comm &c = g_comm;
     if (c.use_flags) {
         ++seq;
         flag_set_kernel<<<1, 1, 0, producer>>>(flag, seq);
         NP_LAUNCH_CHECK("flag_set_kernel");
-        flag_wait_kernel<<<1, 1, 0, consumer>>>(flag, seq, kWaitTimeoutTicks, c.host_error);
+        flag_wait_kernel<<<1, 1, 0, consumer>>>(flag, seq, timeout_ticks, np::device_error_word(), np::kErrCommWait);
         NP_LAUNCH_CHECK("flag_wait_kernel");
         return NP_OK;
     }
@@ -345,18 +372,18 @@ int flags_self_test(hipStream_t compute) {
     Comm &c = g_comm;
     c.use_flags = false;
     c.flags_ok_for = compute;
-    if (g_sync_variant == 1 || !c.flags || !c.host_error) return NP_OK;
+    if (g_sync_variant == 1 || !c.flags || !c.host_error || !np::device_error_word()) return NP_OK;
     // both kernels once with nothing to wait for: their first launch loads code on the host side, and that must not eat
     // into the budget of the wait that is about to spin on the device
     flag_set_kernel<<<1, 1, 0, compute>>>(c.flags + 2, 1u);
     NP_LAUNCH_CHECK("flag_set_kernel");
-    flag_wait_kernel<<<1, 1, 0, c.stream>>>(c.flags + 3, 0u, kSelfTestTicks, c.host_error);
+    flag_wait_kernel<<<1, 1, 0, c.stream>>>(c.flags + 3, 0u, kSelfTestTicks, c.host_error, 1u);
     NP_LAUNCH_CHECK("flag_wait_kernel");
     NP_HIP_CHECK(hipStreamSynchronize(compute));
     NP_HIP_CHECK(hipStreamSynchronize(c.stream));
     *(volatile unsigned *)c.host_error = 0;
     const unsigned seq = ++c.produced_seq;
-    flag_wait_kernel<<<1, 1, 0, c.stream>>>(c.flags, seq, kSelfTestTicks, c.host_error);
+    flag_wait_kernel<<<1, 1, 0, c.stream>>>(c.flags, seq, kSelfTestTicks, c.host_error, 1u);
     NP_LAUNCH_CHECK("flag_wait_kernel");
     flag_set_kernel<<<1, 1, 0, compute>>>(c.flags, seq);
     NP_LAUNCH_CHECK("flag_set_kernel");
@@ -400,8 +427,8 @@ int create_stream_objects() {
     const size_t flag_bytes = sizeof(unsigned) * (8 + Comm::kMaxPieces);
     NP_HIP_CHECK(hipMalloc((void **)&g_comm.flags, flag_bytes));
     NP_HIP_CHECK(hipMemset(g_comm.flags, 0, flag_bytes));
-    NP_HIP_CHECK(hipHostMalloc((void **)&g_comm.host_error, sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable));
-    *g_comm.host_error = 0;
+    NP_HIP_CHECK(hipHostMalloc((void **)&g_comm.host_error, 2 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable));
+    g_comm.host_error[0] = g_comm.host_error[1] = 0;
     g_comm.produced_seq = g_comm.drained_seq = 0;
     return flags_self_test(np::stream());
 }
@@ -409,7 +436,9 @@ int create_stream_objects() {
 // The communication stream picks up everything the library stream has been given so far.
 int comm_stream_follows_compute() {
     Comm &c = g_comm;
-    return stream_follows(c.stream, np::stream(), c.flags + 0, c.produced_seq, c.produced[c.next_event++ % Comm::kEvents]);
+    // the producer is this GPU's own stream: a bounded wait
+    return stream_follows(c.stream, np::stream(), c.flags + 0, c.produced_seq, c.produced[c.next_event++ % Comm::kEvents],
+                          kWaitTimeoutTicks);
 }
 
 // ---- the addressing of the exchange, as pure functions (shared by the real path and by np_comm_debug_plan, which lets a
@@ -477,11 +506,7 @@ int need_comm(const char *who) {
     if (hipGetDevice(&cur) != hipSuccess || cur != g_comm.device)
         return np::fail(NP_ERR_INVALID, "%s: the communicator belongs to device %d but the library is on device %d "
                                         "(np_set_device back, or np_comm_destroy and np_comm_init again)", who, g_comm.device, cur);
-    if (g_comm.host_error && *(volatile unsigned *)g_comm.host_error) {
-        *(volatile unsigned *)g_comm.host_error = 0;
-        return np::fail(NP_ERR_DEVICE, "%s: an earlier device-side wait between the library and the communication stream "
-                                       "timed out (its producer never ran); results since then are incomplete", who);
-    }
+    if (int rc = np::check_device_error(who)) return rc;   // an earlier device-side wait gave up: say so before anything else is built on it
     // the caller may have moved the library onto another stream (np_set_stream): prove the flags again for that one
     if (g_comm.flags_ok_for != np::stream()) return flags_self_test(np::stream());
     return NP_OK;
@@ -588,15 +613,18 @@ int np_allgather_async(const void *dev_send, void *dev_recv_base, size_t bytes, 
 int np_comm_wait(void) {
     if (int rc = need_comm("np_comm_wait")) return rc;
     if (!g_comm.pending) return NP_OK;
-    if (int rc = stream_follows(np::stream(), g_comm.stream, g_comm.flags + 1, g_comm.drained_seq, g_comm.drained)) return rc;
+    // the producer is the communication stream, i.e. transfers other ranks take part in: never given up on
+    if (int rc = stream_follows(np::stream(), g_comm.stream, g_comm.flags + 1, g_comm.drained_seq, g_comm.drained, kWaitForPeers))
+        return rc;
     g_comm.pending = false;
     return NP_OK;
 }
 
 int np_comm_set_variant(int variant) {
-    if (variant < 0 || variant > 2)
-        return np::fail(NP_ERR_INVALID, "np_comm_set_variant: 0 = device-side flags + one progress-reporting GEMM launch (default), "
-                                        "1 = HIP events, one GEMM launch per piece, 2 = device-side flags, one GEMM launch per piece");
+    if (variant < 0 || variant > 3)
+        return np::fail(NP_ERR_INVALID, "np_comm_set_variant: 0 = device-side flags; one progress-reporting GEMM launch without peers, one "
+                                        "launch per piece with peers (default), 1 = HIP events, one GEMM launch per piece, 2 = device-side "
+                                        "flags, one GEMM launch per piece, 3 = device-side flags, one progress-reporting launch at any world size");
     g_sync_variant = variant;
     if (g_comm.comm) return flags_self_test(np::stream());
     return NP_OK;
@@ -646,7 +674,8 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
     const size_t mat = M * N, slab_elems = slab * mat;
     float *mine = C_full + (size_t)g_comm.rank * slab_elems;
     Comm &cm = g_comm;
-    if (cm.use_flags && g_sync_variant == 0 && chunks <= Comm::kMaxPieces) {
+    const bool single_launch = g_sync_variant == 3 || (g_sync_variant == 0 && cm.world == 1);   // (see the header: with peers only on request)
+    if (cm.use_flags && single_launch && chunks <= Comm::kMaxPieces) {
         // ONE launch for the whole slab; its workgroups count finished tiles per piece in cm.flags[8 + c] (zero here:
         // the previous call's last act on the communication stream was to clear them, and np_comm_wait ordered this
         // call's GEMM behind that)
@@ -660,7 +689,8 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
             for (int c = 0; c < chunks && failed == NP_OK; ++c) {
                 size_t lo = 0, count = 0;
                 if ((failed = np_comm_piece(slab, chunks, c, &lo, &count)) != NP_OK) break;
-                flag_wait_kernel<<<1, 1, 0, cm.stream>>>(counters + c, (unsigned)(count * tiles), kWaitTimeoutTicks, cm.host_error);
+                flag_wait_kernel<<<1, 1, 0, cm.stream>>>(counters + c, (unsigned)(count * tiles), kWaitTimeoutTicks,   // producer: this GPU's GEMM
+                                                         np::device_error_word(), np::kErrCommWait);
                 if (hipGetLastError() != hipSuccess) {
                     failed = np::fail(NP_ERR_DEVICE, "launch of flag_wait_kernel failed");
                     break;
@@ -681,7 +711,8 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
             ++cm.drained_seq;
             finish_kernel<<<1, 64, 0, cm.stream>>>(counters, chunks, cm.flags + 1, cm.drained_seq);
             NP_LAUNCH_CHECK("finish_kernel");
-            flag_wait_kernel<<<1, 1, 0, np::stream()>>>(cm.flags + 1, cm.drained_seq, kWaitTimeoutTicks, cm.host_error);
+            flag_wait_kernel<<<1, 1, 0, np::stream()>>>(cm.flags + 1, cm.drained_seq, kWaitForPeers,   // producer: transfers with peers
+                                                        np::device_error_word(), np::kErrCommWait);
             NP_LAUNCH_CHECK("flag_wait_kernel");
             cm.pending = false;
             return NP_OK;
@@ -772,8 +803,22 @@ int np_comm_barrier(void) {
 
 int np_comm_destroy(void) {
     if (!g_comm.comm) return NP_OK;
+    // a wait for peers that is still spinning (a rank that never arrived) is released by the abort word; what it guarded
+    // is reported as incomplete by the next np_sync / np_memcpy_d2h
+    // — after a grace period: a gather that is merely still travelling is waited for, as before
+    unsigned *err = np::device_error_word();
+    const double give_up = now_s() + 30.0;
+    while (err && hipStreamQuery(np::stream()) == hipErrorNotReady) {
+        if (now_s() > give_up) {
+            __atomic_store_n(err + 1, 1u, __ATOMIC_RELEASE);
+            break;
+        }
+        usleep(200);
+    }
+    (void)hipGetLastError();
     if (g_comm.stream) (void)hipStreamSynchronize(g_comm.stream);
     (void)hipStreamSynchronize(np::stream());
+    if (err) __atomic_store_n(err + 1, 0u, __ATOMIC_RELEASE);
     const ncclResult_t rc = g_comm.api.CommDestroy(g_comm.comm);
     g_comm.comm = nullptr;
     destroy_stream_objects();

@@ -39,6 +39,18 @@ struct ResultCall {
 unsigned *next_ticket();
 // `count` consecutive zeroed counters (count <= 256), one per independent fold of the same launch
 unsigned *next_tickets(unsigned count);
+// Stream-K's flag array of the current device (np_sgemm.hip): kStreamKFlagCount zeroed counters allocated by np_init — never
+// lazily, the first stream-K launch may sit inside a stream capture (nullptr + error set on failure).
+constexpr unsigned kStreamKFlagCount = 1024;
+unsigned *streamk_flags();
+// The process's device-error word (pinned host memory, device-visible; nullptr before np_init).  Word [0]: a kernel whose
+// device-side wait gives up ORs one of the kErr* bits in with a system-scope atomic; np_sync, np_memcpy_d2h, the
+// host-result calls and every np_comm_* entry point turn a non-zero word into NP_ERR_DEVICE (check_device_error clears it).
+// Word [1]: the host's ABORT request — an unbounded device-side wait (np_comm.hip: the library stream waiting for transfers
+// that depend on other ranks) polls it and returns when it is non-zero (np_comm_destroy sets it).
+constexpr unsigned kErrCommWait = 1u, kErrStreamK = 2u;
+unsigned *device_error_word();
+int check_device_error(const char *who);
 // Largest first-pass grid whose partials are folded by its own last workgroup rather than by a second kernel.  The
 // ticket is one hot address (~20 ns per workgroup at the memory side) and every workgroup waits a round trip for its
 // own: with 2049 workgroups the in-kernel fold LOST 5 us on a 63 us sum of 10^8 floats; on small grids it saves the

@@ -40,6 +40,7 @@ struct DeviceState {
     std::map<size_t, std::vector<FreeBlock>> free_blocks;   // rounded size -> cached blocks of this device
     unsigned *tickets = nullptr;                         // ring of zeroed device counters (np::next_ticket)
     unsigned ticket_seq = 0;
+    unsigned *streamk_flags = nullptr;                   // np_sgemm.hip's stream-K flags (np::streamk_flags), zero between launches
 };
 
 struct Runtime {
@@ -52,6 +53,7 @@ struct Runtime {
     std::unordered_map<void *, Block> live;              // ptr -> rounded size, owning device, offset from the hipMalloc base
     unsigned large_seq = 0;                              // running count of large blocks obtained from the driver
     float *slots = nullptr;                              // pinned host-result slots (np::ResultCall)
+    unsigned *error_word = nullptr;                      // pinned, device-visible: np::device_error_word()
     int wait_mode = 2;                                   // np_runtime_set_variant: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag,
                                                          // 2 = spin on the result slots themselves (armed with a sentinel)
     uint32_t wait_seq = 0;
@@ -156,7 +158,10 @@ ResultCall::~ResultCall() {
     rt().armed = 0;
     rt().result_mu.unlock();
 }
-int ResultCall::wait() { return result_wait(); }
+int ResultCall::wait() {
+    if (int rc = result_wait()) return rc;
+    return check_device_error("host result");
+}
 
 float *result_slots(int count) {
     Runtime &r = rt();
@@ -199,6 +204,60 @@ static int alloc_tickets_locked(DeviceState &d) {
     }
     d.tickets = (unsigned *)p;   // one ring per device this process has used
     return NP_OK;
+}
+
+// ... and so does the stream-K flag array (np_sgemm.hip): a first stream-K launch inside np_graph_begin .. np_graph_end
+// must not meet a hipMalloc + synchronous hipMemset (the reason the ticket ring moved here)
+static int alloc_streamk_flags_locked(DeviceState &d) {
+    if (d.streamk_flags) return NP_OK;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, kStreamKFlagCount * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(p, 0, kStreamKFlagCount * sizeof(unsigned));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(NP_ERR_ALLOC, "stream-K flags: %s", hipGetErrorString(e));
+    }
+    d.streamk_flags = (unsigned *)p;
+    return NP_OK;
+}
+
+unsigned *streamk_flags() {
+    Runtime &r = rt();
+    std::lock_guard<std::mutex> lk(r.mu);
+    DeviceState &d = r.cur();
+    if (alloc_streamk_flags_locked(d) != NP_OK) return nullptr;   // (np_init did this already; a device first used some other way)
+    return d.streamk_flags;
+}
+
+// The process's device-error word: pinned host memory every kernel of every device can write.  A device-side wait that
+// gives up (np_comm.hip's flag_wait_kernel, the stream-K finisher of np_sgemm.hip) ORs its bit in; the host reports it at
+// the next point where a caller could otherwise consume a wrong result — np_sync, np_memcpy_d2h, a host-result call,
+// any np_comm_* entry point (check_device_error) — instead of returning NP_OK with garbage.
+static int alloc_error_word_locked(Runtime &r) {
+    if (r.error_word) return NP_OK;
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(NP_ERR_ALLOC, "pinned error word: %s", hipGetErrorString(e));
+    }
+    r.error_word = (unsigned *)p;
+    r.error_word[0] = r.error_word[1] = 0;
+    return NP_OK;
+}
+
+unsigned *device_error_word() { return rt().error_word; }
+
+int check_device_error(const char *who) {
+    Runtime &r = rt();
+    if (!r.error_word) return NP_OK;
+    const unsigned bits = __atomic_exchange_n(r.error_word, 0u, __ATOMIC_ACQ_REL);
+    if (!bits) return NP_OK;
+    return fail(NP_ERR_DEVICE, "%s: a device-side wait gave up before this point (%s%s%s): results produced since the last "
+                               "successful np_sync are incomplete and must be discarded", who,
+                bits & kErrCommWait ? "a stream-ordering wait of np_comm timed out" : "",
+                (bits & kErrCommWait) && (bits & kErrStreamK) ? "; " : "",
+                bits & kErrStreamK ? "a stream-K finisher never saw its peers' partial tiles" : "");
 }
 
 unsigned *next_ticket() { return next_tickets(1); }
@@ -308,6 +367,8 @@ int np_init(int device) {
         NP_HIP_CHECK(hipStreamCreateWithFlags(&d.own_stream, hipStreamNonBlocking));
         d.cur_stream = d.own_stream;
         if (int rc = np::alloc_tickets_locked(d)) return rc;
+        if (int rc = np::alloc_streamk_flags_locked(d)) return rc;
+        if (int rc = np::alloc_error_word_locked(r)) return rc;
         d.inited = true;
     }
     // Switching devices tears nothing down: the old device keeps its stream (work in flight there completes), its
@@ -331,6 +392,18 @@ int np_runtime_set_variant(int variant) {
 int np_sync(void) {
     if (int rc = np::ensure_init()) return rc;
     NP_HIP_CHECK(hipStreamSynchronize(rt().cur().cur_stream));
+    return np::check_device_error("np_sync");
+}
+
+__global__ void raise_error_kernel(unsigned *word, unsigned bits) {
+    __hip_atomic_fetch_or(word, bits, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int np_debug_raise_device_error(unsigned bits) {
+    if (int rc = np::ensure_init()) return rc;
+    if (!np::device_error_word()) return np::fail(NP_ERR_DEVICE, "np_debug_raise_device_error: no error word");
+    raise_error_kernel<<<1, 1, 0, np::stream()>>>(np::device_error_word(), bits);
+    NP_LAUNCH_CHECK("raise_error_kernel");
     return NP_OK;
 }
 
@@ -517,7 +590,7 @@ int np_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes) {
     if (int rc = np::ensure_init()) return rc;
     NP_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, np::stream()));
     NP_HIP_CHECK(hipStreamSynchronize(np::stream()));
-    return NP_OK;
+    return np::check_device_error("np_memcpy_d2h");   // a read-back of a result a device-side wait gave up on is an error, not data
 }
 
 int np_memcpy_d2d(void *dev_dst, const void *dev_src, size_t bytes) {

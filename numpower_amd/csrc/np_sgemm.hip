@@ -808,6 +808,7 @@ struct StreamKArgs {
     unsigned seq;
     unsigned nk;            // k-tiles per tile
     unsigned long long iters_total;   // tiles * nk
+    unsigned *error_word;   // np::device_error_word(): a finisher whose poll budget runs out ORs kErrStreamK in (reported at np_sync)
 };
 
 template <bool EDGE, bool KTAIL, bool PRIO = false>
@@ -845,9 +846,17 @@ __global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, Strea
             // one lane per flag (they were posted long ago: polled one after the other, each costs a round trip to memory)
             // (bounded: the schedule guarantees the flags — 2^26 polls, s_sleep between them, are tens of seconds: a wait
             // that long can only be a fault elsewhere, and a wrong tile is a lesser evil than a queue that never drains)
-            for (unsigned p = (unsigned)w + 1 + threadIdx.x; p <= (unsigned)w_last; p += 256)
-                for (unsigned spins = 0; np::dev::coherent_load(sk.flags + p) != sk.seq && spins < (1u << 26); ++spins)
+            // — and NOT a silent one: the lane that gives up raises the process's device-error word, np_sync / the read-back
+            // of C then return NP_ERR_DEVICE instead of NP_OK with a corrupt tile)
+            for (unsigned p = (unsigned)w + 1 + threadIdx.x; p <= (unsigned)w_last; p += 256) {
+                unsigned spins = 0;
+                while (np::dev::coherent_load(sk.flags + p) != sk.seq && spins < (1u << 26)) {
                     __builtin_amdgcn_s_sleep(8);
+                    ++spins;
+                }
+                if (spins == (1u << 26) && sk.error_word)
+                    __hip_atomic_fetch_or(sk.error_word, np::kErrStreamK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             __syncthreads();   // (also: every wave is done with the K loop's LDS before the fold's DMAs land in it)
         }
         const unsigned n_partials = (unsigned)(w_last - w);
@@ -1619,15 +1628,16 @@ unsigned long long *g_probe = nullptr;
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
-// What np::sgemm_batched_with_progress asks of the ONE launch it makes (host-side plumbing; the entry points are not
-// re-entrant across threads for this request, like the communicator that is its only caller).
+// What np::sgemm_batched_with_progress asks of the ONE launch it makes (host-side plumbing).  Per host thread: an np_sgemm
+// on another thread while the communicator's thread is inside np_sgemm_strided_batched_allgather must not pick up that
+// call's progress counters (it would release transfers early and switch its own C to memory-side stores).
 struct ProgressRequest {
     unsigned *counters = nullptr;
     unsigned base = 0, extra = 0;
     unsigned tiles_per_matrix = 0;   // out: written by the launcher that took the request
     unsigned launches = 0;           // out: kernel launches made while the request was active
 };
-ProgressRequest g_progress;
+thread_local ProgressRequest g_progress;
 inline void note_progress_launch(const GemmArgs &g) {
     if (!g.progress) return;
     g_progress.tiles_per_matrix = g.tiles_m * g.tiles_n;
@@ -1831,25 +1841,11 @@ int launch_padded(const GemmArgs &g, const Plan &p, size_t Kp, size_t Np) {
 }
 
 // ---- stream-K launch (sgemm_streamk_kernel) ----
-// Flags live for the life of the process, one array per device, zero between launches: the finisher that consumes
-// workgroup p's partial puts flag[p] back to 0, so a launch leaves them as it found them (and a captured graph can be
-// replayed: nothing in the launch depends on a per-launch sequence number).
-constexpr unsigned kStreamKMaxGrid = 1024;
-unsigned *g_streamk_flags[16] = {};
-
-int streamk_flags(unsigned **flags) {
-    int dev = 0;
-    NP_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return np::fail(NP_ERR_INVALID, "np_sgemm: device %d out of range", dev);
-    if (!g_streamk_flags[dev]) {
-        void *p = nullptr;
-        NP_HIP_CHECK(hipMalloc(&p, kStreamKMaxGrid * sizeof(unsigned)));
-        NP_HIP_CHECK(hipMemset(p, 0, kStreamKMaxGrid * sizeof(unsigned)));
-        g_streamk_flags[dev] = (unsigned *)p;
-    }
-    *flags = g_streamk_flags[dev];
-    return NP_OK;
-}
+// Flags live for the life of the process, one array per device (np_runtime.hip allocates it in np_init, next to the
+// ticket ring: a first stream-K launch inside a stream capture must not meet a hipMalloc), zero between launches: the
+// finisher that consumes workgroup p's partial puts flag[p] back to 0, so a launch leaves them as it found them (and a
+// captured graph can be replayed: nothing in the launch depends on a per-launch sequence number).
+constexpr unsigned kStreamKMaxGrid = np::kStreamKFlagCount;
 
 // Modelled time of the stream-K form of an M x N x K product (one matrix; rows float4-loadable), or a huge number
 // where it does not apply, and the grid to run it on: two workgroups per CU (they share the matrix pipe at the rate
@@ -1894,7 +1890,9 @@ int launch_streamk(GemmArgs g, unsigned G) {
     sk.iters_total = (unsigned long long)g.tiles_m * g.tiles_n * sk.nk;
     sk.seq = 1;
     if (sk.iters_total < G) G = (unsigned)sk.iters_total;
-    if (int rc = streamk_flags(&sk.flags)) return rc;
+    sk.flags = np::streamk_flags();
+    if (!sk.flags) return NP_ERR_ALLOC;   // (message set by the runtime)
+    sk.error_word = np::device_error_word();
     np::Scratch ws;
     if (int rc = ws.alloc((size_t)G * 256 * 128 * sizeof(float))) return rc;
     sk.workspace = (float *)ws.ptr;
@@ -1919,7 +1917,7 @@ int launch_streamk(GemmArgs g, unsigned G) {
 // != 0: the matrices being launched are a PIECE of a batch of this many (np_comm's per-piece pipeline): planned as that
 // batch, so that every piece — a single matrix included — runs the kernel configuration the whole batch would have
 // run, and the pipelined result is bit-identical to the one-call form (np::sgemm_batched_piece)
-size_t g_plan_batch = 0;
+thread_local size_t g_plan_batch = 0;   // (per host thread, like g_progress)
 
 int launch_planned(GemmArgs g, size_t launch_batch, bool vec) {
     const size_t M = g.M, N = g.N, K = g.K;

@@ -235,6 +235,6 @@ def test_comm_entry_points_without_a_communicator_or_device():
     assert lib.np_comm_piece(64, 0, 0, C.byref(lo), C.byref(count)) != 0 and b"np_comm_piece" in lib.np_last_error()
     assert lib.np_comm_piece(64, 3, 3, C.byref(lo), C.byref(count)) != 0
     assert lib.np_comm_piece(64, 3, 0, None, C.byref(count)) != 0
-    assert lib.np_comm_set_variant(3) != 0 and b"np_comm_set_variant" in lib.np_last_error()
-    for ok in (1, 2, 0):
+    assert lib.np_comm_set_variant(4) != 0 and b"np_comm_set_variant" in lib.np_last_error()
+    for ok in (1, 2, 3, 0):
         assert lib.np_comm_set_variant(ok) == 0

@@ -74,7 +74,7 @@ def test_sharded_batched_matmul_through_the_c_abi(hip):
     assert (np.abs(got - want) <= 1e-6 * scale).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2], ids=["flags+one-launch", "events", "flags+launch-per-piece"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3], ids=["default", "events", "flags+launch-per-piece", "flags+one-launch"])
 @pytest.mark.parametrize("chunks,mode", [(1, 0), (1, 1), (1, 2), (2, 0), (4, 2), (5, 0), (8, 0), (64, 0)])
 def test_overlapped_sharded_matmul_is_bit_identical(chunks, mode, variant, hip, oracle):
     """np_sgemm_strided_batched_allgather (GEMM pieces on the library stream, each piece's gather on the communication

@@ -37,7 +37,7 @@ WORKER = textwrap.dedent("""
     B = np.stack([synth.uniform((k, n), 800 + i, -1.0, 1.0) for i in range(rank * slab, (rank + 1) * slab)])
     dA, dB = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B)
     results = {}
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         check(lib.np_comm_set_variant(variant))
         for chunks, mode in ((1, 1), (1, 2), (2, 0), (3, 0), (4, 0)):
             full = D.DeviceArray((batch, m, n))
@@ -45,6 +45,21 @@ WORKER = textwrap.dedent("""
             check(lib.np_sgemm_strided_batched_allgather(slab, m, n, k, dA.ptr, m * k, dB.ptr, k * n, full.ptr, chunks, mode))
             results["v%%d_c%%d_m%%d" %% (variant, chunks, mode)] = full.to_host()
             full.free()
+    # matrices large enough for the ONE progress-reporting launch (variant 3: opt-in with peers, np_comm.hip header) — the
+    # form whose cross-device visibility only a run with real peers can prove; variant 0 = one launch per piece here
+    bm = 1024
+    bA = np.stack([synth.uniform((bm, bm), 900 + i, -1.0, 1.0) for i in range(rank * slab, (rank + 1) * slab)])
+    bB = np.stack([synth.uniform((bm, bm), 950 + i, -1.0, 1.0) for i in range(rank * slab, (rank + 1) * slab)])
+    dbA, dbB = D.DeviceArray.from_host(bA), D.DeviceArray.from_host(bB)
+    for variant in (0, 3):
+        check(lib.np_comm_set_variant(variant))
+        for rep in range(3):
+            full = D.DeviceArray((batch, bm, bm))
+            D.fill(full, float("nan"))
+            check(lib.np_sgemm_strided_batched_allgather(slab, bm, bm, bm, dbA.ptr, bm * bm, dbB.ptr, bm * bm, full.ptr, 2, 0))
+            results["big_v%%d_r%%d" %% (variant, rep)] = full.to_host()[:, ::61, ::67].copy()
+            full.free()
+    check(lib.np_comm_set_variant(0))
     check(lib.np_comm_barrier())
     check(lib.np_comm_destroy())
     np.savez(out, **results)
@@ -80,11 +95,22 @@ def test_sharded_matmul_across_real_ranks(tmp_path, oracle):
     B = np.stack([synth.uniform((k, n), 800 + i, -1.0, 1.0) for i in range(batch)])
     ref = np.stack([oracle.matmul(A[i], B[i]) for i in range(batch)])          # the reference form: a loop of 2-D matmuls
     scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
-    first = None
+    bA = np.stack([synth.uniform((1024, 1024), 900 + i, -1.0, 1.0) for i in range(batch)]).astype(np.float64)
+    bB = np.stack([synth.uniform((1024, 1024), 950 + i, -1.0, 1.0) for i in range(batch)]).astype(np.float64)
+    big_ref = (bA @ bB)[:, ::61, ::67]
+    big_scale = (np.abs(bA) @ np.abs(bB))[:, ::61, ::67]
+    first = big_first = None
     for r in range(world):
         got = np.load(tmp_path / ("rank%d.npz" % r))
         for key in got.files:
             x = got[key]
+            if key.startswith("big_"):      # sampled elements of every matrix of the replicated 1024^3 result
+                assert not np.isnan(x).any(), (r, key)
+                assert (np.abs(x - big_ref) <= 1e-6 * big_scale).all(), (r, key)
+                if big_first is None:
+                    big_first = x
+                assert (x.view(np.uint32) == big_first.view(np.uint32)).all(), (r, key)
+                continue
             assert not np.isnan(x).any(), (r, key)
             assert (np.abs(x - ref) <= 1e-5 * scale).all(), (r, key)
             if first is None:

@@ -46,3 +46,31 @@ def test_wait_modes_agree(hip):
     finally:
         _lib.check(lib.np_runtime_set_variant(2))
         a.free(); b.free(); o.free()
+
+
+def test_device_error_word_is_reported_once_at_the_next_sync_point():
+    """A device-side wait that gives up (np_comm's bounded stream-ordering wait, a stream-K finisher whose peers never
+    posted) raises the process's device-error word instead of letting NP_OK travel with a wrong result:
+    np_sync, np_memcpy_d2h and the host-result calls each turn it into NP_ERR_DEVICE — once; the word is clear afterwards."""
+    import ctypes as C
+    from numpower_amd._lib import load
+    lib = load()
+    assert lib.np_init(0) == 0
+    x = np.arange(1024, dtype=np.float32)
+    dev = C.c_void_p()
+    assert lib.np_malloc(C.byref(dev), x.nbytes) == 0
+    assert lib.np_memcpy_h2d(dev, x.ctypes.data, x.nbytes) == 0
+    out = C.c_float(0.0)
+    back = np.empty_like(x)
+    for bits, what, call in (
+            (1, b"np_comm", lambda: lib.np_sync()),
+            (2, b"stream-K", lambda: lib.np_memcpy_d2h(back.ctypes.data, dev, x.nbytes)),
+            (3, b"stream-K", lambda: lib.np_reduce_all(0, dev, 1024, C.byref(out)))):
+        assert lib.np_debug_raise_device_error(bits) == 0
+        assert call() != 0
+        msg = lib.np_last_error()
+        assert b"device-side wait gave up" in msg and what in msg, msg
+        assert call() == 0, lib.np_last_error()          # reported once: the word is clear again
+    assert lib.np_sync() == 0
+    assert (back == x).all() and out.value == float(x.sum())
+    assert lib.np_free(dev) == 0
