@@ -356,6 +356,47 @@ def hbm_case(name, bytes_per_launch, launch, steps, warmup, dist):
     return out
 
 
+def bench_c1(dist: Dist, steps, warmup):
+    """BASELINE config 1 (SURVEY.md 8(d) row C1: "parity + CPU time"): nd::add and nd::sum on 1000 x 1000 fp32.  The
+    reference runs it on the CPU (arithmetics.c:160-278 AVX2 add, :58-71 sequential sum): the oracle's restatement is timed
+    here as that path; beside it the device kernels on resident buffers, and the whole `$a->gpu()` -> op -> `->cpu()`
+    round trip a PHP caller pays for an array this small."""
+    from oracle import oracle
+    from numpower_amd.ndarray import NDArray
+    R = 1000
+    a = synth.uniform((R, R), 1, 0.0, 1.0)
+    b = synth.uniform((R, R), 2, 0.0, 1.0)
+    t_add, _ = cpu_time(lambda: oracle.binary("add", a, b), budget_s=1.5, max_iters=21)
+    t_sum, _ = cpu_time(lambda: oracle.reduce_all("sum", a), budget_s=1.5, max_iters=21)
+    da, db, do = D.DeviceArray.from_host(a), D.DeviceArray.from_host(b), D.DeviceArray((R, R))
+    add = hbm_case("add 1000x1000 (C1)", 12.0 * R * R, lambda: D.binary("add", da, "full", db, "full", 1, R * R, out=do),
+                   steps, warmup, dist)
+    got_add = do.to_host()
+    ssum = hbm_case("sum 1000x1000 (C1)", 4.0 * R * R, lambda: D.reduce_all("sum", da), steps, warmup, dist)
+    got_sum = D.reduce_all("sum", da)
+    want_add = oracle.binary("add", a, b)
+    want64 = float(a.astype(np.float64).sum())
+    ha, hb = NDArray.array(a), NDArray.array(b)
+    (ha.gpu() + hb.gpu()).cpu()             # once untimed: first-use costs are not the round trip
+    t0 = time.perf_counter()
+    res = (ha.gpu() + hb.gpu()).cpu()
+    e2e_add = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    NDArray.sum(ha.gpu())
+    e2e_sum = time.perf_counter() - t0
+    ok = bool((got_add.view(np.uint32) == want_add.view(np.uint32)).all() and (res.numpy() == want_add).all()
+              and abs(got_sum - want64) <= 1e-5 * want64)
+    for d in (da, db, do):
+        d.free()
+    return {"workload": "nd::add + nd::sum 1000x1000 fp32 (BASELINE config 1)",
+            "cpu_add_ms": t_add * 1e3, "cpu_sum_ms": t_sum * 1e3, "cpu_kind": "port (oracle restatement, AVX2, 1 thread)",
+            "gpu_add_kernel_us": add["launch_ms"]["median"] * 1e3, "gpu_sum_call_us": ssum["launch_ms"]["median"] * 1e3,
+            "gpu_add_back_to_back_us": add["ms_per_launch"] * 1e3, "gpu_sum_back_to_back_us": ssum["ms_per_launch"] * 1e3,
+            "end_to_end_gpu_add_cpu_ms": e2e_add * 1e3, "end_to_end_gpu_sum_ms": e2e_sum * 1e3,
+            "sum_rel_err_vs_fp64": abs(got_sum - want64) / want64,
+            "cpu_sum_rel_err_vs_fp64": abs(float(oracle.reduce_all("sum", a)) - want64) / want64, "parity_ok": ok}
+
+
 def bench_extras(dist: Dist, steps, warmup):
     """The HBM-bound configs (C3a/b/c, C4) at BASELINE.json's sizes, N = 1 only."""
     from oracle import oracle
@@ -607,38 +648,87 @@ def bench_extras(dist: Dist, steps, warmup):
 XGMI_LINK_GBPS = 153.0   # MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU; a peer's slab arrives over that peer's own link
 
 
-def _config5_report(dist, per, n, legs, slab_bytes, err, how):
-    """The common shape of config 5's two reports.  legs: {name: wall seconds per step (max over ranks)}."""
+def interleaved_legs(dist, legs, steps, rounds=5, prewarm=None, prewarm_s=0.25):
+    """Times several forms of the same step so that none of them owns the cold (or the hot) side of the clock ramp
+    (measured one after the other, `compute_only` came out SLOWER than compute + gather).  First
+    `prewarm` runs for >= prewarm_s on every rank (local work, no collective); then `rounds` rounds, each timing every
+    leg once (1 untimed call + `steps` timed calls between barriers, max over ranks) in an order rotated by one per
+    round.  -> {name: {"median": s/step, "min": s/step, "samples": [...]}}"""
+    names = list(legs)
+    if prewarm is not None and not DRYRUN:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < prewarm_s:
+            for _ in range(10):
+                prewarm()
+            D.sync()
+    samples = {k: [] for k in names}
+    for r in range(rounds):
+        k0 = r % len(names)
+        for k in names[k0:] + names[:k0]:
+            fn = legs[k]
+            if getattr(fn, "before", None):      # a switch that synchronises (np_comm_set_variant) stays outside the clock
+                fn.before()
+            samples[k].append(timed(dist, fn, steps, 1)[0] / steps)
+            if getattr(fn, "after", None):
+                fn.after()
+    return {k: {"median": float(np.median(v)), "min": float(min(v)), "samples": v} for k, v in samples.items()}
+
+
+def _config5_report(dist, per, n, legs, slab_bytes, parity, how, steps):
+    """The common shape of config 5's two reports.  legs: interleaved_legs() output (wall seconds per step, max over
+    ranks).  Every derived number uses the per-leg MEDIAN over the rounds; the minimum is printed beside it.  Nothing is
+    clamped: a gathered form that comes out faster than compute alone is reported as what it is — an inconsistent
+    measurement — and no "gather alone" figure is derived from it."""
     total = per * dist.n
     flop = 2.0 * total * n ** 3
+    med = {k: v["median"] for k, v in legs.items()}
+    base = med["compute_only"]
     out = {"workload": "512 x (1024x1024) fp32 batched matmul, %d slab(s) of %d, %s" % (dist.n, per, how),
            "scaling": "strong", "allgather_bytes_per_rank": slab_bytes,
-           "ms_per_step": {k: v * 1e3 for k, v in legs.items()},
-           "compute_only_GFLOPs": flop / legs["compute_only"] / 1e9,
-           "gathered_GFLOPs": flop / legs["gathered"] / 1e9,
-           "overlapped_GFLOPs": {k: flop / v / 1e9 for k, v in legs.items() if k.startswith("overlapped")},
-           "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6)}
-    best = min((v, k) for k, v in legs.items() if k != "compute_only")
+           "protocol": "%d rounds x %d steps per leg, legs interleaved in rotating order behind a 0.25 s pre-warm; median (min)"
+                       % (len(next(iter(legs.values()))["samples"]), steps),
+           "ms_per_step": {k: round(v * 1e3, 4) for k, v in med.items()},
+           "ms_per_step_min": {k: round(v["min"] * 1e3, 4) for k, v in legs.items()},
+           "compute_only_GFLOPs": flop / base / 1e9,
+           "gathered_GFLOPs": flop / med["gathered"] / 1e9,
+           "vs_compute_only": {k: round(v / base, 4) for k, v in med.items() if k != "compute_only"},
+           "parity_max_norm_err_vs_fp64": parity, "parity_ok": bool(max(parity.values()) <= 1e-6)}
+    best = min((v, k) for k, v in med.items() if k != "compute_only")
     out["best_gathered_form"] = best[1]
     out["best_gathered_GFLOPs"] = flop / best[0] / 1e9
-    out["best_gathered_vs_compute_only"] = legs["compute_only"] / best[0]
+    # a form that computes AND moves cannot beat computing alone by more than the noise of the measurement
+    slack = 0.98
+    bad = sorted(k for k, v in med.items() if v < slack * base)
+    out["consistent"] = not bad
+    if bad:
+        out["inconsistent_legs"] = bad
     if dist.n > 1:
         # every rank receives (n - 1) slabs, each over its own link: the rate one link has to sustain
-        exposed = max(legs["gathered"] - legs["compute_only"], 1e-9)
-        out["xgmi"] = {"model_link_GBps": XGMI_LINK_GBPS,
-                       "model_gather_ms": slab_bytes / XGMI_LINK_GBPS / 1e6,
-                       "gather_alone_ms": exposed * 1e3,
-                       "link_GBps_gather_alone": slab_bytes / exposed / 1e9,
-                       "link_GBps_best_form_whole_step": slab_bytes / best[0] / 1e9,
-                       "note": "per-link rate = one slab / time; 'gather alone' = gathered - compute_only"}
+        exposed = med["gathered"] - base
+        x = {"model_link_GBps": XGMI_LINK_GBPS, "model_gather_ms": slab_bytes / XGMI_LINK_GBPS / 1e6,
+             "link_GBps_best_form_whole_step": slab_bytes / best[0] / 1e9}
+        if exposed > 0:
+            x["gather_alone_ms"] = exposed * 1e3                  # = gathered - compute_only (medians)
+            x["link_GBps_gather_alone"] = slab_bytes / exposed / 1e9
+        else:
+            x["gather_alone_ms"] = None
+            x["link_GBps_gather_alone"] = None
+            x["inconsistent"] = True
+        out["xgmi"] = x
     return out
 
 
-def bench_config5(dist: Dist, steps, warmup):
+def _peer_matrix_err(got, j, n):
+    Ah = synth.uniform((n, n), 12_000 + j, -1.0, 1.0).astype(np.float64)
+    Bh = synth.uniform((n, n), 13_000 + j, -1.0, 1.0).astype(np.float64)
+    return float((np.abs(got.astype(np.float64) - Ah @ Bh) / (np.abs(Ah) @ np.abs(Bh))).max())
+
+
+def bench_config5(dist: Dist, steps, rounds=5):
     """BASELINE config 5 with torch.distributed as the plumbing: 512 x (1024 x 1024) batched matmul, batch sharded
     over the ranks in contiguous slabs (strong scaling).  Legs: compute only; compute + ONE all-gather of the result
     slabs behind it; and the overlapped pipeline of numpower_amd.parallel (slab in 2 / 4 / 8 pieces, each piece's
-    point-to-point exchange on the process group's stream while the next piece computes)."""
+    point-to-point exchange on the process group's stream while the next piece computes).  Timed by interleaved_legs."""
     from numpower_amd import parallel
     torch = dist.torch
     total, n = 512, 1024
@@ -677,31 +767,39 @@ def bench_config5(dist: Dist, steps, warmup):
                 h.wait()
         return step
 
-    legs = {"compute_only": timed(dist, compute, steps, warmup)[0] / steps,
-            "gathered": timed(dist, compute_and_gather, steps, warmup)[0] / steps}
+    forms = {"compute_only": compute, "gathered": compute_and_gather}
     for chunks in (2, 4, 8):
         if chunks <= per:
-            Cfull.zero_()
-            legs["overlapped_%d" % chunks] = timed(dist, overlapped(chunks), steps, warmup)[0] / steps
-    # parity: one matrix of a peer's slab, as the LAST (overlapped) leg left it, against fp64
-    peer = (dist.rank + 1) % dist.n
-    j = peer * per + per - 1
-    Ah = synth.uniform((n, n), 12_000 + j, -1.0, 1.0).astype(np.float64)
-    Bh = synth.uniform((n, n), 13_000 + j, -1.0, 1.0).astype(np.float64)
-    err = float((np.abs(Cfull[j].cpu().numpy().astype(np.float64) - Ah @ Bh) / (np.abs(Ah) @ np.abs(Bh))).max())
-    return _config5_report(dist, per, n, legs, per * n * n * 4, err, "torch.distributed (RCCL) collectives")
+            forms["overlapped_%d" % chunks] = overlapped(chunks)
+    legs = interleaved_legs(dist, forms, steps, rounds, prewarm=compute)
+    # parity: one matrix of a PEER's slab as each gathering form leaves it in a zeroed result, against fp64
+    j = ((dist.rank + 1) % dist.n) * per + per - 1
+    parity = {}
+    for name, fn in forms.items():
+        if name == "compute_only":
+            continue
+        Cfull.zero_()
+        fn()
+        torch.cuda.synchronize()
+        parity[name] = _peer_matrix_err(Cfull[j].cpu().numpy(), j, n)
+    return _config5_report(dist, per, n, legs, per * n * n * 4, parity, "torch.distributed (RCCL) collectives", steps)
 
 
-def bench_config5_abi(dist: Dist, steps, warmup, own_comm_port=None, world1=False):
+def bench_config5_abi(dist: Dist, steps, rounds=5, own_comm_port=None, world1=False):
     """BASELINE config 5 the way a C / PHP host writes it — no torch tensor, no torch collective: the rank's
     slab of the batch is written in place into the full result buffer by np_sgemm_strided_batched, and
-      gathered       ONE np_allgather behind it on the same stream (no overlap possible)
-      two_stream     np_sgemm_strided_batched_allgather(chunks = 1): the same all-gather on the communication stream
-      p2p_1          ... chunks = 1, moved as one grouped send/recv exchange instead of ncclAllGather
-      overlapped_k   ... the slab in k pieces, piece c's exchange travelling while piece c + 1 is computed
+      gathered         ONE np_allgather behind it on the same stream (no overlap possible)
+      two_stream       np_sgemm_strided_batched_allgather(chunks = 1): the same all-gather on the communication stream
+      p2p_1            ... chunks = 1, moved as one grouped send/recv exchange instead of ncclAllGather
+      overlapped_k     ... the slab in k pieces, piece c's exchange travelling while piece c + 1 is computed (the
+                       default issue form: one progress-reporting launch without peers, one launch per piece with peers)
+      single_launch_k  (world > 1 only) ... the same with ONE progress-reporting GEMM launch per slab
+                       (np_comm_set_variant(3): opt-in with peers until a multi-GPU run has validated it — this leg,
+                       with the parity check behind it, is that run)
+    Timed by interleaved_legs (pre-warm, rotating order, median / min over the rounds).
     own_comm_port: bring up a communicator just for this leg (torch mode: the job's collectives belong to
     torch.distributed).  world1: a one-rank communicator on a single GPU — nothing travels, but the whole mechanism
-    (second stream, events, chunked launches) runs, so `overlapped_k` ~ `compute_only` shows what the pipeline
+    (second stream, device-side flags, progress counters) runs, so `overlapped_k` / `compute_only` is what the pipeline
     itself costs."""
     from numpower_amd._lib import check
     lib = load()
@@ -729,35 +827,97 @@ def bench_config5_abi(dist: Dist, steps, warmup, own_comm_port=None, world1=Fals
             compute()
             check(lib.np_allgather(mine, full.ptr, slab_bytes))
 
-        def pipelined(chunks, mode):
-            return lambda: check(lib.np_sgemm_strided_batched_allgather(per, n, n, n, A.ptr, n * n, B.ptr, n * n,
-                                                                        full.ptr, chunks, mode))
+        def pipelined(chunks, mode, variant=0):
+            def step():
+                check(lib.np_sgemm_strided_batched_allgather(per, n, n, n, A.ptr, n * n, B.ptr, n * n, full.ptr, chunks, mode))
+            if variant:
+                step.before = lambda: check(lib.np_comm_set_variant(variant))
+                step.after = lambda: check(lib.np_comm_set_variant(0))
+            return step
 
-        legs = {"compute_only": timed(dist, compute, steps, warmup)[0] / steps,
-                "gathered": timed(dist, compute_and_gather, steps, warmup)[0] / steps,
-                "two_stream": timed(dist, pipelined(1, 1), steps, warmup)[0] / steps,
-                "p2p_1": timed(dist, pipelined(1, 2), steps, warmup)[0] / steps}
+        forms = {"compute_only": compute, "gathered": compute_and_gather,
+                 "two_stream": pipelined(1, 1), "p2p_1": pipelined(1, 2)}
         for chunks in (2, 4, 8):
             if chunks <= per:
-                check(lib.np_memset0(full.ptr, total * n * n * 4))
-                legs["overlapped_%d" % chunks] = timed(dist, pipelined(chunks, 0), steps, warmup)[0] / steps
-        j = ((dist.rank + 1) % dist.n) * per + per - 1  # one matrix of a PEER's slab, as the last overlapped leg left it
+                forms["overlapped_%d" % chunks] = pipelined(chunks, 0)
+        if dist.n > 1:
+            for chunks in (4, 8):
+                if chunks <= per:
+                    forms["single_launch_%d" % chunks] = pipelined(chunks, 0, variant=3)
+        legs = interleaved_legs(dist, forms, steps, rounds, prewarm=compute)
+        j = ((dist.rank + 1) % dist.n) * per + per - 1  # one matrix of a PEER's slab, as each gathering form leaves it
+        parity = {}
         got = np.empty((n, n), dtype=np.float32)
-        check(lib.np_memcpy_d2h(got.ctypes.data, full.ptr + j * n * n * 4, n * n * 4))
-        Ah = synth.uniform((n, n), 12_000 + j, -1.0, 1.0).astype(np.float64)
-        Bh = synth.uniform((n, n), 13_000 + j, -1.0, 1.0).astype(np.float64)
-        err = float((np.abs(got.astype(np.float64) - Ah @ Bh) / (np.abs(Ah) @ np.abs(Bh))).max())
+        for name, fn in forms.items():
+            if name == "compute_only":
+                continue
+            check(lib.np_memset0(full.ptr, total * n * n * 4))
+            if getattr(fn, "before", None):
+                fn.before()
+            fn()
+            check(lib.np_memcpy_d2h(got.ctypes.data, full.ptr + j * n * n * 4, n * n * 4))
+            if getattr(fn, "after", None):
+                fn.after()
+            parity[name] = _peer_matrix_err(got, j, n)
         for d in (A, B, full):
             d.free()
     finally:
         if own_comm_port is not None:
             with _stdout_to_devnull():
                 lib.np_comm_destroy()
-    rep = _config5_report(dist, per, n, legs, slab_bytes, err, "np_comm_* (RCCL behind the C ABI)")
+    rep = _config5_report(dist, per, n, legs, slab_bytes, parity, "np_comm_* (RCCL behind the C ABI)", steps)
     if world1:
         rep["workload"] = ("64 x (1024x1024) fp32 batched matmul = ONE rank's slab of config 5 on a one-rank communicator: "
                            "nothing travels, the two-stream pipeline itself is what is measured")
     return rep
+
+
+def _compact(x):
+    """The printed line must fit every BASELINE config into the tail a log keeps: prose (`note`, `name`) stays in this
+    file's docstrings, floats are cut to 6 significant digits, per-round sample lists are dropped."""
+    if isinstance(x, dict):
+        return {k: _compact(v) for k, v in x.items() if k not in ("note", "name", "samples")}
+    if isinstance(x, (list, tuple)):
+        return [_compact(v) for v in x]
+    if isinstance(x, float):
+        return float("%.6g" % x)
+    return x
+
+
+def _summary(result, extras):
+    """One short object with the figure of every BASELINE config (C1 .. C5), placed last on the line."""
+    def frac(key):
+        e = extras.get(key)
+        return _compact(e["roofline"]["frac"]) if isinstance(e, dict) and "roofline" in e else None
+
+    def ok(key):
+        e = extras.get(key)
+        return e.get("parity_ok") if isinstance(e, dict) else None
+
+    out = {"c2_matmul_4096_frac_mfma": _compact(result["roofline"]["frac"]),
+           "c2_matmul_4096_TFLOPs": _compact(result["roofline"]["achieved"]),
+           "c3a_add_1e8_frac_hbm": frac("add_1e8"),
+           "c3a_add_1e8_GBps": _compact(extras["add_1e8"]["GBps"]) if "add_1e8" in extras else None,
+           "c3b_exp_1e8_frac_hbm": frac("exp_1e8"), "c3b_log_1e8_frac_hbm": frac("log_1e8"),
+           "c3c_add_row_frac_hbm": frac("add_row_broadcast"), "c3c_add_col_frac_hbm": frac("add_col_broadcast"),
+           "c3c_exp_plus_row_fused_frac_hbm": frac("exp_plus_row_fused"),
+           "c3c_exp_plus_col_fused_frac_hbm": frac("exp_plus_col_fused"),
+           "c4_sum_axis0_frac_hbm": frac("sum_axis0")}
+    c1 = extras.get("c1")
+    if isinstance(c1, dict) and "cpu_add_ms" in c1:
+        out["c1_cpu_add_ms"], out["c1_cpu_sum_ms"] = _compact(c1["cpu_add_ms"]), _compact(c1["cpu_sum_ms"])
+        out["c1_gpu_add_us"], out["c1_gpu_sum_us"] = _compact(c1["gpu_add_kernel_us"]), _compact(c1["gpu_sum_call_us"])
+        out["c1_end_to_end_add_ms"] = _compact(c1["end_to_end_gpu_add_cpu_ms"])
+    for key in ("config5_one_rank_slab_c_abi", "config5_batched_matmul_allgather_c_abi", "config5_batched_matmul_allgather"):
+        c5 = extras.get(key)
+        if isinstance(c5, dict) and "ms_per_step" in c5:
+            out["c5_" + key[8:]] = {"ms_per_step": c5["ms_per_step"], "consistent": c5["consistent"],
+                                    "compute_only_GFLOPs": _compact(c5["compute_only_GFLOPs"]),
+                                    "best_gathered_GFLOPs": _compact(c5["best_gathered_GFLOPs"]),
+                                    "best_gathered_form": c5["best_gathered_form"], "parity_ok": c5["parity_ok"]}
+    out["parity_all_ok"] = bool(result["parity"]["ok"] and all(
+        e.get("parity_ok", True) for e in extras.values() if isinstance(e, dict)))
+    return out
 
 
 def _diag_add(dist, label):
@@ -853,7 +1013,11 @@ def main():
             try:
                 extras = bench_extras(dist, max(10, args.steps // 2), args.warmup)
                 try:
-                    extras["config5_one_rank_slab_c_abi"] = bench_config5_abi(dist, max(10, args.steps // 2), 10,
+                    extras["c1"] = bench_c1(dist, max(10, args.steps // 2), args.warmup)
+                except Exception as e:
+                    extras["c1"] = {"error": repr(e)}
+                try:
+                    extras["config5_one_rank_slab_c_abi"] = bench_config5_abi(dist, max(10, args.steps // 2), 7,
                                                                                 own_comm_port=_free_port(), world1=True)
                 except Exception as e:
                     extras["config5_one_rank_slab_c_abi"] = {"error": repr(e)}
@@ -897,8 +1061,25 @@ def main():
                 entry["roofline"]["traffic"] = traffic[key].get("hbm_bytes")
         if "secondary" in result and "add_1e8" in traffic:
             result["secondary"]["roofline"]["traffic"] = traffic["add_1e8"].get("hbm_bytes")
+    # The second half of BASELINE.json's metric — GB/s of the elementwise add on 1e8 floats — inside the two objects the
+    # driver's record keeps (`roofline`, `cpu_baseline`): once nested, once as flat scalars (VERDICT r03 missing #2).
+    if "secondary" in result:
+        sec = result["secondary"]
+        r2, c2 = sec["roofline"], sec["cpu_baseline"]
+        result["roofline"]["secondary"] = {"metric": sec["metric"], "kernel": "binary_vec_kernel<add> (float4, non-temporal)",
+                                           "bound": "hbm", "achieved": r2["achieved"], "peak": r2["peak"], "unit": "GB/s",
+                                           "frac": r2["frac"], "traffic": r2.get("traffic"),
+                                           "algorithmic_bytes_per_launch": 1.2e9,
+                                           "frac_median_launch": r2.get("frac_median_launch"),
+                                           "frac_of_copy": r2.get("ceiling", {}).get("frac_of_copy")}
+        for k, v in result["roofline"]["secondary"].items():
+            result["roofline"]["secondary_" + k] = v
+        result["cpu_baseline"]["secondary"] = dict(c2, metric=sec["metric"])
+        for k, v in result["cpu_baseline"]["secondary"].items():
+            result["cpu_baseline"]["secondary_" + k] = v
     if extras:
-        result["extras"] = extras
+        result["extras"] = _compact(extras)
+        result["summary"] = _summary(result, extras)       # LAST key: the tail of the line shows every BASELINE config
     if rank0:
         print(json.dumps(result), flush=True)
     dist.close()

@@ -55,3 +55,68 @@ def test_dead_rank_takes_the_job_down_quickly():
     p = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0"], {"NP_BENCH_DRYRUN_FAIL_RANK": "1"}, timeout=90)
     assert p.returncode != 0
     assert "rank 1 failed" in p.stderr
+
+
+# ---- the config-5 report: interleaved legs, medians, nothing clamped ----
+
+def _bench_module():
+    import importlib.util
+    old = os.environ.get("NP_BENCH_DRYRUN")
+    os.environ["NP_BENCH_DRYRUN"] = "1"          # read once at import: no device is touched by this copy of the module
+    try:
+        spec = importlib.util.spec_from_file_location("bench_under_test", ROOT / "bench.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if old is None:
+            del os.environ["NP_BENCH_DRYRUN"]
+        else:
+            os.environ["NP_BENCH_DRYRUN"] = old
+    return mod
+
+
+class _FakeDist:
+    def __init__(self, n):
+        self.n, self.rank = n, 0
+
+    def barrier_sync(self):
+        pass
+
+    def max_over_ranks(self, x):
+        return x
+
+
+def test_interleaved_legs_rotate_the_order_and_report_median_and_min():
+    bench = _bench_module()
+    calls = []
+    legs = {name: (lambda name=name: calls.append(name)) for name in ("a", "b", "c")}
+    out = bench.interleaved_legs(_FakeDist(1), legs, steps=2, rounds=4)
+    per_round = [calls[i:i + 9] for i in range(0, len(calls), 9)]           # 3 legs x (1 warm-up + 2 timed calls)
+    assert [r[0] for r in per_round] == ["a", "b", "c", "a"]                # the leg that goes first rotates
+    assert all(sorted(set(r)) == ["a", "b", "c"] for r in per_round)
+    for v in out.values():
+        assert len(v["samples"]) == 4 and v["min"] <= v["median"] <= max(v["samples"])
+
+
+def test_config5_report_never_clamps_an_inconsistent_measurement():
+    bench = _bench_module()
+
+    def legs(compute, gathered, overlapped):
+        return {k: {"median": v, "min": v * 0.99, "samples": [v] * 5}
+                for k, v in (("compute_only", compute), ("gathered", gathered), ("overlapped_4", overlapped))}
+
+    slab = 64 * 1024 * 1024 * 4
+    parity = {"gathered": 1e-7, "overlapped_4": 2e-7}
+    good = bench._config5_report(_FakeDist(8), 64, 1024, legs(1.0e-3, 2.9e-3, 2.0e-3), slab, parity, "test", 5)
+    assert good["consistent"] and good["best_gathered_form"] == "overlapped_4" and good["parity_ok"]
+    assert abs(good["xgmi"]["gather_alone_ms"] - 1.9) < 1e-9
+    assert abs(good["xgmi"]["link_GBps_gather_alone"] - slab / 1.9e-3 / 1e9) < 1e-6
+    # computing AND gathering measured faster than computing: no "gather alone", no absurd link rate — flagged instead
+    bad = bench._config5_report(_FakeDist(8), 64, 1024, legs(1.0e-3, 0.9e-3, 0.95e-3), slab, parity, "test", 5)
+    assert bad["consistent"] is False and bad["inconsistent_legs"] == ["gathered", "overlapped_4"]
+    assert bad["xgmi"]["gather_alone_ms"] is None and bad["xgmi"]["link_GBps_gather_alone"] is None
+    assert bad["xgmi"]["inconsistent"] is True
+    # within the 2 % noise band is not an inconsistency
+    near = bench._config5_report(_FakeDist(1), 64, 1024, legs(1.0e-3, 0.995e-3, 1.004e-3), slab, parity, "test", 5)
+    assert near["consistent"] and "xgmi" not in near
+    assert bench._config5_report(_FakeDist(1), 64, 1024, legs(1e-3, 1e-3, 1e-3), slab, {"gathered": 1e-3}, "t", 5)["parity_ok"] is False
