@@ -223,6 +223,10 @@ int np_fused_chain(const float *const *inputs, const int *input_kinds, int n_inp
 int np_fused_chain_reduce(const float *const *inputs, const int *input_kinds, int n_inputs,
                           const np_fused_op *ops, int n_ops, int reduce_op, size_t rows, size_t cols,
                           float *host_out);
+/* Same, the result left on the device (dev_out: 1 float) — no host round trip, so calls can be issued back to back. */
+int np_fused_chain_reduce_dev(const float *const *inputs, const int *input_kinds, int n_inputs,
+                              const np_fused_op *ops, int n_ops, int reduce_op, size_t rows, size_t cols,
+                              float *dev_out);
 /* ... and with a reduction over ONE axis of the rows x cols chain value as the last step: axis 1 (the
  * last axis) -> out[rows], axis 0 -> out[cols]; out is a DEVICE pointer.  sum(exp(X), 1), max(X - c, 1),
  * mean((X - mu) * (X - mu), 0) in one pass over X: 4 B/elem instead of 12.  Last axis: a wave (or, for

@@ -75,6 +75,8 @@ PROTOTYPES = {
                                  C.c_int, _f32p, C.c_size_t, C.c_size_t]),
     "np_fused_chain_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(FusedOp),
                                         C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]),
+    "np_fused_chain_reduce_dev": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(FusedOp),
+                                            C.c_int, C.c_int, C.c_size_t, C.c_size_t, _f32p]),
     "np_fused_chain_reduce_axis": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(FusedOp),
                                              C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, _f32p]),
     "np_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),

@@ -27,8 +27,8 @@ INCLUDE = ROOT / "include"
 LIBDIR = ROOT / "numpower_amd" / "lib"
 OBJDIR = ROOT / "build" / "obj"
 
-HIP_SOURCES = ["np_runtime.hip", "np_elementwise.hip", "np_reduce.hip", "np_sgemm.hip", "np_layout.hip", "np_select.hip",
-               "np_comm.hip"]
+HIP_SOURCES = ["np_runtime.hip", "np_elementwise.hip", "np_fused_static.hip", "np_reduce.hip", "np_sgemm.hip", "np_layout.hip",
+               "np_select.hip", "np_comm.hip"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 

@@ -75,6 +75,27 @@ int sgemm_batched_with_progress(size_t batch, size_t M, size_t N, size_t K, cons
 // np_sgemm_strided_batched for `count` matrices that are a piece of a batch of `whole`: planned as the whole batch (np_sgemm.hip)
 int sgemm_batched_piece(size_t count, size_t whole, size_t M, size_t N, size_t K, const float *A, size_t stride_a, const float *B,
                         size_t stride_b, float *C, size_t stride_c);
+// Compiled chains (np_fused_static.hip): what np_elementwise.hip's fused_chain_impl hands over when a chain of 1-3 steps
+// might be on the menu of straight-line kernels.  operand[k] == nullptr: a scalar operand (or a unary step); idx[k]: how an
+// array operand is indexed by the flat element index e of the rows x cols result — 0 full, 1 row (e % cols), 2 column
+// (e / cols), 3 zero-d.  bcast_cols: the row length when some operand is broadcast (then a multiple of 4), else 0.
+struct FusedStaticDesc {
+    int n_ops;
+    const float *in0;
+    int kind[3], op[3], swap[3], idx[3];
+    const float *operand[3];
+    float scalar[3], p0[3], p1[3];
+    unsigned bcast_cols, div_m, div_s1, div_s2;
+};
+// sink < 0: the chain value is stored; else NP_SUM ... ; axis_mode -1 flat, 0 first axis, 1 last axis
+bool fused_static_covers(const FusedStaticDesc &d, int sink, int axis_mode);
+// flat: out[e] = chain(e) (sink < 0) or one partial per workgroup in out[] under the interpreter's protocol (ticket / result)
+int fused_static_flat(const FusedStaticDesc &d, float *out, size_t n, int sink, unsigned grid, unsigned *ticket, float *result);
+// first axis: out[chunk][c] = sum over the chunk's rows (the geometry fused_chain_impl computed for the interpreter's kernel)
+int fused_static_cols(const FusedStaticDesc &d, float *out, size_t rows, size_t cols, size_t rows_per_chunk, float mean_div,
+                      unsigned col_blocks, unsigned chunks, int rows_in_flight);
+// last axis: out[r] = sum over the row, lane groups of L lanes per row (the interpreter's wave mode); cols % 4 == 0
+int fused_static_rows(const FusedStaticDesc &d, float *out, size_t rows, size_t cols, unsigned L, float mean_div, unsigned grid);
 // Copy kernel for large word-aligned device-to-device copies (np_elementwise.hip); bytes % 4 == 0.
 int device_copy(void *dst, const void *src, size_t bytes);
 
