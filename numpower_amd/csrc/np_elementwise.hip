@@ -30,6 +30,13 @@ template <typename I>
 struct Ragged {
     I cols;
     unsigned m, s1, s2;
+    // A ROW operand too long to stay cached (X + r with 7 x 10^7: each of the 7 result rows re-read the 40 MB vector,
+    // 4.8 TB/s where X + col ran 6.4): rowblock_rows = rows of the result switches the work order from row-major to
+    // column blocks — workgroup w takes 256 float4 slots of column block w / rows in row w % rows, so the workgroups in
+    // flight together need the same piece of the vector, which then comes from HBM once.  wspace = rows x column blocks x
+    // 256 work items.  0 = off (the plain order).
+    unsigned rowblock_rows;
+    I wspace;
 };
 
 template <typename I>
@@ -110,28 +117,47 @@ __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict
 
     // POWREG: the loop and the arithmetic run with the whole wave active (the table lives in its lanes); lanes past
     // the end compute 1^1 and store nothing
-    auto more = [&](I base) { return POWREG ? __builtin_amdgcn_ballot_w64(base < nvec) != 0ull : base < nvec; };
+    constexpr bool ROWBLOCK = (AK == NP_ROW || BK == NP_ROW) && sizeof(I) == 4 && OP != NP_POW;
+    const I limit = ROWBLOCK && rg.rowblock_rows ? rg.wspace : nvec;
+    // work item -> float4 slot (see Ragged::rowblock_rows); ok = the slot exists
+    auto slot_of = [&](I w, bool &ok) -> I {
+        if constexpr (ROWBLOCK) {
+            if (rg.rowblock_rows) {   // uniform
+                const unsigned wg = __builtin_amdgcn_readfirstlane((unsigned)w >> 8);   // a workgroup's 256 items share it
+                const unsigned cb = wg / rg.rowblock_rows, row = wg - cb * rg.rowblock_rows;
+                const unsigned c = cb * 256u + ((unsigned)w & 255u);
+                ok = w < limit && c < (unsigned)cols4;
+                return (I)(row * (unsigned)cols4 + c);
+            }
+        }
+        ok = w < nvec;
+        return w;
+    };
+    auto more = [&](I base) { return POWREG ? __builtin_amdgcn_ballot_w64(base < nvec) != 0ull : base < limit; };
     for (I base = tid; more(base); base += stride * UNROLL) {
         v4f va[UNROLL], vb[UNROLL];
+        I slot[UNROLL];
+        bool live[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const I v = base + (I)u * stride;
+            slot[u] = slot_of(base + (I)u * stride, live[u]);
+            const I v = slot[u];
             if constexpr (POWREG) va[u] = vb[u] = v4f{1.0f, 1.0f, 1.0f, 1.0f};
-            if (v < nvec) {
+            if (live[u]) {
                 va[u] = fetch4<AK, NT, I>(a, v, cols4, sa, rg);
                 vb[u] = fetch4<BK, NT, I>(b, v, cols4, sb, rg);
             }
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const I v = base + (I)u * stride;
+            const I v = slot[u];
             if constexpr (POWREG) {
                 const float px[4] = {va[u][0], va[u][1], va[u][2], va[u][3]};
                 const float py[4] = {vb[u][0], vb[u][1], vb[u][2], vb[u][3]};
                 float pr[4];
                 pow_n<4>(px, py, pr, pow_regs);
-                if (v < nvec) st4<NT>(out + (size_t)v * 4, v4f{pr[0], pr[1], pr[2], pr[3]});
-            } else if (v < nvec) {
+                if (live[u]) st4<NT>(out + (size_t)v * 4, v4f{pr[0], pr[1], pr[2], pr[3]});
+            } else if (live[u]) {
                 v4f r;
                 const I e = v * 4;
                 if constexpr (OP == NP_POW) {
@@ -347,9 +373,19 @@ int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size
                       size_t body_end, float ha, float hb) {
     const LaunchCfg c = cfg_from_variant(g_variant);
     const I nvec = (I)(n / 4), cols4 = (I)(cols / 4), tail = (I)(n / 4 * 4);
-    const unsigned grid = grid_for(n / 4 + 1, c.unroll, c.blocks_per_cu);
+    unsigned grid = grid_for(n / 4 + 1, c.unroll, c.blocks_per_cu);
     hipStream_t s = np::stream();
-    Ragged<I> rg{0, 0, 0, 0};
+    Ragged<I> rg{0, 0, 0, 0, 0, 0};
+    // a ROW operand of >= 4 MB under a result of several rows: column-block order (Ragged::rowblock_rows; variant 8000: off)
+    if ((AK == NP_ROW || BK == NP_ROW) && OP != NP_POW && sizeof(I) == 4 && cols % 4 == 0 && cols >= (size_t(1) << 20) && n / cols >= 2 &&
+        n / cols < (size_t(1) << 16) && g_variant != 8000) {
+        const size_t rows = n / cols, col_blocks = (cols / 4 + 255) / 256;
+        if (rows * col_blocks * 256 < (size_t(1) << 31)) {
+            rg.rowblock_rows = (unsigned)rows;
+            rg.wspace = (I)(rows * col_blocks * 256);
+            grid = grid_for(rows * col_blocks * 256, c.unroll, c.blocks_per_cu);
+        }
+    }
     if ((AK == NP_ROW || AK == NP_COL || BK == NP_ROW || BK == NP_COL) && cols % 4 != 0) {
         rg.cols = (I)cols;
         if (cols > 1 && cols <= 0xffffffffull) {   // fast_div constants (cols == 1: q = n)

@@ -24,14 +24,39 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // is all a row of odd length offers
 struct __attribute__((packed, aligned(4))) U4 { v4f v; };
 
+constexpr int MAX_ND = 8;
+// Where a plane sits: rows `in_pitch` floats apart in the input, output rows `out_pitch` apart; blockIdx.z runs over the
+// batch axes (an N-D permutation whose plane axes are transposed: every other axis is a batch index with its own stride on
+// either side).  The plain 2-D / batched case: pitches = cols / rows, one batch axis of rows * cols on both sides.
+struct PlaneBatch {
+    size_t in_pitch, out_pitch;
+    unsigned nbatch;
+    unsigned bshape[MAX_ND];
+    size_t bin[MAX_ND], bout[MAX_ND];
+};
+__device__ __forceinline__ void plane_offsets(const PlaneBatch &p, unsigned batch, size_t &off_in, size_t &off_out) {
+    off_in = off_out = 0;
+#pragma unroll
+    for (int d = MAX_ND - 1; d >= 0; --d) {
+        if (d < (int)p.nbatch) {
+            const unsigned q = batch / p.bshape[d], r = batch - q * p.bshape[d];
+            off_in += (size_t)r * p.bin[d];
+            off_out += (size_t)r * p.bout[d];
+            batch = q;
+        }
+    }
+}
+
 // in: [batch][rows][cols] -> out: [batch][cols][rows].  TILE x TILE floats per workgroup; the LDS
 // tile is padded to TILE+1 floats per row.  Global reads and writes are float4 per lane along
 // rows: TILE*4 contiguous bytes per row segment on both sides (256 B at TILE 64, 512 B at 128).
+// Non-temporal on both sides in both forms (VEC = every row start 16-byte aligned; else dword-aligned float4s, the
+// matrix edge element by element): nothing is re-read.
 template <int TR, int TC, bool VEC>
 __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__restrict__ in,
                                                              float *__restrict__ out, unsigned rows,
                                                              unsigned cols, unsigned tiles_x,
-                                                             unsigned tiles_y) {
+                                                             unsigned tiles_y, PlaneBatch pb) {
     // a TR x TC tile of the input (TR rows, TC columns) becomes a TC x TR tile of the output
     constexpr int LDT = TR + 1;           // tile[c][r]
     constexpr int C4 = TC / 4;            // float4 columns per input tile row
@@ -41,9 +66,12 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
     constexpr int ORPP = 256 / OC4;
     constexpr int OPASSES = TC / ORPP;
     extern __shared__ __attribute__((aligned(16))) float tile[];
-    const size_t plane = (size_t)rows * cols;
-    const float *src = in + (size_t)blockIdx.z * plane;
-    float *dst = out + (size_t)blockIdx.z * plane;
+    typedef v4f v4f_u __attribute__((aligned(4)));
+    size_t off_in, off_out;
+    plane_offsets(pb, blockIdx.z, off_in, off_out);
+    const float *src = in + off_in;
+    float *dst = out + off_out;
+    const size_t ipitch = pb.in_pitch, opitch = pb.out_pitch;
     // diagonal tile order: workgroups that run at the same time (consecutive blockIdx.x) read
     // neighbouring column blocks AND write different column offsets of the output, instead of all
     // writing segments a power-of-two stride apart (HBM channel camping on 8192 x 8192 etc.)
@@ -60,13 +88,13 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
         const unsigned r = r0 + ty + RPP * j, c = c0 + 4 * tx4;
         v[j] = v4f{0, 0, 0, 0};
         if constexpr (VEC) {
-            if (r < rows && c < cols) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)r * cols + c));
+            if (r < rows && c < cols) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)r * ipitch + c));
         } else if (r < rows && c + 3 < cols) {
-            v[j] = ((const U4 *)(src + (size_t)r * cols + c))->v;
+            v[j] = __builtin_nontemporal_load((const v4f_u *)(src + (size_t)r * ipitch + c));
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (r < rows && c + k < cols) v[j][k] = src[(size_t)r * cols + c + k];
+                if (r < rows && c + k < cols) v[j][k] = src[(size_t)r * ipitch + c + k];
         }
     }
 #pragma unroll
@@ -84,13 +112,13 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
 #pragma unroll
         for (int k = 0; k < 4; ++k) w[k] = tile[oc * LDT + 4 * otx4 + k];
         if constexpr (VEC) {
-            if (orow < cols && ocol < rows) __builtin_nontemporal_store(w, (v4f *)(dst + (size_t)orow * rows + ocol));
+            if (orow < cols && ocol < rows) __builtin_nontemporal_store(w, (v4f *)(dst + (size_t)orow * opitch + ocol));
         } else if (orow < cols && ocol + 3 < rows) {
-            ((U4 *)(dst + (size_t)orow * rows + ocol))->v = w;
+            __builtin_nontemporal_store(w, (v4f_u *)(dst + (size_t)orow * opitch + ocol));
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (orow < cols && ocol + k < rows) dst[(size_t)orow * rows + ocol + k] = w[k];
+                if (orow < cols && ocol + k < rows) dst[(size_t)orow * opitch + ocol + k] = w[k];
         }
     }
 }
@@ -118,7 +146,6 @@ __global__ __launch_bounds__(256) void transpose_skinny_kernel(const float *__re
     }
 }
 
-constexpr int MAX_ND = 8;
 struct PermuteArgs {
     unsigned ndim;
     unsigned out_shape[MAX_ND];
@@ -181,50 +208,49 @@ int launch_gather(const float *in, float *out, size_t n, PermuteArgs a) {
     return NP_OK;
 }
 
-// General permutation whose output-fastest axis is NOT the input-fastest axis (the default
-// transpose() of a 3-D array reverses all axes): the gather kernel above would read with a large
-// stride per lane (0.4-0.5 TB/s).  Here the plane spanned by the input axis that becomes
-// output-fastest (A) and the input-fastest axis (B) goes through a 64 x 64 LDS tile — reads run
-// along B, writes along A, both coalesced — and every other axis is a batch index.
-struct TiledPermuteArgs {
-    unsigned A, B;                  // extents of the two plane axes
-    size_t a_in, b_out;             // input stride of A (B's is 1), output stride of B (A's is 1)
-    unsigned nbatch;                // number of batch axes
-    unsigned bshape[MAX_ND];
-    size_t bin[MAX_ND], bout[MAX_ND];
-    unsigned tiles_a, tiles_b;
+// General permutation whose output-fastest axis is NOT the input-fastest axis (the default transpose() of a 3-D array
+// reverses all axes), or whose innermost axis stays but is only a few floats long (NHWC-like layouts: (64, 128, 1024, 8)
+// with axes 1 and 2 swapped): the gather kernel above would read with a large stride per lane (0.4-0.5 TB/s) or in 32-byte
+// runs (3.4 TB/s).  Here the plane spanned by the input axis that becomes output-fastest (A) and the input-fastest axis
+// (B) goes through an LDS tile — reads run along B, writes along A, both in contiguous runs — an element of the plane being
+// a run of E floats that is contiguous on both sides (E = 1, or the short kept inner axis), and every other axis a batch
+// index.  The tile is ta x tb elements, ta * tb * E <= 4096 floats, and it is walked by LINEAR index in both phases
+// (index -> (a, b, e) by multiply-high): planes whose extents are not multiples of 64 (100 x 100: round 3's fixed 64 x 64
+// tiles ran 61 % of their lanes) cut into balanced tiles (50 x 50) keep every lane busy, and the runs stay 200+ bytes.
+struct PlanePermuteArgs {
+    unsigned A, B, E;               // plane extents (elements), floats per element
+    size_t a_in, b_out;             // input stride of A, output stride of B (floats); B's input / A's output stride is E
+    unsigned ta, tb, tiles_a, tiles_b;
+    unsigned pitch;                 // LDS floats per a
+    unsigned m_tbE, m_taE, m_E;     // floor(2^32 / d) + 1 for d = tb * E, ta * E, E (exact quotients below 2^12 ... 2^13)
+    PlaneBatch pb;
 };
+constexpr unsigned kPlaneLds = 4096 + 512;
 
-__global__ __launch_bounds__(256) void permute_tiled_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                            TiledPermuteArgs p) {
-    __shared__ float tile[64][65];
+__global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restrict__ in, float *__restrict__ out, PlanePermuteArgs p) {
+    __shared__ float tile[kPlaneLds];
     unsigned id = blockIdx.x;
-    const unsigned tb = id % p.tiles_b;
+    const unsigned tb_i = id % p.tiles_b;
     id /= p.tiles_b;
-    const unsigned ta = id % p.tiles_a;
-    unsigned batch = id / p.tiles_a;
-    size_t off_in = 0, off_out = 0;
-#pragma unroll
-    for (int d = MAX_ND - 1; d >= 0; --d) {
-        if (d < (int)p.nbatch) {
-            const unsigned q = batch / p.bshape[d], r = batch - q * p.bshape[d];
-            off_in += (size_t)r * p.bin[d];
-            off_out += (size_t)r * p.bout[d];
-            batch = q;
-        }
-    }
-    const unsigned a0 = ta * 64, b0 = tb * 64;
-    const unsigned tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const unsigned a = a0 + ty + 4 * j, b = b0 + tx;
-        if (a < p.A && b < p.B) tile[ty + 4 * j][tx] = in[off_in + (size_t)a * p.a_in + b];
+    const unsigned ta_i = id % p.tiles_a;
+    size_t off_in, off_out;
+    plane_offsets(p.pb, id / p.tiles_a, off_in, off_out);
+    const unsigned a0 = ta_i * p.ta, b0 = tb_i * p.tb;
+    const unsigned na = p.A - a0 < p.ta ? p.A - a0 : p.ta, nb = p.B - b0 < p.tb ? p.B - b0 : p.tb;
+    const unsigned tbE = p.tb * p.E, taE = p.ta * p.E, total = p.ta * tbE;
+    // phase 1: (a, b, e) with (b, e) fastest — runs of nb * E contiguous floats per a
+    for (unsigned idx = threadIdx.x; idx < total; idx += 256) {
+        const unsigned a = p.E == 1 && p.tb == 64 ? idx >> 6 : __umulhi(idx, p.m_tbE), rem = idx - a * tbE;
+        const unsigned b = p.E == 1 ? rem : __umulhi(rem, p.m_E);
+        if (a < na && b < nb) tile[a * p.pitch + rem] = __builtin_nontemporal_load(in + off_in + (size_t)(a0 + a) * p.a_in + (size_t)b0 * p.E + rem);
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const unsigned b = b0 + ty + 4 * j, a = a0 + tx;
-        if (a < p.A && b < p.B) out[off_out + (size_t)b * p.b_out + a] = tile[tx][ty + 4 * j];
+    // phase 2: (b, a, e) with (a, e) fastest — runs of na * E contiguous floats per b
+    for (unsigned idx = threadIdx.x; idx < total; idx += 256) {
+        const unsigned b = p.E == 1 && p.ta == 64 ? idx >> 6 : __umulhi(idx, p.m_taE), rem = idx - b * taE;
+        const unsigned a = p.E == 1 ? rem : __umulhi(rem, p.m_E), e = rem - a * p.E;
+        if (a < na && b < nb)
+            __builtin_nontemporal_store(tile[a * p.pitch + b * p.E + e], out + off_out + (size_t)(b0 + b) * p.b_out + (size_t)a0 * p.E + rem);
     }
 }
 
@@ -281,7 +307,7 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 int g_tile = 0;   // 0 = default, else 64 / 128 (np_layout_set_variant)
 
 template <int TR, int TC>
-int launch_transpose(const float *in, float *out, size_t batch, size_t rows, size_t cols, bool vec) {
+int launch_transpose(const float *in, float *out, size_t batch, size_t rows, size_t cols, bool vec, const PlaneBatch &pb) {
     const size_t tiles_x = (cols + TC - 1) / TC, tiles_y = (rows + TR - 1) / TR;
     if (tiles_x * tiles_y > 0x7fffffffu) return np::fail(NP_ERR_INVALID, "np_transpose2d: too many tiles");
     const dim3 grid((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch);
@@ -298,10 +324,10 @@ int launch_transpose(const float *in, float *out, size_t batch, size_t rows, siz
     }
     if (vec)
         transpose_tile_kernel<TR, TC, true><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols,
-                                                                             (unsigned)tiles_x, (unsigned)tiles_y);
+                                                                             (unsigned)tiles_x, (unsigned)tiles_y, pb);
     else
         transpose_tile_kernel<TR, TC, false><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols,
-                                                                              (unsigned)tiles_x, (unsigned)tiles_y);
+                                                                              (unsigned)tiles_x, (unsigned)tiles_y, pb);
     NP_LAUNCH_CHECK("transpose_tile_kernel");
     return NP_OK;
 }
@@ -324,6 +350,26 @@ __global__ __launch_bounds__(256) void copy2d_kernel(float *__restrict__ dst, si
             dst[r * dst_pitch + c] = src[r * src_pitch + c];
         }
     }
+}
+
+// rows x cols planes (rows `pb.in_pitch` apart) -> cols x rows planes (rows `pb.out_pitch` apart), `batch` of them
+int transpose_planes(const float *in, float *out, size_t batch, size_t rows, size_t cols, const PlaneBatch &pb) {
+    const bool vec = rows % 4 == 0 && cols % 4 == 0 && aligned16(in) && aligned16(out) && pb.in_pitch % 4 == 0 && pb.out_pitch % 4 == 0;
+    bool vec_batch = vec;
+    for (unsigned d = 0; d < pb.nbatch; ++d) vec_batch = vec_batch && pb.bin[d] % 4 == 0 && pb.bout[d] % 4 == 0;
+    // 128 x 128 tiles (512-byte row segments) for large matrices, 64 x 64 when that would leave
+    // CUs without work
+    int tile = g_tile;
+    if (tile == 0)
+        tile = (((rows + 127) / 128) * ((cols + 127) / 128) * batch >= (size_t)np::num_cus() * 4) ? 128 : 64;
+    // Rectangular tiles (the kernel takes any TR x TC) were measured in round 2 — 256x64, 64x256, 128x64, 64x128, 256x32,
+    // 32x256 (profiles/r02/transpose_rect_ab.log): none beats 128 x 128.  What counts is the length of the READ
+    // segments (64x256: 1 KiB reads, 256 B writes = 128x128's 5.74 TB/s at 65536 x 4096; 256x64: 256 B reads, 1 KiB
+    // writes = 5.16), so only the two square tiles are instantiated.  A probe with the LDS round trip taken out (same
+    // loads and stores, wrong values) runs at the same 5.65 TB/s: the LDS transpose is hidden, the rate is what 512-byte
+    // segments at two tiles per CU get from HBM — and with no LDS allocated (more tiles in flight) it drops to 5.35.
+    if (tile == 128) return launch_transpose<128, 128>(in, out, batch, rows, cols, vec_batch, pb);
+    return launch_transpose<64, 64>(in, out, batch, rows, cols, vec_batch, pb);
 }
 
 }  // namespace
@@ -356,20 +402,17 @@ int np_transpose2d(const float *in, float *out, size_t batch, size_t rows, size_
         NP_LAUNCH_CHECK("transpose_skinny_kernel");
         return NP_OK;
     }
-    const bool vec = rows % 4 == 0 && cols % 4 == 0 && aligned16(in) && aligned16(out);
-    // 128 x 128 tiles (512-byte row segments) for large matrices, 64 x 64 when that would leave
-    // CUs without work
-    int tile = g_tile;
-    if (tile == 0)
-        tile = (((rows + 127) / 128) * ((cols + 127) / 128) * batch >= (size_t)np::num_cus() * 4) ? 128 : 64;
-    // Rectangular tiles (the kernel takes any TR x TC) were measured in round 2 — 256x64, 64x256, 128x64, 64x128, 256x32,
-    // 32x256 (profiles/r02/transpose_rect_ab.log): none beats 128 x 128.  What counts is the length of the READ
-    // segments (64x256: 1 KiB reads, 256 B writes = 128x128's 5.74 TB/s at 65536 x 4096; 256x64: 256 B reads, 1 KiB
-    // writes = 5.16), so only the two square tiles are instantiated.  A probe with the LDS round trip taken out (same
-    // loads and stores, wrong values) runs at the same 5.65 TB/s: the LDS transpose is hidden, the rate is what 512-byte
-    // segments at two tiles per CU get from HBM — and with no LDS allocated (more tiles in flight) it drops to 5.35.
-    if (tile == 128) return launch_transpose<128, 128>(in, out, batch, rows, cols, vec);
-    return launch_transpose<64, 64>(in, out, batch, rows, cols, vec);
+    PlaneBatch pb{};
+    pb.in_pitch = cols;
+    pb.out_pitch = rows;
+    pb.nbatch = 1;
+    for (int d = 0; d < MAX_ND; ++d) {
+        pb.bshape[d] = 1;
+        pb.bin[d] = pb.bout[d] = 0;
+    }
+    pb.bshape[0] = (unsigned)batch;
+    pb.bin[0] = pb.bout[0] = rows * cols;
+    return transpose_planes(in, out, batch, rows, cols, pb);
 }
 
 int np_permute(const float *in, float *out, int ndim, const int *host_shape, const int *host_perm) {
@@ -452,45 +495,86 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
         in_strides[i] = s;
         s *= (size_t)host_shape[i];
     }
-    // output-fastest axis is not the input-fastest one: LDS-tiled plane transpose, batched
-    if (ndim >= 2 && host_perm[ndim - 1] != ndim - 1 && g_tile == 0) {
-        const int ax_a = host_perm[ndim - 1], ax_b = ndim - 1;   // input axes
-        size_t out_strides[MAX_ND];   // output stride of each OUTPUT axis
-        size_t t = 1;
-        for (int i = ndim - 1; i >= 0; --i) {
-            out_strides[i] = t;
-            t *= (size_t)host_shape[host_perm[i]];
+    // The plane path (permute_plane_kernel / the float4 tile transpose): the output-fastest axis is not the input-fastest
+    // one, or the innermost axis is kept but short (E floats, < 32) and the axes in front of it are reordered — then the
+    // "elements" of the plane are runs of E floats.
+    {
+        int nd = ndim;
+        unsigned E = 1;
+        if (nd >= 3 && host_perm[nd - 1] == nd - 1 && host_shape[nd - 1] < 32 && g_tile == 0) {
+            E = (unsigned)host_shape[nd - 1];
+            --nd;   // the remaining axes permute elements of E floats; host_perm[0 .. nd) is a permutation of 0 .. nd - 1
         }
-        TiledPermuteArgs p;
-        p.A = (unsigned)host_shape[ax_a];
-        p.B = (unsigned)host_shape[ax_b];
-        p.a_in = in_strides[ax_a];
-        p.b_out = 0;
-        p.nbatch = 0;
-        size_t batch = 1;
-        for (int i = 0; i < MAX_ND; ++i) {
-            p.bshape[i] = 1;
-            p.bin[i] = p.bout[i] = 0;
-        }
-        for (int o = 0; o < ndim; ++o) {          // o: output axis, fed by input axis host_perm[o]
-            const int ia = host_perm[o];
-            if (ia == ax_b) {
-                p.b_out = out_strides[o];
-            } else if (ia != ax_a) {
-                p.bshape[p.nbatch] = (unsigned)host_shape[ia];
-                p.bin[p.nbatch] = in_strides[ia];
-                p.bout[p.nbatch] = out_strides[o];
-                ++p.nbatch;
-                batch *= (size_t)host_shape[ia];
+        if (nd >= 2 && host_perm[nd - 1] != nd - 1 && g_tile == 0) {
+            const int ax_a = host_perm[nd - 1], ax_b = nd - 1;   // input axes: A becomes output-fastest, B is input-fastest
+            size_t out_strides[MAX_ND];   // output stride of each OUTPUT axis (floats)
+            size_t t = 1;
+            for (int i = ndim - 1; i >= 0; --i) {
+                out_strides[i] = t;
+                t *= (size_t)host_shape[host_perm[i]];
             }
-        }
-        p.tiles_a = (p.A + 63) / 64;
-        p.tiles_b = (p.B + 63) / 64;
-        const size_t blocks = (size_t)p.tiles_a * p.tiles_b * batch;
-        if (blocks <= 0x7fffffffu) {
-            permute_tiled_kernel<<<(unsigned)blocks, 256, 0, np::stream()>>>(in, out, p);
-            NP_LAUNCH_CHECK("permute_tiled_kernel");
-            return NP_OK;
+            PlanePermuteArgs p{};
+            p.A = (unsigned)host_shape[ax_a];
+            p.B = (unsigned)host_shape[ax_b];
+            p.E = E;
+            p.a_in = in_strides[ax_a];
+            p.b_out = 0;
+            PlaneBatch &pb = p.pb;
+            pb.nbatch = 0;
+            size_t batch = 1;
+            for (int i = 0; i < MAX_ND; ++i) {
+                pb.bshape[i] = 1;
+                pb.bin[i] = pb.bout[i] = 0;
+            }
+            for (int o = 0; o < nd; ++o) {          // o: output axis, fed by input axis host_perm[o]
+                const int ia = host_perm[o];
+                if (ia == ax_b) {
+                    p.b_out = out_strides[o];
+                } else if (ia != ax_a) {
+                    pb.bshape[pb.nbatch] = (unsigned)host_shape[ia];
+                    pb.bin[pb.nbatch] = in_strides[ia];
+                    pb.bout[pb.nbatch] = out_strides[o];
+                    ++pb.nbatch;
+                    batch *= (size_t)host_shape[ia];
+                }
+            }
+            pb.in_pitch = p.a_in;
+            pb.out_pitch = p.b_out;
+            // large planes of single floats: the float4 tile transpose of np_transpose2d, pitched (512-byte row segments)
+            if (E == 1 && p.A >= 64 && p.B >= 64 && batch <= 65535)
+                return transpose_planes(in, out, batch, p.A, p.B, pb);
+            // balanced tiles of at most 4096 floats, as square as the extents allow, runs of >= 64 floats where they can be
+            unsigned side = 64;
+            while (side > 1 && (size_t)side * side * E > 4096) --side;
+            unsigned tb_max = p.B < side ? p.B : side;
+            if (p.A < side) {   // a short A leaves room for a longer B run
+                const size_t room = 4096 / ((size_t)p.A * E);
+                tb_max = (unsigned)(room > 256 ? 256 : room);
+                if (tb_max > p.B) tb_max = p.B;
+                if (tb_max < 1) tb_max = 1;
+            }
+            p.tiles_b = (p.B + tb_max - 1) / tb_max;
+            p.tb = (p.B + p.tiles_b - 1) / p.tiles_b;
+            // LDS row pitch: consecutive a (phase 2's lanes) must not share banks — odd for single floats, else
+            // the run length past a multiple of 64 floats
+            const unsigned row = p.tb * E;
+            p.pitch = E == 1 ? (row | 1u) : ((row + 63) / 64 * 64 + E);
+            unsigned ta_max = 4096 / row < kPlaneLds / p.pitch ? 4096 / row : kPlaneLds / p.pitch;
+            if (ta_max > 256) ta_max = 256;
+            if (ta_max > p.A) ta_max = p.A;
+            if (ta_max < 1) ta_max = 1;
+            p.tiles_a = (p.A + ta_max - 1) / ta_max;
+            p.ta = (p.A + p.tiles_a - 1) / p.tiles_a;
+            auto magic = [](unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / d) + 1); };
+            p.m_tbE = magic(p.tb * E);
+            p.m_taE = magic(p.ta * E);
+            p.m_E = magic(E);
+            const size_t blocks = (size_t)p.tiles_a * p.tiles_b * batch;
+            if (blocks <= 0x7fffffffu && (size_t)p.ta * p.pitch <= kPlaneLds && p.tb * E > 1 && p.ta * E > 1) {
+                permute_plane_kernel<<<(unsigned)blocks, 256, 0, np::stream()>>>(in, out, p);
+                NP_LAUNCH_CHECK("permute_plane_kernel");
+                return NP_OK;
+            }
         }
     }
     // general gather

@@ -257,7 +257,7 @@ int check_device_error(const char *who) {
                                "successful np_sync are incomplete and must be discarded", who,
                 bits & kErrCommWait ? "a stream-ordering wait of np_comm timed out" : "",
                 (bits & kErrCommWait) && (bits & kErrStreamK) ? "; " : "",
-                bits & kErrStreamK ? "a stream-K finisher never saw its peers' partial tiles" : "");
+                bits & kErrStreamK ? "a GEMM workgroup folding K-split partial tiles never saw its siblings' (stream-K / in-launch split-K)" : "");
 }
 
 unsigned *next_ticket() { return next_tickets(1); }

@@ -937,6 +937,336 @@ __global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, Strea
     }
 }
 
+// ---- mid-size products: smaller LDS-DMA tiles, K split INSIDE the launch ---------------------------------------
+// 1024^3 is 32 tiles of 256 x 128: an eighth of the machine.  The forms it had (profiles/r03/gemm_sweep_final.log: 30 us,
+// 72 TFLOP/s, where 13.7 us is the matrix cores' time) were 64 x 64 register-staged tiles (LDS stores, one accumulator per
+// wave), or 256 x 128 tiles with K cut into batch entries and a second launch folding 8 partial matrices.  What a PHP
+// caller multiplies is this size, not 4096^3.  So the LDS-DMA pipeline of sgemm_dma_kernel exists
+// for smaller tiles as well — 128 x 128, 128 x 64, 64 x 64, the same staging (global_load_lds, XOR-swizzled A slots,
+// one barrier per K-tile), with as many LDS buffers as it takes to keep a DMA ~1.5 us ahead of its consumer when a K-tile
+// is only 512-2048 cycles of MFMA — and K can be split S ways inside ONE launch:
+//   * workgroup (tile, s) walks K-chunk s of its tile (chunks are multiples of 16: only the last may be ragged);
+//   * S == 1: it stores its tile.  S > 1: it writes its partial tile to the workspace lane-major with memory-side
+//     stores, reports to the tile's counter, waits until all S partials are there, and then folds ITS SHARE of the tile —
+//     register groups g with g % S == s (S a power of two that divides the group count) — over the S partials in chunk order (its own from registers: the same bits) and
+//     stores that share of C.  Every workgroup folds 1 / S of a tile: the fold is as parallel as the product, its traffic
+//     2 x S x |C| in all, nothing is serial at the end (stream-K's finisher folds its tile's partials alone, one after
+//     the other: 3 us each at the very end of the launch), no second launch.  The sum order is fixed: deterministic.
+//   * the counter is a ticket (np::next_tickets): arrivals count to S, departures to 2 S, the last one out zeroes it.
+// All S workgroups of a tile must be resident at once (they wait for each other): the launcher keeps tiles x S within
+// what the device holds (2 workgroups per CU by registers and LDS), like stream-K.
+template <int BM_, int BN_, int NBUF_>
+struct DmasShape {
+    static constexpr int BM = BM_, BN = BN_, BK = 16, NBUF = NBUF_;
+    static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    static constexpr int AC = BM / 64;          // A: 16-row x 64-byte chunks a wave moves per K-tile
+    static constexpr int BC = BN / 64;          // B: 256-float chunks a wave moves per K-tile
+    static constexpr int A_SZ = BM * BK, B_SZ = BK * BN;
+    static constexpr int GROUPS = TM * TN * 4;  // float4 register groups per lane (the unit of the fold)
+};
+
+struct DmasArgs {
+    unsigned S;             // K chunks per tile
+    unsigned Kc;            // chunk length (multiple of 16)
+    float *workspace;       // S > 1: tiles x S partial tiles of BM x BN floats, lane-major
+    unsigned *counters;     // S > 1: one zeroed ticket per tile
+    unsigned *error_word;   // np::device_error_word(): a wait for the sibling chunks that runs out of polls is reported (np_sync)
+};
+
+template <class SH, bool EDGE, bool KTAIL>
+__global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs d) {
+    constexpr int BM = SH::BM, BN = SH::BN, BK = SH::BK, NBUF = SH::NBUF, WM = SH::WM, WN = SH::WN, TM = SH::TM, TN = SH::TN;
+    constexpr int AC = SH::AC, BC = SH::BC, A_SZ = SH::A_SZ, B_SZ = SH::B_SZ;
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * (A_SZ + B_SZ)];
+    float *const As = smem;
+    float *const Bs = smem + NBUF * A_SZ;
+
+    const unsigned tile = blockIdx.x / d.S, chunk = blockIdx.x - tile * d.S;
+    unsigned tile_m, tile_n;
+    tile_coords(g, tile, tile_m, tile_n);
+    const unsigned m0 = tile_m * BM, n0 = tile_n * BN;
+    const unsigned k_begin = chunk * d.Kc;
+    const unsigned K = (g.K - k_begin < d.Kc) ? g.K - k_begin : d.Kc;   // this chunk's inner length (>= 1 by construction)
+    const float *A = g.A + (size_t)blockIdx.z * g.stride_a + k_begin;
+    const float *B = g.B + (size_t)blockIdx.z * g.stride_b + (size_t)k_begin * g.ldb;
+    float *C = g.C + (size_t)blockIdx.z * g.stride_c;
+
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned li = lane & 31, lh = lane >> 5;
+    const unsigned wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+    // DMA sources (see dma_gemm_segment: the same scheme with AC / BC chunks per wave)
+    const unsigned nk = (K + BK - 1) / BK;
+    const unsigned kr = K - (nk - 1) * BK;          // 16 = no tail
+    const float *a_src[AC];
+    unsigned a_q[AC];
+#pragma unroll
+    for (int c = 0; c < AC; ++c) {
+        const unsigned r = (wave * AC + c) * 16 + (lane >> 2);
+        const unsigned q = (lane & 3) ^ ((r >> 2) & 3);
+        unsigned grow = m0 + r;
+        if (EDGE && grow >= g.M) grow = g.M - 1;
+        a_src[c] = A + (size_t)grow * g.lda + q * 4;
+        a_q[c] = q;
+    }
+    const float *b_src[BC];
+    unsigned b_k[BC];
+    unsigned b_cut = 0;
+#pragma unroll
+    for (int c = 0; c < BC; ++c) {
+        const unsigned off = (wave * BC + c) * 256 + lane * 4;   // float offset inside the [16][BN] tile
+        const unsigned krow = off / BN;
+        unsigned gcol = n0 + off % BN;
+        if (EDGE && gcol + 4 > g.N) {
+            if (gcol >= g.N) gcol = 0;
+            else b_cut = g.N - gcol;
+        }
+        b_src[c] = B + (size_t)krow * g.ldb + gcol;
+        b_k[c] = krow;
+    }
+    const size_t b_step = (size_t)BK * g.ldb;
+
+    auto dma_tile = [&](unsigned buf, bool tail) {
+        float *as = As + buf * A_SZ + wave * (AC * 256);
+        float *bs = Bs + buf * B_SZ + wave * (BC * 256);
+#pragma unroll
+        for (int c = 0; c < AC; ++c) {
+            const float *src = a_src[c];
+            if (KTAIL && tail) {
+                const unsigned k0 = a_q[c] * 4;
+                if (k0 + 4 > kr) src -= k0 + 4 - kr;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(as + c * 256), 16, 0, 0);
+            a_src[c] += BK;
+        }
+#pragma unroll
+        for (int c = 0; c < BC; ++c) {
+            const float *src = b_src[c];
+            if (KTAIL && tail && b_k[c] + 1 >= kr) {
+                if (b_k[c] >= kr) src -= (size_t)(b_k[c] - (kr - 1)) * g.ldb;
+                src -= b_cut ? 4 - b_cut : 0;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(bs + c * 256), 16, 0, 0);
+            b_src[c] += b_step;
+        }
+    };
+    auto shifted = [](v4f v, unsigned s) {
+        return v4f{s == 1 ? v[1] : s == 2 ? v[2] : v[3], s == 1 ? v[2] : s == 2 ? v[3] : 0.0f, s == 1 ? v[3] : 0.0f, 0.0f};
+    };
+    auto zero_tail = [&](unsigned buf) {
+        float *as = As + buf * A_SZ + wave * (AC * 256) + lane * 4;
+        float *bs = Bs + buf * B_SZ + wave * (BC * 256) + lane * 4;
+#pragma unroll
+        for (int c = 0; c < AC; ++c) {
+            const unsigned k0 = a_q[c] * 4;
+            v4f *slot = (v4f *)(as + c * 256);
+            if (k0 >= kr) *slot = v4f{0, 0, 0, 0};
+            else if (k0 + 4 > kr) *slot = shifted(*slot, k0 + 4 - kr);
+        }
+#pragma unroll
+        for (int c = 0; c < BC; ++c) {
+            v4f *slot = (v4f *)(bs + c * 256);
+            if (b_k[c] >= kr) *slot = v4f{0, 0, 0, 0};
+            else if (b_cut && b_k[c] + 1 == kr) *slot = shifted(*slot, 4 - b_cut);
+        }
+    };
+    // only the chunk that ends with K can be ragged; N % 4 != 0 concerns B's very last row, which that chunk holds
+    const bool last_chunk = k_begin + K == g.K;
+    const bool has_tail = KTAIL && last_chunk && (kr < BK || (g.N & 3u) != 0);
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    struct Frag {
+        v4f a4[TM];
+        float bv[4][TN];
+    };
+    const unsigned sw = (li >> 2) & 3;
+    const unsigned a_off0 = (wm0 + li) * BK + ((lh ^ sw) * 4);
+    const unsigned a_off1 = (wm0 + li) * BK + (((2 + lh) ^ sw) * 4);
+    const unsigned b_off = (4 * lh) * BN + wn0 + li;
+    auto read_frag = [&](Frag &f, unsigned buf, int kg) {
+        const float *as = As + buf * A_SZ + (kg ? a_off1 : a_off0);
+        const float *bs = Bs + buf * B_SZ + b_off + kg * 8 * BN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a4[i] = *(const v4f *)(as + i * 32 * BK);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f.bv[s][j] = bs[s * BN + j * 32];
+    };
+    auto mfma_group = [&](const Frag &f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a4[i][s], f.bv[s][j], acc[i][j], 0, 0, 0);
+    };
+    constexpr int kMfmaPerHalf = 4 * TM * TN, kReadsPerHalf = TM + 4 * TN, kDmaPerTile = AC + BC;
+    constexpr int kPaired = kReadsPerHalf < kMfmaPerHalf ? kReadsPerHalf : kMfmaPerHalf;
+
+    // prologue: tiles 0 .. NBUF - 2 in flight
+    const bool tail_in_prologue = has_tail && nk <= (unsigned)(NBUF - 1);
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t)
+        if ((unsigned)t < nk) dma_tile((unsigned)t, has_tail && (unsigned)t + 1 == nk);
+    if (nk >= (unsigned)(NBUF - 1) && !tail_in_prologue) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * kDmaPerTile) : "memory");   // tile 0 has landed
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tail_in_prologue) zero_tail(nk - 1);
+    }
+    __syncthreads();
+    Frag f0, f1;
+    read_frag(f0, 0, 0);
+
+    unsigned cur = 0, kt = 0;
+    auto k_tile = [&](auto dma_c, auto next_c) {
+        constexpr bool DMA = decltype(dma_c)::value, NEXT = decltype(next_c)::value;
+        const unsigned nxt = cur + 1 == (unsigned)NBUF ? 0 : cur + 1;
+        const unsigned into = cur == 0 ? (unsigned)(NBUF - 1) : cur - 1;   // the buffer tile kt - 1 vacated = (kt + NBUF - 1) % NBUF
+        read_frag(f1, cur, 1);
+        mfma_group(f0);
+#pragma unroll
+        for (int q = 0; q < kPaired; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerHalf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NEXT) {
+            // tile kt + 1 must have landed for every wave; in the steady state the tiles behind it (kt + 2 .. kt + NBUF - 2)
+            // may still be in flight, towards the end nothing else is
+            if constexpr (DMA)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 3) * kDmaPerTile) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (has_tail && kt + 2 == nk && !tail_in_prologue) zero_tail(nxt);
+            __syncthreads();
+        }
+        if constexpr (DMA) dma_tile(into, has_tail && kt + (unsigned)NBUF == nk);
+        if constexpr (NEXT) read_frag(f0, nxt, 0);
+        mfma_group(f1);
+        if constexpr (DMA) {
+#pragma unroll
+            for (int q = 0; q < (kDmaPerTile < kMfmaPerHalf ? kDmaPerTile : kMfmaPerHalf); ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (global_load_lds)
+            }
+        }
+        if constexpr (NEXT) {
+#pragma unroll
+            for (int q = 0; q < kPaired; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerHalf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    for (; kt + (unsigned)(NBUF - 1) < nk; ++kt) k_tile(T{}, T{});
+    for (; kt + 1 < nk; ++kt) k_tile(F{}, T{});
+    k_tile(F{}, F{});
+
+    const unsigned row0 = (wave >> 1) * WM + 4 * lh, col0 = (wave & 1) * WN + li;
+    const unsigned lim_n = g.n_store ? g.n_store : g.N;
+    if (d.S == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned row = m0 + row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const unsigned col = n0 + col0 + j * 32;
+                    if (!EDGE || (row < g.M && col < lim_n)) __builtin_nontemporal_store(acc[i][j][r], &C[(size_t)row * g.ldc + col]);
+                }
+        return;
+    }
+    // ---- the fold ----
+    // group G = (i * TN + j) * 4 + q holds acc[i][j][4q .. 4q + 3] of all 256 lanes, lane t's float4 at slot[(G * 256 + t) * 4]
+    const size_t batch_tiles = (size_t)g.tiles_m * g.tiles_n;
+    float *const tile_ws = d.workspace + (((size_t)blockIdx.z * batch_tiles + tile) * d.S) * (size_t)(BM * BN);
+    {
+        float *dst = tile_ws + (size_t)chunk * (BM * BN) + (size_t)tid * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (((unsigned)((i * TN + j) * 4 + q) & (d.S - 1)) != chunk) {   // S is a power of two; its own share never leaves the registers
+                        const v4f v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + ((i * TN + j) * 4 + q) * 1024), "v"(v) : "memory");
+                    }
+                }
+    }
+    unsigned *const counter = d.counters + (size_t)blockIdx.z * batch_tiles + tile;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // all S partials of this tile (bounded like stream-K's wait: a fault elsewhere must not hang the queue; reported)
+        unsigned spins = 0;
+        while (np::dev::coherent_load(counter) < d.S && spins < (1u << 26)) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+        }
+        if (spins == (1u << 26) && d.error_word)
+            __hip_atomic_fetch_or(d.error_word, np::kErrStreamK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned G = (unsigned)((i * TN + j) * 4 + q);
+                if ((G & (d.S - 1)) != chunk) continue;   // uniform
+                v4f sum{0.0f, 0.0f, 0.0f, 0.0f};
+                bool first = true;
+                for (unsigned c = 0; c < d.S; ++c) {   // chunk order: the same sum every run
+                    v4f p;
+                    if (c == chunk) {
+                        p = v4f{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    } else {
+                        const float *src = tile_ws + (size_t)c * (BM * BN) + (size_t)G * 1024 + (size_t)tid * 4;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(p) : "v"(src) : "memory");
+                    }
+                    if (first) sum = p;
+                    else
+                        for (int e = 0; e < 4; ++e) sum[e] += p[e];
+                    first = false;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned r = 4 * q + e;
+                    const unsigned row = m0 + row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const unsigned col = n0 + col0 + j * 32;
+                    if (!EDGE || (row < g.M && col < lim_n)) __builtin_nontemporal_store(sum[e], &C[(size_t)row * g.ldc + col]);
+                }
+            }
+    // departures: the last of the S workgroups to leave puts the ticket back to zero
+    __syncthreads();
+    if (tid == 0 && __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2 * d.S - 1)
+        np::dev::coherent_store(counter, 0u);
+}
+
 // Zero-padded copy of a row-major matrix: out (rows_out x ld_out, ld_out % 4 == 0, 16-byte aligned)
 // = in (rows_in x cols_in, row stride ld_in) in the top-left corner, zeros elsewhere.
 __global__ __launch_bounds__(256) void pad_copy_kernel(const float *__restrict__ in, unsigned ld_in,
@@ -1687,10 +2017,26 @@ int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
 // workgroup's barriers and LDS traffic hide under another's MFMAs), eff1 = with a single workgroup
 // per CU (one wave of tiles or less): 2000^3 on 128x128 tiles is exactly 256 tiles and runs at 0.64,
 // not 0.85 (profiles/r01/gemm_plan_sweep.log).
+//   3-5: sgemm_dmas_kernel 128x128 / 128x64 / 64x64 (round 4): the LDS-DMA pipeline on smaller tiles, whole K or K split
+//        in-launch.  Calibrated against the register-staged kernels ON THE SAME BOX (profiles/r04/gemm_mid_sweep_forced.log):
+//        2048^3 on 256 tiles of 128x128 149 us (the model's 0.64 said 171) -> 0.83; 1024^3 on 256 tiles of 64x64 22.4 us
+//        against the old kernel's 31.1 -> 0.74; several waves: 0.87 / 0.82 / 0.80.  Operands of any alignment (1001 x 1003
+//        x 1002: 26.2 us against 40.6 on the padded / register-staged forms), so these take every product the planner has.
 struct TileCfg { unsigned bm, bn; double eff, eff1; };
-constexpr TileCfg kCfg[3] = {{256, 128, 0.93, 0.89}, {128, 128, 0.85, 0.64}, {64, 64, 0.71, 0.52}};
+constexpr int kCfgCount = 6, kFirstMidCfg = 3;
+constexpr TileCfg kCfg[kCfgCount] = {{256, 128, 0.93, 0.89}, {128, 128, 0.85, 0.64}, {64, 64, 0.71, 0.52},
+                                     {128, 128, 0.87, 0.83}, {128, 64, 0.82, 0.80}, {64, 64, 0.80, 0.74}};
+int g_mid_tiles = 1;   // np_sgemm_set_variant(-14) = 0: plans as before round 4 (no sgemm_dmas_kernel), (-15): back
+constexpr unsigned kDmasBM[3] = {128, 128, 64}, kDmasBN[3] = {128, 64, 64}, kDmasMaxS[3] = {16, 8, 4};   // the shapes of cfg 3 .. 5
+
+int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S);
 
 int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
+    if (cfg >= kFirstMidCfg) {
+        const int rc = launch_dmas(cfg - kFirstMidCfg, g, batch, 1);
+        if (rc != 1) return rc;
+        cfg = cfg == kFirstMidCfg ? 1 : 2;   // (does not apply after all: the register-staged kernel of that size)
+    }
     if (cfg == 0) {
         g.tiles_m = (g.M + 255) / 256;
         g.tiles_n = (g.N + 127) / 128;
@@ -1757,9 +2103,11 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
     const double cus = (double)np::num_cus();
     const double cu_flops = 157.3e12 / 256.0, unit_fixed = 1.5e-6, launch = 3e-6, hbm = 4e12;
     Plan best{2, 0, 1, K, 1e300};
-    for (int c = 0; c < 3; ++c) {
+    const bool mid_ok = g_mid_tiles && !only_dma && N >= 4 && K >= 4 && !g_progress.counters;
+    for (int c = 0; c < kCfgCount; ++c) {
         if (c == 0 && !dma_ok) continue;
         if (c != 0 && only_dma) continue;
+        if (c >= kFirstMidCfg && !mid_ok) continue;
         const TileCfg &T = kCfg[c];
         const size_t tm = (M + T.bm - 1) / T.bm, tn = (N + T.bn - 1) / T.bn;
         // time of `units` work units of k inner steps each
@@ -1769,11 +2117,27 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
             const double blend = waves <= 1.0 ? 0.0 : waves >= 2.0 ? 1.0 : waves - 1.0;
             // the register-staged kernels lose ~1/4 when rows are not float4-loadable (4097^3: 97 vs 132), the LDS-DMA
             // kernel 5-9 % (16-byte fetches that straddle cache lines: profiles/r03/gemm_unaligned.log)
-            const double eff = (T.eff1 + (T.eff - T.eff1) * blend) * (vec ? 1.0 : c == 0 ? 0.93 : 0.78);
+            const double eff = (T.eff1 + (T.eff - T.eff1) * blend) * (vec ? 1.0 : c == 0 ? 0.93 : c >= kFirstMidCfg ? 0.97 : 0.78);
             return ceil(waves) * (2.0 * T.bm * T.bn * (double)k / (eff * cu_flops) + unit_fixed);
         };
         const double whole = span((double)(tm * tn * batch), K);
         if (whole < best.t) best = Plan{c, 0, 1, K, whole};
+        if (c >= kFirstMidCfg) {
+            // K split S ways INSIDE the launch (sgemm_dmas_kernel's distributed fold; tail_rows == 0 and S > 1 says so): few
+            // tiles and a long K.  All S workgroups of a tile are resident together: tiles x S within two per CU.  The fold
+            // moves 2 S |C| bytes through memory-side accesses and ends with a round of waiting (512 x 512 x 4096 on 64 x
+            // 64 tiles: 69 us whole, 27.6 with S = 4, where the chunks alone would be ~22).
+            if (!g_splitk || !splitk || K < 256) continue;
+            const size_t tiles = tm * tn * batch;
+            const unsigned max_s = kDmasMaxS[c - kFirstMidCfg];
+            for (unsigned S = 2; S <= max_s && tiles * S <= (size_t)cus * 2 && tiles <= 256; S *= 2) {
+                const size_t Kc = ((K + S - 1) / S + 15) / 16 * 16;
+                if (Kc < 64 || (size_t)(S - 1) * Kc >= K) break;
+                const double t = span((double)(tiles * S), Kc) + 2.0 * S * (double)(M * N * batch * sizeof(float)) / 3e12 + 2.5e-6;
+                if (t < best.t) best = Plan{c, 0, S, Kc, t};
+            }
+            continue;
+        }
         if (!g_splitk || !splitk || batch != 1 || K < 512) continue;
         // candidate tails: up to one machine-wave worth of tile rows, or everything
         size_t max_tail = (size_t)(cus / (double)tn) + 1;
@@ -1914,6 +2278,61 @@ int launch_streamk(GemmArgs g, unsigned G) {
     return NP_OK;
 }
 
+// ---- launch of sgemm_dmas_kernel ----
+// shape: 0 = 128 x 128 tiles (3 LDS buffers), 1 = 128 x 64 (4), 2 = 64 x 64 (6).  S = K chunks per tile: a power of two,
+// at most the shape's register-group count, chunks of at least 64 inner elements.  Returns 1 when the form does not
+// apply (the caller takes another plan): S workgroups wait for each other, so tiles x S x batch must be resident at once.
+typedef DmasShape<128, 128, 3> DmasShape0;
+typedef DmasShape<128, 64, 4> DmasShape1;
+typedef DmasShape<64, 64, 6> DmasShape2;
+
+template <class SH>
+void launch_dmas_shape(const GemmArgs &g, const DmasArgs &d, dim3 grid, bool edge, bool ktail, hipStream_t s) {
+    if (edge && ktail)
+        sgemm_dmas_kernel<SH, true, true><<<grid, 256, 0, s>>>(g, d);
+    else if (edge)
+        sgemm_dmas_kernel<SH, true, false><<<grid, 256, 0, s>>>(g, d);
+    else if (ktail)
+        sgemm_dmas_kernel<SH, false, true><<<grid, 256, 0, s>>>(g, d);
+    else
+        sgemm_dmas_kernel<SH, false, false><<<grid, 256, 0, s>>>(g, d);
+}
+
+int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
+    if (shape < 0 || shape > 2 || g.N < 4 || g.K < 4 || g.K_last || g.progress) return 1;
+    const unsigned bm = kDmasBM[shape], bn = kDmasBN[shape];
+    g.tiles_m = (g.M + bm - 1) / bm;
+    g.tiles_n = (g.N + bn - 1) / bn;
+    g.swizzle = 0;
+    const size_t tiles = (size_t)g.tiles_m * g.tiles_n;
+    if (S < 1 || (S & (S - 1)) || S > kDmasMaxS[shape]) return 1;
+    unsigned Kc = ((g.K + S - 1) / S + 15) / 16 * 16;
+    while (S > 1 && (Kc < 64 || (size_t)(S - 1) * Kc >= g.K)) {   // every chunk holds work
+        S >>= 1;
+        Kc = ((g.K + S - 1) / S + 15) / 16 * 16;
+    }
+    DmasArgs d{S, S == 1 ? (g.K + 15) / 16 * 16 : Kc, nullptr, nullptr, np::device_error_word()};
+    np::Scratch ws;
+    if (S > 1) {
+        if (tiles * S * batch > (size_t)np::num_cus() * 2 || tiles * batch > 256) return 1;
+        if (int rc = ws.alloc(tiles * batch * S * (size_t)bm * bn * sizeof(float))) return rc;
+        d.workspace = (float *)ws.ptr;
+        d.counters = np::next_tickets((unsigned)(tiles * batch));
+        if (!d.counters) return NP_ERR_ALLOC;
+    }
+    if (tiles * S > 0x7fffffffu) return 1;
+    const dim3 grid((unsigned)(tiles * S), 1, batch);
+    const bool edge = g.M % bm || g.N % bn || g.n_store;
+    const bool ktail = g.K % 16 || g.N % 4;
+    hipStream_t s = np::stream();
+    if (shape == 0) launch_dmas_shape<DmasShape0>(g, d, grid, edge, ktail, s);
+    else if (shape == 1) launch_dmas_shape<DmasShape1>(g, d, grid, edge, ktail, s);
+    else launch_dmas_shape<DmasShape2>(g, d, grid, edge, ktail, s);
+    NP_LAUNCH_CHECK("sgemm_dmas_kernel");
+    return NP_OK;
+}
+int g_force_dmas_shape = -1, g_force_dmas_S = 1;   // np_sgemm_set_variant(-(1000 + 100 * shape + S)): every tiled product through this form (A/B, tests); -999: off
+
 // != 0: the matrices being launched are a PIECE of a batch of this many (np_comm's per-piece pipeline): planned as that
 // batch, so that every piece — a single matrix included — runs the kernel configuration the whole batch would have
 // run, and the pipelined result is bit-identical to the one-call form (np::sgemm_batched_piece)
@@ -1989,6 +2408,10 @@ int launch_planned(GemmArgs g, size_t launch_batch, bool vec) {
 
 int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec) {
     const size_t M = g.M, N = g.n_store ? g.n_store : g.N, K = g.K;   // N: row length of C and of the partials
+    if (p.tail_rows == 0 && p.cfg >= kFirstMidCfg && p.S > 1) {
+        const int rc = launch_dmas(p.cfg - kFirstMidCfg, g, (unsigned)batch, p.S);
+        if (rc != 1) return rc;
+    }
     if (p.tail_rows == 0) return launch_cfg(p.cfg, g, (unsigned)batch, vec);
     const TileCfg &T = kCfg[p.cfg];
     const size_t tm = (M + T.bm - 1) / T.bm;
@@ -2051,6 +2474,10 @@ int launch_sgemm_ld(size_t batch, size_t M, size_t N, size_t K, const float *A, 
         }
     }
 #endif
+    if (g_force_dmas_shape >= 0 && !g.progress && (vec || g_dma_any_alignment)) {
+        const int rc = launch_dmas(g_force_dmas_shape, g, (unsigned)batch, (unsigned)g_force_dmas_S);
+        if (rc != 1) return rc;
+    }
     const int tile = g_variant % 10;
     g.swizzle = (unsigned)(g_variant / 10);
     switch (tile) {
@@ -2398,11 +2825,26 @@ int np_debug_sgemm_probe(void *dev_buf) {
 }
 
 int np_sgemm_set_variant(int variant) {
+    if (variant <= -999) {   // -(1000 + 100 * shape + S): sgemm_dmas_kernel with that tile shape and S K-chunks wherever it applies; -999: off
+        if (variant == -999) {
+            g_force_dmas_shape = -1;
+            return NP_OK;
+        }
+        const int code = -variant - 1000;
+        if (code / 100 > 2 || code % 100 < 1) return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: -(1000 + 100 * shape + S) with shape 0..2, S >= 1");
+        g_force_dmas_shape = code / 100;
+        g_force_dmas_S = code % 100;
+        return NP_OK;
+    }
     if (variant <= -100) {   // -(100 + p): priority alternation between co-resident workgroups, p K-tiles per phase (p = 0: off)
         g_prio_period = (unsigned)(-variant - 100);
         return NP_OK;
     }
     if (variant < 0) {   // -1: whole-K plans only, -2: default planner, -3: default + forced operand padding, -4 / -5: stream-K always / never
+        if (variant == -14 || variant == -15) {   // -14: no mid-size LDS-DMA tiles (the plans of round 3), -15: back
+            g_mid_tiles = variant == -15;
+            return NP_OK;
+        }
         if (variant == -12 || variant == -13) {   // -12: no sgemm_fewrows_kernel (M <= 8 on the tiled kernels, as before), -13: back
             g_fewrows = variant == -13;
             return NP_OK;

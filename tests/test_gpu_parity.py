@@ -150,6 +150,29 @@ def test_binary_exact_broadcast(op, shape, hip, oracle):
         assert_bit_equal(got, oracle.binary(op, a, one_by_c), "%s %s arr,1xC" % (op, shape))
 
 
+@pytest.mark.parametrize("shape", [(2, 1 << 20), (5, (1 << 20) + 256), (7, 1500004), (40, 1 << 20)])
+def test_binary_long_row_operand_column_block_order(shape, hip, oracle):
+    """A row operand of >= 4 MB is walked in column blocks (np_elementwise.hip Ragged::rowblock_rows: the workgroups in flight
+    share a piece of the vector instead of each result row re-reading all of it): the same bits as the plain order
+    (np_elementwise_set_variant(8000)) and as the oracle, with the row vector on either side, quirk flags included."""
+    from numpower_amd.ndarray import NDArray
+    from numpower_amd._lib import check, load
+    lib = load()
+    a, b = _pair(shape, 17)
+    row = b[0].copy()
+    ga, grow = NDArray.array(a).gpu(), NDArray.array(row).gpu()
+    for op in ("add", "multiply", "mod"):
+        for x, y, ox, oy in ((ga, grow, a, row), (grow, ga, row, a)):
+            got = NDArray._binary(op, x, y).cpu().numpy()
+            check(lib.np_elementwise_set_variant(8000))
+            try:
+                plain = NDArray._binary(op, x, y).cpu().numpy()
+            finally:
+                check(lib.np_elementwise_set_variant(0))
+            assert_bit_equal(got, plain, "%s %s vs the plain order" % (op, shape))
+            assert_bit_equal(got, oracle.binary(op, ox, oy), "%s %s" % (op, shape))
+
+
 def test_binary_view_operand(hip, oracle):
     """$a + $a[1]: the row operand is a view into the same buffer (unaligned for odd widths)."""
     from numpower_amd.ndarray import NDArray

@@ -1,0 +1,72 @@
+"""Dev tool: the mid-size tile family (sgemm_dmas_kernel: 128x128 / 128x64 / 64x64 LDS-DMA tiles, K split S ways inside
+the launch with a distributed fold) against the default planner, per shape: time, TFLOP/s and the largest difference from
+the default plan's result in units of |A|.|B| (both are fp32 products of the same inputs; ~1e-7 is rounding).
+np_sgemm_set_variant(-(1000 + 100 * shape + S)) forces the form; shapes/S that do not apply fall back and print '-'.
+Usage: python tools/gemm_mid_sweep.py [short]"""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+from numpower_amd import device as D, synth
+from numpower_amd._lib import load, Timer, check
+
+D.init(0)
+lib = load()
+shapes = [(512,) * 3, (768,) * 3, (1000,) * 3, (1024,) * 3, (1280,) * 3, (1536,) * 3, (2000,) * 3, (2048,) * 3,
+          (256, 4096, 4096), (4096, 4096, 256), (4096, 256, 4096), (1024, 1024, 4096), (2048, 2048, 512), (1001, 1003, 1002),
+          (640, 640, 640), (896, 896, 896), (1152, 1152, 1152), (512, 512, 4096), (3072, 3072, 3072)]
+if len(sys.argv) > 1 and sys.argv[1] == "plans":
+    shapes += [(4096,) * 3, (2560,) * 3, (4000,) * 3, (4097,) * 3, (8192, 8192, 512), (16384, 1024, 1024), (1280, 1280, 8192), (100, 100, 100000)]
+if len(sys.argv) > 1 and sys.argv[1] == "short":
+    shapes = [(768,) * 3, (1000,) * 3, (1024,) * 3, (1536,) * 3, (256, 4096, 4096), (4096, 4096, 256)]
+NAMES = ["128x128", "128x64", "64x64"]
+t = Timer()
+
+
+def run(a, b, c, reps):
+    for _ in range(3):
+        D.sgemm(a, b, out=c)
+    D.sync()
+    t.start()
+    for _ in range(reps):
+        D.sgemm(a, b, out=c)
+    t.stop()
+    return t.elapsed_ms() / reps
+
+
+for (m, n, k) in shapes:
+    A = synth.uniform((m, k), 31, -1.0, 1.0)
+    B = synth.uniform((k, n), 32, -1.0, 1.0)
+    a, b, c = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B), D.DeviceArray((m, n))
+    reps = max(5, min(100, int(4e10 / (2.0 * m * n * k))))
+    flop = 2.0 * m * n * k
+    check(lib.np_sgemm_set_variant(-999))
+    check(lib.np_sgemm_set_variant(-14))      # the planner of round 3: no mid-size LDS-DMA tiles
+    ms_r03 = run(a, b, c, reps)
+    check(lib.np_sgemm_set_variant(-15))
+    ms = run(a, b, c, reps)
+    ref = c.to_host().astype(np.float64)
+    scale = float(np.abs(A[:64]).astype(np.float64).sum(1).max()) * float(np.abs(B).max())   # a cheap bound on |A|.|B| per element
+    print("%5d x %5d x %5d  default %7.1f us %6.1f TF   (round-3 planner %7.1f us %6.1f TF)" % (
+        m, n, k, ms * 1e3, flop / ms / 1e9, ms_r03 * 1e3, flop / ms_r03 / 1e9), flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "plans":      # the planner's choice only
+        for d in (a, b, c):
+            d.free()
+        continue
+    best = (ms, "default")
+    for shape in range(3):
+        line = "      %-8s" % NAMES[shape]
+        for S in (1, 2, 4, 8, 16):
+            check(lib.np_sgemm_set_variant(-(1000 + 100 * shape + S)))
+            D.fill(c, float("nan"))
+            ms = run(a, b, c, reps)
+            got = c.to_host().astype(np.float64)
+            err = float(np.abs(got - ref).max()) / scale if not np.isnan(got).any() else float("nan")
+            line += "  S%-2d %6.1f us %5.1f TF (%.0e)" % (S, ms * 1e3, flop / ms / 1e9, err)
+            if ms < best[0] and err == err and err < 1e-5:
+                best = (ms, "%s S=%d" % (NAMES[shape], S))
+        print(line, flush=True)
+    check(lib.np_sgemm_set_variant(-999))
+    print("      best: %s  %.1f us  %.1f TF" % (best[1], best[0] * 1e3, flop / best[0] / 1e9), flush=True)
+    for d in (a, b, c):
+        d.free()
