@@ -457,6 +457,10 @@ int np_comm_debug_plan(int rank, int world, size_t slab, size_t item_bytes, int 
 /* testing: dst <- src through one grouped ncclSend / ncclRecv pair from this rank to itself on the communication
  * stream, then np_comm_wait() — the P2P transport on a box with a single GPU */
 int np_comm_debug_sendrecv_self(const void *dev_src, void *dev_dst, size_t bytes);
+/* testing: `count` (<= 64) self transfers of `bytes` on the communication stream, not ordered behind the library stream (so
+ * they compete with whatever that stream is running), each bracketed by its own events; host_ms[i] = duration of transfer i.
+ * Returns when the communication stream has drained. */
+int np_comm_debug_loopback_timed(const void *dev_src, void *dev_dst, size_t bytes, int count, float *host_ms);
 /* testing: every piece gathered point-to-point is from now on ALSO sent from this rank to itself into dev_scratch
  * (pieces larger than `bytes` are not): real RCCL traffic next to the GEMM on a box without a peer.  (NULL, 0) = off. */
 int np_comm_debug_loopback(void *dev_scratch, size_t bytes);
@@ -475,6 +479,8 @@ int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 12
 int np_select_set_variant(int variant);   /* order statistics: 0 = plain three passes only (no bracket path, no one-workgroup kernel), 1 = default (n >= 2^26), else the smallest n that takes it */
 int np_select_last_path(int *path);       /* tests / tools: 1 if the last selection ran over the bracket's copied keys, 0 if over the array, 2 if in the one-workgroup kernel (synchronises) */
 int np_reduce_set_variant(int variant);   /* streaming reductions, first pass: workgroups per CU (0 = default) */
+/* tools: the shader clock in MHz a ~20 us probe kernel sees on the library stream right now (synchronises the stream) */
+int np_debug_clock_mhz(float *host_mhz);
 /* testing: a one-lane kernel on the library stream raises `bits` in the process's device-error word — what a device-side wait
  * that gives up does (1 = a stream-ordering wait of np_comm, 2 = a stream-K finisher).  The next np_sync / np_memcpy_d2h /
  * host-result call / np_comm_* call returns NP_ERR_DEVICE once, and clears the word. */

@@ -96,6 +96,7 @@ PROTOTYPES = {
     "np_sgemm_strided_batched_allgather": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]),
     "np_comm_debug_sendrecv_self": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "np_comm_debug_loopback_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
     "np_comm_debug_loopback": (C.c_int, [C.c_void_p, C.c_size_t]),
     "np_comm_debug_plan": (C.c_int, [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_ulonglong), C.c_size_t,
                                      C.POINTER(C.c_size_t)]),
@@ -133,6 +134,7 @@ PROTOTYPES = {
     "np_runtime_set_variant": (C.c_int, [C.c_int]),
     "np_select_last_path": (C.c_int, [C.POINTER(C.c_int)]),
     "np_debug_raise_device_error": (C.c_int, [C.c_uint]),
+    "np_debug_clock_mhz": (C.c_int, [C.POINTER(C.c_float)]),
 }
 
 

@@ -785,6 +785,38 @@ int np_comm_debug_sendrecv_self(const void *dev_src, void *dev_dst, size_t bytes
     return np_comm_wait();
 }
 
+// testing: `count` self transfers of `bytes` (dst <- src through one grouped ncclSend / ncclRecv pair each) on the
+// communication stream, NOT ordered behind the library stream — whatever the library stream is running at the moment (a
+// GEMM loop) competes with them for the CUs — each bracketed by its own event pair; returns once the communication stream
+// has drained, host_ms[i] = the i-th transfer's duration.  The regression test of "a transfer issued next to a running GEMM
+// still gets through" (tests/test_gpu_comm.py), which is what the overlapped pipeline rests on.
+int np_comm_debug_loopback_timed(const void *dev_src, void *dev_dst, size_t bytes, int count, float *host_ms) {
+    if (int rc = need_comm("np_comm_debug_loopback_timed")) return rc;
+    if (!dev_src || !dev_dst || bytes == 0 || count < 1 || count > 64 || !host_ms)
+        return np::fail(NP_ERR_INVALID, "np_comm_debug_loopback_timed: bad arguments");
+    std::vector<hipEvent_t> ev((size_t)count * 2, nullptr);
+    int rc = NP_OK;
+    for (hipEvent_t &e : ev)
+        if (rc == NP_OK && hipEventCreate(&e) != hipSuccess) rc = np::fail(NP_ERR_DEVICE, "hipEventCreate failed");
+    for (int i = 0; i < count && rc == NP_OK; ++i) {
+        if (hipEventRecord(ev[2 * i], g_comm.stream) != hipSuccess) rc = np::fail(NP_ERR_DEVICE, "hipEventRecord failed");
+        ncclResult_t r0 = g_comm.api.GroupStart();
+        if (r0 == ncclSuccess) r0 = g_comm.api.Send(dev_src, bytes, ncclChar, g_comm.rank, g_comm.comm, g_comm.stream);
+        if (r0 == ncclSuccess) r0 = g_comm.api.Recv(dev_dst, bytes, ncclChar, g_comm.rank, g_comm.comm, g_comm.stream);
+        const ncclResult_t r1 = g_comm.api.GroupEnd();
+        if (r0 != ncclSuccess || r1 != ncclSuccess)
+            rc = np::fail(NP_ERR_DEVICE, "self ncclSend/ncclRecv failed: %s", g_comm.api.GetErrorString(r0 != ncclSuccess ? r0 : r1));
+        if (rc == NP_OK && hipEventRecord(ev[2 * i + 1], g_comm.stream) != hipSuccess) rc = np::fail(NP_ERR_DEVICE, "hipEventRecord failed");
+    }
+    if (hipStreamSynchronize(g_comm.stream) != hipSuccess && rc == NP_OK) rc = np::fail(NP_ERR_DEVICE, "hipStreamSynchronize failed");
+    for (int i = 0; i < count && rc == NP_OK; ++i)
+        if (hipEventElapsedTime(host_ms + i, ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = np::fail(NP_ERR_DEVICE, "hipEventElapsedTime failed");
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+    (void)hipGetLastError();
+    return rc;
+}
+
 int np_comm_max(float value, float *host_max) {
     if (!host_max) return np::fail(NP_ERR_INVALID, "np_comm_max: null output");
     if (int rc = need_comm("np_comm_max")) return rc;

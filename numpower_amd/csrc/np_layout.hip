@@ -50,8 +50,11 @@ __device__ __forceinline__ void plane_offsets(const PlaneBatch &p, unsigned batc
 // in: [batch][rows][cols] -> out: [batch][cols][rows].  TILE x TILE floats per workgroup; the LDS
 // tile is padded to TILE+1 floats per row.  Global reads and writes are float4 per lane along
 // rows: TILE*4 contiguous bytes per row segment on both sides (256 B at TILE 64, 512 B at 128).
-// Non-temporal on both sides in both forms (VEC = every row start 16-byte aligned; else dword-aligned float4s, the
-// matrix edge element by element): nothing is re-read.
+// VEC = every row start 16-byte aligned: non-temporal on both sides, nothing is re-read.  Otherwise dword-aligned float4s
+// (the matrix edge element by element) WITHOUT the hint: rows of odd length start anywhere in a 128-byte line, so the
+// first and last line of every 512-byte segment are shared with the neighbouring tile, and the L2 has to merge the two
+// partial writes — streaming stores take that away (8191 x 8193: 4.04 TB/s plain, 3.48 non-temporal, same box,
+// profiles/r04/layout_ab_nt_on_ragged.log).
 template <int TR, int TC, bool VEC>
 __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__restrict__ in,
                                                              float *__restrict__ out, unsigned rows,
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
         if constexpr (VEC) {
             if (r < rows && c < cols) v[j] = __builtin_nontemporal_load((const v4f *)(src + (size_t)r * ipitch + c));
         } else if (r < rows && c + 3 < cols) {
-            v[j] = __builtin_nontemporal_load((const v4f_u *)(src + (size_t)r * ipitch + c));
+            v[j] = *(const v4f_u *)(src + (size_t)r * ipitch + c);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
         if constexpr (VEC) {
             if (orow < cols && ocol < rows) __builtin_nontemporal_store(w, (v4f *)(dst + (size_t)orow * opitch + ocol));
         } else if (orow < cols && ocol + 3 < rows) {
-            __builtin_nontemporal_store(w, (v4f_u *)(dst + (size_t)orow * opitch + ocol));
+            *(v4f_u *)(dst + (size_t)orow * opitch + ocol) = w;
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -501,7 +504,8 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
     {
         int nd = ndim;
         unsigned E = 1;
-        if (nd >= 3 && host_perm[nd - 1] == nd - 1 && host_shape[nd - 1] < 32 && g_tile == 0) {
+        // (runs of up to 8 floats: (64, 128, 1024, 8) 3.19 -> 3.58 TB/s; with 16-float runs the gather is ahead, 3.89 against 3.65)
+        if (nd >= 3 && host_perm[nd - 1] == nd - 1 && host_shape[nd - 1] <= 8 && g_tile == 0) {
             E = (unsigned)host_shape[nd - 1];
             --nd;   // the remaining axes permute elements of E floats; host_perm[0 .. nd) is a permutation of 0 .. nd - 1
         }

@@ -407,6 +407,35 @@ int np_debug_raise_device_error(unsigned bits) {
     return NP_OK;
 }
 
+// One wave spins for ~wall_ticks of the 100 MHz wall clock and reports how many shader cycles went by: the clock the
+// power manager grants at THIS point of the stream (a VALU-bound kernel runs as fast as that clock, an HBM-bound one does
+// not care — tools/pow_clock_probe.py uses it to tell the two apart).
+__global__ void clock_probe_kernel(unsigned long long wall_ticks, unsigned long long *out) {
+    const unsigned long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
+    unsigned long long w1 = w0;
+    while (w1 - w0 < wall_ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        w1 = wall_clock64();
+    }
+    out[0] = __builtin_readcyclecounter() - c0;
+    out[1] = w1 - w0;
+}
+
+// testing / tools: the shader clock (MHz) as seen by a ~20 us probe kernel enqueued on the library stream now (synchronises)
+int np_debug_clock_mhz(float *host_mhz) {
+    if (!host_mhz) return np::fail(NP_ERR_INVALID, "np_debug_clock_mhz: null output");
+    if (int rc = np::ensure_init()) return rc;
+    np::Scratch buf;
+    if (int rc = buf.alloc(2 * sizeof(unsigned long long))) return rc;
+    clock_probe_kernel<<<1, 64, 0, np::stream()>>>(2000ull, (unsigned long long *)buf.ptr);
+    NP_LAUNCH_CHECK("clock_probe_kernel");
+    unsigned long long h[2] = {0, 0};
+    NP_HIP_CHECK(hipMemcpyAsync(h, buf.ptr, sizeof(h), hipMemcpyDeviceToHost, np::stream()));
+    NP_HIP_CHECK(hipStreamSynchronize(np::stream()));
+    *host_mhz = h[1] ? (float)((double)h[0] / ((double)h[1] / 100.0)) : 0.0f;
+    return NP_OK;
+}
+
 int np_set_stream(void *hip_stream) {
     if (int rc = np::ensure_init()) return rc;
     DeviceState &d = rt().cur();

@@ -2099,15 +2099,22 @@ bool g_splitk = true;   // np_sgemm_set_variant(-1) turns the K-splitting plans 
 // 2*bm*bn*k / (eff * peak per CU) + a fixed prologue/epilogue, the reduce costs its HBM traffic.
 struct Plan { int cfg; unsigned tail_rows, S; size_t Kc; double t; };
 
-Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool only_dma = false, bool vec = true, bool splitk = true) {
+// t_alt: the modelled time of an alternative the caller holds (stream-K): the mid-size tiles must clear it as well
+Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool only_dma = false, bool vec = true, bool splitk = true,
+                double t_alt = 1e300) {
     const double cus = (double)np::num_cus();
     const double cu_flops = 157.3e12 / 256.0, unit_fixed = 1.5e-6, launch = 3e-6, hbm = 4e12;
     Plan best{2, 0, 1, K, 1e300};
+    Plan best_other{2, 0, 1, K, 1e300};   // the best plan WITHOUT the mid-size tiles (see the end of the function)
     const bool mid_ok = g_mid_tiles && !only_dma && N >= 4 && K >= 4 && !g_progress.counters;
     for (int c = 0; c < kCfgCount; ++c) {
         if (c == 0 && !dma_ok) continue;
         if (c != 0 && only_dma) continue;
         if (c >= kFirstMidCfg && !mid_ok) continue;
+        if (c == kFirstMidCfg) {   // cfg 0 .. 2 are done: what follows competes with their best
+            best_other = best;
+            best = Plan{2, 0, 1, K, 1e300};
+        }
         const TileCfg &T = kCfg[c];
         const size_t tm = (M + T.bm - 1) / T.bm, tn = (N + T.bn - 1) / T.bn;
         // time of `units` work units of k inner steps each
@@ -2161,7 +2168,13 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
             }
         }
     }
-    return best;
+    // The mid-size tiles were calibrated on one box, the older forms (and stream-K, which launch_planned weighs against what
+    // is returned here) on others; where the two models are within a few per cent of each other the measured order goes
+    // either way (2560^3: the model's 323 us on 128 x 128 tiles was right — and stream-K's 296 was better; profiles/r04/
+    // gemm_plans_first.log).  They are taken where they are CLEARLY ahead: up to ~1100^3, thin K, ragged small products.
+    if (!mid_ok) return best;              // (the loop never reached cfg 3: `best` is the old best)
+    const double rival = best_other.t < t_alt ? best_other.t : t_alt;
+    return best.t < 0.93 * rival ? best : best_other;
 }
 
 int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec);
@@ -2345,7 +2358,6 @@ int launch_planned(GemmArgs g, size_t launch_batch, bool vec) {
     // C as a window of a wider matrix (the main block of a peeled product, launch_peeled): the split-K plans fold their
     // partials into a dense C, so they — and the pad path, which may take one — are left out
     const bool dense_c = g.ldc == g.N && g.ldb == g.N;
-    Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec, dense_c);
 #ifdef NP_TUNING   // tuning builds only (python -m numpower_amd.build --tuning): plan tracing
     static const bool debug = getenv("NP_SGEMM_PLAN_DEBUG") != nullptr;
 #else
@@ -2361,6 +2373,7 @@ int launch_planned(GemmArgs g, size_t launch_batch, bool vec) {
         t_sk = streamk_model(M, N, K, &sk_grid) / (vec ? 1.0 : 0.93);
         if (debug && t_sk < 1e299) fprintf(stderr, "[np_sgemm] %zux%zux%zu stream-K model %.1f us on %u workgroups\n", M, N, K, t_sk * 1e6, sk_grid);
     }
+    Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec, dense_c, t_sk);
     const bool take_sk = t_sk < 1e299 && (g_streamk > 0 || t_sk < 0.99 * p.t);
     if (!vec && batch == 1 && g_splitk && dense_c && N >= 1) {   // padded copies + the aligned kernel: still the faster form for the largest products
         const size_t Kp = (K + 15) / 16 * 16, Np = (N + 3) / 4 * 4;

@@ -254,3 +254,62 @@ def test_bad_arguments(hip):
     for args in ((1, 1, b"tcp://127.0.0.1:1"), (-1, 2, b"x"), (0, 0, b"x"), (0, 1, b"")):
         with pytest.raises(NumPowerError):
             check(lib.np_comm_init(*args))
+
+
+def test_a_transfer_issued_next_to_a_running_gemm_gets_through(hip):
+    """The overlapped pipeline of config 5 rests on an RCCL transfer making progress WHILE a GEMM owns the CUs (VERDICT r03
+    weak #4: a scheduling assumption).  World > 1 cannot run on a one-GPU lease; the transport can — self send / recv pairs on
+    the communication stream (np_comm_debug_loopback_timed: not ordered behind the library stream, each with its own event
+    pair) next to a queue of GEMMs on the library stream.  What was measured (profiles/r04/comm_contention.log) and is held
+    here with slack: a 32 MiB transfer takes 0.034 ms alone; next to the slab GEMM of config 5 (64 x 1024^3: four rounds of
+    workgroups, some retire all the time) 0.06-0.33 ms — it waits for CUs, a fraction of a round; next to a 4096^3 product
+    (512 workgroups = ONE resident round) up to one whole product, ~1 ms.  Not the 1.3 x stand-alone one would wish for —
+    but bounded by one round of the GEMM's workgroups, and far from "after the queue": the transfers are back while >= 80 % of
+    the GEMM work is still queued."""
+    import time
+    lib = load()
+    check(lib.np_comm_init(0, 1, ("tcp://127.0.0.1:%d" % free_port()).encode()))
+    try:
+        nbytes, count = 32 << 20, 8
+        src, dst = hip.DeviceArray((nbytes // 4,)), hip.DeviceArray((nbytes // 4,))
+        hip.fill(src, 1.25)
+        hip.fill(dst, 0.0)
+        ms = (C.c_float * count)()
+
+        def transfers():
+            check(lib.np_comm_debug_loopback_timed(src.ptr, dst.ptr, nbytes, count, ms))
+            return np.array(list(ms))
+
+        transfers()
+        alone = float(np.median(transfers()))
+        assert (dst.to_host() == np.float32(1.25)).all()
+        assert alone < 0.5, alone
+
+        def under(launch, loops):
+            for _ in range(3):
+                launch()
+            hip.sync()
+            t0 = time.perf_counter()
+            for _ in range(loops):
+                launch()
+            t = transfers()
+            back = time.perf_counter() - t0
+            hip.sync()
+            return t, back, time.perf_counter() - t0
+
+        per, m = 64, 1024
+        A, B, Cm = hip.DeviceArray((per, m, m)), hip.DeviceArray((per, m, m)), hip.DeviceArray((per, m, m))
+        hip.fill(A, 0.5)
+        hip.fill(B, 0.25)
+        t, back, done = under(lambda: check(lib.np_sgemm_strided_batched(per, m, m, m, A.ptr, m * m, B.ptr, m * m, Cm.ptr, m * m)), 40)
+        assert back < 0.2 * done, ("the transfers waited for the GEMM queue", back, done)
+        assert t.max() <= alone + 0.8, ("next to the slab GEMM", t, alone)       # measured <= 0.33 ms
+        n = 4096
+        A2, B2, C2 = hip.DeviceArray((n, n)), hip.DeviceArray((n, n)), hip.DeviceArray((n, n))
+        hip.fill(A2, 0.5)
+        hip.fill(B2, 0.25)
+        t, back, done = under(lambda: hip.sgemm(A2, B2, out=C2), 40)
+        assert back < 0.5 * done, ("the transfers waited for the GEMM queue", back, done)
+        assert t.max() <= alone + 2.0, ("next to 4096^3 (one resident round): at most ~one product", t, alone)   # measured <= 0.98 ms
+    finally:
+        check(lib.np_comm_destroy())

@@ -1,0 +1,76 @@
+#!/bin/bash
+# What runs on a GPU lease, in one place (rounds 2 and 3 kept one script per lease: tools/attic/gpu_r0*.sh).
+#   gpurun --timeout 1500 -- 'bash tools/gpu_lease.sh <recipe> [tag]'
+# Recipes (outputs under gpurun_out/<tag>/, tag defaults to the recipe name; copy what should be judged to profiles/rNN/):
+#   tests      the -m gpu suite (the gate)
+#   bench      bench.py twice: default flags and the driver's (--steps 20 --warmup 5)
+#   world1     bench.py's N > 1 code paths on one GPU (torch.distributed plumbing, then the C-ABI communicator)
+#   profile    rocprofv3 --kernel-trace --stats of bench.py -> bench_kernel_stats.csv
+#   counters   the PMC passes (their own runs, as the guide prescribes): HBM traffic (FETCH_SIZE / WRITE_SIZE ->
+#              pmc_traffic.json), MFMA / SQ counters of the headline kernels (-> gemm_pmc.json, pmc_sq.txt)
+#   sweeps     GEMM shape sweeps, the layout and misc sweeps, the compiled-chain A/B
+#   evidence   all of the above, in that order (the round's evidence run)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+RECIPE=${1:-tests}
+TAG=${2:-$RECIPE}
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+cd "$R" || exit 1
+
+r_tests() {
+    timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 > "$O/pytest_gpu.log"
+    tail -4 "$O/pytest_gpu.log"
+}
+r_bench() {
+    python bench.py > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"
+    python bench.py --steps 20 --warmup 5 > "$O/bench_driver_args.json" 2> "$O/bench_driver_args.err"; echo "bench (driver args) rc=$?"
+    python - "$O" <<'PY'
+import json, sys
+for name in ("bench.json", "bench_driver_args.json"):
+    try:
+        j = json.load(open(sys.argv[1] + "/" + name))
+    except Exception as e:
+        print(name, "unreadable", e); continue
+    print(name, round(j["value"]), "GFLOP/s  frac", round(j["roofline"]["frac"], 3), " add", j["roofline"].get("secondary_frac"))
+    print("   ", json.dumps(j.get("summary", {}))[:1500])
+PY
+}
+r_world1() {
+    NP_BENCH_FORCE_DIST=1 timeout 600 python bench.py --steps 20 --warmup 5 > "$O/bench_world1_torch.json" 2> "$O/w1t.err"; echo "world1 torch rc=$?"
+    NP_BENCH_FORCE_DIST=1 NP_COMM=abi timeout 600 python bench.py --steps 20 --warmup 5 > "$O/bench_world1_abi.json" 2> "$O/w1a.err"; echo "world1 abi rc=$?"
+}
+r_profile() {
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/kt" -o bench --output-format csv -- python "$R/bench.py" > "$O/bench_under_rocprof.json" 2> "$O/bench_under_rocprof.err")
+    cp "$O"/kt/*kernel_stats.csv "$O/bench_kernel_stats.csv" 2>/dev/null
+    head -16 "$O/bench_kernel_stats.csv" | cut -c1-200
+}
+r_counters() {
+    (cd /tmp && export TMPDIR=/tmp
+     timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$O/fetch" -o f --output-format csv -- python "$R/tools/prof_kernels.py" 3 > "$O/fetch.log" 2>&1
+     timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$O/write" -o w --output-format csv -- python "$R/tools/prof_kernels.py" 3 > "$O/write.log" 2>&1
+     timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE -d "$O/p1" -o p1 --output-format csv -- python "$R/tools/prof_counters.py" 5 gemm,pow,add,cols,rows > "$O/p1.log" 2>&1
+     timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d "$O/p2" -o p2 --output-format csv -- python "$R/tools/prof_counters.py" 5 gemm,pow,add,cols,rows > "$O/p2.log" 2>&1)
+    python tools/pmc_summary.py "$O"/p1/*counter_collection.csv "$O"/p2/*counter_collection.csv > "$O/pmc_sq.txt" 2>&1
+    python tools/pmc_summary.py "$O"/fetch/*counter_collection.csv "$O"/write/*counter_collection.csv > "$O/pmc_summary.txt" 2>&1
+    python tools/pmc_traffic.py "$O"/fetch/*counter_collection.csv "$O"/write/*counter_collection.csv "$O/pmc_traffic.json"
+    python tools/gemm_pmc_json.py "$O/gemm_pmc.json" "$O"/p1/*counter_collection.csv "$O"/p2/*counter_collection.csv
+    cat "$O/pmc_sq.txt" | cut -c1-260
+}
+r_sweeps() {
+    timeout 600 python tools/gemm_sweep.py > "$O/gemm_sweep.log" 2>&1; tail -30 "$O/gemm_sweep.log"
+    timeout 300 python tools/gemm_mid_sweep.py plans > "$O/gemm_mid_plans.log" 2>&1; cat "$O/gemm_mid_plans.log"
+    timeout 300 python tools/misc_sweep.py > "$O/misc_sweep.log" 2>&1
+    timeout 200 python tools/layout_sweep.py > "$O/layout_sweep.log" 2>&1; cat "$O/layout_sweep.log"
+    timeout 200 python tools/fused_static_ab.py 2 > "$O/fused_static_ab.log" 2>&1; tail -14 "$O/fused_static_ab.log"
+}
+
+case "$RECIPE" in
+    tests) r_tests ;;
+    bench) r_bench ;;
+    world1) r_world1 ;;
+    profile) r_profile ;;
+    counters) r_counters ;;
+    sweeps) r_sweeps ;;
+    evidence) r_tests; r_bench; r_world1; r_profile; r_counters; r_sweeps ;;
+    *) echo "unknown recipe $RECIPE (tests | bench | world1 | profile | counters | sweeps | evidence)"; exit 2 ;;
+esac

@@ -14,7 +14,10 @@ KEYS = [  # bench key, substring(s) identifying the kernel
     ("add_row_broadcast", ["binary_vec_kernel<0, 0, 2,"]),
     ("add_col_broadcast", ["binary_vec_kernel<0, 0, 3,"]),
     ("sum_axis0", ["reduce_axis_cols<0, false"]),
-    ("fused_chain_1e8", ["fused_chain_kernel"]),
+    ("fused_chain_1e8", [">, -1>", "fused_chain_kernel"]),          # cchain_flat_kernel<CChain<...>, -1> (store)
+    ("fused_chain_sum_1e8", [">, 0>(", ">, 0>"]),                   # cchain_flat_kernel<CChain<...>, 0> (sum)
+    ("sum_exp_axis0_fused", ["cchain_cols_kernel", "fused_chain_cols_kernel"]),
+    ("sum_exp_axis1_fused", ["cchain_rows_kernel", "fused_chain_rows_kernel"]),
     ("transpose_65536x4096", ["transpose_tile_kernel"]),
 ]
 

@@ -27,11 +27,19 @@ for _ in range(iters): D.reduce_all("sum", a)
 import ctypes as C
 from numpower_amd._lib import BINARY_OPS, UNARY_OPS, FusedOp, check, load
 lib = load()
-prog = (FusedOp * 3)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0), FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 1, N // 8 * 8),
+prog = (FusedOp * 3)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0), FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 0, 0),
                      FusedOp(1, BINARY_OPS["add"], 2, 0, 0, 0, 0, 0))
 two = C.c_float(2.0)
 ptrs = (C.c_void_p * 3)(a.ptr, b.ptr, C.cast(C.pointer(two), C.c_void_p)); kinds = (C.c_int * 3)(0, 0, 4)
 for _ in range(iters): check(lib.np_fused_chain(ptrs, kinds, 3, prog, 3, o.ptr, 1, N))
+# ... the same chain ending in a sum (device result), and sum(exp(X), axis) over 25000 x 4000: the compiled chains
+dsum = D.DeviceArray((1,))
+for _ in range(iters): check(lib.np_fused_chain_reduce_dev(ptrs, kinds, 3, prog, 3, 0, 1, N, dsum.ptr))
+prog1 = (FusedOp * 1)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0))
+ptrs1 = (C.c_void_p * 1)(a.ptr); kinds1 = (C.c_int * 1)(0)
+red0 = D.DeviceArray((4000,)); red1 = D.DeviceArray((25000,))
+for _ in range(iters): check(lib.np_fused_chain_reduce_axis(ptrs1, kinds1, 1, prog1, 1, 0, 25000, 4000, 0, red0.ptr))
+for _ in range(iters): check(lib.np_fused_chain_reduce_axis(ptrs1, kinds1, 1, prog1, 1, 0, 25000, 4000, 1, red1.ptr))
 D.sync()
 a.free(); b.free(); o.free()
 X = D.DeviceArray((65536, 4096)); D.fill(X, 0.5); out = D.DeviceArray((4096,)); out1 = D.DeviceArray((65536,))
