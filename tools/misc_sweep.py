@@ -33,11 +33,15 @@ for off_a, off_o, n in ((0, 0, N), (1, 0, N), (0, 1, N), (1, 1, N), (1, 2, N - 3
     line("exp a+%d out+%d n=%d" % (off_a, off_o, n),
          run(lambda: check(lib.np_unary(UNARY_OPS["exp"], big.ptr + 4 * off_a, out.ptr + 4 * off_o, n, 0.0, 0.0))), 8.0 * n)
 print("broadcast with odd row lengths")
-for rows, cols in ((25000, 4000), (25000, 4001), (33333, 3001), (10_000_000, 7), (7, 10_000_000), (1_000_000, 100)):
+for rows, cols in ((25000, 4000), (25000, 4001), (33333, 3001), (10_000_000, 7), (7, 10_000_000), (40, 2_000_000), (1_000_000, 100)):
     n = rows * cols
     row = D.DeviceArray((cols,)); D.fill(row, 2.0); col = D.DeviceArray((rows,)); D.fill(col, 3.0)
     line("X + row  %dx%d" % (rows, cols), run(lambda: check(lib.np_binary(0, big.ptr, 0, row.ptr, 2, out.ptr, rows, cols, 0, 0))), 8.0 * n)
     line("X + col  %dx%d" % (rows, cols), run(lambda: check(lib.np_binary(0, big.ptr, 0, col.ptr, 3, out.ptr, rows, cols, 0, 0))), 8.0 * n)
+    if cols >= (1 << 20):   # a long row operand: the column-block work order (default) against the plain one
+        check(lib.np_elementwise_set_variant(8000))
+        line("X + row  %dx%d, plain order (variant 8000)" % (rows, cols), run(lambda: check(lib.np_binary(0, big.ptr, 0, row.ptr, 2, out.ptr, rows, cols, 0, 0))), 8.0 * n)
+        check(lib.np_elementwise_set_variant(0))
     row.free(); col.free()
 print("transpose / permute / strided copy")
 for rows, cols in ((8192, 8192), (8191, 8193), (10_000_000, 3), (3, 10_000_000), (100_000, 1000), (1000, 100_000), (4099, 4099)):
