@@ -30,11 +30,13 @@ template <typename I>
 struct Ragged {
     I cols;
     unsigned m, s1, s2;
-    // A ROW operand too long to stay cached (X + r with 7 x 10^7: each of the 7 result rows re-read the 40 MB vector,
-    // 4.8 TB/s where X + col ran 6.4): rowblock_rows = rows of the result switches the work order from row-major to
-    // column blocks — workgroup w takes 256 float4 slots of column block w / rows in row w % rows, so the workgroups in
-    // flight together need the same piece of the vector, which then comes from HBM once.  wspace = rows x column blocks x
-    // 256 work items.  0 = off (the plain order).
+    // A ROW operand too long to stay cached (X + r with 7 x 10^7: each of the 7 result rows re-reads the 40 MB vector,
+    // 4.8 TB/s where X + col runs 6.3): rowblock_rows = rows of the result switches the work order from row-major to
+    // column blocks, XCD by XCD — workgroup w (dispatched to XCD w % 8) takes 256 float4 slots of column block
+    // (w / 8 / rows) * 8 + w % 8 in row (w / 8) % rows: the workgroups that need the same 4 KiB piece of the vector follow
+    // each other on ONE XCD and find it in that XCD's L2 (sharing it across consecutive workgroups, i.e. across the eight
+    // private L2s, changed nothing: profiles/r04/misc_sweep.log).  wspace = rows x column blocks (rounded up to 8) x 256
+    // work items.  0 = off (the plain order).
     unsigned rowblock_rows;
     I wspace;
 };
@@ -124,8 +126,8 @@ __global__ __launch_bounds__(256) void binary_vec_kernel(const float *__restrict
         if constexpr (ROWBLOCK) {
             if (rg.rowblock_rows) {   // uniform
                 const unsigned wg = __builtin_amdgcn_readfirstlane((unsigned)w >> 8);   // a workgroup's 256 items share it
-                const unsigned cb = wg / rg.rowblock_rows, row = wg - cb * rg.rowblock_rows;
-                const unsigned c = cb * 256u + ((unsigned)w & 255u);
+                const unsigned j = wg >> 3, grp = j / rg.rowblock_rows, row = j - grp * rg.rowblock_rows;
+                const unsigned c = (grp * 8u + (wg & 7u)) * 256u + ((unsigned)w & 255u);
                 ok = w < limit && c < (unsigned)cols4;
                 return (I)(row * (unsigned)cols4 + c);
             }
@@ -376,10 +378,12 @@ int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size
     unsigned grid = grid_for(n / 4 + 1, c.unroll, c.blocks_per_cu);
     hipStream_t s = np::stream();
     Ragged<I> rg{0, 0, 0, 0, 0, 0};
-    // a ROW operand of >= 4 MB under a result of several rows: column-block order (Ragged::rowblock_rows; variant 8000: off)
-    if ((AK == NP_ROW || BK == NP_ROW) && OP != NP_POW && sizeof(I) == 4 && cols % 4 == 0 && cols >= (size_t(1) << 20) && n / cols >= 2 &&
+    // a ROW operand of >= 16 MB under a result of several rows: column-block order (Ragged::rowblock_rows; variant 8000: off).
+    // 7 x 10^7 4.79 -> 5.71 TB/s, 3 x 3*10^7 4.84 -> 5.73; an 8 MB vector (40 x 2*10^6) is served by the Infinity Cache either
+    // way and loses 2 % to the index arithmetic (tools/rowblock_ab.py, profiles/r04/rowblock_ab.log)
+    if ((AK == NP_ROW || BK == NP_ROW) && OP != NP_POW && sizeof(I) == 4 && cols % 4 == 0 && cols >= (size_t(1) << 22) && n / cols >= 2 &&
         n / cols < (size_t(1) << 16) && g_variant != 8000) {
-        const size_t rows = n / cols, col_blocks = (cols / 4 + 255) / 256;
+        const size_t rows = n / cols, col_blocks = ((cols / 4 + 255) / 256 + 7) / 8 * 8;
         if (rows * col_blocks * 256 < (size_t(1) << 31)) {
             rg.rowblock_rows = (unsigned)rows;
             rg.wspace = (I)(rows * col_blocks * 256);

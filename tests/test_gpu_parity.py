@@ -150,9 +150,9 @@ def test_binary_exact_broadcast(op, shape, hip, oracle):
         assert_bit_equal(got, oracle.binary(op, a, one_by_c), "%s %s arr,1xC" % (op, shape))
 
 
-@pytest.mark.parametrize("shape", [(2, 1 << 20), (5, (1 << 20) + 256), (7, 1500004), (40, 1 << 20)])
+@pytest.mark.parametrize("shape", [(2, 1 << 22), (3, (1 << 22) + 256), (5, 4500004), (9, 1 << 22)])
 def test_binary_long_row_operand_column_block_order(shape, hip, oracle):
-    """A row operand of >= 4 MB is walked in column blocks (np_elementwise.hip Ragged::rowblock_rows: the workgroups in flight
+    """A row operand of >= 16 MB is walked in column blocks (np_elementwise.hip Ragged::rowblock_rows: the workgroups in flight
     share a piece of the vector instead of each result row re-reading all of it): the same bits as the plain order
     (np_elementwise_set_variant(8000)) and as the oracle, with the row vector on either side, quirk flags included."""
     from numpower_amd.ndarray import NDArray
