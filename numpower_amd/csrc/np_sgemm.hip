@@ -2027,6 +2027,7 @@ constexpr int kCfgCount = 6, kFirstMidCfg = 3;
 constexpr TileCfg kCfg[kCfgCount] = {{256, 128, 0.93, 0.89}, {128, 128, 0.85, 0.64}, {64, 64, 0.71, 0.52},
                                      {128, 128, 0.87, 0.83}, {128, 64, 0.82, 0.80}, {64, 64, 0.80, 0.74}};
 int g_mid_tiles = 1;   // np_sgemm_set_variant(-14) = 0: plans as before round 4 (no sgemm_dmas_kernel), (-15): back
+int g_mid_swizzle = 1;   // np_sgemm_set_variant(-16) = 0: sgemm_dmas_kernel walks its tiles row-major, (-17): XCD-aware bands (default)
 constexpr unsigned kDmasBM[3] = {128, 128, 64}, kDmasBN[3] = {128, 64, 64}, kDmasMaxS[3] = {16, 8, 4};   // the shapes of cfg 3 .. 5
 
 int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S);
@@ -2319,6 +2320,11 @@ int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
     g.swizzle = 0;
     const size_t tiles = (size_t)g.tiles_m * g.tiles_n;
     if (S < 1 || (S & (S - 1)) || S > kDmasMaxS[shape]) return 1;
+    // XCD-aware tile order (tile_coords): workgroup b runs on XCD b % 8, and with the plain row-major order the 32
+    // workgroups of one XCD need ALL of A (1024^3 on 64 x 64 tiles: 4 MiB + half a MiB of B — more than its 4 MiB L2).
+    // Bands of 4 tile rows give every XCD a compact patch (4 x 8 tiles: 1 MiB of A, 2 MiB of B).  Whole-K launches only:
+    // with S > 1 the S chunks of a tile sit on S different XCDs by construction.  (np_sgemm_set_variant(-16): off, -17: on)
+    if (g_mid_swizzle && S == 1 && g.tiles_m >= 8 && tiles >= 64) g.swizzle = 4;
     unsigned Kc = ((g.K + S - 1) / S + 15) / 16 * 16;
     while (S > 1 && (Kc < 64 || (size_t)(S - 1) * Kc >= g.K)) {   // every chunk holds work
         S >>= 1;
@@ -2854,6 +2860,10 @@ int np_sgemm_set_variant(int variant) {
         return NP_OK;
     }
     if (variant < 0) {   // -1: whole-K plans only, -2: default planner, -3: default + forced operand padding, -4 / -5: stream-K always / never
+        if (variant == -16 || variant == -17) {
+            g_mid_swizzle = variant == -17;
+            return NP_OK;
+        }
         if (variant == -14 || variant == -15) {   // -14: no mid-size LDS-DMA tiles (the plans of round 3), -15: back
             g_mid_tiles = variant == -15;
             return NP_OK;
