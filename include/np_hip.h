@@ -475,7 +475,7 @@ int np_comm_debug_loopback(void *dev_scratch, size_t bytes);
 int np_runtime_set_variant(int variant);   /* how host-result calls wait: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag, 2 = spin on the result itself (default) */
 int np_sgemm_set_variant(int variant);
 int np_elementwise_set_variant(int variant);   /* launch shape of the streaming kernels (np_elementwise.hip cfg_from_variant) and A/B switches of single kernels, e.g. 9000 = np_binary(pow) with its log2 table in LDS instead of registers (same bits) */
-int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128 */
+int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128; 1 = default tiles without the write-aligned form for output rows off the 128-byte grid */
 int np_select_set_variant(int variant);   /* order statistics: 0 = plain three passes only (no bracket path, no one-workgroup kernel), 1 = default (n >= 2^26), else the smallest n that takes it */
 int np_select_last_path(int *path);       /* tests / tools: 1 if the last selection ran over the bracket's copied keys, 0 if over the array, 2 if in the one-workgroup kernel (synchronises) */
 int np_reduce_set_variant(int variant);   /* streaming reductions, first pass: workgroups per CU (0 = default) */

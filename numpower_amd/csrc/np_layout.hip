@@ -126,6 +126,89 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
     }
 }
 
+// The same transpose for OUTPUT rows that do not start on the 128-byte line grid (out_pitch % 32 != 0: 8196 x 8192 ran 4.9
+// TB/s where 8192^2 runs 6.3 — it is the write side that pays for misalignment, profiles/r04/transpose_alignment_probe.log:
+// every 512-byte segment shares its first and last line with the neighbouring tile, two partial-line writes per segment).
+// Here the tile's window in output row o is shifted left by s(o) = (o * rows) mod 32 floats, so that it starts ON a line:
+// windows of consecutive tiles still tile the row, every store is a whole aligned float4 of whole lines (non-temporal),
+// only an output row's two ends are partial.  In input terms the workgroup needs, for input column c, the input rows
+// by * TR - s(c) ... + TR: it reads TR + 32 rows of its column block (the 32 extra ones are the neighbouring tile's, mostly
+// cache hits) and files each element under its column's shift.  `out` must be 128-byte aligned (pool blocks are).
+template <int TR, int TC>
+__global__ __launch_bounds__(256) void transpose_walign_kernel(const float *__restrict__ in, float *__restrict__ out, unsigned rows,
+                                                               unsigned cols, unsigned tiles_x, unsigned tiles_y, PlaneBatch pb) {
+    constexpr int C4 = TC / 4, RPP = 256 / C4, PASSES = (TR + 32) / RPP, HALF = PASSES / 2;
+    constexpr int OC4 = TR / 4, ORPP = 256 / OC4, OPASSES = TC / ORPP;
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    typedef v4f v4f_u __attribute__((aligned(4)));
+    size_t off_in, off_out;
+    plane_offsets(pb, blockIdx.z, off_in, off_out);
+    const float *src = in + off_in;
+    float *dst = out + off_out;
+    const size_t ipitch = pb.in_pitch, opitch = pb.out_pitch;
+    const unsigned bx = blockIdx.x % tiles_x;
+    const unsigned by = (blockIdx.x / tiles_x + bx) % tiles_y;
+    const int r0 = (int)(by * TR);
+    const unsigned c0 = bx * TC;
+    const unsigned tx4 = threadIdx.x % C4, ty = threadIdx.x / C4;
+    const unsigned rm = (unsigned)(opitch & 31u);   // (o * opitch) mod 32 = ((o mod 32) * (opitch mod 32)) mod 32
+    // LDS row pitch: column cc's elements sit at cc * LDT + (position + shift(cc)), and shift(cc) advances by rm per column —
+    // the banks a wave's lanes hit are cc * (LDT + rm) mod 64, so LDT + rm must be odd (with the usual TR + 1 and
+    // rm = 31, 8191 x 8193, every lane of a wave hit the SAME bank: 3.4 TB/s)
+    const int LDT = TR + ((rm & 1u) ? 2 : 1);
+    const unsigned c = c0 + 4 * tx4;
+    int shift[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) shift[k] = (int)(((c + k) * rm) & 31u);
+    const bool vec_in = (ipitch & 3u) == 0 && (((uintptr_t)src) & 15u) == 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        v4f v[HALF];
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int R = r0 - 32 + (int)ty + RPP * (h * HALF + j);   // input row
+            v[j] = v4f{0, 0, 0, 0};
+            if (R >= 0 && R < (int)rows) {
+                const float *p = src + (size_t)R * ipitch + c;
+                if (c + 3 < cols) v[j] = vec_in ? __builtin_nontemporal_load((const v4f *)p) : *(const v4f_u *)p;
+                else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c + k < cols) v[j][k] = p[k];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < HALF; ++j) {
+            const int rel = -32 + (int)ty + RPP * (h * HALF + j);   // R - r0
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rr = rel + shift[k];
+                if (rr >= 0 && rr < TR) tile[(4 * tx4 + k) * LDT + rr] = v[j][k];
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned otx4 = threadIdx.x % OC4, oty = threadIdx.x / OC4;
+#pragma unroll
+    for (int j = 0; j < OPASSES; ++j) {
+        const unsigned oc = oty + ORPP * j;
+        const unsigned o = c0 + oc;                              // output row
+        if (o >= cols) continue;
+        const int ocol = r0 - (int)((o * rm) & 31u) + 4 * (int)otx4;   // first of this lane's four output columns
+        v4f w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = tile[oc * LDT + 4 * otx4 + k];
+        float *q = dst + (size_t)o * opitch;
+        if (ocol >= 0 && ocol + 3 < (int)rows) {
+            __builtin_nontemporal_store(w, (v4f *)(q + ocol));   // 16-byte aligned by construction
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ocol + k >= 0 && ocol + k < (int)rows) q[ocol + k] = w[k];
+        }
+    }
+}
+
 // Skinny matrices (one side <= 16): a 64 x 64 tile would be >= 75 % padding.  One thread per LONG-side
 // index walks the short side: TALL (rows long): reads row r's `cols` floats, writes out[c][r]
 // (coalesced per c); !TALL (cols long): reads in[r][c] (coalesced per r), writes the `rows` floats of
@@ -362,7 +445,7 @@ int transpose_planes(const float *in, float *out, size_t batch, size_t rows, siz
     for (unsigned d = 0; d < pb.nbatch; ++d) vec_batch = vec_batch && pb.bin[d] % 4 == 0 && pb.bout[d] % 4 == 0;
     // 128 x 128 tiles (512-byte row segments) for large matrices, 64 x 64 when that would leave
     // CUs without work
-    int tile = g_tile;
+    int tile = g_tile == 1 ? 0 : g_tile;   // (variant 1: default tiles, but never the write-aligned form)
     if (tile == 0)
         tile = (((rows + 127) / 128) * ((cols + 127) / 128) * batch >= (size_t)np::num_cus() * 4) ? 128 : 64;
     // Rectangular tiles (the kernel takes any TR x TC) were measured in round 2 — 256x64, 64x256, 128x64, 64x128, 256x32,
@@ -371,6 +454,25 @@ int transpose_planes(const float *in, float *out, size_t batch, size_t rows, siz
     // writes = 5.16), so only the two square tiles are instantiated.  A probe with the LDS round trip taken out (same
     // loads and stores, wrong values) runs at the same 5.65 TB/s: the LDS transpose is hidden, the rate is what 512-byte
     // segments at two tiles per CU get from HBM — and with no LDS allocated (more tiles in flight) it drops to 5.35.
+    // output rows off the 128-byte line grid: the write-aligned form (variant 1: off)
+    bool walign = g_tile == 0 && tile == 128 && pb.out_pitch % 32 != 0 && ((uintptr_t)out & 127u) == 0 && rows >= 256 && cols >= 64 &&
+                  rows + 31 < 0x7fffffffu;
+    for (unsigned d = 0; d < pb.nbatch; ++d) walign = walign && (pb.bshape[d] == 1 || pb.bout[d] % 32 == 0);
+    if (walign) {
+        const size_t tiles_x = (cols + 127) / 128, tiles_y = (rows + 31 + 127) / 128;
+        if (tiles_x * tiles_y <= 0x7fffffffu) {
+            constexpr size_t lds = (size_t)128 * 130 * sizeof(float);
+            static bool attr_set = false;
+            if (!attr_set) {
+                NP_HIP_CHECK(hipFuncSetAttribute((const void *)transpose_walign_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            transpose_walign_kernel<128, 128><<<dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch), 256, lds, np::stream()>>>(
+                in, out, (unsigned)rows, (unsigned)cols, (unsigned)tiles_x, (unsigned)tiles_y, pb);
+            NP_LAUNCH_CHECK("transpose_walign_kernel");
+            return NP_OK;
+        }
+    }
     if (tile == 128) return launch_transpose<128, 128>(in, out, batch, rows, cols, vec_batch, pb);
     return launch_transpose<64, 64>(in, out, batch, rows, cols, vec_batch, pb);
 }

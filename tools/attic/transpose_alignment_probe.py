@@ -12,8 +12,8 @@ def run(fn, reps=10):
     D.sync(); t.start()
     for _ in range(reps): fn()
     t.stop(); return t.elapsed_ms() / reps
-for variant in (0,):   # (2564 / 2568 = 256 x 64 / 256 x 128 tiles existed for the round-4 probe: profiles/r04/transpose_alignment_probe.log)
+for variant in (1, 0, 1, 0):   # 1 = plain tiles, 0 = default (write-aligned form where output rows are off the line grid)
   check(lib.np_layout_set_variant(variant)); print("-- np_layout_set_variant(%d)" % variant)
-  for rows, cols in ((8192, 8192), (8192, 8196), (8196, 8192), (8192, 8200), (8200, 8192), (8192, 8224), (8224, 8192), (8200, 8200), (8224, 8224), (8192, 8193), (8193, 8192), (8191, 8193), (8190, 8194), (8188, 8196)):
+  for rows, cols in ((8192, 8192), (8192, 8196), (8196, 8192), (8192, 8200), (8200, 8192), (8192, 8224), (8224, 8192), (8200, 8200), (8224, 8224), (8192, 8193), (8193, 8192), (8191, 8193), (8190, 8194), (8188, 8196), (4099, 4099), (12345, 6789), (100_000, 1000), (1000, 100_000), (65536, 1500), (1500, 65536)):
     ms = run(lambda: check(lib.np_transpose2d(big.ptr, out.ptr, 1, rows, cols)))
     print("  " + "transpose %5d x %5d   %.3f ms  %5.0f GB/s" % (rows, cols, ms, 8.0 * rows * cols / ms / 1e6), flush=True)
