@@ -311,10 +311,13 @@ struct PlanePermuteArgs {
     unsigned m_tbE, m_taE, m_E;     // floor(2^32 / d) + 1 for d = tb * E, ta * E, E (exact quotients below 2^12 ... 2^13)
     PlaneBatch pb;
 };
-constexpr unsigned kPlaneLds = 4096 + 512;
+// floats per tile.  16384-float tiles (a 100 x 100 plane as ONE tile, 67 KB of LDS, two workgroups per CU) were measured in
+// round 4 and dropped: runs of 8 floats 3.6 -> 1.4 TB/s, single floats no better on average — each lane's 60 load -> LDS
+// round trips have nobody to hide behind with 8 waves per CU (profiles/r04/layout_plane_tile_ab.log)
+constexpr unsigned kPlaneCap = 4096, kPlanePad = 512;
 
 __global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restrict__ in, float *__restrict__ out, PlanePermuteArgs p) {
-    __shared__ float tile[kPlaneLds];
+    extern __shared__ __attribute__((aligned(16))) float tile[];
     unsigned id = blockIdx.x;
     const unsigned tb_i = id % p.tiles_b;
     id /= p.tiles_b;
@@ -326,14 +329,14 @@ __global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restr
     const unsigned tbE = p.tb * p.E, taE = p.ta * p.E, total = p.ta * tbE;
     // phase 1: (a, b, e) with (b, e) fastest — runs of nb * E contiguous floats per a
     for (unsigned idx = threadIdx.x; idx < total; idx += 256) {
-        const unsigned a = p.E == 1 && p.tb == 64 ? idx >> 6 : __umulhi(idx, p.m_tbE), rem = idx - a * tbE;
+        const unsigned a = __umulhi(idx, p.m_tbE), rem = idx - a * tbE;
         const unsigned b = p.E == 1 ? rem : __umulhi(rem, p.m_E);
         if (a < na && b < nb) tile[a * p.pitch + rem] = __builtin_nontemporal_load(in + off_in + (size_t)(a0 + a) * p.a_in + (size_t)b0 * p.E + rem);
     }
     __syncthreads();
     // phase 2: (b, a, e) with (a, e) fastest — runs of na * E contiguous floats per b
     for (unsigned idx = threadIdx.x; idx < total; idx += 256) {
-        const unsigned b = p.E == 1 && p.ta == 64 ? idx >> 6 : __umulhi(idx, p.m_taE), rem = idx - b * taE;
+        const unsigned b = __umulhi(idx, p.m_taE), rem = idx - b * taE;
         const unsigned a = p.E == 1 ? rem : __umulhi(rem, p.m_E), e = rem - a * p.E;
         if (a < na && b < nb)
             __builtin_nontemporal_store(tile[a * p.pitch + b * p.E + e], out + off_out + (size_t)(b0 + b) * p.b_out + (size_t)a0 * p.E + rem);
@@ -650,11 +653,12 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
             if (E == 1 && p.A >= 64 && p.B >= 64 && batch <= 65535)
                 return transpose_planes(in, out, batch, p.A, p.B, pb);
             // balanced tiles of at most 4096 floats, as square as the extents allow, runs of >= 64 floats where they can be
+            const unsigned cap = kPlaneCap;
             unsigned side = 64;
-            while (side > 1 && (size_t)side * side * E > 4096) --side;
+            while (side > 1 && (size_t)side * side * E > cap) --side;
             unsigned tb_max = p.B < side ? p.B : side;
             if (p.A < side) {   // a short A leaves room for a longer B run
-                const size_t room = 4096 / ((size_t)p.A * E);
+                const size_t room = cap / ((size_t)p.A * E);
                 tb_max = (unsigned)(room > 256 ? 256 : room);
                 if (tb_max > p.B) tb_max = p.B;
                 if (tb_max < 1) tb_max = 1;
@@ -665,7 +669,7 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
             // the run length past a multiple of 64 floats
             const unsigned row = p.tb * E;
             p.pitch = E == 1 ? (row | 1u) : ((row + 63) / 64 * 64 + E);
-            unsigned ta_max = 4096 / row < kPlaneLds / p.pitch ? 4096 / row : kPlaneLds / p.pitch;
+            unsigned ta_max = cap / row < (cap + kPlanePad) / p.pitch ? cap / row : (cap + kPlanePad) / p.pitch;
             if (ta_max > 256) ta_max = 256;
             if (ta_max > p.A) ta_max = p.A;
             if (ta_max < 1) ta_max = 1;
@@ -676,8 +680,15 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
             p.m_taE = magic(p.ta * E);
             p.m_E = magic(E);
             const size_t blocks = (size_t)p.tiles_a * p.tiles_b * batch;
-            if (blocks <= 0x7fffffffu && (size_t)p.ta * p.pitch <= kPlaneLds && p.tb * E > 1 && p.ta * E > 1) {
-                permute_plane_kernel<<<(unsigned)blocks, 256, 0, np::stream()>>>(in, out, p);
+            if (blocks <= 0x7fffffffu && (size_t)p.ta * p.pitch <= cap + kPlanePad && p.tb * E > 1 && p.ta * E > 1) {
+                const size_t lds = ((size_t)p.ta * p.pitch + 3) / 4 * 4 * sizeof(float);
+                static bool attr_set = false;
+                if (!attr_set) {
+                    NP_HIP_CHECK(hipFuncSetAttribute((const void *)permute_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)((kPlaneCap + kPlanePad) * sizeof(float))));
+                    attr_set = true;
+                }
+                permute_plane_kernel<<<(unsigned)blocks, 256, lds, np::stream()>>>(in, out, p);
                 NP_LAUNCH_CHECK("permute_plane_kernel");
                 return NP_OK;
             }

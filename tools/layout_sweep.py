@@ -38,7 +38,11 @@ for rows, cols in ((8192, 8192), (8191, 8193), (4099, 4099), (100_000, 1000), (1
     line("transpose2d %dx%d" % (rows, cols), run(lambda: check(lib.np_transpose2d(big.ptr, out.ptr, 1, rows, cols))), 8.0 * n)
 CASES = (((64, 128, 1024, 8), (0, 2, 1, 3)), ((256, 512, 512), (2, 1, 0)), ((256, 512, 512), (1, 0, 2)), ((100, 100, 100, 100), (3, 2, 1, 0)),
          ((30, 3, 1024, 1024), (0, 2, 3, 1)), ((30, 1024, 1024, 3), (0, 3, 1, 2)), ((1000, 300, 300), (2, 0, 1)), ((50, 60, 70, 80), (1, 3, 0, 2)),
-         ((4096, 4, 4096), (2, 1, 0)), ((128, 128, 128, 16), (2, 1, 0, 3)))
+         ((4096, 4, 4096), (2, 1, 0)), ((128, 128, 128, 16), (2, 1, 0, 3)), ((200, 33, 77, 41), (3, 1, 2, 0)), ((1000, 1000, 5, 20), (3, 2, 1, 0)),
+         ((300, 300, 300), (1, 2, 0)), ((16, 500, 500, 4), (0, 2, 1, 3)))
+import os
+if os.environ.get("NP_LAYOUT_VARIANT"):
+    check(lib.np_layout_set_variant(int(os.environ["NP_LAYOUT_VARIANT"])))
 for shape, perm in CASES:
     n = int(np.prod(shape))
     sh = (C.c_int * len(shape))(*shape)
