@@ -246,6 +246,8 @@ __global__ __launch_bounds__(256) void permute_gather_kernel(const float *__rest
                                                              PermuteArgs a) {
     typedef v4f v4f_u __attribute__((aligned(4)));
     const I stride = (I)gridDim.x * blockDim.x;
+    // (four elements per trip with all loads ahead of the stores — what helped permute_plane_kernel — was measured here and
+    // lost 3-13 %: (256, 512, 512) (1, 0, 2) 5.05 -> 4.85 TB/s, every-2nd-column copy 3.6 -> 3.1; one element per trip stays)
     for (I i = (I)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         I rem = i;
         size_t off = 0;
@@ -312,8 +314,8 @@ struct PlanePermuteArgs {
     PlaneBatch pb;
 };
 // floats per tile.  16384-float tiles (a 100 x 100 plane as ONE tile, 67 KB of LDS, two workgroups per CU) were measured in
-// round 4 and dropped: runs of 8 floats 3.6 -> 1.4 TB/s, single floats no better on average — each lane's 60 load -> LDS
-// round trips have nobody to hide behind with 8 waves per CU (profiles/r04/layout_plane_tile_ab.log)
+// round 4 — before and after the loads were batched — and dropped: runs of 8 floats 5.5 -> 3.2 TB/s, runs of 4 4.7 -> 3.2,
+// single floats +-0 except (200, 33, 77, 41) 2.7 -> 3.3 (profiles/r04/layout_plane_tile_ab.log)
 constexpr unsigned kPlaneCap = 4096, kPlanePad = 512;
 
 __global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restrict__ in, float *__restrict__ out, PlanePermuteArgs p) {
@@ -327,19 +329,45 @@ __global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restr
     const unsigned a0 = ta_i * p.ta, b0 = tb_i * p.tb;
     const unsigned na = p.A - a0 < p.ta ? p.A - a0 : p.ta, nb = p.B - b0 < p.tb ? p.B - b0 : p.tb;
     const unsigned tbE = p.tb * p.E, taE = p.ta * p.E, total = p.ta * tbE;
-    // phase 1: (a, b, e) with (b, e) fastest — runs of nb * E contiguous floats per a
-    for (unsigned idx = threadIdx.x; idx < total; idx += 256) {
-        const unsigned a = __umulhi(idx, p.m_tbE), rem = idx - a * tbE;
-        const unsigned b = p.E == 1 ? rem : __umulhi(rem, p.m_E);
-        if (a < na && b < nb) tile[a * p.pitch + rem] = __builtin_nontemporal_load(in + off_in + (size_t)(a0 + a) * p.a_in + (size_t)b0 * p.E + rem);
+    // phase 1: (a, b, e) with (b, e) fastest — runs of nb * E contiguous floats per a.  Eight loads in flight per lane before
+    // the first LDS store (one load -> store round trip per iteration left the kernel waiting on memory latency)
+    constexpr int UNR = 8;
+    for (unsigned base = threadIdx.x; base < total; base += 256 * UNR) {
+        float v[UNR];
+        unsigned at[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const unsigned idx = base + 256u * u;
+            const unsigned a = __umulhi(idx, p.m_tbE), rem = idx - a * tbE;
+            const unsigned b = p.E == 1 ? rem : __umulhi(rem, p.m_E);
+            ok[u] = idx < total && a < na && b < nb;
+            at[u] = a * p.pitch + rem;
+            v[u] = 0.0f;
+            if (ok[u]) v[u] = __builtin_nontemporal_load(in + off_in + (size_t)(a0 + a) * p.a_in + (size_t)b0 * p.E + rem);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (ok[u]) tile[at[u]] = v[u];
     }
     __syncthreads();
     // phase 2: (b, a, e) with (a, e) fastest — runs of na * E contiguous floats per b
-    for (unsigned idx = threadIdx.x; idx < total; idx += 256) {
-        const unsigned b = __umulhi(idx, p.m_taE), rem = idx - b * taE;
-        const unsigned a = p.E == 1 ? rem : __umulhi(rem, p.m_E), e = rem - a * p.E;
-        if (a < na && b < nb)
-            __builtin_nontemporal_store(tile[a * p.pitch + b * p.E + e], out + off_out + (size_t)(b0 + b) * p.b_out + (size_t)a0 * p.E + rem);
+    for (unsigned base = threadIdx.x; base < total; base += 256 * UNR) {
+        float v[UNR];
+        size_t to[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const unsigned idx = base + 256u * u;
+            const unsigned b = __umulhi(idx, p.m_taE), rem = idx - b * taE;
+            const unsigned a = p.E == 1 ? rem : __umulhi(rem, p.m_E), e = rem - a * p.E;
+            ok[u] = idx < total && a < na && b < nb;
+            to[u] = off_out + (size_t)(b0 + b) * p.b_out + (size_t)a0 * p.E + rem;
+            v[u] = ok[u] ? tile[a * p.pitch + b * p.E + e] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (ok[u]) __builtin_nontemporal_store(v[u], out + to[u]);
     }
 }
 
@@ -448,7 +476,7 @@ int transpose_planes(const float *in, float *out, size_t batch, size_t rows, siz
     for (unsigned d = 0; d < pb.nbatch; ++d) vec_batch = vec_batch && pb.bin[d] % 4 == 0 && pb.bout[d] % 4 == 0;
     // 128 x 128 tiles (512-byte row segments) for large matrices, 64 x 64 when that would leave
     // CUs without work
-    int tile = g_tile == 1 ? 0 : g_tile;   // (variant 1: default tiles, but never the write-aligned form)
+    int tile = (g_tile == 64 || g_tile == 128) ? g_tile : 0;   // (variant 1: default tiles, but never the write-aligned form; 3, 4: np_permute's A/B switches)
     if (tile == 0)
         tile = (((rows + 127) / 128) * ((cols + 127) / 128) * batch >= (size_t)np::num_cus() * 4) ? 128 : 64;
     // Rectangular tiles (the kernel takes any TR x TC) were measured in round 2 — 256x64, 64x256, 128x64, 64x128, 256x32,
@@ -458,7 +486,7 @@ int transpose_planes(const float *in, float *out, size_t batch, size_t rows, siz
     // loads and stores, wrong values) runs at the same 5.65 TB/s: the LDS transpose is hidden, the rate is what 512-byte
     // segments at two tiles per CU get from HBM — and with no LDS allocated (more tiles in flight) it drops to 5.35.
     // output rows off the 128-byte line grid: the write-aligned form (variant 1: off)
-    bool walign = g_tile == 0 && tile == 128 && pb.out_pitch % 32 != 0 && ((uintptr_t)out & 127u) == 0 && rows >= 256 && cols >= 64 &&
+    bool walign = g_tile != 1 && g_tile != 64 && g_tile != 128 && tile == 128 && pb.out_pitch % 32 != 0 && ((uintptr_t)out & 127u) == 0 && rows >= 256 && cols >= 64 &&
                   rows + 31 < 0x7fffffffu;
     for (unsigned d = 0; d < pb.nbatch; ++d) walign = walign && (pb.bshape[d] == 1 || pb.bout[d] % 32 == 0);
     if (walign) {
@@ -609,8 +637,9 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
     {
         int nd = ndim;
         unsigned E = 1;
-        // (runs of up to 8 floats: (64, 128, 1024, 8) 3.19 -> 3.58 TB/s; with 16-float runs the gather is ahead, 3.89 against 3.65)
-        if (nd >= 3 && host_perm[nd - 1] == nd - 1 && host_shape[nd - 1] <= 8 && g_tile == 0) {
+        // (runs shorter than 32 floats; from 32 up the float4 gather has 128-byte runs of its own.  (64, 128, 1024, 8) with axes
+        // 1, 2 swapped: gather 3.2 TB/s, plane kernel 5.5; (128, 128, 128, 16) (2, 1, 0, 3): 3.9 -> 5.5; profiles/r04/layout_sweep.log)
+        if (nd >= 3 && host_perm[nd - 1] == nd - 1 && host_shape[nd - 1] < 32 && g_tile == 0) {
             E = (unsigned)host_shape[nd - 1];
             --nd;   // the remaining axes permute elements of E floats; host_perm[0 .. nd) is a permutation of 0 .. nd - 1
         }
