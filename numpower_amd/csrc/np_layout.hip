@@ -485,6 +485,9 @@ int transpose_planes(const float *in, float *out, size_t batch, size_t rows, siz
     // writes = 5.16), so only the two square tiles are instantiated.  A probe with the LDS round trip taken out (same
     // loads and stores, wrong values) runs at the same 5.65 TB/s: the LDS transpose is hidden, the rate is what 512-byte
     // segments at two tiles per CU get from HBM — and with no LDS allocated (more tiles in flight) it drops to 5.35.
+    // Round 4 tried a persistent form that issues the NEXT tile's loads before it pushes the current one through LDS (more
+    // bytes in flight): 65536 x 4096 5.69 -> 5.33 TB/s, 16384^2 5.31 -> 5.06, 8192^2 equal (profiles/r04/transpose_pipelined_ab.log)
+    // — memory-level parallelism is not what this kernel lacks.
     // output rows off the 128-byte line grid: the write-aligned form (variant 1: off)
     bool walign = g_tile != 1 && g_tile != 64 && g_tile != 128 && tile == 128 && pb.out_pitch % 32 != 0 && ((uintptr_t)out & 127u) == 0 && rows >= 256 && cols >= 64 &&
                   rows + 31 < 0x7fffffffu;
