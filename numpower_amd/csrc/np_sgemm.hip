@@ -2299,6 +2299,8 @@ int launch_streamk(GemmArgs g, unsigned G) {
 typedef DmasShape<128, 128, 3> DmasShape0;
 typedef DmasShape<128, 64, 4> DmasShape1;
 typedef DmasShape<64, 64, 6> DmasShape2;
+// (one to three more LDS buffers per shape — 4 / 6 / 9 — were measured: no difference anywhere, profiles/r04/gemm_mid_depth_ab.log:
+// the DMAs are far enough ahead; what a small tile loses, it loses to its barrier per K-tile and its single accumulator)
 
 template <class SH>
 void launch_dmas_shape(const GemmArgs &g, const DmasArgs &d, dim3 grid, bool edge, bool ktail, hipStream_t s) {
