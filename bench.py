@@ -397,6 +397,48 @@ def bench_c1(dist: Dist, steps, warmup):
             "cpu_sum_rel_err_vs_fp64": abs(float(oracle.reduce_all("sum", a)) - want64) / want64, "parity_ok": ok}
 
 
+def bench_mid(dist: Dist, steps, warmup):
+    """What a PHP caller multiplies and reshapes more often than 4096^3: nd::matmul at 768^3, 1000^3
+    and 1024^3 (round 4: LDS-DMA tiles of 64 x 64, np_sgemm.hip sgemm_dmas_kernel), a transpose whose rows are off the
+    128-byte line grid, an NHWC-like permute.  Each: K launches back to back, parity against fp64 / numpy."""
+    from numpower_amd._lib import check
+    lib = load()
+    out = {}
+    for n in (768, 1000, 1024):
+        A = synth.uniform((n, n), 31, -1.0, 1.0)
+        B = synth.uniform((n, n), 32, -1.0, 1.0)
+        dA, dB, dC = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B), D.DeviceArray((n, n))
+        _, ev_ms = timed(dist, lambda: D.sgemm(dA, dB, out=dC), steps * 2, warmup * 2)
+        us = ev_ms / (steps * 2) * 1e3
+        got = dC.to_host().astype(np.float64)
+        ref = A.astype(np.float64) @ B.astype(np.float64)
+        scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+        err = float((np.abs(got - ref) / scale).max())
+        tf = 2.0 * n ** 3 / us / 1e6
+        out["matmul_%d" % n] = {"us_per_launch": us, "TFLOPs": tf, "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
+                                                                              "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None},
+                                "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6)}
+        for d in (dA, dB, dC):
+            d.free()
+    rows, cols = 8191, 8193
+    X = synth.uniform((rows, cols), 33, -1.0, 1.0)
+    dX, dT = D.DeviceArray.from_host(X), D.DeviceArray((cols, rows))
+    r = hbm_case("transpose 8191x8193", 8.0 * rows * cols, lambda: check(lib.np_transpose2d(dX.ptr, dT.ptr, 1, rows, cols)), steps, warmup, dist)
+    r["parity_ok"] = bool((dT.to_host() == X.T).all())
+    out["transpose_8191x8193"] = r
+    shape, perm = (60, 128, 1024, 8), (0, 2, 1, 3)      # (fits inside X's buffer)
+    n = int(np.prod(shape))
+    sh = (C.c_int * 4)(*shape)
+    pm = (C.c_int * 4)(*perm)
+    dP = D.DeviceArray((n,))
+    r = hbm_case("permute (60,128,1024,8) (0,2,1,3)", 8.0 * n, lambda: check(lib.np_permute(dX.ptr, dP.ptr, 4, sh, pm)), steps, warmup, dist)
+    r["parity_ok"] = bool((dP.to_host().reshape(-1) == np.ascontiguousarray(X.reshape(-1)[:n].reshape(shape).transpose(perm)).reshape(-1)).all())
+    out["permute_nhwc_like"] = r
+    for d in (dX, dT, dP):
+        d.free()
+    return out
+
+
 def bench_extras(dist: Dist, steps, warmup):
     """The HBM-bound configs (C3a/b/c, C4) at BASELINE.json's sizes, N = 1 only."""
     from oracle import oracle
@@ -912,6 +954,11 @@ def _summary(result, extras):
            "c3c_exp_plus_row_fused_frac_hbm": frac("exp_plus_row_fused"),
            "c3c_exp_plus_col_fused_frac_hbm": frac("exp_plus_col_fused"),
            "c4_sum_axis0_frac_hbm": frac("sum_axis0")}
+    for key in ("matmul_768", "matmul_1000", "matmul_1024"):
+        e = extras.get(key)
+        if isinstance(e, dict) and "TFLOPs" in e:
+            out[key + "_TFLOPs"] = _compact(e["TFLOPs"])
+    out["transpose_8191x8193_frac_hbm"], out["permute_nhwc_like_frac_hbm"] = frac("transpose_8191x8193"), frac("permute_nhwc_like")
     c1 = extras.get("c1")
     if isinstance(c1, dict) and "cpu_add_ms" in c1:
         out["c1_cpu_add_ms"], out["c1_cpu_sum_ms"] = _compact(c1["cpu_add_ms"]), _compact(c1["cpu_sum_ms"])
@@ -1025,6 +1072,10 @@ def main():
                     extras["c1"] = bench_c1(dist, max(10, args.steps // 2), args.warmup)
                 except Exception as e:
                     extras["c1"] = {"error": repr(e)}
+                try:
+                    extras.update(bench_mid(dist, max(10, args.steps // 2), args.warmup))
+                except Exception as e:
+                    extras["mid_sizes"] = {"error": repr(e)}
                 try:
                     extras["config5_one_rank_slab_c_abi"] = bench_config5_abi(dist, max(10, args.steps // 2), 7,
                                                                                 own_comm_port=_free_port(), world1=True)

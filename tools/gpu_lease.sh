@@ -10,6 +10,9 @@
 #              pmc_traffic.json), MFMA / SQ counters of the headline kernels (-> gemm_pmc.json, pmc_sq.txt)
 #   sweeps     GEMM shape sweeps, the layout and misc sweeps, the compiled-chain A/B
 #   evidence   all of the above, in that order (the round's evidence run)
+#   cleanbuild a copy of the SOURCES (no prebuilt library, no object files) built from scratch with the box's own hipcc, then
+#              smoke() and a slice of the GPU suite against THAT build (the leases otherwise run the .so files pushed from the
+#              build container: VERDICT r03 #15)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 RECIPE=${1:-tests}
 TAG=${2:-$RECIPE}
@@ -64,6 +67,26 @@ r_sweeps() {
     timeout 200 python tools/fused_static_ab.py 2 > "$O/fused_static_ab.log" 2>&1; tail -14 "$O/fused_static_ab.log"
 }
 
+r_cleanbuild() {
+    C=/tmp/np_clean_build
+    rm -rf "$C"; mkdir -p "$C"
+    tar -C "$R" --exclude='./gpurun_out' --exclude='./build' --exclude='./profiles' --exclude='*.so' --exclude='*.o' --exclude='__pycache__' \
+        --exclude='./numpower_amd/lib' --exclude='./oracle/lib' -cf - . | tar -C "$C" -xf -
+    cd "$C" || exit 1
+    ls numpower_amd/lib 2>/dev/null && echo "UNEXPECTED: prebuilt libraries in the clean copy"
+    start=$(date +%s)
+    python __graft_entry__.py --smoke > "$O/cleanbuild.log" 2>&1; echo "clean build + smoke rc=$? in $(( $(date +%s) - start )) s"
+    tail -3 "$O/cleanbuild.log"
+    timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fusion.py tests/test_gpu_gemm_mid.py -x -q 2>&1 | tail -3 | tee -a "$O/cleanbuild.log"
+    python - <<'PY' | tee -a "$O/cleanbuild.log"
+import sys
+sys.path.insert(0, ".")
+from numpower_amd import _lib
+print("library under test:", _lib.lib_path())
+PY
+    cd "$R"
+}
+
 case "$RECIPE" in
     tests) r_tests ;;
     bench) r_bench ;;
@@ -72,5 +95,6 @@ case "$RECIPE" in
     counters) r_counters ;;
     sweeps) r_sweeps ;;
     evidence) r_tests; r_bench; r_world1; r_profile; r_counters; r_sweeps ;;
-    *) echo "unknown recipe $RECIPE (tests | bench | world1 | profile | counters | sweeps | evidence)"; exit 2 ;;
+    cleanbuild) r_cleanbuild ;;
+    *) echo "unknown recipe $RECIPE (tests | bench | world1 | profile | counters | sweeps | evidence | cleanbuild)"; exit 2 ;;
 esac
