@@ -955,9 +955,16 @@ __global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, Strea
 //   * the counter is a ticket (np::next_tickets): arrivals count to S, departures to 2 S, the last one out zeroes it.
 // All S workgroups of a tile must be resident at once (they wait for each other): the launcher keeps tiles x S within
 // what the device holds (2 workgroups per CU by registers and LDS), like stream-K.
-template <int BM_, int BN_, int NBUF_>
+// KS = accumulator copies per 32 x 32 block (MFMA step s of a K-group adds into copy s % KS, the copies are summed once after
+// the K loop) — an A/B switch that stays at 1.  rocprofv3 (profiles/r04/gemm_mid_pmc.txt) has the matrix pipe busy 0.69 of the
+// CU-busy cycles on 64 x 64 tiles (one accumulator per wave), 0.76 on 128 x 64 (two), 0.87 on 128 x 128 (four), 0.95 on
+// 256 x 128 (eight), which reads like dependent-MFMA stalls; but four independent chains per block (KS = 4, and 2 for the two
+// larger shapes) changed nothing — 1024^3 21.1-21.7 us before, 22.2-22.9 after, 768^3 15.5 -> 16.2: a dependent
+// v_mfma_f32_32x32x2 DOES issue back to back.  What the ratio tracks is ~200-300 cycles per K-tile that are not MFMA (the
+// barrier, the waits around it) against 512 / 1024 / 2048 / 4096 cycles of MFMA: the small tiles need a deeper K-tile.
+template <int BM_, int BN_, int NBUF_, int KS_ = 1>
 struct DmasShape {
-    static constexpr int BM = BM_, BN = BN_, BK = 16, NBUF = NBUF_;
+    static constexpr int BM = BM_, BN = BN_, BK = 16, NBUF = NBUF_, KS = KS_;
     static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     static constexpr int AC = BM / 64;          // A: 16-row x 64-byte chunks a wave moves per K-tile
     static constexpr int BC = BN / 64;          // B: 256-float chunks a wave moves per K-tile
@@ -976,7 +983,7 @@ struct DmasArgs {
 template <class SH, bool EDGE, bool KTAIL>
 __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs d) {
     constexpr int BM = SH::BM, BN = SH::BN, BK = SH::BK, NBUF = SH::NBUF, WM = SH::WM, WN = SH::WN, TM = SH::TM, TN = SH::TN;
-    constexpr int AC = SH::AC, BC = SH::BC, A_SZ = SH::A_SZ, B_SZ = SH::B_SZ;
+    constexpr int AC = SH::AC, BC = SH::BC, A_SZ = SH::A_SZ, B_SZ = SH::B_SZ, KS = SH::KS;
     __shared__ __attribute__((aligned(16))) float smem[NBUF * (A_SZ + B_SZ)];
     float *const As = smem;
     float *const Bs = smem + NBUF * A_SZ;
@@ -1077,13 +1084,15 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
     const bool last_chunk = k_begin + K == g.K;
     const bool has_tail = KTAIL && last_chunk && (kr < BK || (g.N & 3u) != 0);
 
-    v16f acc[TM][TN];
+    v16f accs[KS][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int c = 0; c < KS; ++c)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.0f;
 
     struct Frag {
         v4f a4[TM];
@@ -1110,7 +1119,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a4[i][s], f.bv[s][j], acc[i][j], 0, 0, 0);
+                    accs[s % KS][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a4[i][s], f.bv[s][j], accs[s % KS][i][j], 0, 0, 0);
     };
     constexpr int kMfmaPerHalf = 4 * TM * TN, kReadsPerHalf = TM + 4 * TN, kDmaPerTile = AC + BC;
     constexpr int kPaired = kReadsPerHalf < kMfmaPerHalf ? kReadsPerHalf : kMfmaPerHalf;
@@ -1181,6 +1190,18 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
     for (; kt + 1 < nk; ++kt) k_tile(F{}, T{});
     k_tile(F{}, F{});
 
+    // the accumulator copies of each block, summed in copy order (fixed: deterministic)
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            acc[i][j] = accs[0][i][j];
+#pragma unroll
+            for (int c = 1; c < KS; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += accs[c][i][j][r];
+        }
     const unsigned row0 = (wave >> 1) * WM + 4 * lh, col0 = (wave & 1) * WN + li;
     const unsigned lim_n = g.n_store ? g.n_store : g.N;
     if (d.S == 1) {
