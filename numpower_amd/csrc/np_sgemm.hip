@@ -955,35 +955,41 @@ __global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, Strea
 //   * the counter is a ticket (np::next_tickets): arrivals count to S, departures to 2 S, the last one out zeroes it.
 // All S workgroups of a tile must be resident at once (they wait for each other): the launcher keeps tiles x S within
 // what the device holds (2 workgroups per CU by registers and LDS), like stream-K.
-// KS = accumulator copies per 32 x 32 block (MFMA step s of a K-group adds into copy s % KS, the copies are summed once after
-// the K loop) — an A/B switch that stays at 1.  rocprofv3 (profiles/r04/gemm_mid_pmc.txt) has the matrix pipe busy 0.69 of the
-// CU-busy cycles on 64 x 64 tiles (one accumulator per wave), 0.76 on 128 x 64 (two), 0.87 on 128 x 128 (four), 0.95 on
-// 256 x 128 (eight), which reads like dependent-MFMA stalls; but four independent chains per block (KS = 4, and 2 for the two
-// larger shapes) changed nothing — 1024^3 21.1-21.7 us before, 22.2-22.9 after, 768^3 15.5 -> 16.2: a dependent
-// v_mfma_f32_32x32x2 DOES issue back to back.  What the ratio tracks is ~200-300 cycles per K-tile that are not MFMA (the
-// barrier, the waits around it) against 512 / 1024 / 2048 / 4096 cycles of MFMA: the small tiles need a deeper K-tile.
-template <int BM_, int BN_, int NBUF_, int KS_ = 1>
+// Where a small tile loses (rocprofv3, profiles/r04/gemm_mid_pmc.txt): the matrix pipe is busy 0.69 of the CU-busy cycles on
+// 64 x 64 tiles (one accumulator per wave), 0.76 on 128 x 64 (two), 0.87 on 128 x 128 (four), 0.95 on 256 x 128 (eight).  That
+// reads like dependent-MFMA stalls, but independent accumulator copies (step s of a k-group into copy s % 4, summed after the
+// loop) changed nothing — 1024^3 21.1-21.7 us before, 22.2-22.9 after: a dependent v_mfma_f32_32x32x2 DOES issue back to
+// back.  What the ratio tracks is ~200-300 cycles per K-tile that are not MFMA (the barrier, the waits around it) against 512 /
+// 1024 / 2048 / 4096 cycles of MFMA: hence the deeper K-tile (BK = 32) of the small shapes.
+template <int BM_, int BN_, int NBUF_, int BK_ = 16>
 struct DmasShape {
-    static constexpr int BM = BM_, BN = BN_, BK = 16, NBUF = NBUF_, KS = KS_;
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, NBUF = NBUF_;
     static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    static constexpr int AC = BM / 64;          // A: 16-row x 64-byte chunks a wave moves per K-tile
-    static constexpr int BC = BN / 64;          // B: 256-float chunks a wave moves per K-tile
+    static constexpr int SLOTS = BK / 4;                 // 16-byte slots per A row in LDS (4 or 8)
+    static constexpr int CHUNK_ROWS = 64 / SLOTS;        // A rows one DMA instruction of a wave covers (16 or 8)
+    static constexpr int AC = BM / CHUNK_ROWS / 4;       // A: DMA instructions per wave per K-tile
+    static constexpr int BC = BK * BN / 1024;            // B: 256-float chunks per wave per K-tile
+    static constexpr int NG = BK / 8;                    // k-groups of 8 per K-tile (the MFMA steps of one group: 4)
     static constexpr int A_SZ = BM * BK, B_SZ = BK * BN;
     static constexpr int GROUPS = TM * TN * 4;  // float4 register groups per lane (the unit of the fold)
 };
 
 struct DmasArgs {
     unsigned S;             // K chunks per tile
-    unsigned Kc;            // chunk length (multiple of 16)
+    unsigned Kc;            // chunk length (multiple of the K-tile depth)
     float *workspace;       // S > 1: tiles x S partial tiles of BM x BN floats, lane-major
     unsigned *counters;     // S > 1: one zeroed ticket per tile
     unsigned *error_word;   // np::device_error_word(): a wait for the sibling chunks that runs out of polls is reported (np_sync)
 };
 
+// K-tile depth BK = 16 (two k-groups, as sgemm_dma_kernel) or 32 (four): the barrier and the waits around it cost ~200-300
+// cycles per K-tile whatever its depth, against 512 cycles of MFMA per 16-deep K-tile of a 64 x 64 tile.  A rows are BK
+// floats = BK / 4 slots; slot p of row r holds k-chunk p ^ f(r) with f(r) = (r >> 2) & 3 for 4 slots, (r >> 1) & 7 for 8 —
+// either way the 16 lanes of a ds_read_b128 pass (16 consecutive rows, one k-chunk) land on 16 different 16-byte bank groups.
 template <class SH, bool EDGE, bool KTAIL>
 __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs d) {
     constexpr int BM = SH::BM, BN = SH::BN, BK = SH::BK, NBUF = SH::NBUF, WM = SH::WM, WN = SH::WN, TM = SH::TM, TN = SH::TN;
-    constexpr int AC = SH::AC, BC = SH::BC, A_SZ = SH::A_SZ, B_SZ = SH::B_SZ, KS = SH::KS;
+    constexpr int AC = SH::AC, BC = SH::BC, A_SZ = SH::A_SZ, B_SZ = SH::B_SZ, SLOTS = SH::SLOTS, CHUNK_ROWS = SH::CHUNK_ROWS, NG = SH::NG;
     __shared__ __attribute__((aligned(16))) float smem[NBUF * (A_SZ + B_SZ)];
     float *const As = smem;
     float *const Bs = smem + NBUF * A_SZ;
@@ -1002,16 +1008,17 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
     const unsigned lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned li = lane & 31, lh = lane >> 5;
     const unsigned wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    auto swz = [](unsigned r) { return SLOTS == 4 ? (r >> 2) & 3u : (r >> 1) & 7u; };
 
     // DMA sources (see dma_gemm_segment: the same scheme with AC / BC chunks per wave)
     const unsigned nk = (K + BK - 1) / BK;
-    const unsigned kr = K - (nk - 1) * BK;          // 16 = no tail
+    const unsigned kr = K - (nk - 1) * BK;          // BK = no tail
     const float *a_src[AC];
     unsigned a_q[AC];
 #pragma unroll
     for (int c = 0; c < AC; ++c) {
-        const unsigned r = (wave * AC + c) * 16 + (lane >> 2);
-        const unsigned q = (lane & 3) ^ ((r >> 2) & 3);
+        const unsigned r = (wave * AC + c) * CHUNK_ROWS + lane / SLOTS;
+        const unsigned q = (lane % SLOTS) ^ swz(r);
         unsigned grow = m0 + r;
         if (EDGE && grow >= g.M) grow = g.M - 1;
         a_src[c] = A + (size_t)grow * g.lda + q * 4;
@@ -1022,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
     unsigned b_cut = 0;
 #pragma unroll
     for (int c = 0; c < BC; ++c) {
-        const unsigned off = (wave * BC + c) * 256 + lane * 4;   // float offset inside the [16][BN] tile
+        const unsigned off = (wave * BC + c) * 256 + lane * 4;   // float offset inside the [BK][BN] tile
         const unsigned krow = off / BN;
         unsigned gcol = n0 + off % BN;
         if (EDGE && gcol + 4 > g.N) {
@@ -1084,26 +1091,22 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
     const bool last_chunk = k_begin + K == g.K;
     const bool has_tail = KTAIL && last_chunk && (kr < BK || (g.N & 3u) != 0);
 
-    v16f accs[KS][TM][TN];
+    v16f acc[TM][TN];
 #pragma unroll
-    for (int c = 0; c < KS; ++c)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     struct Frag {
         v4f a4[TM];
         float bv[4][TN];
     };
-    const unsigned sw = (li >> 2) & 3;
-    const unsigned a_off0 = (wm0 + li) * BK + ((lh ^ sw) * 4);
-    const unsigned a_off1 = (wm0 + li) * BK + (((2 + lh) ^ sw) * 4);
+    const unsigned a_row = (wm0 + li) * BK, fsw = swz(li);   // (wm0 and i * 32 are multiples of 32: the swizzle of a row depends on li only)
     const unsigned b_off = (4 * lh) * BN + wn0 + li;
     auto read_frag = [&](Frag &f, unsigned buf, int kg) {
-        const float *as = As + buf * A_SZ + (kg ? a_off1 : a_off0);
+        const float *as = As + buf * A_SZ + a_row + (((unsigned)(kg * 2) + lh) ^ fsw) * 4;
         const float *bs = Bs + buf * B_SZ + b_off + kg * 8 * BN;
 #pragma unroll
         for (int i = 0; i < TM; ++i) f.a4[i] = *(const v4f *)(as + i * 32 * BK);
@@ -1119,10 +1122,10 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    accs[s % KS][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a4[i][s], f.bv[s][j], accs[s % KS][i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a4[i][s], f.bv[s][j], acc[i][j], 0, 0, 0);
     };
-    constexpr int kMfmaPerHalf = 4 * TM * TN, kReadsPerHalf = TM + 4 * TN, kDmaPerTile = AC + BC;
-    constexpr int kPaired = kReadsPerHalf < kMfmaPerHalf ? kReadsPerHalf : kMfmaPerHalf;
+    constexpr int kMfmaPerGroup = 4 * TM * TN, kReadsPerGroup = TM + 4 * TN, kDmaPerTile = AC + BC;
+    constexpr int kPaired = kReadsPerGroup < kMfmaPerGroup ? kReadsPerGroup : kMfmaPerGroup;
 
     // prologue: tiles 0 .. NBUF - 2 in flight
     const bool tail_in_prologue = has_tail && nk <= (unsigned)(NBUF - 1);
@@ -1136,52 +1139,51 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
         if (tail_in_prologue) zero_tail(nk - 1);
     }
     __syncthreads();
-    Frag f0, f1;
-    read_frag(f0, 0, 0);
+    Frag fr[2];
+    read_frag(fr[0], 0, 0);
 
+    // One K-tile = NG k-groups.  While group G's MFMAs run, the fragments of group G + 1 (of the NEXT tile behind the last
+    // group) are fetched, one LDS read behind each MFMA; the ONE barrier sits behind group NG / 2 - 1: it publishes tile
+    // kt + 1 (its DMAs went out NBUF - 1 tiles ago) and frees tile kt - 1's buffer, into which tile kt + NBUF - 1's DMAs go.
     unsigned cur = 0, kt = 0;
     auto k_tile = [&](auto dma_c, auto next_c) {
         constexpr bool DMA = decltype(dma_c)::value, NEXT = decltype(next_c)::value;
         const unsigned nxt = cur + 1 == (unsigned)NBUF ? 0 : cur + 1;
         const unsigned into = cur == 0 ? (unsigned)(NBUF - 1) : cur - 1;   // the buffer tile kt - 1 vacated = (kt + NBUF - 1) % NBUF
-        read_frag(f1, cur, 1);
-        mfma_group(f0);
 #pragma unroll
-        for (int q = 0; q < kPaired; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerHalf, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NEXT) {
-            // tile kt + 1 must have landed for every wave; in the steady state the tiles behind it (kt + 2 .. kt + NBUF - 2)
-            // may still be in flight, towards the end nothing else is
-            if constexpr (DMA)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 3) * kDmaPerTile) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (has_tail && kt + 2 == nk && !tail_in_prologue) zero_tail(nxt);
-            __syncthreads();
-        }
-        if constexpr (DMA) dma_tile(into, has_tail && kt + (unsigned)NBUF == nk);
-        if constexpr (NEXT) read_frag(f0, nxt, 0);
-        mfma_group(f1);
-        if constexpr (DMA) {
+        for (int G = 0; G < NG; ++G) {
+            const bool reads = G + 1 < NG || NEXT;
+            if (G + 1 < NG) read_frag(fr[(G + 1) & 1], cur, G + 1);
+            else if (NEXT) read_frag(fr[0], nxt, 0);
+            if (DMA && G == NG / 2) dma_tile(into, has_tail && kt + (unsigned)NBUF == nk);
+            mfma_group(fr[G & 1]);
+            if (DMA && G == NG / 2) {
 #pragma unroll
-            for (int q = 0; q < (kDmaPerTile < kMfmaPerHalf ? kDmaPerTile : kMfmaPerHalf); ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (global_load_lds)
+                for (int q = 0; q < (kDmaPerTile < kMfmaPerGroup ? kDmaPerTile : kMfmaPerGroup); ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (global_load_lds)
+                }
+            }
+            if (reads) {
+#pragma unroll
+                for (int q = 0; q < kPaired; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerGroup, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (G == NG / 2 - 1 && NEXT) {
+                // tile kt + 1 must have landed for every wave; in the steady state the tiles behind it (kt + 2 .. kt + NBUF - 2)
+                // may still be in flight, towards the end nothing else is
+                if constexpr (DMA)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 3) * kDmaPerTile) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (has_tail && kt + 2 == nk && !tail_in_prologue) zero_tail(nxt);
+                __syncthreads();
             }
         }
-        if constexpr (NEXT) {
-#pragma unroll
-            for (int q = 0; q < kPaired; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerHalf, 0);
-        __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
     };
     using T = std::true_type;
@@ -1190,18 +1192,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
     for (; kt + 1 < nk; ++kt) k_tile(F{}, T{});
     k_tile(F{}, F{});
 
-    // the accumulator copies of each block, summed in copy order (fixed: deterministic)
-    v16f acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            acc[i][j] = accs[0][i][j];
-#pragma unroll
-            for (int c = 1; c < KS; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += accs[c][i][j][r];
-        }
+
     const unsigned row0 = (wave >> 1) * WM + 4 * lh, col0 = (wave & 1) * WN + li;
     const unsigned lim_n = g.n_store ? g.n_store : g.N;
     if (d.S == 1) {
@@ -2049,7 +2040,8 @@ constexpr TileCfg kCfg[kCfgCount] = {{256, 128, 0.93, 0.89}, {128, 128, 0.85, 0.
                                      {128, 128, 0.87, 0.83}, {128, 64, 0.82, 0.80}, {64, 64, 0.80, 0.74}};
 int g_mid_tiles = 1;   // np_sgemm_set_variant(-14) = 0: plans as before round 4 (no sgemm_dmas_kernel), (-15): back
 int g_mid_swizzle = 1;   // np_sgemm_set_variant(-16) = 0: sgemm_dmas_kernel walks its tiles row-major, (-17): XCD-aware bands (default)
-constexpr unsigned kDmasBM[3] = {128, 128, 64}, kDmasBN[3] = {128, 64, 64}, kDmasMaxS[3] = {16, 8, 4};   // the shapes of cfg 3 .. 5
+constexpr unsigned kDmasBM[6] = {128, 128, 64, 128, 128, 64}, kDmasBN[6] = {128, 64, 64, 128, 64, 64}, kDmasMaxS[6] = {16, 8, 4, 16, 8, 4},
+                   kDmasBK[6] = {16, 32, 32, 32, 16, 16};   // 0 .. 2: the shapes of cfg 3 .. 5; 3 .. 5: the same tiles with the other K-tile depth (A/B)
 
 int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S);
 
@@ -2317,9 +2309,15 @@ int launch_streamk(GemmArgs g, unsigned G) {
 // shape: 0 = 128 x 128 tiles (3 LDS buffers), 1 = 128 x 64 (4), 2 = 64 x 64 (6).  S = K chunks per tile: a power of two,
 // at most the shape's register-group count, chunks of at least 64 inner elements.  Returns 1 when the form does not
 // apply (the caller takes another plan): S workgroups wait for each other, so tiles x S x batch must be resident at once.
+// K-tile depth per shape, measured (profiles/r04/gemm_mid_bk_ab.log, same box, BK 16 -> 32): 64 x 64 tiles 1024^3 23.7 -> 22.4 us,
+// 768^3 16.6 -> 15.6, 640^3 14.0 -> 13.2, 256 x 4096 x 4096 86.7 -> 81.9, 1000^3 and 1280^3 +-0 / -2 %; 128 x 64 tiles 1000^3
+// 44.6 -> 40.6, else +1-3 %; 128 x 128 tiles 2 % SLOWER (their K-tile is 2048 cycles of MFMA already; 96 KiB of LDS).
 typedef DmasShape<128, 128, 3> DmasShape0;
-typedef DmasShape<128, 64, 4> DmasShape1;
-typedef DmasShape<64, 64, 6> DmasShape2;
+typedef DmasShape<128, 64, 3, 32> DmasShape1;    // 72 KiB of LDS
+typedef DmasShape<64, 64, 4, 32> DmasShape2;     // 64 KiB
+typedef DmasShape<128, 128, 3, 32> DmasShape3;   // A/B partners of 0 .. 2
+typedef DmasShape<128, 64, 4> DmasShape4;
+typedef DmasShape<64, 64, 6> DmasShape5;
 // (one to three more LDS buffers per shape — 4 / 6 / 9 — were measured: no difference anywhere, profiles/r04/gemm_mid_depth_ab.log:
 // the DMAs are far enough ahead; what a small tile loses, it loses to its barrier per K-tile and its single accumulator)
 
@@ -2336,8 +2334,8 @@ void launch_dmas_shape(const GemmArgs &g, const DmasArgs &d, dim3 grid, bool edg
 }
 
 int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
-    if (shape < 0 || shape > 2 || g.N < 4 || g.K < 4 || g.K_last || g.progress) return 1;
-    const unsigned bm = kDmasBM[shape], bn = kDmasBN[shape];
+    if (shape < 0 || shape > 5 || g.N < 4 || g.K < 4 || g.K_last || g.progress) return 1;
+    const unsigned bm = kDmasBM[shape], bn = kDmasBN[shape], bk = kDmasBK[shape];
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
     g.swizzle = 0;
@@ -2348,12 +2346,12 @@ int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
     // Bands of 4 tile rows give every XCD a compact patch (4 x 8 tiles: 1 MiB of A, 2 MiB of B).  Whole-K launches only:
     // with S > 1 the S chunks of a tile sit on S different XCDs by construction.  (np_sgemm_set_variant(-16): off, -17: on)
     if (g_mid_swizzle && S == 1 && g.tiles_m >= 8 && tiles >= 64) g.swizzle = 4;
-    unsigned Kc = ((g.K + S - 1) / S + 15) / 16 * 16;
+    unsigned Kc = ((g.K + S - 1) / S + bk - 1) / bk * bk;
     while (S > 1 && (Kc < 64 || (size_t)(S - 1) * Kc >= g.K)) {   // every chunk holds work
         S >>= 1;
-        Kc = ((g.K + S - 1) / S + 15) / 16 * 16;
+        Kc = ((g.K + S - 1) / S + bk - 1) / bk * bk;
     }
-    DmasArgs d{S, S == 1 ? (g.K + 15) / 16 * 16 : Kc, nullptr, nullptr, np::device_error_word()};
+    DmasArgs d{S, S == 1 ? (g.K + bk - 1) / bk * bk : Kc, nullptr, nullptr, np::device_error_word()};
     np::Scratch ws;
     if (S > 1) {
         if (tiles * S * batch > (size_t)np::num_cus() * 2 || tiles * batch > 256) return 1;
@@ -2365,11 +2363,14 @@ int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
     if (tiles * S > 0x7fffffffu) return 1;
     const dim3 grid((unsigned)(tiles * S), 1, batch);
     const bool edge = g.M % bm || g.N % bn || g.n_store;
-    const bool ktail = g.K % 16 || g.N % 4;
+    const bool ktail = g.K % bk || g.N % 4;
     hipStream_t s = np::stream();
     if (shape == 0) launch_dmas_shape<DmasShape0>(g, d, grid, edge, ktail, s);
     else if (shape == 1) launch_dmas_shape<DmasShape1>(g, d, grid, edge, ktail, s);
-    else launch_dmas_shape<DmasShape2>(g, d, grid, edge, ktail, s);
+    else if (shape == 2) launch_dmas_shape<DmasShape2>(g, d, grid, edge, ktail, s);
+    else if (shape == 3) launch_dmas_shape<DmasShape3>(g, d, grid, edge, ktail, s);
+    else if (shape == 4) launch_dmas_shape<DmasShape4>(g, d, grid, edge, ktail, s);
+    else launch_dmas_shape<DmasShape5>(g, d, grid, edge, ktail, s);
     NP_LAUNCH_CHECK("sgemm_dmas_kernel");
     return NP_OK;
 }
@@ -2873,7 +2874,7 @@ int np_sgemm_set_variant(int variant) {
             return NP_OK;
         }
         const int code = -variant - 1000;
-        if (code / 100 > 2 || code % 100 < 1) return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: -(1000 + 100 * shape + S) with shape 0..2, S >= 1");
+        if (code / 100 > 5 || code % 100 < 1) return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: -(1000 + 100 * shape + S) with shape 0..5, S >= 1");
         g_force_dmas_shape = code / 100;
         g_force_dmas_S = code % 100;
         return NP_OK;

@@ -17,8 +17,8 @@ shapes = [(512,) * 3, (768,) * 3, (1000,) * 3, (1024,) * 3, (1280,) * 3, (1536,)
           (640, 640, 640), (896, 896, 896), (1152, 1152, 1152), (512, 512, 4096), (3072, 3072, 3072)]
 if len(sys.argv) > 1 and sys.argv[1] == "plans":
     shapes += [(4096,) * 3, (2560,) * 3, (4000,) * 3, (4097,) * 3, (8192, 8192, 512), (16384, 1024, 1024), (1280, 1280, 8192), (100, 100, 100000)]
-if len(sys.argv) > 1 and sys.argv[1] == "swizzle":
-    shapes = [(768,) * 3, (1000,) * 3, (1024,) * 3, (1280,) * 3, (2048,) * 3, (256, 4096, 4096), (4096, 256, 4096), (1024, 1024, 4096), (2048, 2048, 512), (4096, 4096, 256)]
+if len(sys.argv) > 1 and sys.argv[1] in ("swizzle", "bk"):
+    shapes = [(512,) * 3, (640,) * 3, (1001, 1003, 1002)] + [(768,) * 3, (1000,) * 3, (1024,) * 3, (1280,) * 3, (2048,) * 3, (256, 4096, 4096), (4096, 256, 4096), (1024, 1024, 4096), (2048, 2048, 512), (4096, 4096, 256)]
 if len(sys.argv) > 1 and sys.argv[1] == "short":
     shapes = [(768,) * 3, (1000,) * 3, (1024,) * 3, (1536,) * 3, (256, 4096, 4096), (4096, 4096, 256)]
 NAMES = ["128x128", "128x64", "64x64"]
@@ -52,6 +52,21 @@ for (m, n, k) in shapes:
     print("%5d x %5d x %5d  default %7.1f us %6.1f TF   (round-3 planner %7.1f us %6.1f TF)" % (
         m, n, k, ms * 1e3, flop / ms / 1e9, ms_r03 * 1e3, flop / ms_r03 / 1e9), flush=True)
     if len(sys.argv) > 1 and sys.argv[1] == "plans":      # the planner's choice only
+        for d in (a, b, c):
+            d.free()
+        continue
+    if len(sys.argv) > 1 and sys.argv[1] == "bk":          # whole-K mid tiles: the shipped K-tile depth (128x128: 16, 128x64 and 64x64: 32) against the other one (shapes 3 .. 5)
+        for shape in range(3):
+            line = "      %-8s" % NAMES[shape]
+            for sh in (shape, shape + 3, shape, shape + 3):
+                check(lib.np_sgemm_set_variant(-(1000 + 100 * sh + 1)))
+                D.fill(c, float("nan"))
+                ms = run(a, b, c, reps)
+                got = c.to_host().astype(np.float64)
+                err = float(np.abs(got - ref).max()) / scale if not np.isnan(got).any() else float("nan")
+                line += "  %s %6.1f us %5.1f TF (%.0e)" % ("shipped" if sh == shape else "other K-tile depth", ms * 1e3, flop / ms / 1e9, err)
+            print(line, flush=True)
+        check(lib.np_sgemm_set_variant(-999))
         for d in (a, b, c):
             d.free()
         continue
