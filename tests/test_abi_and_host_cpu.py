@@ -224,7 +224,8 @@ def test_comm_entry_points_without_a_communicator_or_device():
     assert not lib.np_comm_stream()
     for call in (lambda: lib.np_allgather_async(1, 2, 4, 4, 0), lambda: lib.np_comm_wait(),
                  lambda: lib.np_sgemm_strided_batched_allgather(4, 8, 8, 8, 1, 64, 2, 64, 3, 2, 0),
-                 lambda: lib.np_comm_debug_sendrecv_self(1, 2, 4), lambda: lib.np_comm_debug_loopback(None, 0)):
+                 lambda: lib.np_comm_debug_sendrecv_self(1, 2, 4), lambda: lib.np_comm_debug_loopback(None, 0),
+                 lambda: lib.np_comm_debug_loopback_timed(1, 2, 4, 1, (C.c_float * 1)())):
         assert call() != 0 and b"no communicator" in lib.np_last_error()
     lo, count = C.c_size_t(0), C.c_size_t(0)
     got = []
