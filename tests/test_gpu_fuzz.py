@@ -428,3 +428,18 @@ def test_fuzz_views_at_odd_offsets(hip, oracle):
             got = nd.matmul(gm, nd.transpose(gw)).cpu().numpy()           # (rows x cols) . (cols x rows)
             ref = m.astype(np.float64) @ w.astype(np.float64).T
             assert (np.abs(got - ref) <= 2e-6 * (np.abs(m).astype(np.float64) @ np.abs(w).astype(np.float64).T)).all(), ("matmul", cols)
+
+
+@pytest.mark.parametrize("tool,cases", [("fused_static_fuzz.py", "80"), ("gemm_mid_fuzz.py", "60")])
+def test_round4_fuzzers_small(tool, cases):
+    """The two round-4 fuzzers (tools/: compiled chains against the chain interpreter on random chains / shapes / special
+    values; sgemm_dmas_kernel on random shapes, tile shapes, splits and operand offsets inside canary frames), a short run
+    each with a seed of its own — the long runs are logged in profiles/r04/fuzz_round4.log."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, str(root / "tools" / tool), cases, "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:]
+    assert "0 mismatches" in p.stdout, p.stdout[-2000:]
