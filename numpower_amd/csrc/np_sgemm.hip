@@ -2354,7 +2354,8 @@ int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
     DmasArgs d{S, S == 1 ? (g.K + bk - 1) / bk * bk : Kc, nullptr, nullptr, np::device_error_word()};
     np::Scratch ws;
     if (S > 1) {
-        if (tiles * S * batch > (size_t)np::num_cus() * 2 || tiles * batch > 256) return 1;
+        // (shape 3, the A/B-only 128 x 128 tile with a 32-deep K-tile, holds 96 KiB of LDS: one workgroup per CU)
+        if (tiles * S * batch > (size_t)np::num_cus() * (shape == 3 ? 1 : 2) || tiles * batch > 256) return 1;
         if (int rc = ws.alloc(tiles * batch * S * (size_t)bm * bn * sizeof(float))) return rc;
         d.workspace = (float *)ws.ptr;
         d.counters = np::next_tickets((unsigned)(tiles * batch));
