@@ -387,7 +387,10 @@ __global__ __launch_bounds__(256) void cchain_rows_kernel(CArgs a, float *__rest
     X(A_(NP_MULTIPLY), A_(NP_ADD), U_(NP_SQRT)) X(A_(NP_MULTIPLY), A_(NP_ADD), U_(NP_ABS))                              \
     X(A_(NP_MULTIPLY), A_(NP_MULTIPLY), A_(NP_ADD)) X(A_(NP_MULTIPLY), S_(NP_MULTIPLY), A_(NP_ADD))                     \
     X(A_(NP_SUBTRACT), A_(NP_MULTIPLY), A_(NP_ADD)) X(A_(NP_SUBTRACT), S_(NP_MULTIPLY), A_(NP_ADD))                     \
-    X(A_(NP_SUBTRACT), A_(NP_DIVIDE), U_(NP_EXP)) X(A_(NP_SUBTRACT), S_(NP_DIVIDE), U_(NP_EXP))
+    X(A_(NP_SUBTRACT), A_(NP_DIVIDE), U_(NP_EXP)) X(A_(NP_SUBTRACT), S_(NP_DIVIDE), U_(NP_EXP))                         \
+    /* distance / affine forms: x * s + col + row (examples/kmeans.py), (x + a) * b + c */                               \
+    X(S_(NP_MULTIPLY), A_(NP_ADD), A_(NP_ADD)) X(A_(NP_MULTIPLY), A_(NP_ADD), A_(NP_ADD)) X(A_(NP_ADD), A_(NP_ADD), A_(NP_ADD))    \
+    X(A_(NP_ADD), A_(NP_MULTIPLY), A_(NP_ADD)) X(A_(NP_SUBTRACT), A_(NP_MULTIPLY), A_(NP_MULTIPLY))
 
 struct Launchers {
     int key[3];

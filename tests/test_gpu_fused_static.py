@@ -45,6 +45,7 @@ CHAINS = [
     ([U("exp"), B("multiply", 1), B("add", 2)], [FULL, HOST]),      # bench.py's exp(a) * b + 2
     ([B("subtract", 1), U("exp"), B("divide", 2)], [COL, COL]),      # a softmax row: exp(x - m) / s
     ([B("subtract", 1), B("divide", 2), U("exp")], [ROW, HOST]),
+    ([B("multiply", 1), B("add", 2), B("add", 3)], [HOST, COL, ROW]),  # examples/kmeans.py: x * -2 + |x|^2 (column) + |c|^2 (row)
     ([U("tanh"), B("add", 1)], [FULL]),                              # NOT on the menu: interpreter both times
     ([B("subtract", 1, 1), U("exp")], [FULL]),                       # swapped operand order: not on the menu either
 ]
