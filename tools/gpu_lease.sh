@@ -46,6 +46,11 @@ r_profile() {
     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/kt" -o bench --output-format csv -- python "$R/bench.py" > "$O/bench_under_rocprof.json" 2> "$O/bench_under_rocprof.err")
     cp "$O"/kt/*kernel_stats.csv "$O/bench_kernel_stats.csv" 2>/dev/null
     head -16 "$O/bench_kernel_stats.csv" | cut -c1-200
+    # the same kernels launched at the BASELINE sizes ONLY (bench.py also runs add / sum at 1000 x 1000 for config 1, which share
+    # kernel names with the 1e8 launches and pull their average down): per-kernel averages that reproduce the bench fractions
+    (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$O/kt2" -o k --output-format csv -- python "$R/tools/prof_kernels.py" 20 > "$O/prof_kernels.log" 2>&1)
+    cp "$O"/kt2/*kernel_stats.csv "$O/prof_kernels_stats.csv" 2>/dev/null
+    head -20 "$O/prof_kernels_stats.csv" | cut -c1-200
 }
 r_counters() {
     (cd /tmp && export TMPDIR=/tmp
