@@ -474,6 +474,12 @@ int np_comm_debug_loopback(void *dev_scratch, size_t bytes);
  * kernels instead of sgemm_fewrows_kernel / sgemm_skinny_kernel (as before round 3), -13 = back). */
 int np_runtime_set_variant(int variant);   /* how host-result calls wait: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag, 2 = spin on the result itself (default) */
 int np_sgemm_set_variant(int variant);
+/* debug: the planner's choice for one dense, aligned M x N x K product on a device of `cus` CUs (0 = the current device; any
+ * other value needs no device: the planner is host arithmetic).  out[11]: cfg, tail_rows, S, modelled us of the tiled plan;
+ * stream-K taken (0/1), its modelled us; cfg, S, us of the best mid-size-tile plan; cfg, us of the best plan without them
+ * (1e300 = does not apply).  tests/test_abi_and_host_cpu.py pins the choices that matter (no reference counterpart:
+ * linalg.c:75-79 hands every product to cblas / cuBLAS). */
+int np_sgemm_debug_plan(size_t M, size_t N, size_t K, size_t batch, int cus, double *out);
 int np_elementwise_set_variant(int variant);   /* launch shape of the streaming kernels (np_elementwise.hip cfg_from_variant) and A/B switches of single kernels, e.g. 9000 = np_binary(pow) with its log2 table in LDS instead of registers (same bits) */
 int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128; 1 = default tiles without the write-aligned form for output rows off the 128-byte grid */
 int np_select_set_variant(int variant);   /* order statistics: 0 = plain three passes only (no bracket path, no one-workgroup kernel), 1 = default (n >= 2^26), else the smallest n that takes it */

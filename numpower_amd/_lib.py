@@ -127,6 +127,7 @@ PROTOTYPES = {
     "np_identity": (C.c_int, [_f32p, C.c_size_t]),
     "np_arange": (C.c_int, [_f32p, C.c_double, C.c_double, C.c_size_t]),
     "np_sgemm_set_variant": (C.c_int, [C.c_int]),
+    "np_sgemm_debug_plan": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "np_elementwise_set_variant": (C.c_int, [C.c_int]),
     "np_layout_set_variant": (C.c_int, [C.c_int]),
     "np_reduce_set_variant": (C.c_int, [C.c_int]),

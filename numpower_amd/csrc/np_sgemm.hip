@@ -961,15 +961,19 @@ __global__ __launch_bounds__(256, 2) void sgemm_streamk_kernel(GemmArgs g, Strea
 // loop) changed nothing — 1024^3 21.1-21.7 us before, 22.2-22.9 after: a dependent v_mfma_f32_32x32x2 DOES issue back to
 // back.  What the ratio tracks is ~200-300 cycles per K-tile that are not MFMA (the barrier, the waits around it) against 512 /
 // 1024 / 2048 / 4096 cycles of MFMA: hence the deeper K-tile (BK = 32) of the small shapes.
-template <int BM_, int BN_, int NBUF_, int BK_ = 16>
+template <int BM_, int BN_, int NBUF_, int BK_ = 16, int KW_ = 1>
 struct DmasShape {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, NBUF = NBUF_;
+    static constexpr int KW = KW_;                       // waves per tile position (1 or 2): KW == 2 = 8 waves, see the kernel
+    static constexpr int WAVES = 4 * KW, THREADS = 256 * KW;
     static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     static constexpr int SLOTS = BK / 4;                 // 16-byte slots per A row in LDS (4 or 8)
     static constexpr int CHUNK_ROWS = 64 / SLOTS;        // A rows one DMA instruction of a wave covers (16 or 8)
-    static constexpr int AC = BM / CHUNK_ROWS / 4;       // A: DMA instructions per wave per K-tile
-    static constexpr int BC = BK * BN / 1024;            // B: 256-float chunks per wave per K-tile
+    static constexpr int AC = BM / CHUNK_ROWS / WAVES;   // A: DMA instructions per wave per K-tile
+    static constexpr int BC = BK * BN / 256 / WAVES;     // B: 256-float chunks per wave per K-tile
     static constexpr int NG = BK / 8;                    // k-groups of 8 per K-tile (the MFMA steps of one group: 4)
+    static constexpr int NGW = NG / KW;                  // ... of which one wave runs this many
+    static_assert(AC >= 1 && BC >= 1 && NGW >= 2 && NGW * KW == NG, "tile too small for this many waves");
     static constexpr int A_SZ = BM * BK, B_SZ = BK * BN;
     static constexpr int GROUPS = TM * TN * 4;  // float4 register groups per lane (the unit of the fold)
 };
@@ -986,10 +990,37 @@ struct DmasArgs {
 // cycles per K-tile whatever its depth, against 512 cycles of MFMA per 16-deep K-tile of a 64 x 64 tile.  A rows are BK
 // floats = BK / 4 slots; slot p of row r holds k-chunk p ^ f(r) with f(r) = (r >> 2) & 3 for 4 slots, (r >> 1) & 7 for 8 —
 // either way the 16 lanes of a ds_read_b128 pass (16 consecutive rows, one k-chunk) land on 16 different 16-byte bank groups.
+// KW = 2: eight waves; waves w and w + 4 compute the same 32 x 32 (x TM x TN) block, w over the even k-groups of every K-tile,
+// w + 4 over the odd ones, and the DMAs are dealt over all eight (DmasShape5 says where that pays).
+// The fold of one register group: the S partials of the sibling chunks, ALL in flight at once (one memory round trip, not
+// S - 1 of them one behind the other; worth little, as it turned out — 512^3 on 128 x 128 tiles with S = 8 19.4 -> 16.6 us, on
+// 64 x 64 with S = 4 12.6 -> 12.3: profiles/r04/gemm_mid_sweep_forced.log / _forced2.log — the ~5 us a fold costs are the chain
+// store -> acknowledge -> ticket -> poll -> load, one memory round trip each), summed in chunk order — the same sum every run —
+// with this workgroup's own partial taken from its registers (the same bits; its slot in the workspace is loaded like the
+// others and ignored: no branch around the loads, so the compiler has no copies to place between a load and its wait).
+template <int SV>
+__device__ inline v4f fold_partials(const float *base, unsigned stride, unsigned chunk, v4f own) {
+    v4f part[SV];
+#pragma unroll
+    for (int c = 0; c < SV; ++c) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[c]) : "v"(base + (size_t)c * stride) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < SV; ++c) asm volatile("" : "+v"(part[c]));   // (nothing below may be scheduled above the wait)
+    v4f sum = chunk == 0 ? own : part[0];
+#pragma unroll
+    for (int c = 1; c < SV; ++c) {
+        const v4f p = (unsigned)c == chunk ? own : part[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[e] += p[e];
+    }
+    return sum;
+}
+
 template <class SH, bool EDGE, bool KTAIL>
-__global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs d) {
+__global__ __launch_bounds__(SH::THREADS, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs d) {
     constexpr int BM = SH::BM, BN = SH::BN, BK = SH::BK, NBUF = SH::NBUF, WM = SH::WM, WN = SH::WN, TM = SH::TM, TN = SH::TN;
-    constexpr int AC = SH::AC, BC = SH::BC, A_SZ = SH::A_SZ, B_SZ = SH::B_SZ, SLOTS = SH::SLOTS, CHUNK_ROWS = SH::CHUNK_ROWS, NG = SH::NG;
+    constexpr int AC = SH::AC, BC = SH::BC, A_SZ = SH::A_SZ, B_SZ = SH::B_SZ, SLOTS = SH::SLOTS, CHUNK_ROWS = SH::CHUNK_ROWS;
+    constexpr int NG = SH::NGW, KW = SH::KW;   // NG: the k-groups of a K-tile THIS wave runs
     __shared__ __attribute__((aligned(16))) float smem[NBUF * (A_SZ + B_SZ)];
     float *const As = smem;
     float *const Bs = smem + NBUF * A_SZ;
@@ -1007,7 +1038,9 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned li = lane & 31, lh = lane >> 5;
-    const unsigned wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    // KW == 2: waves w and w + 4 share a tile position; w + 4 runs the odd k-groups of every K-tile (kh = 1), w the even ones
+    const unsigned wpos = wave & 3u, kh = wave >> 2;
+    const unsigned wm0 = (wpos >> 1) * WM, wn0 = (wpos & 1) * WN;
     auto swz = [](unsigned r) { return SLOTS == 4 ? (r >> 2) & 3u : (r >> 1) & 7u; };
 
     // DMA sources (see dma_gemm_segment: the same scheme with AC / BC chunks per wave)
@@ -1140,7 +1173,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
     }
     __syncthreads();
     Frag fr[2];
-    read_frag(fr[0], 0, 0);
+    read_frag(fr[0], 0, (int)kh);
 
     // One K-tile = NG k-groups.  While group G's MFMAs run, the fragments of group G + 1 (of the NEXT tile behind the last
     // group) are fetched, one LDS read behind each MFMA; the ONE barrier sits behind group NG / 2 - 1: it publishes tile
@@ -1153,8 +1186,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
             const bool reads = G + 1 < NG || NEXT;
-            if (G + 1 < NG) read_frag(fr[(G + 1) & 1], cur, G + 1);
-            else if (NEXT) read_frag(fr[0], nxt, 0);
+            if (G + 1 < NG) read_frag(fr[(G + 1) & 1], cur, (G + 1) * KW + (int)kh);
+            else if (NEXT) read_frag(fr[0], nxt, (int)kh);
             if (DMA && G == NG / 2) dma_tile(into, has_tail && kt + (unsigned)NBUF == nk);
             mfma_group(fr[G & 1]);
             if (DMA && G == NG / 2) {
@@ -1192,8 +1225,31 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
     for (; kt + 1 < nk; ++kt) k_tile(F{}, T{});
     k_tile(F{}, F{});
 
-
-    const unsigned row0 = (wave >> 1) * WM + 4 * lh, col0 = (wave & 1) * WN + li;
+    if constexpr (KW == 2) {
+        // the two halves of every tile position meet in LDS (lane-major: no bank conflicts); waves 0 .. 3 carry the sum on
+        // (kh-0 half + kh-1 half: a fixed order) and do all the stores below, waves 4 .. 7 only keep the barriers company
+        __syncthreads();   // (the last K-tile's fragments have been read by everybody)
+        float *ex = smem + (size_t)wpos * (TM * TN * 16 * 64) + lane;
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ex[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += ex[((i * TN + j) * 16 + r) * 64];
+        }
+    }
+    const bool writer = kh == 0;
+    const unsigned row0 = (wpos >> 1) * WM + 4 * lh, col0 = (wpos & 1) * WN + li;
     const unsigned lim_n = g.n_store ? g.n_store : g.N;
     if (d.S == 1) {
 #pragma unroll
@@ -1204,7 +1260,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
                 for (int r = 0; r < 16; ++r) {
                     const unsigned row = m0 + row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                     const unsigned col = n0 + col0 + j * 32;
-                    if (!EDGE || (row < g.M && col < lim_n)) __builtin_nontemporal_store(acc[i][j][r], &C[(size_t)row * g.ldc + col]);
+                    if (writer && (!EDGE || (row < g.M && col < lim_n))) __builtin_nontemporal_store(acc[i][j][r], &C[(size_t)row * g.ldc + col]);
                 }
         return;
     }
@@ -1220,7 +1276,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (((unsigned)((i * TN + j) * 4 + q) & (d.S - 1)) != chunk) {   // S is a power of two; its own share never leaves the registers
+                    if (writer && ((unsigned)((i * TN + j) * 4 + q) & (d.S - 1)) != chunk) {   // S is a power of two; its own share never leaves the registers
                         const v4f v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                         asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst + ((i * TN + j) * 4 + q) * 1024), "v"(v) : "memory");
                     }
@@ -1249,22 +1305,14 @@ __global__ __launch_bounds__(256, 2) void sgemm_dmas_kernel(GemmArgs g, DmasArgs
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned G = (unsigned)((i * TN + j) * 4 + q);
-                if ((G & (d.S - 1)) != chunk) continue;   // uniform
-                v4f sum{0.0f, 0.0f, 0.0f, 0.0f};
-                bool first = true;
-                for (unsigned c = 0; c < d.S; ++c) {   // chunk order: the same sum every run
-                    v4f p;
-                    if (c == chunk) {
-                        p = v4f{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    } else {
-                        const float *src = tile_ws + (size_t)c * (BM * BN) + (size_t)G * 1024 + (size_t)tid * 4;
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(p) : "v"(src) : "memory");
-                    }
-                    if (first) sum = p;
-                    else
-                        for (int e = 0; e < 4; ++e) sum[e] += p[e];
-                    first = false;
-                }
+                if ((G & (d.S - 1)) != chunk || !writer) continue;   // uniform per wave
+                const float *base = tile_ws + (size_t)G * 1024 + (size_t)tid * 4;
+                const v4f own{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                v4f sum;
+                if (d.S == 2) sum = fold_partials<2>(base, BM * BN, chunk, own);
+                else if (d.S == 4) sum = fold_partials<4>(base, BM * BN, chunk, own);
+                else if (SH::GROUPS >= 8 && d.S == 8) sum = fold_partials<(SH::GROUPS >= 8 ? 8 : 2)>(base, BM * BN, chunk, own);
+                else sum = fold_partials<(SH::GROUPS >= 16 ? 16 : 2)>(base, BM * BN, chunk, own);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned r = 4 * q + e;
@@ -2039,9 +2087,10 @@ constexpr int kCfgCount = 6, kFirstMidCfg = 3;
 constexpr TileCfg kCfg[kCfgCount] = {{256, 128, 0.93, 0.89}, {128, 128, 0.85, 0.64}, {64, 64, 0.71, 0.52},
                                      {128, 128, 0.87, 0.83}, {128, 64, 0.82, 0.80}, {64, 64, 0.80, 0.74}};
 int g_mid_tiles = 1;   // np_sgemm_set_variant(-14) = 0: plans as before round 4 (no sgemm_dmas_kernel), (-15): back
+int g_mid_waves = 1;     // np_sgemm_set_variant(-18) = 0: ragged whole-K 64 x 64 products on four waves like the aligned ones, (-19): on eight (default; see DmasShape5)
 int g_mid_swizzle = 1;   // np_sgemm_set_variant(-16) = 0: sgemm_dmas_kernel walks its tiles row-major, (-17): XCD-aware bands (default)
 constexpr unsigned kDmasBM[6] = {128, 128, 64, 128, 128, 64}, kDmasBN[6] = {128, 64, 64, 128, 64, 64}, kDmasMaxS[6] = {16, 8, 4, 16, 8, 4},
-                   kDmasBK[6] = {16, 32, 32, 32, 16, 16};   // 0 .. 2: the shapes of cfg 3 .. 5; 3 .. 5: the same tiles with the other K-tile depth (A/B)
+                   kDmasBK[6] = {16, 32, 32, 32, 32, 32};   // 0 .. 2: the shapes of cfg 3 .. 5; 3: 128 x 128 with the deeper K-tile, 4 / 5: shapes 1 / 2 on 8 waves (A/B)
 
 int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S);
 
@@ -2114,9 +2163,12 @@ bool g_splitk = true;   // np_sgemm_set_variant(-1) turns the K-splitting plans 
 struct Plan { int cfg; unsigned tail_rows, S; size_t Kc; double t; };
 
 // t_alt: the modelled time of an alternative the caller holds (stream-K): the mid-size tiles must clear it as well
+int g_plan_cus = 0;   // np_sgemm_debug_plan: plan for this many CUs instead of the current device's (the planner is host arithmetic: testable without a device)
+inline int plan_cus() { return g_plan_cus ? g_plan_cus : np::num_cus(); }
+
 Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool only_dma = false, bool vec = true, bool splitk = true,
-                double t_alt = 1e300) {
-    const double cus = (double)np::num_cus();
+                double t_alt = 1e300, Plan *mid_out = nullptr, Plan *other_out = nullptr) {
+    const double cus = (double)plan_cus();
     const double cu_flops = 157.3e12 / 256.0, unit_fixed = 1.5e-6, launch = 3e-6, hbm = 4e12;
     Plan best{2, 0, 1, K, 1e300};
     Plan best_other{2, 0, 1, K, 1e300};   // the best plan WITHOUT the mid-size tiles (see the end of the function)
@@ -2186,9 +2238,18 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
     // is returned here) on others; where the two models are within a few per cent of each other the measured order goes
     // either way (2560^3: the model's 323 us on 128 x 128 tiles was right — and stream-K's 296 was better; profiles/r04/
     // gemm_plans_first.log).  They are taken where they are CLEARLY ahead: up to ~1100^3, thin K, ragged small products.
+    if (mid_out) *mid_out = mid_ok ? best : Plan{-1, 0, 1, K, 1e300};
+    if (other_out) *other_out = mid_ok ? best_other : best;
     if (!mid_ok) return best;              // (the loop never reached cfg 3: `best` is the old best)
+    // One exception, measured in alternation (profiles/r04/gemm_kdeep_ab.log): a whole-K mid plan whose tiles fit the machine
+    // in ONE round is the most predictable form there is (no fold, no second round) and needs no margin — 256 x 4096 x 4096:
+    // both models say 75.3 us, the 64 x 64 tiles run 81.1, the 8-way split with its second launch 84.7; 4096 x 256 x 4096 82.2
+    // against 87.7, 1024 x 1024 x 4096 80.7 against 86.7.
     const double rival = best_other.t < t_alt ? best_other.t : t_alt;
-    return best.t < 0.93 * rival ? best : best_other;
+    const TileCfg &BT = kCfg[best.cfg];
+    const bool one_round = best.S == 1 && best.tail_rows == 0 &&
+                           (double)(((M + BT.bm - 1) / BT.bm) * ((N + BT.bn - 1) / BT.bn) * batch) <= cus;
+    return best.t < (one_round ? 1.001 : 0.93) * rival ? best : best_other;
 }
 
 int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec);
@@ -2248,7 +2309,7 @@ constexpr unsigned kStreamKMaxGrid = np::kStreamKFlagCount;
 // 10 partials, level with the tile form).
 // Ragged tiles (M % 256, N % 128, K % 16) run the guarded instantiations: ~2 % slower.
 double streamk_model(size_t M, size_t N, size_t K, unsigned *grid_out) {
-    const double cus = (double)np::num_cus(), cu_flops = 157.3e12 / 256.0;
+    const double cus = (double)plan_cus(), cu_flops = 157.3e12 / 256.0;
     const size_t tm = (M + 255) / 256, tn = (N + 127) / 128, nk = (K + 15) / 16;
     *grid_out = 0;
     if (tm * tn * nk >= (1ull << 40)) return 1e300;
@@ -2316,25 +2377,30 @@ typedef DmasShape<128, 128, 3> DmasShape0;
 typedef DmasShape<128, 64, 3, 32> DmasShape1;    // 72 KiB of LDS
 typedef DmasShape<64, 64, 4, 32> DmasShape2;     // 64 KiB
 typedef DmasShape<128, 128, 3, 32> DmasShape3;   // A/B partners of 0 .. 2
-typedef DmasShape<128, 64, 4> DmasShape4;
-typedef DmasShape<64, 64, 6> DmasShape5;
+// 64 x 64 on EIGHT waves: waves w and w + 4 share a tile position and split the k-groups of every K-tile; they meet in LDS
+// at the end.  Both waves of a SIMD wait at the same barrier, so this hides nothing of the barrier's cost — aligned products
+// lose 5-10 % to it (profiles/r04/gemm_mid_waves_ab.log: 1024^3 21.9 -> 23.7 us, 768^3 15.6 -> 16.9, 128 x 64 tiles likewise:
+// that instantiation is not kept).  Products whose rows are NOT 128-byte multiples gain: 1000^3 25.4 -> 23.4 us (78 -> 85
+// TFLOP/s), 1001 x 1003 x 1002 25.8 -> 24.0 — twice as many waves issue the DMAs whose rows straddle cache lines.  So: the
+// whole-K 64 x 64 form of ragged / unaligned products only (np_sgemm_set_variant(-18): off, -19: on).
+typedef DmasShape<64, 64, 4, 32, 2> DmasShape5;
 // (one to three more LDS buffers per shape — 4 / 6 / 9 — were measured: no difference anywhere, profiles/r04/gemm_mid_depth_ab.log:
 // the DMAs are far enough ahead; what a small tile loses, it loses to its barrier per K-tile and its single accumulator)
 
 template <class SH>
 void launch_dmas_shape(const GemmArgs &g, const DmasArgs &d, dim3 grid, bool edge, bool ktail, hipStream_t s) {
     if (edge && ktail)
-        sgemm_dmas_kernel<SH, true, true><<<grid, 256, 0, s>>>(g, d);
+        sgemm_dmas_kernel<SH, true, true><<<grid, SH::THREADS, 0, s>>>(g, d);
     else if (edge)
-        sgemm_dmas_kernel<SH, true, false><<<grid, 256, 0, s>>>(g, d);
+        sgemm_dmas_kernel<SH, true, false><<<grid, SH::THREADS, 0, s>>>(g, d);
     else if (ktail)
-        sgemm_dmas_kernel<SH, false, true><<<grid, 256, 0, s>>>(g, d);
+        sgemm_dmas_kernel<SH, false, true><<<grid, SH::THREADS, 0, s>>>(g, d);
     else
-        sgemm_dmas_kernel<SH, false, false><<<grid, 256, 0, s>>>(g, d);
+        sgemm_dmas_kernel<SH, false, false><<<grid, SH::THREADS, 0, s>>>(g, d);
 }
 
 int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
-    if (shape < 0 || shape > 5 || g.N < 4 || g.K < 4 || g.K_last || g.progress) return 1;
+    if (shape < 0 || shape > 5 || shape == 4 || g.N < 4 || g.K < 4 || g.K_last || g.progress) return 1;
     const unsigned bm = kDmasBM[shape], bn = kDmasBN[shape], bk = kDmasBK[shape];
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
@@ -2368,9 +2434,9 @@ int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
     hipStream_t s = np::stream();
     if (shape == 0) launch_dmas_shape<DmasShape0>(g, d, grid, edge, ktail, s);
     else if (shape == 1) launch_dmas_shape<DmasShape1>(g, d, grid, edge, ktail, s);
-    else if (shape == 2) launch_dmas_shape<DmasShape2>(g, d, grid, edge, ktail, s);
+    else if (shape == 2 && !(g_mid_waves && S == 1 && (edge || ktail))) launch_dmas_shape<DmasShape2>(g, d, grid, edge, ktail, s);
+    else if (shape == 2) launch_dmas_shape<DmasShape5>(g, d, grid, edge, ktail, s);
     else if (shape == 3) launch_dmas_shape<DmasShape3>(g, d, grid, edge, ktail, s);
-    else if (shape == 4) launch_dmas_shape<DmasShape4>(g, d, grid, edge, ktail, s);
     else launch_dmas_shape<DmasShape5>(g, d, grid, edge, ktail, s);
     NP_LAUNCH_CHECK("sgemm_dmas_kernel");
     return NP_OK;
@@ -2868,6 +2934,31 @@ int np_debug_sgemm_probe(void *dev_buf) {
     return NP_OK;
 }
 
+// debug: what the planner would run for one M x N x K product (aligned, dense operands) on a device of `cus` CUs (0 = the
+// current device) — out[0..2] = cfg / tail_rows / S of the chosen tiled plan, out[3] its modelled us, out[4] 1 if stream-K is
+// taken instead and out[5] its modelled us (1e300 = not applicable), out[6..8] = cfg / S / us of the best mid-size plan,
+// out[9..10] = cfg / us of the best plan without the mid-size tiles.  Host arithmetic only: no device needed when cus != 0.
+int np_sgemm_debug_plan(size_t M, size_t N, size_t K, size_t batch, int cus, double *out) {
+    if (!out || !M || !N || !K || !batch || cus < 0) return np::fail(NP_ERR_INVALID, "np_sgemm_debug_plan: bad argument");
+    if (cus == 0)
+        if (int rc = np::ensure_init()) return rc;
+    g_plan_cus = cus;
+    const bool vec = K % 4 == 0 && N % 4 == 0;
+    const bool dma_ok = dma_takes(M, N, K, batch, vec);
+    unsigned G = 0;
+    double t_sk = 1e300;
+    if (batch == 1 && g_streamk >= 0 && dma_ok) t_sk = streamk_model(M, N, K, &G) / (vec ? 1.0 : 0.93);
+    Plan mid, other;
+    const Plan p = plan_sgemm(M, N, K, batch, dma_ok, false, vec, true, t_sk, &mid, &other);
+    g_plan_cus = 0;
+    out[0] = p.cfg; out[1] = p.tail_rows; out[2] = p.S; out[3] = p.t * 1e6;
+    out[4] = t_sk < 1e299 && (g_streamk > 0 || t_sk < 0.99 * p.t);
+    out[5] = t_sk < 1e299 ? t_sk * 1e6 : 1e300;
+    out[6] = mid.cfg; out[7] = mid.S; out[8] = mid.t < 1e299 ? mid.t * 1e6 : 1e300;
+    out[9] = other.cfg; out[10] = other.t < 1e299 ? other.t * 1e6 : 1e300;
+    return NP_OK;
+}
+
 int np_sgemm_set_variant(int variant) {
     if (variant <= -999) {   // -(1000 + 100 * shape + S): sgemm_dmas_kernel with that tile shape and S K-chunks wherever it applies; -999: off
         if (variant == -999) {
@@ -2887,6 +2978,10 @@ int np_sgemm_set_variant(int variant) {
     if (variant < 0) {   // -1: whole-K plans only, -2: default planner, -3: default + forced operand padding, -4 / -5: stream-K always / never
         if (variant == -16 || variant == -17) {
             g_mid_swizzle = variant == -17;
+            return NP_OK;
+        }
+        if (variant == -18 || variant == -19) {
+            g_mid_waves = variant == -19;
             return NP_OK;
         }
         if (variant == -14 || variant == -15) {   // -14: no mid-size LDS-DMA tiles (the plans of round 3), -15: back

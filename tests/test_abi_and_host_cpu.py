@@ -213,6 +213,36 @@ def test_tuning_knobs_validate_their_argument_without_a_device():
     assert b"a piece of 3 matrices of a batch of 2" in lib.np_last_error()
 
 
+def test_gemm_planner_choices_on_a_256_cu_device():
+    """np_sgemm_debug_plan: the planner is host arithmetic (np_sgemm.hip plan_sgemm / streamk_model), so what a 256-CU device
+    would run is checkable here.  Pinned: the forms the measurements in profiles/r04 (gemm_plans.log, gemm_kdeep_ab.log) stand
+    on.  cfg 0 = 256 x 128 LDS-DMA tiles, 1 / 2 = register-staged 128 x 128 / 64 x 64, 3 / 4 / 5 = the mid-size LDS-DMA tiles
+    128 x 128 / 128 x 64 / 64 x 64."""
+    from numpower_amd import _lib
+    lib = _lib.load()
+    out = (C.c_double * 11)()
+
+    def plan(m, n, k, batch=1):
+        assert lib.np_sgemm_debug_plan(m, n, k, batch, 256, out) == 0, lib.np_last_error()
+        o = list(out)
+        return {"cfg": int(o[0]), "tail_rows": int(o[1]), "S": int(o[2]), "us": o[3], "streamk": bool(o[4]), "mid_cfg": int(o[6]), "other_cfg": int(o[9])}
+
+    p = plan(4096, 4096, 4096)          # the headline: whole-K 256 x 128 tiles, two per CU, no stream-K
+    assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (0, 0, 1, False) and 850 < p["us"] < 1100
+    for shape in ((768,) * 3, (1000,) * 3, (1024,) * 3, (1001, 1003, 1002), (256, 4096, 4096), (4096, 256, 4096), (1024, 1024, 4096)):
+        p = plan(*shape)               # up to 256 tiles of 64 x 64, whole K, one round
+        assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (5, 0, 1, False), (shape, p)
+    p = plan(512, 512, 4096)           # few tiles, deep K: K split inside the launch
+    assert p["cfg"] == 5 and p["tail_rows"] == 0 and p["S"] == 4 and not p["streamk"]
+    for shape in ((2560,) * 3, (3072,) * 3):   # tile counts that leave a ragged last round: stream-K
+        assert plan(*shape)["streamk"], shape
+    p = plan(100, 100, 100000)         # a dot-product-like shape: the register-staged tiles with K cut into a second launch's fold
+    assert p["cfg"] == 2 and p["tail_rows"] > 0 and p["S"] >= 64
+    p = plan(1024, 1024, 1024, 512)    # BASELINE config 5: a batch is never split along K
+    assert p["S"] == 1 and p["tail_rows"] == 0 and not p["streamk"]
+    assert lib.np_sgemm_debug_plan(0, 4, 4, 1, 256, out) != 0 and lib.np_sgemm_debug_plan(4, 4, 4, 1, 256, None) != 0
+
+
 def test_comm_entry_points_without_a_communicator_or_device():
     """The overlapped-gather entry points refuse politely before any device work when no communicator exists, the piece
     arithmetic is pure, and the communicator's tuning knob validates its argument — on a box without a GPU too."""
