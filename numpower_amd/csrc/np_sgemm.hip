@@ -1327,6 +1327,193 @@ __global__ __launch_bounds__(SH::THREADS, 2) void sgemm_dmas_kernel(GemmArgs g, 
         np::dev::coherent_store(counter, 0u);
 }
 
+// ---- small products: one tile per workgroup, the four waves split K ("k-quartered") -------------------------------
+// 768^3 on 64 x 64 tiles is 144 workgroups — 56 % of the CUs — and any finer cut of those tiles (64 x 32, K in two) puts two
+// units on some CU, which is the same critical path.  What a product of that size needs is a tile whose COUNT is ~256:
+// 48 x 48 for 768^3, 32 x 32 for 512^3 — and v_mfma_f32_32x32x2 cannot cut a 48 x 48 tile into four waves.  So here every
+// wave computes the WHOLE tile, (16 TM) x (16 TN) as TM x TN blocks of v_mfma_f32_16x16x4 (the same flop rate), over a
+// quarter of each 64-deep K-tile, and the four partial tiles meet in LDS at the end (summed in wave order: deterministic).
+//   * staging: global_load_lds_dwordx4 into [BM][64] A rows (16 slots of 16 bytes, slot p of row r holds k-chunk p ^ (r & 15))
+//     and dense [64][BN] B rows; NBUF buffers, one barrier per K-tile: 4 TM TN MFMAs of 32 cycles between barriers
+//     (48 x 48: 1152 cycles; the 64 x 64 tile of sgemm_dmas_kernel has 1024 and twice the LDS reads per flop)
+//   * operands: lane (r = lane % 16, kk = lane / 16) of wave w holds, for MFMA step t, k = 16 w + 4 kk + t — ONE ds_read_b128
+//     per A block row gives a lane its operand for all four steps (which k a lane group holds is free: the MFMA sums over it)
+//   * last K-tile of a K that is a multiple of 16 but not of 64: the waves whose quarter lies beyond K sit it out
+// Takes float4-loadable operands with K % 16 == 0 (the shapes it is for); everything else stays where it was.
+template <int TM, int TN, int NBUF, bool EDGE>
+__global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
+    constexpr int BM = 16 * TM, BN = 16 * TN, BK = 64, A_SZ = BM * BK, B_SZ = BK * BN, NB = TM * TN;
+    constexpr int kDma = TM + TN;   // DMA instructions per wave per K-tile
+    static_assert(NBUF >= 3 && NB * 1024 <= NBUF * (A_SZ + B_SZ), "the four partial tiles meet in the staging buffers");
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * (A_SZ + B_SZ)];
+    float *const As = smem;
+    float *const Bs = smem + NBUF * A_SZ;
+
+    unsigned tile_m, tile_n;
+    tile_coords(g, blockIdx.x, tile_m, tile_n);
+    const unsigned m0 = tile_m * BM, n0 = tile_n * BN;
+    const float *A = g.A + (size_t)blockIdx.z * g.stride_a;
+    const float *B = g.B + (size_t)blockIdx.z * g.stride_b;
+    float *C = g.C + (size_t)blockIdx.z * g.stride_c;
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lr = lane & 15, kk = lane >> 4;
+    const unsigned nk = (g.K + BK - 1) / BK, kr = g.K - (nk - 1) * BK;   // kr: inner length of the last K-tile (16 .. 64)
+
+    // DMA sources.  A: instruction ci = wave * TM + c covers rows 4 ci .. 4 ci + 3, lane -> (row 4 ci + lane / 16, slot lane % 16)
+    // The loop below is ONE uniform body (no "is there a next tile" / "is this the last tile" branches: a branch inside it
+    // splits the scheduling region, and the compiler then parks all LDS reads and DMAs in front of the MFMAs and copies the
+    // accumulators through VGPRs at the joins): a DMA is issued every step; the ones for K-tiles beyond the last re-fetch the
+    // last tile into a buffer nobody reads.
+    const float *a_src[TM];
+    unsigned a_back[TM];   // last K-tile: how far a chunk beyond K is pulled back (to its row's first chunk of that tile: in bounds, unused)
+#pragma unroll
+    for (int c = 0; c < TM; ++c) {
+        const unsigned r = (wave * TM + c) * 4 + kk, q = lr ^ (r & 15u);
+        unsigned grow = m0 + r;
+        if (EDGE && grow >= g.M) grow = g.M - 1;
+        a_src[c] = A + (size_t)grow * g.lda + q * 4;
+        a_back[c] = q * 4 >= kr ? q * 4 : 0;
+    }
+    // B: slot si = (wave * TN + c) * 64 + lane of the dense [64][BN / 4] slot grid
+    const float *b_src[TN];
+    size_t b_back[TN];     // last K-tile: rows beyond K re-read the last valid one (unused)
+#pragma unroll
+    for (int c = 0; c < TN; ++c) {
+        const unsigned si = (wave * TN + c) * 64 + lane, krow = si / (BN / 4);
+        unsigned gcol = n0 + (si % (BN / 4)) * 4;
+        if (EDGE && gcol >= g.N) gcol = n0;   // (N % 4 == 0: chunks are whole; the columns beyond N are never stored)
+        b_src[c] = B + (size_t)krow * g.ldb + gcol;
+        b_back[c] = krow >= kr ? (size_t)(krow - (kr - 1)) * g.ldb : 0;
+    }
+    const size_t b_step = (size_t)BK * g.ldb;
+    unsigned issued = 0;   // K-tiles handed to the DMA so far (uniform)
+    auto dma_tile = [&](unsigned buf) {
+        float *as = As + buf * A_SZ + wave * (TM * 256);
+        float *bs = Bs + buf * B_SZ + wave * (TN * 256);
+        const bool last = issued + 1 >= nk;       // this is the last K-tile (or a re-fetch of it)
+        const unsigned a_adv = last ? 0u : (unsigned)BK;
+        const size_t b_adv = last ? (size_t)0 : b_step;
+#pragma unroll
+        for (int c = 0; c < TM; ++c) {
+            const float *src = a_src[c] - (last ? a_back[c] : 0u);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(as + c * 256), 16, 0, 0);
+            a_src[c] += a_adv;
+        }
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+            const float *src = b_src[c] - (last ? b_back[c] : (size_t)0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(bs + c * 256), 16, 0, 0);
+            b_src[c] += b_adv;
+        }
+        ++issued;
+    };
+
+    v4f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    struct Frag {
+        v4f a4[TM];
+        float bv[TN][4];
+    };
+    const unsigned a_off = lr * BK + (((wave * 4 + kk) ^ lr) * 4);   // (row 16 i + lr: the swizzle depends on lr only)
+    const unsigned b_off = (wave * 16 + kk * 4) * BN + lr;
+    auto read_frag = [&](Frag &f, unsigned buf) {
+        const float *as = As + buf * A_SZ + a_off;
+        const float *bs = Bs + buf * B_SZ + b_off;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a4[i] = *(const v4f *)(as + i * 16 * BK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.bv[j][t] = bs[t * BN + j * 16];
+    };
+    auto mfma_half = [&](const Frag &f, int half) {   // MFMA steps 2 half, 2 half + 1 of a K-tile
+#pragma unroll
+        for (int t = 2 * half; t < 2 * half + 2; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a4[i][t], f.bv[j][t], acc[i][j], 0, 0, 0);
+    };
+    constexpr int kMfmaHalf = 2 * NB, kReads = TM + 4 * TN;
+
+    // prologue: K-tiles 0 .. NBUF - 2 in flight, tile 0 landed and read
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t) dma_tile((unsigned)t);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * kDma) : "memory");
+    __syncthreads();
+    Frag fr[2];
+    read_frag(fr[0], 0);
+
+    // One step = one K-tile that has a successor: the first half of its MFMAs goes out, THEN the wait for the next tile (the
+    // NBUF - 3 behind it may still be in flight) and the barrier — it publishes the next tile and says every wave has read
+    // this tile's fragments (one step ago), so the DMAs of the tile NBUF - 1 ahead may go into the buffer the previous tile
+    // left; the matrix pipe works through the first half while the waves meet.  Behind the barrier: the next tile's fragments
+    // and the DMAs, one behind each MFMA of the second half.
+    unsigned cur = 0;
+    auto step = [&](const Frag &now, Frag &nxt_f) {
+        const unsigned nxt = cur + 1 == (unsigned)NBUF ? 0 : cur + 1;
+        const unsigned into = cur == 0 ? (unsigned)(NBUF - 1) : cur - 1;
+        mfma_half(now, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 3) * kDma) : "memory");
+        __syncthreads();
+        read_frag(nxt_f, nxt);
+        dma_tile(into);
+        mfma_half(now, 1);
+#pragma unroll
+        for (int q = 0; q < (kReads < kMfmaHalf ? kReads : kMfmaHalf); ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        }
+#pragma unroll
+        for (int q = 0; q < kDma; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (global_load_lds)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfmaHalf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    };
+    // tiles 0 .. nk - 2 in pairs (the fragment buffers are addressed statically), the odd one, then the last tile, which a
+    // wave whose quarter lies beyond K sits out
+    for (unsigned kt = 0; kt + 1 < nk; ++kt) {
+        step(fr[0], fr[1]);
+        fr[0] = fr[1];
+    }
+    if (wave * 16 < kr) {
+        mfma_half(fr[0], 0);
+        mfma_half(fr[0], 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-fetches of the last tile: they must not land in what follows)
+
+    // the four partial tiles: red[w][block][q][lane], lane-major (no bank conflicts); thread (q = wave, lane) sums block b
+    __syncthreads();   // (everybody is done with the staging buffers)
+    float *red = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[((wave * NB + i * TN + j) * 4 + q) * 64 + lane] = acc[i][j][q];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned b = i * TN + j;
+            float sum = red[((0 * NB + b) * 4 + wave) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) sum += red[((w * NB + b) * 4 + wave) * 64 + lane];
+            const unsigned row = m0 + i * 16 + 4 * kk + wave, col = n0 + j * 16 + lr;   // D[4 (lane / 16) + q][lane % 16] of a 16 x 16 block
+            if (!EDGE || (row < g.M && col < g.N)) __builtin_nontemporal_store(sum, &C[(size_t)row * g.ldc + col]);
+        }
+}
+
 // Zero-padded copy of a row-major matrix: out (rows_out x ld_out, ld_out % 4 == 0, 16-byte aligned)
 // = in (rows_in x cols_in, row stride ld_in) in the top-left corner, zeros elsewhere.
 __global__ __launch_bounds__(256) void pad_copy_kernel(const float *__restrict__ in, unsigned ld_in,
@@ -2082,10 +2269,18 @@ int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
 //        2048^3 on 256 tiles of 128x128 149 us (the model's 0.64 said 171) -> 0.83; 1024^3 on 256 tiles of 64x64 22.4 us
 //        against the old kernel's 31.1 -> 0.74; several waves: 0.87 / 0.82 / 0.80.  Operands of any alignment (1001 x 1003
 //        x 1002: 26.2 us against 40.6 on the padded / register-staged forms), so these take every product the planner has.
-struct TileCfg { unsigned bm, bn; double eff, eff1; };
-constexpr int kCfgCount = 6, kFirstMidCfg = 3;
-constexpr TileCfg kCfg[kCfgCount] = {{256, 128, 0.93, 0.89}, {128, 128, 0.85, 0.64}, {64, 64, 0.71, 0.52},
-                                     {128, 128, 0.87, 0.83}, {128, 64, 0.82, 0.80}, {64, 64, 0.80, 0.74}};
+//   6, 7 sgemm_kq_kernel: 48 x 48 and 32 x 32 tiles, the four waves of a workgroup split K (v_mfma_f32_16x16x4); whole K only,
+//        float4-loadable operands with K % 16 == 0.  One 48 x 48 workgroup per CU (96 KiB of LDS), two 32 x 32 ones.  Fitted on
+//        profiles/r04/gemm_kq_sweep2.log: a 64-deep K-tile of a 48 x 48 tile takes 0.74 us (0.65 of the pipe's rate), of a
+//        32 x 32 tile 0.39 us alone and 0.69 us for two co-resident ones; on top of the unit's 1.5 us a launch pays ~1-2 us for
+//        the meeting of the four partial tiles in LDS (`extra`): 768^3 12.3 us (model 12.3), 768 x 768 x 3072 39.1 (38.9),
+//        512^3 on 32 x 32 tiles 6.1 (4.6), 704^3 10.6 (10.6), 1024^3 on 48 x 48 tiles 30.0 (28.6: two rounds).
+struct TileCfg { unsigned bm, bn; double eff, eff1, extra; };
+constexpr int kCfgCount = 8, kFirstMidCfg = 3, kFirstKqCfg = 6;
+constexpr TileCfg kCfg[kCfgCount] = {{256, 128, 0.93, 0.89, 0}, {128, 128, 0.85, 0.64, 0}, {64, 64, 0.71, 0.52, 0},
+                                     {128, 128, 0.87, 0.83, 0}, {128, 64, 0.82, 0.80, 0}, {64, 64, 0.80, 0.74, 0},
+                                     {48, 48, 0.649, 0.649, 1.9e-6}, {32, 32, 0.618, 0.547, 0}};
+int g_kq_tiles = 1;      // np_sgemm_set_variant(-20) = 0: plans without sgemm_kq_kernel, (-21): back
 int g_mid_tiles = 1;   // np_sgemm_set_variant(-14) = 0: plans as before round 4 (no sgemm_dmas_kernel), (-15): back
 int g_mid_waves = 1;     // np_sgemm_set_variant(-18) = 0: ragged whole-K 64 x 64 products on four waves like the aligned ones, (-19): on eight (default; see DmasShape5)
 int g_mid_swizzle = 1;   // np_sgemm_set_variant(-16) = 0: sgemm_dmas_kernel walks its tiles row-major, (-17): XCD-aware bands (default)
@@ -2093,8 +2288,14 @@ constexpr unsigned kDmasBM[6] = {128, 128, 64, 128, 128, 64}, kDmasBN[6] = {128,
                    kDmasBK[6] = {16, 32, 32, 32, 32, 32};   // 0 .. 2: the shapes of cfg 3 .. 5; 3: 128 x 128 with the deeper K-tile, 4 / 5: shapes 1 / 2 on 8 waves (A/B)
 
 int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S);
+int launch_kq(int shape, GemmArgs g, unsigned batch, bool vec);
 
 int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
+    if (cfg >= kFirstKqCfg) {
+        const int rc = launch_kq(cfg - kFirstKqCfg, g, batch, vec);
+        if (rc != 1) return rc;
+        cfg = kFirstMidCfg + 2;   // (does not apply after all: the 64 x 64 LDS-DMA tiles)
+    }
     if (cfg >= kFirstMidCfg) {
         const int rc = launch_dmas(cfg - kFirstMidCfg, g, batch, 1);
         if (rc != 1) return rc;
@@ -2177,6 +2378,7 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
         if (c == 0 && !dma_ok) continue;
         if (c != 0 && only_dma) continue;
         if (c >= kFirstMidCfg && !mid_ok) continue;
+        if (c >= kFirstKqCfg && (!g_kq_tiles || !vec || K % 16 || !splitk)) continue;   // (!splitk: C is a window of a wider matrix — fine for the kernel, but keep the peeled forms on the plans they were measured with)
         if (c == kFirstMidCfg) {   // cfg 0 .. 2 are done: what follows competes with their best
             best_other = best;
             best = Plan{2, 0, 1, K, 1e300};
@@ -2193,8 +2395,9 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
             const double eff = (T.eff1 + (T.eff - T.eff1) * blend) * (vec ? 1.0 : c == 0 ? 0.93 : c >= kFirstMidCfg ? 0.97 : 0.78);
             return ceil(waves) * (2.0 * T.bm * T.bn * (double)k / (eff * cu_flops) + unit_fixed);
         };
-        const double whole = span((double)(tm * tn * batch), K);
+        const double whole = span((double)(tm * tn * batch), K) + T.extra;
         if (whole < best.t) best = Plan{c, 0, 1, K, whole};
+        if (c >= kFirstKqCfg) continue;   // whole K only
         if (c >= kFirstMidCfg) {
             // K split S ways INSIDE the launch (sgemm_dmas_kernel's distributed fold; tail_rows == 0 and S > 1 says so): few
             // tiles and a long K.  All S workgroups of a tile are resident together: tiles x S within two per CU.  The fold
@@ -2441,6 +2644,40 @@ int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
     NP_LAUNCH_CHECK("sgemm_dmas_kernel");
     return NP_OK;
 }
+// ---- launch of sgemm_kq_kernel ----
+// shape: 0 = 48 x 48 tiles (4 LDS buffers), 1 = 32 x 32 (5).  Returns 1 where the form does not apply (operands that are not
+// float4-loadable, K % 16, a padded C, a progress request).  Measured and not kept (profiles/r04/gemm_kq_sweep2.log): 64 x 64
+// tiles (1024^3 22.8 us against sgemm_dmas_kernel's 21.1: with 256 tiles either way, the four-position form has the lighter
+// epilogue), 48 x 48 with five buffers (+-0).
+constexpr unsigned kKqTile[2] = {48, 32};
+int g_kq_swizzle = 1;
+
+template <int TM, int TN, int NBUF>
+void launch_kq_shape(const GemmArgs &g, dim3 grid, bool edge, hipStream_t s) {
+    if (edge)
+        sgemm_kq_kernel<TM, TN, NBUF, true><<<grid, 256, 0, s>>>(g);
+    else
+        sgemm_kq_kernel<TM, TN, NBUF, false><<<grid, 256, 0, s>>>(g);
+}
+
+int launch_kq(int shape, GemmArgs g, unsigned batch, bool vec) {
+    if (shape < 0 || shape > 1 || !vec || g.K % 16 || g.K < 16 || g.K_last || g.n_store || g.progress) return 1;
+    const unsigned b = kKqTile[shape];
+    g.tiles_m = (g.M + b - 1) / b;
+    g.tiles_n = (g.N + b - 1) / b;
+    const size_t tiles = (size_t)g.tiles_m * g.tiles_n;
+    if (tiles > 0x7fffffffu) return 1;
+    g.swizzle = (g_kq_swizzle && g.tiles_m >= 8 && tiles >= 64) ? 4 : 0;   // XCD-aware bands, as launch_dmas
+    const dim3 grid((unsigned)tiles, 1, batch);
+    const bool edge = g.M % b || g.N % b;
+    hipStream_t s = np::stream();
+    if (shape == 0) launch_kq_shape<3, 3, 4>(g, grid, edge, s);
+    else launch_kq_shape<2, 2, 5>(g, grid, edge, s);
+    NP_LAUNCH_CHECK("sgemm_kq_kernel");
+    return NP_OK;
+}
+int g_force_kq = -1;   // np_sgemm_set_variant(-(2000 + shape)): every product the k-quartered kernel takes goes through it (A/B, tests); -999: off
+
 int g_force_dmas_shape = -1, g_force_dmas_S = 1;   // np_sgemm_set_variant(-(1000 + 100 * shape + S)): every tiled product through this form (A/B, tests); -999: off
 
 // != 0: the matrices being launched are a PIECE of a batch of this many (np_comm's per-piece pipeline): planned as that
@@ -2584,6 +2821,10 @@ int launch_sgemm_ld(size_t batch, size_t M, size_t N, size_t K, const float *A, 
         }
     }
 #endif
+    if (g_force_kq >= 0) {
+        const int rc = launch_kq(g_force_kq, g, (unsigned)batch, vec);
+        if (rc != 1) return rc;
+    }
     if (g_force_dmas_shape >= 0 && !g.progress && (vec || g_dma_any_alignment)) {
         const int rc = launch_dmas(g_force_dmas_shape, g, (unsigned)batch, (unsigned)g_force_dmas_S);
         if (rc != 1) return rc;
@@ -2963,6 +3204,12 @@ int np_sgemm_set_variant(int variant) {
     if (variant <= -999) {   // -(1000 + 100 * shape + S): sgemm_dmas_kernel with that tile shape and S K-chunks wherever it applies; -999: off
         if (variant == -999) {
             g_force_dmas_shape = -1;
+            g_force_kq = -1;
+            return NP_OK;
+        }
+        if (variant <= -2000) {   // -(2000 + shape): sgemm_kq_kernel wherever it applies
+            if (variant < -2001) return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: -(2000 + shape) with shape 0..1");
+            g_force_kq = -variant - 2000;
             return NP_OK;
         }
         const int code = -variant - 1000;
@@ -2982,6 +3229,10 @@ int np_sgemm_set_variant(int variant) {
         }
         if (variant == -18 || variant == -19) {
             g_mid_waves = variant == -19;
+            return NP_OK;
+        }
+        if (variant == -20 || variant == -21) {
+            g_kq_tiles = variant == -21;
             return NP_OK;
         }
         if (variant == -14 || variant == -15) {   // -14: no mid-size LDS-DMA tiles (the plans of round 3), -15: back

@@ -217,7 +217,7 @@ def test_gemm_planner_choices_on_a_256_cu_device():
     """np_sgemm_debug_plan: the planner is host arithmetic (np_sgemm.hip plan_sgemm / streamk_model), so what a 256-CU device
     would run is checkable here.  Pinned: the forms the measurements in profiles/r04 (gemm_plans.log, gemm_kdeep_ab.log) stand
     on.  cfg 0 = 256 x 128 LDS-DMA tiles, 1 / 2 = register-staged 128 x 128 / 64 x 64, 3 / 4 / 5 = the mid-size LDS-DMA tiles
-    128 x 128 / 128 x 64 / 64 x 64."""
+    128 x 128 / 128 x 64 / 64 x 64, 6 / 7 = the k-quartered 48 x 48 / 32 x 32 tiles."""
     from numpower_amd import _lib
     lib = _lib.load()
     out = (C.c_double * 11)()
@@ -229,7 +229,11 @@ def test_gemm_planner_choices_on_a_256_cu_device():
 
     p = plan(4096, 4096, 4096)          # the headline: whole-K 256 x 128 tiles, two per CU, no stream-K
     assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (0, 0, 1, False) and 850 < p["us"] < 1100
-    for shape in ((768,) * 3, (1000,) * 3, (1024,) * 3, (1001, 1003, 1002), (256, 4096, 4096), (4096, 256, 4096), (1024, 1024, 4096)):
+    for shape, cfg in (((256,) * 3, 7), ((512,) * 3, 7), ((768,) * 3, 6), ((768, 768, 3072), 6)):
+        p = plan(*shape)               # ~256 tiles of 32 x 32 / 48 x 48, the four waves of a workgroup splitting K (sgemm_kq_kernel)
+        assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (cfg, 0, 1, False), (shape, p)
+    assert plan(760, 760, 760)["cfg"] == 5      # K % 16 != 0: not for that kernel
+    for shape in ((896,) * 3, (1000,) * 3, (1024,) * 3, (1001, 1003, 1002), (256, 4096, 4096), (4096, 256, 4096), (1024, 1024, 4096)):
         p = plan(*shape)               # up to 256 tiles of 64 x 64, whole K, one round
         assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (5, 0, 1, False), (shape, p)
     p = plan(512, 512, 4096)           # few tiles, deep K: K split inside the launch

@@ -62,3 +62,54 @@ def test_mid_tiles_batched_and_strided(tile, S, hip):
     want = A.astype(np.float64) @ B.astype(np.float64)
     scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
     assert (np.abs(got - want) <= 1e-6 * scale).all()
+
+
+KQ_SHAPES = [(48, 48, 16), (48, 48, 64), (50, 72, 80), (100, 200, 64), (16, 16, 16), (1, 4, 16), (97, 132, 208), (720, 720, 720), (333, 444, 176), (64, 64, 1024),
+             (130, 68, 4096), (768, 768, 768), (512, 512, 512), (96, 200, 33), (77, 64, 130), (513, 260, 784)]
+
+
+@pytest.mark.parametrize("shape", [0, 1], ids=["48x48", "32x32"])
+def test_k_quartered_tiles(shape, hip, oracle):
+    """sgemm_kq_kernel (one tile per workgroup, its four waves split every 64-deep K-tile, v_mfma_f32_16x16x4, the partial
+    tiles summed in LDS in wave order) forced through np_sgemm_set_variant(-(2000 + shape)): ragged M / N, K = 16 .. 4096 in
+    multiples of 16 (last K-tile a quarter, half, three quarters full); shapes it does not take (K % 16, N % 4) fall through to
+    the planner.  Same bars as above; deterministic."""
+    lib = load()
+    for (m, n, k) in KQ_SHAPES:
+        A = synth.uniform((m, k), 61, -1.0, 1.0)
+        B = synth.uniform((k, n), 62, -1.0, 1.0)
+        a, b, c = hip.DeviceArray.from_host(A), hip.DeviceArray.from_host(B), hip.DeviceArray((m, n))
+        check(lib.np_sgemm_set_variant(-(2000 + shape)))
+        try:
+            runs = []
+            for _ in range(2):
+                hip.fill(c, float("nan"))
+                hip.sgemm(a, b, out=c)
+                runs.append(c.to_host().copy())
+        finally:
+            check(lib.np_sgemm_set_variant(-999))
+        want = A.astype(np.float64) @ B.astype(np.float64)
+        scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+        assert not np.isnan(runs[0]).any(), (m, n, k)
+        assert (np.abs(runs[0] - want) <= 1e-6 * scale).all(), (m, n, k, float((np.abs(runs[0] - want) / scale).max()))
+        assert (runs[1].view(np.uint32) == runs[0].view(np.uint32)).all(), (m, n, k, "not deterministic")
+        assert (np.abs(runs[0] - oracle.matmul(A, B)) <= 1e-5 * scale).all(), (m, n, k, "vs the oracle")
+    # a batch with strides, and non-finite values in the rows / columns a ragged last K-tile re-reads: they must not leak
+    batch, m, n, k = 3, 100, 72, 80
+    A = synth.uniform((batch, m, k), 63, -1.0, 1.0)
+    B = synth.uniform((batch, k, n), 64, -1.0, 1.0)
+    B[:, k - 1, 5] = np.inf          # the row a last K-tile's out-of-range rows are pulled back to
+    A[:, 7, 64:] = np.nan            # row 7's last chunks
+    a, b, c = hip.DeviceArray.from_host(A), hip.DeviceArray.from_host(B), hip.DeviceArray((batch, m, n))
+    check(lib.np_sgemm_set_variant(-(2000 + shape)))
+    try:
+        check(lib.np_sgemm_strided_batched(batch, m, n, k, a.ptr, m * k, b.ptr, k * n, c.ptr, m * n))
+        got = c.to_host()
+    finally:
+        check(lib.np_sgemm_set_variant(-999))
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = np.matmul(A.astype(np.float64), B.astype(np.float64))
+    assert (np.isnan(got) == np.isnan(want)).all() and (np.isinf(got) == np.isinf(want)).all()
+    fin = np.isfinite(want)
+    assert np.allclose(got[fin], want[fin], rtol=0, atol=1e-4)
+    assert lib.np_sync() == 0, lib.np_last_error()
