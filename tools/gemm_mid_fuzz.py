@@ -1,6 +1,8 @@
-"""Random-shape fuzz of sgemm_dmas_kernel: random M, N, K (1 .. 1500, a third of them multiples of 16 / 32 / 64), random tile shape
-(0 .. 5) and split S, operands at random 4-byte offsets inside NaN-filled allocations, C inside a canary frame: within
-1e-6 |A|.|B| of the fp64 product, nothing written outside C, the same bits on a second run.
+"""Random-shape fuzz of the mid-size and small-tile GEMM kernels: random M, N, K (1 .. 1500, a third of them multiples of 16 / 32 /
+64); a third of the cases force sgemm_dmas_kernel with a random tile shape and split S, a third force sgemm_kq_kernel (48x48 /
+32x32; K mostly a multiple of 16, N of 4, operands 16-byte aligned — the rest falls through to the planner, which is part of the
+test), a third take the default planner; operands at random 4-byte offsets inside NaN-filled allocations, C inside a canary
+frame: within 1e-6 |A|.|B| of the fp64 product, nothing written outside C, the same bits on a second run.
 Usage: python tools/gemm_mid_fuzz.py [cases = 300] [seed = 1]"""
 import sys
 from pathlib import Path
@@ -21,15 +23,26 @@ for case in range(cases):
             return int(rng.choice([16, 32, 64, 128, 256, 512, 1024])) * int(rng.integers(1, 3))
         return int(rng.integers(1, 1500))
     m, n, k = dim(), max(4, dim()), max(4, dim())
-    shape, S = int(rng.integers(0, 6)), int(rng.choice([1, 1, 2, 4, 8, 16]))
+    shape, S = int(rng.choice([0, 1, 2, 3, 5])), int(rng.choice([1, 1, 2, 4, 8, 16]))
     oa, ob, oc = (int(x) for x in rng.integers(0, 4, 3))
+    form = ["dmas", "kq", "plan"][case % 3]
+    if form == "kq":
+        shape = int(rng.integers(0, 2))
+        if rng.random() < 0.85:
+            k = max(16, k // 16 * 16)
+            n = max(4, n // 4 * 4)
+            oa, ob = (int(x) * 4 for x in rng.integers(0, 2, 2))
     A = rng.uniform(-1, 1, (m, k)).astype(np.float32)
     B = rng.uniform(-1, 1, (k, n)).astype(np.float32)
     ha = np.full(m * k + 8, np.nan, np.float32); ha[oa:oa + m * k] = A.reshape(-1)
     hb = np.full(k * n + 8, np.nan, np.float32); hb[ob:ob + k * n] = B.reshape(-1)
     hc = np.full(m * n + 64, -777.0, np.float32)
     da, db, dc = D.DeviceArray.from_host(ha), D.DeviceArray.from_host(hb), D.DeviceArray.from_host(hc)
-    check(lib.np_sgemm_set_variant(-(1000 + 100 * shape + S)))
+    check(lib.np_sgemm_set_variant(-999))
+    if form == "dmas":
+        check(lib.np_sgemm_set_variant(-(1000 + 100 * shape + S)))
+    elif form == "kq":
+        check(lib.np_sgemm_set_variant(-(2000 + shape)))
     runs = []
     for _ in range(2):
         check(lib.np_memcpy_h2d(dc.ptr, hc.ctypes.data, hc.nbytes))
@@ -44,7 +57,7 @@ for case in range(cases):
         (runs[0].view(np.uint32) == runs[1].view(np.uint32)).all()
     if not ok:
         bad += 1
-        print("MISMATCH case %d: %d x %d x %d shape %d S %d offsets %d %d %d frame %s" % (case, m, n, k, shape, S, oa, ob, oc, frame_ok), flush=True)
+        print("MISMATCH case %d (%s): %d x %d x %d shape %d S %d offsets %d %d %d frame %s" % (case, form, m, n, k, shape, S, oa, ob, oc, frame_ok), flush=True)
     for d in (da, db, dc):
         d.free()
 rc = lib.np_sync()
