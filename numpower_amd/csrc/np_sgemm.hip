@@ -1338,8 +1338,9 @@ __global__ __launch_bounds__(SH::THREADS, 2) void sgemm_dmas_kernel(GemmArgs g, 
 //     (48 x 48: 1152 cycles; the 64 x 64 tile of sgemm_dmas_kernel has 1024 and twice the LDS reads per flop)
 //   * operands: lane (r = lane % 16, kk = lane / 16) of wave w holds, for MFMA step t, k = 16 w + 4 kk + t — ONE ds_read_b128
 //     per A block row gives a lane its operand for all four steps (which k a lane group holds is free: the MFMA sums over it)
-//   * last K-tile of a K that is a multiple of 16 but not of 64: the waves whose quarter lies beyond K sit it out
-// Takes float4-loadable operands with K % 16 == 0 (the shapes it is for); everything else stays where it was.
+//   * last K-tile of a K that is not a multiple of 64: the waves whose quarter lies beyond K sit it out, the one whose
+//     quarter ends inside zeroes the operands of its lane groups beyond K
+// Takes float4-loadable operands (K % 4 == 0, N % 4 == 0, 16-byte aligned rows); everything else stays where it was.
 template <int TM, int TN, int NBUF, bool EDGE>
 __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
     constexpr int BM = 16 * TM, BN = 16 * TN, BK = 64, A_SZ = BM * BK, B_SZ = BK * BN, NB = TM * TN;
@@ -1357,7 +1358,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
     float *C = g.C + (size_t)blockIdx.z * g.stride_c;
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lr = lane & 15, kk = lane >> 4;
-    const unsigned nk = (g.K + BK - 1) / BK, kr = g.K - (nk - 1) * BK;   // kr: inner length of the last K-tile (16 .. 64)
+    const unsigned nk = (g.K + BK - 1) / BK, kr = g.K - (nk - 1) * BK;   // kr: inner length of the last K-tile (4 .. 64, a multiple of 4)
 
     // DMA sources.  A: instruction ci = wave * TM + c covers rows 4 ci .. 4 ci + 3, lane -> (row 4 ci + lane / 16, slot lane % 16)
     // The loop below is ONE uniform body (no "is there a next tile" / "is this the last tile" branches: a branch inside it
@@ -1486,6 +1487,17 @@ __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
         fr[0] = fr[1];
     }
     if (wave * 16 < kr) {
+        if (wave * 16 + 16 > kr) {   // K % 16 != 0: this wave's quarter ends inside; the lane groups beyond K hold re-read values
+            const bool ok = wave * 16 + kk * 4 < kr;   // (K % 4 == 0: a lane's four k are all inside or all outside)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fr[0].a4[i][e] = ok ? fr[0].a4[i][e] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fr[0].bv[j][t] = ok ? fr[0].bv[j][t] : 0.0f;   // both: 0 x (a re-read NaN) would be NaN
+        }
         mfma_half(fr[0], 0);
         mfma_half(fr[0], 1);
     }
@@ -2270,7 +2282,7 @@ int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
 //        against the old kernel's 31.1 -> 0.74; several waves: 0.87 / 0.82 / 0.80.  Operands of any alignment (1001 x 1003
 //        x 1002: 26.2 us against 40.6 on the padded / register-staged forms), so these take every product the planner has.
 //   6, 7 sgemm_kq_kernel: 48 x 48 and 32 x 32 tiles, the four waves of a workgroup split K (v_mfma_f32_16x16x4); whole K only,
-//        float4-loadable operands with K % 16 == 0.  One 48 x 48 workgroup per CU (96 KiB of LDS), two 32 x 32 ones.  Fitted on
+//        float4-loadable operands.  One 48 x 48 workgroup per CU (96 KiB of LDS), two 32 x 32 ones.  Fitted on
 //        profiles/r04/gemm_kq_sweep2.log: a 64-deep K-tile of a 48 x 48 tile takes 0.74 us (0.65 of the pipe's rate), of a
 //        32 x 32 tile 0.39 us alone and 0.69 us for two co-resident ones; on top of the unit's 1.5 us a launch pays ~1-2 us for
 //        the meeting of the four partial tiles in LDS (`extra`): 768^3 12.3 us (model 12.3), 768 x 768 x 3072 39.1 (38.9),
@@ -2378,7 +2390,7 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
         if (c == 0 && !dma_ok) continue;
         if (c != 0 && only_dma) continue;
         if (c >= kFirstMidCfg && !mid_ok) continue;
-        if (c >= kFirstKqCfg && (!g_kq_tiles || !vec || K % 16 || !splitk)) continue;   // (!splitk: C is a window of a wider matrix — fine for the kernel, but keep the peeled forms on the plans they were measured with)
+        if (c >= kFirstKqCfg && (!g_kq_tiles || !vec || !splitk)) continue;   // (!splitk: C is a window of a wider matrix — fine for the kernel, but keep the peeled forms on the plans they were measured with)
         if (c == kFirstMidCfg) {   // cfg 0 .. 2 are done: what follows competes with their best
             best_other = best;
             best = Plan{2, 0, 1, K, 1e300};
@@ -2646,7 +2658,7 @@ int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
 }
 // ---- launch of sgemm_kq_kernel ----
 // shape: 0 = 48 x 48 tiles (4 LDS buffers), 1 = 32 x 32 (5).  Returns 1 where the form does not apply (operands that are not
-// float4-loadable, K % 16, a padded C, a progress request).  Measured and not kept (profiles/r04/gemm_kq_sweep2.log): 64 x 64
+// float4-loadable, a padded C, a progress request).  Measured and not kept (profiles/r04/gemm_kq_sweep2.log): 64 x 64
 // tiles (1024^3 22.8 us against sgemm_dmas_kernel's 21.1: with 256 tiles either way, the four-position form has the lighter
 // epilogue), 48 x 48 with five buffers (+-0).
 constexpr unsigned kKqTile[2] = {48, 32};
@@ -2661,7 +2673,7 @@ void launch_kq_shape(const GemmArgs &g, dim3 grid, bool edge, hipStream_t s) {
 }
 
 int launch_kq(int shape, GemmArgs g, unsigned batch, bool vec) {
-    if (shape < 0 || shape > 1 || !vec || g.K % 16 || g.K < 16 || g.K_last || g.n_store || g.progress) return 1;
+    if (shape < 0 || shape > 1 || !vec || g.K % 4 || g.K < 4 || g.K_last || g.n_store || g.progress) return 1;
     const unsigned b = kKqTile[shape];
     g.tiles_m = (g.M + b - 1) / b;
     g.tiles_n = (g.N + b - 1) / b;

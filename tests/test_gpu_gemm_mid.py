@@ -65,15 +65,16 @@ def test_mid_tiles_batched_and_strided(tile, S, hip):
 
 
 KQ_SHAPES = [(48, 48, 16), (48, 48, 64), (50, 72, 80), (100, 200, 64), (16, 16, 16), (1, 4, 16), (97, 132, 208), (720, 720, 720), (333, 444, 176), (64, 64, 1024),
-             (130, 68, 4096), (768, 768, 768), (512, 512, 512), (96, 200, 33), (77, 64, 130), (513, 260, 784)]
+             (130, 68, 4096), (768, 768, 768), (512, 512, 512), (96, 200, 33), (77, 64, 130), (513, 260, 784), (60, 60, 4), (60, 60, 20), (100, 52, 36),
+             (200, 200, 100), (700, 700, 700), (50, 48, 1000), (33, 36, 68), (48, 48, 60), (48, 48, 124)]
 
 
 @pytest.mark.parametrize("shape", [0, 1], ids=["48x48", "32x32"])
 def test_k_quartered_tiles(shape, hip, oracle):
     """sgemm_kq_kernel (one tile per workgroup, its four waves split every 64-deep K-tile, v_mfma_f32_16x16x4, the partial
-    tiles summed in LDS in wave order) forced through np_sgemm_set_variant(-(2000 + shape)): ragged M / N, K = 16 .. 4096 in
-    multiples of 16 (last K-tile a quarter, half, three quarters full); shapes it does not take (K % 16, N % 4) fall through to
-    the planner.  Same bars as above; deterministic."""
+    tiles summed in LDS in wave order) forced through np_sgemm_set_variant(-(2000 + shape)): ragged M / N, K = 4 .. 4096 in
+    multiples of 4 (last K-tile from one chunk to full, quarters that end inside); shapes it does not take (K % 4, N % 4) fall
+    through to the planner.  Same bars as above; deterministic."""
     lib = load()
     for (m, n, k) in KQ_SHAPES:
         A = synth.uniform((m, k), 61, -1.0, 1.0)

@@ -17,7 +17,7 @@ t = Timer()
 NAMES = ["48x48", "32x32"]
 check_only = len(sys.argv) > 1 and sys.argv[1] == "check"
 shapes = [(512,) * 3, (576,) * 3, (640,) * 3, (704,) * 3, (768,) * 3, (832,) * 3, (896,) * 3, (960,) * 3, (1024,) * 3, (768, 768, 3072), (384, 384, 384),
-          (256, 256, 256), (768, 768, 256), (512, 1024, 512)]
+          (256, 256, 256), (768, 768, 256), (512, 1024, 512), (600,) * 3, (700,) * 3, (760,) * 3, (500,) * 3, (128, 4096, 4096)]
 if check_only:
     shapes = [(48, 48, 16), (48, 48, 64), (50, 72, 80), (100, 200, 64), (16, 16, 16), (1, 4, 16), (97, 132, 208), (720, 720, 720), (333, 444, 176), (64, 64, 1024), (130, 68, 4096)]
 
