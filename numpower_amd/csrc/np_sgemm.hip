@@ -1333,22 +1333,35 @@ __global__ __launch_bounds__(SH::THREADS, 2) void sgemm_dmas_kernel(GemmArgs g, 
 // 48 x 48 for 768^3, 32 x 32 for 512^3 — and v_mfma_f32_32x32x2 cannot cut a 48 x 48 tile into four waves.  So here every
 // wave computes the WHOLE tile, (16 TM) x (16 TN) as TM x TN blocks of v_mfma_f32_16x16x4 (the same flop rate), over a
 // quarter of each 64-deep K-tile, and the four partial tiles meet in LDS at the end (summed in wave order: deterministic).
-//   * staging: global_load_lds_dwordx4 into [BM][64] A rows (16 slots of 16 bytes, slot p of row r holds k-chunk p ^ (r & 15))
-//     and dense [64][BN] B rows; NBUF buffers, one barrier per K-tile: 4 TM TN MFMAs of 32 cycles between barriers
-//     (48 x 48: 1152 cycles; the 64 x 64 tile of sgemm_dmas_kernel has 1024 and twice the LDS reads per flop)
 //   * operands: lane (r = lane % 16, kk = lane / 16) of wave w holds, for MFMA step t, k = 16 w + 4 kk + t — ONE ds_read_b128
 //     per A block row gives a lane its operand for all four steps (which k a lane group holds is free: the MFMA sums over it)
+//   * NO barrier in the K loop: wave w needs exactly k-quarter w of every K-tile — A[:, 16 w .. 16 w + 15] and
+//     B[16 w .. 16 w + 15, :] — so it stages THAT slice itself (global_load_lds_dwordx4), into a ring of NBUF LDS buffers only it
+//     reads; it waits for its own DMAs (s_waitcnt vmcnt) and nobody else.  A slice: [BM][16] floats, 64 bytes per row — a
+//     wave's ds_read_b128 covers 1 KiB contiguous, no swizzle needed — and [16][BN] with the B rows stored in the order 0, 4, 8,
+//     12, 1, 5, ... (row 4 kk + t at position 4 t + kk): the four lane groups of a ds_read_b32 sit BN floats apart
+//   * the loop is ONE uniform body: a first version with "is there a next tile" / "is this the last tile" branches inside it had
+//     its accumulators copied through VGPRs at every join and all LDS reads parked in front of the MFMAs (768^3 14.6 us, 12.3
+//     without the branches); the DMAs for K-tiles beyond the last re-fetch the last tile into a buffer nobody reads
 //   * last K-tile of a K that is not a multiple of 64: the waves whose quarter lies beyond K sit it out, the one whose
 //     quarter ends inside zeroes the operands of its lane groups beyond K
 // Takes float4-loadable operands (K % 4 == 0, N % 4 == 0, 16-byte aligned rows); everything else stays where it was.
+// What a K-tile costs beyond its MFMAs (timing ablations, 768 x 768 x 3072, us per K-tile of a 48 x 48 tile — profiles/r04/
+// gemm_kq_ablation.log): MFMAs + LDS reads 0.56, + the DMAs 0.74, the DMAs alone 0.35.  Every global_load_lds costs the SIMD that
+// issues it ~60 cycles of MFMA issue (MI355X_MICROARCH.md prices an LDS-DMA piece at 60-185 cycles beside MFMAs; fitted over
+// the 32 / 48 / 64 tiles: 61 + 76 (TM + TN) cycles per K-tile), whoever issues it: a form with shared staging and one barrier
+// per K-tile was 1-5 % slower than this one, handing the DMAs to four extra producer waves (one per SIMD) changed nothing,
+// to two of them lost 15 % (a wave issues an LDS-DMA every ~120 cycles at best) — profiles/r04/gemm_kq_forms_ab.log.  It is
+// not the L2 either: 83 % hits, per-K-tile time independent of the row pitch (gemm_pitch_probe.log), and one CU can pull
+// 105 GB/s out of L2 through LDS-DMA when it does nothing else (tools/explore/l2_fill_bw.hip) against the 32 GB/s used here.
+// The way to spend less on staging is a tile with more flops per staged byte, i.e. fewer, larger tiles — which is what the
+// planner weighs.
 template <int TM, int TN, int NBUF, bool EDGE>
 __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
-    constexpr int BM = 16 * TM, BN = 16 * TN, BK = 64, A_SZ = BM * BK, B_SZ = BK * BN, NB = TM * TN;
-    constexpr int kDma = TM + TN;   // DMA instructions per wave per K-tile
-    static_assert(NBUF >= 3 && NB * 1024 <= NBUF * (A_SZ + B_SZ), "the four partial tiles meet in the staging buffers");
-    __shared__ __attribute__((aligned(16))) float smem[NBUF * (A_SZ + B_SZ)];
-    float *const As = smem;
-    float *const Bs = smem + NBUF * A_SZ;
+    constexpr int BM = 16 * TM, BN = 16 * TN, BK = 64, A_W = BM * 16, B_W = 16 * BN, SLICE = A_W + B_W, NB = TM * TN;
+    constexpr int kDma = TM + TN;   // DMA instructions per wave per K-tile: BM * 4 / 64 for A, 4 * BN / 64 for B
+    static_assert(NBUF >= 3 && NB * 1024 <= 4 * NBUF * SLICE, "the four partial tiles meet in the staging buffers");
+    __shared__ __attribute__((aligned(16))) float smem[4 * NBUF * SLICE];
 
     unsigned tile_m, tile_n;
     tile_coords(g, blockIdx.x, tile_m, tile_n);
@@ -1359,39 +1372,36 @@ __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lr = lane & 15, kk = lane >> 4;
     const unsigned nk = (g.K + BK - 1) / BK, kr = g.K - (nk - 1) * BK;   // kr: inner length of the last K-tile (4 .. 64, a multiple of 4)
+    float *const ring = smem + wave * (NBUF * SLICE);   // this wave's buffers
 
-    // DMA sources.  A: instruction ci = wave * TM + c covers rows 4 ci .. 4 ci + 3, lane -> (row 4 ci + lane / 16, slot lane % 16)
-    // The loop below is ONE uniform body (no "is there a next tile" / "is this the last tile" branches: a branch inside it
-    // splits the scheduling region, and the compiler then parks all LDS reads and DMAs in front of the MFMAs and copies the
-    // accumulators through VGPRs at the joins): a DMA is issued every step; the ones for K-tiles beyond the last re-fetch the
-    // last tile into a buffer nobody reads.
+    // DMA sources (one uniform loop body, as sgemm_kq_kernel: the DMAs for K-tiles beyond the last re-fetch the last tile)
     const float *a_src[TM];
-    unsigned a_back[TM];   // last K-tile: how far a chunk beyond K is pulled back (to its row's first chunk of that tile: in bounds, unused)
+    unsigned a_back[TM];
 #pragma unroll
     for (int c = 0; c < TM; ++c) {
-        const unsigned r = (wave * TM + c) * 4 + kk, q = lr ^ (r & 15u);
+        const unsigned si = c * 64 + lane, r = si >> 2, kc = si & 3u;   // row r, k-chunk kc of this wave's quarter
         unsigned grow = m0 + r;
         if (EDGE && grow >= g.M) grow = g.M - 1;
-        a_src[c] = A + (size_t)grow * g.lda + q * 4;
-        a_back[c] = q * 4 >= kr ? q * 4 : 0;
+        const unsigned k0 = wave * 16 + kc * 4;
+        a_src[c] = A + (size_t)grow * g.lda + k0;
+        a_back[c] = k0 >= kr ? k0 : 0;   // last K-tile: a chunk beyond K re-reads the row's first chunk of that tile (in bounds, unused)
     }
-    // B: slot si = (wave * TN + c) * 64 + lane of the dense [64][BN / 4] slot grid
     const float *b_src[TN];
-    size_t b_back[TN];     // last K-tile: rows beyond K re-read the last valid one (unused)
+    size_t b_back[TN];
 #pragma unroll
     for (int c = 0; c < TN; ++c) {
-        const unsigned si = (wave * TN + c) * 64 + lane, krow = si / (BN / 4);
+        const unsigned si = c * 64 + lane, pr = si / (BN / 4), krow = wave * 16 + (pr & 3u) * 4 + (pr >> 2);
         unsigned gcol = n0 + (si % (BN / 4)) * 4;
-        if (EDGE && gcol >= g.N) gcol = n0;   // (N % 4 == 0: chunks are whole; the columns beyond N are never stored)
+        if (EDGE && gcol >= g.N) gcol = n0;
         b_src[c] = B + (size_t)krow * g.ldb + gcol;
-        b_back[c] = krow >= kr ? (size_t)(krow - (kr - 1)) * g.ldb : 0;
+        b_back[c] = krow >= kr ? (size_t)(krow - (kr - 1)) * g.ldb : 0;   // last K-tile: rows beyond K re-read the last valid one
     }
     const size_t b_step = (size_t)BK * g.ldb;
-    unsigned issued = 0;   // K-tiles handed to the DMA so far (uniform)
+    unsigned issued = 0;
     auto dma_tile = [&](unsigned buf) {
-        float *as = As + buf * A_SZ + wave * (TM * 256);
-        float *bs = Bs + buf * B_SZ + wave * (TN * 256);
-        const bool last = issued + 1 >= nk;       // this is the last K-tile (or a re-fetch of it)
+        float *as = ring + buf * SLICE;
+        float *bs = as + A_W;
+        const bool last = issued + 1 >= nk;
         const unsigned a_adv = last ? 0u : (unsigned)BK;
         const size_t b_adv = last ? (size_t)0 : b_step;
 #pragma unroll
@@ -1420,54 +1430,47 @@ __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
         v4f a4[TM];
         float bv[TN][4];
     };
-    const unsigned a_off = lr * BK + (((wave * 4 + kk) ^ lr) * 4);   // (row 16 i + lr: the swizzle depends on lr only)
-    const unsigned b_off = (wave * 16 + kk * 4) * BN + lr;
+    const unsigned a_off = lr * 16 + kk * 4;
+    const unsigned b_off = A_W + kk * BN + lr;
     auto read_frag = [&](Frag &f, unsigned buf) {
-        const float *as = As + buf * A_SZ + a_off;
-        const float *bs = Bs + buf * B_SZ + b_off;
+        const float *as = ring + buf * SLICE + a_off;
+        const float *bs = ring + buf * SLICE + b_off;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) f.a4[i] = *(const v4f *)(as + i * 16 * BK);
+        for (int i = 0; i < TM; ++i) f.a4[i] = *(const v4f *)(as + i * 256);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) f.bv[j][t] = bs[t * BN + j * 16];
+            for (int t = 0; t < 4; ++t) f.bv[j][t] = bs[t * 4 * BN + j * 16];
     };
-    auto mfma_half = [&](const Frag &f, int half) {   // MFMA steps 2 half, 2 half + 1 of a K-tile
+    auto mfma_tile = [&](const Frag &f) {
 #pragma unroll
-        for (int t = 2 * half; t < 2 * half + 2; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a4[i][t], f.bv[j][t], acc[i][j], 0, 0, 0);
     };
-    constexpr int kMfmaHalf = 2 * NB, kReads = TM + 4 * TN;
+    constexpr int kMfma = 4 * NB, kReads = TM + 4 * TN;
 
-    // prologue: K-tiles 0 .. NBUF - 2 in flight, tile 0 landed and read
 #pragma unroll
     for (int t = 0; t < NBUF - 1; ++t) dma_tile((unsigned)t);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * kDma) : "memory");
-    __syncthreads();
     Frag fr[2];
     read_frag(fr[0], 0);
 
-    // One step = one K-tile that has a successor: the first half of its MFMAs goes out, THEN the wait for the next tile (the
-    // NBUF - 3 behind it may still be in flight) and the barrier — it publishes the next tile and says every wave has read
-    // this tile's fragments (one step ago), so the DMAs of the tile NBUF - 1 ahead may go into the buffer the previous tile
-    // left; the matrix pipe works through the first half while the waves meet.  Behind the barrier: the next tile's fragments
-    // and the DMAs, one behind each MFMA of the second half.
+    // One step = one K-tile that has a successor: wait for the successor's DMAs (this wave's own; the NBUF - 3 tiles behind it
+    // may still be in flight), fetch its fragments and issue the DMAs of the tile NBUF - 1 ahead (into the buffer the previous
+    // tile left: its fragments were read a step ago) behind the MFMAs of this tile.
     unsigned cur = 0;
     auto step = [&](const Frag &now, Frag &nxt_f) {
         const unsigned nxt = cur + 1 == (unsigned)NBUF ? 0 : cur + 1;
         const unsigned into = cur == 0 ? (unsigned)(NBUF - 1) : cur - 1;
-        mfma_half(now, 0);
-        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 3) * kDma) : "memory");
-        __syncthreads();
         read_frag(nxt_f, nxt);
         dma_tile(into);
-        mfma_half(now, 1);
+        mfma_tile(now);
 #pragma unroll
-        for (int q = 0; q < (kReads < kMfmaHalf ? kReads : kMfmaHalf); ++q) {
+        for (int q = 0; q < (kReads < kMfma ? kReads : kMfma); ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
         }
@@ -1476,19 +1479,17 @@ __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (global_load_lds)
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, kMfmaHalf, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfma, 0);
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
     };
-    // tiles 0 .. nk - 2 in pairs (the fragment buffers are addressed statically), the odd one, then the last tile, which a
-    // wave whose quarter lies beyond K sits out
     for (unsigned kt = 0; kt + 1 < nk; ++kt) {
         step(fr[0], fr[1]);
         fr[0] = fr[1];
     }
     if (wave * 16 < kr) {
-        if (wave * 16 + 16 > kr) {   // K % 16 != 0: this wave's quarter ends inside; the lane groups beyond K hold re-read values
-            const bool ok = wave * 16 + kk * 4 < kr;   // (K % 4 == 0: a lane's four k are all inside or all outside)
+        if (wave * 16 + 16 > kr) {   // this wave's quarter ends inside the last K-tile: the lane groups beyond K hold re-read values
+            const bool ok = wave * 16 + kk * 4 < kr;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1496,14 +1497,13 @@ __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) fr[0].bv[j][t] = ok ? fr[0].bv[j][t] : 0.0f;   // both: 0 x (a re-read NaN) would be NaN
+                for (int t = 0; t < 4; ++t) fr[0].bv[j][t] = ok ? fr[0].bv[j][t] : 0.0f;
         }
-        mfma_half(fr[0], 0);
-        mfma_half(fr[0], 1);
+        mfma_tile(fr[0]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-fetches of the last tile: they must not land in what follows)
 
-    // the four partial tiles: red[w][block][q][lane], lane-major (no bank conflicts); thread (q = wave, lane) sums block b
+    // the four partial tiles: red[w][block][q][lane], lane-major; thread (q = wave, lane) sums block b in wave order
     __syncthreads();   // (everybody is done with the staging buffers)
     float *red = smem;
 #pragma unroll
@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
             float sum = red[((0 * NB + b) * 4 + wave) * 64 + lane];
 #pragma unroll
             for (int w = 1; w < 4; ++w) sum += red[((w * NB + b) * 4 + wave) * 64 + lane];
-            const unsigned row = m0 + i * 16 + 4 * kk + wave, col = n0 + j * 16 + lr;   // D[4 (lane / 16) + q][lane % 16] of a 16 x 16 block
+            const unsigned row = m0 + i * 16 + 4 * kk + wave, col = n0 + j * 16 + lr;
             if (!EDGE || (row < g.M && col < g.N)) __builtin_nontemporal_store(sum, &C[(size_t)row * g.ldc + col]);
         }
 }
@@ -2376,7 +2376,7 @@ bool g_splitk = true;   // np_sgemm_set_variant(-1) turns the K-splitting plans 
 struct Plan { int cfg; unsigned tail_rows, S; size_t Kc; double t; };
 
 // t_alt: the modelled time of an alternative the caller holds (stream-K): the mid-size tiles must clear it as well
-int g_plan_cus = 0;   // np_sgemm_debug_plan: plan for this many CUs instead of the current device's (the planner is host arithmetic: testable without a device)
+thread_local int g_plan_cus = 0;   // (per host thread, like g_progress) np_sgemm_debug_plan: plan for this many CUs instead of the current device's (the planner is host arithmetic: testable without a device)
 inline int plan_cus() { return g_plan_cus ? g_plan_cus : np::num_cus(); }
 
 Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool only_dma = false, bool vec = true, bool splitk = true,
