@@ -368,6 +368,38 @@ unsigned grid_for(size_t work_items, int per_thread, int blocks_per_cu) {
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
+// FULL (op) ROW with whole float4 columns (cols % 4 == 0, at least one workgroup of them): a lane owns ONE float4 column of a
+// block of RPT rows — the row operand's four values are loaded once and stay in registers, the RPT loads of the full operand
+// are independent and in flight together, one multiply-high division per lane.  binary_vec_kernel's flat walk pays a 32-bit
+// modulo and a second (cache-resident) load per float4 for the same result (profiles/r04/bcast2d_ab.log).  Same binary_apply, same bits.  blockIdx.x = column block (fastest: neighbouring workgroups stream
+// neighbouring memory), blockIdx.y strides over the row blocks.
+template <int OP, bool QUIRK, bool ROW_IS_A, int RPT>
+__global__ __launch_bounds__(256) void binary_rows2d_kernel(const float *__restrict__ full, const float *__restrict__ row,
+                                                            float *__restrict__ out, unsigned rows, unsigned cols, unsigned body_end,
+                                                            unsigned items, unsigned div_m, unsigned div_s1, unsigned div_s2) {
+    // work item = (row block, float4 column), column fastest, no padding of the last column block: ONE multiply-high division
+    // per lane (for RPT float4s) instead of a modulo per float4
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= items) return;
+    const unsigned cols4 = cols / 4, rb = fast_div(id, div_m, div_s1, div_s2), c0 = (id - rb * cols4) * 4, r0 = rb * RPT;
+    const v4f rv = *(const v4f_u *)(row + c0);
+    v4f x[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u)
+        if (r0 + u < rows) x[u] = ld4<true>(full + (size_t)(r0 + u) * cols + c0);
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        if (r0 + u < rows) {
+            const unsigned e = (r0 + u) * cols + c0;
+            v4f r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r[k] = ROW_IS_A ? binary_apply<OP, QUIRK>(rv[k], x[u][k], (e + k) < body_end) : binary_apply<OP, QUIRK>(x[u][k], rv[k], (e + k) < body_end);
+            st4<true>(out + (size_t)(r0 + u) * cols + c0, r);
+        }
+    }
+}
+
 // ---- binary dispatch ----
 
 template <int OP, int AK, int BK, bool QUIRK, typename I>
@@ -377,6 +409,28 @@ int launch_binary_vec(const float *a, const float *b, float *out, size_t n, size
     const I nvec = (I)(n / 4), cols4 = (I)(cols / 4), tail = (I)(n / 4 * 4);
     unsigned grid = grid_for(n / 4 + 1, c.unroll, c.blocks_per_cu);
     hipStream_t s = np::stream();
+    // FULL (op) ROW on whole float4 columns: the 2-D form (binary_rows2d_kernel; variant 8100: off).  Rows shorter than one
+    // workgroup of float4s and vectors too long to stay cached (the column-block order below) keep the flat walk.
+    if constexpr (((AK == NP_ROW && BK == NP_FULL) || (AK == NP_FULL && BK == NP_ROW)) && OP != NP_POW && sizeof(I) == 4) {
+        // (measured in alternation, profiles/r04/bcast2d_ab.log: row (op) X +8-10 % everywhere; X (op) row +-1 % on rows of a few
+        // thousand floats — the flat walk's modulo and second load are hidden there — and +2-4 % on rows of 10^5 and more)
+        if (cols % 32 == 0 && cols >= 1024 && (AK == NP_ROW || cols >= 65536) && cols < (size_t(1) << 22) && n / cols >= 2 && g_variant == 0 &&
+            !np::g_bcast2d_off) {
+            constexpr int RPT = 2;   // (as binary_vec_kernel's two float4 per lane: fatter lanes stream slower on this machine, 8 rows per lane lost 4 %)
+            const size_t rows = n / cols, row_blocks = (rows + RPT - 1) / RPT, items = row_blocks * (cols / 4);   // (< 2^31: n is)
+            unsigned dm, d1, d2;
+            fast_div_magic(cols / 4, dm, d1, d2);
+            const unsigned grid2 = (unsigned)((items + 255) / 256);
+            if constexpr (AK == NP_ROW)
+                binary_rows2d_kernel<OP, QUIRK, true, RPT><<<grid2, 256, 0, s>>>(b, a, out, (unsigned)rows, (unsigned)cols, (unsigned)body_end,
+                                                                                   (unsigned)items, dm, d1, d2);
+            else
+                binary_rows2d_kernel<OP, QUIRK, false, RPT><<<grid2, 256, 0, s>>>(a, b, out, (unsigned)rows, (unsigned)cols, (unsigned)body_end,
+                                                                                    (unsigned)items, dm, d1, d2);
+            NP_LAUNCH_CHECK("binary_rows2d_kernel");
+            return NP_OK;
+        }
+    }
     Ragged<I> rg{0, 0, 0, 0, 0, 0};
     // a ROW operand of >= 16 MB under a result of several rows: column-block order (Ragged::rowblock_rows; variant 8000: off).
     // 7 x 10^7 4.79 -> 5.71 TB/s, 3 x 3*10^7 4.84 -> 5.73; an 8 MB vector (40 x 2*10^6) is served by the Infinity Cache either
@@ -1542,6 +1596,7 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
 }
 
 namespace np {
+int g_bcast2d_off = 0;
 int device_copy(void *dst, const void *src, size_t bytes) {
     const size_t n = bytes / 4;
     const unsigned grid = grid_for(n / 4 + 1, 2, 0);
@@ -1623,6 +1678,10 @@ int np_fused_chain_reduce_axis(const float *const *inputs, const int *input_kind
 }
 
 int np_elementwise_set_variant(int variant) {
+    if (variant == 8100 || variant == 8101) {   // 8100: broadcasts on the flat kernels as before round 4's 2-D forms (A/B), 8101: back
+        np::g_bcast2d_off = variant == 8100;
+        return NP_OK;
+    }
     g_variant = variant;
     return NP_OK;
 }

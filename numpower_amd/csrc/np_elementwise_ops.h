@@ -452,6 +452,15 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned m, unsigned s1
     return (t + ((n - t) >> s1)) >> s2;
 }
 
+// host side: the constants of fast_div for a divisor d >= 1 (d == 1: q = n through m = 0 ... handled by the callers' d >= 2)
+inline void fast_div_magic(unsigned long long d, unsigned &m, unsigned &s1, unsigned &s2) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    m = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+    s1 = l ? 1 : 0;
+    s2 = l ? l - 1 : 0;
+}
+
 }  // namespace
 
 #endif

@@ -302,6 +302,75 @@ __global__ __launch_bounds__(256) void cchain_cols_kernel(CArgs a, float *__rest
     }
 }
 
+// out[r][c] = chain(r, c) with broadcast operands, on whole float4 columns (cols % 4 == 0, at least one workgroup of them): a
+// lane owns ONE float4 column of a block of RPT rows — the geometry of binary_rows2d_kernel (np_elementwise.hip).  A ROW
+// operand's four values are loaded once, a COL operand is one scalar per row (the same address in every lane), no division
+// to find (row, col), RPT independent loads of every full operand in flight.  The flat kernel pays a fast_div and a second
+// (cached) load per float4 for the same values: exp(X) + col 6.1 -> 6.4 TB/s, x * x + col + row +12-14 %, exp(X) + row +-0
+// (profiles/r04/bcast2d_ab.log, in alternation).  Two rows per lane: fatter lanes stream slower on this machine (four: -3 %).
+template <class CH, int RPT>
+__global__ __launch_bounds__(256) void cchain_tile2d_kernel(CArgs a, float *__restrict__ out, unsigned rows, unsigned cols, unsigned items) {
+    // work item = (row block, float4 column), column fastest; a.div_* divide by cols / 4 here
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= items) return;
+    const unsigned rb = fast_div(id, a.div_m, a.div_s1, a.div_s2), c0 = (id - rb * (cols / 4)) * 4, r0 = rb * RPT;
+    float rowop[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k < CH::n && cs_kind(CH::at(k)) == CK_ARRAY) {
+            v4f t = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+            if (a.idx[k] == 1) t = *(const v4f_u *)(a.operand[k] + c0);
+            else if (a.idx[k] == 3) t = v4f{a.operand[k][0], a.operand[k][0], a.operand[k][0], a.operand[k][0]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rowop[k][e] = t[e];
+        }
+    const auto rows_at = [&](auto count, unsigned r) {   // `count` consecutive rows from r
+        constexpr int U = decltype(count)::value;
+        v4f x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load((const v4f_u *)(a.in0 + (size_t)(r + u) * cols + c0));
+        float oth[3][U * 4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < CH::n && cs_kind(CH::at(k)) == CK_ARRAY) {
+                if (a.idx[k] == 0) {   // uniform
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const v4f t = __builtin_nontemporal_load((const v4f_u *)(a.operand[k] + (size_t)(r + u) * cols + c0));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) oth[k][u * 4 + e] = t[e];
+                    }
+                } else if (a.idx[k] == 2) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float t = a.operand[k][r + u];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) oth[k][u * 4 + e] = t;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) oth[k][u * 4 + e] = rowop[k][e];
+                }
+            }
+        float acc[U * 4];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[u * 4 + e] = x[u][e];
+        c_step<CH, 0, U * 4>(a, acc, oth);
+        c_step<CH, 1, U * 4>(a, acc, oth);
+        c_step<CH, 2, U * 4>(a, acc, oth);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            __builtin_nontemporal_store(v4f{acc[u * 4], acc[u * 4 + 1], acc[u * 4 + 2], acc[u * 4 + 3]}, (v4f_u *)(out + (size_t)(r + u) * cols + c0));
+    };
+    if (r0 + RPT <= rows) rows_at(std::integral_constant<int, RPT>{}, r0);
+    else
+        for (unsigned r = r0; r < rows; ++r) rows_at(std::integral_constant<int, 1>{}, r);
+}
+
 // Chain ending in a reduction over the LAST axis: out[r] = reduce over c of chain(r, c).  The interpreter's wave mode
 // (fused_chain_rows_kernel): groups of L lanes (a power of two <= 64) own a row each, so short rows still fill the wave; no
 // barrier anywhere.  cols % 4 == 0; the row index is known (no division), two slots per trip without masks, the ragged
@@ -394,6 +463,7 @@ __global__ __launch_bounds__(256) void cchain_rows_kernel(CArgs a, float *__rest
 
 struct Launchers {
     int key[3];
+    void (*tile2d_store)(const CArgs &, float *, unsigned, unsigned, unsigned, hipStream_t);   // chains with an array operand, len >= 2
     void (*flat_store)(const CArgs &, float *, unsigned, unsigned, hipStream_t);
     void (*flat_sum)(const CArgs &, float *, unsigned, unsigned, hipStream_t);
     void (*cols_sum)(const CArgs &, float *, unsigned, unsigned, unsigned, float, dim3, hipStream_t, int);
@@ -403,6 +473,15 @@ struct Launchers {
 template <class CH, int SINK>
 void launch_flat(const CArgs &a, float *out, unsigned n, unsigned grid, hipStream_t s) {
     cchain_flat_kernel<CH, SINK><<<grid, 256, 0, s>>>(a, out, n);
+}
+template <class CH>
+void launch_tile2d(const CArgs &a, float *out, unsigned rows, unsigned cols, unsigned items, hipStream_t s) {
+    cchain_tile2d_kernel<CH, 2><<<(items + 255) / 256, 256, 0, s>>>(a, out, rows, cols, items);
+}
+template <class CH>
+constexpr auto tile2d_or_null() -> void (*)(const CArgs &, float *, unsigned, unsigned, unsigned, hipStream_t) {
+    if constexpr (CH::has_array()) return launch_tile2d<CH>;
+    else return nullptr;
 }
 template <class CH>
 void launch_cols(const CArgs &a, float *out, unsigned rows, unsigned cols, unsigned rows_per_chunk, float mean_div, dim3 grid,
@@ -418,9 +497,9 @@ void launch_rows(const CArgs &a, float *out, unsigned rows, unsigned cols, unsig
     cchain_rows_kernel<CH, NP_SUM><<<grid, 256, 0, s>>>(a, out, rows, cols, L, mean_div);
 }
 
-#define NP_ROW1(S0) {{S0, kNoStep, kNoStep}, nullptr, launch_flat<CChain<S0>, NP_SUM>, launch_cols<CChain<S0>>, launch_rows<CChain<S0>>},
-#define NP_ROW2(S0, S1) {{S0, S1, kNoStep}, launch_flat<CChain<S0, S1>, -1>, launch_flat<CChain<S0, S1>, NP_SUM>, launch_cols<CChain<S0, S1>>, launch_rows<CChain<S0, S1>>},
-#define NP_ROW3(S0, S1, S2) {{S0, S1, S2}, launch_flat<CChain<S0, S1, S2>, -1>, launch_flat<CChain<S0, S1, S2>, NP_SUM>, launch_cols<CChain<S0, S1, S2>>, launch_rows<CChain<S0, S1, S2>>},
+#define NP_ROW1(S0) {{S0, kNoStep, kNoStep}, nullptr, nullptr, launch_flat<CChain<S0>, NP_SUM>, launch_cols<CChain<S0>>, launch_rows<CChain<S0>>},
+#define NP_ROW2(S0, S1) {{S0, S1, kNoStep}, tile2d_or_null<CChain<S0, S1>>(), launch_flat<CChain<S0, S1>, -1>, launch_flat<CChain<S0, S1>, NP_SUM>, launch_cols<CChain<S0, S1>>, launch_rows<CChain<S0, S1>>},
+#define NP_ROW3(S0, S1, S2) {{S0, S1, S2}, tile2d_or_null<CChain<S0, S1, S2>>(), launch_flat<CChain<S0, S1, S2>, -1>, launch_flat<CChain<S0, S1, S2>, NP_SUM>, launch_cols<CChain<S0, S1, S2>>, launch_rows<CChain<S0, S1, S2>>},
 const Launchers kMenu[] = {NP_CCHAINS_1(NP_ROW1) NP_CCHAINS_2(NP_ROW2) NP_CCHAINS_3(NP_ROW3)};
 #undef NP_ROW1
 #undef NP_ROW2
@@ -478,6 +557,16 @@ int fused_static_flat(const FusedStaticDesc &d, float *out, size_t n, int sink, 
     fill_args(d, a);
     a.ticket = ticket;
     a.result = result;
+    // stored chains with a broadcast operand on whole float4 columns: the 2-D form (cchain_tile2d_kernel)
+    if (sink < 0 && l->tile2d_store && d.bcast_cols >= 1024 && d.bcast_cols % 32 == 0 && n % d.bcast_cols == 0 && n / d.bcast_cols >= 2 &&
+        !np::g_bcast2d_off) {
+        constexpr unsigned RPT = 2;   // (the template argument of launch_tile2d)
+        const unsigned rows = (unsigned)(n / d.bcast_cols), row_blocks = (rows + RPT - 1) / RPT;
+        fast_div_magic(d.bcast_cols / 4, a.div_m, a.div_s1, a.div_s2);   // (the flat kernel divides by cols, this one by cols / 4)
+        l->tile2d_store(a, out, rows, d.bcast_cols, row_blocks * (d.bcast_cols / 4), np::stream());
+        NP_LAUNCH_CHECK("cchain_tile2d_kernel");
+        return NP_OK;
+    }
     (sink < 0 ? l->flat_store : l->flat_sum)(a, out, (unsigned)n, grid, np::stream());
     NP_LAUNCH_CHECK("cchain_flat_kernel");
     return NP_OK;

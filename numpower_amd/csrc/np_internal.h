@@ -79,6 +79,7 @@ int sgemm_batched_piece(size_t count, size_t whole, size_t M, size_t N, size_t K
 // might be on the menu of straight-line kernels.  operand[k] == nullptr: a scalar operand (or a unary step); idx[k]: how an
 // array operand is indexed by the flat element index e of the rows x cols result — 0 full, 1 row (e % cols), 2 column
 // (e / cols), 3 zero-d.  bcast_cols: the row length when some operand is broadcast (then a multiple of 4), else 0.
+extern int g_bcast2d_off;   // np_elementwise_set_variant(8100): the 2-D broadcast kernels off (A/B)
 struct FusedStaticDesc {
     int n_ops;
     const float *in0;

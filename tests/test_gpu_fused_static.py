@@ -49,7 +49,7 @@ CHAINS = [
     ([U("tanh"), B("add", 1)], [FULL]),                              # NOT on the menu: interpreter both times
     ([B("subtract", 1, 1), U("exp")], [FULL]),                       # swapped operand order: not on the menu either
 ]
-SHAPES = [(1, 5), (3, 8), (1, 1028), (37, 64), (300, 1000), (1, 70001), (515, 516), (2000, 4000), (9000, 36)]
+SHAPES = [(1, 5), (3, 8), (1, 1028), (37, 64), (300, 1000), (1, 70001), (515, 516), (2000, 4000), (9000, 36), (3, 1024), (37, 2048)]   # (the last three: cchain_tile2d_kernel)
 
 
 def _build(steps, kinds, rows, cols, seed):

@@ -173,6 +173,29 @@ def test_binary_long_row_operand_column_block_order(shape, hip, oracle):
             assert_bit_equal(got, oracle.binary(op, ox, oy), "%s %s" % (op, shape))
 
 
+@pytest.mark.parametrize("shape", [(37, 1024), (2, 2048), (1001, 1056), (3, 65536), (5, 131104), (8, 70016)])
+def test_binary_row_operand_2d_form(shape, hip, oracle):
+    """X (op) row on whole, 128-byte-aligned float4 columns runs binary_rows2d_kernel (a lane owns one float4 column of two
+    rows; np_elementwise.hip) — for the row vector as the LEFT operand from 1024 columns, as the right one from 65536: the same
+    bits as the flat walk (np_elementwise_set_variant(8100)) and as the oracle, odd row counts and quirk flags included."""
+    from numpower_amd.ndarray import NDArray
+    from numpower_amd._lib import check, load
+    lib = load()
+    a, b = _pair(shape, 23)
+    row = b[0].copy()
+    ga, grow = NDArray.array(a).gpu(), NDArray.array(row).gpu()
+    for op in ("add", "divide", "multiply", "mod"):
+        for x, y, ox, oy in ((ga, grow, a, row), (grow, ga, row, a)):
+            got = NDArray._binary(op, x, y).cpu().numpy()
+            check(lib.np_elementwise_set_variant(8100))
+            try:
+                flat = NDArray._binary(op, x, y).cpu().numpy()
+            finally:
+                check(lib.np_elementwise_set_variant(8101))
+            assert_bit_equal(got, flat, "%s %s vs the flat walk" % (op, shape))
+            assert_bit_equal(got, oracle.binary(op, ox, oy), "%s %s" % (op, shape))
+
+
 def test_binary_view_operand(hip, oracle):
     """$a + $a[1]: the row operand is a view into the same buffer (unaligned for odd widths)."""
     from numpower_amd.ndarray import NDArray
