@@ -1333,35 +1333,31 @@ __global__ __launch_bounds__(SH::THREADS, 2) void sgemm_dmas_kernel(GemmArgs g, 
 // 48 x 48 for 768^3, 32 x 32 for 512^3 — and v_mfma_f32_32x32x2 cannot cut a 48 x 48 tile into four waves.  So here every
 // wave computes the WHOLE tile, (16 TM) x (16 TN) as TM x TN blocks of v_mfma_f32_16x16x4 (the same flop rate), over a
 // quarter of each 64-deep K-tile, and the four partial tiles meet in LDS at the end (summed in wave order: deterministic).
-//   * operands: lane (r = lane % 16, kk = lane / 16) of wave w holds, for MFMA step t, k = 16 w + 4 kk + t — ONE ds_read_b128
-//     per A block row gives a lane its operand for all four steps (which k a lane group holds is free: the MFMA sums over it)
-//   * NO barrier in the K loop: wave w needs exactly k-quarter w of every K-tile — A[:, 16 w .. 16 w + 15] and
-//     B[16 w .. 16 w + 15, :] — so it stages THAT slice itself (global_load_lds_dwordx4), into a ring of NBUF LDS buffers only it
-//     reads; it waits for its own DMAs (s_waitcnt vmcnt) and nobody else.  A slice: [BM][16] floats, 64 bytes per row — a
-//     wave's ds_read_b128 covers 1 KiB contiguous, no swizzle needed — and [16][BN] with the B rows stored in the order 0, 4, 8,
-//     12, 1, 5, ... (row 4 kk + t at position 4 t + kk): the four lane groups of a ds_read_b32 sit BN floats apart
-//   * the loop is ONE uniform body: a first version with "is there a next tile" / "is this the last tile" branches inside it had
-//     its accumulators copied through VGPRs at every join and all LDS reads parked in front of the MFMAs (768^3 14.6 us, 12.3
-//     without the branches); the DMAs for K-tiles beyond the last re-fetch the last tile into a buffer nobody reads
-//   * last K-tile of a K that is not a multiple of 64: the waves whose quarter lies beyond K sit it out, the one whose
-//     quarter ends inside zeroes the operands of its lane groups beyond K
-// Takes float4-loadable operands (K % 4 == 0, N % 4 == 0, 16-byte aligned rows); everything else stays where it was.
-// What a K-tile costs beyond its MFMAs (timing ablations, 768 x 768 x 3072, us per K-tile of a 48 x 48 tile — profiles/r04/
-// gemm_kq_ablation.log): MFMAs + LDS reads 0.56, + the DMAs 0.74, the DMAs alone 0.35.  Every global_load_lds costs the SIMD that
-// issues it ~60 cycles of MFMA issue (MI355X_MICROARCH.md prices an LDS-DMA piece at 60-185 cycles beside MFMAs; fitted over
-// the 32 / 48 / 64 tiles: 61 + 76 (TM + TN) cycles per K-tile), whoever issues it: a form with shared staging and one barrier
-// per K-tile was 1-5 % slower than this one, handing the DMAs to four extra producer waves (one per SIMD) changed nothing,
-// to two of them lost 15 % (a wave issues an LDS-DMA every ~120 cycles at best) — profiles/r04/gemm_kq_forms_ab.log.  It is
-// not the L2 either: 83 % hits, per-K-tile time independent of the row pitch (gemm_pitch_probe.log), and one CU can pull
-// 105 GB/s out of L2 through LDS-DMA when it does nothing else (tools/explore/l2_fill_bw.hip) against the 32 GB/s used here.
-// The way to spend less on staging is a tile with more flops per staged byte, i.e. fewer, larger tiles — which is what the
-// planner weighs.
-template <int TM, int TN, int NBUF, bool EDGE>
-__global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
-    constexpr int BM = 16 * TM, BN = 16 * TN, BK = 64, A_W = BM * 16, B_W = 16 * BN, SLICE = A_W + B_W, NB = TM * TN;
-    constexpr int kDma = TM + TN;   // DMA instructions per wave per K-tile: BM * 4 / 64 for A, 4 * BN / 64 for B
-    static_assert(NBUF >= 3 && NB * 1024 <= 4 * NBUF * SLICE, "the four partial tiles meet in the staging buffers");
-    __shared__ __attribute__((aligned(16))) float smem[4 * NBUF * SLICE];
+// NO LDS in the K loop: a wave's k-quarter is read by nobody else, and the v_mfma_f32_16x16x4 operand layouts ARE loadable
+// straight from row-major memory — lane (r, kk) takes A[16 i + r][k0 + 4 kk .. + 3] as one global_load_dwordx4 (its A operand
+// for four MFMA steps; which k a lane group holds is free: the MFMA sums over it) and B[k0 + 4 kk + t][16 j + r] as four
+// global_load_dword (16 lanes = 64 contiguous bytes).  Operands for the K-tile two ahead are in flight in registers (three
+// stages, the loop unrolled by three so that they are addressed statically; the compiler places the s_waitcnt).
+// How it got here (profiles/r04/gemm_kq_forms_ab.log, gemm_kq_ablation.log, mfma_filler_cost.log, gemm_kq_direct_ab.log):
+//   * first form: the slices staged through LDS by global_load_lds, shared [BM][64] / [64][BN] buffers, one barrier per K-tile:
+//     768^3 12.3 us, a K-tile of a 48 x 48 tile 0.74 us where its 36 MFMAs take 0.51.  Wave-private LDS rings without any
+//     barrier: -2 %.  The DMAs on two / four extra producer waves: +15 % / +-0.  Timing ablations: MFMAs + LDS reads 0.56 us,
+//     + the DMAs 0.74, the DMAs alone 0.35.  The L2 was not it (83 % hits, per-K-tile time independent of the row pitch, one CU
+//     pulls 105 GB/s through LDS-DMA when it does nothing else, against the 32 GB/s used).
+//   * what it was: beside back-to-back MFMAs an LDS-DMA piece costs the issuing SIMD ~45 cycles, a ds_write_b128 ~20, a
+//     ds_read_b128 ~11, a plain global load ~7 and a VALU instruction ~6 (tools/explore/mfma_filler_cost.hip) — so 6 DMAs + 9 LDS
+//     reads per K-tile became 15 plain loads, and the per-lane 64-bit pointer arithmetic of a first direct version (~50 VALU
+//     instructions per K-tile) became a uniform base advanced by scalar instructions plus constant 32-bit byte offsets:
+//     0.74 -> 0.69 -> 0.61 us per K-tile; 768^3 12.2 -> 10.3 us (74 -> 88 TFLOP/s), 768 x 768 x 3072 39.6 -> 32.3 (112),
+//     512^3 5.7 -> 4.9 (55), 704^3 10.7 -> 9.3, 832^3 17.0 (64 x 64 LDS-DMA tiles) -> 14.7.
+// Takes float4-loadable operands (K % 4 == 0, N % 4 == 0, 16-byte aligned rows) below 4 GiB each; the rest stays where it was.
+// Last K-tile of a K that is not a multiple of 64: the waves whose quarter lies beyond K sit it out, the one whose quarter
+// ends inside zeroes the operands of its lane groups beyond K (loads beyond K re-read something in bounds); K-tiles beyond the
+// last (the prefetch runs two ahead) re-fetch the last one.
+template <int TM, int TN, bool EDGE>
+__global__ __launch_bounds__(256, 2) void sgemm_kq_kernel(GemmArgs g) {
+    constexpr int BM = 16 * TM, BN = 16 * TN, BK = 64, NB = TM * TN;
+    __shared__ float red[4 * NB * 4 * 64];
 
     unsigned tile_m, tile_n;
     tile_coords(g, blockIdx.x, tile_m, tile_n);
@@ -1372,76 +1368,61 @@ __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lr = lane & 15, kk = lane >> 4;
     const unsigned nk = (g.K + BK - 1) / BK, kr = g.K - (nk - 1) * BK;   // kr: inner length of the last K-tile (4 .. 64, a multiple of 4)
-    float *const ring = smem + wave * (NBUF * SLICE);   // this wave's buffers
+    const unsigned kq = wave * 16 + kk * 4;                                // this lane's first k inside a K-tile
 
-    // DMA sources (one uniform loop body, as sgemm_kq_kernel: the DMAs for K-tiles beyond the last re-fetch the last tile)
-    const float *a_src[TM];
-    unsigned a_back[TM];
+    // Sources: a UNIFORM base per operand, advanced one K-tile per load (scalar arithmetic), plus per-lane BYTE offsets that never
+    // change (32-bit: the launcher checks that both operands are below 4 GiB) — the loads take the base-in-SGPRs form and cost
+    // no vector arithmetic per K-tile (a first version with per-lane 64-bit pointers spent ~50 VALU instructions per K-tile on
+    // them, ~6 cycles each beside MFMAs).  Last K-tile: a second offset set, with what lies beyond K pulled back to something
+    // in bounds (zeroed / skipped below).
+    const char *a_base = (const char *)A, *b_base = (const char *)B;
+    unsigned a_off[TM], a_off_last[TM];
 #pragma unroll
-    for (int c = 0; c < TM; ++c) {
-        const unsigned si = c * 64 + lane, r = si >> 2, kc = si & 3u;   // row r, k-chunk kc of this wave's quarter
-        unsigned grow = m0 + r;
+    for (int i = 0; i < TM; ++i) {
+        unsigned grow = m0 + 16 * i + lr;
         if (EDGE && grow >= g.M) grow = g.M - 1;
-        const unsigned k0 = wave * 16 + kc * 4;
-        a_src[c] = A + (size_t)grow * g.lda + k0;
-        a_back[c] = k0 >= kr ? k0 : 0;   // last K-tile: a chunk beyond K re-reads the row's first chunk of that tile (in bounds, unused)
+        a_off[i] = (grow * g.lda + kq) * 4u;
+        a_off_last[i] = a_off[i] - (kq >= kr ? kq : 0u) * 4u;
     }
-    const float *b_src[TN];
-    size_t b_back[TN];
+    unsigned b_off[4], b_off_last[4], col_b[TN];
 #pragma unroll
-    for (int c = 0; c < TN; ++c) {
-        const unsigned si = c * 64 + lane, pr = si / (BN / 4), krow = wave * 16 + (pr & 3u) * 4 + (pr >> 2);
-        unsigned gcol = n0 + (si % (BN / 4)) * 4;
-        if (EDGE && gcol >= g.N) gcol = n0;
-        b_src[c] = B + (size_t)krow * g.ldb + gcol;
-        b_back[c] = krow >= kr ? (size_t)(krow - (kr - 1)) * g.ldb : 0;   // last K-tile: rows beyond K re-read the last valid one
+    for (int j = 0; j < TN; ++j) {
+        unsigned gcol = n0 + 16 * j + lr;
+        if (EDGE && gcol >= g.N) gcol = g.N - 1;
+        col_b[j] = EDGE ? gcol * 4u : (unsigned)(16 * j * 4);   // (not EDGE: n0 + lr sits in b_off, 64 j becomes the instruction's offset)
     }
-    const size_t b_step = (size_t)BK * g.ldb;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        b_off[t] = ((kq + t) * g.ldb + (EDGE ? 0u : n0 + lr)) * 4u;
+        b_off_last[t] = b_off[t] - (kq + t >= kr ? (kq + t - (kr - 1)) * g.ldb : 0u) * 4u;
+    }
+    const size_t b_step = (size_t)BK * g.ldb * 4;
+    struct Frag {
+        v4f a4[TM];
+        float bv[TN][4];
+    };
     unsigned issued = 0;
-    auto dma_tile = [&](unsigned buf) {
-        float *as = ring + buf * SLICE;
-        float *bs = as + A_W;
-        const bool last = issued + 1 >= nk;
-        const unsigned a_adv = last ? 0u : (unsigned)BK;
-        const size_t b_adv = last ? (size_t)0 : b_step;
+    auto load_tile = [&](Frag &f) {
+        const bool last = issued + 1 >= nk;   // uniform
 #pragma unroll
-        for (int c = 0; c < TM; ++c) {
-            const float *src = a_src[c] - (last ? a_back[c] : 0u);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(as + c * 256), 16, 0, 0);
-            a_src[c] += a_adv;
+        for (int i = 0; i < TM; ++i) f.a4[i] = *(const v4f *)(a_base + (last ? a_off_last[i] : a_off[i]));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned off = last ? b_off_last[t] : b_off[t];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f.bv[j][t] = *(const float *)(b_base + (off + col_b[j]));
         }
-#pragma unroll
-        for (int c = 0; c < TN; ++c) {
-            const float *src = b_src[c] - (last ? b_back[c] : (size_t)0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(bs + c * 256), 16, 0, 0);
-            b_src[c] += b_adv;
+        if (!last) {
+            a_base += BK * 4;
+            b_base += b_step;
         }
         ++issued;
     };
-
     v4f acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    struct Frag {
-        v4f a4[TM];
-        float bv[TN][4];
-    };
-    const unsigned a_off = lr * 16 + kk * 4;
-    const unsigned b_off = A_W + kk * BN + lr;
-    auto read_frag = [&](Frag &f, unsigned buf) {
-        const float *as = ring + buf * SLICE + a_off;
-        const float *bs = ring + buf * SLICE + b_off;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) f.a4[i] = *(const v4f *)(as + i * 256);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) f.bv[j][t] = bs[t * 4 * BN + j * 16];
-    };
     auto mfma_tile = [&](const Frag &f) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -1450,62 +1431,55 @@ __global__ __launch_bounds__(256, 1) void sgemm_kq_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a4[i][t], f.bv[j][t], acc[i][j], 0, 0, 0);
     };
-    constexpr int kMfma = 4 * NB, kReads = TM + 4 * TN;
-
-#pragma unroll
-    for (int t = 0; t < NBUF - 1; ++t) dma_tile((unsigned)t);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * kDma) : "memory");
-    Frag fr[2];
-    read_frag(fr[0], 0);
-
-    // One step = one K-tile that has a successor: wait for the successor's DMAs (this wave's own; the NBUF - 3 tiles behind it
-    // may still be in flight), fetch its fragments and issue the DMAs of the tile NBUF - 1 ahead (into the buffer the previous
-    // tile left: its fragments were read a step ago) behind the MFMAs of this tile.
-    unsigned cur = 0;
-    auto step = [&](const Frag &now, Frag &nxt_f) {
-        const unsigned nxt = cur + 1 == (unsigned)NBUF ? 0 : cur + 1;
-        const unsigned into = cur == 0 ? (unsigned)(NBUF - 1) : cur - 1;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 3) * kDma) : "memory");
-        read_frag(nxt_f, nxt);
-        dma_tile(into);
+    constexpr int kMfma = 4 * NB, kLoads = TM + 4 * TN;
+    auto step = [&](const Frag &now, Frag &into) {   // the loads of the K-tile two ahead behind the MFMAs of this one
+        load_tile(into);
         mfma_tile(now);
 #pragma unroll
-        for (int q = 0; q < (kReads < kMfma ? kReads : kMfma); ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-        }
-#pragma unroll
-        for (int q = 0; q < kDma; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (global_load_lds)
+        for (int q = 0; q < kLoads; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, kMfma / kLoads, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
         }
         __builtin_amdgcn_sched_group_barrier(0x008, kMfma, 0);
         __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
     };
-    for (unsigned kt = 0; kt + 1 < nk; ++kt) {
-        step(fr[0], fr[1]);
-        fr[0] = fr[1];
-    }
-    if (wave * 16 < kr) {
-        if (wave * 16 + 16 > kr) {   // this wave's quarter ends inside the last K-tile: the lane groups beyond K hold re-read values
-            const bool ok = wave * 16 + kk * 4 < kr;
+    auto final_tile = [&](Frag &f) {
+        if (wave * 16 >= kr) return;   // this wave's quarter lies beyond K
+        if (wave * 16 + 16 > kr) {     // ... or ends inside: the lane groups beyond K hold re-read values
+            const bool ok = kq < kr;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) fr[0].a4[i][e] = ok ? fr[0].a4[i][e] : 0.0f;
+                for (int e = 0; e < 4; ++e) f.a4[i][e] = ok ? f.a4[i][e] : 0.0f;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) fr[0].bv[j][t] = ok ? fr[0].bv[j][t] : 0.0f;
+                for (int t = 0; t < 4; ++t) f.bv[j][t] = ok ? f.bv[j][t] : 0.0f;
         }
-        mfma_tile(fr[0]);
+        mfma_tile(f);
+    };
+
+    Frag s0, s1, s2;
+    load_tile(s0);
+    load_tile(s1);
+    unsigned kt = 0;
+    for (; kt + 3 < nk; kt += 3) {   // K-tiles kt, kt + 1, kt + 2 all have a successor
+        step(s0, s2);
+        step(s1, s0);
+        step(s2, s1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-fetches of the last tile: they must not land in what follows)
+    const unsigned left = nk - 1 - kt;   // 0 .. 2 tiles before the last one
+    if (left == 0) final_tile(s0);
+    else if (left == 1) {
+        step(s0, s2);
+        final_tile(s1);
+    } else {
+        step(s0, s2);
+        step(s1, s0);
+        final_tile(s2);
+    }
 
     // the four partial tiles: red[w][block][q][lane], lane-major; thread (q = wave, lane) sums block b in wave order
-    __syncthreads();   // (everybody is done with the staging buffers)
-    float *red = smem;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -2281,17 +2255,20 @@ int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
 //        2048^3 on 256 tiles of 128x128 149 us (the model's 0.64 said 171) -> 0.83; 1024^3 on 256 tiles of 64x64 22.4 us
 //        against the old kernel's 31.1 -> 0.74; several waves: 0.87 / 0.82 / 0.80.  Operands of any alignment (1001 x 1003
 //        x 1002: 26.2 us against 40.6 on the padded / register-staged forms), so these take every product the planner has.
-//   6, 7 sgemm_kq_kernel: 48 x 48 and 32 x 32 tiles, the four waves of a workgroup split K (v_mfma_f32_16x16x4); whole K only,
-//        float4-loadable operands.  One 48 x 48 workgroup per CU (96 KiB of LDS), two 32 x 32 ones.  Fitted on
-//        profiles/r04/gemm_kq_sweep2.log: a 64-deep K-tile of a 48 x 48 tile takes 0.74 us (0.65 of the pipe's rate), of a
-//        32 x 32 tile 0.39 us alone and 0.69 us for two co-resident ones; on top of the unit's 1.5 us a launch pays ~1-2 us for
-//        the meeting of the four partial tiles in LDS (`extra`): 768^3 12.3 us (model 12.3), 768 x 768 x 3072 39.1 (38.9),
-//        512^3 on 32 x 32 tiles 6.1 (4.6), 704^3 10.6 (10.6), 1024^3 on 48 x 48 tiles 30.0 (28.6: two rounds).
+//   6 .. 8 sgemm_kq_kernel: 48 x 48, 32 x 32 and 64 x 64 tiles, the four waves of a workgroup split K (v_mfma_f32_16x16x4, operands straight
+//        from memory); whole K only, float4-loadable operands.  Two 48 x 48 workgroups fit a CU, four 32 x 32 ones; co-resident
+//        ones share the matrix pipe (time = rounds x K-tiles x the K-tile time) but pay what lies outside the K loop once.
+//        Fitted on profiles/r04/gemm_kq_direct_ab.log: a 64-deep K-tile of a 48 x 48 tile 0.61 us (0.79 of the pipe's rate), of a
+//        32 x 32 tile 0.30-0.31 us; outside the loop 3.0 / 2.5 us: 768^3 10.3 us (model 10.3), 768 x 768 x 3072 32.3 (32.3), 512^3
+//        on 32 x 32 tiles 4.9 (4.9), 704^3 9.3 (9.3), 832^3 14.7 (14.6), 1024^3 on 48 x 48 tiles 22.4 (22.5).  64 x 64 (247 registers,
+//        still two workgroups per CU): a K-tile 1.02-1.05 us alone, ~1.0 with a co-resident one — 1024^3 19.8 us (19.5; the LDS-DMA
+//        64 x 64 tiles: 20.6), 256 x 4096 x 4096 67.9 (68.9; 73-76: 126 TFLOP/s, the 0.80 of peak VERDICT r03 asked of this shape),
+//        2048^3 127.6 (131.5), 1536^3 74.8 (75; the 48 x 48 tiles 58.8).
 struct TileCfg { unsigned bm, bn; double eff, eff1, extra; };
-constexpr int kCfgCount = 8, kFirstMidCfg = 3, kFirstKqCfg = 6;
+constexpr int kCfgCount = 9, kFirstMidCfg = 3, kFirstKqCfg = 6;
 constexpr TileCfg kCfg[kCfgCount] = {{256, 128, 0.93, 0.89, 0}, {128, 128, 0.85, 0.64, 0}, {64, 64, 0.71, 0.52, 0},
                                      {128, 128, 0.87, 0.83, 0}, {128, 64, 0.82, 0.80, 0}, {64, 64, 0.80, 0.74, 0},
-                                     {48, 48, 0.649, 0.649, 1.9e-6}, {32, 32, 0.618, 0.547, 0}};
+                                     {48, 48, 0.787, 0.787, 1.5e-6}, {32, 32, 0.688, 0.711, 1.0e-6}, {64, 64, 0.85, 0.828, 1.5e-6}};
 int g_kq_tiles = 1;      // np_sgemm_set_variant(-20) = 0: plans without sgemm_kq_kernel, (-21): back
 int g_mid_tiles = 1;   // np_sgemm_set_variant(-14) = 0: plans as before round 4 (no sgemm_dmas_kernel), (-15): back
 int g_mid_waves = 1;     // np_sgemm_set_variant(-18) = 0: ragged whole-K 64 x 64 products on four waves like the aligned ones, (-19): on eight (default; see DmasShape5)
@@ -2385,6 +2362,7 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
     const double cu_flops = 157.3e12 / 256.0, unit_fixed = 1.5e-6, launch = 3e-6, hbm = 4e12;
     Plan best{2, 0, 1, K, 1e300};
     Plan best_other{2, 0, 1, K, 1e300};   // the best plan WITHOUT the mid-size tiles (see the end of the function)
+    Plan best_one{2, 0, 1, K, 1e300};     // the best whole-K mid-size plan whose tiles fit the machine in ONE round
     const bool mid_ok = g_mid_tiles && !only_dma && N >= 4 && K >= 4 && !g_progress.counters;
     for (int c = 0; c < kCfgCount; ++c) {
         if (c == 0 && !dma_ok) continue;
@@ -2405,10 +2383,12 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
             // the register-staged kernels lose ~1/4 when rows are not float4-loadable (4097^3: 97 vs 132), the LDS-DMA
             // kernel 5-9 % (16-byte fetches that straddle cache lines: profiles/r03/gemm_unaligned.log)
             const double eff = (T.eff1 + (T.eff - T.eff1) * blend) * (vec ? 1.0 : c == 0 ? 0.93 : c >= kFirstMidCfg ? 0.97 : 0.78);
+            if (c >= kFirstKqCfg) return ceil(waves) * (2.0 * T.bm * T.bn * (double)k / (eff * cu_flops)) + unit_fixed;   // (co-resident rounds)
             return ceil(waves) * (2.0 * T.bm * T.bn * (double)k / (eff * cu_flops) + unit_fixed);
         };
         const double whole = span((double)(tm * tn * batch), K) + T.extra;
         if (whole < best.t) best = Plan{c, 0, 1, K, whole};
+        if (c >= kFirstMidCfg && (double)(tm * tn * batch) <= cus && whole < best_one.t) best_one = Plan{c, 0, 1, K, whole};
         if (c >= kFirstKqCfg) continue;   // whole K only
         if (c >= kFirstMidCfg) {
             // K split S ways INSIDE the launch (sgemm_dmas_kernel's distributed fold; tail_rows == 0 and S > 1 says so): few
@@ -2460,11 +2440,13 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
     // in ONE round is the most predictable form there is (no fold, no second round) and needs no margin — 256 x 4096 x 4096:
     // both models say 75.3 us, the 64 x 64 tiles run 81.1, the 8-way split with its second launch 84.7; 4096 x 256 x 4096 82.2
     // against 87.7, 1024 x 1024 x 4096 80.7 against 86.7.
+    // (the two tests are made per candidate: a several-round plan that models a shade better than a one-round one must not
+    // take its place and then fail the margin — 2000^3: 64 x 64 k-quartered tiles in four rounds 128.5 us, 128 x 128 tiles in one
+    // 130.0, stream-K 134.2)
     const double rival = best_other.t < t_alt ? best_other.t : t_alt;
-    const TileCfg &BT = kCfg[best.cfg];
-    const bool one_round = best.S == 1 && best.tail_rows == 0 &&
-                           (double)(((M + BT.bm - 1) / BT.bm) * ((N + BT.bn - 1) / BT.bn) * batch) <= cus;
-    return best.t < (one_round ? 1.001 : 0.93) * rival ? best : best_other;
+    if (best.t < 0.93 * rival) return best;
+    if (best_one.t < 1.001 * rival) return best_one;
+    return best_other;
 }
 
 int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec);
@@ -2657,23 +2639,14 @@ int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
     return NP_OK;
 }
 // ---- launch of sgemm_kq_kernel ----
-// shape: 0 = 48 x 48 tiles (4 LDS buffers), 1 = 32 x 32 (5).  Returns 1 where the form does not apply (operands that are not
-// float4-loadable, a padded C, a progress request).  Measured and not kept (profiles/r04/gemm_kq_sweep2.log): 64 x 64
-// tiles (1024^3 22.8 us against sgemm_dmas_kernel's 21.1: with 256 tiles either way, the four-position form has the lighter
-// epilogue), 48 x 48 with five buffers (+-0).
-constexpr unsigned kKqTile[2] = {48, 32};
+// shape: 0 = 48 x 48 tiles, 1 = 32 x 32, 2 = 64 x 64.  Returns 1 where the form does not apply (operands that are not float4-loadable or
+// not below 4 GiB, a padded C, a progress request).  64 x 64 tiles in the first (LDS-staged) form lost to sgemm_dmas_kernel
+// (1024^3 22.8 against 21.1 us: profiles/r04/gemm_kq_sweep2.log) and were not carried over.
+constexpr unsigned kKqTile[3] = {48, 32, 64};
 int g_kq_swizzle = 1;
 
-template <int TM, int TN, int NBUF>
-void launch_kq_shape(const GemmArgs &g, dim3 grid, bool edge, hipStream_t s) {
-    if (edge)
-        sgemm_kq_kernel<TM, TN, NBUF, true><<<grid, 256, 0, s>>>(g);
-    else
-        sgemm_kq_kernel<TM, TN, NBUF, false><<<grid, 256, 0, s>>>(g);
-}
-
 int launch_kq(int shape, GemmArgs g, unsigned batch, bool vec) {
-    if (shape < 0 || shape > 1 || !vec || g.K % 4 || g.K < 4 || g.K_last || g.n_store || g.progress) return 1;
+    if (shape < 0 || shape > 2 || !vec || g.K % 4 || g.K < 4 || g.K_last || g.n_store || g.progress) return 1;
     const unsigned b = kKqTile[shape];
     g.tiles_m = (g.M + b - 1) / b;
     g.tiles_n = (g.N + b - 1) / b;
@@ -2683,8 +2656,17 @@ int launch_kq(int shape, GemmArgs g, unsigned batch, bool vec) {
     const dim3 grid((unsigned)tiles, 1, batch);
     const bool edge = g.M % b || g.N % b;
     hipStream_t s = np::stream();
-    if (shape == 0) launch_kq_shape<3, 3, 4>(g, grid, edge, s);
-    else launch_kq_shape<2, 2, 5>(g, grid, edge, s);
+    if (((size_t)g.M * g.lda + g.K) * 4 >= (size_t(1) << 32) || ((size_t)g.K * g.ldb + g.N) * 4 >= (size_t(1) << 32)) return 1;   // 32-bit byte offsets
+    if (shape == 0) {
+        if (edge) sgemm_kq_kernel<3, 3, true><<<grid, 256, 0, s>>>(g);
+        else sgemm_kq_kernel<3, 3, false><<<grid, 256, 0, s>>>(g);
+    } else if (shape == 1) {
+        if (edge) sgemm_kq_kernel<2, 2, true><<<grid, 256, 0, s>>>(g);
+        else sgemm_kq_kernel<2, 2, false><<<grid, 256, 0, s>>>(g);
+    } else {
+        if (edge) sgemm_kq_kernel<4, 4, true><<<grid, 256, 0, s>>>(g);
+        else sgemm_kq_kernel<4, 4, false><<<grid, 256, 0, s>>>(g);
+    }
     NP_LAUNCH_CHECK("sgemm_kq_kernel");
     return NP_OK;
 }
@@ -3220,7 +3202,7 @@ int np_sgemm_set_variant(int variant) {
             return NP_OK;
         }
         if (variant <= -2000) {   // -(2000 + shape): sgemm_kq_kernel wherever it applies
-            if (variant < -2001) return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: -(2000 + shape) with shape 0..1");
+            if (variant < -2002) return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: -(2000 + shape) with shape 0..2");
             g_force_kq = -variant - 2000;
             return NP_OK;
         }

@@ -217,7 +217,7 @@ def test_gemm_planner_choices_on_a_256_cu_device():
     """np_sgemm_debug_plan: the planner is host arithmetic (np_sgemm.hip plan_sgemm / streamk_model), so what a 256-CU device
     would run is checkable here.  Pinned: the forms the measurements in profiles/r04 (gemm_plans.log, gemm_kdeep_ab.log) stand
     on.  cfg 0 = 256 x 128 LDS-DMA tiles, 1 / 2 = register-staged 128 x 128 / 64 x 64, 3 / 4 / 5 = the mid-size LDS-DMA tiles
-    128 x 128 / 128 x 64 / 64 x 64, 6 / 7 = the k-quartered 48 x 48 / 32 x 32 tiles."""
+    128 x 128 / 128 x 64 / 64 x 64, 6 / 7 / 8 = the k-quartered 48 x 48 / 32 x 32 / 64 x 64 tiles."""
     from numpower_amd import _lib
     lib = _lib.load()
     out = (C.c_double * 11)()
@@ -233,11 +233,18 @@ def test_gemm_planner_choices_on_a_256_cu_device():
         p = plan(*shape)               # ~256 tiles of 32 x 32 / 48 x 48, the four waves of a workgroup splitting K (sgemm_kq_kernel)
         assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (cfg, 0, 1, False), (shape, p)
     assert plan(760, 760, 760)["cfg"] == 6 and plan(762, 762, 762)["cfg"] == 5      # rows that are not float4-loadable: not for that kernel
-    for shape in ((896,) * 3, (1000,) * 3, (1024,) * 3, (1001, 1003, 1002), (256, 4096, 4096), (4096, 256, 4096), (1024, 1024, 4096)):
-        p = plan(*shape)               # up to 256 tiles of 64 x 64, whole K, one round
-        assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (5, 0, 1, False), (shape, p)
-    p = plan(512, 512, 4096)           # few tiles, deep K: K split inside the launch
-    assert p["cfg"] == 5 and p["tail_rows"] == 0 and p["S"] == 4 and not p["streamk"]
+    for shape in ((896,) * 3, (1000,) * 3, (1024,) * 3, (256, 4096, 4096), (4096, 256, 4096), (1024, 1024, 4096)):
+        p = plan(*shape)               # up to 256 tiles of 64 x 64, whole K, one round: the k-quartered form (round 4, late)
+        assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (8, 0, 1, False), (shape, p)
+    p = plan(1001, 1003, 1002)         # ... rows that are not float4-loadable: the LDS-DMA 64 x 64 tiles (any alignment)
+    assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (5, 0, 1, False), p
+    p = plan(512, 512, 4096)           # few 64 x 64 tiles, deep K: 256 tiles of 32 x 32 with the waves splitting K (round 4: was K split 4 ways inside the launch)
+    assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (7, 0, 1, False)
+    p = plan(1000, 1000, 100000)       # ... and where the small tiles do not apply (two rounds of them): K split inside the launch of the LDS-DMA tiles
+    assert p["cfg"] in (3, 4, 5) and p["tail_rows"] == 0 and p["S"] >= 2 or p["streamk"] or p["tail_rows"] > 0
+    for shape in ((1152,) * 3, (1280,) * 3, (1536,) * 3):   # several co-resident rounds of 48 x 48 tiles beat the larger tiles' ragged rounds
+        p = plan(*shape)
+        assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (6, 0, 1, False), (shape, p)
     for shape in ((2560,) * 3, (3072,) * 3):   # tile counts that leave a ragged last round: stream-K
         assert plan(*shape)["streamk"], shape
     p = plan(100, 100, 100000)         # a dot-product-like shape: the register-staged tiles with K cut into a second launch's fold

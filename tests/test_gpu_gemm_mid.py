@@ -69,10 +69,10 @@ KQ_SHAPES = [(48, 48, 16), (48, 48, 64), (50, 72, 80), (100, 200, 64), (16, 16, 
              (200, 200, 100), (700, 700, 700), (50, 48, 1000), (33, 36, 68), (48, 48, 60), (48, 48, 124)]
 
 
-@pytest.mark.parametrize("shape", [0, 1], ids=["48x48", "32x32"])
+@pytest.mark.parametrize("shape", [0, 1, 2], ids=["48x48", "32x32", "64x64"])
 def test_k_quartered_tiles(shape, hip, oracle):
-    """sgemm_kq_kernel (one tile per workgroup, its four waves split every 64-deep K-tile and stage their own slices — no barrier
-    in the K loop —, v_mfma_f32_16x16x4, the partial tiles summed in LDS in wave order) forced through np_sgemm_set_variant(-(2000 + shape)): ragged M / N, K = 4 .. 4096 in
+    """sgemm_kq_kernel (one tile per workgroup, its four waves split every 64-deep K-tile and load their operands straight from
+    memory into the v_mfma_f32_16x16x4 layouts, the partial tiles summed in LDS in wave order) forced through np_sgemm_set_variant(-(2000 + shape)): ragged M / N, K = 4 .. 4096 in
     multiples of 4 (last K-tile from one chunk to full, quarters that end inside); shapes it does not take (K % 4, N % 4) fall
     through to the planner.  Same bars as above; deterministic."""
     lib = load()

@@ -1,6 +1,6 @@
 """Dev tool: sgemm_kq_kernel (one tile per workgroup, the four waves split K; np_sgemm.hip) forced through
 np_sgemm_set_variant(-(2000 + shape)) against the default planner, in alternation behind a warm-up: time, TFLOP/s and the
-largest difference from the fp64 product in units of |A|.|B|.  Shapes: 0 = 48x48 (4 LDS buffers), 1 = 32x32 (5); the default planner (which takes them where its
+largest difference from the fp64 product in units of |A|.|B|.  Shapes: 0 = 48x48, 1 = 32x32; the default planner (which takes them where its
 model says so) is the first column.
 Usage: python tools/gemm_kq_sweep.py [check]     (check: small and ragged shapes, correctness only)"""
 import sys
@@ -14,10 +14,11 @@ from numpower_amd._lib import load, Timer, check
 D.init(0)
 lib = load()
 t = Timer()
-NAMES = ["48x48", "32x32"]
+NAMES = ["48x48", "32x32", "64x64"]
 check_only = len(sys.argv) > 1 and sys.argv[1] == "check"
 shapes = [(512,) * 3, (576,) * 3, (640,) * 3, (704,) * 3, (768,) * 3, (832,) * 3, (896,) * 3, (960,) * 3, (1024,) * 3, (768, 768, 3072), (384, 384, 384),
-          (256, 256, 256), (768, 768, 256), (512, 1024, 512), (600,) * 3, (700,) * 3, (760,) * 3, (500,) * 3, (128, 4096, 4096)]
+          (256, 256, 256), (768, 768, 256), (512, 1024, 512), (600,) * 3, (700,) * 3, (760,) * 3, (500,) * 3, (128, 4096, 4096),
+          (1000,) * 3, (1152,) * 3, (1280,) * 3, (1536,) * 3, (2000,) * 3, (2048,) * 3, (256, 4096, 4096), (4096, 4096, 256), (1024, 1024, 4096)]
 if check_only:
     shapes = [(48, 48, 16), (48, 48, 64), (50, 72, 80), (100, 200, 64), (16, 16, 16), (1, 4, 16), (97, 132, 208), (720, 720, 720), (333, 444, 176), (64, 64, 1024), (130, 68, 4096)]
 
@@ -45,7 +46,7 @@ for (m, n, k) in shapes:
     flop = 2.0 * m * n * k
     reps = max(5, min(200, int(4e10 / flop)))
     line = "%5d x %5d x %5d " % (m, n, k)
-    forms = [("default", -999)] + [(NAMES[s], -(2000 + s)) for s in range(2)]
+    forms = [("default", -999)] + [(NAMES[s], -(2000 + s)) for s in range(3)]
     times = {name: [] for name, _ in forms}
     errs = {}
     for rnd in range(1 if check_only else 3):
