@@ -1354,10 +1354,16 @@ __global__ __launch_bounds__(SH::THREADS, 2) void sgemm_dmas_kernel(GemmArgs g, 
 // Last K-tile of a K that is not a multiple of 64: the waves whose quarter lies beyond K sit it out, the one whose quarter
 // ends inside zeroes the operands of its lane groups beyond K (loads beyond K re-read something in bounds); K-tiles beyond the
 // last (the prefetch runs two ahead) re-fetch the last one.
-template <int TM, int TN, bool EDGE>
-__global__ __launch_bounds__(256, 2) void sgemm_kq_kernel(GemmArgs g) {
+// Tile (16 TM) x (16 TN), TM, TN = 2 .. 6; STAGES = operand stages in registers (3: the K-tile two ahead is in flight; 2 for the
+// large tiles, whose K-tile lasts longer than a load takes, so that accumulators + stages stay within 256 registers and two
+// workgroups fit a CU).  The final sum goes through LDS in chunks of CH blocks (32 KiB at a time for the large tiles).
+constexpr int kq_regs(int tm, int tn, int stages) { return 4 * tm * tn + stages * 4 * (tm + tn) + 28; }
+template <int TM, int TN, int STAGES, bool EDGE>
+__global__ __launch_bounds__(256, kq_regs(TM, TN, STAGES) <= 256 ? 2 : 1) void sgemm_kq_kernel(GemmArgs g) {
     constexpr int BM = 16 * TM, BN = 16 * TN, BK = 64, NB = TM * TN;
-    __shared__ float red[4 * NB * 4 * 64];
+    constexpr int CH = NB <= 16 ? NB : 8;   // blocks per pass of the final sum
+    static_assert(STAGES == 2 || STAGES == 3, "two or three operand stages");
+    __shared__ float red[4 * CH * 4 * 64];
 
     unsigned tile_m, tile_n;
     tile_coords(g, blockIdx.x, tile_m, tile_n);
@@ -1459,45 +1465,60 @@ __global__ __launch_bounds__(256, 2) void sgemm_kq_kernel(GemmArgs g) {
         mfma_tile(f);
     };
 
-    Frag s0, s1, s2;
-    load_tile(s0);
-    load_tile(s1);
-    unsigned kt = 0;
-    for (; kt + 3 < nk; kt += 3) {   // K-tiles kt, kt + 1, kt + 2 all have a successor
-        step(s0, s2);
-        step(s1, s0);
-        step(s2, s1);
-    }
-    const unsigned left = nk - 1 - kt;   // 0 .. 2 tiles before the last one
-    if (left == 0) final_tile(s0);
-    else if (left == 1) {
-        step(s0, s2);
-        final_tile(s1);
+    if constexpr (STAGES == 3) {
+        Frag s0, s1, s2;
+        load_tile(s0);
+        load_tile(s1);
+        unsigned kt = 0;
+        for (; kt + 3 < nk; kt += 3) {   // K-tiles kt, kt + 1, kt + 2 all have a successor
+            step(s0, s2);
+            step(s1, s0);
+            step(s2, s1);
+        }
+        const unsigned left = nk - 1 - kt;   // 0 .. 2 tiles before the last one
+        if (left == 0) final_tile(s0);
+        else if (left == 1) {
+            step(s0, s2);
+            final_tile(s1);
+        } else {
+            step(s0, s2);
+            step(s1, s0);
+            final_tile(s2);
+        }
     } else {
-        step(s0, s2);
-        step(s1, s0);
-        final_tile(s2);
+        Frag s0, s1;
+        load_tile(s0);
+        unsigned kt = 0;
+        for (; kt + 2 < nk; kt += 2) {
+            step(s0, s1);
+            step(s1, s0);
+        }
+        if (nk - 1 - kt == 0) final_tile(s0);
+        else {
+            step(s0, s1);
+            final_tile(s1);
+        }
     }
 
-    // the four partial tiles: red[w][block][q][lane], lane-major; thread (q = wave, lane) sums block b in wave order
+    // the four partial tiles, CH blocks at a time: red[w][block][q][lane], lane-major; thread (q = wave, lane) sums a block in
+    // wave order
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int c0 = 0; c0 < NB; c0 += CH) {
+        if (c0) __syncthreads();   // (the previous pass has been read)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int b = c0; b < (c0 + CH < NB ? c0 + CH : NB); ++b)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) red[((wave * NB + i * TN + j) * 4 + q) * 64 + lane] = acc[i][j][q];
-    __syncthreads();
+            for (int q = 0; q < 4; ++q) red[((wave * CH + (b - c0)) * 4 + q) * 64 + lane] = acc[b / TN][b % TN][q];
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int b = c0; b < (c0 + CH < NB ? c0 + CH : NB); ++b) {
+            float sum = red[((0 * CH + (b - c0)) * 4 + wave) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const unsigned b = i * TN + j;
-            float sum = red[((0 * NB + b) * 4 + wave) * 64 + lane];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) sum += red[((w * NB + b) * 4 + wave) * 64 + lane];
-            const unsigned row = m0 + i * 16 + 4 * kk + wave, col = n0 + j * 16 + lr;
+            for (int w = 1; w < 4; ++w) sum += red[((w * CH + (b - c0)) * 4 + wave) * 64 + lane];
+            const unsigned row = m0 + (b / TN) * 16 + 4 * kk + wave, col = n0 + (b % TN) * 16 + lr;
             if (!EDGE || (row < g.M && col < g.N)) __builtin_nontemporal_store(sum, &C[(size_t)row * g.ldc + col]);
         }
+    }
 }
 
 // Zero-padded copy of a row-major matrix: out (rows_out x ld_out, ld_out % 4 == 0, 16-byte aligned)
@@ -2265,10 +2286,33 @@ int launch_sgemm_pipe(GemmArgs g, unsigned batch, bool vec) {
 //        64 x 64 tiles: 20.6), 256 x 4096 x 4096 67.9 (68.9; 73-76: 126 TFLOP/s, the 0.80 of peak VERDICT r03 asked of this shape),
 //        2048^3 127.6 (131.5), 1536^3 74.8 (75; the 48 x 48 tiles 58.8).
 struct TileCfg { unsigned bm, bn; double eff, eff1, extra; };
-constexpr int kCfgCount = 9, kFirstMidCfg = 3, kFirstKqCfg = 6;
-constexpr TileCfg kCfg[kCfgCount] = {{256, 128, 0.93, 0.89, 0}, {128, 128, 0.85, 0.64, 0}, {64, 64, 0.71, 0.52, 0},
-                                     {128, 128, 0.87, 0.83, 0}, {128, 64, 0.82, 0.80, 0}, {64, 64, 0.80, 0.74, 0},
-                                     {48, 48, 0.787, 0.787, 1.5e-6}, {32, 32, 0.688, 0.711, 1.0e-6}, {64, 64, 0.85, 0.828, 1.5e-6}};
+struct KqShape { int tm, tn, stages; };
+// (measured and not kept — profiles/r04/gemm_kq_family.log: 80 x 64, 80 x 80, 96 x 64, 96 x 80 spill registers at two workgroups
+// per CU and run 1.5-3x slower than the model; 96 x 96 on one workgroup per CU never beat 48 x 48 on three rounds)
+constexpr KqShape kKqShapes[] = {{3, 3, 3}, {2, 2, 3}, {4, 4, 3}, {3, 2, 3}, {4, 2, 3}, {4, 3, 3}, {5, 3, 3}};
+constexpr int kKqShapeCount = (int)(sizeof(kKqShapes) / sizeof(kKqShapes[0]));
+//        The whole family (TM, TN = 2 .. 6) follows one cost model, which is what the table below is generated from: a K-tile takes
+//        128 TM TN cycles of MFMA + 7 per load (TM + 4 TN of them) + ~90 (scalar bookkeeping, the waits) at the ~2.25 GHz these
+//        kernels run at, i.e. eff = 0.9375 x 128 TM TN / that; outside the loop 1.0 us + 0.06 us per block (the final sum), once.
+constexpr int kFirstMidCfg = 3, kFirstKqCfg = 6, kCfgCount = kFirstKqCfg + kKqShapeCount;
+struct CfgTable { TileCfg c[kCfgCount]; };
+constexpr CfgTable make_cfg_table() {
+    CfgTable t{};
+    t.c[0] = {256, 128, 0.93, 0.89, 0};
+    t.c[1] = {128, 128, 0.85, 0.64, 0};
+    t.c[2] = {64, 64, 0.71, 0.52, 0};
+    t.c[3] = {128, 128, 0.87, 0.83, 0};
+    t.c[4] = {128, 64, 0.82, 0.80, 0};
+    t.c[5] = {64, 64, 0.80, 0.74, 0};
+    for (int s = 0; s < kKqShapeCount; ++s) {
+        const double tm = kKqShapes[s].tm, tn = kKqShapes[s].tn, mfma = 128.0 * tm * tn;
+        const double eff = 0.9375 * mfma / (mfma + 7.0 * (tm + 4.0 * tn) + 90.0);
+        t.c[kFirstKqCfg + s] = {(unsigned)(16 * kKqShapes[s].tm), (unsigned)(16 * kKqShapes[s].tn), eff, eff, 1.0e-6 + 0.06e-6 * tm * tn};
+    }
+    return t;
+}
+constexpr CfgTable kCfgTable = make_cfg_table();
+constexpr const TileCfg (&kCfg)[kCfgCount] = kCfgTable.c;
 int g_kq_tiles = 1;      // np_sgemm_set_variant(-20) = 0: plans without sgemm_kq_kernel, (-21): back
 int g_mid_tiles = 1;   // np_sgemm_set_variant(-14) = 0: plans as before round 4 (no sgemm_dmas_kernel), (-15): back
 int g_mid_waves = 1;     // np_sgemm_set_variant(-18) = 0: ragged whole-K 64 x 64 products on four waves like the aligned ones, (-19): on eight (default; see DmasShape5)
@@ -2639,34 +2683,34 @@ int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
     return NP_OK;
 }
 // ---- launch of sgemm_kq_kernel ----
-// shape: 0 = 48 x 48 tiles, 1 = 32 x 32, 2 = 64 x 64.  Returns 1 where the form does not apply (operands that are not float4-loadable or
-// not below 4 GiB, a padded C, a progress request).  64 x 64 tiles in the first (LDS-staged) form lost to sgemm_dmas_kernel
-// (1024^3 22.8 against 21.1 us: profiles/r04/gemm_kq_sweep2.log) and were not carried over.
-constexpr unsigned kKqTile[3] = {48, 32, 64};
+// The tile shapes (in 16-row / 16-column blocks) and their operand stages; shape s is planner cfg kFirstKqCfg + s.  0 .. 2 are the
+// three the kernel was developed on (48 x 48, 32 x 32, 64 x 64).  Returns 1 where the form does not apply (operands that are
+// not float4-loadable or not below 4 GiB, a padded C, a progress request).
 int g_kq_swizzle = 1;
 
+template <int S>
+void launch_kq_shape(const GemmArgs &g, dim3 grid, bool edge, hipStream_t s) {
+    constexpr KqShape sh = kKqShapes[S];
+    if (edge) sgemm_kq_kernel<sh.tm, sh.tn, sh.stages, true><<<grid, 256, 0, s>>>(g);
+    else sgemm_kq_kernel<sh.tm, sh.tn, sh.stages, false><<<grid, 256, 0, s>>>(g);
+}
+template <int... S>
+void launch_kq_any(int shape, const GemmArgs &g, dim3 grid, bool edge, hipStream_t s, std::integer_sequence<int, S...>) {
+    ((shape == S ? launch_kq_shape<S>(g, grid, edge, s) : (void)0), ...);
+}
+
 int launch_kq(int shape, GemmArgs g, unsigned batch, bool vec) {
-    if (shape < 0 || shape > 2 || !vec || g.K % 4 || g.K < 4 || g.K_last || g.n_store || g.progress) return 1;
-    const unsigned b = kKqTile[shape];
-    g.tiles_m = (g.M + b - 1) / b;
-    g.tiles_n = (g.N + b - 1) / b;
+    if (shape < 0 || shape >= kKqShapeCount || !vec || g.K % 4 || g.K < 4 || g.K_last || g.n_store || g.progress) return 1;
+    const unsigned bm = 16 * kKqShapes[shape].tm, bn = 16 * kKqShapes[shape].tn;
+    g.tiles_m = (g.M + bm - 1) / bm;
+    g.tiles_n = (g.N + bn - 1) / bn;
     const size_t tiles = (size_t)g.tiles_m * g.tiles_n;
     if (tiles > 0x7fffffffu) return 1;
+    if (((size_t)g.M * g.lda + g.K) * 4 >= (size_t(1) << 32) || ((size_t)g.K * g.ldb + g.N) * 4 >= (size_t(1) << 32)) return 1;   // 32-bit byte offsets
     g.swizzle = (g_kq_swizzle && g.tiles_m >= 8 && tiles >= 64) ? 4 : 0;   // XCD-aware bands, as launch_dmas
     const dim3 grid((unsigned)tiles, 1, batch);
-    const bool edge = g.M % b || g.N % b;
-    hipStream_t s = np::stream();
-    if (((size_t)g.M * g.lda + g.K) * 4 >= (size_t(1) << 32) || ((size_t)g.K * g.ldb + g.N) * 4 >= (size_t(1) << 32)) return 1;   // 32-bit byte offsets
-    if (shape == 0) {
-        if (edge) sgemm_kq_kernel<3, 3, true><<<grid, 256, 0, s>>>(g);
-        else sgemm_kq_kernel<3, 3, false><<<grid, 256, 0, s>>>(g);
-    } else if (shape == 1) {
-        if (edge) sgemm_kq_kernel<2, 2, true><<<grid, 256, 0, s>>>(g);
-        else sgemm_kq_kernel<2, 2, false><<<grid, 256, 0, s>>>(g);
-    } else {
-        if (edge) sgemm_kq_kernel<4, 4, true><<<grid, 256, 0, s>>>(g);
-        else sgemm_kq_kernel<4, 4, false><<<grid, 256, 0, s>>>(g);
-    }
+    const bool edge = g.M % bm || g.N % bn;
+    launch_kq_any(shape, g, grid, edge, np::stream(), std::make_integer_sequence<int, kKqShapeCount>{});
     NP_LAUNCH_CHECK("sgemm_kq_kernel");
     return NP_OK;
 }
@@ -3202,7 +3246,7 @@ int np_sgemm_set_variant(int variant) {
             return NP_OK;
         }
         if (variant <= -2000) {   // -(2000 + shape): sgemm_kq_kernel wherever it applies
-            if (variant < -2002) return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: -(2000 + shape) with shape 0..2");
+            if (variant < -2000 - 63) return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: -(2000 + shape): no such shape");
             g_force_kq = -variant - 2000;
             return NP_OK;
         }

@@ -217,7 +217,7 @@ def test_gemm_planner_choices_on_a_256_cu_device():
     """np_sgemm_debug_plan: the planner is host arithmetic (np_sgemm.hip plan_sgemm / streamk_model), so what a 256-CU device
     would run is checkable here.  Pinned: the forms the measurements in profiles/r04 (gemm_plans.log, gemm_kdeep_ab.log) stand
     on.  cfg 0 = 256 x 128 LDS-DMA tiles, 1 / 2 = register-staged 128 x 128 / 64 x 64, 3 / 4 / 5 = the mid-size LDS-DMA tiles
-    128 x 128 / 128 x 64 / 64 x 64, 6 / 7 / 8 = the k-quartered 48 x 48 / 32 x 32 / 64 x 64 tiles."""
+    128 x 128 / 128 x 64 / 64 x 64, 6 .. 12 = the k-quartered tiles."""
     from numpower_amd import _lib
     lib = _lib.load()
     out = (C.c_double * 11)()
@@ -229,22 +229,19 @@ def test_gemm_planner_choices_on_a_256_cu_device():
 
     p = plan(4096, 4096, 4096)          # the headline: whole-K 256 x 128 tiles, two per CU, no stream-K
     assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (0, 0, 1, False) and 850 < p["us"] < 1100
-    for shape, cfg in (((256,) * 3, 7), ((512,) * 3, 7), ((768,) * 3, 6), ((768, 768, 3072), 6)):
-        p = plan(*shape)               # ~256 tiles of 32 x 32 / 48 x 48, the four waves of a workgroup splitting K (sgemm_kq_kernel)
-        assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (cfg, 0, 1, False), (shape, p)
-    assert plan(760, 760, 760)["cfg"] == 6 and plan(762, 762, 762)["cfg"] == 5      # rows that are not float4-loadable: not for that kernel
-    for shape in ((896,) * 3, (1000,) * 3, (1024,) * 3, (256, 4096, 4096), (4096, 256, 4096), (1024, 1024, 4096)):
-        p = plan(*shape)               # up to 256 tiles of 64 x 64, whole K, one round: the k-quartered form (round 4, late)
-        assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (8, 0, 1, False), (shape, p)
-    p = plan(1001, 1003, 1002)         # ... rows that are not float4-loadable: the LDS-DMA 64 x 64 tiles (any alignment)
-    assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (5, 0, 1, False), p
-    p = plan(512, 512, 4096)           # few 64 x 64 tiles, deep K: 256 tiles of 32 x 32 with the waves splitting K (round 4: was K split 4 ways inside the launch)
-    assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (7, 0, 1, False)
-    p = plan(1000, 1000, 100000)       # ... and where the small tiles do not apply (two rounds of them): K split inside the launch of the LDS-DMA tiles
-    assert p["cfg"] in (3, 4, 5) and p["tail_rows"] == 0 and p["S"] >= 2 or p["streamk"] or p["tail_rows"] > 0
-    for shape in ((1152,) * 3, (1280,) * 3, (1536,) * 3):   # several co-resident rounds of 48 x 48 tiles beat the larger tiles' ragged rounds
+    # the k-quartered tiles (sgemm_kq_kernel): cfg 6 + shape, shapes 48x48, 32x32, 64x64, 48x32, 64x32, 64x48, 80x48 — the one whose
+    # tile count fits the 256 CUs best
+    for shape, cfg in (((256,) * 3, 7), ((512,) * 3, 7), ((576,) * 3, 9), ((640,) * 3, 10), ((768,) * 3, 6), ((768, 768, 3072), 6), ((832,) * 3, 11),
+                       ((896,) * 3, 12), ((1000,) * 3, 8), ((1024,) * 3, 8), ((256, 4096, 4096), 8), ((4096, 256, 4096), 8), ((1024, 1024, 4096), 8),
+                       ((512, 512, 4096), 7), ((760,) * 3, 6)):
         p = plan(*shape)
-        assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (6, 0, 1, False), (shape, p)
+        assert (p["cfg"], p["tail_rows"], p["S"], p["streamk"]) == (cfg, 0, 1, False), (shape, p)
+    for shape in ((1152,) * 3, (1280,) * 3, (1536,) * 3):   # several co-resident rounds of small tiles beat the larger tiles' ragged rounds
+        p = plan(*shape)
+        assert p["cfg"] >= 6 and (p["tail_rows"], p["S"], p["streamk"]) == (0, 1, False), (shape, p)
+    assert plan(762, 762, 762)["cfg"] == 5 and plan(1001, 1003, 1002)["cfg"] == 5   # rows that are not float4-loadable: the LDS-DMA 64 x 64 tiles (any alignment)
+    p = plan(1000, 1000, 100000)       # a few tiles and a very deep K: K is split, one way or another
+    assert p["S"] >= 2 or p["streamk"] or p["tail_rows"] > 0
     for shape in ((2560,) * 3, (3072,) * 3):   # tile counts that leave a ragged last round: stream-K
         assert plan(*shape)["streamk"], shape
     p = plan(100, 100, 100000)         # a dot-product-like shape: the register-staged tiles with K cut into a second launch's fold

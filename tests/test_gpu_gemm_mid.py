@@ -69,7 +69,10 @@ KQ_SHAPES = [(48, 48, 16), (48, 48, 64), (50, 72, 80), (100, 200, 64), (16, 16, 
              (200, 200, 100), (700, 700, 700), (50, 48, 1000), (33, 36, 68), (48, 48, 60), (48, 48, 124)]
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2], ids=["48x48", "32x32", "64x64"])
+KQ_TILES = ["48x48", "32x32", "64x64", "48x32", "64x32", "64x48", "80x48"]
+
+
+@pytest.mark.parametrize("shape", list(range(len(KQ_TILES))), ids=KQ_TILES)
 def test_k_quartered_tiles(shape, hip, oracle):
     """sgemm_kq_kernel (one tile per workgroup, its four waves split every 64-deep K-tile and load their operands straight from
     memory into the v_mfma_f32_16x16x4 layouts, the partial tiles summed in LDS in wave order) forced through np_sgemm_set_variant(-(2000 + shape)): ragged M / N, K = 4 .. 4096 in

@@ -14,9 +14,9 @@ from numpower_amd._lib import load, Timer, check
 D.init(0)
 lib = load()
 t = Timer()
-NAMES = ["48x48", "32x32", "64x64"]
+NAMES = ["48x48", "32x32", "64x64", "48x32", "64x32", "64x48", "80x48"]
 check_only = len(sys.argv) > 1 and sys.argv[1] == "check"
-shapes = [(512,) * 3, (576,) * 3, (640,) * 3, (704,) * 3, (768,) * 3, (832,) * 3, (896,) * 3, (960,) * 3, (1024,) * 3, (768, 768, 3072), (384, 384, 384),
+shapes = [(512,) * 3, (576,) * 3, (640,) * 3, (704,) * 3, (768,) * 3, (832,) * 3, (896,) * 3, (960,) * 3, (1024,) * 3, (1088,) * 3, (1216,) * 3, (1344,) * 3, (1600,) * 3, (1920,) * 3, (2560,) * 3, (768, 768, 3072), (384, 384, 384),
           (256, 256, 256), (768, 768, 256), (512, 1024, 512), (600,) * 3, (700,) * 3, (760,) * 3, (500,) * 3, (128, 4096, 4096),
           (1000,) * 3, (1152,) * 3, (1280,) * 3, (1536,) * 3, (2000,) * 3, (2048,) * 3, (256, 4096, 4096), (4096, 4096, 256), (1024, 1024, 4096)]
 if check_only:
@@ -46,7 +46,7 @@ for (m, n, k) in shapes:
     flop = 2.0 * m * n * k
     reps = max(5, min(200, int(4e10 / flop)))
     line = "%5d x %5d x %5d " % (m, n, k)
-    forms = [("default", -999)] + [(NAMES[s], -(2000 + s)) for s in range(3)]
+    forms = [("default", -999)] + [(NAMES[s], -(2000 + s)) for s in range(len(NAMES))]
     times = {name: [] for name, _ in forms}
     errs = {}
     for rnd in range(1 if check_only else 3):
@@ -63,12 +63,18 @@ for (m, n, k) in shapes:
             if not check_only:
                 times[name].append(run(a, b, c, reps))
     check(lib.np_sgemm_set_variant(-999))
+    best = None
     for name, _ in forms:
         if check_only:
             line += "  %s %.0e" % (name, errs[name])
         else:
             ms = float(np.median(times[name]))
-            line += "  %s %6.1f us %5.1f TF (%.0e)" % (name, ms * 1e3, flop / ms / 1e9, errs[name])
+            line += "  %s %.1f" % (name, ms * 1e3)
+            if name != "default" and (best is None or ms < best[0]):
+                best = (ms, name)
+    if not check_only:
+        d = float(np.median(times["default"]))
+        line += "   | default %.1f us %.1f TF, best forced %s %.1f us %.1f TF" % (d * 1e3, flop / d / 1e9, best[1], best[0] * 1e3, flop / best[0] / 1e9)
     print(line, flush=True)
     for d in (a, b, c):
         d.free()

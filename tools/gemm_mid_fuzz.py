@@ -1,6 +1,6 @@
 """Random-shape fuzz of the mid-size and small-tile GEMM kernels: random M, N, K (1 .. 1500, a third of them multiples of 16 / 32 /
-64); a third of the cases force sgemm_dmas_kernel with a random tile shape and split S, a third force sgemm_kq_kernel (48x48 /
-32x32 / 64x64; K and N mostly multiples of 4, operands 16-byte aligned — the rest falls through to the planner, which is part of the
+64); a third of the cases force sgemm_dmas_kernel with a random tile shape and split S, a third force sgemm_kq_kernel (any of its 7 tile
+shapes; K and N mostly multiples of 4, operands 16-byte aligned — the rest falls through to the planner, which is part of the
 test), a third take the default planner; operands at random 4-byte offsets inside NaN-filled allocations, C inside a canary
 frame: within 1e-6 |A|.|B| of the fp64 product, nothing written outside C, the same bits on a second run.
 Usage: python tools/gemm_mid_fuzz.py [cases = 300] [seed = 1]"""
@@ -27,7 +27,7 @@ for case in range(cases):
     oa, ob, oc = (int(x) for x in rng.integers(0, 4, 3))
     form = ["dmas", "kq", "plan"][case % 3]
     if form == "kq":
-        shape = int(rng.integers(0, 3))
+        shape = int(rng.integers(0, 7))
         if rng.random() < 0.85:
             k = max(4, k // 4 * 4)
             n = max(4, n // 4 * 4)

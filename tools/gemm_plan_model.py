@@ -9,7 +9,9 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from numpower_amd._lib import check, load
 
 lib = load()
-CFG = {0: "256x128 dma", 1: "128x128 reg", 2: "64x64 reg", 3: "128x128 mid", 4: "128x64 mid", 5: "64x64 mid", 6: "48x48 kq", 7: "32x32 kq", 8: "64x64 kq", -1: "-"}
+CFG = {0: "256x128 dma", 1: "128x128 reg", 2: "64x64 reg", 3: "128x128 mid", 4: "128x64 mid", 5: "64x64 mid", -1: "-"}
+for _i, (_tm, _tn) in enumerate([(3, 3), (2, 2), (4, 4), (3, 2), (4, 2), (4, 3), (5, 3)]):
+    CFG[6 + _i] = "%dx%d kq" % (16 * _tm, 16 * _tn)
 shapes = [(256,) * 3, (384,) * 3, (512,) * 3, (576,) * 3, (640,) * 3, (704,) * 3, (768,) * 3, (832,) * 3, (896,) * 3, (1000,) * 3, (1024,) * 3, (1152,) * 3, (1280,) * 3, (1536,) * 3, (2000,) * 3, (2048,) * 3,
           (2560,) * 3, (3072,) * 3, (4096,) * 3, (256, 4096, 4096), (4096, 4096, 256), (4096, 256, 4096), (1024, 1024, 4096), (2048, 2048, 512),
           (512, 512, 4096), (768, 768, 3072), (768, 768, 256), (512, 1024, 512), (8192, 8192, 512), (16384, 1024, 1024), (1280, 1280, 8192), (100, 100, 100000), (1001, 1003, 1002)]
