@@ -1350,15 +1350,16 @@ __global__ __launch_bounds__(SH::THREADS, 2) void sgemm_dmas_kernel(GemmArgs g, 
 //     instructions per K-tile) became a uniform base advanced by scalar instructions plus constant 32-bit byte offsets:
 //     0.74 -> 0.69 -> 0.61 us per K-tile; 768^3 12.2 -> 10.3 us (74 -> 88 TFLOP/s), 768 x 768 x 3072 39.6 -> 32.3 (112),
 //     512^3 5.7 -> 4.9 (55), 704^3 10.7 -> 9.3, 832^3 17.0 (64 x 64 LDS-DMA tiles) -> 14.7.
-// Takes float4-loadable operands (K % 4 == 0, N % 4 == 0, 16-byte aligned rows) below 4 GiB each; the rest stays where it was.
+// Operands below 4 GiB each, K >= 4.  VEC = float4-loadable rows (K % 4 == 0, N % 4 == 0, 16-byte aligned): the A operand is one
+// dwordx4; otherwise (odd lengths, unaligned bases) four dwords — 9 more loads per K-tile of a 48 x 48 tile, ~5 %.
 // Last K-tile of a K that is not a multiple of 64: the waves whose quarter lies beyond K sit it out, the one whose quarter
-// ends inside zeroes the operands of its lane groups beyond K (loads beyond K re-read something in bounds); K-tiles beyond the
-// last (the prefetch runs two ahead) re-fetch the last one.
+// ends inside zeroes the operands beyond K (loads beyond K re-read something in bounds); K-tiles beyond the last (the prefetch
+// runs two ahead) re-fetch the last one.
 // Tile (16 TM) x (16 TN), TM, TN = 2 .. 6; STAGES = operand stages in registers (3: the K-tile two ahead is in flight; 2 for the
 // large tiles, whose K-tile lasts longer than a load takes, so that accumulators + stages stay within 256 registers and two
 // workgroups fit a CU).  The final sum goes through LDS in chunks of CH blocks (32 KiB at a time for the large tiles).
 constexpr int kq_regs(int tm, int tn, int stages) { return 4 * tm * tn + stages * 4 * (tm + tn) + 28; }
-template <int TM, int TN, int STAGES, bool EDGE>
+template <int TM, int TN, int STAGES, bool EDGE, bool VEC>
 __global__ __launch_bounds__(256, kq_regs(TM, TN, STAGES) <= 256 ? 2 : 1) void sgemm_kq_kernel(GemmArgs g) {
     constexpr int BM = 16 * TM, BN = 16 * TN, BK = 64, NB = TM * TN;
     constexpr int CH = NB <= 16 ? NB : 8;   // blocks per pass of the final sum
@@ -1373,8 +1374,13 @@ __global__ __launch_bounds__(256, kq_regs(TM, TN, STAGES) <= 256 ? 2 : 1) void s
     float *C = g.C + (size_t)blockIdx.z * g.stride_c;
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lr = lane & 15, kk = lane >> 4;
-    const unsigned nk = (g.K + BK - 1) / BK, kr = g.K - (nk - 1) * BK;   // kr: inner length of the last K-tile (4 .. 64, a multiple of 4)
+    const unsigned nk = (g.K + BK - 1) / BK, kr = g.K - (nk - 1) * BK;   // kr: inner length of the last K-tile (1 .. 64; K >= 4)
     const unsigned kq = wave * 16 + kk * 4;                                // this lane's first k inside a K-tile
+    // Last K-tile: a lane whose four k do not all lie inside K is pulled back by `pull` = kq + 4 - kr, so that what it loads ends
+    // at K - 1 exactly (K >= 4: in bounds whatever the row, the last one included — reading a row's first chunk instead ran up to
+    // 12 bytes past the end of A when kr < 4).  It then holds k = kr - 4 + t: nothing of its own if kq >= kr, its own k for
+    // t >= pull if it STRADDLES K (only when K % 4 != 0); the rest belongs to its neighbours and is zeroed below, A and B alike.
+    const unsigned pull = kq + 4 > kr ? kq + 4 - kr : 0u;
 
     // Sources: a UNIFORM base per operand, advanced one K-tile per load (scalar arithmetic), plus per-lane BYTE offsets that never
     // change (32-bit: the launcher checks that both operands are below 4 GiB) — the loads take the base-in-SGPRs form and cost
@@ -1388,7 +1394,7 @@ __global__ __launch_bounds__(256, kq_regs(TM, TN, STAGES) <= 256 ? 2 : 1) void s
         unsigned grow = m0 + 16 * i + lr;
         if (EDGE && grow >= g.M) grow = g.M - 1;
         a_off[i] = (grow * g.lda + kq) * 4u;
-        a_off_last[i] = a_off[i] - (kq >= kr ? kq : 0u) * 4u;
+        a_off_last[i] = a_off[i] + 16u - pull * 4u;   // relative to a_base - 16: never negative (kr - 4 may be)
     }
     unsigned b_off[4], b_off_last[4], col_b[TN];
 #pragma unroll
@@ -1400,9 +1406,9 @@ __global__ __launch_bounds__(256, kq_regs(TM, TN, STAGES) <= 256 ? 2 : 1) void s
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         b_off[t] = ((kq + t) * g.ldb + (EDGE ? 0u : n0 + lr)) * 4u;
-        b_off_last[t] = b_off[t] - (kq + t >= kr ? (kq + t - (kr - 1)) * g.ldb : 0u) * 4u;
+        b_off_last[t] = b_off[t] + (4u * g.ldb - pull * g.ldb) * 4u;   // rows kr - 4 + t, like A; relative to b_base - 4 rows
     }
-    const size_t b_step = (size_t)BK * g.ldb * 4;
+    const size_t b_step = (size_t)BK * g.ldb * 4, b_back4 = (size_t)4 * g.ldb * 4;
     struct Frag {
         v4f a4[TM];
         float bv[TN][4];
@@ -1410,13 +1416,20 @@ __global__ __launch_bounds__(256, kq_regs(TM, TN, STAGES) <= 256 ? 2 : 1) void s
     unsigned issued = 0;
     auto load_tile = [&](Frag &f) {
         const bool last = issued + 1 >= nk;   // uniform
+        const char *ab = last ? a_base - 16 : a_base, *bb = last ? b_base - b_back4 : b_base;   // (see a_off_last / b_off_last)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) f.a4[i] = *(const v4f *)(a_base + (last ? a_off_last[i] : a_off[i]));
+        for (int i = 0; i < TM; ++i) {
+            const unsigned off = last ? a_off_last[i] : a_off[i];
+            if constexpr (VEC) f.a4[i] = *(const v4f *)(ab + off);
+            else   // rows of any alignment and length: four dword loads (the instruction's offset field carries 4 t)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) f.a4[i][t] = *(const float *)(ab + off + 4 * t);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const unsigned off = last ? b_off_last[t] : b_off[t];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) f.bv[j][t] = *(const float *)(b_base + (off + col_b[j]));
+            for (int j = 0; j < TN; ++j) f.bv[j][t] = *(const float *)(bb + (off + col_b[j]));
         }
         if (!last) {
             a_base += BK * 4;
@@ -1451,16 +1464,16 @@ __global__ __launch_bounds__(256, kq_regs(TM, TN, STAGES) <= 256 ? 2 : 1) void s
     };
     auto final_tile = [&](Frag &f) {
         if (wave * 16 >= kr) return;   // this wave's quarter lies beyond K
-        if (wave * 16 + 16 > kr) {     // ... or ends inside: the lane groups beyond K hold re-read values
-            const bool ok = kq < kr;
+        if (wave * 16 + 16 > kr) {     // ... or ends inside: lanes beyond K hold re-read values, a straddling lane its neighbours' in t < pull
+            const unsigned first_ok = kq >= kr ? 4u : pull;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int t = 0; t < 4; ++t) {
+                const bool ok = (unsigned)t >= first_ok;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f.a4[i][e] = ok ? f.a4[i][e] : 0.0f;
+                for (int i = 0; i < TM; ++i) f.a4[i][t] = ok ? f.a4[i][t] : 0.0f;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) f.bv[j][t] = ok ? f.bv[j][t] : 0.0f;
+                for (int j = 0; j < TN; ++j) f.bv[j][t] = ok ? f.bv[j][t] : 0.0f;
+            }
         }
         mfma_tile(f);
     };
@@ -2412,7 +2425,7 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
         if (c == 0 && !dma_ok) continue;
         if (c != 0 && only_dma) continue;
         if (c >= kFirstMidCfg && !mid_ok) continue;
-        if (c >= kFirstKqCfg && (!g_kq_tiles || !vec || !splitk)) continue;   // (!splitk: C is a window of a wider matrix — fine for the kernel, but keep the peeled forms on the plans they were measured with)
+        if (c >= kFirstKqCfg && (!g_kq_tiles || K < 4 || !splitk)) continue;   // (!splitk: C is a window of a wider matrix — fine for the kernel, but keep the peeled forms on the plans they were measured with)
         if (c == kFirstMidCfg) {   // cfg 0 .. 2 are done: what follows competes with their best
             best_other = best;
             best = Plan{2, 0, 1, K, 1e300};
@@ -2426,7 +2439,7 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
             const double blend = waves <= 1.0 ? 0.0 : waves >= 2.0 ? 1.0 : waves - 1.0;
             // the register-staged kernels lose ~1/4 when rows are not float4-loadable (4097^3: 97 vs 132), the LDS-DMA
             // kernel 5-9 % (16-byte fetches that straddle cache lines: profiles/r03/gemm_unaligned.log)
-            const double eff = (T.eff1 + (T.eff - T.eff1) * blend) * (vec ? 1.0 : c == 0 ? 0.93 : c >= kFirstMidCfg ? 0.97 : 0.78);
+            const double eff = (T.eff1 + (T.eff - T.eff1) * blend) * (vec ? 1.0 : c == 0 ? 0.93 : c >= kFirstKqCfg ? 0.95 : c >= kFirstMidCfg ? 0.97 : 0.78);
             if (c >= kFirstKqCfg) return ceil(waves) * (2.0 * T.bm * T.bn * (double)k / (eff * cu_flops)) + unit_fixed;   // (co-resident rounds)
             return ceil(waves) * (2.0 * T.bm * T.bn * (double)k / (eff * cu_flops) + unit_fixed);
         };
@@ -2689,18 +2702,21 @@ int launch_dmas(int shape, GemmArgs g, unsigned batch, unsigned S) {
 int g_kq_swizzle = 1;
 
 template <int S>
-void launch_kq_shape(const GemmArgs &g, dim3 grid, bool edge, hipStream_t s) {
+void launch_kq_shape(const GemmArgs &g, dim3 grid, bool edge, bool vec, hipStream_t s) {
     constexpr KqShape sh = kKqShapes[S];
-    if (edge) sgemm_kq_kernel<sh.tm, sh.tn, sh.stages, true><<<grid, 256, 0, s>>>(g);
-    else sgemm_kq_kernel<sh.tm, sh.tn, sh.stages, false><<<grid, 256, 0, s>>>(g);
+    if (vec) {
+        if (edge) sgemm_kq_kernel<sh.tm, sh.tn, sh.stages, true, true><<<grid, 256, 0, s>>>(g);
+        else sgemm_kq_kernel<sh.tm, sh.tn, sh.stages, false, true><<<grid, 256, 0, s>>>(g);
+    } else   // rows that are not float4-loadable (odd lengths, unaligned bases, K % 4): dword loads, always the guarded form
+        sgemm_kq_kernel<sh.tm, sh.tn, sh.stages, true, false><<<grid, 256, 0, s>>>(g);
 }
 template <int... S>
-void launch_kq_any(int shape, const GemmArgs &g, dim3 grid, bool edge, hipStream_t s, std::integer_sequence<int, S...>) {
-    ((shape == S ? launch_kq_shape<S>(g, grid, edge, s) : (void)0), ...);
+void launch_kq_any(int shape, const GemmArgs &g, dim3 grid, bool edge, bool vec, hipStream_t s, std::integer_sequence<int, S...>) {
+    ((shape == S ? launch_kq_shape<S>(g, grid, edge, vec, s) : (void)0), ...);
 }
 
 int launch_kq(int shape, GemmArgs g, unsigned batch, bool vec) {
-    if (shape < 0 || shape >= kKqShapeCount || !vec || g.K % 4 || g.K < 4 || g.K_last || g.n_store || g.progress) return 1;
+    if (shape < 0 || shape >= kKqShapeCount || g.K < 4 || g.K_last || g.n_store || g.progress) return 1;
     const unsigned bm = 16 * kKqShapes[shape].tm, bn = 16 * kKqShapes[shape].tn;
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
@@ -2710,7 +2726,7 @@ int launch_kq(int shape, GemmArgs g, unsigned batch, bool vec) {
     g.swizzle = (g_kq_swizzle && g.tiles_m >= 8 && tiles >= 64) ? 4 : 0;   // XCD-aware bands, as launch_dmas
     const dim3 grid((unsigned)tiles, 1, batch);
     const bool edge = g.M % bm || g.N % bn;
-    launch_kq_any(shape, g, grid, edge, np::stream(), std::make_integer_sequence<int, kKqShapeCount>{});
+    launch_kq_any(shape, g, grid, edge, vec, np::stream(), std::make_integer_sequence<int, kKqShapeCount>{});
     NP_LAUNCH_CHECK("sgemm_kq_kernel");
     return NP_OK;
 }

@@ -66,7 +66,8 @@ def test_mid_tiles_batched_and_strided(tile, S, hip):
 
 KQ_SHAPES = [(48, 48, 16), (48, 48, 64), (50, 72, 80), (100, 200, 64), (16, 16, 16), (1, 4, 16), (97, 132, 208), (720, 720, 720), (333, 444, 176), (64, 64, 1024),
              (130, 68, 4096), (768, 768, 768), (512, 512, 512), (96, 200, 33), (77, 64, 130), (513, 260, 784), (60, 60, 4), (60, 60, 20), (100, 52, 36),
-             (200, 200, 100), (700, 700, 700), (50, 48, 1000), (33, 36, 68), (48, 48, 60), (48, 48, 124)]
+             (200, 200, 100), (700, 700, 700), (50, 48, 1000), (33, 36, 68), (48, 48, 60), (48, 48, 124),
+             (97, 131, 67), (50, 50, 5), (64, 64, 4), (33, 35, 1001), (129, 66, 130), (200, 136, 97), (1, 1, 7), (65, 3, 63), (300, 8, 515)]
 
 
 KQ_TILES = ["48x48", "32x32", "64x64", "48x32", "64x32", "64x48", "80x48"]
@@ -75,9 +76,9 @@ KQ_TILES = ["48x48", "32x32", "64x64", "48x32", "64x32", "64x48", "80x48"]
 @pytest.mark.parametrize("shape", list(range(len(KQ_TILES))), ids=KQ_TILES)
 def test_k_quartered_tiles(shape, hip, oracle):
     """sgemm_kq_kernel (one tile per workgroup, its four waves split every 64-deep K-tile and load their operands straight from
-    memory into the v_mfma_f32_16x16x4 layouts, the partial tiles summed in LDS in wave order) forced through np_sgemm_set_variant(-(2000 + shape)): ragged M / N, K = 4 .. 4096 in
-    multiples of 4 (last K-tile from one chunk to full, quarters that end inside); shapes it does not take (K % 4, N % 4) fall
-    through to the planner.  Same bars as above; deterministic."""
+    memory into the v_mfma_f32_16x16x4 layouts, the partial tiles summed in LDS in wave order) forced through np_sgemm_set_variant(-(2000 + shape)): ragged M / N, K = 4 .. 4096 (last K-tile from one
+    chunk to full, quarters that end inside, lanes that straddle K when K % 4 != 0), rows that are not float4-loadable (odd K / N:
+    the dword-load form); K < 4 falls through to the planner.  Same bars as above; deterministic."""
     lib = load()
     for (m, n, k) in KQ_SHAPES:
         A = synth.uniform((m, k), 61, -1.0, 1.0)

@@ -1,6 +1,6 @@
 """Random-shape fuzz of the mid-size and small-tile GEMM kernels: random M, N, K (1 .. 1500, a third of them multiples of 16 / 32 /
 64); a third of the cases force sgemm_dmas_kernel with a random tile shape and split S, a third force sgemm_kq_kernel (any of its 7 tile
-shapes; K and N mostly multiples of 4, operands 16-byte aligned — the rest falls through to the planner, which is part of the
+shapes; K and N multiples of 4 in most cases — the float4 form — and anything in the others, the dword form, operands 16-byte aligned — the rest falls through to the planner, which is part of the
 test), a third take the default planner; operands at random 4-byte offsets inside NaN-filled allocations, C inside a canary
 frame: within 1e-6 |A|.|B| of the fp64 product, nothing written outside C, the same bits on a second run.
 Usage: python tools/gemm_mid_fuzz.py [cases = 300] [seed = 1]"""
