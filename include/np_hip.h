@@ -471,7 +471,12 @@ int np_comm_debug_loopback(void *dev_scratch, size_t bytes);
  * go to the LDS-DMA kernel as they are (padded copies / register-staged kernels, as before round 3), -8 = they always do, whatever the size, -7 = back to the
  * default: from a size threshold up), -9 = never peel a thin ragged edge (M % 256 <= 32 rows, N % 128 <= 2 columns) off a
  * large product, -11 = always when there is one, -10 = back to the default: when the planner's model says it pays), -12 = products with M <= 64 rows go to the tiled
- * kernels instead of sgemm_fewrows_kernel / sgemm_skinny_kernel (as before round 3), -13 = back). */
+ * kernels instead of sgemm_fewrows_kernel / sgemm_skinny_kernel (as before round 3), -13 = back; round 4: -14 / -15 = plans
+ * without / with the mid-size LDS-DMA tiles (sgemm_dmas_kernel), -16 / -17 = their tiles walked row-major / in XCD-aware bands,
+ * -18 / -19 = ragged whole-K 64 x 64 products on four / eight waves, -20 / -21 = plans without / with the k-quartered tiles
+ * (sgemm_kq_kernel); -(1000 + 100 * shape + S) forces sgemm_dmas_kernel's tile `shape` with K split S ways wherever it applies,
+ * -(2000 + shape) forces sgemm_kq_kernel's tile `shape` (0 .. 6: 48x48, 32x32, 64x64, 48x32, 64x32, 64x48, 80x48), -999 ends
+ * either forcing).  All of them are process-wide setters for A/B measurements and tests: results stay within the same bounds. */
 int np_runtime_set_variant(int variant);   /* how host-result calls wait: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag, 2 = spin on the result itself (default) */
 int np_sgemm_set_variant(int variant);
 /* debug: the planner's choice for one dense, aligned M x N x K product on a device of `cus` CUs (0 = the current device; any
