@@ -252,6 +252,27 @@ def test_gemm_planner_choices_on_a_256_cu_device():
     assert lib.np_sgemm_debug_plan(0, 4, 4, 1, 256, out) != 0 and lib.np_sgemm_debug_plan(4, 4, 4, 1, 256, None) != 0
 
 
+def test_gemm_planner_is_total_on_random_shapes():
+    """Whatever the shape, np_sgemm_debug_plan answers with a plan the launchers know: a cfg in range, a positive finite model
+    time, no second-launch fold or stream-K for batches, no k-quartered tiles below K = 4 — 3000 random shapes from 1 to 20000 per dimension."""
+    from numpower_amd import _lib
+    lib = _lib.load()
+    out = (C.c_double * 11)()
+    rng = np.random.default_rng(5)
+    for _ in range(3000):
+        m, n, k = (int(10 ** rng.uniform(0, 4.3)) for _ in range(3))
+        batch = int(rng.choice([1, 1, 1, 2, 64]))
+        assert lib.np_sgemm_debug_plan(m, n, k, batch, 256, out) == 0, (m, n, k, batch, lib.np_last_error())
+        cfg, tail, S, us, sk = int(out[0]), int(out[1]), int(out[2]), out[3], bool(out[4])
+        assert 0 <= cfg <= 12 and S >= 1 and tail >= 0 and 0.0 < us < 1e9, (m, n, k, batch, list(out))
+        if batch > 1:     # batches: no second-launch fold and no stream-K; K may be split INSIDE the launch of the mid-size tiles
+            assert tail == 0 and not sk and (S == 1 or 3 <= cfg <= 5), (m, n, k, batch, list(out))
+        if k < 4:
+            assert cfg < 6, (m, n, k, list(out))
+        if cfg >= 6:      # whole K only
+            assert S == 1 and tail == 0, (m, n, k, list(out))
+
+
 def test_comm_entry_points_without_a_communicator_or_device():
     """The overlapped-gather entry points refuse politely before any device work when no communicator exists, the piece
     arithmetic is pure, and the communicator's tuning knob validates its argument — on a box without a GPU too."""
