@@ -35,3 +35,20 @@ def uniform(shape, seed: int, lo: float = 0.0, hi: float = 1.0, chunk: int = 1 <
         bits = (splitmix64(idx) >> np.uint64(40)).astype(np.float32)
         out[start:stop] = np.float32(lo) + bits * scale
     return out.reshape(shape)
+
+
+def uniform_many(shape, seeds, lo: float = 0.0, hi: float = 1.0, threads: int | None = None):
+    """uniform(shape, seed, lo, hi) for every seed, generated on a thread pool (numpy's ufuncs release the GIL) and yielded
+    in order — the 2 x 512 matrices of BASELINE config 5 are 10^9 elements, minutes on one core."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    seeds = list(seeds)
+    workers = max(1, min(threads or (os.cpu_count() or 1), 64, len(seeds)))
+    with ThreadPoolExecutor(workers) as pool:
+        window = []
+        for sd in seeds:
+            window.append(pool.submit(uniform, shape, sd, lo, hi))
+            if len(window) >= 2 * workers:
+                yield window.pop(0).result()
+        for f in window:
+            yield f.result()

@@ -215,6 +215,51 @@ def test_batched_matmul_slab_64x1024(hip):
     dB.free()
 
 
+def test_batched_matmul_512x1024_world1(hip, oracle):
+    """The WHOLE of BASELINE config 5 on the one GPU a test box has: 512 x (1024 x 1024), seeds 12 / 13 (one seed pair per
+    matrix, the generator bench.py uses: 12_000 + i / 13_000 + i), 2 GiB each of A, B and C.  On a one-rank communicator the
+    slab is the batch, so np_sgemm_strided_batched_allgather runs its whole mechanism (pieces, second stream, device-side
+    flags) with nothing travelling.  Every matrix of every form bit for bit against the plain np_sgemm_strided_batched
+    launch (compared on the device: np_count_mismatch), eight sampled matrices against fp64 (1e-6 |A|.|B|) and against the
+    oracle's OpenBLAS product (the reference has no batched entry point: a loop of linalg.c:44-82 calls, :239-242)."""
+    import ctypes as C
+    import socket
+    from numpower_amd._lib import check, load
+    lib = load()
+    D = hip
+    total, n = 512, 1024
+    item = n * n
+    A, B = D.DeviceArray((total, n, n)), D.DeviceArray((total, n, n))
+    for dst, base in ((A, 12_000), (B, 13_000)):
+        for i, h in enumerate(synth.uniform_many((n, n), range(base, base + total), -1.0, 1.0)):
+            check(lib.np_memcpy_h2d(dst.ptr + i * item * 4, h.ctypes.data, item * 4))
+    plain, over = D.DeviceArray((total, n, n)), D.DeviceArray((total, n, n))
+    check(lib.np_sgemm_strided_batched(total, n, n, n, A.ptr, item, B.ptr, item, plain.ptr, item))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    check(lib.np_comm_init(0, 1, ("tcp://127.0.0.1:%d" % port).encode()))
+    try:
+        bad = C.c_int(1)
+        for chunks, mode in ((1, 1), (8, 0), (1, 0), (8, 2)):        # the default form first, then the pipelined ones
+            D.fill(over, float("nan"))
+            check(lib.np_sgemm_strided_batched_allgather(total, n, n, n, A.ptr, item, B.ptr, item, over.ptr, chunks, mode))
+            check(lib.np_count_mismatch(0, over.ptr, plain.ptr, total * item, 0.0, 0.0, C.byref(bad)))   # NP_MISMATCH_EXACT
+            assert bad.value == 0, "chunks=%d mode=%d: some element differs from the plain launch" % (chunks, mode)
+    finally:
+        check(lib.np_comm_destroy())
+    for i in (0, 1, 63, 64, 255, 256, 300, 511):
+        a = synth.uniform((n, n), 12_000 + i, -1.0, 1.0)
+        b = synth.uniform((n, n), 13_000 + i, -1.0, 1.0)
+        got = over.view(i * item, (n, n)).to_host()
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+        assert (np.abs(got - ref) <= 1e-6 * scale).all(), i
+        assert (np.abs(got - oracle.matmul(a, b)) <= 1e-5 * scale).all(), i
+    for d in (A, B, plain, over):
+        d.free()
+
+
 def test_elementwise_beyond_2p31_elements(hip):
     """The reference's `int` element counts and `unsigned int` byte sizes stop at 2^31 elements /
     4 GiB (gpu_alloc.c:11, cuda_math.cu:1104); this back end is size_t end to end.  8.6 GB per
