@@ -131,7 +131,7 @@ def build_host(force: bool = False, verbose: bool = False) -> Path:
     if not srcs:
         return lib
     headers = list(INCLUDE.glob("*.h")) + list(HOST.glob("*.h"))
-    ext_objs = _ext_objects(EXT_GLUE + ["hip_math_drivers.c"], force, verbose)
+    ext_objs = _ext_objects(EXT_GLUE + ["hip_math_drivers.c", "hip_fast.c"], force, verbose)
     if force or _newer(lib, srcs + headers + ext_objs + [LIBDIR / "libnp_hip.so"]):
         if verbose:
             print("[build] compiling host layer", flush=True)
@@ -155,6 +155,31 @@ def build_method_bodies(force: bool = False, verbose: bool = False) -> Path:
         cc = shutil.which("gcc") or "gcc"
         flags = [f for f in EXT_CFLAGS if f != "-fPIC"]
         _run([cc, *flags, str(src), "-o", str(exe), f"-L{LIBDIR}", "-lnumpower_host", "-lnp_hip",
+              "-Wl,-rpath,$ORIGIN"])
+    return exe
+
+
+def build_fast_path_bodies(force: bool = False, verbose: bool = False) -> Path:
+    """The text tools/apply_with_hip.py inserts into the reference's device-dispatching L2 functions,
+    wrapped into a C99 program by the tool itself (fast_path_program_source) -> build/gen/fast_path_bodies.c ->
+    numpower_amd/lib/fast_path_bodies; -Wall -Wextra -Werror against numpower_host.h + hip_fast.h."""
+    exe = LIBDIR / "fast_path_bodies"
+    tool = ROOT / "tools" / "apply_with_hip.py"
+    gen = ROOT / "build" / "gen" / "fast_path_bodies.c"
+    deps = [tool, LIBDIR / "libnumpower_host.so"] + list(INCLUDE.glob("*.h")) + list(EXT.glob("*.h"))
+    if force or _newer(exe, deps):
+        if verbose:
+            print("[build] generating + compiling fast_path_bodies", flush=True)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("np_apply_with_hip", tool)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod          # dataclasses looks the module up while the class body runs
+        spec.loader.exec_module(mod)
+        gen.parent.mkdir(parents=True, exist_ok=True)
+        gen.write_text(mod.fast_path_program_source())
+        cc = shutil.which("gcc") or "gcc"
+        flags = [f for f in EXT_CFLAGS if f != "-fPIC"]
+        _run([cc, *flags, str(gen), "-o", str(exe), f"-L{LIBDIR}", "-lnumpower_host", "-lnp_hip",
               "-Wl,-rpath,$ORIGIN"])
     return exe
 
@@ -184,6 +209,7 @@ def build_all(force: bool = False, verbose: bool = False):
     host = build_host(force, verbose)
     build_ext_glue(force, verbose)
     build_method_bodies(force, verbose)
+    build_fast_path_bodies(force, verbose)
     oracle = build_oracle(force, verbose)
     return hip, host, oracle
 

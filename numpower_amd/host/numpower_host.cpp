@@ -28,6 +28,7 @@
 
 #include <vector>
 
+#include "hip_fast.h"
 #include "np_hip.h"
 
 namespace {
@@ -131,113 +132,11 @@ bool require_gpu(const NDArray *a, const char *what) {
     return false;
 }
 
-// How the smaller operand maps onto the larger one (the patterns of NDArray_Broadcast,
-// ndarray.c:1196-1291, with the intended NumPy meaning: the reference's own materialisation
-// leaves memory uninitialised for ndim > 2 destinations and for 1xC sources with C != R).
-// Returns the np_operand_kind or -1 ("Can't broadcast arrays.").
-int broadcast_kind(const NDArray *small, const NDArray *large, size_t *rows, size_t *cols) {
-    const int ln = large->ndim, sn = small->ndim;
-    const long lnum = NDArray_NUMELEMENTS(large);
-    if (!NDArray_IsBroadcastable(small, large)) return -1;
-    if (sn == 1 && ln > 1) {   // ndarray.c:1202-1223
-        *cols = (size_t)large->dimensions[ln - 1];
-        *rows = (size_t)(lnum / (long)*cols);
-        return NP_ROW;
-    }
-    if (sn == 2 && ln == 2) {
-        const int sr = small->dimensions[0], sc = small->dimensions[1];
-        const int lr = large->dimensions[0], lc = large->dimensions[1];
-        *rows = (size_t)lr;
-        *cols = (size_t)lc;
-        if (sr == 1 && sc == 1) return NP_SCALAR;          // ndarray.c:1238-1246
-        if (sr == lr && sc == 1) return NP_COL;            // ndarray.c:1227-1237
-        if (sr == 1 && sc == lc) return NP_ROW;            // ndarray.c:1273-1291
-    }
-    return -1;
-}
-
-typedef NDArray *(*binary_fn)(NDArray *, NDArray *);
-
-// Shared body of NDArray_{Add,Subtract,Multiply,Divide,Mod,Pow}_Float (arithmetics.c:160-926)
-// and of the comparison family NDArray_{Equal,NotEqual,Greater,GreaterEqual,Less,LessEqual}
-// (logic.c:67-670), which repeats the same scalar-expand + broadcast skeleton.
-NDArray *binary_op(int op, NDArray *a, NDArray *b) {
-    if (!a || !b) return nullptr;
-    const bool compare = op >= NP_EQUAL && op <= NP_LESS_EQUAL;
-    // arithmetics.c:163-166 / logic.c:70-73 — 0-d operands are exempt from the device check
-    if (NDArray_DEVICE(a) != NDArray_DEVICE(b) && NDArray_NDIM(a) != 0 && NDArray_NDIM(b) != 0) {
-        throw_error(compare ? "Devices mismatch in `equal` function"
-                            : "Device mismatch, both NDArray MUST be in the same device.");
-        return nullptr;
-    }
-    const bool a_scalar = NDArray_NDIM(a) == 0, b_scalar = NDArray_NDIM(b) == 0;
-    // where does the result live?  With a 0-d operand the other one decides.
-    const NDArray *place = a_scalar && !b_scalar ? b : a;
-    if (a_scalar && b_scalar && NDArray_DEVICE(a) != NDARRAY_DEVICE_GPU &&
-        NDArray_DEVICE(b) != NDARRAY_DEVICE_GPU) {
-        throw_error("binary op on two CPU scalars: not a GPU operation");
-        return nullptr;
-    }
-    if (a_scalar && b_scalar && NDArray_DEVICE(a) != NDARRAY_DEVICE_GPU) place = b;
-    if (!require_gpu(place, "binary op")) return nullptr;
-
-    const long na = NDArray_NUMELEMENTS(a), nb = NDArray_NUMELEMENTS(b);
-    int ak = NP_FULL, bk = NP_FULL;
-    size_t rows = 1, cols = 1;
-    const NDArray *shape_of = a;
-    // AVX-body bound of the reference: NDArray_NUMELEMENTS(a) with a = first operand after the
-    // scalar expand but before the broadcast (arithmetics.c:251)
-    size_t loop_numel_a = (size_t)na;
-
-    if (a_scalar || b_scalar) {
-        const NDArray *full = a_scalar ? b : a;   // both scalars: 1 x 1
-        shape_of = full;
-        cols = (size_t)NDArray_NUMELEMENTS(full);
-        if (a_scalar && !b_scalar) {
-            ak = NDArray_DEVICE(a) == NDARRAY_DEVICE_GPU ? NP_SCALAR : NP_HOST_SCALAR;
-            loop_numel_a = (size_t)nb;
-        } else if (b_scalar && !a_scalar) {
-            bk = NDArray_DEVICE(b) == NDARRAY_DEVICE_GPU ? NP_SCALAR : NP_HOST_SCALAR;
-        } else {
-            ak = NDArray_DEVICE(a) == NDARRAY_DEVICE_GPU ? NP_SCALAR : NP_HOST_SCALAR;
-            bk = NDArray_DEVICE(b) == NDARRAY_DEVICE_GPU ? NP_SCALAR : NP_HOST_SCALAR;
-        }
-    } else if (na < nb) {           // arithmetics.c:186-189
-        const int k = broadcast_kind(a, b, &rows, &cols);
-        if (k < 0) {
-            throw_error("Can't broadcast arrays.");
-            return nullptr;
-        }
-        ak = k;
-        shape_of = b;
-    } else if (nb < na) {           // arithmetics.c:190-193
-        const int k = broadcast_kind(b, a, &rows, &cols);
-        if (k < 0) {
-            throw_error("Can't broadcast arrays.");
-            return nullptr;
-        }
-        bk = k;
-    } else {
-        cols = (size_t)na;          // equal element counts: flat elementwise (arithmetics.c:194-197)
-    }
-
-    NDArray *result = new_array(shape_of->dimensions, shape_of->ndim, NDARRAY_DEVICE_GPU, false);
-    if (!result) return nullptr;
-    // 0-d x 0-d multiply/divide take the plain short cut (arithmetics.c:302-316,575-580)
-    const bool quirk_ops = ((op == NP_MULTIPLY || op == NP_MOD) && !(a_scalar && b_scalar)) ||
-                           op == NP_EQUAL || op == NP_NOT_EQUAL;
-    const unsigned flags = quirk_ops ? NP_QUIRK_AVX_BODY : 0u;
-    // AVX-body bound: NotEqual loops over the broadcast operand (logic.c:636), everything else over
-    // the first operand before the broadcast (arithmetics.c:251, logic.c:535)
-    if (op == NP_NOT_EQUAL) loop_numel_a = rows * cols;
-    const size_t body_end = quirk_ops ? np_avx_body_end(loop_numel_a) : 0;
-    if (!dev_ok(np_binary(op, NDArray_FDATA(a), ak, NDArray_FDATA(b), bk, NDArray_FDATA(result), rows,
-                          cols, flags, body_end))) {
-        NDArray_FREE(result);
-        return nullptr;
-    }
-    return result;
-}
+// Shared body of NDArray_{Add,Subtract,Multiply,Divide,Mod,Pow}_Float (arithmetics.c:160-926) and of the comparison family
+// NDArray_{Equal,NotEqual,Greater,GreaterEqual,Less,LessEqual} (logic.c:67-670): ext/hip_fast.c — the same C that a
+// `--with-hip` NumPower tree compiles as the GPU early-out of those functions, so the GPU test tier
+// that drives this library drives exactly the code a PHP build runs.
+NDArray *binary_op(int op, NDArray *a, NDArray *b) { return NPH_Binary_Float(op, a, b); }
 
 NDArray *unary_op(NDArray *x, int op, float p0, float p1) {
     if (!x) return nullptr;
@@ -285,10 +184,8 @@ NDArray *reduce_axis(NDArray *array, int axis, int op, bool quirk) {
     }
     NDArray *rtn = new_array(out_shape, nd - 1, NDARRAY_DEVICE_GPU, false);
     if (!rtn) return nullptr;
-    // slices are (nd - axis - 1)-dimensional; 0-d slices multiply without the zero-sign fix
-    const unsigned flags = (quirk && nd - axis - 1 >= 1) ? NP_QUIRK_AVX_BODY : 0u;
-    if (!dev_ok(np_reduce_axis(op, NDArray_FDATA(array), outer, (size_t)array->dimensions[axis], inner,
-                               NDArray_FDATA(rtn), flags))) {
+    // ext/hip_fast.c: what a patched reduce() (ndarray.c:572) calls on GPU arrays
+    if (NPH_ReduceAxisInto(array, axis, op, quirk ? NP_QUIRK_AVX_BODY : 0u, rtn) != 0) {
         NDArray_FREE(rtn);
         return nullptr;
     }
@@ -1238,7 +1135,7 @@ bool prepare_chain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n
                 kinds[i] = NP_FULL;          // equal element counts: flat elementwise (arithmetics.c:194-197)
             } else if (NDArray_NUMELEMENTS(x) < n) {
                 size_t br = 1, bc = 1;
-                const int k = broadcast_kind(x, first, &br, &bc);
+                const int k = NPH_BroadcastKind(x, first, &br, &bc);
                 if (k < 0 || (have_2d && (br != rows || bc != cols))) {
                     throw_error("Can't broadcast arrays.");
                     return false;

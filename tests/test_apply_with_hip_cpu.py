@@ -20,11 +20,13 @@ ROOT = Path(__file__).resolve().parent.parent
 REF = Path("/root/reference")
 sys.path.insert(0, str(ROOT / "tools"))
 
-pytestmark = pytest.mark.skipif(not (REF / "numpower.c").exists(), reason="reference checkout not present on this box")
+needs_reference = pytest.mark.skipif(not (REF / "numpower.c").exists(), reason="reference checkout not present on this box")
 
 
 @pytest.fixture(scope="module")
 def patched(tmp_path_factory):
+    if not (REF / "numpower.c").exists():
+        pytest.skip("reference checkout not present on this box")
     import apply_with_hip as tool
     out = tmp_path_factory.mktemp("with_hip") / "numpower"
     applied = tool.apply(REF, out)
@@ -68,7 +70,7 @@ def test_the_cuda_side_is_kept_verbatim(patched):
             if stack and s == "#else" and stack[-1] is True:
                 stack[-1] = False
                 continue
-            if stack and s == "#endif" and stack[-1] is False:
+            if stack and s == "#endif":          # closes the #else side of a wrapped edit, or an inserted (#else-less) block
                 stack.pop()
                 continue
             if stack and stack[-1] is True:
@@ -101,7 +103,7 @@ def test_the_new_statements_compile_against_the_c_abi(tmp_path):
     src = tmp_path / "snippets.c"
     src.write_text(tool.snippet_check_source())
     n = sum(1 for e in tool.EDITS if e.context)
-    assert n >= 14
+    assert n >= 14 + 12 + 1          # section 2a's statements, the twelve early-outs, reduce()
     proc = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
                            "-I", str(ROOT / "include"), "-I", str(ROOT / "ext"), str(src)], capture_output=True, text=True)
     assert proc.returncode == 0, proc.stderr
@@ -115,6 +117,7 @@ def test_the_new_statements_compile_against_the_c_abi(tmp_path):
     assert proc.returncode != 0
 
 
+@needs_reference
 def test_a_moved_anchor_is_a_hard_error(tmp_path):
     import apply_with_hip as tool
     broken = tmp_path / "broken"
@@ -137,3 +140,52 @@ def test_a_moved_anchor_is_a_hard_error(tmp_path):
     proc = subprocess.run([sys.executable, str(ROOT / "tools" / "apply_with_hip.py"), str(broken), str(tmp_path / "out3")],
                           capture_output=True, text=True)
     assert proc.returncode == 2 and "matched 0 time" in proc.stderr
+
+
+def test_the_fast_path_inserts_replace_nothing(patched):
+    """Section 2b: the GPU early-outs are INSERTED behind each function's own device-mismatch check — no reference symbol
+    is replaced, the whole body below (scalar expand, broadcast, AVX2 loop) is still there for CPU operands — and the tree
+    compiles ext/hip_fast.c, which holds NPH_Binary_Float / NPH_ReduceAxisInto."""
+    tool, out, _ = patched
+    assert len(tool.FAST_BINARY) == 12
+    for rel, ref_rel in (("src/ndmath/arithmetics.c", "src/ndmath/arithmetics.c"), ("src/logic.c", "src/logic.c")):
+        text, ref = (out / rel).read_text(), (REF / ref_rel).read_text()
+        n = sum(1 for _, e in tool.FAST_BINARY if e.file == rel)
+        assert text.count("if (NPH_TAKES(") == n == 6
+        # every line of the reference file is still in the patched one, in order (insert-only for these two files'
+        # early-outs; the wrapped 2a edits keep theirs on the #else side)
+        it = iter(text.split("\n"))
+        assert all(any(line == cand for cand in it) for line in ref.split("\n")), rel
+    for name, e in tool.FAST_BINARY:
+        text = (out / e.file).read_text()
+        head = text.index(name + "(NDArray*")
+        body = text[head:head + 1500]
+        # order inside the function: the reference's device check, then the early-out, then the scalar expand
+        assert body.index("mismatch") < body.index("NPH_TAKES") < body.index("// If a or b are scalars, reshape"), name
+    nd = (out / "src/ndarray.c").read_text()
+    assert nd.count("NPH_ReduceAxisInto(") == 1 and nd.count(" _reduce(0, 0, axis, array, rtn, operation);") == 2   # HIP side's else + the #else side
+    assert "src/hip/hip_fast.c" in (out / "config.m4").read_text()
+    assert (out / "src/hip/hip_fast.c").exists() and (out / "src/hip/hip_fast.h").exists()
+
+
+def test_cpu_operands_still_reach_the_reference_code(tmp_path):
+    """The inserted text, verbatim, inside functions with the reference's signatures, as a program (the tool generates it):
+    with CPU operands — BASELINE config 1 — every call falls through to the stand-in for the reference's own body and
+    nothing touches a device.  Needs no reference checkout and no GPU."""
+    import apply_with_hip as tool
+    from numpower_amd import build
+    build.build_all()
+    src = tmp_path / "fast_path_bodies.c"
+    src.write_text(tool.fast_path_program_source())
+    for name, e in tool.FAST_BINARY:
+        assert e.new in src.read_text().replace("\n    ", "\n"), name       # the inserted text is in there as the tool holds it
+    exe = tmp_path / "fast_path_bodies"
+    lib = ROOT / "numpower_amd" / "lib"
+    proc = subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I", str(ROOT / "include"), "-I", str(ROOT / "ext"),
+                           str(src), "-o", str(exe), "-L", str(lib), "-lnumpower_host", "-lnp_hip", "-Wl,-rpath," + str(lib)],
+                          capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    proc = subprocess.run([str(exe), "cpu"], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    m = re.search(r"(\d+) calls, (\d+) reached the reference's own code", proc.stdout)
+    assert m and m.group(1) == m.group(2) and int(m.group(1)) >= 80

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""apply_with_hip.py — turn a NumPower checkout into a `--with-hip` tree (as code).
+"""apply_with_hip.py — turn a NumPower checkout into a `--with-hip` tree (INTEGRATION.md sections 2a and 2b, as code).
 
     python tools/apply_with_hip.py <NumPower checkout> <output directory>
 
@@ -16,6 +16,12 @@ table cannot silently rot when the reference moves.  Each replaced statement is 
 
 so the output still builds `--with-cuda`; `--with-hip` (config.m4, added by the last edits) defines HAVE_CUBLAS —
 the name the reference's C files gate every NDARRAY_DEVICE_GPU branch on — and HAVE_NP_HIP.
+
+Section 2b's edits INSERT (Edit.after) instead of replacing: the L2 functions that pick the device inside the function
+(NDArray_{Add...Pow}_Float, the six comparisons, reduce()) gain `#ifdef HAVE_NP_HIP if (NPH_TAKES(a, b)) return
+NPH_Binary_Float(...); #endif` behind their own device-mismatch check, so GPU operands cost one launch and CPU operands
+fall through to the reference's code, untouched.  fast_path_program_source() wraps that inserted text into a C program
+(numpower_amd/lib/fast_path_bodies) that the CPU and GPU test tiers run.
 
 After the edits the tool CHECKS the tree (check_tree): with HAVE_NP_HIP and HAVE_CUBLAS defined and HAVE_CUDNN
 undefined, no preprocessor-visible line of the extension's C sources may name the CUDA runtime or cuBLAS
@@ -49,15 +55,50 @@ class Edit:
     new: str           # the HAVE_NP_HIP side (same indentation as the old text is applied automatically)
     expect: int = 1    # how many times the anchor must match
     wrap: bool = True  # True: #ifdef HAVE_NP_HIP new #else old #endif;  False: plain substitution by `new`
+    after: bool = False  # True: `old` stays where it is and `#ifdef HAVE_NP_HIP new #endif` is INSERTED behind it (the
+                         # fast-path early-outs of section 2b: nothing of the reference is replaced)
     context: str = ""  # C declarations of the locals of the surrounding reference function that `new` uses (CONTEXTS
                        # below): with them the new text is compiled on its own — snippet_check_source() — against
                        # include/np_hip.h, include/numpower_host.h and ext/hip_math.h; "" = nothing to compile
 
 
-def _cuda_includes(file: str, line: str) -> Edit:
+def _cuda_includes(file: str, line: str, more: str = "") -> Edit:
     return Edit(file, "%s: CUDA headers -> <np_hip.h>" % line,
                 r"^(?P<old>#include <cuda_runtime\.h>\n#include <cublas_v2\.h>)$",
-                "#include <np_hip.h>")
+                "#include <np_hip.h>" + more)
+
+
+# ---- section 2b: GPU early-outs at the top of the L2 functions that pick the device inside (ext/hip_fast.h) ----
+_FAST_NOTE = ("/* numpower_amd: an array operand on the GPU leaves here through ONE np_binary launch — no Zeros + Fill scalar\n"
+              " * temporary, no materialised NDArray_Broadcast; CPU operands fall through to the code below, untouched */\n")
+
+
+def _fast_arith(name: str, op: str, line: str) -> Edit:
+    return Edit("src/ndmath/arithmetics.c", "arithmetics.c:%s NDArray_%s_Float: GPU early-out" % (line, name),
+                r"^(?P<old>NDArray_%s_Float\(NDArray\* a, NDArray\* b\) \{\n" % name +
+                r"(?:[^\n]*\n){1,3}?"
+                r"[ \t]*if \(NDArray_DEVICE\(a\) != NDArray_DEVICE\(b\) && NDArray_NDIM\(a\) != 0 && NDArray_NDIM\(b\) != 0\) \{\n"
+                r"[ \t]*zend_throw_error\(NULL, \"Device mismatch, both NDArray MUST be in the same device\.\"\);\n"
+                r"[ \t]*return NULL;\n"
+                r"[ \t]*\})$",
+                _FAST_NOTE +
+                "if (NPH_TAKES(a, b)) {\n"
+                "    return NPH_Binary_Float(%s, a, b);\n"
+                "}" % op, after=True)
+
+
+def _fast_compare(name: str, op: str, line: str) -> Edit:
+    return Edit("src/logic.c", "logic.c:%s NDArray_%s: GPU early-out" % (line, name),
+                r"^(?P<old>NDArray_%s\(NDArray\* nda, NDArray\* ndb\) \{\n" % name +
+                r"(?:[^\n]*\n){1,3}?"
+                r"[ \t]*if \(\(NDArray_DEVICE\(nda\) != NDArray_DEVICE\(ndb\)\) && NDArray_NDIM\(nda\) != 0 && NDArray_NDIM\(ndb\) != 0\) \{\n"
+                r"[ \t]*zend_throw_error\(NULL, \"Devices mismatch in `equal` function\"\);\n"
+                r"[ \t]*return NULL;\n"
+                r"[ \t]*\})$",
+                _FAST_NOTE +
+                "if (NPH_TAKES(nda, ndb)) {\n"
+                "    return NPH_Binary_Float(%s, nda, ndb);\n"
+                "}" % op, after=True)
 
 
 _SYNC = (r"^(?P<old>[ \t]*cudaDeviceSynchronize\(\);)$")
@@ -66,8 +107,8 @@ EDITS = [
     # ---- headers ----
     _cuda_includes("numpower.c", "numpower.c:31-32"),
     _cuda_includes("src/initializers.c", "initializers.c:15-16"),
-    _cuda_includes("src/ndarray.c", "ndarray.c:18-19"),
-    _cuda_includes("src/ndmath/arithmetics.c", "arithmetics.c:14-15"),
+    _cuda_includes("src/ndarray.c", "ndarray.c:18-19", "\n#include <hip_fast.h>\n#include \"ndmath/arithmetics.h\""),
+    _cuda_includes("src/ndmath/arithmetics.c", "arithmetics.c:14-15", "\n#include <hip_fast.h>"),
     _cuda_includes("src/ndmath/linalg.c", "linalg.c:27-28"),
     _cuda_includes("src/manipulation.c", "manipulation.c:13-14"),
     _cuda_includes("src/debug.c", "debug.c:9-10"),
@@ -187,6 +228,37 @@ EDITS = [
          "} else {\n"
          "    rtn = NDArrayMathGPU_ElementWise(nda, cuda_float_exp2);\n"
          "}"),
+    # ---- section 2b: the fast path, reachable from PHP without replacing a single reference symbol ----
+    Edit("src/logic.c", "logic.c:10-11: <hip_fast.h>",
+         r"^(?P<old>#include \"ndmath/cuda/cuda_math\.h\"\n#include \"debug\.h\")$",
+         "#include <hip_fast.h>", after=True),
+    _fast_arith("Add", "NP_ADD", "161-166"),
+    _fast_arith("Multiply", "NP_MULTIPLY", "294-300"),
+    _fast_arith("Subtract", "NP_SUBTRACT", "440-446"),
+    _fast_arith("Divide", "NP_DIVIDE", "567-574"),
+    _fast_arith("Mod", "NP_MOD", "701-707"),
+    _fast_arith("Pow", "NP_POW", "826-832"),
+    _fast_compare("Greater", "NP_GREATER", "68-73"),
+    _fast_compare("Less", "NP_LESS", "172-177"),
+    _fast_compare("LessEqual", "NP_LESS_EQUAL", "272-277"),
+    _fast_compare("GreaterEqual", "NP_GREATER_EQUAL", "378-383"),
+    _fast_compare("Equal", "NP_EQUAL", "479-484"),
+    _fast_compare("NotEqual", "NP_NOT_EQUAL", "580-585"),
+    Edit("src/ndarray.c", "ndarray.c:570 reduce(): one np_reduce_axis launch for GPU arrays",
+         r"^(?P<old>[ \t]*_reduce\(0, 0, axis, array, rtn, operation\);)$",
+         "/* numpower_amd: sum / prod over an axis of a GPU array is ONE np_reduce_axis launch into the result allocated\n"
+         " * above, instead of one operation() + allocation + copy per slice (_reduce, ndarray.c:394-429); CPU arrays and any\n"
+         " * other operation keep the reference's loop */\n"
+         "if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU &&\n"
+         "    (operation == NDArray_Add_Float || operation == NDArray_Multiply_Float)) {\n"
+         "    if (NPH_ReduceAxisInto(array, *axis, operation == NDArray_Add_Float ? NP_SUM : NP_PROD,\n"
+         "                           operation == NDArray_Multiply_Float ? NP_QUIRK_AVX_BODY : 0u, rtn) != 0) {\n"
+         "        NDArray_FREE(rtn);\n"
+         "        rtn = NULL;\n"
+         "    }\n"
+         "} else {\n"
+         "    _reduce(0, 0, axis, array, rtn, operation);\n"
+         "}"),
     # ---- config.m4: the option, and the source list ----
     Edit("config.m4", "config.m4:7-8: --with-hip next to --with-cuda",
          r"^(?P<old>PHP_ARG_WITH\(cuda, for CUDA support,\n\[  --with-cuda           Include CUDA support\], \[no\], \[no\]\))$",
@@ -213,7 +285,12 @@ CONTEXTS = {
     "debug.c:220-254 NDArray_DumpDevices": " ",
     "numpower.c:1791 PHP_METHOD(rsqrt): the right device function": "NDArray *rtn = 0, *nda = 0;",
     "numpower.c:3153 PHP_METHOD(exp2): a device branch": "NDArray *rtn = 0, *nda = 0;",
+    "ndarray.c:570 reduce(): one np_reduce_axis launch for GPU arrays":
+        "NDArray *array = 0, *rtn = 0; int *axis = 0; NDArray *(*operation)(NDArray *, NDArray *) = 0;",
 }
+for _e in EDITS:
+    if _e.what.endswith("GPU early-out"):
+        CONTEXTS[_e.what] = "NDArray *nda = 0, *ndb = 0;" if _e.file == "src/logic.c" else "NDArray *a = 0, *b = 0;"
 
 HIP_M4_BLOCK = '''dnl ---- MI355X (gfx950) through numpower_amd: added by numpower_amd/tools/apply_with_hip.py ----
 dnl No device compiler step: the kernels live in a prebuilt libnp_hip.so, everything compiled here is plain C
@@ -244,11 +321,11 @@ if test "$PHP_HIP" != "no"; then
   AC_DEFINE([HAVE_CUBLAS], [1], [a device back end is present (the C files gate every GPU branch on this name)])
   AC_DEFINE([HAVE_NP_HIP], [1], [the device back end is numpower_amd / MI355X])
   CFLAGS+=" -DNUMPOWER_NDARRAY_HEADER='\\"src/initializers.h\\"' "
-  NP_GPU_ALLOC_SOURCES="src/hip/gpu_alloc_hip.c src/hip/hip_math.c src/hip/hip_math_drivers.c src/hip/zend_hooks.c"
+  NP_GPU_ALLOC_SOURCES="src/hip/gpu_alloc_hip.c src/hip/hip_math.c src/hip/hip_math_drivers.c src/hip/hip_fast.c src/hip/zend_hooks.c"
 fi'''
 
-GLUE_FILES = ["ext/gpu_alloc_hip.c", "ext/hip_math.c", "ext/hip_math.h", "ext/hip_math_drivers.c", "ext/zend_hooks.c",
-              "ext/np_ext_hooks.h", "include/np_hip.h"]
+GLUE_FILES = ["ext/gpu_alloc_hip.c", "ext/hip_math.c", "ext/hip_math.h", "ext/hip_math_drivers.c", "ext/hip_fast.c",
+              "ext/hip_fast.h", "ext/zend_hooks.c", "ext/np_ext_hooks.h", "include/np_hip.h"]
 # not compiled in a --with-hip build: replaced wholesale by the glue
 REPLACED_BY_GLUE = ("src/gpu_alloc.c", "src/ndmath/cuda/")
 
@@ -266,14 +343,16 @@ def snippet_check_source() -> str:
     PHP build.  The only foreign declarations are the three reference symbols the new text itself calls."""
     out = ["/* generated by tools/apply_with_hip.py: snippet_check_source() */",
            "#include <stdio.h>", "#include <stddef.h>",
-           '#include "np_hip.h"', '#include "numpower_host.h"', '#include "hip_math.h"',
+           '#include "np_hip.h"', '#include "numpower_host.h"', '#include "hip_math.h"', '#include "hip_fast.h"',
            "void zend_throw_error(void *exception_ce, const char *format, ...);   /* Zend/zend_exceptions.h */",
+           "void _reduce(int current_axis, int rtn_init, int *axis, NDArray *target, NDArray *rtn,",
+           "             NDArray *(*operation)(NDArray *, NDArray *));                 /* src/ndarray.c:394 */",
            "NDArray *NDArray_Map(NDArray *array, float (*op)(float));                /* src/ndarray.h */",
            "float float_exp2(float val);                                             /* src/ndmath/double_math.h */", ""]
     for k, e in enumerate(EDITS):
         if not e.context:
             continue
-        ret = "void *" if "return NULL;" in e.new else "void "
+        ret = "void *" if ("return NULL;" in e.new or "return NPH_" in e.new) else "void "
         out.append("/* %s */" % e.what)
         out.append("%ssnippet_%d(void) {" % (ret, k))
         out.append("    " + e.context)
@@ -283,6 +362,177 @@ def snippet_check_source() -> str:
         out.append("}")
         out.append("")
     return "\n".join(out)
+
+
+FAST_BINARY = [(e.what.split(" ")[1].rstrip(":"), e) for e in EDITS if e.what.endswith("GPU early-out")]   # ("NDArray_Add_Float", edit)
+
+
+def fast_path_program_source() -> str:
+    """A C99 PROGRAM around the text section 2b inserts: for each early-out a function with the reference function's
+    signature whose body is the inserted text VERBATIM (as EDITS holds it) followed by a stand-in for "the reference's code
+    below the insertion" that only counts how often it is reached; for reduce() the reference's result allocation, then the
+    edited statement with `_reduce` as such a counter.  Built against include/numpower_host.h + ext/hip_fast.h and linked
+    with libnumpower_host.so (which carries ext/hip_fast.c), -Wall -Wextra -Werror.
+
+        fast_path_bodies cpu          every patched function called with CPU operands: each call must FALL THROUGH to the
+                                      stand-in (BASELINE config 1 still reaches arithmetics.c) and no device is touched —
+                                      runs without a GPU (tests/test_apply_with_hip_cpu.py)
+        fast_path_bodies gpu <file>   the same calls with ->gpu() operands: none may fall through; results are written to
+                                      <file> (method_bodies.c's record format) and checked against the oracle by
+                                      tests/test_gpu_fast_path.py
+    """
+    reduce_edit = next(e for e in EDITS if e.what.startswith("ndarray.c:570 reduce()"))
+    o = ["/* generated by tools/apply_with_hip.py: fast_path_program_source() — do not edit */",
+         "#define _POSIX_C_SOURCE 200809L",
+         "#include <stdint.h>", "#include <stdio.h>", "#include <stdlib.h>", "#include <string.h>", "",
+         "#define HAVE_NP_HIP 1", '#include "numpower_host.h"', '#include "hip_fast.h"', "",
+         "static int g_fell_through;   /* calls that reached the reference's own code (the stand-ins below) */",
+         "static NDArray *reference_body(void) { g_fell_through++; return NULL; }",
+         "static void _reduce(int current_axis, int rtn_init, int *axis, NDArray *target, NDArray *rtn,",
+         "                    NDArray *(*operation)(NDArray *, NDArray *)) {",
+         "    (void) current_axis; (void) rtn_init; (void) axis; (void) target; (void) rtn; (void) operation;",
+         "    g_fell_through++;", "}", ""]
+    for name, e in FAST_BINARY:
+        args = "NDArray *nda, NDArray *ndb" if e.file == "src/logic.c" else "NDArray *a, NDArray *b"
+        o += ["static NDArray *patched_%s(%s) {" % (name, args), "#ifdef HAVE_NP_HIP", _indent(e.new, "    "), "#endif",
+              "    return reference_body();", "}", ""]
+    o += ["static NDArray *patched_reduce(NDArray *array, int *axis, NDArray *(*operation)(NDArray *, NDArray *)) {",
+          "    /* reduce()'s own shape arithmetic and result allocation (ndarray.c:541-569), then the edited statement */",
+          "    int out_shape[8], j = 0;",
+          "    for (int i = 0; i < NDArray_NDIM(array); i++) if (i != *axis) out_shape[j++] = NDArray_SHAPE(array)[i];",
+          '    NDArray *rtn = NDArray_Zeros(out_shape, j, "float32", NDArray_DEVICE(array));',
+          "#ifdef HAVE_NP_HIP", _indent(reduce_edit.new, "    "), "#endif", "    return rtn;", "}", ""]
+    table = ",\n".join('    {"%s", patched_%s}' % (name[len("NDArray_"):], name) for name, _ in FAST_BINARY)
+    o.append(_FAST_PROGRAM_MAIN.replace("@TABLE@", table))
+    return "\n".join(o)
+
+
+_FAST_PROGRAM_MAIN = r'''typedef NDArray *(*Binary)(NDArray *, NDArray *);
+static const struct { const char *name; Binary fn; } kPatched[] = {
+@TABLE@
+};
+enum { kCount = (int) (sizeof kPatched / sizeof kPatched[0]) };
+
+static FILE *g_out;
+static int g_failed;
+
+/* method_bodies.c's record: 32-byte name, int32 ndim, int32 dims[4], the floats */
+static void dump(const char *op, const char *form, NDArray *a) {
+    char label[32];
+    int32_t head[5] = {0, 1, 1, 1, 1};
+    if (a == NULL) {
+        fprintf(stderr, "fast_path_bodies: %s.%s returned NULL: %s\n", op, form, numpower_host_last_error());
+        g_failed = 1;
+        return;
+    }
+    memset(label, 0, sizeof label);
+    snprintf(label, sizeof label, "%s.%s", op, form);
+    head[0] = NDArray_NDIM(a);
+    for (int i = 0; i < NDArray_NDIM(a) && i < 4; i++) head[1 + i] = NDArray_SHAPE(a)[i];
+    NDArray *host = NDArray_ToCPU(a);
+    if (host == NULL) {
+        fprintf(stderr, "fast_path_bodies: cpu() of %s failed: %s\n", label, numpower_host_last_error());
+        g_failed = 1;
+        return;
+    }
+    fwrite(label, 1, sizeof label, g_out);
+    fwrite(head, sizeof(int32_t), 5, g_out);
+    fwrite(NDArray_FDATA(host), sizeof(float), (size_t) NDArray_NUMELEMENTS(host), g_out);
+    NDArray_FREE(host);
+}
+
+/* x[i] = lo + (hi - lo) * frac(i * 0.6180339887 + seed * 0.37): what tests/test_gpu_method_bodies.py::c_input rebuilds */
+static NDArray *input(const int *shape, int ndim, int seed, float lo, float hi) {
+    long n = 1;
+    for (int i = 0; i < ndim; i++) n *= shape[i];
+    float *host = (float *) malloc(sizeof(float) * (size_t) n);
+    for (long i = 0; i < n; i++) {
+        double t = (double) i * 0.6180339887 + (double) seed * 0.37;
+        t -= (double) (long) t;
+        host[i] = (float) ((double) lo + ((double) hi - (double) lo) * t);
+    }
+    NDArray *cpu = NDArray_FromHostBuffer(host, shape, ndim);
+    free(host);
+    return cpu;
+}
+
+static NDArray *placed(NDArray *host, int on_gpu) {   /* $a->gpu() when asked; the caller keeps `host` */
+    if (!on_gpu) return host;
+    NDArray *dev = NDArray_ToGPU(host);
+    if (dev == NULL) {
+        fprintf(stderr, "fast_path_bodies: gpu() failed: %s\n", numpower_host_last_error());
+        exit(1);
+    }
+    return dev;
+}
+
+int main(int argc, char **argv) {
+    const int gpu = argc >= 2 && strcmp(argv[1], "gpu") == 0;
+    if (argc < 2 || (!gpu && strcmp(argv[1], "cpu") != 0) || (gpu && argc != 3)) {
+        fprintf(stderr, "usage: %s cpu | gpu <output file>\n", argv[0]);
+        return 2;
+    }
+    if (gpu && (g_out = fopen(argv[2], "wb")) == NULL) {
+        perror(argv[2]);
+        return 2;
+    }
+    const int rows = 257, cols = 255;                        /* AVX2 body + ragged tail */
+    const int s2[2] = {rows, cols}, s1[1] = {cols}, scol[2] = {rows, 1}, s3[3] = {6, 37, 20};
+    NDArray *hx = input(s2, 2, 101, -50, 50), *hy = input(s2, 2, 102, -50, 50), *hrow = input(s1, 1, 103, 0.5f, 4);
+    NDArray *hcol = input(scol, 2, 105, 0.5f, 4), *hp = input(s2, 2, 104, 0.25f, 4), *h3 = input(s3, 3, 106, -2, 2);
+    NDArray *two = NDArray_CreateFromDoubleScalar(2.5);      /* a PHP float operand: 0-d, on the host (numpower.c:193-229) */
+    NDArray *x = placed(hx, gpu), *y = placed(hy, gpu), *row = placed(hrow, gpu), *col = placed(hcol, gpu);
+    NDArray *p = placed(hp, gpu), *a3 = placed(h3, gpu), *two_dev = placed(two, gpu);
+    int calls = 0;
+    for (int k = 0; k < kCount; k++) {
+        const int is_pow = strcmp(kPatched[k].name, "Pow_Float") == 0;
+        NDArray *lhs = is_pow ? p : x;                       /* positive bases for pow */
+        const struct { const char *form; NDArray *a, *b; } forms[] = {
+            {"full", lhs, y}, {"row", lhs, row}, {"col", lhs, col}, {"scalar", lhs, two}, {"rscalar", two, lhs},
+            {"devscalar", lhs, two_dev}, {"rrow", row, lhs},
+        };
+        for (size_t f = 0; f < sizeof forms / sizeof forms[0]; f++) {
+            if (is_pow && (strcmp(forms[f].form, "full") == 0 || strcmp(forms[f].form, "rscalar") == 0)) continue;
+            NDArray *r = kPatched[k].fn(forms[f].a, forms[f].b);
+            calls++;
+            if (gpu) {
+                dump(kPatched[k].name, forms[f].form, r);
+                if (r) NDArray_FREE(r);
+            } else if (r != NULL) {
+                fprintf(stderr, "fast_path_bodies: %s.%s computed something for CPU operands\n", kPatched[k].name, forms[f].form);
+                g_failed = 1;
+            }
+        }
+    }
+    for (int axis_i = 0; axis_i < 3; axis_i++) {             /* reduce(nda, &axis_i, NDArray_Add_Float | Multiply) */
+        static const struct { const char *name; Binary op; } kReduce[] = {{"sum", NDArray_Add_Float}, {"prod", NDArray_Multiply_Float}};
+        for (int k = 0; k < 2; k++) {
+            char form[16];
+            snprintf(form, sizeof form, "axis%d", axis_i);
+            NDArray *r = patched_reduce(a3, &axis_i, kReduce[k].op);
+            calls++;
+            if (gpu) dump(kReduce[k].name, form, r);
+            if (r) NDArray_FREE(r);
+        }
+    }
+    /* any other operation keeps the reference's loop, GPU array or not */
+    { int axis_i = 0; NDArray *r = patched_reduce(a3, &axis_i, NDArray_Subtract_Float); if (r) NDArray_FREE(r); }
+    const int expect_fell = gpu ? 1 : calls + 1;
+    printf("fast_path_bodies %s: %d calls, %d reached the reference's own code (expected %d)\n", argv[1], calls + 1,
+           g_fell_through, expect_fell);
+    if (g_fell_through != expect_fell) g_failed = 1;
+    if (gpu) {
+        NDArray_FREE(x); NDArray_FREE(y); NDArray_FREE(row); NDArray_FREE(col); NDArray_FREE(p); NDArray_FREE(a3); NDArray_FREE(two_dev);
+        fclose(g_out);
+        if (NDArray_LiveDeviceAllocations() != 0) {
+            fprintf(stderr, "fast_path_bodies: %ld device allocations leaked\n", NDArray_LiveDeviceAllocations());
+            g_failed = 1;
+        }
+    }
+    NDArray_FREE(hx); NDArray_FREE(hy); NDArray_FREE(hrow); NDArray_FREE(hcol); NDArray_FREE(hp); NDArray_FREE(h3); NDArray_FREE(two);
+    return g_failed;
+}
+'''
 
 
 def _indent(text: str, pad: str) -> str:
@@ -300,7 +550,12 @@ def apply_edit(text: str, e: Edit):
         old = m.group("old")
         pad = re.match(r"[ \t]*", old).group(0)
         new = e.new.replace("@HIP_M4_BLOCK@", HIP_M4_BLOCK)
-        if e.wrap:
+        if e.after:
+            last_pad = re.match(r"[ \t]*", old.split("\n")[-1]).group(0)
+            if old.lstrip().startswith("#"):
+                last_pad = ""          # behind a preprocessor line: at the margin
+            rep = "%s\n#ifdef HAVE_NP_HIP\n%s\n#endif" % (old, _indent(new, last_pad))
+        elif e.wrap:
             rep = "#ifdef HAVE_NP_HIP\n%s\n#else\n%s\n#endif" % (_indent(new, pad), old)
         else:
             rep = new
