@@ -429,73 +429,18 @@ int np_comm_piece(size_t slab, int chunks, int c, size_t *host_lo, size_t *host_
 int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K, const float *A, size_t stride_a,
                                        const float *B, size_t stride_b, float *C_full, int chunks, int mode);
 
-/* How the communicator orders its two streams and issues the sharded GEMM (tuning / A-B; np_comm.hip):
- *   0  default: device-side flags (a one-lane kernel publishes a sequence number on the producing stream, a one-lane
- *      kernel on the consuming stream waits for it).  On a one-rank communicator the slab is ONE progress-reporting
- *      GEMM launch (piece c's transfer is released by the GEMM's own tile counter); with peers it is one GEMM launch
- *      per piece, a kernel boundary behind every piece — the single launch has only ever run on one GPU, so with
- *      world > 1 it is opt-in (3).  Falls back to HIP events by itself if the self-test at np_comm_init finds that
- *      flags do not get through (both streams on one hardware queue).
- *   1  HIP events (hipEventRecord + hipStreamWaitEvent) and one GEMM launch per piece
- *   2  device-side flags, one GEMM launch per piece
- *   3  device-side flags, ONE progress-reporting GEMM launch per slab at any world size
- * A device-side wait for this GPU's own work gives up after 60 s and raises the process's device-error word: the next
- * np_sync / np_memcpy_d2h / host-result call / np_comm_* call returns NP_ERR_DEVICE.  A wait for transfers (which depend on
- * other ranks) never gives up by itself — same as the RCCL kernel it waits for; np_comm_destroy releases it after 30 s.
- * np_comm_sync_mode: 1 = flags in use, 0 = events, -1 = no communicator. */
-int np_comm_set_variant(int variant);
-int np_comm_sync_mode(void);
+/* Device-side waits.  A wait for this GPU's own work (a stream-ordering wait of the sharded matmul whose producer never ran,
+ * a GEMM workgroup that never saw its siblings' partial tiles) gives up after a bounded number of polls and raises the
+ * process's device-error word: the next np_sync / np_memcpy_d2h / host-result call / np_comm_* call returns NP_ERR_DEVICE.
+ * A wait for TRANSFERS (which depend on other ranks) gives up after np_comm_set_wait_limit seconds (default 600; 0 = never,
+ * like the RCCL kernel it waits for) and raises the same error; np_comm_destroy releases whatever still waits.
+ * With peers (world > 1) the sharded GEMM is one launch per piece; see np_hip_debug.h (np_comm_set_variant) for the
+ * forms kept for A/B measurements. */
+int np_comm_set_wait_limit(double seconds);
 
-/* testing: the rendezvous of np_comm_init alone (no device, no RCCL) — rank 0's 128 bytes reach every peer */
-int np_comm_debug_exchange(int rank, int world, const char *endpoint, void *bytes128, double timeout_s);
-/* testing: the exchange np_sgemm_strided_batched_allgather makes rank `rank` of `world` issue for a slab of `slab` items
- * of item_bytes in `chunks` pieces (point to point), computed by the same functions as the real path, without a device or
- * a communicator: records {piece, send to, send offset, bytes, receive from, receive offset} (byte offsets into the
- * replicated result); *host_count = number of records (also when max_records is smaller). */
-int np_comm_debug_plan(int rank, int world, size_t slab, size_t item_bytes, int chunks, unsigned long long *host_out,
-                       size_t max_records, size_t *host_count);
-/* testing: dst <- src through one grouped ncclSend / ncclRecv pair from this rank to itself on the communication
- * stream, then np_comm_wait() — the P2P transport on a box with a single GPU */
-int np_comm_debug_sendrecv_self(const void *dev_src, void *dev_dst, size_t bytes);
-/* testing: `count` (<= 64) self transfers of `bytes` on the communication stream, not ordered behind the library stream (so
- * they compete with whatever that stream is running), each bracketed by its own events; host_ms[i] = duration of transfer i.
- * Returns when the communication stream has drained. */
-int np_comm_debug_loopback_timed(const void *dev_src, void *dev_dst, size_t bytes, int count, float *host_ms);
-/* testing: every piece gathered point-to-point is from now on ALSO sent from this rank to itself into dev_scratch
- * (pieces larger than `bytes` are not): real RCCL traffic next to the GEMM on a box without a peer.  (NULL, 0) = off. */
-int np_comm_debug_loopback(void *dev_scratch, size_t bytes);
-
-/* Kernel-variant selection for tuning/benchmarks (0 = default heuristic; -1 = whole-K plans only (no split-K, no
- * stream-K), -2 = default planner again, -3 = default planner + always pad unaligned operands, -4 = stream-K wherever
- * the kernel can run it, -5 = default planner without stream-K, -6 = operands whose rows are not float4-loadable never
- * go to the LDS-DMA kernel as they are (padded copies / register-staged kernels, as before round 3), -8 = they always do, whatever the size, -7 = back to the
- * default: from a size threshold up), -9 = never peel a thin ragged edge (M % 256 <= 32 rows, N % 128 <= 2 columns) off a
- * large product, -11 = always when there is one, -10 = back to the default: when the planner's model says it pays), -12 = products with M <= 64 rows go to the tiled
- * kernels instead of sgemm_fewrows_kernel / sgemm_skinny_kernel (as before round 3), -13 = back; round 4: -14 / -15 = plans
- * without / with the mid-size LDS-DMA tiles (sgemm_dmas_kernel), -16 / -17 = their tiles walked row-major / in XCD-aware bands,
- * -18 / -19 = ragged whole-K 64 x 64 products on four / eight waves, -20 / -21 = plans without / with the k-quartered tiles
- * (sgemm_kq_kernel); -(1000 + 100 * shape + S) forces sgemm_dmas_kernel's tile `shape` with K split S ways wherever it applies,
- * -(2000 + shape) forces sgemm_kq_kernel's tile `shape` (0 .. 6: 48x48, 32x32, 64x64, 48x32, 64x32, 64x48, 80x48), -999 ends
- * either forcing).  All of them are process-wide setters for A/B measurements and tests: results stay within the same bounds. */
-int np_runtime_set_variant(int variant);   /* how host-result calls wait: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag, 2 = spin on the result itself (default) */
-int np_sgemm_set_variant(int variant);
-/* debug: the planner's choice for one dense, aligned M x N x K product on a device of `cus` CUs (0 = the current device; any
- * other value needs no device: the planner is host arithmetic).  out[11]: cfg, tail_rows, S, modelled us of the tiled plan;
- * stream-K taken (0/1), its modelled us; cfg, S, us of the best mid-size-tile plan; cfg, us of the best plan without them
- * (1e300 = does not apply).  tests/test_abi_and_host_cpu.py pins the choices that matter (no reference counterpart:
- * linalg.c:75-79 hands every product to cblas / cuBLAS). */
-int np_sgemm_debug_plan(size_t M, size_t N, size_t K, size_t batch, int cus, double *out);
-int np_elementwise_set_variant(int variant);   /* launch shape of the streaming kernels (np_elementwise.hip cfg_from_variant) and A/B switches of single kernels, e.g. 9000 = np_binary(pow) with its log2 table in LDS instead of registers (same bits) */
-int np_layout_set_variant(int variant);   /* transpose tile: 0 = default, 64, 128; 1 = default tiles without the write-aligned form for output rows off the 128-byte grid */
-int np_select_set_variant(int variant);   /* order statistics: 0 = plain three passes only (no bracket path, no one-workgroup kernel), 1 = default (n >= 2^26), else the smallest n that takes it */
-int np_select_last_path(int *path);       /* tests / tools: 1 if the last selection ran over the bracket's copied keys, 0 if over the array, 2 if in the one-workgroup kernel (synchronises) */
-int np_reduce_set_variant(int variant);   /* streaming reductions, first pass: workgroups per CU (0 = default) */
-/* tools: the shader clock in MHz a ~20 us probe kernel sees on the library stream right now (synchronises the stream) */
-int np_debug_clock_mhz(float *host_mhz);
-/* testing: a one-lane kernel on the library stream raises `bits` in the process's device-error word — what a device-side wait
- * that gives up does (1 = a stream-ordering wait of np_comm, 2 = a stream-K finisher).  The next np_sync / np_memcpy_d2h /
- * host-result call / np_comm_* call returns NP_ERR_DEVICE once, and clears the word. */
-int np_debug_raise_device_error(unsigned bits);
+/* Everything that only tests, sweeps and A/B measurements need — kernel-variant switches (process-global state),
+ * planner / rendezvous / transport probes, error injection — is declared in np_hip_debug.h.  Same library; a binding
+ * needs none of it. */
 
 #ifdef __cplusplus
 }

@@ -25,10 +25,11 @@
 // GPU's own work (the communication stream waiting for the library stream's GEMM) is bounded — it gives up after a
 // time-out and raises the process's device-error word (np_internal.h), which np_sync, np_memcpy_d2h, the host-result
 // calls and every np_comm_* entry point turn into NP_ERR_DEVICE.  The opposite direction — the library stream waiting
-// for transfers to be delivered — depends on OTHER ranks (skew, RCCL's lazy connect, a peer that is minutes late) and
-// is NOT bounded, exactly like the RCCL kernel it waits for and like the hipStreamWaitEvent it replaces: a result that
-// has not been gathered is never handed to the caller as if it had.  The host can still release such a wait
-// (np_comm_destroy raises the abort word it polls).  The sharded GEMM goes one step further: ONE launch computes the whole
+// for transfers to be delivered — depends on OTHER ranks (skew, RCCL's lazy connect, a peer that is minutes late): its
+// bound is generous and configurable (np_comm_set_wait_limit, default ten minutes, 0 = never — like the RCCL kernel it
+// waits for), and giving up raises the same error word: a result that has not been gathered is never handed to the
+// caller as if it had, and a dead peer ends as NP_ERR_DEVICE instead of a hang.  The host can release such a wait early
+// (np_comm_destroy raises the abort word every wait polls, and aborts the communicator if RCCL's own kernel is stuck).  The sharded GEMM goes one step further: ONE launch computes the whole
 // slab and its workgroups count finished tiles per piece (GemmArgs::progress, np_sgemm.hip); the wait kernel in front
 // of piece c's transfer releases it when the count is complete — no launch per piece, no host in the loop.  Both
 // need the two streams to sit on different hardware queues (they do: the communication stream is created at high
@@ -81,6 +82,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -138,6 +140,7 @@ int load_rccl(Rccl &r) {
     NP_SYM(GetUniqueId, "ncclGetUniqueId");
     NP_SYM(CommInitRank, "ncclCommInitRank");
     NP_SYM(CommDestroy, "ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.handle, "ncclCommAbort");   // optional: only a stuck communicator needs it
     NP_SYM(AllGather, "ncclAllGather");
     NP_SYM(AllReduce, "ncclAllReduce");
     NP_SYM(Send, "ncclSend");
@@ -307,7 +310,11 @@ int exchange_file(const std::string &path, int rank, ncclUniqueId &id, double ti
 // ---- the communication stream ----
 
 constexpr unsigned long long kWaitTimeoutTicks = 60ull * 100000000ull;   // 60 s of the 100 MHz wall clock: waits for THIS GPU's own work
-constexpr unsigned long long kWaitForPeers = 0ull;                       // no time-out: waits for transfers (other ranks decide when they end)
+// Waits for transfers depend on other ranks: generous, configurable (np_comm_set_wait_limit), 0 = never give up — like the RCCL
+// kernel they wait for.  A peer that died must end as NP_ERR_DEVICE at the next sync point, not as a hang nobody can leave
+// (ADVICE r04): the default is ten minutes.
+unsigned long long g_peer_wait_ticks = 600ull * 100000000ull;
+#define kWaitForPeers g_peer_wait_ticks
 constexpr unsigned long long kSelfTestTicks = 20000000ull;               // 200 ms (only ever spent when the test FAILS)
 
 __global__ void flag_set_kernel(unsigned *flag, unsigned value) {
@@ -318,7 +325,7 @@ __global__ void flag_set_kernel(unsigned *flag, unsigned value) {
 // Spins until *flag has reached `target` (sequence numbers: compared as a signed difference, so wrap-around is fine;
 // tile counters: plain >=).  One lane; s_sleep keeps it off the issue ports of the CU it sits on.  timeout_ticks != 0:
 // gives up after that long, ORs error_bit into error_word[0] (reported by the host, np::check_device_error) and lets the
-// queue drain.  timeout_ticks == 0: never gives up by itself — only when the host raises error_word[1] (abort).
+// queue drain.  timeout_ticks == 0: never gives up by itself.  Either way it ends when the host raises error_word[1] (abort).
 __global__ void flag_wait_kernel(const unsigned *flag, unsigned target, unsigned long long timeout_ticks, unsigned *error_word,
                                  unsigned error_bit) {
     const unsigned long long t0 = wall_clock64();
@@ -326,13 +333,12 @@ __global__ void flag_wait_kernel(const unsigned *flag, unsigned target, unsigned
         const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // memory-side; the next kernel on this stream starts with an acquire
         if ((int)(v - target) >= 0) return;
         __builtin_amdgcn_s_sleep(16);
-        if (timeout_ticks) {
-            if ((spins & 63u) == 63u && wall_clock64() - t0 > timeout_ticks) {
-                __hip_atomic_fetch_or(error_word, error_bit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                return;   // give up rather than hang the queue: the host reports it (np_sync, np_memcpy_d2h, np_comm_*)
-            }
-        } else if ((spins & 4095u) == 4095u &&   // one read over the host link every few milliseconds
-                   __hip_atomic_load(error_word + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+        if (timeout_ticks && (spins & 63u) == 63u && wall_clock64() - t0 > timeout_ticks) {
+            __hip_atomic_fetch_or(error_word, error_bit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;   // give up rather than hang the queue: the host reports it (np_sync, np_memcpy_d2h, np_comm_*)
+        }
+        if ((spins & 4095u) == 4095u &&   // one read over the host link every few milliseconds
+            __hip_atomic_load(error_word + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
             __hip_atomic_fetch_or(error_word, error_bit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return;   // the host asked every wait to end (np_comm_destroy): what it guarded is incomplete, and reported as such
         }
@@ -848,10 +854,26 @@ int np_comm_destroy(void) {
         usleep(200);
     }
     (void)hipGetLastError();
-    if (g_comm.stream) (void)hipStreamSynchronize(g_comm.stream);
+    // the communication stream may sit in an RCCL kernel whose peer never arrived: the abort word does not reach that kernel,
+    // and hipStreamSynchronize on it would never return.  Give it the rest of the grace period, then abort the communicator
+    // (ncclCommAbort makes its kernels leave) instead of destroying it.
+    bool aborted = false;
+    if (g_comm.stream) {
+        const double comm_give_up = (now_s() > give_up ? now_s() : give_up) + 5.0;
+        while (hipStreamQuery(g_comm.stream) == hipErrorNotReady && now_s() <= comm_give_up) usleep(200);
+        (void)hipGetLastError();
+        if (hipStreamQuery(g_comm.stream) == hipErrorNotReady && g_comm.api.CommAbort) {
+            (void)hipGetLastError();
+            if (err) __atomic_store_n(err + 1, 1u, __ATOMIC_RELEASE);
+            (void)g_comm.api.CommAbort(g_comm.comm);
+            aborted = true;
+        }
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(g_comm.stream);
+    }
     (void)hipStreamSynchronize(np::stream());
     if (err) __atomic_store_n(err + 1, 0u, __ATOMIC_RELEASE);
-    const ncclResult_t rc = g_comm.api.CommDestroy(g_comm.comm);
+    const ncclResult_t rc = aborted ? ncclSuccess : g_comm.api.CommDestroy(g_comm.comm);
     g_comm.comm = nullptr;
     destroy_stream_objects();
     if (g_comm.scratch) np_free(g_comm.scratch);
@@ -861,6 +883,14 @@ int np_comm_destroy(void) {
         g_comm.file_to_remove.clear();
     }
     if (rc != ncclSuccess) return np::fail(NP_ERR_DEVICE, "ncclCommDestroy failed: %s", g_comm.api.GetErrorString(rc));
+    if (aborted) return np::fail(NP_ERR_DEVICE, "np_comm_destroy: a transfer never completed (a peer is gone); the communicator was aborted");
+    return NP_OK;
+}
+
+int np_comm_set_wait_limit(double seconds) {
+    if (!(seconds >= 0.0) || seconds > 1e7) return np::fail(NP_ERR_INVALID, "np_comm_set_wait_limit: %g s is not a limit (0 = never give up)", seconds);
+    g_peer_wait_ticks = (unsigned long long)(seconds * 1e8);   // wall_clock64 ticks at 100 MHz
+    if (seconds > 0.0 && g_peer_wait_ticks == 0) g_peer_wait_ticks = 1;
     return NP_OK;
 }
 

@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include "np_hip.h"
+#include "np_hip_debug.h"
 
 namespace np {
 

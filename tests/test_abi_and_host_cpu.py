@@ -19,8 +19,14 @@ def _declared(header: Path, pattern: str):
 def test_np_hip_exports_every_declared_symbol():
     from numpower_amd import _lib
     lib = _lib.load()
-    names = _declared(ROOT / "include" / "np_hip.h", r"\b(np_\w+)\s*\(")
-    assert len(names) >= 35
+    product = _declared(ROOT / "include" / "np_hip.h", r"\b(np_\w+)\s*\(")
+    probes = _declared(ROOT / "include" / "np_hip_debug.h", r"\b(np_\w+)\s*\(")
+    # the product header holds no kernel-variant switch and no probe: those live in np_hip_debug.h (same library)
+    assert not [n for n in product if n.endswith("_set_variant") or "_debug_" in n or n.startswith("np_debug_") or n == "np_select_last_path"]
+    assert all(n.endswith("_set_variant") or "_debug_" in n or n.startswith("np_debug_") or n in ("np_select_last_path", "np_comm_sync_mode")
+               for n in probes), probes
+    assert len(product) >= 35 and len(probes) >= 14
+    names = sorted(set(product) | set(probes))
     for n in names:
         assert hasattr(lib, n), "libnp_hip.so does not export %s" % n
         assert n in _lib.PROTOTYPES, "numpower_amd/_lib.py has no prototype for %s" % n

@@ -313,3 +313,32 @@ def test_a_transfer_issued_next_to_a_running_gemm_gets_through(hip):
         assert t.max() <= alone + 2.0, ("next to 4096^3 (one resident round): at most ~one product", t, alone)   # measured <= 0.98 ms
     finally:
         check(lib.np_comm_destroy())
+
+
+def test_transfer_wait_limit_is_configurable(hip):
+    """np_comm_set_wait_limit: the bound on the library stream's wait for transfers (it used to be unbounded, a
+    dead peer was an unkillable hang).  Refuses nonsense, and a tight limit does not disturb transfers that do complete."""
+    lib = load()
+    with pytest.raises(NumPowerError, match="not a limit"):
+        check(lib.np_comm_set_wait_limit(-1.0))
+    with pytest.raises(NumPowerError, match="not a limit"):
+        check(lib.np_comm_set_wait_limit(float("nan")))
+    batch, n = 8, 128
+    A = synth.uniform((batch, n, n), 12, -1.0, 1.0)
+    B = synth.uniform((batch, n, n), 13, -1.0, 1.0)
+    check(lib.np_comm_init(0, 1, ("tcp://127.0.0.1:%d" % free_port()).encode()))
+    try:
+        check(lib.np_comm_set_wait_limit(0.5))
+        dA, dB = hip.DeviceArray.from_host(A), hip.DeviceArray.from_host(B)
+        out = hip.DeviceArray((batch, n, n))
+        for chunks in (1, 4):
+            check(lib.np_sgemm_strided_batched_allgather(batch, n, n, n, dA.ptr, n * n, dB.ptr, n * n, out.ptr, chunks, 0))
+            got = out.to_host().astype(np.float64)
+            scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+            assert (np.abs(got - A.astype(np.float64) @ B.astype(np.float64)) <= 1e-6 * scale).all()
+        check(lib.np_comm_set_wait_limit(0.0))      # never give up (the behaviour before this round) is still selectable
+        check(lib.np_sgemm_strided_batched_allgather(batch, n, n, n, dA.ptr, n * n, dB.ptr, n * n, out.ptr, 2, 0))
+        check(lib.np_sync())
+    finally:
+        check(lib.np_comm_set_wait_limit(600.0))
+        check(lib.np_comm_destroy())
