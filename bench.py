@@ -672,6 +672,32 @@ def bench_extras(dist: Dist, steps, warmup):
         dred.free()
     del e64
     tmp.free()
+    # SURVEY.md section 8(f) rows 2 and 4 at the sizes of tools/misc_sweep.py: argmax of the flat 1e8 array
+    # (4 B/elem, calculation.c:73-194), variance's two passes (np_moments: 8 B/elem, statistics.c:117-130) and
+    # dot(matrix, vector) with few long rows (10 x 1e7: 4 (M K + K + M) bytes, linalg.c:367-386)
+    idx = D.DeviceArray((1,))
+    r = hbm_case("argmax flat 1e8 (8f row 2)", 4.0 * N, lambda: check(lib.np_argreduce(1, da.ptr, 1, N, 1, idx.ptr)), steps, warmup, dist)
+    r["parity_ok"] = bool(idx.to_host()[0] == np.float32(np.argmax(a)))
+    ex["argmax_1e8"] = r
+    mean, m2 = C.c_float(), C.c_float()
+    r = hbm_case("moments (variance) 1e8 (8f row 2)", 8.0 * N,
+                 lambda: check(lib.np_moments(da.ptr, N, C.byref(mean), C.byref(m2))), steps, warmup, dist)
+    a64 = a.astype(np.float64)
+    var64 = float(((a64 - a64.mean()) ** 2).sum())
+    r["parity_rel_err_vs_fp64"] = abs(m2.value - var64) / var64
+    r["parity_ok"] = bool(r["parity_rel_err_vs_fp64"] <= 1e-5 and abs(mean.value - a64.mean()) <= 1e-5 * a64.mean())
+    ex["moments_1e8"] = r
+    del a64
+    Mv, Kv = 10, 10_000_000
+    yv = D.DeviceArray((Mv,))
+    r = hbm_case("sgemv 10 x 1e7 (8f row 4)", 4.0 * (Mv * Kv + Kv + Mv), lambda: check(lib.np_sgemv(Mv, Kv, da.ptr, db.ptr, yv.ptr)),
+                 steps, warmup, dist)
+    refv = a.reshape(Mv, Kv).astype(np.float64) @ b[:Kv].astype(np.float64)
+    r["parity_max_rel_err_vs_fp64"] = float((np.abs(yv.to_host().astype(np.float64) - refv) / np.abs(refv)).max())
+    r["parity_ok"] = bool(r["parity_max_rel_err_vs_fp64"] <= 1e-5)
+    ex["sgemv_10x1e7"] = r
+    yv.free()
+    idx.free()
     for d in (da, db, do, drow, dcol):
         d.free()
     del a, b, got
@@ -703,6 +729,14 @@ def bench_extras(dist: Dist, steps, warmup):
     r["parity_ok"] = bool((dT.to_host()[:, :4096] == X[:4096].T).all())
     ex["transpose_65536x4096"] = r
     dT.free()
+    # argmax over the last axis of 65536 x 1024 (the first quarter of the same buffer, contiguous): one wave per row
+    ar, ac = 65536, 1024
+    didx = D.DeviceArray((ar,))
+    r = hbm_case("argmax(axis 1) 65536x1024 (8f row 2)", 4.0 * ar * ac + 4.0 * ar,
+                 lambda: check(lib.np_argreduce(1, dX.ptr, ar, ac, 1, didx.ptr)), steps, warmup, dist)
+    r["parity_ok"] = bool((didx.to_host() == np.argmax(X.reshape(-1)[:ar * ac].reshape(ar, ac), axis=1).astype(np.float32)).all())
+    ex["argmax_axis1_65536x1024"] = r
+    didx.free()
     dX.free()
     return ex
 
@@ -1006,6 +1040,8 @@ def _summary(result, extras):
         if isinstance(e, dict) and "TFLOPs" in e:
             out[key + "_TFLOPs"] = _compact(e["TFLOPs"])
     out["transpose_8191x8193_frac_hbm"], out["permute_nhwc_like_frac_hbm"] = frac("transpose_8191x8193"), frac("permute_nhwc_like")
+    out["argmax_1e8_frac_hbm"], out["argmax_axis1_65536x1024_frac_hbm"] = frac("argmax_1e8"), frac("argmax_axis1_65536x1024")
+    out["moments_1e8_frac_hbm"], out["sgemv_10x1e7_frac_hbm"] = frac("moments_1e8"), frac("sgemv_10x1e7")
     c1 = extras.get("c1")
     if isinstance(c1, dict) and "cpu_add_ms" in c1:
         out["c1_cpu_add_ms"], out["c1_cpu_sum_ms"] = _compact(c1["cpu_add_ms"]), _compact(c1["cpu_sum_ms"])

@@ -417,7 +417,10 @@ void *np_comm_stream(void);   /* the communication stream as a raw hipStream_t (
  * rank multiplies its slab (A, B: `slab` matrices, strides in elements) straight into its window
  * C_full + rank * slab * M * N, in `chunks` pieces (as equal as they come; clipped to slab); the gather of piece c is
  * handed to the communication stream as soon as piece c's GEMM is enqueued and travels while piece c + 1 computes.
- * Ends with np_comm_wait(), so the next call on the library stream (or np_sync) sees the whole result.  chunks = 1
+ * Ends with np_comm_wait(), so the next call on the library stream (or np_sync) sees the whole result.  chunks = 0
+ * leaves the piece count to the library: a step model of the pipeline (GEMM rate, one xGMI link per peer, the start delay
+ * a transfer pays while the GEMM holds the CUs) picks it from 1, 2, 4, 8, 16 — one piece when nothing travels (a one-rank
+ * communicator) or under NP_GATHER_COLLECTIVE; this is what a caller without a reason of its own should pass.  chunks = 1
  * is "compute, then one all-gather" on two streams (mode picks the transport); chunks > 1 always travels P2P (the
  * pieces of a slab are one slab apart across ranks) and mode NP_GATHER_COLLECTIVE is refused.  The result is
  * bit-identical for every chunks / mode: the same GEMM kernel computes every matrix.  The reference has no batched

@@ -42,6 +42,10 @@ int np_comm_debug_exchange(int rank, int world, const char *endpoint, void *byte
  * replicated result); *host_count = number of records (also when max_records is smaller). */
 int np_comm_debug_plan(int rank, int world, size_t slab, size_t item_bytes, int chunks, unsigned long long *host_out,
                        size_t max_records, size_t *host_count);
+/* the step model behind np_sgemm_strided_batched_allgather(chunks = 0) (np_comm.hip: model_pieces), for any
+ * world / shape on a device of `cus` CUs (0 = 256), without a device or a communicator: *host_chunks = the piece count it
+ * picks; host_ms5 (may be NULL) = the modelled step in ms with 1, 2, 4, 8, 16 pieces. */
+int np_comm_debug_model(int world, size_t slab, size_t M, size_t N, size_t K, int cus, int *host_chunks, double *host_ms5);
 /* testing: dst <- src through one grouped ncclSend / ncclRecv pair from this rank to itself on the communication
  * stream, then np_comm_wait() — the P2P transport on a box with a single GPU */
 int np_comm_debug_sendrecv_self(const void *dev_src, void *dev_dst, size_t bytes);

@@ -284,11 +284,14 @@ NDArray *NDArray_BatchedMatmul(NDArray *a, NDArray *b);
  *                NP_SHARD_GATHER (1)    -> [batch x M x N] replicated on every rank: the GEMM, then ONE all-gather
  *                k >= 2                 -> the same result, slab computed in k pieces, each piece's transfer
  *                                          overlapped with the next piece's GEMM (np_sgemm_strided_batched_allgather)
+ *                NP_SHARD_OVERLAP (-1)  -> the same, the number of pieces chosen by the library's step model (chunks = 0):
+ *                                          what a caller without a reason of its own passes
  * Without a communicator the process is a world of one: batch must equal slab.  Errors (thrown like every other
  * method's): device mismatch / shape mismatch with NDArray_Matmul's messages (linalg.c:219-237),
  * "Batch of %d is not %d slab(s) of %d" when the shares do not add up. */
 #define NP_SHARD_KEEP 0
 #define NP_SHARD_GATHER 1
+#define NP_SHARD_OVERLAP (-1)
 int NDArray_CommInit(int rank, int world, const char *endpoint);
 int NDArray_CommDestroy(void);
 int NDArray_CommRank(void);

@@ -665,13 +665,63 @@ void *np_comm_stream(void) { return g_comm.comm ? (void *)g_comm.stream : nullpt
 // The sharded batched matmul of BASELINE config 5 as ONE call: this rank's slab of `slab` products, written in
 // place into its window of the replicated result, in `chunks` pieces — piece c's gather is given to the
 // communication stream the moment piece c's GEMM has been enqueued, and travels while piece c + 1 is computed.
+// ---- how many pieces (chunks = 0): a step model of the pipeline, host arithmetic ----
+// Piece c's GEMM ends at (c + 1) T_g / k.  Transfers are serialised on the communication stream; each takes T_x / k (every
+// peer's share of the piece arrives over that peer's own xGMI link, all links at once) plus a fixed issue cost, starts when
+// its GEMM piece and the previous transfer are done, and — what one GPU could measure (profiles/r04/comm_contention.log) —
+// starts LATE by one round of the GEMM's workgroups when the GEMM still holds the CUs.  The step ends with the last
+// transfer (or the GEMM).  The smallest k within 2 % of the best modelled step is taken: fewer, larger pieces when it is a
+// tie.  Constants: 130 TFLOP/s sustained by the slab GEMM, 153 GB/s per link (MI355X_MICROARCH.md), 256 x 128 tiles, two
+// resident workgroups per CU, 10 us per piece.  Unmeasured on more than one GPU; the model is what is pinned
+// (tests/test_parallel_cpu.py), not a claim about a node.
+constexpr int kModelPieces[5] = {1, 2, 4, 8, 16};
+int model_pieces(int world, size_t slab, size_t M, size_t N, size_t K, int cus, double *ms5) {
+    const double t_g = 2.0 * (double)slab * (double)M * (double)N * (double)K / 130e12 * 1e3;
+    const double t_x = world > 1 ? (double)slab * (double)M * (double)N * 4.0 / 153e9 * 1e3 : 0.0;
+    const double tiles = (double)slab * (double)((M + 255) / 256) * (double)((N + 127) / 128);
+    const double rounds = tiles / (2.0 * (cus > 0 ? cus : 256));
+    const double delay = t_g / (rounds < 1.0 ? 1.0 : rounds);
+    const double issue = 0.01;
+    double best = 1e300;
+    double ms[5];
+    for (int i = 0; i < 5; ++i) {
+        const int k = kModelPieces[i];
+        if ((size_t)k > slab && i > 0) {
+            ms[i] = 1e300;
+            continue;
+        }
+        double end_prev = 0.0;
+        for (int c = 0; c < k; ++c) {
+            double start = (c + 1) * t_g / k;
+            if (end_prev > start) start = end_prev;
+            if (k > 1 && start < t_g) start += delay;      // the communication kernels wait for CUs while the GEMM runs
+            end_prev = start + t_x / k + issue;
+        }
+        ms[i] = end_prev > t_g ? end_prev : t_g;
+        if (ms[i] < best) best = ms[i];
+    }
+    int pick = 1;
+    for (int i = 0; i < 5; ++i) {
+        if (ms5) ms5[i] = ms[i];
+    }
+    for (int i = 0; i < 5; ++i)
+        if (ms[i] <= 1.02 * best) {
+            pick = kModelPieces[i];
+            break;
+        }
+    return world > 1 ? pick : 1;                            // nothing travels on a one-rank communicator
+}
+
 int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K, const float *A, size_t stride_a,
                                        const float *B, size_t stride_b, float *C_full, int chunks, int mode) {
     if (int rc = need_comm("np_sgemm_strided_batched_allgather")) return rc;
     if (mode != NP_GATHER_AUTO && mode != NP_GATHER_COLLECTIVE && mode != NP_GATHER_P2P)
         return np::fail(NP_ERR_INVALID, "np_sgemm_strided_batched_allgather: unknown mode %d", mode);
-    if (chunks < 1) return np::fail(NP_ERR_INVALID, "np_sgemm_strided_batched_allgather: chunks = %d", chunks);
+    if (chunks < 0) return np::fail(NP_ERR_INVALID, "np_sgemm_strided_batched_allgather: chunks = %d", chunks);
     if (slab == 0 || M == 0 || N == 0) return NP_OK;
+    if (chunks == 0) {   // the library's own choice: the step model above (one piece under NP_GATHER_COLLECTIVE, which moves whole slabs)
+        chunks = mode == NP_GATHER_COLLECTIVE ? 1 : model_pieces(g_comm.world, slab, M, N, K, np::num_cus(), nullptr);
+    }
     if (!A || !B || !C_full) return np::fail(NP_ERR_INVALID, "np_sgemm_strided_batched_allgather: null pointer");
     if ((size_t)chunks > slab) chunks = (int)slab;
     if (mode == NP_GATHER_COLLECTIVE && chunks > 1)
@@ -772,6 +822,15 @@ int np_comm_debug_plan(int rank, int world, size_t slab, size_t item_bytes, int 
         }
     }
     *host_count = n;
+    return NP_OK;
+}
+
+// the step model behind chunks = 0, for any world / shape, without a device or a communicator: *host_chunks = the piece count
+// it picks, host_ms5[i] = the modelled step with 1, 2, 4, 8, 16 pieces (1e300 where the slab has fewer items)
+int np_comm_debug_model(int world, size_t slab, size_t M, size_t N, size_t K, int cus, int *host_chunks, double *host_ms5) {
+    if (world < 1 || slab == 0 || M == 0 || N == 0 || K == 0 || !host_chunks)
+        return np::fail(NP_ERR_INVALID, "np_comm_debug_model: bad arguments");
+    *host_chunks = model_pieces(world, slab, M, N, K, cus, host_ms5);
     return NP_OK;
 }
 

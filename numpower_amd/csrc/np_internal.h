@@ -58,6 +58,18 @@ int check_device_error(const char *who);
 // second launch — nd::sum() of 1024 floats 13.2 -> 10.3 us, of 10^5 (98 workgroups) 15.9 -> 13.0 (tools/latency_ab.py).
 // (Cutting mid-size grids down to 511 fatter workgroups so that they qualify was tried: 10^6 floats 17.0 -> 18.1 us.)
 constexpr size_t kFoldInKernelMaxBlocks = 256;
+// Round 5 tried to lift that limit with tickets taken in 32 GROUPS (workgroup b draws from counter 1 + b % 32, the last of a
+// group from counter 0): correct and bit-identical, but nd::sum() of 10^6 floats (977 workgroups) took 16.1 us that way against
+// 12.3 us with the second launch — two dependent memory-side round trips for the tickets and one more for the partials cost
+// more than a 4 us launch (profiles/r05/reduce_small_ab.log) — and was removed.  What did help a little: np_reduce_all of up to
+// 4 M elements on at most g_small_reduce_blocks fat workgroups, which then fold behind ONE ticket (10^6: 12.0 us).
+extern size_t g_fold_in_kernel_max;   // largest grid that folds in-kernel, <= kFoldInKernelMaxBlocks (np_reduce_set_variant(2000000 + N): A/B, tests)
+extern size_t g_small_reduce_blocks;  // np_reduce_all of up to 4 M elements on at most this many workgroups (0 = off; np_reduce_set_variant(3000000 + N))
+// the ticket for a first pass of `blocks` workgroups, or nullptr (a second launch folds)
+inline unsigned *fold_ticket(size_t blocks) {
+    if (blocks <= kFoldInKernelMaxBlocks && blocks <= g_fold_in_kernel_max) return next_ticket();
+    return nullptr;
+}
 
 // Block count of a capped grid-stride kernel.  With `cap` a power of two (CUs x 8 ...) every lane's accesses
 // sit a power-of-two number of bytes apart — 2048 workgroups x 4 KiB = 8 MiB — and land on the same HBM channel:
@@ -207,8 +219,20 @@ __device__ __forceinline__ void fold_in_last_workgroup(float r, float *partials,
     }
     if (threadIdx.x == 0) coherent_store(&partials[blockIdx.x], r);
     if (!last_workgroup_done(ticket, gridDim.x)) return;
+    // thread t folds partials t, t + blockDim, ... in that order (the order of the one-workgroup second kernel).  The loads
+    // are memory-side atomics, a microsecond or two each: eight are issued before the first is used (lanes past the end load
+    // nothing and fold the identity, which changes no bit: x + 0, x * 1, min(x, +inf), max(x, -inf))
     float f = r_identity<OP>();
-    for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) f = r_combine<OP>(f, coherent_load(&partials[i]));
+    for (unsigned base = 0; base < gridDim.x; base += 8 * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned i = base + u * blockDim.x + threadIdx.x;
+            v[u] = i < gridDim.x ? coherent_load(&partials[i]) : r_identity<OP>();
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) f = r_combine<OP>(f, v[u]);
+    }
     f = block_reduce<OP>(f, lds4);
     if (threadIdx.x == 0) {
         if constexpr (OP == NP_MEAN) f = __fdiv_rn(f, mean_count);

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "np_internal.h"
@@ -232,6 +233,97 @@ __global__ __launch_bounds__(256) void transpose_skinny_kernel(const float *__re
     }
 }
 
+// Two to four long rows (NCHW <-> NHWC with C = 2 .. 4, an (N, 3) point list <-> three coordinate arrays): neither side of
+// transpose_skinny_kernel is a float4 stream — the strided side moves 8-16 bytes per lane.  Here a workgroup takes 2048
+// positions of the R planes: float4 loads on the side it reads, a pass through LDS (lds[k][pos]: 128-bit accesses on the plane
+// side, scalar ones on the interleaved side), float4 stores on the side it writes — both sides contiguous and non-temporal, all
+// loads of the tile in flight before the first LDS store.  n (positions per plane) % 4 == 0, both pointers 16-byte aligned.
+// TO_INTERLEAVED: in = [batch][R][n] -> out = [batch][n][R]; else the reverse.
+template <int R, bool TO_INTERLEAVED>
+__global__ __launch_bounds__(256) void interleave_kernel(const float *__restrict__ in, float *__restrict__ out, unsigned n) {
+    constexpr unsigned P = 2048, PITCH = P + 4;
+    __shared__ __attribute__((aligned(16))) float lds[R * PITCH];
+    const unsigned t = threadIdx.x;
+    const unsigned p0 = blockIdx.x * P;
+    const unsigned np_ = n - p0 < P ? n - p0 : P;                 // positions of this tile (a multiple of 4)
+    const unsigned nseg4 = np_ * R / 4;                           // float4s of its interleaved segment
+    const size_t batch = blockIdx.y;
+    const float *planes_in = in + batch * R * (size_t)n + p0;     // TO_INTERLEAVED: plane k at + k * n
+    float *planes_out = out + batch * R * (size_t)n + p0;
+    const float *seg_in = in + (batch * (size_t)n + p0) * R;
+    float *seg_out = out + (batch * (size_t)n + p0) * R;
+    if constexpr (TO_INTERLEAVED) {
+        v4f v[R][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned pos = (t + 256u * u) * 4;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (pos < np_) v[k][u] = __builtin_nontemporal_load((const v4f *)(planes_in + (size_t)k * n + pos));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned pos = (t + 256u * u) * 4;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (pos < np_) *(v4f *)&lds[k * PITCH + pos] = v[k][u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) {
+            const unsigned f = t + 256u * j;
+            if (f < nseg4) {
+                v4f w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned e = 4 * f + i;
+                    w[i] = lds[(e % R) * PITCH + e / R];
+                }
+                __builtin_nontemporal_store(w, (v4f *)(seg_out + (size_t)f * 4));
+            }
+        }
+    } else {
+        v4f v[2 * R];
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) {
+            const unsigned f = t + 256u * j;
+            if (f < nseg4) v[j] = __builtin_nontemporal_load((const v4f *)(seg_in + (size_t)f * 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) {
+            const unsigned f = t + 256u * j;
+            if (f < nseg4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned e = 4 * f + i;
+                    lds[(e % R) * PITCH + e / R] = v[j][i];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned pos = (t + 256u * u) * 4;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (pos < np_) __builtin_nontemporal_store(*(const v4f *)&lds[k * PITCH + pos], (v4f *)(planes_out + (size_t)k * n + pos));
+        }
+    }
+}
+
+template <bool TO_INTERLEAVED>
+int launch_interleave(const float *in, float *out, size_t batch, unsigned R, size_t n) {
+    const dim3 grid((unsigned)((n + 2047) / 2048), (unsigned)batch);
+    hipStream_t s = np::stream();
+    switch (R) {
+        case 2: interleave_kernel<2, TO_INTERLEAVED><<<grid, 256, 0, s>>>(in, out, (unsigned)n); break;
+        case 3: interleave_kernel<3, TO_INTERLEAVED><<<grid, 256, 0, s>>>(in, out, (unsigned)n); break;
+        default: interleave_kernel<4, TO_INTERLEAVED><<<grid, 256, 0, s>>>(in, out, (unsigned)n); break;
+    }
+    NP_LAUNCH_CHECK("interleave_kernel");
+    return NP_OK;
+}
+
 struct PermuteArgs {
     unsigned ndim;
     unsigned out_shape[MAX_ND];
@@ -318,8 +410,15 @@ struct PlanePermuteArgs {
 // single floats +-0 except (200, 33, 77, 41) 2.7 -> 3.3 (profiles/r04/layout_plane_tile_ab.log)
 constexpr unsigned kPlaneCap = 4096, kPlanePad = 512;
 
-__global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restrict__ in, float *__restrict__ out, PlanePermuteArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];
+// W = 4: the element is a whole number of float4s (E % 4 == 0: an NHWC-like layout with 8 channels) — everything in `p` is then
+// in float4 units and every access, global and LDS, is 128 bits wide.
+template <int W>
+__global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restrict__ in_f, float *__restrict__ out_f, PlanePermuteArgs p) {
+    typedef typename std::conditional<W == 4, v4f, float>::type T;
+    extern __shared__ __attribute__((aligned(16))) float tile_f[];
+    T *tile = (T *)tile_f;
+    const T *in = (const T *)in_f;
+    T *out = (T *)out_f;
     unsigned id = blockIdx.x;
     const unsigned tb_i = id % p.tiles_b;
     id /= p.tiles_b;
@@ -333,7 +432,7 @@ __global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restr
     // the first LDS store (one load -> store round trip per iteration left the kernel waiting on memory latency)
     constexpr int UNR = 8;
     for (unsigned base = threadIdx.x; base < total; base += 256 * UNR) {
-        float v[UNR];
+        T v[UNR];
         unsigned at[UNR];
         bool ok[UNR];
 #pragma unroll
@@ -343,7 +442,7 @@ __global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restr
             const unsigned b = p.E == 1 ? rem : __umulhi(rem, p.m_E);
             ok[u] = idx < total && a < na && b < nb;
             at[u] = a * p.pitch + rem;
-            v[u] = 0.0f;
+            v[u] = T{};
             if (ok[u]) v[u] = __builtin_nontemporal_load(in + off_in + (size_t)(a0 + a) * p.a_in + (size_t)b0 * p.E + rem);
         }
 #pragma unroll
@@ -353,7 +452,7 @@ __global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restr
     __syncthreads();
     // phase 2: (b, a, e) with (a, e) fastest — runs of na * E contiguous floats per b
     for (unsigned base = threadIdx.x; base < total; base += 256 * UNR) {
-        float v[UNR];
+        T v[UNR];
         size_t to[UNR];
         bool ok[UNR];
 #pragma unroll
@@ -363,7 +462,7 @@ __global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restr
             const unsigned a = p.E == 1 ? rem : __umulhi(rem, p.m_E), e = rem - a * p.E;
             ok[u] = idx < total && a < na && b < nb;
             to[u] = off_out + (size_t)(b0 + b) * p.b_out + (size_t)a0 * p.E + rem;
-            v[u] = ok[u] ? tile[a * p.pitch + b * p.E + e] : 0.0f;
+            v[u] = ok[u] ? tile[a * p.pitch + b * p.E + e] : T{};
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
@@ -430,13 +529,15 @@ int launch_transpose(const float *in, float *out, size_t batch, size_t rows, siz
     const dim3 grid((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch);
     constexpr size_t lds = (size_t)TC * (TR + 1) * sizeof(float);
     if (lds > 64 * 1024) {   // above the 64 KB default limit of dynamic LDS
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[64] = {false};   // per device: the attribute belongs to the device's copy of the kernel
+        int dev = 0;
+        NP_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
             NP_HIP_CHECK(hipFuncSetAttribute((const void *)transpose_tile_kernel<TR, TC, true>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             NP_HIP_CHECK(hipFuncSetAttribute((const void *)transpose_tile_kernel<TR, TC, false>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
     if (vec)
@@ -496,10 +597,12 @@ int transpose_planes(const float *in, float *out, size_t batch, size_t rows, siz
         const size_t tiles_x = (cols + 127) / 128, tiles_y = (rows + 31 + 127) / 128;
         if (tiles_x * tiles_y <= 0x7fffffffu) {
             constexpr size_t lds = (size_t)128 * 130 * sizeof(float);
-            static bool attr_set = false;
-            if (!attr_set) {
+            static bool attr_set[64] = {false};   // per device, as in launch_transpose
+            int dev = 0;
+            NP_HIP_CHECK(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !attr_set[dev]) {
                 NP_HIP_CHECK(hipFuncSetAttribute((const void *)transpose_walign_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
+                if (dev >= 0 && dev < 64) attr_set[dev] = true;
             }
             transpose_walign_kernel<128, 128><<<dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch), 256, lds, np::stream()>>>(
                 in, out, (unsigned)rows, (unsigned)cols, (unsigned)tiles_x, (unsigned)tiles_y, pb);
@@ -527,7 +630,12 @@ int np_transpose2d(const float *in, float *out, size_t batch, size_t rows, size_
     if (rows > 0x7fffffffu || cols > 0x7fffffffu || batch > 65535)
         return np::fail(NP_ERR_INVALID, "np_transpose2d: dimension too large");
     if (int rc = np::ensure_init()) return rc;
-    if ((rows <= 16 || cols <= 16) && g_tile == 0) {
+    // two to four long rows or columns: the float4 interleave (variant 5: off, the skinny kernel below as before round 5)
+    if (g_tile == 0 && aligned16(in) && aligned16(out)) {
+        if (rows >= 2 && rows <= 4 && cols % 4 == 0 && cols >= 1024) return launch_interleave<true>(in, out, batch, (unsigned)rows, cols);
+        if (cols >= 2 && cols <= 4 && rows % 4 == 0 && rows >= 1024) return launch_interleave<false>(in, out, batch, (unsigned)cols, rows);
+    }
+    if ((rows <= 16 || cols <= 16) && (g_tile == 0 || g_tile == 5)) {
         const bool tall = cols <= rows;
         const size_t n_long = tall ? rows : cols;
         size_t blocks = (n_long + 255) / 256;
@@ -642,11 +750,11 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
         unsigned E = 1;
         // (runs shorter than 32 floats; from 32 up the float4 gather has 128-byte runs of its own.  (64, 128, 1024, 8) with axes
         // 1, 2 swapped: gather 3.2 TB/s, plane kernel 5.5; (128, 128, 128, 16) (2, 1, 0, 3): 3.9 -> 5.5; profiles/r04/layout_sweep.log)
-        if (nd >= 3 && host_perm[nd - 1] == nd - 1 && host_shape[nd - 1] < 32 && g_tile == 0) {
+        if (nd >= 3 && host_perm[nd - 1] == nd - 1 && host_shape[nd - 1] < 32 && (g_tile == 0 || g_tile == 6)) {
             E = (unsigned)host_shape[nd - 1];
             --nd;   // the remaining axes permute elements of E floats; host_perm[0 .. nd) is a permutation of 0 .. nd - 1
         }
-        if (nd >= 2 && host_perm[nd - 1] != nd - 1 && g_tile == 0) {
+        if (nd >= 2 && host_perm[nd - 1] != nd - 1 && (g_tile == 0 || g_tile == 6)) {
             const int ax_a = host_perm[nd - 1], ax_b = nd - 1;   // input axes: A becomes output-fastest, B is input-fastest
             size_t out_strides[MAX_ND];   // output stride of each OUTPUT axis (floats)
             size_t t = 1;
@@ -684,8 +792,22 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
             // large planes of single floats: the float4 tile transpose of np_transpose2d, pitched (512-byte row segments)
             if (E == 1 && p.A >= 64 && p.B >= 64 && batch <= 65535)
                 return transpose_planes(in, out, batch, p.A, p.B, pb);
+            // elements that are whole float4s move as float4s (variant 6: off): every stride below is then a multiple of 4 floats
+            const bool w4 = E % 4 == 0 && aligned16(in) && aligned16(out) && g_tile != 6;
+            if (w4) {
+                E /= 4;
+                p.E = E;
+                p.a_in /= 4;
+                p.b_out /= 4;
+                for (unsigned d = 0; d < pb.nbatch; ++d) {
+                    pb.bin[d] /= 4;
+                    pb.bout[d] /= 4;
+                }
+                pb.in_pitch = p.a_in;
+                pb.out_pitch = p.b_out;
+            }
             // balanced tiles of at most 4096 floats, as square as the extents allow, runs of >= 64 floats where they can be
-            const unsigned cap = kPlaneCap;
+            const unsigned cap = w4 ? kPlaneCap / 4 : kPlaneCap, pad = w4 ? kPlanePad / 4 : kPlanePad;
             unsigned side = 64;
             while (side > 1 && (size_t)side * side * E > cap) --side;
             unsigned tb_max = p.B < side ? p.B : side;
@@ -700,8 +822,8 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
             // LDS row pitch: consecutive a (phase 2's lanes) must not share banks — odd for single floats, else
             // the run length past a multiple of 64 floats
             const unsigned row = p.tb * E;
-            p.pitch = E == 1 ? (row | 1u) : ((row + 63) / 64 * 64 + E);
-            unsigned ta_max = cap / row < (cap + kPlanePad) / p.pitch ? cap / row : (cap + kPlanePad) / p.pitch;
+            p.pitch = (E == 1 || w4) ? (row | 1u) : ((row + 63) / 64 * 64 + E);   // (float4 units: an odd pitch spreads 8 lanes over all banks)
+            unsigned ta_max = cap / row < (cap + pad) / p.pitch ? cap / row : (cap + pad) / p.pitch;
             if (ta_max > 256) ta_max = 256;
             if (ta_max > p.A) ta_max = p.A;
             if (ta_max < 1) ta_max = 1;
@@ -712,15 +834,12 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
             p.m_taE = magic(p.ta * E);
             p.m_E = magic(E);
             const size_t blocks = (size_t)p.tiles_a * p.tiles_b * batch;
-            if (blocks <= 0x7fffffffu && (size_t)p.ta * p.pitch <= cap + kPlanePad && p.tb * E > 1 && p.ta * E > 1) {
-                const size_t lds = ((size_t)p.ta * p.pitch + 3) / 4 * 4 * sizeof(float);
-                static bool attr_set = false;
-                if (!attr_set) {
-                    NP_HIP_CHECK(hipFuncSetAttribute((const void *)permute_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)((kPlaneCap + kPlanePad) * sizeof(float))));
-                    attr_set = true;
-                }
-                permute_plane_kernel<<<(unsigned)blocks, 256, lds, np::stream()>>>(in, out, p);
+            if (blocks <= 0x7fffffffu && (size_t)p.ta * p.pitch <= cap + pad && p.tb * E > 1 && p.ta * E > 1) {
+                const size_t lds = ((size_t)p.ta * p.pitch + 3) / 4 * 4 * sizeof(float) * (w4 ? 4 : 1);
+                if (w4)
+                    permute_plane_kernel<4><<<(unsigned)blocks, 256, lds, np::stream()>>>(in, out, p);
+                else
+                    permute_plane_kernel<1><<<(unsigned)blocks, 256, lds, np::stream()>>>(in, out, p);
                 NP_LAUNCH_CHECK("permute_plane_kernel");
                 return NP_OK;
             }

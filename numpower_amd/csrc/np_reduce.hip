@@ -229,7 +229,101 @@ __device__ __forceinline__ ArgPair arg_combine(ArgPair a, ArgPair b) {
     return arg_replace<IS_MAX>(a.v, a.i, b.v, b.i) ? b : a;
 }
 
-// One workgroup per (row, chunk): rows are contiguous (inner == 1).  partial index = row*chunks+chunk.
+// ---- the streaming forms (round 5) ----------------------------------------------------------------------------------
+// An ACCUMULATOR (one float4 component of one of the loads a lane keeps in flight) meets its elements in increasing index
+// order, so "the first occurrence wins" is a strict compare and an update is three VALU ops — compare, select the value,
+// select the trip counter (shared by the four components of a load: no per-element index arithmetic).  The general
+// (value, index) combine with its tie and NaN rules runs once per accumulator at the end.  NaN rules inside the loop:
+// argmax — a NaN never wins (`x > best` is false), which is its key -inf of arg_key(); a NaN in position 0 of the axis is
+// maximal and is patched in by whoever owns position 0.  argmin — the first NaN wins and then stays.
+constexpr unsigned kArgNone = 0xffffffffu;
+
+template <bool IS_MAX>
+__device__ __forceinline__ void arg_take(float &bv, unsigned &bt, float x, unsigned t) {
+    bool r;
+    if constexpr (IS_MAX) r = x > bv;
+    else r = !(bv <= x) && (bv == bv);
+    bv = r ? x : bv;
+    bt = r ? t : bt;
+}
+
+// what a single element is worth to the general combine when its position is not 0 (position 0: the caller)
+template <bool IS_MAX>
+__device__ __forceinline__ float arg_key_later(float x) {
+    if constexpr (IS_MAX) return (x != x) ? -INFINITY : x;
+    return x;
+}
+
+typedef v4f arg_v4f_u __attribute__((aligned(4)));   // a dwordx4 load from any dword-aligned address
+#define ARG_LOAD4(ptr) __builtin_nontemporal_load((const arg_v4f_u *)(ptr))
+
+// `count` contiguous elements at q, element e has index base + e along the reduced axis; the STRIDE threads of the caller
+// (a wave, or every thread of the workgroups that share a row: grid-stride, as reduce_all_pass1 walks; tid < STRIDE) share them.  Returns this thread's best (value, index), {identity, kArgNone} if it
+// met nothing.  Aligned float4 loads behind a scalar head, four loads in flight per lane.
+template <bool IS_MAX>
+__device__ __forceinline__ ArgPair arg_scan_contig(const float *__restrict__ q, unsigned count, unsigned base, unsigned tid,
+                                                   const unsigned STRIDE) {
+    const float id = IS_MAX ? -INFINITY : INFINITY;
+    unsigned head = (unsigned)(((16u - ((uintptr_t)q & 15u)) & 15u) >> 2);
+    if (head > count) head = count;
+    const float *qa = q + head;
+    const unsigned nvec = (count - head) >> 2;
+    float bv[4][4];
+    unsigned bt[4][4];
+    const bool main_runs = tid + 3 * STRIDE < nvec;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bv[s2][k] = id;
+            bt[s2][k] = s2 == 0 ? (tid < nvec ? tid : kArgNone) : (main_runs ? tid + s2 * STRIDE : kArgNone);
+        }
+    unsigned v = tid;
+    for (; v + 3 * STRIDE < nvec; v += 4 * STRIDE) {
+        const v4f x0 = __builtin_nontemporal_load((const v4f *)(qa + (size_t)v * 4));
+        const v4f x1 = __builtin_nontemporal_load((const v4f *)(qa + (size_t)(v + STRIDE) * 4));
+        const v4f x2 = __builtin_nontemporal_load((const v4f *)(qa + (size_t)(v + 2 * STRIDE) * 4));
+        const v4f x3 = __builtin_nontemporal_load((const v4f *)(qa + (size_t)(v + 3 * STRIDE) * 4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            arg_take<IS_MAX>(bv[0][k], bt[0][k], x0[k], v);
+            arg_take<IS_MAX>(bv[1][k], bt[1][k], x1[k], v + STRIDE);
+            arg_take<IS_MAX>(bv[2][k], bt[2][k], x2[k], v + 2 * STRIDE);
+            arg_take<IS_MAX>(bv[3][k], bt[3][k], x3[k], v + 3 * STRIDE);
+        }
+    }
+    for (; v < nvec; v += STRIDE) {
+        const v4f x0 = *(const v4f *)(qa + (size_t)v * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) arg_take<IS_MAX>(bv[0][k], bt[0][k], x0[k], v);
+    }
+    ArgPair best{id, kArgNone};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const ArgPair c{bv[s2][k], bt[s2][k] == kArgNone ? kArgNone : base + head + 4u * bt[s2][k] + (unsigned)k};
+            best = arg_combine<IS_MAX>(best, c);
+        }
+    if (tid < head) best = arg_combine<IS_MAX>(best, ArgPair{arg_key_later<IS_MAX>(q[tid]), base + tid});
+    const unsigned t = head + 4u * nvec + tid;
+    if (t < count) best = arg_combine<IS_MAX>(best, ArgPair{arg_key_later<IS_MAX>(q[t]), base + t});
+    return best;
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ ArgPair arg_wave_reduce(ArgPair best) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ArgPair o;
+        o.v = __shfl_down(best.v, off, 64);
+        o.i = __shfl_down(best.i, off, 64);
+        best = arg_combine<IS_MAX>(best, o);   // a lane without a candidate holds {identity, kArgNone}: it loses every tie
+    }
+    return best;
+}
+
+// `chunks` workgroups per contiguous row (inner == 1) walk it together, grid-stride; partial index = row*chunks+chunk.
 template <bool IS_MAX>
 __global__ __launch_bounds__(256) void argreduce_rows_kernel(const float *__restrict__ in, float *__restrict__ pv,
                                                              unsigned *__restrict__ pi, unsigned len,
@@ -237,50 +331,9 @@ __global__ __launch_bounds__(256) void argreduce_rows_kernel(const float *__rest
     __shared__ float sv[4];
     __shared__ unsigned si[4];
     const unsigned row = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
-    const unsigned per = (len + chunks - 1) / chunks;
-    const unsigned lo = chunk * per;
-    unsigned hi = lo + per;
-    if (hi > len) hi = len;
     const float *p = in + (size_t)row * len;
-    ArgPair best{IS_MAX ? -INFINITY : INFINITY, 0xffffffffu};
-    bool have = false;
-    auto take = [&](float x, unsigned i) {
-        const ArgPair c{arg_key<IS_MAX>(x, i), i};
-        if (!have) {
-            best = c;
-            have = true;
-        } else {
-            best = arg_combine<IS_MAX>(best, c);
-        }
-    };
-    // 4 consecutive elements per lane per trip (dword-aligned dwordx4 loads: rows start anywhere),
-    // two trips in flight; ties are broken by index, so the visiting order does not matter
-    struct __attribute__((packed, aligned(4))) U4 { v4f v; };
-    const unsigned nvec = (hi - lo) / 4;
-    unsigned v = threadIdx.x;
-    for (; v + blockDim.x < nvec; v += 2 * blockDim.x) {
-        const unsigned i0 = lo + 4 * v, i1 = lo + 4 * (v + blockDim.x);
-        const v4f x0 = ((const U4 *)(p + i0))->v, x1 = ((const U4 *)(p + i1))->v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) take(x0[k], i0 + k);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) take(x1[k], i1 + k);
-    }
-    for (; v < nvec; v += blockDim.x) {
-        const unsigned i0 = lo + 4 * v;
-        const v4f x0 = ((const U4 *)(p + i0))->v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) take(x0[k], i0 + k);
-    }
-    for (unsigned i = lo + 4 * nvec + threadIdx.x; i < hi; i += blockDim.x) take(p[i], i);
-    // lanes without a candidate carry index 0xffffffff and a neutral value: they lose every tie
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        ArgPair o;
-        o.v = __shfl_down(best.v, off, 64);
-        o.i = __shfl_down(best.i, off, 64);
-        if (o.i != 0xffffffffu) best = (best.i == 0xffffffffu) ? o : arg_combine<IS_MAX>(best, o);
-    }
+    ArgPair best = arg_scan_contig<IS_MAX>(p, len, 0u, chunk * 256u + threadIdx.x, chunks * 256u);
+    best = arg_wave_reduce<IS_MAX>(best);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
         sv[wave] = best.v;
@@ -289,12 +342,27 @@ __global__ __launch_bounds__(256) void argreduce_rows_kernel(const float *__rest
     __syncthreads();
     if (threadIdx.x == 0) {
         ArgPair r{sv[0], si[0]};
-        for (int w = 1; w < 4; ++w) {
-            const ArgPair o{sv[w], si[w]};
-            if (o.i != 0xffffffffu) r = (r.i == 0xffffffffu) ? o : arg_combine<IS_MAX>(r, o);
-        }
+        for (int w = 1; w < 4; ++w) r = arg_combine<IS_MAX>(r, ArgPair{sv[w], si[w]});
+        if (IS_MAX && chunk == 0 && p[0] != p[0]) r = ArgPair{INFINITY, 0u};   // a NaN in position 0 is maximal
         pv[blockIdx.x] = r.v;
         pi[blockIdx.x] = r.i;
+    }
+}
+
+// One WAVE per contiguous row (rows of a few hundred to a few thousand elements, many of them): every load of the row in
+// flight at once, folded with shuffles, no LDS, no partials, no second launch.
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void argreduce_rows_wave(const float *__restrict__ in, float *__restrict__ out,
+                                                           size_t rows, unsigned len) {
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const unsigned lane = threadIdx.x & 63;
+    const float *p = in + row * len;
+    ArgPair best = arg_scan_contig<IS_MAX>(p, len, 0u, lane, 64u);
+    best = arg_wave_reduce<IS_MAX>(best);
+    if (lane == 0) {
+        if (IS_MAX && p[0] != p[0]) best = ArgPair{INFINITY, 0u};
+        out[row] = (float)best.i;
     }
 }
 
@@ -829,11 +897,13 @@ int launch_reduce_all(const float *in, size_t n, float *dev_out) {
     if (head > n) head = n;
     const size_t nvec = (n - head) / 4;
     // enough workgroups to fill the chip (8 per CU), but never more than one per 4 KiB of input
-    const size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
+    size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
+    // (A/B, np_reduce_set_variant(3000000 + N): a few MB on N fat workgroups, so that one ticket and one fold load per thread do)
+    if (np::g_small_reduce_blocks && n <= (size_t(1) << 22) && blocks > np::g_small_reduce_blocks) blocks = np::g_small_reduce_blocks;
     np::Scratch partials;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
     // small grids: the last workgroup to finish folds the partials, no second launch (np_internal.h)
-    unsigned *ticket = blocks <= np::kFoldInKernelMaxBlocks ? np::next_ticket() : nullptr;
+    unsigned *ticket = np::fold_ticket(blocks);
     reduce_all_pass1<OP, I><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (I)n, (I)head, (I)nvec,
                                                            ticket, dev_out, (float)n);
     NP_LAUNCH_CHECK("reduce_all_pass1");
@@ -1114,7 +1184,7 @@ static int xform_sum(const float *in, const float *in2, size_t n, float p0, floa
     const size_t blocks = np::capped_grid(((vec ? nvec : n / 4) + 255) / 256, stream_cap());
     np::Scratch partials;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
-    unsigned *ticket = blocks <= np::kFoldInKernelMaxBlocks ? np::next_ticket() : nullptr;
+    unsigned *ticket = np::fold_ticket(blocks);
     if (vec)
         reduce_xform_pass1<XFORM, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, in2, (float *)partials.ptr, (uint32_t)n,
                                                                          (uint32_t)nvec, p0, p1, ticket, dev_out);
@@ -1128,43 +1198,246 @@ static int xform_sum(const float *in, const float *in2, size_t n, float p0, floa
     return NP_OK;
 }
 
-// argmax / argmin with a handful of columns and many rows (inner <= 64): slabs of rows read as flat
-// memory, as reduce_small_inner does — a thread's column never changes (stride T is a multiple of
-// inner), its row advances by T / inner per step.  Partials [outer][blocks][inner].
+// argmax / argmin with a handful of columns and many rows (inner <= 64): slabs of rows read as FLAT memory with float4
+// loads.  T = the largest multiple of `inner` threads that fits: a thread's vector v = t + j T starts at flat element
+// 4 t + 4 j T, and 4 j T is a whole number of rows — so component k of thread t stays in column (4 t + k) % inner for the whole
+// walk and its row advances by 4 T / inner per trip: four accumulators per load, each with a fixed column, the trip counter j
+// as their index.  Four loads in flight.  Partials [outer][blocks][inner].
 template <bool IS_MAX>
 __global__ __launch_bounds__(256) void argreduce_small_inner(const float *__restrict__ in, float *__restrict__ pv,
                                                              unsigned *__restrict__ pi, unsigned axis_len,
                                                              unsigned inner, unsigned rows_per_block) {
-    __shared__ float sv[256];
-    __shared__ unsigned si[256];
+    __shared__ float sv[1024];
+    __shared__ unsigned si[1024];
+    const float id = IS_MAX ? -INFINITY : INFINITY;
     const unsigned T = (256u / inner) * inner;
     const unsigned o = blockIdx.y, b = blockIdx.x;
     const unsigned r0 = b * rows_per_block;
     unsigned r1 = r0 + rows_per_block;
     if (r1 > axis_len) r1 = axis_len;
-    const size_t cnt = (size_t)(r1 - r0) * inner;
+    const unsigned cnt = (r1 - r0) * inner;          // the host keeps rows_per_block * inner below 2^31
+    const unsigned nvec = cnt >> 2;
     const float *p = in + ((size_t)o * axis_len + r0) * inner;
-    ArgPair best{IS_MAX ? -INFINITY : INFINITY, 0xffffffffu};
-    if (threadIdx.x < T) {
-        unsigned row = r0 + threadIdx.x / inner;
-        const unsigned row_step = T / inner;
-        for (size_t e = threadIdx.x; e < cnt; e += T, row += row_step) {
-            const ArgPair c{arg_key<IS_MAX>(p[e], row), row};
-            best = (best.i == 0xffffffffu) ? c : arg_combine<IS_MAX>(best, c);
+    const unsigned t = threadIdx.x;
+    if (t < T) {
+        float bv[4][4];
+        unsigned bj[4][4];
+        const bool main_runs = t + 3 * T < nvec;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bv[s2][k] = id;
+                bj[s2][k] = s2 == 0 ? (t < nvec ? 0u : kArgNone) : (main_runs ? (unsigned)s2 : kArgNone);
+            }
+        unsigned v = t, j = 0;
+        for (; v + 3 * T < nvec; v += 4 * T, j += 4) {
+            const v4f x0 = ARG_LOAD4(p + (size_t)v * 4), x1 = ARG_LOAD4(p + (size_t)(v + T) * 4);
+            const v4f x2 = ARG_LOAD4(p + (size_t)(v + 2 * T) * 4), x3 = ARG_LOAD4(p + (size_t)(v + 3 * T) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                arg_take<IS_MAX>(bv[0][k], bj[0][k], x0[k], j);
+                arg_take<IS_MAX>(bv[1][k], bj[1][k], x1[k], j + 1);
+                arg_take<IS_MAX>(bv[2][k], bj[2][k], x2[k], j + 2);
+                arg_take<IS_MAX>(bv[3][k], bj[3][k], x3[k], j + 3);
+            }
+        }
+        for (; v < nvec; v += T, ++j) {
+            const v4f x0 = ARG_LOAD4(p + (size_t)v * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) arg_take<IS_MAX>(bv[0][k], bj[0][k], x0[k], j);
+        }
+        const unsigned rows_per_trip = 4 * T / inner;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned row0 = r0 + (4 * t + k) / inner;
+            ArgPair best{id, kArgNone};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+                best = arg_combine<IS_MAX>(best, ArgPair{bv[s2][k], bj[s2][k] == kArgNone ? kArgNone : row0 + bj[s2][k] * rows_per_trip});
+            sv[4 * t + k] = best.v;
+            si[4 * t + k] = best.i;
         }
     }
-    sv[threadIdx.x] = best.v;
-    si[threadIdx.x] = best.i;
     __syncthreads();
-    if (threadIdx.x < inner) {
-        ArgPair r{sv[threadIdx.x], si[threadIdx.x]};
-        for (unsigned k = threadIdx.x + inner; k < T; k += inner) {
-            const ArgPair q{sv[k], si[k]};
-            if (q.i != 0xffffffffu) r = (r.i == 0xffffffffu) ? q : arg_combine<IS_MAX>(r, q);
+    // entry e' = m * inner + c (m < 4 T / inner) belongs to column c: halve the m range until one entry per column is left
+    // (a thread per column walking its 4 T / inner entries was 340 dependent steps for inner = 3: 16 % of the kernel)
+    for (unsigned mcur = 4 * T / inner; mcur > 1;) {
+        const unsigned half = (mcur + 1) / 2;
+        for (unsigned idx = t; idx < (mcur - half) * inner; idx += 256) {
+            const unsigned hi = idx + half * inner;
+            const ArgPair r = arg_combine<IS_MAX>(ArgPair{sv[idx], si[idx]}, ArgPair{sv[hi], si[hi]});
+            sv[idx] = r.v;
+            si[idx] = r.i;
         }
-        const size_t at = ((size_t)o * gridDim.x + b) * inner + threadIdx.x;
+        __syncthreads();
+        mcur = half;
+    }
+    if (t < inner) {
+        ArgPair r{sv[t], si[t]};
+        for (unsigned e = 4 * nvec; e < cnt; ++e)                                                       // the <= 3 leftover elements
+            if (e % inner == t) r = arg_combine<IS_MAX>(r, ArgPair{arg_key_later<IS_MAX>(p[e]), r0 + e / inner});
+        if (IS_MAX && r0 == 0 && p[t] != p[t]) r = ArgPair{INFINITY, 0u};   // a NaN in position 0 is maximal
+        const size_t at = ((size_t)o * gridDim.x + b) * inner + t;
         pv[at] = r.v;
         pi[at] = r.i;
+    }
+}
+
+// The same walk with a float4 COLUMN GROUP as the element, for inner % 4 == 0 and inner <= 256 (inner4 = inner / 4 groups per
+// row): T4 = the largest multiple of inner4 threads; thread t keeps group t % inner4, its row advances by T4 / inner4 per trip.
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void argreduce_small_inner4(const float *__restrict__ in, float *__restrict__ pv,
+                                                              unsigned *__restrict__ pi, unsigned axis_len,
+                                                              unsigned inner4, unsigned rows_per_block) {
+    __shared__ float sv[1024];
+    __shared__ unsigned si[1024];
+    const float id = IS_MAX ? -INFINITY : INFINITY;
+    const unsigned T = (256u / inner4) * inner4;
+    const unsigned o = blockIdx.y, b = blockIdx.x;
+    const unsigned r0 = b * rows_per_block;
+    unsigned r1 = r0 + rows_per_block;
+    if (r1 > axis_len) r1 = axis_len;
+    const unsigned nvec = (r1 - r0) * inner4;
+    const float *p = in + ((size_t)o * axis_len + r0) * inner4 * 4;
+    const unsigned t = threadIdx.x;
+    if (t < T) {
+        float bv[4][4];
+        unsigned bj[4][4];
+        const bool main_runs = t + 3 * T < nvec;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bv[s2][k] = id;
+                bj[s2][k] = s2 == 0 ? (t < nvec ? 0u : kArgNone) : (main_runs ? (unsigned)s2 : kArgNone);
+            }
+        unsigned v = t, j = 0;
+        for (; v + 3 * T < nvec; v += 4 * T, j += 4) {
+            const v4f x0 = ARG_LOAD4(p + (size_t)v * 4), x1 = ARG_LOAD4(p + (size_t)(v + T) * 4);
+            const v4f x2 = ARG_LOAD4(p + (size_t)(v + 2 * T) * 4), x3 = ARG_LOAD4(p + (size_t)(v + 3 * T) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                arg_take<IS_MAX>(bv[0][k], bj[0][k], x0[k], j);
+                arg_take<IS_MAX>(bv[1][k], bj[1][k], x1[k], j + 1);
+                arg_take<IS_MAX>(bv[2][k], bj[2][k], x2[k], j + 2);
+                arg_take<IS_MAX>(bv[3][k], bj[3][k], x3[k], j + 3);
+            }
+        }
+        for (; v < nvec; v += T, ++j) {
+            const v4f x0 = ARG_LOAD4(p + (size_t)v * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) arg_take<IS_MAX>(bv[0][k], bj[0][k], x0[k], j);
+        }
+        const unsigned rows_per_trip = T / inner4, row0 = r0 + t / inner4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ArgPair best{id, kArgNone};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+                best = arg_combine<IS_MAX>(best, ArgPair{bv[s2][k], bj[s2][k] == kArgNone ? kArgNone : row0 + bj[s2][k] * rows_per_trip});
+            sv[4 * t + k] = best.v;
+            si[4 * t + k] = best.i;
+        }
+    }
+    __syncthreads();
+    if (t < 4 * inner4) {                              // one thread per column: group t / 4, component t % 4
+        ArgPair r{id, kArgNone};
+        for (unsigned e = t; e < 4 * T; e += 4 * inner4) r = arg_combine<IS_MAX>(r, ArgPair{sv[e], si[e]});
+        if (IS_MAX && r0 == 0 && p[t] != p[t]) r = ArgPair{INFINITY, 0u};
+        const size_t at = ((size_t)o * gridDim.x + b) * (4 * inner4) + t;
+        pv[at] = r.v;
+        pi[at] = r.i;
+    }
+}
+
+// Wide inner (>= 192 columns or so): a workgroup owns 64 float4 column groups and one chunk of the axis; its four waves walk
+// interleaved rows (a wave-level load is one contiguous 1 KiB piece of a row), four rows in flight per lane, and meet in LDS.
+// Rows need not be 16-byte aligned (dwordx4 loads from dword-aligned addresses); the last group of a row with inner % 4 != 0
+// reads its 1-3 columns one by one.  FINAL: chunks == 1, the index goes straight to out[]; else partials [outer][chunks][inner].
+template <bool IS_MAX, bool FINAL>
+__global__ __launch_bounds__(256) void argreduce_cols_tile(const float *__restrict__ in, float *__restrict__ pv,
+                                                           unsigned *__restrict__ pi, float *__restrict__ out,
+                                                           unsigned axis_len, unsigned inner, unsigned chunk_len) {
+    __shared__ float sv[3][64][4];
+    __shared__ unsigned si[3][64][4];
+    const float id = IS_MAX ? -INFINITY : INFINITY;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned o = blockIdx.z, c = blockIdx.y, chunks = gridDim.y;
+    const unsigned col = (blockIdx.x * 64 + lane) * 4;
+    const unsigned ncol = col >= inner ? 0u : (inner - col >= 4 ? 4u : inner - col);   // columns this lane owns
+    const unsigned a0 = c * chunk_len;
+    unsigned a1 = a0 + chunk_len;
+    if (a1 > axis_len) a1 = axis_len;
+    const float *p = in + (size_t)o * axis_len * inner + col;
+    float bv[4] = {id, id, id, id};
+    unsigned ba[4];
+    const unsigned first = a0 + wave;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ba[k] = (first < a1 && (unsigned)k < ncol) ? first : kArgNone;
+    if (ncol == 4) {
+        unsigned a = first;
+        for (; a + 28 < a1; a += 32) {   // eight rows in flight per lane
+            v4f x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = ARG_LOAD4(p + (size_t)(a + 4 * u) * inner);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) arg_take<IS_MAX>(bv[k], ba[k], x[u][k], a + 4 * u);
+        }
+        for (; a + 12 < a1; a += 16) {
+            const v4f x0 = ARG_LOAD4(p + (size_t)a * inner), x1 = ARG_LOAD4(p + (size_t)(a + 4) * inner);
+            const v4f x2 = ARG_LOAD4(p + (size_t)(a + 8) * inner), x3 = ARG_LOAD4(p + (size_t)(a + 12) * inner);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                arg_take<IS_MAX>(bv[k], ba[k], x0[k], a);
+                arg_take<IS_MAX>(bv[k], ba[k], x1[k], a + 4);
+                arg_take<IS_MAX>(bv[k], ba[k], x2[k], a + 8);
+                arg_take<IS_MAX>(bv[k], ba[k], x3[k], a + 12);
+            }
+        }
+        for (; a < a1; a += 4) {
+            const v4f x0 = ARG_LOAD4(p + (size_t)a * inner);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) arg_take<IS_MAX>(bv[k], ba[k], x0[k], a);
+        }
+    } else if (ncol > 0) {
+        for (unsigned a = first; a < a1; a += 4)
+            for (unsigned k = 0; k < ncol; ++k) {
+                const float x = p[(size_t)a * inner + k];
+                // (k is not a compile-time index here: the four accumulators are selected by hand)
+                if (k == 0) arg_take<IS_MAX>(bv[0], ba[0], x, a);
+                else if (k == 1) arg_take<IS_MAX>(bv[1], ba[1], x, a);
+                else arg_take<IS_MAX>(bv[2], ba[2], x, a);
+            }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sv[wave - 1][lane][k] = bv[k];
+            si[wave - 1][lane][k] = ba[k];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((unsigned)k >= ncol) continue;
+            ArgPair r{bv[k], ba[k]};
+            for (int w = 0; w < 3; ++w) r = arg_combine<IS_MAX>(r, ArgPair{sv[w][lane][k], si[w][lane][k]});
+            if (IS_MAX && c == 0) {
+                const float x0 = p[k];
+                if (x0 != x0) r = ArgPair{INFINITY, 0u};                   // a NaN in position 0 is maximal
+            }
+            if (FINAL) {
+                out[(size_t)o * inner + col + k] = (float)r.i;
+            } else {
+                const size_t at = ((size_t)o * chunks + c) * inner + col + k;
+                pv[at] = r.v;
+                pi[at] = r.i;
+            }
+        }
     }
 }
 
@@ -1194,11 +1467,63 @@ __global__ __launch_bounds__(256) void argreduce_rows_group(const float *__restr
     if (l == 0 && row < rows) out[row] = (float)best.i;
 }
 
+// the same fold for WIDE inner (partials [outer][chunks][inner], inner >= 192: what argreduce_cols_tile leaves): a workgroup
+// per COLS columns, lanes along the columns first (rows of partials are read in contiguous pieces), its 256 / COLS phases over
+// interleaved chunks with four loads in flight, meeting in LDS.  (argreduce_fold_block_kernel reads one column's partials
+// `inner` floats apart: a cache line per element — with 768 chunks of 1024 columns that fold cost more than the pass it followed.)
+// COLS = 64, 16 or 4: the host takes the widest that still gives the fold 64 workgroups.
+template <bool IS_MAX, int COLS>
+__global__ __launch_bounds__(256) void argreduce_fold_cols_kernel(const float *__restrict__ pv, const unsigned *__restrict__ pi,
+                                                                  float *__restrict__ out, unsigned chunks, size_t inner) {
+    constexpr unsigned P = 256 / COLS;
+    __shared__ float sv[256];
+    __shared__ unsigned si[256];
+    const unsigned col = threadIdx.x % COLS, ph = threadIdx.x / COLS;
+    const size_t j = (size_t)blockIdx.x * COLS + col;
+    const size_t o = blockIdx.y;
+    ArgPair best{IS_MAX ? -INFINITY : INFINITY, kArgNone};
+    if (j < inner) {
+        const size_t base = o * chunks * inner + j;
+        unsigned c = ph;
+        for (; c + 3 * P < chunks; c += 4 * P) {
+            const ArgPair q0{pv[base + (size_t)c * inner], pi[base + (size_t)c * inner]};
+            const ArgPair q1{pv[base + (size_t)(c + P) * inner], pi[base + (size_t)(c + P) * inner]};
+            const ArgPair q2{pv[base + (size_t)(c + 2 * P) * inner], pi[base + (size_t)(c + 2 * P) * inner]};
+            const ArgPair q3{pv[base + (size_t)(c + 3 * P) * inner], pi[base + (size_t)(c + 3 * P) * inner]};
+            best = arg_combine<IS_MAX>(best, arg_combine<IS_MAX>(arg_combine<IS_MAX>(q0, q1), arg_combine<IS_MAX>(q2, q3)));
+        }
+        for (; c < chunks; c += P) best = arg_combine<IS_MAX>(best, ArgPair{pv[base + (size_t)c * inner], pi[base + (size_t)c * inner]});
+    }
+    sv[threadIdx.x] = best.v;
+    si[threadIdx.x] = best.i;
+    __syncthreads();
+    if (ph == 0 && j < inner) {
+        for (unsigned q = 1; q < P; ++q) best = arg_combine<IS_MAX>(best, ArgPair{sv[q * COLS + col], si[q * COLS + col]});
+        out[o * inner + j] = (float)best.i;
+    }
+}
+
 // fold [outer][chunks][inner] partials: thread per output for short chunk lists, workgroup per output
 // for long ones
 static int launch_arg_fold(int is_max, const float *pv, const unsigned *pi, float *out, size_t outputs,
                            size_t chunks, size_t inner) {
     hipStream_t s = np::stream();
+    if (inner >= 192 && chunks > 8 && outputs / inner <= 65535) {
+        const size_t outer = outputs / inner;
+        const int cols = ((inner + 63) / 64) * outer >= 64 ? 64 : (((inner + 15) / 16) * outer >= 64 ? 16 : 4);
+        const dim3 grid((unsigned)((inner + cols - 1) / cols), (unsigned)outer);
+#define NP_FOLDC(C_)                                                                                          \
+    do {                                                                                                      \
+        if (is_max) argreduce_fold_cols_kernel<true, C_><<<grid, 256, 0, s>>>(pv, pi, out, (unsigned)chunks, inner);  \
+        else argreduce_fold_cols_kernel<false, C_><<<grid, 256, 0, s>>>(pv, pi, out, (unsigned)chunks, inner);        \
+    } while (0)
+        if (cols == 64) NP_FOLDC(64);
+        else if (cols == 16) NP_FOLDC(16);
+        else NP_FOLDC(4);
+#undef NP_FOLDC
+        NP_LAUNCH_CHECK("argreduce_fold_cols_kernel");
+        return NP_OK;
+    }
     if (chunks > 64 && outputs <= 0x7fffffffu) {
         if (is_max)
             argreduce_fold_block_kernel<true><<<(unsigned)outputs, 256, 0, s>>>(pv, pi, out, (unsigned)chunks, inner);
@@ -1250,13 +1575,23 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
             return NP_OK;
         }
     }
+    if (inner == 1 && axis_len <= 32768 && outer >= (size_t)np::num_cus() * 16 && (outer + 3) / 4 <= 0x7fffffffu) {
+        // many rows of a few hundred to a few thousand elements: one wave per row, one launch, no partials
+        const unsigned grid = (unsigned)((outer + 3) / 4);
+        if (is_max)
+            argreduce_rows_wave<true><<<grid, 256, 0, s>>>(in, out, outer, (unsigned)axis_len);
+        else
+            argreduce_rows_wave<false><<<grid, 256, 0, s>>>(in, out, outer, (unsigned)axis_len);
+        NP_LAUNCH_CHECK("argreduce_rows_wave");
+        return NP_OK;
+    }
     if (inner == 1) {
         // contiguous rows: (row, chunk) workgroups + a fold over the chunks of each row
-        const size_t target = (size_t)np::num_cus() * 8;
+        const size_t target = np::capped_grid((size_t)np::num_cus() * 8 + 1, (size_t)np::num_cus() * 8);   // odd: np_internal.h
         size_t chunks = 1;
         if (outer < target) {
             chunks = (target + outer - 1) / outer;
-            const size_t max_chunks = (axis_len + 1023) / 1024;   // >= 1024 elements per chunk
+            const size_t max_chunks = (axis_len + 4095) / 4096;   // >= 4096 elements per chunk (four float4 per lane)
             if (chunks > max_chunks) chunks = max_chunks;
         }
         if (outer * chunks > 0x7fffffffull) return np::fail(NP_ERR_INVALID, "np_argreduce: too many rows");
@@ -1272,24 +1607,73 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
         return launch_arg_fold(is_max, (const float *)pv.ptr, (const unsigned *)pi.ptr, out, outer, chunks, 1);
     }
     const size_t total = outer * inner;
-    if (inner <= 64 && axis_len >= 512 && outer <= 65535 && total < (size_t)np::num_cus() * 8 * 64) {
+    // a few columns (inner <= 64, or whole float4 groups up to 256 columns), many rows: slabs of rows as flat memory
+    const bool groups4 = inner % 4 == 0 && inner <= 256;
+    if ((groups4 || inner <= 64) && axis_len * inner >= 4096 && outer <= 65535) {
         const size_t target_wg = (size_t)np::num_cus() * 8;
-        size_t blocks = target_wg / outer;
-        const size_t max_blocks = axis_len / 256;
+        size_t blocks = (target_wg + outer - 1) / outer;
+        const size_t min_rows = (4096 + inner - 1) / inner;              // a block walks >= 16 KiB
+        const size_t max_blocks = axis_len / min_rows > 0 ? axis_len / min_rows : 1;
         if (blocks > max_blocks) blocks = max_blocks;
         if (blocks < 1) blocks = 1;
-        const size_t rows_per_block = (axis_len + blocks - 1) / blocks;
-        blocks = (axis_len + rows_per_block - 1) / rows_per_block;
-        np::Scratch pv, pi;
-        if (int rc = pv.alloc(total * blocks * sizeof(float))) return rc;
-        if (int rc = pi.alloc(total * blocks * sizeof(unsigned))) return rc;
-        const dim3 grid((unsigned)blocks, (unsigned)outer);
-        if (is_max)
-            argreduce_small_inner<true><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)inner, (unsigned)rows_per_block);
-        else
-            argreduce_small_inner<false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)inner, (unsigned)rows_per_block);
-        NP_LAUNCH_CHECK("argreduce_small_inner");
-        return launch_arg_fold(is_max, (const float *)pv.ptr, (const unsigned *)pi.ptr, out, total, blocks, inner);
+        size_t rows_per_block = ((axis_len + blocks - 1) / blocks + 3) / 4 * 4;   // slabs start on a float4 boundary of the flat view
+        if (rows_per_block * inner < (size_t(1) << 31)) {
+            blocks = (axis_len + rows_per_block - 1) / rows_per_block;
+            np::Scratch pv, pi;
+            if (int rc = pv.alloc(total * blocks * sizeof(float))) return rc;
+            if (int rc = pi.alloc(total * blocks * sizeof(unsigned))) return rc;
+            const dim3 grid((unsigned)blocks, (unsigned)outer);
+            if (groups4) {
+                if (is_max)
+                    argreduce_small_inner4<true><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)(inner / 4), (unsigned)rows_per_block);
+                else
+                    argreduce_small_inner4<false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)(inner / 4), (unsigned)rows_per_block);
+            } else if (is_max) {
+                argreduce_small_inner<true><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)inner, (unsigned)rows_per_block);
+            } else {
+                argreduce_small_inner<false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, (unsigned)axis_len, (unsigned)inner, (unsigned)rows_per_block);
+            }
+            NP_LAUNCH_CHECK("argreduce_small_inner");
+            return launch_arg_fold(is_max, (const float *)pv.ptr, (const unsigned *)pi.ptr, out, total, blocks, inner);
+        }
+    }
+    // wide inner: 64 float4 column groups per workgroup, the axis cut into chunks like the column sum (choose_splits)
+    if (inner >= 192 && outer <= 65535 && axis_len >= 16) {
+        const size_t inner4 = (inner + 3) / 4;
+        const size_t tiles = (inner4 + 63) / 64;
+        // four workgroups per CU (the column SUM takes twelve, choose_splits: its partials are 4 bytes per column and chunk,
+        // these are 8 and are read back by a fold that has far fewer workgroups to do it with), chunks of >= 64 rows, an odd
+        // number of rows per chunk (np_internal.h: no power-of-two distances between the rows in flight)
+        size_t chunks = 1;
+        const size_t base_wg = tiles * outer, target_wg = (size_t)np::num_cus() * 4;
+        if (base_wg < target_wg) {
+            chunks = (target_wg + base_wg - 1) / base_wg;
+            const size_t max_chunks = axis_len / 64 > 0 ? axis_len / 64 : 1;
+            if (chunks > max_chunks) chunks = max_chunks;
+        }
+        size_t chunk_len = (axis_len + chunks - 1) / chunks;
+        if (chunks > 1 && chunk_len % 2 == 0) ++chunk_len;
+        chunks = (axis_len + chunk_len - 1) / chunk_len;
+        if (tiles <= 0x7fffffffu && chunks <= 65535) {
+            const dim3 grid((unsigned)tiles, (unsigned)chunks, (unsigned)outer);
+            if (chunks == 1) {
+                if (is_max)
+                    argreduce_cols_tile<true, true><<<grid, 256, 0, s>>>(in, nullptr, nullptr, out, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len);
+                else
+                    argreduce_cols_tile<false, true><<<grid, 256, 0, s>>>(in, nullptr, nullptr, out, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len);
+                NP_LAUNCH_CHECK("argreduce_cols_tile");
+                return NP_OK;
+            }
+            np::Scratch pv, pi;
+            if (int rc = pv.alloc(total * chunks * sizeof(float))) return rc;
+            if (int rc = pi.alloc(total * chunks * sizeof(unsigned))) return rc;
+            if (is_max)
+                argreduce_cols_tile<true, false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, nullptr, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len);
+            else
+                argreduce_cols_tile<false, false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, nullptr, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len);
+            NP_LAUNCH_CHECK("argreduce_cols_tile");
+            return launch_arg_fold(is_max, (const float *)pv.ptr, (const unsigned *)pi.ptr, out, total, chunks, inner);
+        }
     }
     // few outputs, long axis (argmax over the rows of an N x 3 array): one thread per output would
     // leave the chip idle — cut the axis into chunks, then fold the (value, index) partials
@@ -1399,7 +1783,7 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
     float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
     const uint32_t body_end = (uint32_t)np_avx_body_end(n);
-    unsigned *ticket = blocks <= np::kFoldInKernelMaxBlocks ? np::next_ticket() : nullptr;
+    unsigned *ticket = np::fold_ticket(blocks);
     if (flags & NP_QUIRK_AVX_BODY)
         all_pass1<true, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n, (uint32_t)head,
                                                                    (uint32_t)nvec, body_end, ticket, slot);
@@ -1417,6 +1801,14 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
 }
 
 int np_reduce_set_variant(int variant) {
+    if (variant >= 2000000 && variant < 2100000) {   // the largest first-pass grid that folds its partials in-kernel
+        np::g_fold_in_kernel_max = (size_t)(variant - 2000000);
+        return NP_OK;
+    }
+    if (variant >= 3000000 && variant < 3100000) {   // np_reduce_all of <= 4 M elements on at most N workgroups (0 = off)
+        np::g_small_reduce_blocks = (size_t)(variant - 3000000);
+        return NP_OK;
+    }
     if (variant < 0 || variant > 1000000) return np::fail(NP_ERR_INVALID, "np_reduce_set_variant: workgroups per CU out of range");
     g_wg_per_cu = variant;
     return NP_OK;

@@ -253,6 +253,24 @@ int check_device_error(const char *who) {
     if (!r.error_word) return NP_OK;
     const unsigned bits = __atomic_exchange_n(r.error_word, 0u, __ATOMIC_ACQ_REL);
     if (!bits) return NP_OK;
+    if (bits & kErrStreamK) {
+        // A GEMM workgroup that gave up waiting for its siblings leaves its ticket / its stream-K flag where it stood — shared
+        // rings that later launches assume are zero.  Behind everything already enqueued on the library stream,
+        // put both back to zero on every device this process has used: the error is reported once, but no later product may
+        // fold early or wrong because of it.
+        std::lock_guard<std::mutex> lk(r.mu);
+        int keep = 0;
+        (void)hipGetDevice(&keep);
+        for (int dv = 0; dv < kMaxDevices; ++dv) {
+            DeviceState &d = r.dev[dv];
+            if (!d.inited || !d.cur_stream || (!d.tickets && !d.streamk_flags)) continue;
+            if (hipSetDevice(dv) != hipSuccess) continue;
+            if (d.tickets) (void)hipMemsetAsync(d.tickets, 0, kTicketRing * sizeof(unsigned), d.cur_stream);
+            if (d.streamk_flags) (void)hipMemsetAsync(d.streamk_flags, 0, kStreamKFlagCount * sizeof(unsigned), d.cur_stream);
+        }
+        (void)hipSetDevice(keep);
+        (void)hipGetLastError();
+    }
     return fail(NP_ERR_DEVICE, "%s: a device-side wait gave up before this point (%s%s%s): results produced since the last "
                                "successful np_sync are incomplete and must be discarded", who,
                 bits & kErrCommWait ? "a stream-ordering wait of np_comm timed out" : "",
@@ -260,6 +278,8 @@ int check_device_error(const char *who) {
                 bits & kErrStreamK ? "a GEMM workgroup folding K-split partial tiles never saw its siblings' (stream-K / in-launch split-K)" : "");
 }
 
+size_t g_small_reduce_blocks = 128;   // np_internal.h
+size_t g_fold_in_kernel_max = 256;
 unsigned *next_ticket() { return next_tickets(1); }
 
 // `count` consecutive tickets (count <= kTicketRing / 4): a run that would cross the end of the ring starts over at slot 0

@@ -1634,8 +1634,8 @@ NDArray *NDArray_ShardedBatchedMatmul(NDArray *a, NDArray *b, int batch, int gat
         throw_error("Shape mismatch for matmul. cols(a) != rows(b)");
         return nullptr;
     }
-    if (gather_mode < 0) {
-        throw_error("gather mode must be 0 (keep sharded), 1 (gather) or a number of overlapped pieces");
+    if (gather_mode < NP_SHARD_OVERLAP) {
+        throw_error("gather mode must be 0 (keep sharded), 1 (gather), -1 (overlapped, piece count chosen by the library) or a number of overlapped pieces");
         return nullptr;
     }
     const int world = NDArray_CommWorld(), slab = a->dimensions[0];
@@ -1650,7 +1650,8 @@ NDArray *NDArray_ShardedBatchedMatmul(NDArray *a, NDArray *b, int batch, int gat
     NDArray *result = new_array(shape, 3, NDARRAY_DEVICE_GPU, false);   // every rank's window is written by its owner
     if (!result) return nullptr;
     if (!dev_ok(np_sgemm_strided_batched_allgather((size_t)slab, M, N, K, NDArray_FDATA(a), M * K, NDArray_FDATA(b), K * N,
-                                                   NDArray_FDATA(result), gather_mode == NP_SHARD_GATHER ? 1 : gather_mode,
+                                                   NDArray_FDATA(result),
+                                                   gather_mode == NP_SHARD_GATHER ? 1 : (gather_mode == NP_SHARD_OVERLAP ? 0 : gather_mode),
                                                    NP_GATHER_AUTO))) {
         NDArray_FREE(result);
         return nullptr;

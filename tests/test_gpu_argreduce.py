@@ -121,3 +121,45 @@ def test_argreduce_short_rows(cols, hip, oracle):
         got = (NDArray.argmax(g, 1) if is_max else NDArray.argmin(g, 1)).cpu().numpy()
         want = oracle.argreduce(x, 1, is_max)
         assert np.array_equal(np.asarray(got, np.float32), np.asarray(want, np.float32)), (cols, is_max)
+
+
+@pytest.mark.parametrize("shape,axis", [
+    ((4200, 1024), 1), ((4100, 1000), 1), ((4100, 1027), 1), ((4099, 300), 1), ((4100, 8195), 1),   # one wave per row
+    ((3, 1_000_001), 1), ((1, 5_000_003), 1), ((600, 40_001), 1),                                   # (row, chunk) workgroups
+    ((200_003, 3), 0), ((100_001, 7), 0), ((33_000, 63), 0), ((2, 50_001, 5), 1),                   # a few columns, flat float4 walk
+    ((50_001, 8), 0), ((30_001, 100), 0), ((7, 3001, 100), 1), ((9001, 256), 0), ((300, 77, 12), 1),  # whole float4 column groups
+    ((2000, 1003), 0), ((4096, 1024), 0), ((1500, 9973), 0), ((4000, 20, 201), 1), ((3, 700, 260), 1), ((5, 17, 193), 1),  # wide inner
+])
+def test_argreduce_streaming_forms(shape, axis, hip, oracle):
+    """Every streaming form of round 5 (per-component accumulators, strict compares inside a lane, the general tie / NaN
+    combine only across lanes): exact indices against the oracle with whole regions of ties, +-inf, NaNs in position 0 of
+    some rows / columns (maximal for argmax, first NaN for argmin) and NaNs elsewhere, ragged sizes off every vector width."""
+    from numpower_amd._lib import check, load
+    x = synth.uniform(shape, 53, -1.0, 1.0)
+    flat = x.reshape(-1)
+    flat[::7] = np.float32(0.75)
+    flat[3::11] = np.float32(-0.75)
+    flat[5::1013] = np.inf
+    flat[6::1511] = -np.inf
+    flat[flat.size // 2] = np.nan
+    flat[9::4099] = np.nan
+    xm = np.moveaxis(x, axis, 0)
+    xm[0, ...].reshape(-1)[::5] = np.nan               # position 0 of every fifth output is a NaN
+    outer = int(np.prod(shape[:axis], dtype=np.int64))
+    inner = int(np.prod(shape[axis + 1:], dtype=np.int64))
+    d = hip.DeviceArray.from_host(x)
+    out = hip.DeviceArray((outer * inner,))
+    for is_max in (True, False):
+        check(load().np_argreduce(1 if is_max else 0, d.ptr, outer, shape[axis], inner, out.ptr))
+        got = out.to_host()
+        want = np.asarray(oracle.argreduce(x, axis, is_max), np.float32).reshape(-1)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, (shape, axis, is_max, bad[:5], got[bad[:5]], want[bad[:5]])
+    # an all-equal and an all-(-inf) array: index 0 everywhere, whichever lane or chunk looked at what
+    for fill in (np.float32(0.25), np.float32(-np.inf), np.float32(np.inf)):
+        hip.fill(d, float(fill))
+        for is_max in (True, False):
+            check(load().np_argreduce(1 if is_max else 0, d.ptr, outer, shape[axis], inner, out.ptr))
+            assert not out.to_host().any(), (shape, axis, is_max, fill)
+    d.free()
+    out.free()

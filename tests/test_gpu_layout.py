@@ -106,3 +106,64 @@ def test_transpose2d_skinny_and_odd(rc, hip):
     x = synth.uniform(rc, 74, -1.0, 1.0)
     got = NDArray.transpose(NDArray.array(x).gpu()).cpu().numpy()
     assert got.shape == (rc[1], rc[0]) and (_bits(got) == _bits(np.ascontiguousarray(x.T))).all()
+
+
+@pytest.mark.parametrize("batch,planes,n", [(1, 3, 100_004), (5, 3, 4096), (30, 3, 64 * 65 * 4), (2, 2, 2048), (3, 4, 2052), (1, 2, 1_000_000),
+                                            (7, 4, 6148), (1, 3, 1024), (2, 3, 1028)])
+def test_interleave_few_planes_both_ways(batch, planes, n, hip):
+    """Two to four long rows / columns (NCHW <-> NHWC with C <= 4): the float4 interleave kernels of round 5, every tile
+    boundary (2048 positions), ragged last tiles, batches — bit for bit against numpy, and against the skinny kernel they
+    replace (np_layout_set_variant(5))."""
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    lib = load()
+    x = synth.uniform((batch, planes, n), 75, -1.0, 1.0)
+    dx = hip.DeviceArray.from_host(x)
+    dy, dz, dw = hip.DeviceArray((batch, n, planes)), hip.DeviceArray((batch, planes, n)), hip.DeviceArray((batch, n, planes))
+    check(lib.np_transpose2d(dx.ptr, dy.ptr, batch, planes, n))                 # planes -> interleaved
+    y = dy.to_host()
+    assert (_bits(y) == _bits(np.ascontiguousarray(x.transpose(0, 2, 1)))).all()
+    check(lib.np_transpose2d(dy.ptr, dz.ptr, batch, n, planes))                 # and back
+    assert (_bits(dz.to_host()) == _bits(x)).all()
+    try:
+        check(lib.np_layout_set_variant(5))
+        check(lib.np_transpose2d(dx.ptr, dw.ptr, batch, planes, n))
+    finally:
+        check(lib.np_layout_set_variant(0))
+    assert (_bits(dw.to_host()) == _bits(y)).all()
+    # a view that starts 4 bytes into the buffer is not float4-loadable: the same call must still be right (skinny kernel)
+    if n >= 8:
+        m = n - 4
+        sub = dx.view(1, (planes, m))
+        out = hip.DeviceArray((m, planes))
+        check(lib.np_transpose2d(sub.ptr, out.ptr, 1, planes, m))
+        want = x.reshape(-1)[1:1 + planes * m].reshape(planes, m).T
+        assert (_bits(out.to_host()) == _bits(np.ascontiguousarray(want))).all()
+        out.free()
+    for d in (dx, dy, dz, dw):
+        d.free()
+    del C
+
+
+@pytest.mark.parametrize("shape,axes", [((6, 40, 300, 8), (0, 2, 1, 3)), ((3, 33, 65, 4), (0, 2, 1, 3)), ((5, 17, 19, 12), (2, 1, 0, 3)),
+                                        ((2, 64, 64, 16), (2, 0, 1, 3)), ((4, 50, 70, 28), (0, 2, 1, 3)), ((7, 9, 100, 8), (1, 2, 0, 3))])
+def test_permute_float4_elements(shape, axes, hip):
+    """A kept innermost axis of 4, 8, 12 ... floats (NHWC-like): the plane permute moves whole float4s (round 5); against numpy
+    and against the single-float form of the same kernel (np_layout_set_variant(6)), bit for bit."""
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    lib = load()
+    x = synth.uniform(shape, 76, -1.0, 1.0)
+    want = np.ascontiguousarray(np.transpose(x, axes))
+    dx, dy = hip.DeviceArray.from_host(x), hip.DeviceArray(want.shape)
+    sh, pm = (C.c_int * 4)(*shape), (C.c_int * 4)(*axes)
+    for variant in (0, 6):
+        hip.fill(dy, float("nan"))
+        try:
+            check(lib.np_layout_set_variant(variant))
+            check(lib.np_permute(dx.ptr, dy.ptr, 4, sh, pm))
+        finally:
+            check(lib.np_layout_set_variant(0))
+        assert (_bits(dy.to_host()) == _bits(want)).all(), variant
+    dx.free()
+    dy.free()

@@ -1012,3 +1012,45 @@ def test_matmul_thin(mnk, hip, oracle):
     scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
     assert got.shape == (m, n)
     assert (np.abs(got - ref64) <= 1e-6 * np.maximum(scale, 1e-30)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [70_000, 300_001, 1_000_000, 4_100_003])
+def test_full_reduction_one_launch_is_bit_identical_to_two(n, hip):
+    """nd::sum() of up to 4 M elements (BASELINE config 1's 1000 x 1000) runs on at most 128 fat workgroups whose last one folds
+    the partials behind one ticket (np_internal.h) instead of a second launch: the same partials in the same order, so the value
+    is bit-identical to the two-launch form of the same grid (np_reduce_set_variant(2000000 + 0) brings that back), call
+    after call (the ticket must come back clean), and within 1e-6 of the sum the streaming grid of rounds 2-4 produces
+    (np_reduce_set_variant(3000000 + 0): a different grouping of the same fp32 additions)."""
+    import ctypes as C
+    from numpower_amd._lib import check, load, REDUCE_OPS
+    lib = load()
+    x = synth.uniform((n,), 77, 0.5, 1.5)
+    d = hip.DeviceArray.from_host(x)
+    v = C.c_float()
+    try:
+        for op in ("sum", "prod", "min", "max", "mean"):
+            vals = []
+            for variant in (2000000 + 0, 2000000 + 256, 2000000 + 0, 2000000 + 256):
+                check(lib.np_reduce_set_variant(variant))
+                for _ in range(3):
+                    check(lib.np_reduce_all(REDUCE_OPS[op], d.ptr, n, C.byref(v)))
+                    vals.append(np.float32(v.value).view(np.uint32))
+            assert len(set(int(b) for b in vals)) == 1, (op, n, vals)
+            fat = v.value
+            check(lib.np_reduce_set_variant(3000000 + 0))
+            check(lib.np_reduce_all(REDUCE_OPS[op], d.ptr, n, C.byref(v)))
+            check(lib.np_reduce_set_variant(3000000 + 128))
+            if op in ("min", "max"):
+                assert v.value == fat
+            elif op != "prod":
+                assert abs(v.value - fat) <= 1e-6 * abs(fat), (op, v.value, fat)
+        flag = C.c_int(-1)
+        for variant in (2000000 + 0, 2000000 + 256):
+            check(lib.np_reduce_set_variant(variant))
+            check(lib.np_count_mismatch(0, d.ptr, d.ptr, n, 0.0, 0.0, C.byref(flag)))
+            assert flag.value == 0
+    finally:
+        check(lib.np_reduce_set_variant(2000000 + 256))
+        check(lib.np_reduce_set_variant(3000000 + 128))
+        d.free()

@@ -181,3 +181,38 @@ def test_c_abi_exchange_plan_replicates_the_result(world, chunks):
         others = np.ones(total, dtype=bool)
         others[own] = False
         assert (written[r][others] == 1).all()
+
+
+def test_piece_count_model_is_pinned():
+    """np_sgemm_strided_batched_allgather(chunks = 0) asks the library's step model for the number of pieces
+    (np_comm.hip: model_pieces) — host arithmetic, reachable without a device through
+    np_comm_debug_model.  Pinned here: the choices for BASELINE config 5 at 2 / 4 / 8 ranks and the model's properties
+    (nothing to overlap on one rank; a transfer-bound step is never modelled slower in pieces than whole; tiny slabs stay
+    whole; a tie goes to fewer pieces)."""
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    lib = load()
+    pick, ms = C.c_int(0), (C.c_double * 5)()
+
+    def model(world, slab, m=1024, n=1024, k=1024, cus=256):
+        check(lib.np_comm_debug_model(world, slab, m, n, k, cus, C.byref(pick), ms))
+        return pick.value, list(ms)
+
+    assert model(1, 512)[0] == 1                                   # one rank: nothing travels
+    for world in (2, 4, 8):
+        k, t = model(world, 512 // world)
+        assert k in (2, 4, 8, 16)
+        whole = t[0]
+        best = min(t)
+        assert t[[1, 2, 4, 8, 16].index(k)] <= 1.02 * best         # within 2 % of the best modelled step ...
+        assert all(x > 1.02 * best for x in t[:[1, 2, 4, 8, 16].index(k)])   # ... and the smallest such count
+        assert best < whole                                        # overlapping is modelled to pay at config 5's sizes
+        # GEMM 2 * slab * 1024^3 / 130e12, transfer slab * 4 MiB / 153 GB/s: whole = their sum (+ the issue cost)
+        slab = 512 // world
+        assert abs(whole - (2.0 * slab * 1024 ** 3 / 130e12 * 1e3 + slab * 4 * 1024 ** 2 / 153e9 * 1e3 + 0.01)) < 1e-9
+    assert model(8, 64)[0] == 8                                    # config 5 on a node (the default bench.py's "overlapped_auto" leg runs)
+    assert model(8, 1)[0] == 1 and model(8, 1)[1][1] > 1e299      # a slab of one matrix cannot be cut
+    k_small, _ = model(8, 64, 16, 16, 16)                          # microscopic matrices: the per-piece issue cost decides
+    assert k_small == 1
+    with pytest.raises(Exception, match="bad arguments"):
+        check(lib.np_comm_debug_model(0, 64, 1024, 1024, 1024, 256, C.byref(pick), ms))

@@ -19,6 +19,7 @@ TAG=${2:-$RECIPE}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd "$R" || exit 1
+python tools/source_stamp.py --json > "$O/stamp.json"
 
 r_tests() {
     timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 > "$O/pytest_gpu.log"
@@ -48,7 +49,8 @@ r_profile() {
     head -16 "$O/bench_kernel_stats.csv" | cut -c1-200
     # the same kernels launched at the BASELINE sizes ONLY (bench.py also runs add / sum at 1000 x 1000 for config 1, which share
     # kernel names with the 1e8 launches and pull their average down): per-kernel averages that reproduce the bench fractions
-    (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$O/kt2" -o k --output-format csv -- python "$R/tools/prof_kernels.py" 20 > "$O/prof_kernels.log" 2>&1)
+    # ... each kept running for >= 250 ms, so the averages are those of warm kernels (tools/prof_kernels.py)
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/kt2" -o k --output-format csv -- python "$R/tools/prof_kernels.py" 20 250 > "$O/prof_kernels.log" 2>&1)
     cp "$O"/kt2/*kernel_stats.csv "$O/prof_kernels_stats.csv" 2>/dev/null
     head -20 "$O/prof_kernels_stats.csv" | cut -c1-200
 }
@@ -62,6 +64,21 @@ r_counters() {
     python tools/pmc_summary.py "$O"/fetch/*counter_collection.csv "$O"/write/*counter_collection.csv > "$O/pmc_summary.txt" 2>&1
     python tools/pmc_traffic.py "$O"/fetch/*counter_collection.csv "$O"/write/*counter_collection.csv "$O/pmc_traffic.json"
     python tools/gemm_pmc_json.py "$O/gemm_pmc.json" "$O"/p1/*counter_collection.csv "$O"/p2/*counter_collection.csv
+    # both carry the stamp of the sources they were measured on (tools/source_stamp.py; the same lease's kernel stats sit next to them)
+    python - "$O" <<'PY'
+import json, sys
+sys.path.insert(0, "tools")
+from source_stamp import stamp
+st = stamp()
+for name in ("pmc_traffic.json", "gemm_pmc.json"):
+    path = sys.argv[1] + "/" + name
+    try:
+        j = json.load(open(path))
+    except Exception as e:
+        print(name, "unreadable", e); continue
+    j["source_sha16"] = st["source_sha16"]
+    json.dump(j, open(path, "w"), indent=1)
+PY
     cat "$O/pmc_sq.txt" | cut -c1-260
 }
 r_sweeps() {

@@ -69,4 +69,5 @@ line("allclose ptr+4", run(lambda: check(lib.np_count_mismatch(1, big.ptr + 4, b
 line("reduce_all sum ptr+4", run(lambda: check(lib.np_reduce_all(0, big.ptr + 4, N, C.byref(mean)))), 4.0 * N)
 print("sgemv")
 for M, K in ((4096, 4096), (100_000, 1000), (1000, 100_000), (10, 10_000_000), (10_000_000, 10), (1, 100_000_000)):
-    line("sgemv %dx%d" % (M, K), run(lambda: check(lib.np_sgemv(M, K, big.ptr, big2.ptr, out.ptr))), 4.0 * M * K)
+    # bytes: the matrix, the vector (as long as a row: for 1 x 1e8 it weighs as much as the matrix) and the result
+    line("sgemv %dx%d" % (M, K), run(lambda: check(lib.np_sgemv(M, K, big.ptr, big2.ptr, out.ptr))), 4.0 * (M * K + K + M))

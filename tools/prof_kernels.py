@@ -1,14 +1,44 @@
-"""Profiling driver (dev tool): launches each headline kernel a few times at BASELINE sizes so
-that rocprofv3 (--kernel-trace --stats, or --pmc passes) sees clean per-kernel dispatches.
-Usage: python tools/prof_kernels.py [iters]"""
+"""Profiling driver (dev tool): launches each headline kernel at BASELINE sizes so that rocprofv3 (--kernel-trace --stats, or
+--pmc passes) sees clean per-kernel dispatches.
+Usage: python tools/prof_kernels.py [iters] [warm_ms]
+warm_ms > 0 (the kernel-trace pass: 250): each kernel keeps being launched, back to back, until warm_ms have passed — the
+per-kernel AVERAGE rocprofv3 reports is then that of a kernel running on a clock that has come up, the state bench.py's timed
+region measures (20 launches right after an upload average 7 % slower than the bench's ms_per_step).
+The PMC passes keep warm_ms = 0: counters do not depend on the clock and every dispatch is serialised there."""
 import sys
+import time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np
 from numpower_amd import device as D, synth
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+warm_s = (float(sys.argv[2]) if len(sys.argv) > 2 else 0.0) / 1e3
 D.init(0)
+
+
+class _Times:
+    """`for _ in range(iters)` that, with warm_ms, keeps going until the time is up (synchronising every 16 launches so that
+    the clock it reads is the device's, not the queue's)."""
+    def __init__(self, n):
+        self.n = n
+
+    def __iter__(self):
+        t0, k = time.perf_counter(), 0
+        while k < self.n or time.perf_counter() - t0 < warm_s:
+            yield k
+            k += 1
+            if warm_s and k % 16 == 0:
+                D.sync()
+
+
+_range = range
+
+
+def range(n):   # noqa: A001 — every `for _ in range(iters)` below becomes time-bounded
+    return _Times(n)
+
+
 n = 4096
 A = D.DeviceArray.from_host(synth.uniform((n, n), 3, -1, 1)); B = D.DeviceArray.from_host(synth.uniform((n, n), 4, -1, 1)); Cm = D.DeviceArray((n, n))
 for _ in range(iters): D.sgemm(A, B, out=Cm)
@@ -47,5 +77,13 @@ for _ in range(iters): D.reduce_axis("sum", X, 0, out=out)
 for _ in range(iters): D.reduce_axis("sum", X, 1, out=out1)
 XT = D.DeviceArray((4096, 65536))
 for _ in range(iters): check(lib.np_transpose2d(X.ptr, XT.ptr, 1, 65536, 4096))
+# SURVEY 8(f) rows 2 and 4 as bench.py's extras run them (round 5): argmax over the last axis of 65536 x 1024 (one wave per
+# row), argmax of 1e8 flat, variance's second pass, dot(matrix, vector) with ten long rows
+idx = D.DeviceArray((65536,))
+for _ in range(iters): check(lib.np_argreduce(1, X.ptr, 65536, 1024, 1, idx.ptr))
+for _ in range(iters): check(lib.np_argreduce(1, X.ptr, 1, 100_000_000, 1, idx.ptr))
+mean, m2 = C.c_float(), C.c_float()
+for _ in range(iters): check(lib.np_moments(X.ptr, 100_000_000, C.byref(mean), C.byref(m2)))
+for _ in range(iters): check(lib.np_sgemv(10, 10_000_000, X.ptr, XT.ptr, idx.ptr))
 D.sync()
 print("done")
