@@ -1644,6 +1644,55 @@ __global__ __launch_bounds__(256) void sgemv_chunks_kernel(const float *__restri
     if (threadIdx.x == 0) partial[(size_t)row * gridDim.x + chunk] = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
+// The same for 2 .. 16 long rows (dot(matrix, vector) with a 10 x 10^7 matrix): a workgroup per CHUNK takes every row of its
+// chunk, so the chunk of x is read once and stays in registers while the rows stream past it.  With a workgroup per (chunk,
+// row) each row's workgroups re-read x from memory — 10 x 10^7 moved 800 MB for 440 MB of operands (0.48 of the roofline,
+// BENCH r05 lease 4).  partial[row][chunk], folded by np_reduce_axis like the kernel above.
+__global__ __launch_bounds__(256) void sgemv_fewrows_chunks_kernel(const float *__restrict__ A, const float *__restrict__ x,
+                                                                   float *__restrict__ partial, unsigned M, unsigned N,
+                                                                   unsigned chunk_len) {
+    typedef v4f v4f_u __attribute__((aligned(4)));
+    __shared__ float lds[16][4];
+    const unsigned chunk = blockIdx.x;
+    const unsigned k0 = chunk * chunk_len;
+    const unsigned len = (N - k0 < chunk_len) ? N - k0 : chunk_len;
+    const float *xx = x + k0;
+    float acc[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc[m] = 0.0f;
+    const unsigned n4 = len / 4;
+    for (unsigned v = threadIdx.x; v < n4; v += 256) {
+        const v4f x0 = *(const v4f_u *)(xx + (size_t)v * 4);
+        v4f a[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if ((unsigned)m < M) a[m] = __builtin_nontemporal_load((const v4f_u *)(A + (size_t)m * N + k0 + (size_t)v * 4));
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if ((unsigned)m < M) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[m] = fmaf(a[m][k], x0[k], acc[m]);
+            }
+    }
+    for (unsigned k = n4 * 4 + threadIdx.x; k < len; k += 256) {
+        const float xk = xx[k];
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if ((unsigned)m < M) acc[m] = fmaf(A[(size_t)m * N + k0 + k], xk, acc[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        if ((unsigned)m < M) {
+            float r = acc[m];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+            if ((threadIdx.x & 63) == 0) lds[m][threadIdx.x >> 6] = r;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < M) partial[(size_t)threadIdx.x * gridDim.x + chunk] = (lds[threadIdx.x][0] + lds[threadIdx.x][1]) + (lds[threadIdx.x][2] + lds[threadIdx.x][3]);
+}
+
 // Many short rows (N <= 256, a 10^7 x 10 matrix): L lanes per row (L = 1 .. 32, a power of two) instead
 // of a whole wave, which would use 10 of its 64 lanes.  Lanes of a group read the row interleaved and
 // fold with xor-shuffles; neighbouring groups read neighbouring (contiguous) rows.
@@ -2221,6 +2270,12 @@ int g_variant = 0;
 // sgemm_dma_kernel<.., PRIO>: K-tiles per priority phase; np_sgemm_set_variant(-(100 + p)) sets it (p = 0: off).
 // 16: 145.4 -> 146.4 TFLOP/s at 4096^3 (tools/gemm_prio_ab.py, profiles/r02/gemm_prio_ab.log; 2...64 all within 0.3 %)
 unsigned g_prio_period = 16;
+// ... from this K up.  Below it the alternation is OFF (round 5): with few K-tiles the epilogue — 128 KiB of C per workgroup, stored
+// by all 512 of them at once — is a fifth of the kernel, and two workgroups of a CU that do NOT finish together overlap one's stores
+// with the other's MFMAs.  Same box, alternation on -> off (profiles/r05/gemm_thin_k_ab.log): 4096 x 4096 x 128 94.6 -> 108.9 TFLOP/s,
+// x 256 119.5 -> 124.9, 8192 x 8192 x 256 124.8 -> 133.5, K = 512 equal, K = 1024 139.5 -> 141.7, 4096^3 144.9 -> 145.3 (noise).
+// np_sgemm_set_variant(-(100 + p)) with p != 16 applies period p at every K (A/B); p = 16 restores this default.
+unsigned g_prio_min_k = 2048;
 unsigned long long *g_probe = nullptr;
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
@@ -2363,7 +2418,7 @@ int launch_cfg(int cfg, GemmArgs g, unsigned batch, bool vec) {
             sgemm_dma_kernel<true, false><<<grid, 256, 0, np::stream()>>>(g);
         else if (ktail)
             sgemm_dma_kernel<false, true><<<grid, 256, 0, np::stream()>>>(g);
-        else if (g_prio_period) {
+        else if (g_prio_period && g.K >= g_prio_min_k) {
             g.prio_period = g_prio_period;
             sgemm_dma_kernel<false, false, true><<<grid, 256, 0, np::stream()>>>(g);
         } else
@@ -3274,6 +3329,7 @@ int np_sgemm_set_variant(int variant) {
     }
     if (variant <= -100) {   // -(100 + p): priority alternation between co-resident workgroups, p K-tiles per phase (p = 0: off)
         g_prio_period = (unsigned)(-variant - 100);
+        g_prio_min_k = g_prio_period == 16 ? 2048u : 0u;
         return NP_OK;
     }
     if (variant < 0) {   // -1: whole-K plans only, -2: default planner, -3: default + forced operand padding, -4 / -5: stream-K always / never
@@ -3434,6 +3490,19 @@ int np_sgemv(size_t M, size_t N, const float *A, const float *x, float *y) {
             NP_LAUNCH_CHECK("sgemv_short_rows_kernel");
             return NP_OK;
         }
+    }
+    if (M >= 2 && M <= 16 && N >= 65536) {   // a few long rows: a workgroup per chunk of x takes all of them (x is read once)
+        size_t chunks = 2 * target;
+        const size_t max_chunks = N / 1024;
+        if (chunks > max_chunks) chunks = max_chunks;
+        const size_t chunk_len = ((N + chunks - 1) / chunks + 3) / 4 * 4;
+        chunks = (N + chunk_len - 1) / chunk_len;
+        np::Scratch partial;
+        if (int rc = partial.alloc(M * chunks * sizeof(float))) return rc;
+        sgemv_fewrows_chunks_kernel<<<(unsigned)chunks, 256, 0, np::stream()>>>(A, x, (float *)partial.ptr, (unsigned)M, (unsigned)N,
+                                                                              (unsigned)chunk_len);
+        NP_LAUNCH_CHECK("sgemv_fewrows_chunks_kernel");
+        return np_reduce_axis(NP_SUM, (const float *)partial.ptr, M, chunks, 1, y, 0);
     }
     if (M < 2 * target && N >= 16384 && M <= 65535) {   // one wave per row would leave most of the chip idle
         size_t chunks = (2 * target + M - 1) / M;

@@ -923,6 +923,8 @@ def test_axis_reduce_few_outputs_long_axis(shape, axis, hip, oracle):
 
 
 @pytest.mark.parametrize("mn", [(1, 3_000_001), (1, 65536), (10, 500_000), (7, 16385), (200_000, 10), (5000, 1), (4096, 33),
+                                # 2 .. 16 long rows: a workgroup per chunk of x takes all rows (sgemv_fewrows_chunks_kernel, round 5)
+                                (2, 1_000_003), (16, 300_001), (3, 65536), (13, 70_002), (17, 200_000),
                                 (300, 70_001), (50_000, 100), (20_000, 256), (20_000, 257), (100_000, 8), (100_000, 9),
                                 # LDS-staged slabs of short rows (M >= 262144, 4 <= N <= 63), incl. a ragged last slab and M * N % 4 != 0
                                 (300_000, 10), (262_144, 4), (262_145, 63), (400_003, 7), (1_000_000, 16), (270_001, 33)])
