@@ -935,6 +935,10 @@ def bench_config5_abi(dist: Dist, steps, rounds=5, own_comm_port=None, world1=Fa
         for chunks in (2, 4, 8):
             if chunks <= per:
                 forms["overlapped_%d" % chunks] = pipelined(chunks, 0)
+        model_pick = C.c_int(0)
+        check(lib.np_comm_debug_model(dist.n, per, n, n, n, 0, C.byref(model_pick), None))
+        if dist.n > 1:
+            forms["overlapped_auto"] = pipelined(0, 0)     # chunks = 0: the library's step model picks the piece count
         if full_batch:
             forms = {k: forms[k] for k in ("compute_only", "gathered", "two_stream", "overlapped_8")}
         j = ((dist.rank + 1) % dist.n) * per + per - 1  # one matrix of a PEER's slab, as each gathering form leaves it
@@ -958,6 +962,7 @@ def bench_config5_abi(dist: Dist, steps, rounds=5, own_comm_port=None, world1=Fa
 
         legs, parity = measure(forms)
         rep = _config5_report(dist, per, n, legs, slab_bytes, parity, "np_comm_* (RCCL behind the C ABI)", steps)
+        rep["model_piece_count"] = model_pick.value            # what chunks = 0 resolves to for this world / slab
         if world1 and not full_batch:
             rep["workload"] = ("64 x (1024x1024) fp32 batched matmul = ONE rank's slab of config 5 on a one-rank communicator: "
                                "nothing travels, the two-stream pipeline itself is what is measured")
@@ -965,7 +970,6 @@ def bench_config5_abi(dist: Dist, steps, rounds=5, own_comm_port=None, world1=Fa
             rep["workload"] = ("512 x (1024x1024) fp32 batched matmul = the WHOLE of config 5 on one GPU (one-rank communicator: "
                                "nothing travels)")
             # every matrix of the pipelined form against the plain launch, bit for bit, on the device
-            import ctypes as C
             ref = D.DeviceArray((total, n, n))
             check(lib.np_sgemm_strided_batched(per, n, n, n, A.ptr, n * n, B.ptr, n * n, ref.ptr, n * n))
             forms["overlapped_8"]()

@@ -241,7 +241,7 @@ def test_batched_matmul_512x1024_world1(hip, oracle):
     check(lib.np_comm_init(0, 1, ("tcp://127.0.0.1:%d" % port).encode()))
     try:
         bad = C.c_int(1)
-        for chunks, mode in ((1, 1), (8, 0), (1, 0), (8, 2)):        # the default form first, then the pipelined ones
+        for chunks, mode in ((0, 0), (1, 1), (8, 0), (8, 2)):        # the library's own choice first (chunks = 0), then forced forms
             D.fill(over, float("nan"))
             check(lib.np_sgemm_strided_batched_allgather(total, n, n, n, A.ptr, item, B.ptr, item, over.ptr, chunks, mode))
             check(lib.np_count_mismatch(0, over.ptr, plain.ptr, total * item, 0.0, 0.0, C.byref(bad)))   # NP_MISMATCH_EXACT

@@ -139,6 +139,44 @@ def test_fuzz_permute_and_concatenate(hip):
         assert (_bits(got) == _bits(np.concatenate([x, y, x], axis))).all(), (shape, axis)
 
 
+def test_fuzz_argreduce(hip, oracle):
+    """np_argreduce over random (outer, axis, inner) views — every streaming form of round 5 is picked by shape (one wave per row,
+    grid-stride rows, flat float4 walks for a few columns / whole float4 column groups, column tiles with the coalesced fold, the
+    lane-group and generic kernels) — with ties, +-inf and NaNs thrown in, position 0 included: exact indices against the oracle."""
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    lib = load()
+    rng = np.random.default_rng(61 + SEED)
+    inners = [1, 1, 1, 2, 3, 4, 5, 8, 12, 16, 63, 64, 100, 128, 191, 192, 193, 256, 257, 1000, 1024, 4099]
+    for case in range(CASES):
+        inner = int(rng.choice(inners))
+        outer, length = _shape(rng, 2, max(2, 4_000_000 // inner))
+        if rng.integers(0, 3) == 0:
+            outer, length = 1, outer * length              # one long axis
+        length = max(length, 1)
+        shape = (outer, length, inner)
+        x = synth.uniform(shape, 15000 + case + 100_000 * SEED, -1.0, 1.0)
+        flat = x.reshape(-1)
+        if rng.integers(0, 2):
+            flat[::int(rng.choice([3, 7, 64]))] = np.float32(rng.choice([0.75, -0.75, 0.0]))      # runs of exact ties
+        for v, step in ((np.inf, 1013), (-np.inf, 1511), (np.nan, 4099)):
+            if rng.integers(0, 2):
+                flat[int(rng.integers(0, flat.size))::step] = v
+        if rng.integers(0, 2):
+            x[:, 0, :].reshape(-1)[::int(rng.choice([1, 2, 5]))] = np.nan                         # NaNs in position 0 of the axis
+        d = hip.DeviceArray.from_host(x)
+        out = hip.DeviceArray((outer * inner,))
+        for is_max in (True, False):
+            check(lib.np_argreduce(1 if is_max else 0, d.ptr, outer, length, inner, out.ptr))
+            got = out.to_host()
+            want = np.asarray(oracle.argreduce(x, 1, is_max), np.float32).reshape(-1)
+            bad = np.flatnonzero(got != want)
+            assert bad.size == 0, (shape, is_max, case, bad[:5].tolist(), got[bad[:5]].tolist(), want[bad[:5]].tolist())
+        d.free()
+        out.free()
+    del C
+
+
 def test_fuzz_order_statistics(hip, oracle):
     nd = _nd()
     rng = np.random.default_rng(11 + SEED)

@@ -87,6 +87,9 @@ r_sweeps() {
     timeout 300 python tools/misc_sweep.py > "$O/misc_sweep.log" 2>&1
     timeout 200 python tools/layout_sweep.py > "$O/layout_sweep.log" 2>&1; cat "$O/layout_sweep.log"
     timeout 200 python tools/fused_static_ab.py 2 > "$O/fused_static_ab.log" 2>&1; tail -14 "$O/fused_static_ab.log"
+    timeout 200 python tools/arg_sweep.py > "$O/arg_sweep.log" 2>&1; cat "$O/arg_sweep.log"
+    timeout 200 python tools/gemm_thin_k_ab.py > "$O/gemm_thin_k_ab.log" 2>&1; cat "$O/gemm_thin_k_ab.log"
+    timeout 200 python tools/reduce_small_ab.py > "$O/reduce_small_ab.log" 2>&1; cut -c1-300 "$O/reduce_small_ab.log"
 }
 
 r_cleanbuild() {
