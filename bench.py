@@ -1214,6 +1214,15 @@ def main():
     if traffic:
         result["roofline"]["traffic"] = traffic.get("sgemm_dma_kernel", {}).get("hbm_bytes")
         result["roofline"]["traffic_source"] = src
+        # the counters were taken by rocprofv3 in their own passes (they cannot be read in-process): say whether the committed
+        # file was measured on THESE kernel sources (tools/source_stamp.py; stamped by tools/gpu_lease.sh since round 5)
+        try:
+            sys.path.insert(0, str(ROOT / "tools"))
+            from source_stamp import stamp
+            result["roofline"]["traffic_kernel_sha16"] = traffic.get("kernel_sha16")
+            result["roofline"]["traffic_measured_on_these_kernels"] = bool(traffic.get("kernel_sha16") == stamp()["kernel_sha16"])
+        except Exception:
+            pass
         for key, entry in extras.items():
             if isinstance(entry, dict) and key in traffic and "roofline" in entry:
                 entry["roofline"]["traffic"] = traffic[key].get("hbm_bytes")

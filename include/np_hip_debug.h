@@ -84,6 +84,12 @@ int np_select_last_path(int *path);       /* tests / tools: 1 if the last select
 int np_reduce_set_variant(int variant);   /* streaming reductions, first pass: workgroups per CU (0 = default) */
 /* tools: the shader clock in MHz a ~20 us probe kernel sees on the library stream right now (synchronises the stream) */
 int np_debug_clock_mhz(float *host_mhz);
+/* tools: host_out2[2 w] = HW_REG_HW_ID, host_out2[2 w + 1] = HW_REG_XCC_ID of workgroup w of a `workgroups`-wide launch of one-wave
+ * workgroups on the library stream (each spins ~10 us first): where a (CU-masked) stream's work lands (tools/cu_mask_probe.py) */
+int np_debug_hw_ids(unsigned *host_out2, size_t workgroups);
+/* tools: the CU count every planner (GEMM tiles / stream-K, streaming grids) assumes from now on; 0 = the device's own.  For a CU-masked
+ * library stream (np_set_stream): a product planned for 256 CUs runs a partial extra round of workgroups on 248.  Process-global. */
+int np_debug_set_cus(int cus);
 /* testing: a one-lane kernel on the library stream raises `bits` in the process's device-error word — what a device-side wait
  * that gives up does (1 = a stream-ordering wait of np_comm, 2 = a stream-K finisher).  The next np_sync / np_memcpy_d2h /
  * host-result call / np_comm_* call returns NP_ERR_DEVICE once, and clears the word. */

@@ -91,6 +91,8 @@ PROTOTYPES = {
     "np_comm_wait": (C.c_int, []),
     "np_comm_set_variant": (C.c_int, [C.c_int]),
     "np_comm_set_wait_limit": (C.c_int, [C.c_double]),
+    "np_debug_hw_ids": (C.c_int, [C.POINTER(C.c_uint), C.c_size_t]),
+    "np_debug_set_cus": (C.c_int, [C.c_int]),
     "np_comm_debug_model": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "np_comm_sync_mode": (C.c_int, []),
     "np_comm_piece": (C.c_int, [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

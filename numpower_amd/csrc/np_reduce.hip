@@ -135,6 +135,18 @@ __global__ __launch_bounds__(256) void reduce_xform_pass1(const float *__restric
     __shared__ float lds4[4];
     const I stride = (I)gridDim.x * blockDim.x;
     const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    // XFORM 1 with in2 set: in2[0] is the SUM the pass before this one left in device-visible memory, p1 the element count — the
+    // mean is formed here (the same IEEE division the host would do) and np_moments needs no host round trip between its passes
+    // (ONE lane per workgroup reads it — the slot is pinned host memory, a read is a trip over the host link: every thread
+    // reading it for itself made the pass seven times slower, BENCH lease 7 of round 5)
+    if constexpr (XFORM == 1) {
+        if (in2) {
+            __shared__ float s_mean;
+            if (threadIdx.x == 0) s_mean = __fdiv_rn(__hip_atomic_load(in2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), p1);
+            __syncthreads();
+            p0 = s_mean;
+        }
+    }
     v4f acc0{0, 0, 0, 0}, acc1 = acc0;
     auto xf = [&](float x, float y) -> float { return xform_term<XFORM>(x, y, p0, p1); };
     I v = tid;
@@ -1714,15 +1726,15 @@ int np_moments(const float *in, size_t n, float *host_mean, float *host_m2) {
     if (!host_mean || !host_m2) return np::fail(NP_ERR_INVALID, "np_moments: null output");
     if (n == 0 || !in) return np::fail(NP_ERR_INVALID, "np_moments: empty input");
     if (int rc = np::ensure_init()) return rc;
-    float sum = 0.0f;
-    if (int rc = np_reduce_all(NP_SUM, in, n, &sum)) return rc;
-    const float mean = sum / (float)n;   // NDArray_Sum_Float(a) / NDArray_NUMELEMENTS(a), statistics.c:95,119
-    np::ResultCall call;
+    // both passes behind ONE host wait (round 5): the sum goes to result slot 1, the second pass reads it from there and forms
+    // the mean itself — sum / (float) n, the division NDArray_Sum_Float(a) / NDArray_NUMELEMENTS(a) is (statistics.c:95,119)
+    np::ResultCall call(2);
     float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
-    if (int rc = xform_sum<1>(in, nullptr, n, mean, 0.0f, slot)) return rc;
+    if (int rc = np_reduce_all_dev(NP_SUM, in, n, slot + 1)) return rc;
+    if (int rc = xform_sum<1>(in, slot + 1, n, 0.0f, (float)n, slot)) return rc;
     if (int rc = call.wait()) return rc;
-    *host_mean = mean;
+    *host_mean = slot[1] / (float)n;
     *host_m2 = slot[0];
     return NP_OK;
 }

@@ -122,7 +122,8 @@ int fail(int code, const char *fmt, ...) {
 }
 
 hipStream_t stream() { return rt().cur().cur_stream; }
-int num_cus() { return rt().cur().cus; }
+int g_cus_override = 0;   // np_debug_set_cus: what the planners take for the CU count (a CU-masked library stream reaches fewer)
+int num_cus() { return g_cus_override > 0 ? g_cus_override : rt().cur().cus; }
 
 // Entry-point guard.  First use: bind the library to the calling thread's CURRENT HIP device (whatever
 // the caller — PHP's setDevice, torch.cuda.set_device — selected; device 0 only if nothing did).  Later:
@@ -453,6 +454,37 @@ int np_debug_clock_mhz(float *host_mhz) {
     NP_HIP_CHECK(hipMemcpyAsync(h, buf.ptr, sizeof(h), hipMemcpyDeviceToHost, np::stream()));
     NP_HIP_CHECK(hipStreamSynchronize(np::stream()));
     *host_mhz = h[1] ? (float)((double)h[0] / ((double)h[1] / 100.0)) : 0.0f;
+    return NP_OK;
+}
+
+// tools: where the workgroups of a launch on the library stream land — HW_REG_HW_ID (wave / simd / cu / sh / se ids) and
+// HW_REG_XCC_ID of each workgroup's first wave, after ~10 us of spinning so that a whole grid is resident at once.  With the library
+// stream swapped for a CU-masked one (np_set_stream) this is how the mask's bit <-> (XCD, SE, CU) mapping is read off the
+// hardware (tools/cu_mask_probe.py).
+__global__ void hw_id_kernel(unsigned *out, unsigned long long spin_ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       // HW_ID, all 32 bits
+        out[2 * blockIdx.x + 1] = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));  // XCC_ID
+    }
+}
+
+int np_debug_set_cus(int cus) {
+    if (cus < 0 || cus > 4096) return np::fail(NP_ERR_INVALID, "np_debug_set_cus: %d", cus);
+    np::g_cus_override = cus;
+    return NP_OK;
+}
+
+int np_debug_hw_ids(unsigned *host_out2, size_t workgroups) {
+    if (!host_out2 || workgroups == 0 || workgroups > 65536) return np::fail(NP_ERR_INVALID, "np_debug_hw_ids: bad arguments");
+    if (int rc = np::ensure_init()) return rc;
+    np::Scratch buf;
+    if (int rc = buf.alloc(2 * workgroups * sizeof(unsigned))) return rc;
+    hw_id_kernel<<<(unsigned)workgroups, 64, 0, np::stream()>>>((unsigned *)buf.ptr, 1000ull);
+    NP_LAUNCH_CHECK("hw_id_kernel");
+    NP_HIP_CHECK(hipMemcpyAsync(host_out2, buf.ptr, 2 * workgroups * sizeof(unsigned), hipMemcpyDeviceToHost, np::stream()));
+    NP_HIP_CHECK(hipStreamSynchronize(np::stream()));
     return NP_OK;
 }
 

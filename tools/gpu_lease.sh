@@ -76,7 +76,7 @@ for name in ("pmc_traffic.json", "gemm_pmc.json"):
         j = json.load(open(path))
     except Exception as e:
         print(name, "unreadable", e); continue
-    j["source_sha16"] = st["source_sha16"]
+    j["source_sha16"], j["kernel_sha16"] = st["source_sha16"], st["kernel_sha16"]
     json.dump(j, open(path, "w"), indent=1)
 PY
     cat "$O/pmc_sq.txt" | cut -c1-260

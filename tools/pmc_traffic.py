@@ -19,6 +19,10 @@ KEYS = [  # bench key, substring(s) identifying the kernel
     ("sum_exp_axis0_fused", ["cchain_cols_kernel", "fused_chain_cols_kernel"]),
     ("sum_exp_axis1_fused", ["cchain_rows_kernel", "fused_chain_rows_kernel"]),
     ("transpose_65536x4096", ["transpose_tile_kernel"]),
+    ("argmax_1e8", ["argreduce_rows_kernel<true"]),
+    ("argmax_axis1_65536x1024", ["argreduce_rows_wave<true"]),
+    ("sgemv_10x1e7", ["sgemv_fewrows_chunks_kernel"]),
+    ("moments_second_pass_1e8", ["reduce_xform_pass1<1"]),
 ]
 
 
@@ -38,10 +42,10 @@ def pick(table, pats):
 
 
 fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
-out = {"_note": __doc__.split("Usage")[0].strip()}
+out = {"_note": __doc__.split("Usage")[0].strip() + "  (the non-kernel keys: _note, and source_sha16 / kernel_sha16 written by tools/gpu_lease.sh)"}
 for key, pats in KEYS:
     f, w = pick(fetch, pats), pick(write, pats)
     if f is not None and w is not None:
         out[key] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes": (2 * f + w) * 1024}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: round(v["hbm_bytes"] / 1e6) for k, v in out.items() if k != "_note"}))
+print(json.dumps({k: round(v["hbm_bytes"] / 1e6) for k, v in out.items() if isinstance(v, dict)}))
