@@ -92,8 +92,20 @@ template <int OP>
 __global__ __launch_bounds__(256) void reduce_all_pass2(const float *__restrict__ partials, int np,
                                                         float *__restrict__ out, float count) {
     __shared__ float lds4[4];
+    // thread t folds partials t, t + 256, ... in that order; eight loads are in flight before the first is used (one load -> add
+    // round trip per iteration was ~6 us for the 2049 partials of a 10^8-element reduction); lanes past the end fold the identity,
+    // which changes no bit (x + 0, x * 1, min(x, +inf), max(x, -inf))
     float r = r_identity<OP>();
-    for (int i = threadIdx.x; i < np; i += blockDim.x) r = r_combine<OP>(r, partials[i]);
+    for (int base = 0; base < np; base += 8 * (int)blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
+            v[u] = i < np ? partials[i] : r_identity<OP>();
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r = r_combine<OP>(r, v[u]);
+    }
     r = block_reduce<OP>(r, lds4);
     if (threadIdx.x == 0) {
         if constexpr (OP == NP_MEAN) r = __fdiv_rn(r, count);
@@ -135,18 +147,6 @@ __global__ __launch_bounds__(256) void reduce_xform_pass1(const float *__restric
     __shared__ float lds4[4];
     const I stride = (I)gridDim.x * blockDim.x;
     const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
-    // XFORM 1 with in2 set: in2[0] is the SUM the pass before this one left in device-visible memory, p1 the element count — the
-    // mean is formed here (the same IEEE division the host would do) and np_moments needs no host round trip between its passes
-    // (ONE lane per workgroup reads it — the slot is pinned host memory, a read is a trip over the host link: every thread
-    // reading it for itself made the pass seven times slower, BENCH lease 7 of round 5)
-    if constexpr (XFORM == 1) {
-        if (in2) {
-            __shared__ float s_mean;
-            if (threadIdx.x == 0) s_mean = __fdiv_rn(__hip_atomic_load(in2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), p1);
-            __syncthreads();
-            p0 = s_mean;
-        }
-    }
     v4f acc0{0, 0, 0, 0}, acc1 = acc0;
     auto xf = [&](float x, float y) -> float { return xform_term<XFORM>(x, y, p0, p1); };
     I v = tid;
@@ -410,9 +410,16 @@ __global__ __launch_bounds__(256) void argreduce_fold_block_kernel(const float *
     const size_t o = idx / inner, j = idx - o * inner;
     const size_t base = o * chunks * inner + j;
     ArgPair best{IS_MAX ? -INFINITY : INFINITY, 0xffffffffu};
-    for (unsigned c = threadIdx.x; c < chunks; c += blockDim.x) {
-        const ArgPair q{pv[base + (size_t)c * inner], pi[base + (size_t)c * inner]};
-        if (q.i != 0xffffffffu) best = (best.i == 0xffffffffu) ? q : arg_combine<IS_MAX>(best, q);
+    for (unsigned cb = 0; cb < chunks; cb += 8 * blockDim.x) {   // eight (value, index) loads in flight per lane
+        ArgPair q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned c = cb + u * blockDim.x + threadIdx.x;
+            q[u] = c < chunks ? ArgPair{pv[base + (size_t)c * inner], pi[base + (size_t)c * inner]} : ArgPair{best.v, 0xffffffffu};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (q[u].i != 0xffffffffu) best = (best.i == 0xffffffffu) ? q[u] : arg_combine<IS_MAX>(best, q[u]);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1726,15 +1733,18 @@ int np_moments(const float *in, size_t n, float *host_mean, float *host_m2) {
     if (!host_mean || !host_m2) return np::fail(NP_ERR_INVALID, "np_moments: null output");
     if (n == 0 || !in) return np::fail(NP_ERR_INVALID, "np_moments: empty input");
     if (int rc = np::ensure_init()) return rc;
-    // both passes behind ONE host wait (round 5): the sum goes to result slot 1, the second pass reads it from there and forms
-    // the mean itself — sum / (float) n, the division NDArray_Sum_Float(a) / NDArray_NUMELEMENTS(a) is (statistics.c:95,119)
-    np::ResultCall call(2);
+    // (Round 5 tried both passes behind ONE host wait — the sum left in a pinned result slot, the second pass forming the mean
+    // itself: reading the slot over the host link from 2049 workgroups made the pass 3-7 x slower, BENCH leases 7 and 8; with the
+    // sum in device memory and a forwarding kernel the gain would be ~5 us of 150.  Two host-result calls it stays.)
+    float sum = 0.0f;
+    if (int rc = np_reduce_all(NP_SUM, in, n, &sum)) return rc;
+    const float mean = sum / (float)n;   // NDArray_Sum_Float(a) / NDArray_NUMELEMENTS(a), statistics.c:95,119
+    np::ResultCall call;
     float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
-    if (int rc = np_reduce_all_dev(NP_SUM, in, n, slot + 1)) return rc;
-    if (int rc = xform_sum<1>(in, slot + 1, n, 0.0f, (float)n, slot)) return rc;
+    if (int rc = xform_sum<1>(in, nullptr, n, mean, 0.0f, slot)) return rc;
     if (int rc = call.wait()) return rc;
-    *host_mean = slot[1] / (float)n;
+    *host_mean = mean;
     *host_m2 = slot[0];
     return NP_OK;
 }
