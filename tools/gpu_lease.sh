@@ -10,6 +10,7 @@
 #              pmc_traffic.json), MFMA / SQ counters of the headline kernels (-> gemm_pmc.json, pmc_sq.txt)
 #   sweeps     GEMM shape sweeps, the layout and misc sweeps, the compiled-chain A/B
 #   evidence   all of the above, in that order (the round's evidence run)
+#   fuzz       the long random-shape parity sweeps (tests/test_gpu_fuzz.py x 400, GEMM tiles / splits, compiled chains)
 #   cleanbuild a copy of the SOURCES (no prebuilt library, no object files) built from scratch with the box's own hipcc, then
 #              smoke() and a slice of the GPU suite against THAT build (the leases otherwise run the .so files pushed from the
 #              build container: VERDICT r03 #15)
@@ -112,6 +113,13 @@ PY
     cd "$R"
 }
 
+r_fuzz() {
+    # the long random-shape sweeps on the library as shipped (cases per family / seed offsets differ from the test tier's)
+    timeout 900 python tools/fuzz_parity.py 400 6 2>&1 | tail -3 > "$O/fuzz_parity.log"; cat "$O/fuzz_parity.log"
+    timeout 400 python tools/gemm_mid_fuzz.py 400 2 2>&1 | tail -3 > "$O/gemm_mid_fuzz.log"; cat "$O/gemm_mid_fuzz.log"
+    timeout 400 python tools/fused_static_fuzz.py 400 2 2>&1 | tail -3 > "$O/fused_static_fuzz.log"; cat "$O/fused_static_fuzz.log"
+}
+
 case "$RECIPE" in
     tests) r_tests ;;
     bench) r_bench ;;
@@ -121,5 +129,6 @@ case "$RECIPE" in
     sweeps) r_sweeps ;;
     evidence) r_tests; r_bench; r_world1; r_profile; r_counters; r_sweeps ;;
     cleanbuild) r_cleanbuild ;;
-    *) echo "unknown recipe $RECIPE (tests | bench | world1 | profile | counters | sweeps | evidence | cleanbuild)"; exit 2 ;;
+    fuzz) r_fuzz ;;
+    *) echo "unknown recipe $RECIPE (tests | bench | world1 | profile | counters | sweeps | evidence | cleanbuild | fuzz)"; exit 2 ;;
 esac
