@@ -189,3 +189,25 @@ def test_cpu_operands_still_reach_the_reference_code(tmp_path):
     assert proc.returncode == 0, proc.stdout + proc.stderr
     m = re.search(r"(\d+) calls, (\d+) reached the reference's own code", proc.stdout)
     assert m and m.group(1) == m.group(2) and int(m.group(1)) >= 80
+
+
+@needs_reference
+def test_hip_fast_uses_only_what_the_reference_headers_declare():
+    """ext/hip_fast.c is compiled inside the patched tree against the reference's OWN headers (src/initializers.h -> src/ndarray.h):
+    every NDArray_* / NDARRAY_* name it uses must be a macro or a prototype there, with the argument list the call sites assume —
+    the one check of that build that needs no PHP."""
+    src = re.sub(r"/\*.*?\*/", "", (ROOT / "ext" / "hip_fast.c").read_text(), flags=re.S)
+    used = sorted(set(re.findall(r"\b(NDArray_\w+|NDARRAY_\w+)\b", src)) - {"NDArray_Binary"})
+    headers = (REF / "src" / "ndarray.h").read_text() + (REF / "src" / "initializers.h").read_text()
+    assert {"NDArray_EmptyLike", "NDArray_FREE", "NDArray_IsBroadcastable", "NDArray_NDIM", "NDArray_DEVICE", "NDARRAY_DEVICE_GPU"} <= set(used)
+    for name in used:
+        assert re.search(r"#define\s+%s\b|\b%s\s*\(" % (name, name), headers), "%s is not declared by the reference's headers" % name
+    protos = {"NDArray_EmptyLike": r"NDArray\s*\*\s*NDArray_EmptyLike\(NDArray \*a\);",
+              "NDArray_FREE": r"void NDArray_FREE\(NDArray \*array\);",
+              "NDArray_IsBroadcastable": r"int NDArray_IsBroadcastable\(const NDArray \*arr1, const NDArray \*arr2\);"}
+    for name, rx in protos.items():
+        assert re.search(rx, headers), name
+    # the same names, the same shapes, in the header the stand-alone build compiles it against
+    ours = (ROOT / "include" / "numpower_host.h").read_text()
+    for name in used:
+        assert re.search(r"#define\s+%s\b|\b%s\s*\(" % (name, name), ours), "%s missing from include/numpower_host.h" % name
