@@ -283,6 +283,45 @@ def test_elementwise_beyond_2p31_elements(hip):
         d.free()
 
 
+def test_argreduce_beyond_2p31_elements(hip):
+    """np_argreduce with more than 2^31 elements along one axis and in all (the reference's `int` counts stop there,
+    calculation.c:73-194): the grid-stride row form on one 8.6 GB row, the wave-per-row form on 2^21 + 4 rows of 1024, and
+    the column-tile form on (2^21 + 4) x 1024 with the axis first.  The index comes back as a float, as the reference returns it:
+    above 2^24 it is the nearest float to the position."""
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    lib = load()
+    D = hip
+    n = (1 << 31) + 4096
+    a = D.DeviceArray((n,))
+    D.fill(a, 1.0)
+    for pos, val in (((1 << 31) + 5, 3.0), (7, -2.0), ((1 << 31) + 9, 3.0), (123_456_789, -2.0)):
+        D.fill(a.view(pos, (1,)), val)
+    out = D.DeviceArray((4,))
+    check(lib.np_argreduce(1, a.ptr, 1, n, 1, out.ptr))
+    assert out.to_host()[0] == np.float32((1 << 31) + 5)            # the FIRST of the two maxima
+    check(lib.np_argreduce(0, a.ptr, 1, n, 1, out.ptr))
+    assert out.to_host()[0] == np.float32(7)
+    rows, cols = n // 1024, 1024                                    # 2^21 + 4 rows: all n elements
+    idx = D.DeviceArray((rows,))
+    check(lib.np_argreduce(1, a.ptr, rows, cols, 1, idx.ptr))       # one wave per row
+    got = idx.to_host()
+    want = np.zeros(rows, np.float32)
+    for pos in ((1 << 31) + 5, (1 << 31) + 9):
+        want[pos // cols] = pos % cols if want[pos // cols] == 0 else want[pos // cols]
+    assert (got == want).all(), np.flatnonzero(got != want)[:5]
+    cidx = D.DeviceArray((cols,))
+    check(lib.np_argreduce(0, a.ptr, 1, rows, cols, cidx.ptr))      # axis first: column tiles + the coalesced fold
+    got = cidx.to_host()
+    want = np.zeros(cols, np.float32)
+    want[7 % cols] = 7 // cols
+    want[123_456_789 % cols] = 123_456_789 // cols
+    assert (got == want).all(), np.flatnonzero(got != want)[:5]
+    for d in (a, out, idx, cidx):
+        d.free()
+    del C
+
+
 def test_order_stat_beyond_2p31_elements(hip):
     """np_order_stat with 64-bit indices (bracket path and plain passes): 2^31 + 2^24 floats built on the device from
     129 copies of a shuffled 0 .. 2^24-1 pattern, so the k-th smallest is k // 129 exactly."""
