@@ -20,7 +20,8 @@
  *
  * GPU operands leave through ONE np_binary launch (operand kinds NP_SCALAR / NP_HOST_SCALAR / NP_ROW / NP_COL instead
  * of temporaries); CPU operands fall through to the reference's code, untouched.  reduce() keeps its own argument
- * checks and result allocation and swaps `_reduce(...)` for NPH_ReduceAxisInto on GPU arrays (one np_reduce_axis).
+ * checks and result allocation and swaps `_reduce(...)` for NPH_ReduceAxisInto on GPU arrays (one np_reduce_axis); so does
+ * single_reduce() for NDArray_Mean_Float, where PHP_METHOD(mean) sends GPU arrays that come with an axis (numpower.c:2677).
  *
  * The file is plain C and compiles against whatever header provides struct NDArray with the reference's layout,
  * NDArray_EmptyLike / NDArray_FREE / NDArray_IsBroadcastable and the NDArray_* accessor macros — the reference's own

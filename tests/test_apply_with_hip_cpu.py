@@ -103,7 +103,7 @@ def test_the_new_statements_compile_against_the_c_abi(tmp_path):
     src = tmp_path / "snippets.c"
     src.write_text(tool.snippet_check_source())
     n = sum(1 for e in tool.EDITS if e.context)
-    assert n >= 14 + 12 + 1          # section 2a's statements, the twelve early-outs, reduce()
+    assert n >= 14 + 12 + 2          # section 2a's statements, the twelve early-outs, reduce(), single_reduce()
     proc = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
                            "-I", str(ROOT / "include"), "-I", str(ROOT / "ext"), str(src)], capture_output=True, text=True)
     assert proc.returncode == 0, proc.stderr
@@ -163,7 +163,8 @@ def test_the_fast_path_inserts_replace_nothing(patched):
         # order inside the function: the reference's device check, then the early-out, then the scalar expand
         assert body.index("mismatch") < body.index("NPH_TAKES") < body.index("// If a or b are scalars, reshape"), name
     nd = (out / "src/ndarray.c").read_text()
-    assert nd.count("NPH_ReduceAxisInto(") == 1 and nd.count(" _reduce(0, 0, axis, array, rtn, operation);") == 2   # HIP side's else + the #else side
+    assert nd.count("NPH_ReduceAxisInto(") == 2 and nd.count(" _reduce(0, 0, axis, array, rtn, operation);") == 2   # HIP side's else + the #else side
+    assert nd.count("_single_reduce(0, 0, axis, array, rtn, operation);") == 2 and "operation == NDArray_Mean_Float" in nd
     assert "src/hip/hip_fast.c" in (out / "config.m4").read_text()
     assert (out / "src/hip/hip_fast.c").exists() and (out / "src/hip/hip_fast.h").exists()
 

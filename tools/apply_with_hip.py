@@ -259,6 +259,20 @@ EDITS = [
          "} else {\n"
          "    _reduce(0, 0, axis, array, rtn, operation);\n"
          "}"),
+    Edit("src/ndarray.c", "ndarray.c:509 single_reduce(): mean over an axis of a GPU array",
+         r"^(?P<old>[ \t]*_single_reduce\(0, 0, axis, array, rtn, operation\);)$",
+         "/* numpower_amd: PHP_METHOD(mean) sends GPU arrays with an axis here (numpower.c:2677), and the loop below writes NOTHING\n"
+         " * for them (apply_single_reduce stores only when the target is on the CPU, ndarray.c:389).  For a GPU array this is what\n"
+         " * the method's CPU branch computes — reduce(Add) / n, numpower.c:2662-2669 — as one np_reduce_axis launch; every other\n"
+         " * operation (min / max / median / all) and every CPU array keeps the reference's loop */\n"
+         "if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && operation == NDArray_Mean_Float) {\n"
+         "    if (NPH_ReduceAxisInto(array, *axis, NP_MEAN, 0u, rtn) != 0) {\n"
+         "        NDArray_FREE(rtn);\n"
+         "        rtn = NULL;\n"
+         "    }\n"
+         "} else {\n"
+         "    _single_reduce(0, 0, axis, array, rtn, operation);\n"
+         "}"),
     # ---- config.m4: the option, and the source list ----
     Edit("config.m4", "config.m4:7-8: --with-hip next to --with-cuda",
          r"^(?P<old>PHP_ARG_WITH\(cuda, for CUDA support,\n\[  --with-cuda           Include CUDA support\], \[no\], \[no\]\))$",
@@ -287,6 +301,8 @@ CONTEXTS = {
     "numpower.c:3153 PHP_METHOD(exp2): a device branch": "NDArray *rtn = 0, *nda = 0;",
     "ndarray.c:570 reduce(): one np_reduce_axis launch for GPU arrays":
         "NDArray *array = 0, *rtn = 0; int *axis = 0; NDArray *(*operation)(NDArray *, NDArray *) = 0;",
+    "ndarray.c:509 single_reduce(): mean over an axis of a GPU array":
+        "NDArray *array = 0, *rtn = 0; int *axis = 0; float (*operation)(NDArray *) = 0;",
 }
 for _e in EDITS:
     if _e.what.endswith("GPU early-out"):
@@ -347,6 +363,8 @@ def snippet_check_source() -> str:
            "void zend_throw_error(void *exception_ce, const char *format, ...);   /* Zend/zend_exceptions.h */",
            "void _reduce(int current_axis, int rtn_init, int *axis, NDArray *target, NDArray *rtn,",
            "             NDArray *(*operation)(NDArray *, NDArray *));                 /* src/ndarray.c:394 */",
+           "void _single_reduce(int current_axis, int rtn_init, int *axis, NDArray *target, NDArray *rtn,",
+           "                    float (*operation)(NDArray *));                        /* src/ndarray.c:431 */",
            "NDArray *NDArray_Map(NDArray *array, float (*op)(float));                /* src/ndarray.h */",
            "float float_exp2(float val);                                             /* src/ndmath/double_math.h */", ""]
     for k, e in enumerate(EDITS):
@@ -382,6 +400,7 @@ def fast_path_program_source() -> str:
                                       tests/test_gpu_fast_path.py
     """
     reduce_edit = next(e for e in EDITS if e.what.startswith("ndarray.c:570 reduce()"))
+    single_edit = next(e for e in EDITS if e.what.startswith("ndarray.c:509 single_reduce()"))
     o = ["/* generated by tools/apply_with_hip.py: fast_path_program_source() — do not edit */",
          "#define _POSIX_C_SOURCE 200809L",
          "#include <stdint.h>", "#include <stdio.h>", "#include <stdlib.h>", "#include <string.h>", "",
@@ -390,6 +409,9 @@ def fast_path_program_source() -> str:
          "static NDArray *reference_body(void) { g_fell_through++; return NULL; }",
          "static void _reduce(int current_axis, int rtn_init, int *axis, NDArray *target, NDArray *rtn,",
          "                    NDArray *(*operation)(NDArray *, NDArray *)) {",
+         "    (void) current_axis; (void) rtn_init; (void) axis; (void) target; (void) rtn; (void) operation;",
+         "    g_fell_through++;", "}",
+         "static void _single_reduce(int current_axis, int rtn_init, int *axis, NDArray *target, NDArray *rtn, float (*operation)(NDArray *)) {",
          "    (void) current_axis; (void) rtn_init; (void) axis; (void) target; (void) rtn; (void) operation;",
          "    g_fell_through++;", "}", ""]
     for name, e in FAST_BINARY:
@@ -401,7 +423,13 @@ def fast_path_program_source() -> str:
           "    int out_shape[8], j = 0;",
           "    for (int i = 0; i < NDArray_NDIM(array); i++) if (i != *axis) out_shape[j++] = NDArray_SHAPE(array)[i];",
           '    NDArray *rtn = NDArray_Zeros(out_shape, j, "float32", NDArray_DEVICE(array));',
-          "#ifdef HAVE_NP_HIP", _indent(reduce_edit.new, "    "), "#endif", "    return rtn;", "}", ""]
+          "#ifdef HAVE_NP_HIP", _indent(reduce_edit.new, "    "), "#endif", "    return rtn;", "}", "",
+          "static NDArray *patched_single_reduce(NDArray *array, int *axis, float (*operation)(NDArray *)) {",
+          "    /* single_reduce()'s own result allocation (ndarray.c:476-508), then the edited statement */",
+          "    int out_shape[8], j = 0;",
+          "    for (int i = 0; i < NDArray_NDIM(array); i++) if (i != *axis) out_shape[j++] = NDArray_SHAPE(array)[i];",
+          '    NDArray *rtn = NDArray_Zeros(out_shape, j, "float32", NDArray_DEVICE(array));',
+          "#ifdef HAVE_NP_HIP", _indent(single_edit.new, "    "), "#endif", "    return rtn;", "}", ""]
     table = ",\n".join('    {"%s", patched_%s}' % (name[len("NDArray_"):], name) for name, _ in FAST_BINARY)
     o.append(_FAST_PROGRAM_MAIN.replace("@TABLE@", table))
     return "\n".join(o)
@@ -517,7 +545,16 @@ int main(int argc, char **argv) {
     }
     /* any other operation keeps the reference's loop, GPU array or not */
     { int axis_i = 0; NDArray *r = patched_reduce(a3, &axis_i, NDArray_Subtract_Float); if (r) NDArray_FREE(r); }
-    const int expect_fell = gpu ? 1 : calls + 1;
+    for (int axis_i = 0; axis_i < 3; axis_i++) {             /* single_reduce(nda, &i_axis, NDArray_Mean_Float): PHP_METHOD(mean) on a GPU array */
+        char form[16];
+        snprintf(form, sizeof form, "axis%d", axis_i);
+        NDArray *r = patched_single_reduce(a3, &axis_i, NDArray_Mean_Float);
+        calls++;
+        if (gpu) dump("mean", form, r);
+        if (r) NDArray_FREE(r);
+    }
+    { int axis_i = 1; NDArray *r = patched_single_reduce(a3, &axis_i, NDArray_Min); calls++; if (r) NDArray_FREE(r); }   /* min keeps the loop */
+    const int expect_fell = gpu ? 2 : calls + 1;
     printf("fast_path_bodies %s: %d calls, %d reached the reference's own code (expected %d)\n", argv[1], calls + 1,
            g_fell_through, expect_fell);
     if (g_fell_through != expect_fell) g_failed = 1;
