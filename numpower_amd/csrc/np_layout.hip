@@ -521,6 +521,11 @@ __global__ __launch_bounds__(256) void arange_kernel(float *__restrict__ out, co
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 int g_tile = 0;   // 0 = default, else 64 / 128 (np_layout_set_variant)
+// Write-aligned transposes with fewer 128 x 128 tiles than this take 64 x 64 tiles (0 = never; np_layout_set_variant(7000 + N) sets it): at two
+// workgroups of 67 KB LDS per CU, 1089 tiles (4099^2) are 2.1 resident rounds and a third of the last one idles; 4225 small tiles at eight
+// per CU end more evenly — 4099^2 4.80 -> 5.07 TB/s, 5000 x 4099 (1320 tiles) +1 %; from ~2000 tiles up the small tiles LOSE (8191 x 8193 -2 %,
+// 6001 x 6003 -14 %, 12345 x 6789 -19 %: they read 96 rows for every 64 they write) — profiles/r05/walign_tile_ab.log.
+size_t g_walign64_below_tiles = 1200;
 
 template <int TR, int TC>
 int launch_transpose(const float *in, float *out, size_t batch, size_t rows, size_t cols, bool vec, const PlaneBatch &pb) {
@@ -593,6 +598,17 @@ int transpose_planes(const float *in, float *out, size_t batch, size_t rows, siz
     bool walign = g_tile != 1 && g_tile != 64 && g_tile != 128 && tile == 128 && pb.out_pitch % 32 != 0 && ((uintptr_t)out & 127u) == 0 && rows >= 256 && cols >= 64 &&
                   rows + 31 < 0x7fffffffu;
     for (unsigned d = 0; d < pb.nbatch; ++d) walign = walign && (pb.bshape[d] == 1 || pb.bout[d] % 32 == 0);
+    // 64 x 64 write-aligned tiles: variant 7 = always; by default for the smallest matrices that get here (g_walign64_below_tiles)
+    if (walign && (g_tile == 7 || (g_walign64_below_tiles && ((cols + 127) / 128) * ((rows + 31 + 127) / 128) * batch < g_walign64_below_tiles))) {
+        const size_t tiles_x = (cols + 63) / 64, tiles_y = (rows + 31 + 63) / 64;
+        if (tiles_x * tiles_y <= 0x7fffffffu) {
+            constexpr size_t lds = (size_t)64 * 66 * sizeof(float);
+            transpose_walign_kernel<64, 64><<<dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch), 256, lds, np::stream()>>>(
+                in, out, (unsigned)rows, (unsigned)cols, (unsigned)tiles_x, (unsigned)tiles_y, pb);
+            NP_LAUNCH_CHECK("transpose_walign_kernel");
+            return NP_OK;
+        }
+    }
     if (walign) {
         const size_t tiles_x = (cols + 127) / 128, tiles_y = (rows + 31 + 127) / 128;
         if (tiles_x * tiles_y <= 0x7fffffffu) {
@@ -619,6 +635,10 @@ int transpose_planes(const float *in, float *out, size_t batch, size_t rows, siz
 extern "C" {
 
 int np_layout_set_variant(int variant) {
+    if (variant >= 7000 && variant < 17000) {
+        g_walign64_below_tiles = (size_t)(variant - 7000);
+        return NP_OK;
+    }
     g_tile = variant;
     return NP_OK;
 }

@@ -28,6 +28,7 @@ using namespace np::dev;   // r_identity / r_combine / wave_reduce / block_reduc
 // Workgroups per CU of the streaming reductions' first pass (np_reduce_set_variant; tools/reduce_cap_ab.py).
 // One partial per workgroup, so more workgroups = more partials for the one-block second pass to fold.
 int g_wg_per_cu = 0;   // 0 = the default below
+int g_arg_cols_wg_per_cu = 0;   // argreduce_cols_tile: workgroups per CU the axis is cut for; 0 = by alignment (np_reduce_set_variant(4000000 + N): A/B)
 constexpr int kStreamWgPerCu = 8;
 inline size_t stream_cap() {
     if (g_wg_per_cu >= 1000) return (size_t)g_wg_per_cu;   // tuning: an exact workgroup count
@@ -1660,11 +1661,16 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
     if (inner >= 192 && outer <= 65535 && axis_len >= 16) {
         const size_t inner4 = (inner + 3) / 4;
         const size_t tiles = (inner4 + 63) / 64;
-        // four workgroups per CU (the column SUM takes twelve, choose_splits: its partials are 4 bytes per column and chunk,
-        // these are 8 and are read back by a fold that has far fewer workgroups to do it with), chunks of >= 64 rows, an odd
-        // number of rows per chunk (np_internal.h: no power-of-two distances between the rows in flight)
+        // TWO workgroups per CU when the rows are float4-aligned, EIGHT when they are not (the column SUM takes twelve, choose_splits:
+        // its partials are 4 bytes per column and chunk; these are 8 and are read back by a fold with far fewer workgroups).  Same box,
+        // 2 / 4 / 8 per CU (profiles/r05/arg_cols_ab.log): 65536 x 1024 5.92 / 5.54 / 5.17 TB/s, 25000 x 4000 6.26 / 6.17 / 5.87,
+        // 64 x 1500 x 1000 5.71 / 5.61 / 5.33 — eight rows in flight per lane fill the machine from few workgroups, and fewer chunks
+        // are fewer partials; 9973^2 (every wave-level load unaligned, latency-bound) 3.44 / 4.36 / 4.78.  Chunks of >= 64 rows, an
+        // odd number of rows per chunk (np_internal.h: no power-of-two distances between the rows in flight)
         size_t chunks = 1;
-        const size_t base_wg = tiles * outer, target_wg = (size_t)np::num_cus() * 4;
+        const bool rows_aligned = inner % 4 == 0 && ((uintptr_t)in & 15u) == 0;
+        const size_t wg_per_cu = g_arg_cols_wg_per_cu > 0 ? (size_t)g_arg_cols_wg_per_cu : (rows_aligned ? 2 : 8);
+        const size_t base_wg = tiles * outer, target_wg = (size_t)np::num_cus() * wg_per_cu;
         if (base_wg < target_wg) {
             chunks = (target_wg + base_wg - 1) / base_wg;
             const size_t max_chunks = axis_len / 64 > 0 ? axis_len / 64 : 1;
@@ -1825,6 +1831,10 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
 int np_reduce_set_variant(int variant) {
     if (variant >= 2000000 && variant < 2100000) {   // the largest first-pass grid that folds its partials in-kernel
         np::g_fold_in_kernel_max = (size_t)(variant - 2000000);
+        return NP_OK;
+    }
+    if (variant >= 4000000 && variant < 4000100) {   // argmax / argmin over wide inner: workgroups per CU
+        g_arg_cols_wg_per_cu = variant - 4000000;   // 0 = the default rule
         return NP_OK;
     }
     if (variant >= 3000000 && variant < 3100000) {   // np_reduce_all of <= 4 M elements on at most N workgroups (0 = off)

@@ -98,7 +98,8 @@ def test_permute_paths(shape, axes, hip):
 
 
 @pytest.mark.parametrize("rc", [(100_003, 3), (3, 100_003), (70_000, 1), (1, 70_000), (5000, 16), (16, 5000), (1031, 1033),
-                                (4099, 257), (2, 2), (17, 17)])
+                                (4099, 257), (2, 2), (17, 17),
+                                (4099, 4099), (4100, 4243), (5000, 4099)])   # write-aligned tiles: 64 x 64 below 1200 tiles of 128 (round 5), 128 x 128 above
 def test_transpose2d_skinny_and_odd(rc, hip):
     """Tall-skinny / short-wide matrices (one side <= 16: transpose_skinny_kernel; these also have
     more tile rows than gridDim.y allows) and odd sizes (dword-aligned float4 path)."""
