@@ -62,9 +62,9 @@ constexpr size_t kFoldInKernelMaxBlocks = 256;
 // group from counter 0): correct and bit-identical, but nd::sum() of 10^6 floats (977 workgroups) took 16.1 us that way against
 // 12.3 us with the second launch — two dependent memory-side round trips for the tickets and one more for the partials cost
 // more than a 4 us launch (profiles/r05/reduce_small_ab.log) — and was removed.  What did help a little: np_reduce_all of up to
-// 4 M elements on at most g_small_reduce_blocks fat workgroups, which then fold behind ONE ticket (10^6: 12.0 us).
+// 2^20 elements on at most g_small_reduce_blocks fat workgroups, which then fold behind ONE ticket (10^6: 12.0 us).
 extern size_t g_fold_in_kernel_max;   // largest grid that folds in-kernel, <= kFoldInKernelMaxBlocks (np_reduce_set_variant(2000000 + N): A/B, tests)
-extern size_t g_small_reduce_blocks;  // np_reduce_all of up to 4 M elements on at most this many workgroups (0 = off; np_reduce_set_variant(3000000 + N))
+extern size_t g_small_reduce_blocks;  // np_reduce_all of up to 2^20 elements on at most this many workgroups (0 = off; np_reduce_set_variant(3000000 + N))
 // the ticket for a first pass of `blocks` workgroups, or nullptr (a second launch folds)
 inline unsigned *fold_ticket(size_t blocks) {
     if (blocks <= kFoldInKernelMaxBlocks && blocks <= g_fold_in_kernel_max) return next_ticket();

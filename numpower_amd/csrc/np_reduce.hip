@@ -28,6 +28,7 @@ using namespace np::dev;   // r_identity / r_combine / wave_reduce / block_reduc
 // Workgroups per CU of the streaming reductions' first pass (np_reduce_set_variant; tools/reduce_cap_ab.py).
 // One partial per workgroup, so more workgroups = more partials for the one-block second pass to fold.
 int g_wg_per_cu = 0;   // 0 = the default below
+int g_arg_flat_wg_per_cu = 0;   // the flat walks for a few columns: workgroups per CU, 0 = by shape (np_reduce_set_variant(4100000 + N): A/B)
 int g_arg_cols_wg_per_cu = 0;   // argreduce_cols_tile: workgroups per CU the axis is cut for; 0 = by alignment (np_reduce_set_variant(4000000 + N): A/B)
 constexpr int kStreamWgPerCu = 8;
 inline size_t stream_cap() {
@@ -67,10 +68,21 @@ __global__ __launch_bounds__(256) void reduce_all_pass1(const float *__restrict_
             acc3[k] = r_combine<OP>(acc3[k], x3[k]);
         }
     }
-    for (; v < nvec; v += stride) {
-        const v4f x0 = *(const v4f *)(base + (size_t)v * 4);
+    if (v < nvec) {
+        // what is left — at most three vectors per lane — is issued together too: one load per iteration was three memory round
+        // trips one behind the other at the very end of every workgroup (~5 % of a 10^8-element pass, a third of a 10^6-element one)
+        const I v1 = v + stride, v2 = v + 2 * stride;
+        const bool h1 = v1 < nvec, h2 = v2 < nvec;
+        const v4f x0 = __builtin_nontemporal_load((const v4f *)(base + (size_t)v * 4));
+        v4f x1{id, id, id, id}, x2 = x1;
+        if (h1) x1 = __builtin_nontemporal_load((const v4f *)(base + (size_t)v1 * 4));
+        if (h2) x2 = __builtin_nontemporal_load((const v4f *)(base + (size_t)v2 * 4));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc0[k] = r_combine<OP>(acc0[k], x0[k]);
+        for (int k = 0; k < 4; ++k) {
+            acc0[k] = r_combine<OP>(acc0[k], x0[k]);
+            if (h1) acc1[k] = r_combine<OP>(acc1[k], x1[k]);
+            if (h2) acc2[k] = r_combine<OP>(acc2[k], x2[k]);
+        }
     }
     float r = id;
 #pragma unroll
@@ -305,10 +317,23 @@ __device__ __forceinline__ ArgPair arg_scan_contig(const float *__restrict__ q, 
             arg_take<IS_MAX>(bv[3][k], bt[3][k], x3[k], v + 3 * STRIDE);
         }
     }
-    for (; v < nvec; v += STRIDE) {
-        const v4f x0 = *(const v4f *)(qa + (size_t)v * 4);
+    if (v < nvec) {   // at most three vectors are left per lane: issued together, into the accumulators whose turn it would have been
+        const unsigned v1 = v + STRIDE, v2 = v + 2 * STRIDE;
+        const bool h1 = v1 < nvec, h2 = v2 < nvec;
+        const v4f x0 = __builtin_nontemporal_load((const v4f *)(qa + (size_t)v * 4));
+        v4f x1{id, id, id, id}, x2 = x1;
+        if (h1) x1 = __builtin_nontemporal_load((const v4f *)(qa + (size_t)v1 * 4));
+        if (h2) x2 = __builtin_nontemporal_load((const v4f *)(qa + (size_t)v2 * 4));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) arg_take<IS_MAX>(bv[0][k], bt[0][k], x0[k], v);
+        for (int k = 0; k < 4; ++k) {
+            if (!main_runs) {   // accumulators 1 and 2 meet their first element here: it is a candidate even if it equals the identity
+                if (h1) bt[1][k] = v1;
+                if (h2) bt[2][k] = v2;
+            }
+            arg_take<IS_MAX>(bv[0][k], bt[0][k], x0[k], v);
+            if (h1) arg_take<IS_MAX>(bv[1][k], bt[1][k], x1[k], v1);
+            if (h2) arg_take<IS_MAX>(bv[2][k], bt[2][k], x2[k], v2);
+        }
     }
     ArgPair best{id, kArgNone};
 #pragma unroll
@@ -919,7 +944,9 @@ int launch_reduce_all(const float *in, size_t n, float *dev_out) {
     // enough workgroups to fill the chip (8 per CU), but never more than one per 4 KiB of input
     size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
     // (A/B, np_reduce_set_variant(3000000 + N): a few MB on N fat workgroups, so that one ticket and one fold load per thread do)
-    if (np::g_small_reduce_blocks && n <= (size_t(1) << 22) && blocks > np::g_small_reduce_blocks) blocks = np::g_small_reduce_blocks;
+    // (up to 2^20 elements: at 4 M the 128 workgroups — half the CUs — take longer to stream 16 MB than the second launch costs:
+    // 15.1 against 12.2 us, profiles/r05/reduce_small_ab_final.log)
+    if (np::g_small_reduce_blocks && n <= (size_t(1) << 20) && blocks > np::g_small_reduce_blocks) blocks = np::g_small_reduce_blocks;
     np::Scratch partials;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
     // small grids: the last workgroup to finish folds the partials, no second launch (np_internal.h)
@@ -1262,10 +1289,22 @@ __global__ __launch_bounds__(256) void argreduce_small_inner(const float *__rest
                 arg_take<IS_MAX>(bv[3][k], bj[3][k], x3[k], j + 3);
             }
         }
-        for (; v < nvec; v += T, ++j) {
+        if (v < nvec) {   // at most three vectors are left per lane: issued together (arg_scan_contig does the same)
+            const bool h1 = v + T < nvec, h2 = v + 2 * T < nvec;
             const v4f x0 = ARG_LOAD4(p + (size_t)v * 4);
+            v4f x1{id, id, id, id}, x2 = x1;
+            if (h1) x1 = ARG_LOAD4(p + (size_t)(v + T) * 4);
+            if (h2) x2 = ARG_LOAD4(p + (size_t)(v + 2 * T) * 4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) arg_take<IS_MAX>(bv[0][k], bj[0][k], x0[k], j);
+            for (int k = 0; k < 4; ++k) {
+                if (!main_runs) {
+                    if (h1) bj[1][k] = j + 1;
+                    if (h2) bj[2][k] = j + 2;
+                }
+                arg_take<IS_MAX>(bv[0][k], bj[0][k], x0[k], j);
+                if (h1) arg_take<IS_MAX>(bv[1][k], bj[1][k], x1[k], j + 1);
+                if (h2) arg_take<IS_MAX>(bv[2][k], bj[2][k], x2[k], j + 2);
+            }
         }
         const unsigned rows_per_trip = 4 * T / inner;
 #pragma unroll
@@ -1344,10 +1383,22 @@ __global__ __launch_bounds__(256) void argreduce_small_inner4(const float *__res
                 arg_take<IS_MAX>(bv[3][k], bj[3][k], x3[k], j + 3);
             }
         }
-        for (; v < nvec; v += T, ++j) {
+        if (v < nvec) {   // at most three vectors are left per lane: issued together (arg_scan_contig does the same)
+            const bool h1 = v + T < nvec, h2 = v + 2 * T < nvec;
             const v4f x0 = ARG_LOAD4(p + (size_t)v * 4);
+            v4f x1{id, id, id, id}, x2 = x1;
+            if (h1) x1 = ARG_LOAD4(p + (size_t)(v + T) * 4);
+            if (h2) x2 = ARG_LOAD4(p + (size_t)(v + 2 * T) * 4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) arg_take<IS_MAX>(bv[0][k], bj[0][k], x0[k], j);
+            for (int k = 0; k < 4; ++k) {
+                if (!main_runs) {
+                    if (h1) bj[1][k] = j + 1;
+                    if (h2) bj[2][k] = j + 2;
+                }
+                arg_take<IS_MAX>(bv[0][k], bj[0][k], x0[k], j);
+                if (h1) arg_take<IS_MAX>(bv[1][k], bj[1][k], x1[k], j + 1);
+                if (h2) arg_take<IS_MAX>(bv[2][k], bj[2][k], x2[k], j + 2);
+            }
         }
         const unsigned rows_per_trip = T / inner4, row0 = r0 + t / inner4;
 #pragma unroll
@@ -1630,7 +1681,11 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
     // a few columns (inner <= 64, or whole float4 groups up to 256 columns), many rows: slabs of rows as flat memory
     const bool groups4 = inner % 4 == 0 && inner <= 256;
     if ((groups4 || inner <= 64) && axis_len * inner >= 4096 && outer <= 65535) {
-        const size_t target_wg = (size_t)np::num_cus() * 8;
+        // one long axis (outer == 1: argmax over the rows of an N x C array): TWO workgroups per CU — four float4 loads in flight per
+        // lane fill the machine, and a quarter of the blocks is a quarter of the partials the fold has to read (profiles/r05/arg_flat_ab.log,
+        // 2 against 8 per CU: N x 3 6.21 / 5.91 TB/s, N x 64 5.52 / 5.19, N x 256 5.61 / 5.15); with several outer slices eight, as before
+        // (16 x 100000 x 60: 4.81 / 5.73)
+        const size_t target_wg = (size_t)np::num_cus() * (size_t)(g_arg_flat_wg_per_cu > 0 ? g_arg_flat_wg_per_cu : (outer == 1 ? 2 : 8));
         size_t blocks = (target_wg + outer - 1) / outer;
         const size_t min_rows = (4096 + inner - 1) / inner;              // a block walks >= 16 KiB
         const size_t max_blocks = axis_len / min_rows > 0 ? axis_len / min_rows : 1;
@@ -1831,6 +1886,10 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
 int np_reduce_set_variant(int variant) {
     if (variant >= 2000000 && variant < 2100000) {   // the largest first-pass grid that folds its partials in-kernel
         np::g_fold_in_kernel_max = (size_t)(variant - 2000000);
+        return NP_OK;
+    }
+    if (variant >= 4100000 && variant < 4100100) {   // argmax / argmin over a few columns (flat walks): workgroups per CU
+        g_arg_flat_wg_per_cu = variant - 4100000;   // 0 = the default rule
         return NP_OK;
     }
     if (variant >= 4000000 && variant < 4000100) {   // argmax / argmin over wide inner: workgroups per CU

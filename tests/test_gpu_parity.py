@@ -1017,9 +1017,9 @@ def test_matmul_thin(mnk, hip, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [70_000, 300_001, 1_000_000, 4_100_003])
+@pytest.mark.parametrize("n", [70_000, 300_001, 1_000_000, 1_048_576, 1_100_003])
 def test_full_reduction_one_launch_is_bit_identical_to_two(n, hip):
-    """nd::sum() of up to 4 M elements (BASELINE config 1's 1000 x 1000) runs on at most 128 fat workgroups whose last one folds
+    """nd::sum() of up to 2^20 elements (BASELINE config 1's 1000 x 1000) runs on at most 128 fat workgroups whose last one folds
     the partials behind one ticket (np_internal.h) instead of a second launch: the same partials in the same order, so the value
     is bit-identical to the two-launch form of the same grid (np_reduce_set_variant(2000000 + 0) brings that back), call
     after call (the ticket must come back clean), and within 1e-6 of the sum the streaming grid of rounds 2-4 produces
