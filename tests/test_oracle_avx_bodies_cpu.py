@@ -147,3 +147,39 @@ def test_equal_rules_differ_between_body_and_tail(oracle):
     assert ne[[0, 1, 2]].tolist() == [0.0, 1.0, 0.0] and ne[[16, 17, 18]].tolist() == [1.0, 0.0, 1.0]
     assert (_bits(eq) == _bits(second_restatement("equal", a, b))).all()
     assert (_bits(ne) == _bits(second_restatement("not_equal", a, b))).all()
+
+
+@pytest.mark.parametrize("shape", [(5,), (64,), (1000,), (7, 9), (33, 8), (4, 5, 17), (3, 16, 8)])
+def test_oracle_reductions_against_a_second_restatement(shape, oracle):
+    """Reductions, restated a second time from the reference text:
+      NDArray_Sum_Float / Float_Prod (arithmetics.c:36-71): one fp32 accumulator walked over the elements in memory order —
+        numpy's accumulate (ufunc.accumulate is sequential, unlike np.sum's pairwise tree);
+      NDArray_Min / NDArray_Max (ndarray.c:752-772,939-959): `if (x < min) min = x` — a NaN never replaces;
+      reduce(a, &axis, NDArray_Add_Float | NDArray_Multiply_Float) (ndarray.c:394-429,523-578): the result starts as slice 0 and
+        every further slice is folded in by ONE call of the elementwise function — so per element a sequential sum / product
+        over the axis, the products with Multiply_Float's zero-sign rule applied per fold (body / tail by the SLICE's size)."""
+    x = synth.uniform(shape, 91, -2.0, 2.0)
+    flat = x.reshape(-1)
+    with np.errstate(all="ignore"):
+        assert _bits(oracle.reduce_all("sum", x)) == _bits(np.add.accumulate(flat, dtype=np.float32)[-1])
+        assert _bits(oracle.reduce_all("prod", x)) == _bits(np.multiply.accumulate(flat, dtype=np.float32)[-1])
+        assert oracle.reduce_all("min", x) == flat.min() and oracle.reduce_all("max", x) == flat.max()
+        for axis in range(len(shape)):
+            if len(shape) == 1:
+                continue
+            xm = np.moveaxis(x, axis, 0)                      # slices along the axis, each C-contiguous in the reference's walk
+            want_sum = xm[0].copy()
+            want_prod = xm[0].copy()
+            for k in range(1, xm.shape[0]):
+                want_sum = want_sum + xm[k]
+                if want_prod.ndim > 0:      # slices with at least one axis go through Multiply_Float's loops (0-d ones take its short cut)
+                    want_prod = second_restatement("multiply", np.ascontiguousarray(want_prod).reshape(-1),
+                                                   np.ascontiguousarray(xm[k]).reshape(-1)).reshape(want_prod.shape)
+                else:
+                    want_prod = want_prod * xm[k]
+            got_sum, got_prod = oracle.reduce_axis("sum", x, axis), oracle.reduce_axis("prod", x, axis)
+            _same(np.asarray(got_sum).reshape(-1), np.asarray(want_sum, np.float32).reshape(-1), ("sum", shape, axis))
+            _same(np.asarray(got_prod).reshape(-1), np.asarray(want_prod, np.float32).reshape(-1), ("prod", shape, axis))
+    y = x.copy().reshape(-1)
+    y[1::3] = np.nan                                          # NaNs that are not first: min / max ignore them
+    assert oracle.reduce_all("min", y) == np.nanmin(y) and oracle.reduce_all("max", y) == np.nanmax(y)
