@@ -183,3 +183,25 @@ def test_oracle_reductions_against_a_second_restatement(shape, oracle):
     y = x.copy().reshape(-1)
     y[1::3] = np.nan                                          # NaNs that are not first: min / max ignore them
     assert oracle.reduce_all("min", y) == np.nanmin(y) and oracle.reduce_all("max", y) == np.nanmax(y)
+
+
+def test_oracle_argreduce_transpose_matmul_against_numpy(oracle):
+    """The rest of the checker's surface against numpy where numpy has the same definition: argmax / argmin without NaNs
+    (first occurrence on ties, calculation.c:9-72) and the two NaN rules spelled out; transpose = numpy's strided copy
+    (manipulation.c:68-130, :381-421); matmul (cblas_sgemm through the bundled OpenBLAS, linalg.c:75-79) within 1e-6 |A|.|B| of
+    the fp64 product."""
+    x = synth.uniform((37, 11, 5), 92, -1.0, 1.0)
+    x.reshape(-1)[::7] = np.float32(0.5)                       # ties
+    for axis in (None, 0, 1, 2):
+        assert (oracle.argreduce(x, axis, True) == np.argmax(x, axis)).all()
+        assert (oracle.argreduce(x, axis, False) == np.argmin(x, axis)).all()
+    nan = np.nan
+    for row, amax, amin in (([nan, 1, 5, 2], 0, 0), ([1, nan, 5, 2], 2, 1), ([1, 5, nan, nan, -7], 1, 2), ([np.inf, 2, np.inf], 0, 1)):
+        r = np.float32(row)
+        assert (float(oracle.argreduce(r, None, True)), float(oracle.argreduce(r, None, False))) == (amax, amin), row
+    for axes in (None, (0, 2, 1), (2, 0, 1), (1, 0, 2)):
+        assert (_bits(oracle.transpose(x, axes)) == _bits(np.ascontiguousarray(np.transpose(x, axes)))).all()
+    a, b = synth.uniform((130, 70), 93, -1.0, 1.0), synth.uniform((70, 96), 94, -1.0, 1.0)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(oracle.matmul(a, b) - ref) <= 1e-6 * scale).all()
