@@ -372,7 +372,18 @@ def bench_c1(dist: Dist, steps, warmup):
     add = hbm_case("add 1000x1000 (C1)", 12.0 * R * R, lambda: D.binary("add", da, "full", db, "full", 1, R * R, out=do),
                    steps, warmup, dist)
     got_add = do.to_host()
-    ssum = hbm_case("sum 1000x1000 (C1)", 4.0 * R * R, lambda: D.reduce_all("sum", da), steps, warmup, dist)
+    # the call as a C / PHP host makes it — np_reduce_all(op, ptr, n, &value) with nothing allocated per call (the Python
+    # convenience wrapper D.reduce_all builds a ctypes float and a reference every time: ~1-2 us that are not the library's)
+    from numpower_amd._lib import REDUCE_OPS
+    lib_c1, val_c1 = load(), C.c_float()
+    ref_c1, op_c1, ptr_c1 = C.byref(val_c1), REDUCE_OPS["sum"], da.ptr
+    call_sum = lib_c1.np_reduce_all
+
+    def sum_call():
+        if call_sum(op_c1, ptr_c1, R * R, ref_c1) != 0:
+            raise RuntimeError(lib_c1.np_last_error().decode())
+
+    ssum = hbm_case("sum 1000x1000 (C1)", 4.0 * R * R, sum_call, steps, warmup, dist)
     got_sum = D.reduce_all("sum", da)
     want_add = oracle.binary("add", a, b)
     want64 = float(a.astype(np.float64).sum())
