@@ -16,7 +16,8 @@
  *   matmul / dot         NDArray_Matmul(nda, ndb), NDArray_Dot(nda, ndb)
  *   sharded batched matmul  NDArray_CommInit(rank, world, endpoint); NDArray_ShardedBatchedMatmul(a, b, batch, mode)
  *                        (this project's own extension, SURVEY.md section 8e: the reference has no multi-device
- *                        code; run here as a world of one rank — kept, gathered and in 3 overlapped pieces)
+ *                        code; run here as a world of one rank — kept, gathered, in 3 overlapped pieces, and with the piece
+ *                        count left to the library)
  *   gpu() / cpu()        NDArray_ToGPU / NDArray_ToCPU
  *
  * Zend argument parsing (zval -> NDArray*) and RETURN_NDARRAY are the only parts of a method that are
@@ -257,7 +258,8 @@ int main(int argc, char **argv) {
             g_failed = 1;
         } else {
             static const struct { const char *name; int mode; } kShard[] = {
-                {"sharded_keep", NP_SHARD_KEEP}, {"sharded_gather", NP_SHARD_GATHER}, {"sharded_overlap3", 3}};
+                {"sharded_keep", NP_SHARD_KEEP}, {"sharded_gather", NP_SHARD_GATHER}, {"sharded_overlap3", 3},
+                {"sharded_overlap_auto", NP_SHARD_OVERLAP}};
             for (size_t i = 0; i < sizeof kShard / sizeof kShard[0]; i++) {
                 r = NDArray_ShardedBatchedMatmul(a3, b3, 6 * NDArray_CommWorld(), kShard[i].mode);
                 dump(kShard[i].name, r);

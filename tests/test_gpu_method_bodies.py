@@ -120,7 +120,7 @@ def test_sharded_batched_matmul_method(records, oracle):
     b = c_input(6 * 47, 29, 107, -1, 1).reshape(6, 47, 29)
     keep = records["sharded_keep"]
     assert keep.shape == (6, 33, 29)
-    for name in ("sharded_gather", "sharded_overlap3"):
+    for name in ("sharded_gather", "sharded_overlap3", "sharded_overlap_auto"):
         assert_bit_equal(records[name], keep, name)
     for i in range(6):
         ref = oracle.matmul(a[i], b[i])
