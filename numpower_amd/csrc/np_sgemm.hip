@@ -45,6 +45,7 @@ struct GemmArgs {
     unsigned tiles_m, tiles_n;
     unsigned swizzle;                       // 0 = row-major tile order, else XCD-aware grouping
     unsigned prio_period;                   // sgemm_dma_kernel<.., PRIO>: K-tiles between priority flips (see there)
+    unsigned k_chunks;                      // sgemm_kq_kernel: != 0: the batch is this many K-chunks of ONE product, launched chunk-major over the XCDs (see there)
     unsigned long long *probe;              // optional per-workgroup timing record (debug), else null
     // Progress reporting (np::sgemm_batched_with_progress): when non-null, every workgroup adds 1 to progress[c] once its
     // C tile is visible device-wide, c = the piece (np_comm_piece split: piece_extra pieces of piece_base + 1 batch
@@ -1366,12 +1367,28 @@ __global__ __launch_bounds__(256, kq_regs(TM, TN, STAGES) <= 256 ? 2 : 1) void s
     static_assert(STAGES == 2 || STAGES == 3, "two or three operand stages");
     __shared__ float red[4 * CH * 4 * 64];
 
+    // K-chunks of one product (k_chunks != 0; a one-dimensional grid of tiles x chunks): the tiles of a chunk read the same slices
+    // of A and B — once each from memory if they share an L2.  Workgroup b runs on XCD b % 8 (observed dispatch order), so the
+    // units, numbered chunk-major (chunk * tiles + tile), are dealt to the XCDs in eight contiguous runs (the bijection of
+    // tile_coords): an XCD works on whole chunks, every XCD on the same number of units +-1.  Deep-K products of a few tiles
+    // stream their operands (100 x 100 x 100000: 80 MB under 2 GFLOP); tile-major, every slice crossed the fabric once per tile
+    // that reads it: 64 x 32 tiles in 32 chunks 55.7 us, chunk-major 35.1 (profiles/r05/gemm_deep_k_sweep.log).
+    unsigned bx = blockIdx.x, bz = blockIdx.z, nz = gridDim.z;
+    if (g.k_chunks) {
+        const unsigned tiles = g.tiles_m * g.tiles_n, units = tiles * g.k_chunks;
+        const unsigned q = units / 8, r = units % 8, xcd = bx % 8, idx = bx / 8;
+        const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        bz = id / tiles;
+        bx = id % tiles;
+        nz = g.k_chunks;
+    }
+    if (g.K_last && bz + 1 == nz) g.K = g.K_last;   // uniform: split-K remainder chunk (>= 4: launch_kq)
     unsigned tile_m, tile_n;
-    tile_coords(g, blockIdx.x, tile_m, tile_n);
+    tile_coords(g, bx, tile_m, tile_n);
     const unsigned m0 = tile_m * BM, n0 = tile_n * BN;
-    const float *A = g.A + (size_t)blockIdx.z * g.stride_a;
-    const float *B = g.B + (size_t)blockIdx.z * g.stride_b;
-    float *C = g.C + (size_t)blockIdx.z * g.stride_c;
+    const float *A = g.A + (size_t)bz * g.stride_a;
+    const float *B = g.B + (size_t)bz * g.stride_b;
+    float *C = g.C + (size_t)bz * g.stride_c;
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lr = lane & 15, kk = lane >> 4;
     const unsigned nk = (g.K + BK - 1) / BK, kr = g.K - (nk - 1) * BK;   // kr: inner length of the last K-tile (1 .. 64; K >= 4)
@@ -2382,6 +2399,10 @@ constexpr CfgTable make_cfg_table() {
 constexpr CfgTable kCfgTable = make_cfg_table();
 constexpr const TileCfg (&kCfg)[kCfgCount] = kCfgTable.c;
 int g_kq_tiles = 1;      // np_sgemm_set_variant(-20) = 0: plans without sgemm_kq_kernel, (-21): back
+int g_force_kq_split_shape = 0, g_force_kq_split_S = 0;   // np_sgemm_set_variant(-(30000 + 1000 * shape + S)): single products of K >= 512 as S K-chunks on that k-quartered shape (A/B); -30000: off
+int g_thin_underfilled_to_planner = 1;   // np_sgemm_set_variant(-27) = 0: 17..64 x 17..64 x (16384 <= K < ~5e5) on the thin K-chunk kernels as before round 5, (-28): to the planner (default)
+int g_kq_chunk_major = 1;   // np_sgemm_set_variant(-25) = 0: K-chunked k-quartered launches tile-major (blockIdx.z = chunk), (-26): chunk-major over the XCDs (default)
+int g_kq_splitk = 1;     // np_sgemm_set_variant(-22) = 0: no K-chunked plans on the k-quartered tiles (deep-K products as before round 5: the register-staged tiles), (-23): back
 int g_mid_tiles = 1;   // np_sgemm_set_variant(-14) = 0: plans as before round 4 (no sgemm_dmas_kernel), (-15): back
 int g_mid_waves = 1;     // np_sgemm_set_variant(-18) = 0: ragged whole-K 64 x 64 products on four waves like the aligned ones, (-19): on eight (default; see DmasShape5)
 int g_mid_swizzle = 1;   // np_sgemm_set_variant(-16) = 0: sgemm_dmas_kernel walks its tiles row-major, (-17): XCD-aware bands (default)
@@ -2475,6 +2496,7 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
     Plan best{2, 0, 1, K, 1e300};
     Plan best_other{2, 0, 1, K, 1e300};   // the best plan WITHOUT the mid-size tiles (see the end of the function)
     Plan best_one{2, 0, 1, K, 1e300};     // the best whole-K mid-size plan whose tiles fit the machine in ONE round
+    Plan best_kq_split{2, 0, 1, K, 1e300};   // the best K-chunked plan on the k-quartered tiles
     const bool mid_ok = g_mid_tiles && !only_dma && N >= 4 && K >= 4 && !g_progress.counters;
     for (int c = 0; c < kCfgCount; ++c) {
         if (c == 0 && !dma_ok) continue;
@@ -2501,7 +2523,26 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
         const double whole = span((double)(tm * tn * batch), K) + T.extra;
         if (whole < best.t) best = Plan{c, 0, 1, K, whole};
         if (c >= kFirstMidCfg && (double)(tm * tn * batch) <= cus && whole < best_one.t) best_one = Plan{c, 0, 1, K, whole};
-        if (c >= kFirstKqCfg) continue;   // whole K only
+        if (c >= kFirstKqCfg) {
+            // ... or, for a handful of tiles under a very deep K (100 x 100 x 100000: four 64 x 64 tiles), the whole product cut
+            // along K into chunks that run as the batch dimension of one launch, folded by one np_reduce_axis like the
+            // register-staged forms below (tail_rows == all tile rows says so) — whose 64 x 64 tiles run at 0.52 of a CU's rate
+            // where these run at 0.84.  Chunks of whole 64-deep K-tiles, at least four of them.
+            if (!g_splitk || !g_kq_splitk || !splitk || batch != 1 || K < 2048 || tm * tn > (size_t)cus / 2) continue;
+            for (size_t S = 2; S <= 256; S = S < 8 ? S + 1 : S * 2) {
+                const size_t Kc = ((K + S - 1) / S + 63) / 64 * 64;
+                if (Kc < 256) break;
+                const size_t chunks = (K + Kc - 1) / Kc, rem = K - (chunks - 1) * Kc;
+                if (chunks < 2 || rem < 4) continue;
+                // the fold, timed alone (profiles/r05/gemm_deep_k_sweep.log): 3.6-4.0 us up to 32 chunks of 100 x 100 .. 300 x 300, 4.4-5.4 at 64,
+                // 6.7-10 at 128, 7-18 at 256
+                const double fold = 3.5e-6 + (double)((chunks + 1) * M * N * sizeof(float)) / hbm + (chunks > 32 ? 0.025e-6 * (double)(chunks - 32) : 0.0);
+                const double t = span((double)(tm * tn * chunks), Kc) + T.extra + fold + 0.5e-6;
+                if (t < best.t) best = Plan{c, (unsigned)tm, (unsigned)chunks, Kc, t};
+                if (t < best_kq_split.t) best_kq_split = Plan{c, (unsigned)tm, (unsigned)chunks, Kc, t};
+            }
+            continue;
+        }
         if (c >= kFirstMidCfg) {
             // K split S ways INSIDE the launch (sgemm_dmas_kernel's distributed fold; tail_rows == 0 and S > 1 says so): few
             // tiles and a long K.  All S workgroups of a tile are resident together: tiles x S within two per CU.  The fold
@@ -2555,7 +2596,19 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
     // (the two tests are made per candidate: a several-round plan that models a shade better than a one-round one must not
     // take its place and then fail the margin — 2000^3: 64 x 64 k-quartered tiles in four rounds 128.5 us, 128 x 128 tiles in one
     // 130.0, stream-K 134.2)
+    if (g_kq_splitk == 2 && best_kq_split.t < 1e299) return best_kq_split;   // (A/B: np_sgemm_set_variant(-24))
+    if (g_force_kq_split_S >= 2 && batch == 1 && splitk && K >= 512) {        // (A/B: np_sgemm_set_variant(-(30000 + 1000 * shape + S)))
+        const TileCfg &T = kCfg[kFirstKqCfg + g_force_kq_split_shape];
+        const size_t S = (size_t)g_force_kq_split_S, Kc = ((K + S - 1) / S + 63) / 64 * 64, chunks = (K + Kc - 1) / Kc;
+        if (chunks >= 2 && K - (chunks - 1) * Kc >= 4) return Plan{kFirstKqCfg + g_force_kq_split_shape, (unsigned)((M + T.bm - 1) / T.bm), (unsigned)chunks, Kc, 1e-6};
+    }
     const double rival = best_other.t < t_alt ? best_other.t : t_alt;
+    // The K-chunked k-quartered plans need no margin against the older forms' models either: theirs is within 5 % of the clock
+    // on every shape of profiles/r05/gemm_deep_k_sweep.log, while the chunked register-staged / LDS-DMA plans they replace run
+    // 5-27 % BEHIND their models (100 x 100 x 100000: 36.7 us modelled, 46.7 measured; 200 x 200 x 50000: 57.5 / 68).
+    // (hence the 12 % against a rival that is such a chunked plan: 100 x 100 x 10000 modelled 9.9 against 9.2, measured 8.6 against 12.9)
+    const bool rival_chunked = best_other.t <= t_alt && best_other.tail_rows > 0;
+    if (best_kq_split.t < 1e299 && best_kq_split.t <= best.t && best_kq_split.t < (rival_chunked ? 1.12 : 1.0) * rival) return best_kq_split;
     if (best.t < 0.93 * rival) return best;
     if (best_one.t < 1.001 * rival) return best_one;
     return best_other;
@@ -2771,7 +2824,7 @@ void launch_kq_any(int shape, const GemmArgs &g, dim3 grid, bool edge, bool vec,
 }
 
 int launch_kq(int shape, GemmArgs g, unsigned batch, bool vec) {
-    if (shape < 0 || shape >= kKqShapeCount || g.K < 4 || g.K_last || g.n_store || g.progress) return 1;
+    if (shape < 0 || shape >= kKqShapeCount || g.K < 4 || (g.K_last && g.K_last < 4) || g.n_store || g.progress) return 1;
     const unsigned bm = 16 * kKqShapes[shape].tm, bn = 16 * kKqShapes[shape].tn;
     g.tiles_m = (g.M + bm - 1) / bm;
     g.tiles_n = (g.N + bn - 1) / bn;
@@ -2779,7 +2832,14 @@ int launch_kq(int shape, GemmArgs g, unsigned batch, bool vec) {
     if (tiles > 0x7fffffffu) return 1;
     if (((size_t)g.M * g.lda + g.K) * 4 >= (size_t(1) << 32) || ((size_t)g.K * g.ldb + g.N) * 4 >= (size_t(1) << 32)) return 1;   // 32-bit byte offsets
     g.swizzle = (g_kq_swizzle && g.tiles_m >= 8 && tiles >= 64) ? 4 : 0;   // XCD-aware bands, as launch_dmas
-    const dim3 grid((unsigned)tiles, 1, batch);
+    dim3 grid((unsigned)tiles, 1, batch);
+    if (g.k_chunks) {   // (launch_plan: the batch is K-chunks of one product) chunk-major over the XCDs
+        if (g.k_chunks != batch || tiles * batch > 0x7fffffffu) g.k_chunks = 0;
+        else {
+            g.swizzle = 0;
+            grid = dim3((unsigned)(tiles * batch), 1, 1);
+        }
+    }
     const bool edge = g.M % bm || g.N % bn;
     launch_kq_any(shape, g, grid, edge, vec, np::stream(), std::make_integer_sequence<int, kKqShapeCount>{});
     NP_LAUNCH_CHECK("sgemm_kq_kernel");
@@ -2893,6 +2953,7 @@ int launch_plan(const Plan &p, GemmArgs g, size_t batch, bool vec) {
     // chunk rides in the same launch as the last batch entry (K_last): as a launch of its own it
     // would cost a whole extra work-unit time on a mostly idle machine.
     part.K_last = (unsigned)rem;
+    if (p.cfg >= kFirstKqCfg && g_kq_chunk_major) part.k_chunks = (unsigned)chunks;
     if (int rc = launch_cfg(p.cfg, part, (unsigned)chunks, vec && rem % 4 == 0)) return rc;
     return np_reduce_axis(NP_SUM, W, 1, chunks, m2 * N, g.C + m1 * N, 0);
 }
@@ -2910,6 +2971,7 @@ int launch_sgemm_ld(size_t batch, size_t M, size_t N, size_t K, const float *A, 
     g.stride_a = sa; g.stride_b = sb; g.stride_c = sc;
     g.tiles_m = g.tiles_n = 0;
     g.prio_period = 0;
+    g.k_chunks = 0;
     g.probe = g_probe;
     g.progress = g_progress.counters;
     g.piece_base = g_progress.base;
@@ -3093,6 +3155,9 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
     }
     // measured (profiles/r01/skinny_gemm.log): wins for one or two row tiles and N > 16 (32 x 64 x 2e6: 0.334 -> 0.199 ms,
     // 32 x 32 x 2e6: 0.183 -> 0.114); at four row tiles, or N <= 16 (the 16x16x4 tile), the LDS-staged kernel below is ahead
+    // (both K-chunked forms below were sized on K ~ 2e6: chunks of >= 1024 / 2048 inner elements.  At K ~ 1e5 that is ~50 workgroups on
+    // 256 CUs — 64 x 64 x 100000: 89 us for 51 MB — and the planner's K-chunked k-quartered tiles, 256 of them, take it)
+    if (g_thin_underfilled_to_planner && M > 16 && M <= 64 && N > 16 && K >= 16384 && K % 4 == 0 && N % 4 == 0 && K / 1024 < (size_t)np::num_cus() * 2) return 1;
     if (M > 16 && M <= 64 && N > 16 && K >= 16384) {
         const size_t row_tiles = (M + 31) / 32;
         size_t chunks = (target * 4 * 2 + row_tiles - 1) / row_tiles;      // wave-chunks
@@ -3310,6 +3375,13 @@ int np_sgemm_debug_plan(size_t M, size_t N, size_t K, size_t batch, int cus, dou
 }
 
 int np_sgemm_set_variant(int variant) {
+    if (variant <= -30000) {
+        const int code = -variant - 30000;
+        if (code / 1000 >= kKqShapeCount) return np::fail(NP_ERR_INVALID, "np_sgemm_set_variant: -(30000 + 1000 * shape + S): no such shape");
+        g_force_kq_split_shape = code / 1000;
+        g_force_kq_split_S = code % 1000;
+        return NP_OK;
+    }
     if (variant <= -999) {   // -(1000 + 100 * shape + S): sgemm_dmas_kernel with that tile shape and S K-chunks wherever it applies; -999: off
         if (variant == -999) {
             g_force_dmas_shape = -1;
@@ -3343,6 +3415,22 @@ int np_sgemm_set_variant(int variant) {
         }
         if (variant == -20 || variant == -21) {
             g_kq_tiles = variant == -21;
+            return NP_OK;
+        }
+        if (variant == -27 || variant == -28) {
+            g_thin_underfilled_to_planner = variant == -28;
+            return NP_OK;
+        }
+        if (variant == -25 || variant == -26) {
+            g_kq_chunk_major = variant == -26;
+            return NP_OK;
+        }
+        if (variant == -24) {   // (A/B) the K-chunked k-quartered plan wherever one exists
+            g_kq_splitk = 2;
+            return NP_OK;
+        }
+        if (variant == -22 || variant == -23) {   // -22: deep-K products on the register-staged tiles as before round 5, -23: back (the K-chunked k-quartered plans)
+            g_kq_splitk = variant == -23;
             return NP_OK;
         }
         if (variant == -14 || variant == -15) {   // -14: no mid-size LDS-DMA tiles (the plans of round 3), -15: back

@@ -251,8 +251,17 @@ def test_gemm_planner_choices_on_a_256_cu_device():
     assert p["S"] >= 2 or p["streamk"] or p["tail_rows"] > 0
     for shape in ((2560,) * 3, (3072,) * 3):   # tile counts that leave a ragged last round: stream-K
         assert plan(*shape)["streamk"], shape
-    p = plan(100, 100, 100000)         # a dot-product-like shape: the register-staged tiles with K cut into a second launch's fold
-    assert p["cfg"] == 2 and p["tail_rows"] > 0 and p["S"] >= 64
+    # a dot-product-like shape: K cut into chunks on the k-quartered tiles, one workgroup per CU, folded by a second launch
+    # (round 5, profiles/r05/gemm_deep_k_ab.log; until then the register-staged 64 x 64 tiles in 128 chunks)
+    for shape in ((100, 100, 100000), (128, 128, 65536), (64, 64, 100000), (256, 256, 32768), (300, 300, 20000)):
+        p = plan(*shape)
+        assert p["cfg"] >= 6 and p["tail_rows"] > 0 and p["S"] >= 2 and not p["streamk"], (shape, p)
+    lib.np_sgemm_set_variant(-22)
+    try:
+        p = plan(100, 100, 100000)
+        assert p["cfg"] == 2 and p["tail_rows"] > 0 and p["S"] >= 64
+    finally:
+        lib.np_sgemm_set_variant(-23)
     p = plan(1024, 1024, 1024, 512)    # BASELINE config 5: a batch is never split along K
     assert p["S"] == 1 and p["tail_rows"] == 0 and not p["streamk"]
     assert lib.np_sgemm_debug_plan(0, 4, 4, 1, 256, out) != 0 and lib.np_sgemm_debug_plan(4, 4, 4, 1, 256, None) != 0
@@ -275,8 +284,8 @@ def test_gemm_planner_is_total_on_random_shapes():
             assert tail == 0 and not sk and (S == 1 or 3 <= cfg <= 5), (m, n, k, batch, list(out))
         if k < 4:
             assert cfg < 6, (m, n, k, list(out))
-        if cfg >= 6:      # whole K only
-            assert S == 1 and tail == 0, (m, n, k, list(out))
+        if cfg >= 6:      # whole K, or (single deep-K products of a few tiles) every tile row cut into K-chunks
+            assert (S == 1 and tail == 0) or (batch == 1 and S >= 2 and tail > 0 and k >= 2048), (m, n, k, list(out))
 
 
 def test_comm_entry_points_without_a_communicator_or_device():

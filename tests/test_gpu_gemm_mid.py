@@ -118,3 +118,66 @@ def test_k_quartered_tiles(shape, hip, oracle):
     fin = np.isfinite(want)
     assert np.allclose(got[fin], want[fin], rtol=0, atol=1e-4)
     assert lib.np_sync() == 0, lib.np_last_error()
+
+
+KQ_CHUNKED = [(100, 100, 100000), (64, 64, 30000), (100, 100, 100001), (96, 160, 7002), (20, 40, 50000), (130, 68, 4099), (200, 200, 5000), (33, 35, 2049),
+              (64, 36, 16384), (48, 48, 2051), (100, 100, 512), (256, 256, 8192), (300, 300, 2500), (17, 17, 65537)]
+
+
+@pytest.mark.parametrize("shape,S", [(2, 63), (2, 5), (1, 16), (1, 7), (0, 9), (3, 32), (4, 32), (5, 12), (6, 3), (2, 255)])
+def test_k_quartered_tiles_over_k_chunks(shape, S, hip, oracle):
+    """Deep-K products of a few tiles: K cut into chunks that run as ONE launch of sgemm_kq_kernel (chunk-major over the XCDs:
+    GemmArgs::k_chunks) and are folded by np_reduce_axis — forced through np_sgemm_set_variant(-(30000 + 1000 * shape + S)) for
+    every tile shape, chunk counts that are not multiples of eight, remainder chunks of every length (a remainder under four
+    inner elements falls through to the older tiles), rows that are not float4-loadable.  Same bars as above; the chunk-major and
+    the tile-major launch (np_sgemm_set_variant(-25)) compute the same chunks, so their results are bit-identical."""
+    lib = load()
+    for (m, n, k) in KQ_CHUNKED:
+        A = synth.uniform((m, k), 71, -1.0, 1.0)
+        B = synth.uniform((k, n), 72, -1.0, 1.0)
+        a, b, c = hip.DeviceArray.from_host(A), hip.DeviceArray.from_host(B), hip.DeviceArray((m, n))
+        check(lib.np_sgemm_set_variant(-(30000 + 1000 * shape + S)))
+        try:
+            runs = []
+            for major in (-26, -26, -25):
+                check(lib.np_sgemm_set_variant(major))
+                hip.fill(c, float("nan"))
+                hip.sgemm(a, b, out=c)
+                runs.append(c.to_host().copy())
+        finally:
+            check(lib.np_sgemm_set_variant(-26))
+            check(lib.np_sgemm_set_variant(-30000))
+        want = A.astype(np.float64) @ B.astype(np.float64)
+        scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+        assert not np.isnan(runs[0]).any(), (m, n, k)
+        assert (np.abs(runs[0] - want) <= 1e-6 * scale).all(), (m, n, k, float((np.abs(runs[0] - want) / scale).max()))
+        for r in runs[1:]:
+            assert (r.view(np.uint32) == runs[0].view(np.uint32)).all(), (m, n, k, "not deterministic / launch order matters")
+        assert (np.abs(runs[0] - oracle.matmul(A, B)) <= 1e-5 * scale).all(), (m, n, k, "vs the oracle")
+    assert lib.np_sync() == 0, lib.np_last_error()
+
+
+def test_deep_k_products_take_the_k_chunked_plan(hip, oracle):
+    """What the planner does by itself with the deep-K class (profiles/r05/gemm_deep_k_ab.log): the K-chunked k-quartered plan,
+    also for the 17..64-row shapes the thin K-chunk kernels leave underfilled; non-finite values in one chunk stay in the
+    elements they belong to."""
+    lib = load()
+    out = (C.c_double * 11)()
+    for (m, n, k) in [(100, 100, 100000), (128, 128, 65536), (64, 64, 100000), (200, 200, 50000), (32, 64, 100000), (100, 100, 100001), (160, 96, 25000)]:
+        check(lib.np_sgemm_debug_plan(m, n, k, 1, 0, out))
+        assert out[0] >= 6 and out[1] > 0 and out[2] >= 2, (m, n, k, list(out))
+        A = synth.uniform((m, k), 73, -1.0, 1.0)
+        B = synth.uniform((k, n), 74, -1.0, 1.0)
+        A[3, k // 2] = np.inf
+        B[k - 1, 1] = np.nan
+        a, b, c = hip.DeviceArray.from_host(A), hip.DeviceArray.from_host(B), hip.DeviceArray((m, n))
+        hip.fill(c, 5.0)
+        hip.sgemm(a, b, out=c)
+        got = c.to_host()
+        with np.errstate(invalid="ignore", over="ignore"):
+            want = A.astype(np.float64) @ B.astype(np.float64)
+        assert (np.isnan(got) == np.isnan(want)).all() and (np.isinf(got) == np.isinf(want)).all(), (m, n, k)
+        fin = np.isfinite(want)
+        scale = np.abs(np.nan_to_num(A, posinf=0.0)).astype(np.float64) @ np.abs(np.nan_to_num(B, nan=0.0)).astype(np.float64)
+        assert (np.abs(got[fin] - want[fin]) <= 1e-6 * scale[fin]).all(), (m, n, k)
+    assert lib.np_sync() == 0, lib.np_last_error()

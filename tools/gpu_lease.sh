@@ -91,6 +91,8 @@ r_sweeps() {
     timeout 200 python tools/arg_sweep.py > "$O/arg_sweep.log" 2>&1; cat "$O/arg_sweep.log"
     timeout 200 python tools/gemm_thin_k_ab.py > "$O/gemm_thin_k_ab.log" 2>&1; cat "$O/gemm_thin_k_ab.log"
     timeout 200 python tools/reduce_small_ab.py > "$O/reduce_small_ab.log" 2>&1; cut -c1-300 "$O/reduce_small_ab.log"
+    timeout 300 python tools/gemm_deep_k_ab.py > "$O/gemm_deep_k_ab.log" 2>&1; cut -c1-200 "$O/gemm_deep_k_ab.log"
+    timeout 300 python tools/gemm_deep_k_sweep.py > "$O/gemm_deep_k_sweep.log" 2>&1; tail -5 "$O/gemm_deep_k_sweep.log"
 }
 
 r_cleanbuild() {
@@ -118,6 +120,7 @@ r_fuzz() {
     timeout 900 python tools/fuzz_parity.py 400 6 2>&1 | tail -3 > "$O/fuzz_parity.log"; cat "$O/fuzz_parity.log"
     timeout 400 python tools/gemm_mid_fuzz.py 400 2 2>&1 | tail -3 > "$O/gemm_mid_fuzz.log"; cat "$O/gemm_mid_fuzz.log"
     timeout 400 python tools/fused_static_fuzz.py 400 2 2>&1 | tail -3 > "$O/fused_static_fuzz.log"; cat "$O/fused_static_fuzz.log"
+    timeout 400 python tools/gemm_deep_k_fuzz.py 200 3 2>&1 | tail -4 > "$O/gemm_deep_k_fuzz.log"; cat "$O/gemm_deep_k_fuzz.log"
 }
 
 case "$RECIPE" in
