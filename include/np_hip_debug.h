@@ -68,7 +68,11 @@ int np_comm_debug_loopback(void *dev_scratch, size_t bytes);
  * -18 / -19 = ragged whole-K 64 x 64 products on four / eight waves, -20 / -21 = plans without / with the k-quartered tiles
  * (sgemm_kq_kernel); -(1000 + 100 * shape + S) forces sgemm_dmas_kernel's tile `shape` with K split S ways wherever it applies,
  * -(2000 + shape) forces sgemm_kq_kernel's tile `shape` (0 .. 6: 48x48, 32x32, 64x64, 48x32, 64x32, 64x48, 80x48), -999 ends
- * either forcing).  All of them are process-wide setters for A/B measurements and tests: results stay within the same bounds. */
+ * either forcing; round 5, deep-K products of a few tiles: -22 / -23 = plans without / with K-chunks on the k-quartered tiles,
+ * -24 = that plan wherever one exists, -25 / -26 = its launch tile-major / chunk-major over the XCDs, -(30000 + 1000 * shape + S)
+ * forces single products of K >= 512 onto S K-chunks of k-quartered tile `shape` (-30000: off), -(40 + q), q = 0 .. 59: a thin
+ * K-chunk launch (17 .. 2047 rows, N <= 64, K >= 16384) of fewer than q / 4 workgroups per CU goes to the planner instead
+ * (0 = never, as before round 5; default 59).  All of them are process-wide setters for A/B measurements and tests: results stay within the same bounds. */
 int np_runtime_set_variant(int variant);   /* how host-result calls wait: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag, 2 = spin on the result itself (default) */
 int np_sgemm_set_variant(int variant);
 /* debug: the planner's choice for one dense, aligned M x N x K product on a device of `cus` CUs (0 = the current device; any

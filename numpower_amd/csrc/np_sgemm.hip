@@ -2400,7 +2400,15 @@ constexpr CfgTable kCfgTable = make_cfg_table();
 constexpr const TileCfg (&kCfg)[kCfgCount] = kCfgTable.c;
 int g_kq_tiles = 1;      // np_sgemm_set_variant(-20) = 0: plans without sgemm_kq_kernel, (-21): back
 int g_force_kq_split_shape = 0, g_force_kq_split_S = 0;   // np_sgemm_set_variant(-(30000 + 1000 * shape + S)): single products of K >= 512 as S K-chunks on that k-quartered shape (A/B); -30000: off
-int g_thin_underfilled_to_planner = 1;   // np_sgemm_set_variant(-27) = 0: 17..64 x 17..64 x (16384 <= K < ~5e5) on the thin K-chunk kernels as before round 5, (-28): to the planner (default)
+// The two K-chunked thin forms (17 .. 2047 rows, N <= 64, K >= 16384) were sized on K ~ 2e6: chunks of >= 1024 / 2048 inner elements.
+// At K ~ 1e5 that is ~50 workgroups on 256 CUs — 64 x 64 x 100000: 89 us for 51 MB — so a launch of fewer than q / 4 workgroups
+// per CU is left to the planner (its K-chunked k-quartered tiles: 16.5 us).  np_sgemm_set_variant(-(40 + q)), q = 0: never.
+// Measured at q = 0, 1, 2, 4, 8, 59 on 16 shapes (profiles/r05/gemm_thin_fill_ab.log): the planner is level or ahead at EVERY fill —
+// 64 x 64 x 400000 (196 workgroups) 94 -> 40 us, 32 x 32 x 1000000 (244) 62 -> 46, 32 x 64 x 2000000 (489) 190 -> 149, 1500 x 32 x 20000
+// 89 -> 25 — so q = 59 (the largest the variant encodes): these two forms now only run launches of ~15 workgroups per CU and more
+// (K beyond ~1.5e7).
+int g_thin_underfilled_to_planner = 59;
+inline bool thin_to_planner(size_t workgroups) { return workgroups * 4 < (size_t)g_thin_underfilled_to_planner * (size_t)np::num_cus(); }
 int g_kq_chunk_major = 1;   // np_sgemm_set_variant(-25) = 0: K-chunked k-quartered launches tile-major (blockIdx.z = chunk), (-26): chunk-major over the XCDs (default)
 int g_kq_splitk = 1;     // np_sgemm_set_variant(-22) = 0: no K-chunked plans on the k-quartered tiles (deep-K products as before round 5: the register-staged tiles), (-23): back
 int g_mid_tiles = 1;   // np_sgemm_set_variant(-14) = 0: plans as before round 4 (no sgemm_dmas_kernel), (-15): back
@@ -3155,9 +3163,6 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
     }
     // measured (profiles/r01/skinny_gemm.log): wins for one or two row tiles and N > 16 (32 x 64 x 2e6: 0.334 -> 0.199 ms,
     // 32 x 32 x 2e6: 0.183 -> 0.114); at four row tiles, or N <= 16 (the 16x16x4 tile), the LDS-staged kernel below is ahead
-    // (both K-chunked forms below were sized on K ~ 2e6: chunks of >= 1024 / 2048 inner elements.  At K ~ 1e5 that is ~50 workgroups on
-    // 256 CUs — 64 x 64 x 100000: 89 us for 51 MB — and the planner's K-chunked k-quartered tiles, 256 of them, take it)
-    if (g_thin_underfilled_to_planner && M > 16 && M <= 64 && N > 16 && K >= 16384 && K % 4 == 0 && N % 4 == 0 && K / 1024 < (size_t)np::num_cus() * 2) return 1;
     if (M > 16 && M <= 64 && N > 16 && K >= 16384) {
         const size_t row_tiles = (M + 31) / 32;
         size_t chunks = (target * 4 * 2 + row_tiles - 1) / row_tiles;      // wave-chunks
@@ -3168,6 +3173,7 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
             kc = (kc + 31) / 32 * 32;
             chunks = (K + kc - 1) / kc;
             const size_t groups = (chunks + 3) / 4;
+            if (thin_to_planner(row_tiles * groups)) return 1;
             if (groups <= 65535) {
                 np::Scratch partial;
                 if (int rc = partial.alloc(chunks * M * N * sizeof(float))) return rc;
@@ -3192,6 +3198,7 @@ int launch_thin_nv(size_t M, size_t N, size_t K, const float *A, const float *B,
             size_t kc = (K + chunks - 1) / chunks;
             kc = (kc + 63) / 64 * 64;
             chunks = (K + kc - 1) / kc;
+            if (thin_to_planner(blocks * chunks)) return 1;
             np::Scratch partial;
             if (int rc = partial.alloc(chunks * M * N * sizeof(float))) return rc;
             const dim3 grid((unsigned)blocks, (unsigned)chunks);
@@ -3399,6 +3406,10 @@ int np_sgemm_set_variant(int variant) {
         g_force_dmas_S = code % 100;
         return NP_OK;
     }
+    if (variant <= -40 && variant >= -99) {   // -(40 + q): see g_thin_underfilled_to_planner
+        g_thin_underfilled_to_planner = -variant - 40;
+        return NP_OK;
+    }
     if (variant <= -100) {   // -(100 + p): priority alternation between co-resident workgroups, p K-tiles per phase (p = 0: off)
         g_prio_period = (unsigned)(-variant - 100);
         g_prio_min_k = g_prio_period == 16 ? 2048u : 0u;
@@ -3415,10 +3426,6 @@ int np_sgemm_set_variant(int variant) {
         }
         if (variant == -20 || variant == -21) {
             g_kq_tiles = variant == -21;
-            return NP_OK;
-        }
-        if (variant == -27 || variant == -28) {
-            g_thin_underfilled_to_planner = variant == -28;
             return NP_OK;
         }
         if (variant == -25 || variant == -26) {

@@ -1,7 +1,7 @@
 """Deep-K products of a few tiles (100 x 100 x 100000: four 64 x 64 tiles under 1563 K-tiles): the plan of rounds 1-4 cuts K into
 up to 128 chunks that run as the batch of the register-staged 64 x 64 kernel (cfg 2) and folds them with np_reduce_axis; round 5
-runs the same chunks on the k-quartered tiles (sgemm_kq_kernel, operands straight from memory).  np_sgemm_set_variant(-22) and (-27): the
-old plans, (-23) and (-28): the default planner, (-24): the K-chunked k-quartered plan wherever one exists.  Same box, alternating; every
+runs the same chunks on the k-quartered tiles (sgemm_kq_kernel, operands straight from memory).  np_sgemm_set_variant(-22) and (-40): the
+old plans, (-23) and (-99): the default planner, (-24): the K-chunked k-quartered plan wherever one exists.  Same box, alternating; every
 form's result is checked against fp64 first (1e-6 of sum |a||b|).
 Usage: python tools/gemm_deep_k_ab.py"""
 import ctypes as C
@@ -41,7 +41,7 @@ for (m, n, k) in SHAPES:
     for rnd in range(3):
         for v in (-22, -23, -24):
             check(lib.np_sgemm_set_variant(v))
-            check(lib.np_sgemm_set_variant(-27 if v == -22 else -28))   # (the thin K-chunk kernels' underfilled shapes: old / new)
+            check(lib.np_sgemm_set_variant(-40 if v == -22 else -(40 + 59)))   # (the thin K-chunk kernels' underfilled shapes: old / new)
             if rnd == 0:
                 check(lib.np_sgemm_debug_plan(m, n, k, 1, 0, out))
                 plans[v] = "cfg %d rows %d S %d model %.1f" % (out[0], out[1], out[2], out[3])

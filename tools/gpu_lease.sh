@@ -93,6 +93,7 @@ r_sweeps() {
     timeout 200 python tools/reduce_small_ab.py > "$O/reduce_small_ab.log" 2>&1; cut -c1-300 "$O/reduce_small_ab.log"
     timeout 300 python tools/gemm_deep_k_ab.py > "$O/gemm_deep_k_ab.log" 2>&1; cut -c1-200 "$O/gemm_deep_k_ab.log"
     timeout 300 python tools/gemm_deep_k_sweep.py > "$O/gemm_deep_k_sweep.log" 2>&1; tail -5 "$O/gemm_deep_k_sweep.log"
+    timeout 300 python tools/gemm_thin_fill_ab.py > "$O/gemm_thin_fill_ab.log" 2>&1; cut -c1-200 "$O/gemm_thin_fill_ab.log"
 }
 
 r_cleanbuild() {
