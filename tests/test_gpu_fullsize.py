@@ -283,6 +283,51 @@ def test_elementwise_beyond_2p31_elements(hip):
         d.free()
 
 
+def test_deep_k_matmul_with_operands_beyond_4gib(hip):
+    """100 x 100 x 11 000 000: 4.4 GB per operand (the reference's `unsigned int` byte sizes stop at 4 GiB, gpu_alloc.c:11).  The
+    planner answers with K-chunks on the k-quartered tiles, whose 32-bit byte offsets do not reach that far: the launcher says so
+    and the chunks run on the register-staged tiles (64-bit addressing) under the same fold.  Built on the device from values
+    whose partial sums fp32 holds EXACTLY inside a chunk (eighths, sums below 2^21; constant terms that are not exact lose the same
+    half-ulp at every step — 0.3 % with 0.5 + i / 128 — which is fp32 arithmetic, not addressing): A[i, :] = 1 + (i mod 4) / 4,
+    B[:, j] = 1 + (j mod 2) / 2, one element of A in the row that crosses byte 2^32 and one row of B beyond it scaled by 1024:
+    every element of the result has a closed form, to the fold's last roundings."""
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    lib = load()
+    D = hip
+    m = n = 100
+    k = 11_000_000
+    out = (C.c_double * 11)()
+    check(lib.np_sgemm_debug_plan(m, n, k, 1, 0, out))
+    assert out[0] >= 6 and out[1] > 0 and out[2] >= 2, list(out)
+    a, b, c = D.DeviceArray((m * k,)), D.DeviceArray((k * n,)), D.DeviceArray((m, n))
+    ai = 1.0 + (np.arange(m) % 4) / 4.0
+    rj = 1.0 + (np.arange(n) % 2) / 2.0
+    for i in range(m):
+        D.fill(a.view(i * k, (k,)), float(ai[i]))
+    D.fill(b, 0.0)
+    rowvec = D.DeviceArray.from_host(rj.astype(np.float32))
+    D.binary("add", b, "full", rowvec, "row", k, n, out=b)       # every row of B = rj
+    big_row = (1024.0 * rj).astype(np.float32)
+    check(lib.np_memcpy_h2d(b.view((k - 1) * n, (n,)).ptr, big_row.ctypes.data, big_row.nbytes))   # (k - 1) * 400 bytes > 2^32
+    D.fill(a.view(99 * k + k - 5, (1,)), 1024.0)             # row 99 starts at byte 4.36e9 > 2^32
+    assert b.view(5 * n, (n,)).to_host().tolist() == rj.tolist()
+    D.fill(c, float("nan"))
+    check(lib.np_sgemm(m, n, k, a.ptr, b.ptr, c.ptr))
+    got = c.to_host().astype(np.float64)
+    want = np.outer(ai, rj) * (k - 1) + np.outer(ai, 1024.0 * rj)
+    want[99, :] += (1024.0 - ai[99]) * rj
+    assert np.isfinite(got).all()
+    assert (np.abs(got - want) <= 1e-5 * want).all(), float((np.abs(got - want) / want).max())
+    # the two scaled entries are 5e-5 of an element: an operand read 2^32 bytes too low would miss them
+    plain = np.outer(ai, rj) * k
+    assert (np.abs(got - plain)[99, :] > 3e-5 * plain[99, :]).all() and (np.abs(got - plain)[:99, :] > 3e-5 * plain[:99, :]).all()
+    assert lib.np_sync() == 0, lib.np_last_error()
+    for d in (a, b, c, rowvec):
+        d.free()
+    del C
+
+
 def test_argreduce_beyond_2p31_elements(hip):
     """np_argreduce with more than 2^31 elements along one axis and in all (the reference's `int` counts stop there,
     calculation.c:73-194): the grid-stride row form on one 8.6 GB row, the wave-per-row form on 2^21 + 4 rows of 1024, and
