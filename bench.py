@@ -415,10 +415,11 @@ def bench_mid(dist: Dist, steps, warmup):
     from numpower_amd._lib import check
     lib = load()
     out = {}
-    for n in (768, 1000, 1024):
-        A = synth.uniform((n, n), 31, -1.0, 1.0)
-        B = synth.uniform((n, n), 32, -1.0, 1.0)
-        dA, dB, dC = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B), D.DeviceArray((n, n))
+    # ... and (round 5) a deep-K product of a few tiles, 100 x 100 x 100000: K-chunks on the k-quartered tiles
+    for (m, n, k) in ((768,) * 3, (1000,) * 3, (1024,) * 3, (100, 100, 100000)):
+        A = synth.uniform((m, k), 31, -1.0, 1.0)
+        B = synth.uniform((k, n), 32, -1.0, 1.0)
+        dA, dB, dC = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B), D.DeviceArray((m, n))
         # a launch is ~20 us: K of them after an upload are over before the clock has come up (1024^3: 24.5 us for the first
         # hundred, 22.7 a moment later, profiles/r04/gemm_mid_sweep_forced2.log).  Both are reported: `us_first_launches` (what a
         # caller's first product costs) and `us_per_launch` after 0.25 s of the same product (what the 500th costs).
@@ -436,8 +437,8 @@ def bench_mid(dist: Dist, steps, warmup):
         ref = A.astype(np.float64) @ B.astype(np.float64)
         scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
         err = float((np.abs(got - ref) / scale).max())
-        tf = 2.0 * n ** 3 / us / 1e6
-        out["matmul_%d" % n] = {"us_per_launch": us, "us_first_launches": us_first, "TFLOPs": tf, "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
+        tf = 2.0 * m * n * k / us / 1e6
+        out["matmul_%d" % n if m == n == k else "matmul_%dx%dx%d" % (m, n, k)] = {"us_per_launch": us, "us_first_launches": us_first, "TFLOPs": tf, "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS,
                                                                               "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None},
                                 "parity_max_norm_err_vs_fp64": err, "parity_ok": bool(err <= 1e-6)}
         for d in (dA, dB, dC):
@@ -1050,7 +1051,7 @@ def _summary(result, extras):
            "c3c_exp_plus_row_fused_frac_hbm": frac("exp_plus_row_fused"),
            "c3c_exp_plus_col_fused_frac_hbm": frac("exp_plus_col_fused"),
            "c4_sum_axis0_frac_hbm": frac("sum_axis0")}
-    for key in ("matmul_768", "matmul_1000", "matmul_1024"):
+    for key in ("matmul_768", "matmul_1000", "matmul_1024", "matmul_100x100x100000"):
         e = extras.get(key)
         if isinstance(e, dict) and "TFLOPs" in e:
             out[key + "_TFLOPs"] = _compact(e["TFLOPs"])
