@@ -267,6 +267,28 @@ def test_gemm_planner_choices_on_a_256_cu_device():
     assert lib.np_sgemm_debug_plan(0, 4, 4, 1, 256, out) != 0 and lib.np_sgemm_debug_plan(4, 4, 4, 1, 256, None) != 0
 
 
+def test_gemm_deep_k_switches_validate_and_restore():
+    """The round-5 planner switches of include/np_hip_debug.h are host state: each code is accepted or refused as documented, and
+    the forced K-chunk plan shows in np_sgemm_debug_plan exactly while it is on (no device needed)."""
+    from numpower_amd import _lib
+    lib = _lib.load()
+    lib.np_last_error.restype = C.c_char_p
+    out = (C.c_double * 11)()
+    assert lib.np_sgemm_set_variant(-(30000 + 1000 * 7 + 4)) != 0 and b"no such shape" in lib.np_last_error()
+    try:
+        assert lib.np_sgemm_set_variant(-(30000 + 1000 * 1 + 16)) == 0          # 32 x 32 tiles, 16 chunks
+        assert lib.np_sgemm_debug_plan(512, 512, 4096, 1, 256, out) == 0
+        assert (int(out[0]), int(out[1]), int(out[2])) == (7, 16, 16), list(out)
+        assert lib.np_sgemm_debug_plan(512, 512, 4096, 4, 256, out) == 0       # batches are never K-chunked
+        assert int(out[1]) == 0
+    finally:
+        assert lib.np_sgemm_set_variant(-30000) == 0
+    assert lib.np_sgemm_debug_plan(512, 512, 4096, 1, 256, out) == 0
+    assert (int(out[0]), int(out[1]), int(out[2])) == (7, 0, 1), list(out)
+    for code in (-22, -23, -24, -23, -25, -26, -40, -(40 + 59)):
+        assert lib.np_sgemm_set_variant(code) == 0, code
+
+
 def test_gemm_planner_is_total_on_random_shapes():
     """Whatever the shape, np_sgemm_debug_plan answers with a plan the launchers know: a cfg in range, a positive finite model
     time, no second-launch fold or stream-K for batches, no k-quartered tiles below K = 4 — 3000 random shapes from 1 to 20000 per dimension."""
