@@ -685,21 +685,39 @@ def bench_extras(dist: Dist, steps, warmup):
     del e64
     tmp.free()
     # SURVEY.md section 8(f) rows 2 and 4 at the sizes of tools/misc_sweep.py: argmax of the flat 1e8 array
-    # (4 B/elem, calculation.c:73-194), variance's two passes (np_moments: 8 B/elem, statistics.c:117-130) and
+    # (4 B/elem, calculation.c:73-194), variance in one read (np_moments: 4 B/elem, statistics.c:88-130), the weighted average's two sums (8 B/elem, :131-154) and
     # dot(matrix, vector) with few long rows (10 x 1e7: 4 (M K + K + M) bytes, linalg.c:367-386)
     idx = D.DeviceArray((1,))
     r = hbm_case("argmax flat 1e8 (8f row 2)", 4.0 * N, lambda: check(lib.np_argreduce(1, da.ptr, 1, N, 1, idx.ptr)), steps, warmup, dist)
     r["parity_ok"] = bool(idx.to_host()[0] == np.float32(np.argmax(a)))
     ex["argmax_1e8"] = r
     mean, m2 = C.c_float(), C.c_float()
-    r = hbm_case("moments (variance) 1e8 (8f row 2)", 8.0 * N,
+    r = hbm_case("moments (variance) 1e8, one read (8f row 2)", 4.0 * N,
                  lambda: check(lib.np_moments(da.ptr, N, C.byref(mean), C.byref(m2))), steps, warmup, dist)
     a64 = a.astype(np.float64)
     var64 = float(((a64 - a64.mean()) ** 2).sum())
     r["parity_rel_err_vs_fp64"] = abs(m2.value - var64) / var64
     r["parity_ok"] = bool(r["parity_rel_err_vs_fp64"] <= 1e-5 and abs(mean.value - a64.mean()) <= 1e-5 * a64.mean())
+    # the same values moved to 1e4 (large mean, small spread) on the device and read back: fp64 of the very array the device holds
+    dsc = D.DeviceArray.from_host(np.array([1e4], dtype=np.float32))
+    D.binary("add", da, "full", dsc, "scalar", 1, N, out=do)
+    dsc.free()
+    check(lib.np_moments(do.ptr, N, C.byref(mean), C.byref(m2)))
+    s64 = do.to_host().astype(np.float64)
+    svar = float(((s64 - s64.mean()) ** 2).sum())
+    r["large_mean_rel_err_vs_fp64"] = abs(m2.value - svar) / svar
+    r["parity_ok"] = bool(r["parity_ok"] and r["large_mean_rel_err_vs_fp64"] <= 1e-5)
+    del s64
     ex["moments_1e8"] = r
-    del a64
+    saw, sw = C.c_float(), C.c_float()
+    r = hbm_case("weighted sums (average) 1e8, one read of each (8f row 2)", 8.0 * N,
+                 lambda: check(lib.np_weighted_sums(da.ptr, db.ptr, N, C.byref(saw), C.byref(sw))), steps, warmup, dist)
+    b64 = b.astype(np.float64)
+    r["parity_rel_err_vs_fp64"] = max(abs(saw.value - float((a64 * b64).sum())) / float((a64 * b64).sum()),
+                                      abs(sw.value - float(b64.sum())) / float(b64.sum()))
+    r["parity_ok"] = bool(r["parity_rel_err_vs_fp64"] <= 1e-5)
+    ex["weighted_sums_1e8"] = r
+    del a64, b64
     Mv, Kv = 10, 10_000_000
     yv = D.DeviceArray((Mv,))
     r = hbm_case("sgemv 10 x 1e7 (8f row 4)", 4.0 * (Mv * Kv + Kv + Mv), lambda: check(lib.np_sgemv(Mv, Kv, da.ptr, db.ptr, yv.ptr)),
@@ -1058,6 +1076,7 @@ def _summary(result, extras):
     out["transpose_8191x8193_frac_hbm"], out["permute_nhwc_like_frac_hbm"] = frac("transpose_8191x8193"), frac("permute_nhwc_like")
     out["argmax_1e8_frac_hbm"], out["argmax_axis1_65536x1024_frac_hbm"] = frac("argmax_1e8"), frac("argmax_axis1_65536x1024")
     out["moments_1e8_frac_hbm"], out["sgemv_10x1e7_frac_hbm"] = frac("moments_1e8"), frac("sgemv_10x1e7")
+    out["weighted_sums_1e8_frac_hbm"] = frac("weighted_sums_1e8")
     c1 = extras.get("c1")
     if isinstance(c1, dict) and "cpu_add_ms" in c1:
         out["c1_cpu_add_ms"], out["c1_cpu_sum_ms"] = _compact(c1["cpu_add_ms"]), _compact(c1["cpu_sum_ms"])

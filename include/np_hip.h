@@ -255,11 +255,16 @@ int np_reduce_all_dev(int op, const float *in, size_t n, float *dev_out);
 
 /* Statistics (src/ndmath/statistics.c:88-154).  The reference composes these
  * from Sum / Subtract / Abs / Pow with a full-size temporary per step (32 B/elem for variance);
- * here: mean, then ONE fused pass over (x - mean)^2 (8 B/elem in total).
- *   variance = m2 / n (NDArray_Variance), std = sqrtf(m2 / n) (NDArray_Std). */
+ * here the array is read ONCE (4 B/elem): per-lane (count, mean, M2) merged pairwise in a fixed order
+ * (Chan's formula; means carried as anchor + offset, so the result is as accurate as the two-pass form
+ * for data with a large mean and a small spread).  host_m2 = sum (x - mean)^2:
+ *   variance = m2 / n (NDArray_Variance), std = sqrtf(m2 / n) (NDArray_Std).  n >= 1. */
 int np_moments(const float *in, size_t n, float *host_mean, float *host_m2);
-/* NDArray_Average with weights (statistics.c:131-154): sum(a*w) and sum(w), the product fused
- * into the reduction (no a*w temporary). */
+/* Same, results left on the device: dev_out[0] = mean, dev_out[1] = m2 (2 floats). */
+int np_moments_dev(const float *in, size_t n, float *dev_out);
+/* NDArray_Average with weights (statistics.c:131-154): sum(a*w) and sum(w) from one kernel that reads
+ * a and w once each (8 B/elem; no a*w temporary, products rounded before they are added as the
+ * reference's Multiply-then-Sum). */
 int np_weighted_sums(const float *a, const float *w, size_t n, float *host_sum_aw, float *host_sum_w);
 
 /* argmax (is_max != 0) / argmin along the middle axis of outer x axis_len x inner; out receives

@@ -113,6 +113,7 @@ PROTOTYPES = {
     "np_count_mismatch": (C.c_int, [C.c_int, _f32p, _f32p, C.c_size_t, C.c_float, C.c_float, C.POINTER(C.c_int)]),
     "np_argreduce": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p]),
     "np_moments": (C.c_int, [_f32p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "np_moments_dev": (C.c_int, [_f32p, C.c_size_t, _f32p]),
     "np_weighted_sums": (C.c_int, [_f32p, _f32p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "np_reduce_axis": (C.c_int, [C.c_int, _f32p, C.c_size_t, C.c_size_t, C.c_size_t, _f32p,
                                  C.c_uint]),

@@ -126,6 +126,25 @@ __global__ __launch_bounds__(256) void reduce_all_pass2(const float *__restrict_
     }
 }
 
+// two sums behind one first pass (weighted_sums_pass1): workgroup b folds partials[b * np ...] into out[b], reduce_all_pass2's order
+__global__ __launch_bounds__(256) void reduce_all_pass2_pair(const float *__restrict__ partials, int np, float *__restrict__ out) {
+    __shared__ float lds4[4];
+    const float *p = partials + (size_t)blockIdx.x * np;
+    float r = 0.0f;
+    for (int base = 0; base < np; base += 8 * (int)blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
+            v[u] = i < np ? p[i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r += v[u];
+    }
+    r = block_reduce<NP_SUM>(r, lds4);
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
 // Fused sum-reductions over a transformed input (src/ndmath/statistics.c):
 //   XFORM 1: (x - p0)^2      second pass of variance / std (p0 = mean)
 //   XFORM 2: x * y           weighted sum of NDArray_Average
@@ -207,6 +226,281 @@ __global__ __launch_bounds__(256) void reduce_xform_scalar(const float *__restri
         r += xform_term<XFORM>(in[i], XFORM >= 2 ? in2[i] : 0.0f, p0, p1);
     r = block_reduce<NP_SUM>(r, lds4);
     fold_in_last_workgroup<NP_SUM>(r, partials, ticket, out, 1.0f, lds4);
+}
+
+// ------------------------------------------------------------------------------------------
+// mean and sum of squared deviations in ONE read (variance / std, src/ndmath/statistics.c:88-130)
+// ------------------------------------------------------------------------------------------
+//
+// The reference forms the mean with one pass (NDArray_Sum_Float / numElements, statistics.c:95,119) and walks the
+// array again for sum (x - mean)^2 (:98-100; variance: Subtract, Abs, Pow, Sum — four more passes and three
+// temporaries, :119-129).  Here every element is read once: a running (count, mean, M2) per lane, merged pairwise
+// (Chan, Golub & LeVeque) through the wave shuffles, LDS and the per-workgroup partials of the other reductions.
+//
+// What keeps that at the accuracy of the two-pass form in fp32: a mean is carried as ANCHOR + OFFSET — `k`, a float near
+// the mean (a data value for a fresh batch, the rounded mean after a merge), and `mu` = mean - k, far below the data's
+// magnitude.  A merge needs the difference of two means, (kb - ka) + (mub - mua): floats that are close subtract exactly,
+// and every rounding that is left is relative to that difference — a mean stored as ONE float is off by up to half an ulp
+// of ITS OWN magnitude, an error that enters a merge to first order (2 delta eps n_a n_b / n) and is 6e-5 of the variance
+// of a few hundred values near 1e4.  Within a lane a trip's 16 values are taken relative to the first of them: s = sum d, q = sum d^2,
+// M2 = q - s^2 / 16; that subtraction cancels at most four bits (the anchor is one of the 16: s^2 <= 15 q).
+// Order of the merges is fixed by the launch geometry: bit-identical from run to run.  NaN / inf anywhere: NaN, as the
+// reference's inf - inf.
+struct Mom {
+    float n, k, mu, m2;   // count; anchor; mean - anchor; sum of squared deviations from the mean
+};
+
+// a comes first; 1 / (a.n + b.n) to an ulp is enough (the error is relative to delta)
+__device__ __forceinline__ Mom mom_merge(const Mom a, const Mom b) {
+    const float n = a.n + b.n;
+    const float delta = (b.k - a.k) + (b.mu - a.mu);
+    const float w = b.n * __builtin_amdgcn_rcpf(n);
+    Mom r;
+    r.n = n;
+    // the merged mean a.k + (a.mu + delta w), renormalised (TwoSum): the anchor moves to the mean rounded to a float and the
+    // offset becomes what that rounding lost — an offset kept relative to a FAR anchor (an outlier that happened to come
+    // first) would carry the rounding error of its own size, eps |mean - k|, into the mean
+    const float mu = __fmaf_rn(delta, w, a.mu);
+    const float k = a.k + mu;
+    const float bb = k - a.k;
+    r.k = k;
+    r.mu = (a.k - (k - bb)) + (mu - bb);
+    r.m2 = (a.m2 + b.m2) + delta * delta * (a.n * w);
+    const bool a_empty = a.n == 0.0f, b_empty = b.n == 0.0f;
+    if (b_empty) r = a;
+    if (a_empty) r = b;
+    return r;
+}
+
+// four values as one batch, anchored on the first
+__device__ __forceinline__ Mom mom_of4(const v4f x) {
+    const float k = x[0];
+    const float d1 = x[1] - k, d2 = x[2] - k, d3 = x[3] - k;
+    const float s = (d1 + d2) + d3;
+    const float q = __fmaf_rn(d3, d3, __fmaf_rn(d2, d2, d1 * d1));
+    const float mu = 0.25f * s;
+    return Mom{4.0f, k, mu, __fmaf_rn(-s, mu, q) + (k - k)};   // k - k: 0, or NaN for an infinite anchor (inf is not "equal to the mean")
+}
+
+// sixteen values (a lane's four loads of one trip) as one batch, anchored on the first
+__device__ __forceinline__ Mom mom_of16(const v4f x0, const v4f x1, const v4f x2, const v4f x3) {
+    const float k = x0[0];
+    v4f s4{0, 0, 0, 0}, q4 = s4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float d0 = x0[c] - k, d1 = x1[c] - k, d2 = x2[c] - k, d3 = x3[c] - k;
+        s4[c] = (d0 + d1) + (d2 + d3);
+        q4[c] = __fmaf_rn(d3, d3, __fmaf_rn(d2, d2, __fmaf_rn(d1, d1, d0 * d0)));
+    }
+    const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    const float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+    const float mu = 0.0625f * s;
+    return Mom{16.0f, k, mu, __fmaf_rn(-s, mu, q)};   // d0 of component 0 is k - k: NaN for an infinite anchor
+}
+
+__device__ __forceinline__ Mom mom_shfl_down(const Mom a, int off) {
+    return Mom{__shfl_down(a.n, off, 64), __shfl_down(a.k, off, 64), __shfl_down(a.mu, off, 64), __shfl_down(a.m2, off, 64)};
+}
+
+// the 256 threads' states -> one, valid in thread 0: lanes pairwise (offsets 32 ... 1), then the four waves in order
+__device__ __forceinline__ Mom mom_block_reduce(Mom a, Mom *lds) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a = mom_merge(a, mom_shfl_down(a, off));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = lds[0];
+        for (int w = 1; w < 4; ++w) a = mom_merge(a, lds[w]);
+    }
+    return a;
+}
+
+// thread t merges partials t, t + 256, ... in that order, the workgroup joins them; partials are [4][np] (n, k, mu, m2)
+template <bool COHERENT>
+__device__ __forceinline__ Mom mom_fold_partials(const float *partials, unsigned np, Mom *lds) {
+    Mom f{0.0f, 0.0f, 0.0f, 0.0f};
+    for (unsigned base = 0; base < np; base += 4 * 256u) {
+        Mom v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = base + u * 256u + threadIdx.x;
+            v[u] = Mom{0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < np) {
+                if constexpr (COHERENT)
+                    v[u] = Mom{coherent_load(&partials[i]), coherent_load(&partials[np + i]), coherent_load(&partials[2 * np + i]),
+                               coherent_load(&partials[3 * np + i])};
+                else
+                    v[u] = Mom{partials[i], partials[np + i], partials[2 * np + i], partials[3 * np + i]};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f = mom_merge(f, v[u]);
+    }
+    return mom_block_reduce(f, lds);
+}
+
+// out[0] = mean, out[1] = sum (x - mean)^2
+__device__ __forceinline__ void mom_write(const Mom r, float *out) {
+    out[0] = r.k + r.mu;
+    out[1] = r.m2;
+}
+
+// pass 1: the walk of reduce_all_pass1 (aligned non-temporal float4 loads from in + head, four in flight per lane, the <= 3
+// vectors left at the end of a lane's walk issued together; block 0 takes the ragged head and tail)
+template <typename I>
+__global__ __launch_bounds__(256) void moments_pass1(const float *__restrict__ in, float *__restrict__ partials, I n, I head,
+                                                     I nvec, unsigned *__restrict__ ticket, float *__restrict__ out) {
+    __shared__ Mom lds[4];
+    const I stride = (I)gridDim.x * blockDim.x;
+    const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    const float *base = in + head;
+    Mom acc{0.0f, 0.0f, 0.0f, 0.0f};
+    I v = tid;
+    for (; v + 3 * stride < nvec; v += 4 * stride) {
+        const v4f x0 = __builtin_nontemporal_load((const v4f *)(base + (size_t)v * 4));
+        const v4f x1 = __builtin_nontemporal_load((const v4f *)(base + (size_t)(v + stride) * 4));
+        const v4f x2 = __builtin_nontemporal_load((const v4f *)(base + (size_t)(v + 2 * stride) * 4));
+        const v4f x3 = __builtin_nontemporal_load((const v4f *)(base + (size_t)(v + 3 * stride) * 4));
+        acc = mom_merge(acc, mom_of16(x0, x1, x2, x3));
+    }
+    if (v < nvec) {
+        const I v1 = v + stride, v2 = v + 2 * stride;
+        const bool h1 = v1 < nvec, h2 = v2 < nvec;
+        const v4f x0 = __builtin_nontemporal_load((const v4f *)(base + (size_t)v * 4));
+        v4f x1{0, 0, 0, 0}, x2 = x1;
+        if (h1) x1 = __builtin_nontemporal_load((const v4f *)(base + (size_t)v1 * 4));
+        if (h2) x2 = __builtin_nontemporal_load((const v4f *)(base + (size_t)v2 * 4));
+        acc = mom_merge(acc, mom_of4(x0));
+        if (h1) acc = mom_merge(acc, mom_of4(x1));
+        if (h2) acc = mom_merge(acc, mom_of4(x2));
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) {
+            const float x = in[threadIdx.x];
+            acc = mom_merge(acc, Mom{1.0f, x, 0.0f, x - x});
+        }
+        const I t = head + nvec * 4 + threadIdx.x;
+        if (t < n) {
+            const float x = in[t];
+            acc = mom_merge(acc, Mom{1.0f, x, 0.0f, x - x});
+        }
+    }
+    acc = mom_block_reduce(acc, lds);
+    const unsigned np = gridDim.x;
+    if (np == 1) {
+        if (threadIdx.x == 0) mom_write(acc, out);
+        return;
+    }
+    if (!ticket) {   // a one-workgroup second kernel folds
+        if (threadIdx.x == 0) {
+            partials[blockIdx.x] = acc.n;
+            partials[np + blockIdx.x] = acc.k;
+            partials[2 * np + blockIdx.x] = acc.mu;
+            partials[3 * np + blockIdx.x] = acc.m2;
+        }
+        return;
+    }
+    if (threadIdx.x == 0) {
+        coherent_store(&partials[blockIdx.x], acc.n);
+        coherent_store(&partials[np + blockIdx.x], acc.k);
+        coherent_store(&partials[2 * np + blockIdx.x], acc.mu);
+        coherent_store(&partials[3 * np + blockIdx.x], acc.m2);
+    }
+    if (!last_workgroup_done(ticket, np)) return;
+    const Mom r = mom_fold_partials<true>(partials, np, lds);
+    if (threadIdx.x == 0) {
+        mom_write(r, out);
+        coherent_store(ticket, 0u);
+    }
+}
+
+__global__ __launch_bounds__(256) void moments_pass2(const float *__restrict__ partials, unsigned np, float *__restrict__ out) {
+    __shared__ Mom lds[4];
+    const Mom r = mom_fold_partials<false>(partials, np, lds);
+    if (threadIdx.x == 0) mom_write(r, out);
+}
+
+// sum a w and sum w of NDArray_Average (statistics.c:147-150) in one read of both arrays: the walk of
+// reduce_xform_pass1 (dword-aligned float4 loads: the two operands need not agree in alignment) with two sums per lane.
+// Partials [2][blocks]; out[0] = sum a w, out[1] = sum w.
+template <typename I>
+__global__ __launch_bounds__(256) void weighted_sums_pass1(const float *__restrict__ a, const float *__restrict__ w,
+                                                           float *__restrict__ partials, I n, I nvec,
+                                                           unsigned *__restrict__ ticket, float *__restrict__ out) {
+    __shared__ float lds4[4];
+    __shared__ float lds4b[4];
+    const I stride = (I)gridDim.x * blockDim.x;
+    const I tid = (I)blockIdx.x * blockDim.x + threadIdx.x;
+    v4f p0{0, 0, 0, 0}, p1 = p0, s0 = p0, s1 = p0;
+    I v = tid;
+    for (; v + stride < nvec; v += 2 * stride) {
+        const v4f x0 = __builtin_nontemporal_load((const v4f_u *)(a + (size_t)v * 4));
+        const v4f x1 = __builtin_nontemporal_load((const v4f_u *)(a + (size_t)(v + stride) * 4));
+        const v4f y0 = __builtin_nontemporal_load((const v4f_u *)(w + (size_t)v * 4));
+        const v4f y1 = __builtin_nontemporal_load((const v4f_u *)(w + (size_t)(v + stride) * 4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            p0[k] += x0[k] * y0[k];   // a product rounded, then added: NDArray_Multiply_Float then NDArray_Sum_Float (no FMA)
+            p1[k] += x1[k] * y1[k];
+            s0[k] += y0[k];
+            s1[k] += y1[k];
+        }
+    }
+    if (v < nvec) {
+        const v4f x0 = *(const v4f_u *)(a + (size_t)v * 4);
+        const v4f y0 = *(const v4f_u *)(w + (size_t)v * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            p0[k] += x0[k] * y0[k];
+            s0[k] += y0[k];
+        }
+    }
+    float rp = (p0[0] + p1[0]) + (p0[1] + p1[1]) + ((p0[2] + p1[2]) + (p0[3] + p1[3]));
+    float rs = (s0[0] + s1[0]) + (s0[1] + s1[1]) + ((s0[2] + s1[2]) + (s0[3] + s1[3]));
+    if (blockIdx.x == 0) {
+        const I t = nvec * 4 + threadIdx.x;   // ragged tail (n % 4 elements)
+        if (t < n) {
+            rp += a[t] * w[t];
+            rs += w[t];
+        }
+    }
+    rp = block_reduce<NP_SUM>(rp, lds4);
+    rs = block_reduce<NP_SUM>(rs, lds4b);
+    const unsigned np = gridDim.x;
+    if (np == 1) {
+        if (threadIdx.x == 0) {
+            out[0] = rp;
+            out[1] = rs;
+        }
+        return;
+    }
+    if (!ticket) {
+        if (threadIdx.x == 0) {
+            partials[blockIdx.x] = rp;
+            partials[np + blockIdx.x] = rs;
+        }
+        return;
+    }
+    if (threadIdx.x == 0) {
+        coherent_store(&partials[blockIdx.x], rp);
+        coherent_store(&partials[np + blockIdx.x], rs);
+    }
+    if (!last_workgroup_done(ticket, np)) return;
+    // np <= 256 (np::fold_ticket): one partial of each sum per thread, the fold order of reduce_all_pass2
+    float fp = 0.0f, fs = 0.0f;
+    for (unsigned i = threadIdx.x; i < np; i += blockDim.x) {
+        fp += coherent_load(&partials[i]);
+        fs += coherent_load(&partials[np + i]);
+    }
+    __syncthreads();   // lds4 / lds4b are read by thread 0 of block_reduce above
+    fp = block_reduce<NP_SUM>(fp, lds4);
+    fs = block_reduce<NP_SUM>(fs, lds4b);
+    if (threadIdx.x == 0) {
+        out[0] = fp;
+        out[1] = fs;
+        coherent_store(ticket, 0u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1221,6 +1515,43 @@ int np_reduce_all(int op, const float *in, size_t n, float *host_out) {
 
 }  // extern "C" (the template below cannot have C linkage)
 
+// mean and sum of squared deviations -> dev_out[0], dev_out[1]: one streaming pass (+ a one-workgroup fold above 256 workgroups)
+template <typename I>
+static int launch_moments(const float *in, size_t n, float *dev_out) {
+    hipStream_t s = np::stream();
+    size_t head = ((16 - ((uintptr_t)in & 15u)) & 15u) / 4;
+    if (head > n) head = n;
+    const size_t nvec = (n - head) / 4;
+    size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
+    if (np::g_small_reduce_blocks && n <= (size_t(1) << 20) && blocks > np::g_small_reduce_blocks) blocks = np::g_small_reduce_blocks;
+    np::Scratch partials;
+    if (int rc = partials.alloc(4 * blocks * sizeof(float))) return rc;
+    unsigned *ticket = np::fold_ticket(blocks);
+    moments_pass1<I><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (I)n, (I)head, (I)nvec, ticket, dev_out);
+    NP_LAUNCH_CHECK("moments_pass1");
+    if (ticket || blocks == 1) return NP_OK;
+    moments_pass2<<<1, 256, 0, s>>>((const float *)partials.ptr, (unsigned)blocks, dev_out);
+    NP_LAUNCH_CHECK("moments_pass2");
+    return NP_OK;
+}
+
+// sum a w -> dev_out[0], sum w -> dev_out[1]
+template <typename I>
+static int launch_weighted_sums(const float *a, const float *w, size_t n, float *dev_out) {
+    hipStream_t s = np::stream();
+    const size_t nvec = n / 4;
+    const size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
+    np::Scratch partials;
+    if (int rc = partials.alloc(2 * blocks * sizeof(float))) return rc;
+    unsigned *ticket = np::fold_ticket(blocks);
+    weighted_sums_pass1<I><<<(unsigned)blocks, 256, 0, s>>>(a, w, (float *)partials.ptr, (I)n, (I)nvec, ticket, dev_out);
+    NP_LAUNCH_CHECK("weighted_sums_pass1");
+    if (ticket || blocks == 1) return NP_OK;
+    reduce_all_pass2_pair<<<2, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, dev_out);
+    NP_LAUNCH_CHECK("reduce_all_pass2_pair");
+    return NP_OK;
+}
+
 // sum over XFORM(in[, in2]) -> one device float
 template <int XFORM>
 static int xform_sum(const float *in, const float *in2, size_t n, float p0, float p1, float *dev_out) {
@@ -1790,23 +2121,26 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
     return NP_OK;
 }
 
+int np_moments_dev(const float *in, size_t n, float *dev_out) {
+    if (!dev_out) return np::fail(NP_ERR_INVALID, "np_moments: null output");
+    if (n == 0 || !in) return np::fail(NP_ERR_INVALID, "np_moments: empty input");
+    if (int rc = np::ensure_init()) return rc;
+    if (n < (size_t(1) << 31)) return launch_moments<uint32_t>(in, n, dev_out);
+    return launch_moments<uint64_t>(in, n, dev_out);
+}
+
 int np_moments(const float *in, size_t n, float *host_mean, float *host_m2) {
     if (!host_mean || !host_m2) return np::fail(NP_ERR_INVALID, "np_moments: null output");
     if (n == 0 || !in) return np::fail(NP_ERR_INVALID, "np_moments: empty input");
     if (int rc = np::ensure_init()) return rc;
-    // (Round 5 tried both passes behind ONE host wait — the sum left in a pinned result slot, the second pass forming the mean
-    // itself: reading the slot over the host link from 2049 workgroups made the pass 3-7 x slower, BENCH leases 7 and 8; with the
-    // sum in device memory and a forwarding kernel the gain would be ~5 us of 150.  Two host-result calls it stays.)
-    float sum = 0.0f;
-    if (int rc = np_reduce_all(NP_SUM, in, n, &sum)) return rc;
-    const float mean = sum / (float)n;   // NDArray_Sum_Float(a) / NDArray_NUMELEMENTS(a), statistics.c:95,119
-    np::ResultCall call;
+    // ONE read of the array, one host wait (until round 6: np_reduce_all for the mean, the host's division, a second pass)
+    np::ResultCall call(2);
     float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
-    if (int rc = xform_sum<1>(in, nullptr, n, mean, 0.0f, slot)) return rc;
+    if (int rc = np_moments_dev(in, n, slot)) return rc;
     if (int rc = call.wait()) return rc;
-    *host_mean = mean;
-    *host_m2 = slot[0];
+    *host_mean = slot[0];
+    *host_m2 = slot[1];
     return NP_OK;
 }
 
@@ -1817,8 +2151,12 @@ int np_weighted_sums(const float *a, const float *w, size_t n, float *host_sum_a
     np::ResultCall call(2);
     float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
-    if (int rc = xform_sum<2>(a, w, n, 0.0f, 0.0f, slot)) return rc;
-    if (int rc = np_reduce_all_dev(NP_SUM, w, n, slot + 1)) return rc;   // both values behind ONE wait
+    // one kernel carrying both sums: a and w are read once each (8 B/elem; until round 6 w was read a second time)
+    if (n < (size_t(1) << 31)) {
+        if (int rc = launch_weighted_sums<uint32_t>(a, w, n, slot)) return rc;
+    } else {
+        if (int rc = launch_weighted_sums<uint64_t>(a, w, n, slot)) return rc;
+    }
     if (int rc = call.wait()) return rc;
     *host_sum_aw = slot[0];
     *host_sum_w = slot[1];

@@ -65,3 +65,103 @@ def test_moments_1e8(hip):
     assert abs(mean.value - x64.mean()) <= 1e-5 * x64.mean()
     assert abs(m2.value / n - x64.var()) <= 1e-5 * x64.var()
     d.free()
+
+
+def _moments(hip, x, offset=0):
+    """np_moments on x[offset:] of a device copy of x (offset elements: a 4-byte aligned view)."""
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    d = hip.DeviceArray.from_host(np.ascontiguousarray(x, dtype=np.float32))
+    mean, m2 = C.c_float(), C.c_float()
+    check(load().np_moments(d.ptr + 4 * offset, x.size - offset, C.byref(mean), C.byref(m2)))
+    d.free()
+    return mean.value, m2.value
+
+
+@pytest.mark.parametrize("n", [5, 300, 4099, 65536, 1_000_003, 10_000_000])
+def test_variance_of_a_large_mean_and_a_small_spread(n, hip, oracle):
+    """1e4 + U[0,1): the case a one-pass sum x^2 - (sum x)^2 / n form loses every digit on, and a Chan merge with means
+    stored as single floats loses 6e-5 on at a few hundred elements (np_reduce.hip: anchor + offset).  Bar: 1e-5 of the
+    fp64 variance; next to it the oracle (the reference's own two passes, statistics.c:117-130), which is held to what its
+    sequential fp32 sum allows — the GPU result must be at least as close to fp64 as the oracle is, up to the bar."""
+    x = (np.float32(1e4) + synth.uniform((n,), 77, 0.0, 1.0)).astype(np.float32)
+    x64 = x.astype(np.float64)
+    var64 = x64.var()
+    mean, m2 = _moments(hip, x)
+    assert abs(mean - x64.mean()) <= 1e-6 * x64.mean()
+    assert abs(m2 / n - var64) <= 1e-5 * var64
+    o = float(oracle.reduce_all("variance", x))
+    assert abs(m2 / n - o) <= abs(o - var64) + 1e-5 * var64
+    # through the class surface too
+    from numpower_amd.ndarray import NDArray
+    g = NDArray.array(x).gpu()
+    assert abs(NDArray.variance(g) - var64) <= 1e-5 * var64
+    assert abs(NDArray.std(g) - x64.std()) <= 1e-5 * x64.std()
+
+
+def test_moments_every_small_size_and_alignment(hip):
+    """Sizes 1 ... 70 and every start alignment: the ragged head, the tail, the <= 3 vectors left over per lane."""
+    x = synth.uniform((80,), 9, -2.0, 7.0)
+    for off in range(4):
+        for n in range(1, 71):
+            v = x[off:off + n].astype(np.float64)
+            mean, m2 = _moments(hip, x[:off + n], off)
+            assert abs(mean - v.mean()) <= 1e-6 * np.abs(v).max(), (off, n)
+            assert abs(m2 - ((v - v.mean()) ** 2).sum()) <= 1e-5 * max(((v - v.mean()) ** 2).sum(), 1e-30), (off, n)
+    mean, m2 = _moments(hip, np.array([3.25], dtype=np.float32))
+    assert (mean, m2) == (3.25, 0.0)
+
+
+@pytest.mark.parametrize("n", [1000, 262_144 + 5, 3_000_001])
+def test_moments_are_deterministic_exact_on_constants_and_nan_on_non_finite(n, hip):
+    x = synth.uniform((n,), 13, -1.0, 1.0)
+    first = _moments(hip, x)
+    for _ in range(3):
+        assert _moments(hip, x) == first                  # fixed merge order: bit-identical from run to run
+    c = np.full(n, 1234.5678, dtype=np.float32)
+    mean, m2 = _moments(hip, c)
+    assert mean == c[0] and m2 == 0.0                        # every deviation is an exact zero
+    for bad in (np.inf, -np.inf, np.nan):
+        for pos in (0, n // 2, n - 1):
+            y = x.copy()
+            y[pos] = bad
+            mean, m2 = _moments(hip, y)
+            assert np.isnan(m2), (bad, pos)                  # the reference: inf - inf (statistics.c:99,120)
+    # an outlier as the very first element (the anchor of lane 0's first batch) costs nothing
+    y = x.copy()
+    y[0] = 1e6
+    y64 = y.astype(np.float64)
+    mean, m2 = _moments(hip, y)
+    assert abs(m2 - ((y64 - y64.mean()) ** 2).sum()) <= 1e-5 * ((y64 - y64.mean()) ** 2).sum()
+    assert abs(mean - y64.mean()) <= 1e-5 * abs(y64.mean())
+
+
+def test_moments_1e8_large_mean(hip):
+    """BASELINE size, mean 1e4, spread 1: against the closed form of the generator and fp64."""
+    n = 100_000_000
+    x = synth.uniform((n,), 5, 0.0, 1.0)
+    x += np.float32(1e4)
+    x64 = x.astype(np.float64)
+    mean, m2 = _moments(hip, x)
+    assert abs(mean - x64.mean()) <= 1e-6 * x64.mean()
+    assert abs(m2 / n - x64.var()) <= 1e-5 * x64.var()
+
+
+@pytest.mark.parametrize("n", [3, 1001, 65536, 5_000_001])
+def test_weighted_sums_read_once(n, hip):
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    a = synth.uniform((n + 1,), 21, -3.0, 5.0)
+    w = synth.uniform((n + 3,), 22, 0.1, 2.0)
+    da, dw = hip.DeviceArray.from_host(a), hip.DeviceArray.from_host(w)
+    for oa, ow in ((0, 0), (1, 0), (0, 3), (1, 2)):          # the two operands need not agree in alignment
+        saw, sw = C.c_float(), C.c_float()
+        check(load().np_weighted_sums(da.ptr + 4 * oa, dw.ptr + 4 * ow, n, C.byref(saw), C.byref(sw)))
+        a64, w64 = a[oa:oa + n].astype(np.float64), w[ow:ow + n].astype(np.float64)
+        assert abs(saw.value - (a64 * w64).sum()) <= 1e-5 * (np.abs(a64) * w64).sum()
+        assert abs(sw.value - w64.sum()) <= 1e-5 * w64.sum()
+        again_aw, again_w = C.c_float(), C.c_float()
+        check(load().np_weighted_sums(da.ptr + 4 * oa, dw.ptr + 4 * ow, n, C.byref(again_aw), C.byref(again_w)))
+        assert (again_aw.value, again_w.value) == (saw.value, sw.value)
+    da.free()
+    dw.free()
