@@ -3,9 +3,10 @@
 Runs the tool on a scratch copy of the reference checkout (this container only: /root/reference does not exist on
 the GPU box, where these tests skip; nothing of the reference is committed or shipped) and asserts that
   * every edit's anchor is found exactly as many times as the tool expects (no anchor missing or ambiguous),
-  * each replaced statement is kept on the #else side, so the tree still builds --with-cuda,
-  * with HAVE_NP_HIP + HAVE_CUBLAS defined, no preprocessor-visible line of the extension's C sources names the
-    CUDA runtime or cuBLAS any more,
+  * the DEFAULT output is a HIP-only tree: no CUDA-runtime / cuBLAS name is left anywhere in the text of a source the
+    build compiles (comments and inactive preprocessor branches included), no `#ifdef HAVE_NP_HIP ... #else <CUDA>` pair,
+  * with --keep-cuda each replaced statement is kept on the #else side (that tree still builds --with-cuda) and, with
+    HAVE_NP_HIP + HAVE_CUBLAS defined, no preprocessor-visible line names the CUDA runtime or cuBLAS,
   * the glue travels with the tree (src/hip/),
 and that the tool fails loudly — not silently — when an anchor has moved."""
 import re
@@ -33,18 +34,56 @@ def patched(tmp_path_factory):
     return tool, out, applied
 
 
+@pytest.fixture(scope="module")
+def patched_keep_cuda(tmp_path_factory):
+    if not (REF / "numpower.c").exists():
+        pytest.skip("reference checkout not present on this box")
+    import apply_with_hip as tool
+    out = tmp_path_factory.mktemp("with_hip_keep_cuda") / "numpower"
+    applied = tool.apply(REF, out, keep_cuda=True)
+    return tool, out, applied
+
+
 def test_every_edit_applies_exactly_as_often_as_expected(patched):
     tool, out, applied = patched
     assert len(applied) == len(tool.EDITS)
     for e in tool.EDITS:
         assert applied[e.what] == e.expect, e.what
     # 7 header swaps + the call sites of INTEGRATION.md section 2a
-    assert sum(1 for e in tool.EDITS if "CUDA headers" in e.what) == 7
+    assert sum(1 for e in tool.EDITS if "CUDA headers" in e.what) == 8      # + php_numpower.h, which numpower.c includes
 
 
-def test_no_cuda_runtime_name_is_visible_to_a_hip_build(patched):
+def test_the_default_tree_is_hip_only(patched):
+    """No CUDA / HIP dual path: the raw text of every source a --with-hip build compiles — the headers numpower.c pulls in
+    included — is free of CUDA-runtime and cuBLAS names, and no `#ifdef HAVE_NP_HIP` block has an #else side."""
     tool, out, _ = patched
-    assert tool.check_tree(out) == []
+    assert tool.check_tree(out, raw=True) == []
+    compiled = [p for p in list(out.glob("*.c")) + list(out.glob("*.h")) + list(out.glob("src/**/*.c")) + list(out.glob("src/**/*.h"))
+                if not p.relative_to(out).as_posix().startswith(tool.REPLACED_BY_GLUE + ("src/hip/",))]
+    assert len(compiled) > 30
+    for p in compiled:
+        text = p.read_text(errors="replace")
+        assert not re.search(r"cuda[A-Z]|cublas|<cuda_runtime\.h>", text), p
+    # the only HAVE_NP_HIP blocks with an #else side are the three feature guards around device-independent reference code
+    # (reduce() / single_reduce()'s slice loops, exp2's NDArray_Map): what a build WITHOUT --with-hip compiles there
+    else_sides = []
+    for p in compiled:
+        for m in re.finditer(r"^#ifdef HAVE_NP_HIP\n(.*?)^#endif", p.read_text(errors="replace"), flags=re.S | re.M):
+            if "\n#else\n" in m.group(1):
+                else_sides.append(m.group(1).split("\n#else\n")[1].strip())
+    assert sorted(else_sides) == sorted(["_reduce(0, 0, axis, array, rtn, operation);", "_single_reduce(0, 0, axis, array, rtn, operation);",
+                                         "rtn = NDArray_Map(nda, float_exp2);"])
+    # the two things that are left are not compiled by a --with-hip build (config.m4 swaps them for the glue)
+    assert (out / "src" / "gpu_alloc.c").exists() and "src/hip/gpu_alloc_hip.c" in (out / "config.m4").read_text()
+    # the checker is not vacuous: the --keep-cuda tree fails the raw check at its #else sides
+    import apply_with_hip
+    assert apply_with_hip.raw_cuda_names("x\n#else\n    cudaSetDevice(deviceId);\n#endif\n") == [(3, "cudaSetDevice(deviceId);")]
+
+
+def test_no_cuda_runtime_name_is_visible_to_a_hip_build(patched_keep_cuda):
+    tool, out, _ = patched_keep_cuda
+    assert tool.check_tree(out, raw=False) == []
+    assert tool.check_tree(out, raw=True) != []          # ... while its text still holds every CUDA statement
     # the checker is not vacuous: the UNPATCHED tree fails it, at the very call sites the table lists
     problems = []
     for rel in ("numpower.c", "src/ndarray.c", "src/initializers.c", "src/ndmath/arithmetics.c", "src/ndmath/linalg.c", "src/debug.c"):
@@ -55,10 +94,10 @@ def test_no_cuda_runtime_name_is_visible_to_a_hip_build(patched):
         assert site in problems, site
 
 
-def test_the_cuda_side_is_kept_verbatim(patched):
-    """Each wrapped edit leaves the reference's statement on the #else side: with HAVE_NP_HIP undefined the patched
-    file preprocesses back to the reference's text."""
-    tool, out, _ = patched
+def test_the_cuda_side_is_kept_verbatim(patched_keep_cuda):
+    """--keep-cuda: each wrapped edit leaves the reference's statement on the #else side: with HAVE_NP_HIP undefined the
+    patched file preprocesses back to the reference's text."""
+    tool, out, _ = patched_keep_cuda
 
     def without_hip(text):
         keep, stack = [], []          # stack entries: True = inside the HAVE_NP_HIP side of one of OUR blocks, False = its #else side
@@ -152,10 +191,12 @@ def test_the_fast_path_inserts_replace_nothing(patched):
         text, ref = (out / rel).read_text(), (REF / ref_rel).read_text()
         n = sum(1 for _, e in tool.FAST_BINARY if e.file == rel)
         assert text.count("if (NPH_TAKES(") == n == 6
-        # every line of the reference file is still in the patched one, in order (insert-only for these two files'
-        # early-outs; the wrapped 2a edits keep theirs on the #else side)
+        # every line of the reference file that does not name CUDA is still in the patched one, in order (insert-only for
+        # these two files' early-outs; section 2a replaced the CUDA includes and the five cudaDeviceSynchronize() calls)
         it = iter(text.split("\n"))
-        assert all(any(line == cand for cand in it) for line in ref.split("\n")), rel
+        kept = [line for line in ref.split("\n") if not tool._CUDA_NAME.search(line)]
+        assert len(kept) >= len(ref.split("\n")) - 7
+        assert all(any(line == cand for cand in it) for line in kept), rel
     for name, e in tool.FAST_BINARY:
         text = (out / e.file).read_text()
         head = text.index(name + "(NDArray*")
@@ -163,7 +204,7 @@ def test_the_fast_path_inserts_replace_nothing(patched):
         # order inside the function: the reference's device check, then the early-out, then the scalar expand
         assert body.index("mismatch") < body.index("NPH_TAKES") < body.index("// If a or b are scalars, reshape"), name
     nd = (out / "src/ndarray.c").read_text()
-    assert nd.count("NPH_ReduceAxisInto(") == 2 and nd.count(" _reduce(0, 0, axis, array, rtn, operation);") == 2   # HIP side's else + the #else side
+    assert nd.count("NPH_ReduceAxisInto(") == 2 and nd.count(" _reduce(0, 0, axis, array, rtn, operation);") == 2   # HIP side's else + the #else side (a build without --with-hip)
     assert nd.count("_single_reduce(0, 0, axis, array, rtn, operation);") == 2 and "operation == NDArray_Mean_Float" in nd
     assert "src/hip/hip_fast.c" in (out / "config.m4").read_text()
     assert (out / "src/hip/hip_fast.c").exists() and (out / "src/hip/hip_fast.h").exists()

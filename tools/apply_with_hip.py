@@ -1,12 +1,21 @@
 #!/usr/bin/env python3
 """apply_with_hip.py — turn a NumPower checkout into a `--with-hip` tree (INTEGRATION.md sections 2a and 2b, as code).
 
-    python tools/apply_with_hip.py <NumPower checkout> <output directory>
+    python tools/apply_with_hip.py [--keep-cuda] <NumPower checkout> <output directory>
 
 Copies the checkout to <output directory>, applies every edit of INTEGRATION.md section 2a by ANCHORED regex and
 copies the glue (ext/*.c, ext/*.h, include/np_hip.h) to <output>/src/hip/.  Every edit names its file, the exact
 text it expects to find and how many times; a missing or ambiguous anchor is a hard error (exit status 2) — the
-table cannot silently rot when the reference moves.  Each replaced statement is kept:
+table cannot silently rot when the reference moves.
+
+**The default output is a HIP-only tree**: each CUDA-runtime / cuBLAS statement is REPLACED by its np_* / v* call — no
+`#ifdef HAVE_NP_HIP ... #else <CUDA statement> #endif` pairs, no CUDA / HIP dual code path (BASELINE north star).  What
+is left of CUDA in the tree is the reference's own src/gpu_alloc.c and src/ndmath/cuda/, which a `--with-hip` build does
+not compile (config.m4: the glue takes their place), and the `--with-cuda` option text of config.m4.  check_tree() then
+greps the RAW text of every C source the build compiles — comments and inactive preprocessor branches included — for
+cuda[A-Z]*, cublas[A-Z]*, CUBLAS_*, <cuda_runtime.h>, <cublas_v2.h>: none may be left.
+
+`--keep-cuda` keeps each replaced statement on an #else side instead:
 
     #ifdef HAVE_NP_HIP
         <the np_* / v* call>
@@ -14,8 +23,10 @@ table cannot silently rot when the reference moves.  Each replaced statement is 
         <the reference's CUDA-runtime statement, untouched>
     #endif
 
-so the output still builds `--with-cuda`; `--with-hip` (config.m4, added by the last edits) defines HAVE_CUBLAS —
-the name the reference's C files gate every NDARRAY_DEVICE_GPU branch on — and HAVE_NP_HIP.
+so that ONE tree still builds `--with-cuda` (a maintainer who wants to carry both back ends upstream); there the check
+is the weaker one: no preprocessor-VISIBLE line of a --with-hip build may name CUDA.  Either way `--with-hip` (config.m4,
+added by the last edits) defines HAVE_CUBLAS — the name the reference's C files gate every NDARRAY_DEVICE_GPU branch
+on — and HAVE_NP_HIP.
 
 Section 2b's edits INSERT (Edit.after) instead of replacing: the L2 functions that pick the device inside the function
 (NDArray_{Add...Pow}_Float, the six comparisons, reduce()) gain `#ifdef HAVE_NP_HIP if (NPH_TAKES(a, b)) return
@@ -23,10 +34,10 @@ NPH_Binary_Float(...); #endif` behind their own device-mismatch check, so GPU op
 fall through to the reference's code, untouched.  fast_path_program_source() wraps that inserted text into a C program
 (numpower_amd/lib/fast_path_bodies) that the CPU and GPU test tiers run.
 
-After the edits the tool CHECKS the tree (check_tree): with HAVE_NP_HIP and HAVE_CUBLAS defined and HAVE_CUDNN
-undefined, no preprocessor-visible line of the extension's C sources may name the CUDA runtime or cuBLAS
-(cuda[A-Z]*, cublas[A-Z]*, CUBLAS_*, <cuda_runtime.h>, <cublas_v2.h>).  src/gpu_alloc.c and src/ndmath/cuda/ are
-replaced wholesale by the glue and are not part of a --with-hip build.
+Section 2b's inserts (and section 2c's, the pending chains) stay inside `#ifdef HAVE_NP_HIP` in both modes: that guard
+is not a second back end, it is what lets the same tree still configure WITHOUT a GPU (CPU-only build: no src/hip/ on
+the include path).  src/gpu_alloc.c and src/ndmath/cuda/ are replaced wholesale by the glue and are not part of a
+--with-hip build.
 
 All file:line remarks refer to NumPower/numpower @ 2024_08_07.  Nothing of the reference is stored in this
 repository: the tool holds anchors (regexes) and replacement text only, and tests/test_apply_with_hip_cpu.py runs it
@@ -54,7 +65,11 @@ class Edit:
     anchor: str        # regex (re.M); group "old" = the text that is wrapped / replaced
     new: str           # the HAVE_NP_HIP side (same indentation as the old text is applied automatically)
     expect: int = 1    # how many times the anchor must match
-    wrap: bool = True  # True: #ifdef HAVE_NP_HIP new #else old #endif;  False: plain substitution by `new`
+    wrap: bool = True  # True: a CUDA statement with a HIP counterpart — replaced by `new` (default), or with --keep-cuda
+                       # `#ifdef HAVE_NP_HIP new #else old #endif`;  False: plain substitution by `new` in both modes
+    guard: bool = False  # True: `old` is NOT a CUDA statement but device-independent reference code that a build without
+                         # --with-hip must keep (reduce()'s slice loop, exp2's NDArray_Map): BOTH modes emit
+                         # `#ifdef HAVE_NP_HIP new #else old #endif` — a feature guard, not a second GPU back end
     after: bool = False  # True: `old` stays where it is and `#ifdef HAVE_NP_HIP new #endif` is INSERTED behind it (the
                          # fast-path early-outs of section 2b: nothing of the reference is replaced)
     context: str = ""  # C declarations of the locals of the surrounding reference function that `new` uses (CONTEXTS
@@ -106,6 +121,9 @@ _SYNC = (r"^(?P<old>[ \t]*cudaDeviceSynchronize\(\);)$")
 EDITS = [
     # ---- headers ----
     _cuda_includes("numpower.c", "numpower.c:31-32"),
+    # (found by the raw-text check of round 6: numpower.c:15 includes this header, and HAVE_CUBLAS — which --with-hip
+    #  defines — pulled <cuda_runtime.h> in through it; rounds 4-5 only scanned *.c and src/)
+    _cuda_includes("php_numpower.h", "php_numpower.h:9-10"),
     _cuda_includes("src/initializers.c", "initializers.c:15-16"),
     _cuda_includes("src/ndarray.c", "ndarray.c:18-19", "\n#include <hip_fast.h>\n#include \"ndmath/arithmetics.h\""),
     _cuda_includes("src/ndmath/arithmetics.c", "arithmetics.c:14-15", "\n#include <hip_fast.h>"),
@@ -227,7 +245,7 @@ EDITS = [
          "    rtn = NDArray_Map(nda, float_exp2);\n"
          "} else {\n"
          "    rtn = NDArrayMathGPU_ElementWise(nda, cuda_float_exp2);\n"
-         "}"),
+         "}", guard=True),
     # ---- section 2b: the fast path, reachable from PHP without replacing a single reference symbol ----
     Edit("src/logic.c", "logic.c:10-11: <hip_fast.h>",
          r"^(?P<old>#include \"ndmath/cuda/cuda_math\.h\"\n#include \"debug\.h\")$",
@@ -258,7 +276,7 @@ EDITS = [
          "    }\n"
          "} else {\n"
          "    _reduce(0, 0, axis, array, rtn, operation);\n"
-         "}"),
+         "}", guard=True),
     Edit("src/ndarray.c", "ndarray.c:509 single_reduce(): mean over an axis of a GPU array",
          r"^(?P<old>[ \t]*_single_reduce\(0, 0, axis, array, rtn, operation\);)$",
          "/* numpower_amd: PHP_METHOD(mean) sends GPU arrays with an axis here (numpower.c:2677), and the loop below writes NOTHING\n"
@@ -272,7 +290,7 @@ EDITS = [
          "    }\n"
          "} else {\n"
          "    _single_reduce(0, 0, axis, array, rtn, operation);\n"
-         "}"),
+         "}", guard=True),
     # ---- config.m4: the option, and the source list ----
     Edit("config.m4", "config.m4:7-8: --with-hip next to --with-cuda",
          r"^(?P<old>PHP_ARG_WITH\(cuda, for CUDA support,\n\[  --with-cuda           Include CUDA support\], \[no\], \[no\]\))$",
@@ -576,7 +594,7 @@ def _indent(text: str, pad: str) -> str:
     return "\n".join((pad + line) if line else line for line in text.split("\n"))
 
 
-def apply_edit(text: str, e: Edit):
+def apply_edit(text: str, e: Edit, keep_cuda: bool = False):
     """-> (new text, number of matches); raises PatchError if the anchor count is not e.expect."""
     rx = re.compile(e.anchor, re.M)
     matches = list(rx.finditer(text))
@@ -592,8 +610,10 @@ def apply_edit(text: str, e: Edit):
             if old.lstrip().startswith("#"):
                 last_pad = ""          # behind a preprocessor line: at the margin
             rep = "%s\n#ifdef HAVE_NP_HIP\n%s\n#endif" % (old, _indent(new, last_pad))
-        elif e.wrap:
+        elif e.wrap and (keep_cuda or e.guard):
             rep = "#ifdef HAVE_NP_HIP\n%s\n#else\n%s\n#endif" % (_indent(new, pad), old)
+        elif e.wrap:
+            rep = _indent(new, pad)
         else:
             rep = new
         out.append(text[pos:m.start("old")])
@@ -656,21 +676,30 @@ def hip_visible_cuda_names(text: str):
     return bad
 
 
-def check_tree(out: Path):
-    """Every C source a --with-hip build compiles: no CUDA / cuBLAS name on a visible line."""
+def raw_cuda_names(text: str):
+    """[(line number, line)] of EVERY line that names CUDA / cuBLAS — comments and inactive branches included."""
+    return [(no, line.strip()) for no, line in enumerate(text.split("\n"), 1) if _CUDA_NAME.search(line)]
+
+
+def check_tree(out: Path, raw: bool = True):
+    """Every C source a --with-hip build compiles.  raw (the HIP-only default): no CUDA / cuBLAS name anywhere in the text;
+    not raw (--keep-cuda): none on a line a --with-hip build's preprocessor lets through."""
     problems = []
-    for path in sorted(list(out.glob("*.c")) + list(out.glob("src/**/*.c")) + list(out.glob("src/**/*.h"))):
+    for path in sorted(list(out.glob("*.c")) + list(out.glob("*.h")) + list(out.glob("src/**/*.c")) + list(out.glob("src/**/*.h"))):
         rel = path.relative_to(out).as_posix()
         if rel.startswith(REPLACED_BY_GLUE):
             continue
-        for no, line in hip_visible_cuda_names(path.read_text(errors="replace")):
+        text = path.read_text(errors="replace")
+        if raw and rel.startswith("src/hip/"):
+            text = _strip_comments(text)   # the glue's comments CITE the reference statement each entry point replaces
+        for no, line in (raw_cuda_names(text) if raw else hip_visible_cuda_names(text)):
             if rel.startswith("src/hip/") and re.search(r"\bcuda_\w+", line) and not _CUDA_NAME.search(line):
                 continue
             problems.append("%s:%d: %s" % (rel, no, line))
     return problems
 
 
-def apply(checkout: Path, out: Path):
+def apply(checkout: Path, out: Path, keep_cuda: bool = False):
     """-> {edit description: times applied}.  Raises PatchError on any anchor problem or leftover CUDA name."""
     if out.exists():
         raise PatchError("%s exists; give a fresh output directory" % out)
@@ -687,24 +716,27 @@ def apply(checkout: Path, out: Path):
             raise PatchError("%s: file missing from the checkout" % file)
         text = path.read_text()
         for e in edits:
-            text, n = apply_edit(text, e)
+            text, n = apply_edit(text, e, keep_cuda)
             applied[e.what] = n
         path.write_text(text)
     (out / "src" / "hip").mkdir(parents=True, exist_ok=True)
     for g in GLUE_FILES:
         shutil.copy2(ROOT / g, out / "src" / "hip" / Path(g).name)
-    problems = check_tree(out)
+    problems = check_tree(out, raw=not keep_cuda)
     if problems:
-        raise PatchError("CUDA / cuBLAS names still visible to a --with-hip build:\n  " + "\n  ".join(problems))
+        raise PatchError("CUDA / cuBLAS names still %s:\n  " % ("visible to a --with-hip build" if keep_cuda else "in the tree's text") +
+                         "\n  ".join(problems))
     return applied
 
 
 def main(argv):
+    keep_cuda = "--keep-cuda" in argv
+    argv = [a for a in argv if a != "--keep-cuda"]
     if len(argv) != 3:
         print(__doc__, file=sys.stderr)
         return 2
     try:
-        applied = apply(Path(argv[1]).resolve(), Path(argv[2]).resolve())
+        applied = apply(Path(argv[1]).resolve(), Path(argv[2]).resolve(), keep_cuda)
     except PatchError as e:
         print("apply_with_hip: %s" % e, file=sys.stderr)
         return 2
