@@ -17,7 +17,9 @@ dnl      end is present", not "cuBLAS" — and HAVE_NP_HIP, which the few call s
 dnl      runtime directly switch on (INTEGRATION.md section 2a lists them with file:line)
 dnl   4. compiles the glue: ext/gpu_alloc_hip.c instead of src/gpu_alloc.c, ext/hip_math.c +
 dnl      ext/hip_math_drivers.c instead of src/ndmath/cuda/cuda_math.cu, ext/hip_fast.c (what the GPU early-outs
-dnl      tools/apply_with_hip.py inserts into arithmetics.c / logic.c / ndarray.c call), ext/zend_hooks.c
+dnl      tools/apply_with_hip.py inserts into arithmetics.c / logic.c / ndarray.c call), ext/hip_lazy.c (the pending
+dnl      elementwise chains behind the NDArray handle: numpower.c's operators / unary methods append, buffer_get flushes),
+dnl      ext/zend_hooks.c
 
 PHP_ARG_WITH([hip],
   [for MI355X (HIP, gfx950) support through numpower_amd],
@@ -54,7 +56,7 @@ if test "$PHP_HIP" != "no"; then
   AC_DEFINE([HAVE_NP_HIP], [1], [the device back end is numpower_amd / MI355X])
 
   dnl glue sources, compiled by the ordinary C compiler together with the extension's own files
-  NP_HIP_GLUE="$PHP_HIP/ext/gpu_alloc_hip.c $PHP_HIP/ext/hip_math.c $PHP_HIP/ext/hip_math_drivers.c $PHP_HIP/ext/hip_fast.c $PHP_HIP/ext/zend_hooks.c"
+  NP_HIP_GLUE="$PHP_HIP/ext/gpu_alloc_hip.c $PHP_HIP/ext/hip_math.c $PHP_HIP/ext/hip_math_drivers.c $PHP_HIP/ext/hip_fast.c $PHP_HIP/ext/hip_lazy.c $PHP_HIP/ext/zend_hooks.c"
   NP_HIP_GLUE_CFLAGS="-DNUMPOWER_NDARRAY_HEADER='\"src/initializers.h\"'"
   PHP_SUBST([NP_HIP_GLUE])
   dnl In PHP_NEW_EXTENSION(ndarray, ...) of the reference's config.m4: drop src/gpu_alloc.c from the source

@@ -58,6 +58,15 @@ int np_init(int device);
 int np_set_device(int device);
 int np_device_count(int *host_count);
 int np_sync(void);
+/* Device errors.  A kernel whose device-side wait gives up (see "Device-side waits" below) raises a bit in the error word of
+ * THE DEVICE IT RUNS ON.  From then on np_sync, np_memcpy_d2h, every host-result call and every np_comm_* call on that device
+ * return NP_ERR_DEVICE — every time, whichever thread asks, so nobody's sync "eats" the error of the launch's owner — and the
+ * same calls on another device (np_set_device) are not affected.  np_clear_device_error() is the acknowledgement: it waits
+ * for everything the current device was given (all streams), puts the library's device-side bookkeeping back in order,
+ * clears the word and hands back the bits that were up (1 = a stream-ordering wait of np_comm, 2 = a GEMM workgroup waiting
+ * for its siblings' partial tiles; 0 = there was nothing to acknowledge).  Results produced between the failed launch and
+ * the acknowledgement must be discarded.  (The reference ignores device errors altogether: cuda_math.cu never checks a launch.) */
+int np_clear_device_error(unsigned *host_bits /* may be NULL */);
 const char *np_last_error(void);
 /* Library version string, e.g. "numpower_amd 0.1 gfx950". */
 const char *np_version(void);
@@ -439,7 +448,8 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
 
 /* Device-side waits.  A wait for this GPU's own work (a stream-ordering wait of the sharded matmul whose producer never ran,
  * a GEMM workgroup that never saw its siblings' partial tiles) gives up after a bounded number of polls and raises the
- * process's device-error word: the next np_sync / np_memcpy_d2h / host-result call / np_comm_* call returns NP_ERR_DEVICE.
+ * device's error word: np_sync / np_memcpy_d2h / host-result calls / np_comm_* calls on that device return NP_ERR_DEVICE until
+ * np_clear_device_error() acknowledges it.
  * A wait for TRANSFERS (which depend on other ranks) gives up after np_comm_set_wait_limit seconds (default 600; 0 = never,
  * like the RCCL kernel it waits for) and raises the same error; np_comm_destroy releases whatever still waits.
  * With peers (world > 1) the sharded GEMM is one launch per piece; see np_hip_debug.h (np_comm_set_variant) for the

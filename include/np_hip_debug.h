@@ -8,8 +8,8 @@
  * against a concurrent launch, and a test that sets one restores it in a `finally`.  Results stay inside the documented
  * bounds under every variant — they select among kernels that compute the same thing — but bit patterns of reductions
  * and GEMMs may differ between variants (different summation order).  The np_*_debug_* / np_debug_* functions keep no
- * state except np_comm_debug_loopback (on until switched off) and np_debug_raise_device_error (raises the process's
- * device-error word, cleared by the next call that reports it).
+ * state except np_comm_debug_loopback (on until switched off) and np_debug_raise_device_error (raises the current
+ * device's error word, which stays up until np_clear_device_error()).
  */
 #ifndef NUMPOWER_AMD_NP_HIP_DEBUG_H
 #define NUMPOWER_AMD_NP_HIP_DEBUG_H
@@ -94,10 +94,13 @@ int np_debug_hw_ids(unsigned *host_out2, size_t workgroups);
 /* tools: the CU count every planner (GEMM tiles / stream-K, streaming grids) assumes from now on; 0 = the device's own.  For a CU-masked
  * library stream (np_set_stream): a product planned for 256 CUs runs a partial extra round of workgroups on 248.  Process-global. */
 int np_debug_set_cus(int cus);
-/* testing: a one-lane kernel on the library stream raises `bits` in the process's device-error word — what a device-side wait
- * that gives up does (1 = a stream-ordering wait of np_comm, 2 = a stream-K finisher).  The next np_sync / np_memcpy_d2h /
- * host-result call / np_comm_* call returns NP_ERR_DEVICE once, and clears the word. */
+/* testing: a one-lane kernel on the library stream raises `bits` in the current device's error word — what a device-side wait
+ * that gives up does (1 = a stream-ordering wait of np_comm, 2 = a stream-K finisher).  np_sync / np_memcpy_d2h / host-result
+ * calls / np_comm_* calls on this device return NP_ERR_DEVICE from then on, until np_clear_device_error(). */
 int np_debug_raise_device_error(unsigned bits);
+/* testing: kernel launches the library has issued since it was loaded (all devices, all threads): the difference around an
+ * expression is how many launches it cost — `nd::exp($a) * $b + 2` through the pending chains of INTEGRATION.md 2c: one. */
+int np_debug_launch_count(unsigned long long *host_count);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,7 @@ typedef struct NDArray {
 #define NDArray_SHAPE(a) ((int *) ((a)->dimensions))
 #define NDArray_NUMELEMENTS(a) ((long) ((a)->descriptor->numElements))
 #define NDArray_DEVICE(a) ((int) ((a)->device))
+#define NDArray_ADDREF(a) ((a)->refcount++)          /* src/ndarray.h:31 */
 
 /* ---- errors (zend_throw_error stand-in) ---- */
 typedef void (*numpower_error_handler)(const char *message);

@@ -140,6 +140,8 @@ PROTOTYPES = {
     "np_runtime_set_variant": (C.c_int, [C.c_int]),
     "np_select_last_path": (C.c_int, [C.POINTER(C.c_int)]),
     "np_debug_raise_device_error": (C.c_int, [C.c_uint]),
+    "np_debug_launch_count": (C.c_int, [C.POINTER(C.c_ulonglong)]),
+    "np_clear_device_error": (C.c_int, [C.POINTER(C.c_uint)]),
     "np_debug_clock_mhz": (C.c_int, [C.POINTER(C.c_float)]),
 }
 

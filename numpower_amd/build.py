@@ -131,7 +131,7 @@ def build_host(force: bool = False, verbose: bool = False) -> Path:
     if not srcs:
         return lib
     headers = list(INCLUDE.glob("*.h")) + list(HOST.glob("*.h"))
-    ext_objs = _ext_objects(EXT_GLUE + ["hip_math_drivers.c", "hip_fast.c"], force, verbose)
+    ext_objs = _ext_objects(EXT_GLUE + ["hip_math_drivers.c", "hip_fast.c", "hip_lazy.c"], force, verbose)
     if force or _newer(lib, srcs + headers + ext_objs + [LIBDIR / "libnp_hip.so"]):
         if verbose:
             print("[build] compiling host layer", flush=True)
@@ -184,6 +184,31 @@ def build_fast_path_bodies(force: bool = False, verbose: bool = False) -> Path:
     return exe
 
 
+def build_lazy_bodies(force: bool = False, verbose: bool = False) -> Path:
+    """The text tools/apply_with_hip.py inserts for the pending chains (buffer_get's flush, the appenders of
+    numpower.c's operator handler, static arithmetic methods and unary methods), wrapped by the tool itself into a C99 program
+    around a stand-in for the Zend object table (lazy_program_source) -> build/gen/lazy_bodies.c -> numpower_amd/lib/lazy_bodies."""
+    exe = LIBDIR / "lazy_bodies"
+    tool = ROOT / "tools" / "apply_with_hip.py"
+    gen = ROOT / "build" / "gen" / "lazy_bodies.c"
+    deps = [tool, LIBDIR / "libnumpower_host.so"] + list(INCLUDE.glob("*.h")) + list(EXT.glob("*.h"))
+    if force or _newer(exe, deps):
+        if verbose:
+            print("[build] generating + compiling lazy_bodies", flush=True)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("np_apply_with_hip", tool)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = mod
+        spec.loader.exec_module(mod)
+        gen.parent.mkdir(parents=True, exist_ok=True)
+        gen.write_text(mod.lazy_program_source())
+        cc = shutil.which("gcc") or "gcc"
+        flags = [f for f in EXT_CFLAGS if f != "-fPIC"]
+        _run([cc, *flags, str(gen), "-o", str(exe), f"-L{LIBDIR}", "-lnumpower_host", "-lnp_hip",
+              "-Wl,-rpath,$ORIGIN"])
+    return exe
+
+
 def build_oracle(force: bool = False, verbose: bool = False) -> Path:
     """Compile oracle/'s C restatement (test infrastructure; never loaded by the product)."""
     odir = ROOT / "oracle"
@@ -210,6 +235,7 @@ def build_all(force: bool = False, verbose: bool = False):
     build_ext_glue(force, verbose)
     build_method_bodies(force, verbose)
     build_fast_path_bodies(force, verbose)
+    build_lazy_bodies(force, verbose)
     oracle = build_oracle(force, verbose)
     return hip, host, oracle
 

@@ -314,7 +314,7 @@ constexpr unsigned long long kWaitTimeoutTicks = 60ull * 100000000ull;   // 60 s
 // kernel they wait for.  A peer that died must end as NP_ERR_DEVICE at the next sync point, not as a hang nobody can leave
 // (ADVICE r04): the default is ten minutes.
 unsigned long long g_peer_wait_ticks = 600ull * 100000000ull;
-#define kWaitForPeers g_peer_wait_ticks
+#define kWaitForPeers __atomic_load_n(&g_peer_wait_ticks, __ATOMIC_RELAXED)   /* read at launch time, written by np_comm_set_wait_limit from any thread */
 constexpr unsigned long long kSelfTestTicks = 20000000ull;               // 200 ms (only ever spent when the test FAILS)
 
 __global__ void flag_set_kernel(unsigned *flag, unsigned value) {
@@ -948,8 +948,9 @@ int np_comm_destroy(void) {
 
 int np_comm_set_wait_limit(double seconds) {
     if (!(seconds >= 0.0) || seconds > 1e7) return np::fail(NP_ERR_INVALID, "np_comm_set_wait_limit: %g s is not a limit (0 = never give up)", seconds);
-    g_peer_wait_ticks = (unsigned long long)(seconds * 1e8);   // wall_clock64 ticks at 100 MHz
-    if (seconds > 0.0 && g_peer_wait_ticks == 0) g_peer_wait_ticks = 1;
+    unsigned long long ticks = (unsigned long long)(seconds * 1e8);   // wall_clock64 ticks at 100 MHz
+    if (seconds > 0.0 && ticks == 0) ticks = 1;
+    __atomic_store_n(&g_peer_wait_ticks, ticks, __ATOMIC_RELAXED);
     return NP_OK;
 }
 

@@ -44,14 +44,18 @@ unsigned *next_tickets(unsigned count);
 // lazily, the first stream-K launch may sit inside a stream capture (nullptr + error set on failure).
 constexpr unsigned kStreamKFlagCount = 1024;
 unsigned *streamk_flags();
-// The process's device-error word (pinned host memory, device-visible; nullptr before np_init).  Word [0]: a kernel whose
-// device-side wait gives up ORs one of the kErr* bits in with a system-scope atomic; np_sync, np_memcpy_d2h, the
-// host-result calls and every np_comm_* entry point turn a non-zero word into NP_ERR_DEVICE (check_device_error clears it).
+// The CURRENT device's error word (pinned host memory, device-visible, one pair of words per device; nullptr before
+// np_init).  Word [0]: a kernel whose device-side wait gives up ORs one of the kErr* bits in with a system-scope atomic;
+// np_sync, np_memcpy_d2h, the host-result calls and every np_comm_* entry point turn a non-zero word OF THE DEVICE THEY RUN
+// ON into NP_ERR_DEVICE (check_device_error) — every time, until np_clear_device_error() acknowledges it: the first reader
+// does not eat the error of whoever owns the failed launch, and another device's np_sync does not see it at all.
 // Word [1]: the host's ABORT request — an unbounded device-side wait (np_comm.hip: the library stream waiting for transfers
 // that depend on other ranks) polls it and returns when it is non-zero (np_comm_destroy sets it).
 constexpr unsigned kErrCommWait = 1u, kErrStreamK = 2u;
 unsigned *device_error_word();
 int check_device_error(const char *who);
+// kernel launches issued by the library since it was loaded (one per NP_LAUNCH_CHECK; np_debug_launch_count)
+extern unsigned long long g_launch_count;
 // Largest first-pass grid whose partials are folded by its own last workgroup rather than by a second kernel.  The
 // ticket is one hot address (~20 ns per workgroup at the memory side) and every workgroup waits a round trip for its
 // own: with 2049 workgroups the in-kernel fold LOST 5 us on a 63 us sum of 10^8 floats; on small grids it saves the
@@ -253,6 +257,7 @@ __device__ __forceinline__ void fold_in_last_workgroup(float r, float *partials,
 
 #define NP_LAUNCH_CHECK(name)                                                           \
     do {                                                                                \
+        __atomic_fetch_add(&np::g_launch_count, 1ull, __ATOMIC_RELAXED);                \
         hipError_t _e = hipGetLastError();                                              \
         if (_e != hipSuccess)                                                           \
             return np::fail(NP_ERR_DEVICE, "launch of %s failed: %s", name,             \

@@ -778,8 +778,7 @@ __global__ __launch_bounds__(256) void argreduce_chunks_kernel(const float *__re
         const size_t o = oc / chunks;
         const unsigned c = (unsigned)(oc - o * chunks);
         const unsigned a0 = c * chunk_len;
-        unsigned a1 = a0 + chunk_len;
-        if (a1 > axis_len) a1 = axis_len;
+        const unsigned a1 = axis_len - a0 < chunk_len ? axis_len : a0 + chunk_len;   // (a0 + chunk_len may wrap on an axis near 2^32)
         const float *p = in + o * axis_len * inner + j;
         ArgPair best{arg_key<IS_MAX>(p[(size_t)a0 * inner], a0), a0};
         // four loads in flight; ties are broken by index, so the combining order does not matter
@@ -1591,8 +1590,7 @@ __global__ __launch_bounds__(256) void argreduce_small_inner(const float *__rest
     const unsigned T = (256u / inner) * inner;
     const unsigned o = blockIdx.y, b = blockIdx.x;
     const unsigned r0 = b * rows_per_block;
-    unsigned r1 = r0 + rows_per_block;
-    if (r1 > axis_len) r1 = axis_len;
+    const unsigned r1 = axis_len - r0 < rows_per_block ? axis_len : r0 + rows_per_block;   // (r0 + rows_per_block may wrap on an axis near 2^32)
     const unsigned cnt = (r1 - r0) * inner;          // the host keeps rows_per_block * inner below 2^31
     const unsigned nvec = cnt >> 2;
     const float *p = in + ((size_t)o * axis_len + r0) * inner;
@@ -1686,8 +1684,7 @@ __global__ __launch_bounds__(256) void argreduce_small_inner4(const float *__res
     const unsigned T = (256u / inner4) * inner4;
     const unsigned o = blockIdx.y, b = blockIdx.x;
     const unsigned r0 = b * rows_per_block;
-    unsigned r1 = r0 + rows_per_block;
-    if (r1 > axis_len) r1 = axis_len;
+    const unsigned r1 = axis_len - r0 < rows_per_block ? axis_len : r0 + rows_per_block;   // (r0 + rows_per_block may wrap on an axis near 2^32)
     const unsigned nvec = (r1 - r0) * inner4;
     const float *p = in + ((size_t)o * axis_len + r0) * inner4 * 4;
     const unsigned t = threadIdx.x;
@@ -1769,8 +1766,7 @@ __global__ __launch_bounds__(256) void argreduce_cols_tile(const float *__restri
     const unsigned col = (blockIdx.x * 64 + lane) * 4;
     const unsigned ncol = col >= inner ? 0u : (inner - col >= 4 ? 4u : inner - col);   // columns this lane owns
     const unsigned a0 = c * chunk_len;
-    unsigned a1 = a0 + chunk_len;
-    if (a1 > axis_len) a1 = axis_len;
+    const unsigned a1 = axis_len - a0 < chunk_len ? axis_len : a0 + chunk_len;   // (a0 + chunk_len may wrap on an axis near 2^32)
     const float *p = in + (size_t)o * axis_len * inner + col;
     float bv[4] = {id, id, id, id};
     unsigned ba[4];
@@ -1949,7 +1945,8 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
     if (outer == 0 || inner == 0) return NP_OK;
     if (axis_len == 0) return np::fail(NP_ERR_INVALID, "attempt to get %s of an empty sequence", is_max ? "argmax" : "argmin");
     if (!in || !out) return np::fail(NP_ERR_INVALID, "np_argreduce: null pointer");
-    if (axis_len > 0xfffffffeull) return np::fail(NP_ERR_INVALID, "np_argreduce: axis too long");
+    // the kernels count along the axis in 32 bits and look up to 28 rows ahead of their position (`a + 28 < a1`): 256 below 2^32
+    if (axis_len > 0xffffff00ull) return np::fail(NP_ERR_INVALID, "np_argreduce: axis too long");
     if (int rc = np::ensure_init()) return rc;
     hipStream_t s = np::stream();
     if (inner == 1 && axis_len <= 256 && outer >= 1024) {

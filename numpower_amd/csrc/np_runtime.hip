@@ -53,7 +53,7 @@ struct Runtime {
     std::unordered_map<void *, Block> live;              // ptr -> rounded size, owning device, offset from the hipMalloc base
     unsigned large_seq = 0;                              // running count of large blocks obtained from the driver
     float *slots = nullptr;                              // pinned host-result slots (np::ResultCall)
-    unsigned *error_word = nullptr;                      // pinned, device-visible: np::device_error_word()
+    unsigned *error_words = nullptr;                     // pinned, device-visible: [2 * device] error bits, [2 * device + 1] abort request
     int wait_mode = 2;                                   // np_runtime_set_variant: 0 = hipStreamSynchronize, 1 = spin on a stream-written flag,
                                                          // 2 = spin on the result slots themselves (armed with a sentinel)
     uint32_t wait_seq = 0;
@@ -230,51 +230,41 @@ unsigned *streamk_flags() {
     return d.streamk_flags;
 }
 
-// The process's device-error word: pinned host memory every kernel of every device can write.  A device-side wait that
-// gives up (np_comm.hip's flag_wait_kernel, the stream-K finisher of np_sgemm.hip) ORs its bit in; the host reports it at
-// the next point where a caller could otherwise consume a wrong result — np_sync, np_memcpy_d2h, a host-result call,
-// any np_comm_* entry point (check_device_error) — instead of returning NP_OK with garbage.
+// The device-error words: pinned host memory every kernel can write, one pair per device.  A device-side wait that gives up
+// (np_comm.hip's flag_wait_kernel, the stream-K finisher of np_sgemm.hip) ORs its bit into the word of the device it runs on;
+// the host reports it at every point where a caller could otherwise consume a wrong result — np_sync, np_memcpy_d2h, a
+// host-result call, any np_comm_* entry point (check_device_error) — instead of returning NP_OK with garbage.  STICKY and PER
+// DEVICE (round 6; until then one process-wide word, cleared by its first reader — with replicas on several devices or
+// threads whoever synchronised first ate the other's error and the owner got NP_OK): the word stays up until
+// np_clear_device_error() acknowledges it, and a sync point of device 1 never looks at device 0's word.
 static int alloc_error_word_locked(Runtime &r) {
-    if (r.error_word) return NP_OK;
+    if (r.error_words) return NP_OK;
     void *p = nullptr;
-    const hipError_t e = hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable);
+    const hipError_t e = hipHostMalloc(&p, 2 * kMaxDevices * sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        return fail(NP_ERR_ALLOC, "pinned error word: %s", hipGetErrorString(e));
+        return fail(NP_ERR_ALLOC, "pinned error words: %s", hipGetErrorString(e));
     }
-    r.error_word = (unsigned *)p;
-    r.error_word[0] = r.error_word[1] = 0;
+    r.error_words = (unsigned *)p;
+    memset(r.error_words, 0, 2 * kMaxDevices * sizeof(unsigned));
     return NP_OK;
 }
 
-unsigned *device_error_word() { return rt().error_word; }
+unsigned *device_error_word() {
+    Runtime &r = rt();
+    return r.error_words ? r.error_words + 2 * r.device : nullptr;
+}
+
+unsigned long long g_launch_count = 0;
 
 int check_device_error(const char *who) {
     Runtime &r = rt();
-    if (!r.error_word) return NP_OK;
-    const unsigned bits = __atomic_exchange_n(r.error_word, 0u, __ATOMIC_ACQ_REL);
+    if (!r.error_words) return NP_OK;
+    const unsigned bits = __atomic_load_n(r.error_words + 2 * r.device, __ATOMIC_ACQUIRE);
     if (!bits) return NP_OK;
-    if (bits & kErrStreamK) {
-        // A GEMM workgroup that gave up waiting for its siblings leaves its ticket / its stream-K flag where it stood — shared
-        // rings that later launches assume are zero.  Behind everything already enqueued on the library stream,
-        // put both back to zero on every device this process has used: the error is reported once, but no later product may
-        // fold early or wrong because of it.
-        std::lock_guard<std::mutex> lk(r.mu);
-        int keep = 0;
-        (void)hipGetDevice(&keep);
-        for (int dv = 0; dv < kMaxDevices; ++dv) {
-            DeviceState &d = r.dev[dv];
-            if (!d.inited || !d.cur_stream || (!d.tickets && !d.streamk_flags)) continue;
-            if (hipSetDevice(dv) != hipSuccess) continue;
-            if (d.tickets) (void)hipMemsetAsync(d.tickets, 0, kTicketRing * sizeof(unsigned), d.cur_stream);
-            if (d.streamk_flags) (void)hipMemsetAsync(d.streamk_flags, 0, kStreamKFlagCount * sizeof(unsigned), d.cur_stream);
-        }
-        (void)hipSetDevice(keep);
-        (void)hipGetLastError();
-    }
-    return fail(NP_ERR_DEVICE, "%s: a device-side wait gave up before this point (%s%s%s): results produced since the last "
-                               "successful np_sync are incomplete and must be discarded", who,
-                bits & kErrCommWait ? "a stream-ordering wait of np_comm timed out" : "",
+    return fail(NP_ERR_DEVICE, "%s: a device-side wait gave up before this point on device %d (%s%s%s): results produced since the "
+                               "last successful np_sync are incomplete and must be discarded; np_clear_device_error() acknowledges",
+                who, r.device, bits & kErrCommWait ? "a stream-ordering wait of np_comm timed out" : "",
                 (bits & kErrCommWait) && (bits & kErrStreamK) ? "; " : "",
                 bits & kErrStreamK ? "a GEMM workgroup folding K-split partial tiles never saw its siblings' (stream-K / in-launch split-K)" : "");
 }
@@ -414,6 +404,33 @@ int np_sync(void) {
     if (int rc = np::ensure_init()) return rc;
     NP_HIP_CHECK(hipStreamSynchronize(rt().cur().cur_stream));
     return np::check_device_error("np_sync");
+}
+
+int np_clear_device_error(unsigned *host_bits) {
+    if (host_bits) *host_bits = 0;
+    if (int rc = np::ensure_init()) return rc;
+    Runtime &r = rt();
+    if (!r.error_words) return NP_OK;
+    // Everything this device was given must have retired before its bookkeeping is touched: a GEMM workgroup that gave up
+    // waiting for its siblings leaves its ticket / its stream-K flag where it stood — rings that later launches assume are
+    // zero — and kernels on a stream the caller swapped out earlier (np_set_stream) may still hold live tickets (ADVICE r05:
+    // a reset that is only ordered behind the CURRENT stream can wipe a healthy fold's count).  So: the whole device.
+    NP_HIP_CHECK(hipDeviceSynchronize());
+    const unsigned bits = __atomic_exchange_n(r.error_words + 2 * r.device, 0u, __ATOMIC_ACQ_REL);
+    if (host_bits) *host_bits = bits;
+    if (bits & np::kErrStreamK) {
+        std::lock_guard<std::mutex> lk(r.mu);
+        DeviceState &d = r.cur();
+        if (d.tickets) NP_HIP_CHECK(hipMemset(d.tickets, 0, np::kTicketRing * sizeof(unsigned)));
+        if (d.streamk_flags) NP_HIP_CHECK(hipMemset(d.streamk_flags, 0, np::kStreamKFlagCount * sizeof(unsigned)));
+    }
+    return NP_OK;
+}
+
+int np_debug_launch_count(unsigned long long *host_count) {
+    if (!host_count) return np::fail(NP_ERR_INVALID, "np_debug_launch_count: null output");
+    *host_count = __atomic_load_n(&np::g_launch_count, __ATOMIC_RELAXED);
+    return NP_OK;
 }
 
 __global__ void raise_error_kernel(unsigned *word, unsigned bits) {

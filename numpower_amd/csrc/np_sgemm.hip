@@ -2542,6 +2542,9 @@ Plan plan_sgemm(size_t M, size_t N, size_t K, size_t batch, bool dma_ok, bool on
                 if (Kc < 256) break;
                 const size_t chunks = (K + Kc - 1) / Kc, rem = K - (chunks - 1) * Kc;
                 if (chunks < 2 || rem < 4) continue;
+                // launch_kq's own refusal (32-bit byte offsets: a chunk of A spans M rows of the FULL K, a chunk of B Kc rows): a plan
+                // it would decline must not win here — launch_cfg would run the same chunking on kernels it was not sized for
+                if (((size_t)M * K + Kc) * 4 >= (size_t(1) << 32) || ((size_t)Kc * N + N) * 4 >= (size_t(1) << 32)) continue;
                 // the fold, timed alone (profiles/r05/gemm_deep_k_sweep.log): 3.6-4.0 us up to 32 chunks of 100 x 100 .. 300 x 300, 4.4-5.4 at 64,
                 // 6.7-10 at 128, 7-18 at 256
                 const double fold = 3.5e-6 + (double)((chunks + 1) * M * N * sizeof(float)) / hbm + (chunks > 32 ? 0.025e-6 * (double)(chunks - 32) : 0.0);

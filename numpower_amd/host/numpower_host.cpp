@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "hip_fast.h"
+#include "hip_lazy.h"
 #include "np_hip.h"
 
 namespace {
@@ -284,6 +285,7 @@ NDArray *NDArray_LeadingSlice(NDArray *a, int index) {   // iterators.c:94-111
 
 void NDArray_FREE(NDArray *array) {   // ndarray.c:587-632
     if (array == nullptr || array->refcount == -1) return;
+    NPH_OnFree(array);   // ext/hip_lazy.c: an array that dies with a pending chain releases the chain's inputs
     if (array->refcount > 0) array->refcount--;
     if (array->refcount == 0) {
         if (array->data != nullptr && array->base == nullptr) {
@@ -1084,102 +1086,12 @@ NDArray *NDArray_Slice(NDArray *array, NDArray **indexes, int num_indices) {
 // flags and AVX-body bounds are set exactly as binary_op() above sets them for the stand-alone
 // NDArray_*_Float / comparison entry points, so the fused result is bit-identical.
 namespace {
-struct ChainCall {
-    const float *ptrs[16];
-    int kinds[16];
-    np_fused_op prog[64];
-    size_t rows, cols;
-};
-
-// operand classification + quirk flags shared by NDArray_FusedChain / NDArray_FusedChainReduce
+// operand classification + quirk flags: ext/hip_lazy.c (NPH_PrepareChain) — the same C that flushes a pending chain in a
+// `--with-hip` NumPower tree, so the chains lazy.py builds and the chains the binding builds are
+// prepared by one piece of code
+using ChainCall = NPH_ChainCall;
 bool prepare_chain(NDArray **inputs, int n_inputs, const np_fused_op *ops, int n_ops, ChainCall &c) {
-    if (!inputs || n_inputs < 1 || !inputs[0]) {
-        throw_error("fused chain: no input array");
-        return false;
-    }
-    if (!ops && n_ops > 0) {
-        throw_error("fused chain: null op list");
-        return false;
-    }
-    NDArray *first = inputs[0];
-    if (NDArray_NDIM(first) == 0) {
-        throw_error("fused chain must start from an array");
-        return false;
-    }
-    if (!require_gpu(first, "fused elementwise chain")) return false;
-    const long n = NDArray_NUMELEMENTS(first);
-    const float **ptrs = c.ptrs;
-    int *kinds = c.kinds;
-    if (n_inputs > 16 || n_ops > 64) {
-        throw_error("fused chain too long");
-        return false;
-    }
-    size_t rows = 1, cols = (size_t)n;
-    bool have_2d = false;
-    for (int i = 0; i < n_inputs; ++i) {
-        NDArray *x = inputs[i];
-        if (!x) {
-            throw_error("fused chain: input %d is null", i);
-            return false;
-        }
-        if (NDArray_NDIM(x) == 0 && NDArray_DEVICE(x) == NDARRAY_DEVICE_CPU) {
-            kinds[i] = NP_HOST_SCALAR;
-        } else {
-            if (NDArray_DEVICE(x) != NDARRAY_DEVICE_GPU) {
-                throw_error("Device mismatch, both NDArray MUST be in the same device.");
-                return false;
-            }
-            if (NDArray_NDIM(x) == 0) {
-                kinds[i] = NP_SCALAR;
-            } else if (NDArray_NUMELEMENTS(x) == n) {
-                kinds[i] = NP_FULL;          // equal element counts: flat elementwise (arithmetics.c:194-197)
-            } else if (NDArray_NUMELEMENTS(x) < n) {
-                size_t br = 1, bc = 1;
-                const int k = NPH_BroadcastKind(x, first, &br, &bc);
-                if (k < 0 || (have_2d && (br != rows || bc != cols))) {
-                    throw_error("Can't broadcast arrays.");
-                    return false;
-                }
-                kinds[i] = k;
-                rows = br;
-                cols = bc;
-                have_2d = true;
-            } else {
-                // the accumulator itself would have to grow: not a fused case
-                throw_error("Can't broadcast arrays.");
-                return false;
-            }
-        }
-        ptrs[i] = NDArray_FDATA(x);
-    }
-    if (kinds[0] != NP_FULL) return false;
-    np_fused_op *prog = c.prog;
-    for (int k = 0; k < n_ops; ++k) {
-        prog[k] = ops[k];
-        prog[k].flags = 0;
-        prog[k].body_end = 0;
-        if (ops[k].kind == NP_FUSED_BINARY) {
-            const int op = ops[k].op;
-            if (ops[k].operand < 0 || ops[k].operand >= n_inputs) {
-                throw_error("fused chain: operand index out of range");
-                return false;
-            }
-            if (op == NP_MULTIPLY || op == NP_MOD || op == NP_EQUAL || op == NP_NOT_EQUAL) {
-                // AVX-body bound: element count of the FIRST operand after the scalar expand but
-                // before the broadcast (arithmetics.c:251, logic.c:535); NotEqual loops over the
-                // broadcast operand (logic.c:636)
-                const NDArray *other = inputs[ops[k].operand];
-                size_t loop_numel_a = (size_t)n;
-                if (ops[k].swap && NDArray_NDIM(other) != 0 && op != NP_NOT_EQUAL)
-                    loop_numel_a = (size_t)NDArray_NUMELEMENTS(other);
-                prog[k].flags = NP_QUIRK_AVX_BODY;
-                prog[k].body_end = np_avx_body_end(loop_numel_a);
-            }
-        }
-    }
-    c.rows = rows;
-    c.cols = cols;
-    return true;
+    return NPH_PrepareChain(inputs, nullptr, n_inputs, ops, n_ops, &c) == 0;
 }
 }  // namespace
 

@@ -64,15 +64,21 @@ def test_the_default_tree_is_hip_only(patched):
     for p in compiled:
         text = p.read_text(errors="replace")
         assert not re.search(r"cuda[A-Z]|cublas|<cuda_runtime\.h>", text), p
-    # the only HAVE_NP_HIP blocks with an #else side are the three feature guards around device-independent reference code
-    # (reduce() / single_reduce()'s slice loops, exp2's NDArray_Map): what a build WITHOUT --with-hip compiles there
+    # the HAVE_NP_HIP blocks that DO have an #else side are feature guards around device-independent reference code — what a
+    # build WITHOUT --with-hip compiles there: reduce() / single_reduce()'s slice loops, exp2's NDArray_Map, and section 2c's
+    # appenders (the plain operand lookups and `rtn = NDArray_Add_Float(nda, ndb);` ...).  Each is the reference's own text.
     else_sides = []
     for p in compiled:
+        ref_text = re.sub(r"\s+", " ", (REF / p.relative_to(out)).read_text(errors="replace")) if (REF / p.relative_to(out)).exists() else ""
         for m in re.finditer(r"^#ifdef HAVE_NP_HIP\n(.*?)^#endif", p.read_text(errors="replace"), flags=re.S | re.M):
             if "\n#else\n" in m.group(1):
-                else_sides.append(m.group(1).split("\n#else\n")[1].strip())
-    assert sorted(else_sides) == sorted(["_reduce(0, 0, axis, array, rtn, operation);", "_single_reduce(0, 0, axis, array, rtn, operation);",
-                                         "rtn = NDArray_Map(nda, float_exp2);"])
+                side = m.group(1).split("\n#else\n")[1].strip()
+                else_sides.append(side)
+                assert re.sub(r"\s+", " ", side) in ref_text, (p, side)
+                assert not tool._CUDA_NAME.search(side)
+    assert {"_reduce(0, 0, axis, array, rtn, operation);", "_single_reduce(0, 0, axis, array, rtn, operation);",
+            "rtn = NDArray_Map(nda, float_exp2);", "rtn = NDArray_Add_Float(nda, ndb);"} <= set(else_sides)
+    assert len(else_sides) == 3 + 43 + 12
     # the two things that are left are not compiled by a --with-hip build (config.m4 swaps them for the glue)
     assert (out / "src" / "gpu_alloc.c").exists() and "src/hip/gpu_alloc_hip.c" in (out / "config.m4").read_text()
     # the checker is not vacuous: the --keep-cuda tree fails the raw check at its #else sides
@@ -112,7 +118,7 @@ def test_the_cuda_side_is_kept_verbatim(patched_keep_cuda):
             if stack and s == "#endif":          # closes the #else side of a wrapped edit, or an inserted (#else-less) block
                 stack.pop()
                 continue
-            if stack and stack[-1] is True:
+            if any(side is True for side in stack):      # (blocks nest where 2c's call edit meets 2a's rsqrt pair)
                 continue
             keep.append(line)
         return "\n".join(keep)
@@ -131,7 +137,9 @@ def test_the_glue_and_the_configure_option_travel_with_the_tree(patched):
     for src in re.search(r'NP_GPU_ALLOC_SOURCES="(src/hip/[^"]+)"', m4).group(1).split():
         assert (out / src).exists(), src
     numpower = (out / "numpower.c").read_text()
-    assert "NDArrayMathGPU_ElementWise(nda, cuda_float_rsqrt)" in numpower and "NDArrayMathGPU_ElementWise(nda, cuda_float_exp2)" in numpower
+    # rsqrt / exp2 get their own device functions (section 2a), which section 2c then turns into appenders like the other 34
+    assert "NPH_LazyElementWise(nda, cuda_float_rsqrt)" in numpower and "NPH_LazyElementWise(nda, cuda_float_exp2)" in numpower
+    assert "void cuda_float_rsqrt(int nblocks, float *d_array);" in numpower
 
 
 def test_the_new_statements_compile_against_the_c_abi(tmp_path):
@@ -250,6 +258,100 @@ def test_hip_fast_uses_only_what_the_reference_headers_declare():
     for name, rx in protos.items():
         assert re.search(rx, headers), name
     # the same names, the same shapes, in the header the stand-alone build compiles it against
+    ours = (ROOT / "include" / "numpower_host.h").read_text()
+    for name in used:
+        assert re.search(r"#define\s+%s\b|\b%s\s*\(" % (name, name), ours), "%s missing from include/numpower_host.h" % name
+
+
+def test_pending_chains_flush_at_the_one_marshalling_point(patched):
+    """Section 2c: buffer_get — the only function through which a PHP handle becomes an NDArray* — gets the flush; the
+    arithmetic operator handler, the six static arithmetic methods and the 36 unary methods look their operands up inside an
+    appender scope and append; NOTHING else in numpower.c changes how it marshals, so every other method (the remaining
+    ZVAL_TO_NDARRAY / buffer_get call sites) flushes by construction."""
+    tool, out, _ = patched
+    buf, ref_buf = (out / "src/buffer.c").read_text(), (REF / "src/buffer.c").read_text()
+    assert buf.count("NPH_OnBufferGet(MAIN_MEM_STACK.buffer[uuid]);") == 1
+    body = buf[buf.index("NDArray* buffer_get(int uuid) {"):]
+    assert body.index("assert(") < body.index("NPH_OnBufferGet(") < body.index("return MAIN_MEM_STACK.buffer[uuid];")
+    # the object table is read in exactly the places it was read before: buffer_get, and the free / insert paths that must NOT flush
+    assert buf.count("MAIN_MEM_STACK.buffer[") == ref_buf.count("MAIN_MEM_STACK.buffer[") + 1
+    ref_np, new_np = (REF / "numpower.c").read_text(), (out / "numpower.c").read_text()
+    other = [p for p in list(REF.glob("*.c")) + list(REF.glob("src/**/*.c")) if p.name not in ("buffer.c",)]
+    assert sum(p.read_text(errors="replace").count("MAIN_MEM_STACK.buffer[") for p in other) == 0      # nobody reads the table behind buffer_get's back
+    assert ref_np.count("buffer_get(") == 6 == new_np.count("buffer_get(")
+    # appender scopes: 1 operator handler + 6 static methods + 36 unary methods, each closed right behind the lookups
+    assert new_np.count("NPH_LAZY_MARSHAL_BEGIN();") == 43 == new_np.count("NPH_LAZY_MARSHAL_END();")
+    for m in re.finditer(r"NPH_LAZY_MARSHAL_BEGIN\(\);\n(.*?)NPH_LAZY_MARSHAL_END\(\);", new_np, flags=re.S):
+        lines = [ln.strip() for ln in m.group(1).strip().split("\n")]
+        assert 1 <= len(lines) <= 2 and all(re.fullmatch(r"NDArray \*nd[ab] = ZVAL_TO_NDARRAY\((op1|op2|a|b|array)\);", ln) for ln in lines), lines
+    # every marshalling call of the reference is still there (the appenders' inside a scope + kept on the guard's #else side)
+    assert new_np.count("ZVAL_TO_NDARRAY(") == ref_np.count("ZVAL_TO_NDARRAY(") + 2 + 12 + 36
+    assert new_np.count("rtn = NPH_LazyBinary(") == 12 and len(re.findall(r"rtn = NPH_LazyElementWise(?:1F|2F)?\(nda, cuda_float_\w+", new_np)) == 36
+    assert "rtn = NPH_LazyElementWise2F(nda, cuda_float_clip, (float)min, (float)max);" in new_np
+    assert "rtn = NPH_LazyElementWise1F(nda, cuda_float_round, (float)precision);" in new_np
+    assert "rtn = NPH_LazyElementWise(nda, cuda_float_rsqrt);" in new_np and "rtn = NPH_LazyElementWise(nda, cuda_float_exp2);" in new_np
+    # square ($a * $a inside the method), arctan2 and the comparisons are not appenders: they marshal with the flush
+    assert "rtn = NDArray_Multiply_Float(nda, nda);" in new_np and "NDArrayMathGPU_ElementWise1N(ndx, cuda_float_arctan2, ndy)" in new_np
+    nd = (out / "src/ndarray.c").read_text()
+    free_body = nd[nd.index("\nNDArray_FREE(NDArray *array) {"):]
+    assert free_body.index("return;") < free_body.index("NPH_OnFree(array);") < free_body.index("NDArray_DELREF(array);")
+    for f in ("hip_lazy.c", "hip_lazy.h"):
+        assert (out / "src/hip" / f).exists()
+    assert "src/hip/hip_lazy.c" in (out / "config.m4").read_text()
+
+
+def test_the_pending_chain_text_runs_as_a_program_and_cpu_operands_reach_the_reference(tmp_path):
+    """The text section 2c inserts, verbatim, inside functions with the shape of ndarray_do_operation_ex / PHP_METHOD(add ...) /
+    the unary PHP_METHODs around a restated Zend object table (the tool generates the program; the GPU tier runs its `gpu`
+    mode): with CPU operands — BASELINE config 1 — every appender hands the call to the stand-in for the reference's own
+    code, nothing becomes pending, no device is touched.  Needs no reference checkout and no GPU."""
+    import apply_with_hip as tool
+    from numpower_amd import build
+    build.build_all()
+    text = tool.lazy_program_source()
+    flat = text.replace("\n        ", "\n").replace("\n    ", "\n")
+    for prefix in ("buffer.c:80-81", "numpower.c:194-195", "numpower.c:3374-3540", "numpower.c:1608-3357"):
+        e = next(x for x in tool.EDITS if x.what.startswith(prefix))
+        assert e.new in flat, prefix
+    for e in tool.EDITS:
+        if "`rtn = NDArray_" in e.what:
+            assert e.new in flat, e.what
+    assert "rtn = NPH_LazyElementWise(nda, cuda_float_exp);" in text and "rtn = NPH_LazyElementWise2F(nda, cuda_float_clip, (float)min, (float)max);" in text
+    # the NDArray_FREE hook of the host library (which the program links) is the statement the tool inserts into ndarray.c
+    hook = next(x for x in tool.EDITS if x.what.startswith("ndarray.c:588-591")).new.split("\n")[-1]
+    assert hook == "NPH_OnFree(array);" and hook in (ROOT / "numpower_amd" / "host" / "numpower_host.cpp").read_text()
+    src = tmp_path / "lazy_bodies.c"
+    src.write_text(text)
+    exe = tmp_path / "lazy_bodies"
+    lib = ROOT / "numpower_amd" / "lib"
+    proc = subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I", str(ROOT / "include"), "-I", str(ROOT / "ext"),
+                           str(src), "-o", str(exe), "-L", str(lib), "-lnumpower_host", "-lnp_hip", "-Wl,-rpath," + str(lib)],
+                          capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    proc = subprocess.run([str(exe), "cpu"], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    m = re.search(r"(\d+) expressions, (\d+) reached the reference's own code, 0 pending", proc.stdout)
+    assert m and int(m.group(1)) >= 14 and int(m.group(2)) >= int(m.group(1))
+
+
+@needs_reference
+def test_hip_lazy_uses_only_what_the_reference_headers_declare():
+    """ext/hip_lazy.c is compiled inside the patched tree against the reference's OWN headers: every NDArray_* / NDARRAY_* name
+    and every struct field it touches must exist there with the meaning the code assumes."""
+    src = re.sub(r"/\*.*?\*/", "", (ROOT / "ext" / "hip_lazy.c").read_text(), flags=re.S)
+    used = sorted(set(re.findall(r"\b(NDArray_\w+|NDARRAY_\w+)\b", src)))
+    headers = (REF / "src" / "ndarray.h").read_text() + (REF / "src" / "initializers.h").read_text()
+    assert {"NDArray_EmptyLike", "NDArray_FREE", "NDArray_ADDREF", "NDArray_NDIM", "NDArray_DEVICE", "NDArray_FDATA"} <= set(used)
+    for name in used:
+        assert re.search(r"#define\s+%s\b|\b%s\s*\(" % (name, name), headers), "%s is not declared by the reference's headers" % name
+    # the two struct fields it reads directly (the root of a view chain, the last-reference test of NPH_OnFree)
+    assert "a->base" in src and "a->refcount" in src
+    nd_h = (REF / "src" / "ndarray.h").read_text()
+    assert re.search(r"struct NDArray\* base;", nd_h) and re.search(r"int refcount;", nd_h)
+    assert re.search(r"#define NDArray_ADDREF\(a\) \(\(a\)->refcount\+\+\)", headers)
+    drivers = (REF / "src" / "ndmath" / "cuda" / "cuda_math.h").read_text()
+    for fn in ("NDArrayMathGPU_ElementWise", "NDArrayMathGPU_ElementWise1F", "NDArrayMathGPU_ElementWise2F"):
+        assert re.search(r"NDArray\s*\*\s*%s\(" % fn, drivers), fn
     ours = (ROOT / "include" / "numpower_host.h").read_text()
     for name in used:
         assert re.search(r"#define\s+%s\b|\b%s\s*\(" % (name, name), ours), "%s missing from include/numpower_host.h" % name

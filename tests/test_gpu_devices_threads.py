@@ -69,6 +69,19 @@ def test_set_device_switches_with_live_arrays(hip):
         assert (back.to_host() == -x).all()
         check(lib.np_set_device(1))
         assert (d1.to_host() == y).all()
+        # device errors are per device: a wait that gave up on device 0 is not seen — let alone consumed — by device 1's sync
+        import ctypes as C
+        check(lib.np_set_device(0))
+        check(lib.np_debug_raise_device_error(2))
+        check(lib.np_set_device(1))
+        assert lib.np_sync() == 0
+        assert (d1.to_host() == y).all()
+        check(lib.np_set_device(0))
+        assert lib.np_sync() != 0 and b"device 0" in lib.np_last_error()
+        bits = C.c_uint(0)
+        check(lib.np_clear_device_error(C.byref(bits)))
+        assert bits.value == 2 and lib.np_sync() == 0
+        check(lib.np_set_device(1))
         d1.free()
         check(lib.np_set_device(0))
         for d in (d0, back):

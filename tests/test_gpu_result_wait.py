@@ -48,29 +48,46 @@ def test_wait_modes_agree(hip):
         a.free(); b.free(); o.free()
 
 
-def test_device_error_word_is_reported_once_at_the_next_sync_point():
+def test_device_error_is_sticky_per_device_and_needs_an_acknowledgement():
     """A device-side wait that gives up (np_comm's bounded stream-ordering wait, a stream-K finisher whose peers never
-    posted) raises the process's device-error word instead of letting NP_OK travel with a wrong result:
-    np_sync, np_memcpy_d2h and the host-result calls each turn it into NP_ERR_DEVICE — once; the word is clear afterwards."""
+    posted) raises the error word OF ITS DEVICE instead of letting NP_OK travel with a wrong result.  np_sync, np_memcpy_d2h
+    and the host-result calls on that device return NP_ERR_DEVICE — EVERY time and to EVERY thread, until
+    np_clear_device_error() acknowledges: the first reader no longer eats the error of whoever owns the failed launch
+    (VERDICT r05 weak #12; until round 6 the word was process-wide and cleared by its first reader)."""
     import ctypes as C
+    import threading
     from numpower_amd._lib import load
     lib = load()
     assert lib.np_init(0) == 0
+    assert lib.np_clear_device_error(None) == 0
     x = np.arange(1024, dtype=np.float32)
     dev = C.c_void_p()
     assert lib.np_malloc(C.byref(dev), x.nbytes) == 0
     assert lib.np_memcpy_h2d(dev, x.ctypes.data, x.nbytes) == 0
     out = C.c_float(0.0)
     back = np.empty_like(x)
-    for bits, what, call in (
-            (1, b"np_comm", lambda: lib.np_sync()),
-            (2, b"stream-K", lambda: lib.np_memcpy_d2h(back.ctypes.data, dev, x.nbytes)),
-            (3, b"stream-K", lambda: lib.np_reduce_all(0, dev, 1024, C.byref(out)))):
+    calls = ((b"np_comm", lambda: lib.np_sync()),
+             (b"np_comm", lambda: lib.np_memcpy_d2h(back.ctypes.data, dev, x.nbytes)),
+             (b"np_comm", lambda: lib.np_reduce_all(0, dev, 1024, C.byref(out))))
+    for bits, what in ((1, b"np_comm"), (2, b"stream-K"), (3, b"stream-K")):
         assert lib.np_debug_raise_device_error(bits) == 0
-        assert call() != 0
-        msg = lib.np_last_error()
-        assert b"device-side wait gave up" in msg and what in msg, msg
-        assert call() == 0, lib.np_last_error()          # reported once: the word is clear again
+        for _ in range(2):                                   # sticky: every sync point reports it, as often as it is asked
+            for _, call in calls:
+                assert call() != 0
+                msg = lib.np_last_error()
+                assert b"device-side wait gave up" in msg and what in msg and b"device 0" in msg, msg
+        # another thread that synchronises first does not take the error away from this one
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(lib.np_sync()))
+        t.start()
+        t.join()
+        assert seen and seen[0] != 0
+        assert lib.np_sync() != 0
+        got = C.c_uint(0)
+        assert lib.np_clear_device_error(C.byref(got)) == 0 and got.value == bits
+        for _, call in calls:
+            assert call() == 0, lib.np_last_error()
+        assert lib.np_clear_device_error(C.byref(got)) == 0 and got.value == 0      # nothing left to acknowledge
     assert lib.np_sync() == 0
     assert (back == x).all() and out.value == float(x.sum())
     assert lib.np_free(dev) == 0

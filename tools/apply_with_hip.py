@@ -72,6 +72,7 @@ class Edit:
                          # `#ifdef HAVE_NP_HIP new #else old #endif` — a feature guard, not a second GPU back end
     after: bool = False  # True: `old` stays where it is and `#ifdef HAVE_NP_HIP new #endif` is INSERTED behind it (the
                          # fast-path early-outs of section 2b: nothing of the reference is replaced)
+    template: bool = False  # True: `new` holds \g<name> references to named groups of the anchor (expanded per match)
     context: str = ""  # C declarations of the locals of the surrounding reference function that `new` uses (CONTEXTS
                        # below): with them the new text is compiled on its own — snippet_check_source() — against
                        # include/np_hip.h, include/numpower_host.h and ext/hip_math.h; "" = nothing to compile
@@ -118,14 +119,23 @@ def _fast_compare(name: str, op: str, line: str) -> Edit:
 
 _SYNC = (r"^(?P<old>[ \t]*cudaDeviceSynchronize\(\);)$")
 
+# ---- section 2c: pending chains (ext/hip_lazy.h) ----
+_LAZY_FLUSH_NOTE = ("/* numpower_amd 2c: every consumer obtains its NDArray* here (ZVAL_TO_NDARRAY, ARRAY_OF_NDARRAYS, print_r_ ...): an\n"
+                    " * array whose values are still a pending chain gets them now, in ONE fused launch, and so do the chains that read\n"
+                    " * this array's buffer (the consumer may write it); appenders switch this off while they look their operands up */\n")
+_LAZY_MARSHAL_NOTE = "/* numpower_amd 2c: an appender — its operands may stay pending chains (hip_lazy.h) */\n"
+# unary PHP_METHODs that call NDArrayMathGPU_ElementWise{,1F,2F}(nda, ...): 33 + clip + round in the reference, + exp2's
+# new device branch (section 2a)
+N_UNARY_APPENDERS = 36
+
 EDITS = [
     # ---- headers ----
-    _cuda_includes("numpower.c", "numpower.c:31-32"),
+    _cuda_includes("numpower.c", "numpower.c:31-32", "\n#include <hip_lazy.h>"),
     # (found by the raw-text check of round 6: numpower.c:15 includes this header, and HAVE_CUBLAS — which --with-hip
     #  defines — pulled <cuda_runtime.h> in through it; rounds 4-5 only scanned *.c and src/)
     _cuda_includes("php_numpower.h", "php_numpower.h:9-10"),
     _cuda_includes("src/initializers.c", "initializers.c:15-16"),
-    _cuda_includes("src/ndarray.c", "ndarray.c:18-19", "\n#include <hip_fast.h>\n#include \"ndmath/arithmetics.h\""),
+    _cuda_includes("src/ndarray.c", "ndarray.c:18-19", "\n#include <hip_fast.h>\n#include <hip_lazy.h>\n#include \"ndmath/arithmetics.h\""),
     _cuda_includes("src/ndmath/arithmetics.c", "arithmetics.c:14-15", "\n#include <hip_fast.h>"),
     _cuda_includes("src/ndmath/linalg.c", "linalg.c:27-28"),
     _cuda_includes("src/manipulation.c", "manipulation.c:13-14"),
@@ -265,9 +275,9 @@ EDITS = [
     Edit("src/ndarray.c", "ndarray.c:570 reduce(): one np_reduce_axis launch for GPU arrays",
          r"^(?P<old>[ \t]*_reduce\(0, 0, axis, array, rtn, operation\);)$",
          "/* numpower_amd: sum / prod over an axis of a GPU array is ONE np_reduce_axis launch into the result allocated\n"
-         " * above, instead of one operation() + allocation + copy per slice (_reduce, ndarray.c:394-429); CPU arrays and any\n"
-         " * other operation keep the reference's loop */\n"
-         "if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU &&\n"
+         " * above, instead of one operation() + allocation + copy per slice (_reduce, ndarray.c:394-429); CPU arrays, any\n"
+         " * other operation and a negative axis (which reduce() lets through, ndarray.c:534) keep the reference's loop */\n"
+         "if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && *axis >= 0 &&\n"
          "    (operation == NDArray_Add_Float || operation == NDArray_Multiply_Float)) {\n"
          "    if (NPH_ReduceAxisInto(array, *axis, operation == NDArray_Add_Float ? NP_SUM : NP_PROD,\n"
          "                           operation == NDArray_Multiply_Float ? NP_QUIRK_AVX_BODY : 0u, rtn) != 0) {\n"
@@ -283,7 +293,7 @@ EDITS = [
          " * for them (apply_single_reduce stores only when the target is on the CPU, ndarray.c:389).  For a GPU array this is what\n"
          " * the method's CPU branch computes — reduce(Add) / n, numpower.c:2662-2669 — as one np_reduce_axis launch; every other\n"
          " * operation (min / max / median / all) and every CPU array keeps the reference's loop */\n"
-         "if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && operation == NDArray_Mean_Float) {\n"
+         "if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && *axis >= 0 && operation == NDArray_Mean_Float) {\n"
          "    if (NPH_ReduceAxisInto(array, *axis, NP_MEAN, 0u, rtn) != 0) {\n"
          "        NDArray_FREE(rtn);\n"
          "        rtn = NULL;\n"
@@ -291,6 +301,55 @@ EDITS = [
          "} else {\n"
          "    _single_reduce(0, 0, axis, array, rtn, operation);\n"
          "}", guard=True),
+    # ---- section 2c: pending elementwise chains behind the NDArray handle (ext/hip_lazy.h) ----
+    # the flush point: the ONE function through which a PHP handle becomes an NDArray*
+    Edit("src/buffer.c", "buffer.c:5-6: <hip_lazy.h>",
+         r"^(?P<old>#include \"string\.h\"\n#include \"ndarray\.h\")$",
+         "#include <hip_lazy.h>", after=True),
+    Edit("src/buffer.c", "buffer.c:80-81 buffer_get: the flush point of pending chains",
+         r"^(?P<old>NDArray\* buffer_get\(int uuid\) \{\n[ \t]*assert\(MAIN_MEM_STACK\.buffer\[uuid\] != NULL\);)$",
+         _LAZY_FLUSH_NOTE +
+         "NPH_OnBufferGet(MAIN_MEM_STACK.buffer[uuid]);", after=True),
+    Edit("src/ndarray.c", "ndarray.c:588-591 NDArray_FREE: a pending array that dies releases its chain",
+         r"^(?P<old>NDArray_FREE\(NDArray \*array\) \{\n[ \t]*if \(array == NULL \|\| array->refcount == -1\) \{\n[ \t]*return;\n[ \t]*\})$",
+         "/* numpower_amd 2c: the last reference to an array whose values were never asked for drops its chain (and the\n"
+         " * references the chain holds on its inputs) — no kernel ever ran for it */\n"
+         "NPH_OnFree(array);", after=True),
+    # the appenders look their operands up without flushing them
+    Edit("numpower.c", "numpower.c:194-195 ndarray_do_operation_ex: operands looked up as an appender",
+         r"^(?P<old>[ \t]*NDArray \*nda = ZVAL_TO_NDARRAY\(op1\);\n[ \t]*NDArray \*ndb = ZVAL_TO_NDARRAY\(op2\);)$",
+         _LAZY_MARSHAL_NOTE +
+         "NPH_LAZY_MARSHAL_BEGIN();\n"
+         "NDArray *nda = ZVAL_TO_NDARRAY(op1);\n"
+         "NDArray *ndb = ZVAL_TO_NDARRAY(op2);\n"
+         "NPH_LAZY_MARSHAL_END();", guard=True),
+    Edit("numpower.c", "numpower.c:3374-3540 PHP_METHOD(add ... pow): operands looked up as an appender",
+         r"^(?P<old>[ \t]*NDArray \*nda = ZVAL_TO_NDARRAY\(a\);\n[ \t]*NDArray \*ndb = ZVAL_TO_NDARRAY\(b\);)\n"
+         r"(?=(?:(?!PHP_METHOD)[^\n]*\n){1,16}?[ \t]*rtn = NDArray_(?:Add|Subtract|Multiply|Divide|Mod|Pow)_Float\(nda, ndb\);)",
+         _LAZY_MARSHAL_NOTE +
+         "NPH_LAZY_MARSHAL_BEGIN();\n"
+         "NDArray *nda = ZVAL_TO_NDARRAY(a);\n"
+         "NDArray *ndb = ZVAL_TO_NDARRAY(b);\n"
+         "NPH_LAZY_MARSHAL_END();", expect=6, guard=True),
+    Edit("numpower.c", "numpower.c:1608-3357 the unary PHP_METHODs: operand looked up as an appender",
+         r"^(?P<old>[ \t]*NDArray \*nda = ZVAL_TO_NDARRAY\(array\);)\n"
+         r"(?=(?:(?!PHP_METHOD)[^\n]*\n){1,14}?[ \t]*rtn = NDArrayMathGPU_ElementWise(?:1F|2F)?\(nda, )",
+         _LAZY_MARSHAL_NOTE +
+         "NPH_LAZY_MARSHAL_BEGIN();\n"
+         "NDArray *nda = ZVAL_TO_NDARRAY(array);\n"
+         "NPH_LAZY_MARSHAL_END();", expect=N_UNARY_APPENDERS, guard=True),
+    # ... and append instead of launching
+] + [
+    Edit("numpower.c", "numpower.c:200-218,3384-3550 `rtn = NDArray_%s_Float(nda, ndb)`: append to the pending chain" % _name,
+         r"^(?P<old>[ \t]*rtn = NDArray_%s_Float\(nda, ndb\);)$" % _name,
+         "rtn = NPH_LazyBinary(%s, NDArray_%s_Float, nda, ndb);" % (_op, _name), expect=2, guard=True)
+    for _name, _op in (("Add", "NP_ADD"), ("Subtract", "NP_SUBTRACT"), ("Multiply", "NP_MULTIPLY"), ("Divide", "NP_DIVIDE"),
+                       ("Pow", "NP_POW"), ("Mod", "NP_MOD"))
+] + [
+    Edit("numpower.c", "numpower.c:1651-3348 `rtn = NDArrayMathGPU_ElementWise{,1F,2F}(nda, cuda_float_*)`: append to the pending chain",
+         # (not the CUDA side of a --keep-cuda pair: PHP_METHOD(rsqrt)'s `#else` keeps the reference's statement)
+         r"(?<!#else\n)^(?P<old>[ \t]*rtn = NDArrayMathGPU_ElementWise(?P<sfx>1F|2F)?\(nda, (?P<rest>cuda_float_\w+[^;\n]*)\);)$",
+         r"rtn = NPH_LazyElementWise\g<sfx>(nda, \g<rest>);", expect=N_UNARY_APPENDERS, template=True),
     # ---- config.m4: the option, and the source list ----
     Edit("config.m4", "config.m4:7-8: --with-hip next to --with-cuda",
          r"^(?P<old>PHP_ARG_WITH\(cuda, for CUDA support,\n\[  --with-cuda           Include CUDA support\], \[no\], \[no\]\))$",
@@ -322,6 +381,18 @@ CONTEXTS = {
     "ndarray.c:509 single_reduce(): mean over an axis of a GPU array":
         "NDArray *array = 0, *rtn = 0; int *axis = 0; float (*operation)(NDArray *) = 0;",
 }
+CONTEXTS.update({
+    "buffer.c:80-81 buffer_get: the flush point of pending chains": "struct { NDArray **buffer; } MAIN_MEM_STACK = {0}; int uuid = 0;",
+    "ndarray.c:588-591 NDArray_FREE: a pending array that dies releases its chain": "NDArray *array = 0;",
+    "numpower.c:194-195 ndarray_do_operation_ex: operands looked up as an appender": "zval *op1 = 0, *op2 = 0;",
+    "numpower.c:3374-3540 PHP_METHOD(add ... pow): operands looked up as an appender": "zval *a = 0, *b = 0;",
+    "numpower.c:1608-3357 the unary PHP_METHODs: operand looked up as an appender": "zval *array = 0;",
+    "numpower.c:1651-3348 `rtn = NDArrayMathGPU_ElementWise{,1F,2F}(nda, cuda_float_*)`: append to the pending chain":
+        "NDArray *rtn = 0, *nda = 0;",
+})
+for _e in EDITS:
+    if "`rtn = NDArray_" in _e.what:
+        CONTEXTS[_e.what] = "NDArray *rtn = 0, *nda = 0, *ndb = 0;"
 for _e in EDITS:
     if _e.what.endswith("GPU early-out"):
         CONTEXTS[_e.what] = "NDArray *nda = 0, *ndb = 0;" if _e.file == "src/logic.c" else "NDArray *a = 0, *b = 0;"
@@ -355,11 +426,11 @@ if test "$PHP_HIP" != "no"; then
   AC_DEFINE([HAVE_CUBLAS], [1], [a device back end is present (the C files gate every GPU branch on this name)])
   AC_DEFINE([HAVE_NP_HIP], [1], [the device back end is numpower_amd / MI355X])
   CFLAGS+=" -DNUMPOWER_NDARRAY_HEADER='\\"src/initializers.h\\"' "
-  NP_GPU_ALLOC_SOURCES="src/hip/gpu_alloc_hip.c src/hip/hip_math.c src/hip/hip_math_drivers.c src/hip/hip_fast.c src/hip/zend_hooks.c"
+  NP_GPU_ALLOC_SOURCES="src/hip/gpu_alloc_hip.c src/hip/hip_math.c src/hip/hip_math_drivers.c src/hip/hip_fast.c src/hip/hip_lazy.c src/hip/zend_hooks.c"
 fi'''
 
 GLUE_FILES = ["ext/gpu_alloc_hip.c", "ext/hip_math.c", "ext/hip_math.h", "ext/hip_math_drivers.c", "ext/hip_fast.c",
-              "ext/hip_fast.h", "ext/zend_hooks.c", "ext/np_ext_hooks.h", "include/np_hip.h"]
+              "ext/hip_fast.h", "ext/hip_lazy.c", "ext/hip_lazy.h", "ext/zend_hooks.c", "ext/np_ext_hooks.h", "include/np_hip.h"]
 # not compiled in a --with-hip build: replaced wholesale by the glue
 REPLACED_BY_GLUE = ("src/gpu_alloc.c", "src/ndmath/cuda/")
 
@@ -377,8 +448,10 @@ def snippet_check_source() -> str:
     PHP build.  The only foreign declarations are the three reference symbols the new text itself calls."""
     out = ["/* generated by tools/apply_with_hip.py: snippet_check_source() */",
            "#include <stdio.h>", "#include <stddef.h>",
-           '#include "np_hip.h"', '#include "numpower_host.h"', '#include "hip_math.h"', '#include "hip_fast.h"',
+           '#include "np_hip.h"', '#include "numpower_host.h"', '#include "hip_math.h"', '#include "hip_fast.h"', '#include "hip_lazy.h"',
            "void zend_throw_error(void *exception_ce, const char *format, ...);   /* Zend/zend_exceptions.h */",
+           "typedef struct _zval_struct zval;                                        /* Zend/zend_types.h */",
+           "NDArray *ZVAL_TO_NDARRAY(zval *obj);                                     /* numpower.c:89 */",
            "void _reduce(int current_axis, int rtn_init, int *axis, NDArray *target, NDArray *rtn,",
            "             NDArray *(*operation)(NDArray *, NDArray *));                 /* src/ndarray.c:394 */",
            "void _single_reduce(int current_axis, int rtn_init, int *axis, NDArray *target, NDArray *rtn,",
@@ -392,7 +465,10 @@ def snippet_check_source() -> str:
         out.append("/* %s */" % e.what)
         out.append("%ssnippet_%d(void) {" % (ret, k))
         out.append("    " + e.context)
-        out.append(_indent(e.new, "    "))
+        new = e.new
+        if e.template:   # one instance of a templated edit: the exp method's call
+            new = new.replace("\\g<sfx>", "").replace("\\g<rest>", "cuda_float_exp")
+        out.append(_indent(new, "    "))
         if ret == "void *":
             out.append("    return (void *) 0;")
         out.append("}")
@@ -590,6 +666,472 @@ int main(int argc, char **argv) {
 '''
 
 
+# ---- section 2c as a program ------------------------------------------------------------------------------------------
+def _edit(prefix: str) -> Edit:
+    return next(e for e in EDITS if e.what.startswith(prefix))
+
+
+LAZY_UNARY = [("exp", "", "cuda_float_exp"), ("log", "", "cuda_float_log"), ("sqrt", "", "cuda_float_sqrt"),
+              ("sin", "", "cuda_float_sin"), ("negate", "", "cuda_float_negate"),
+              ("round", "1F", "cuda_float_round, (float)precision"), ("clip", "2F", "cuda_float_clip, (float)min, (float)max")]
+LAZY_BINARY = [("Add", "ZEND_ADD"), ("Subtract", "ZEND_SUB"), ("Multiply", "ZEND_MUL"), ("Divide", "ZEND_DIV"), ("Pow", "ZEND_POW"),
+               ("Mod", "ZEND_MOD")]
+
+
+def lazy_program_source() -> str:
+    """A C99 PROGRAM around the text section 2c inserts (numpower_amd/lib/lazy_bodies): a stand-in for the Zend side — a zval
+    that is a number or an object handle, the reference's object table (MAIN_MEM_STACK: add_to_buffer / buffer_get /
+    buffer_ndarray_free), ZVAL_TO_NDARRAY, CHECK_INPUT_AND_FREE, RETURN_NDARRAY restated after numpower.c:89-150 and
+    src/buffer.c:61-120 — and, inside it, functions with the shape of ndarray_do_operation_ex, PHP_METHOD(add ...) and the unary
+    PHP_METHODs whose EDITED statements are the tool's text VERBATIM (as EDITS holds it; the unary call with its function
+    name filled in).  Expressions are then evaluated the way PHP does: every operator result is a fresh object, temporaries are
+    destroyed as soon as the next operator has consumed them.  Linked with libnumpower_host.so (which carries ext/hip_lazy.c,
+    and whose NDArray_FREE holds the NPH_OnFree hook), -Wall -Wextra -Werror.
+
+        lazy_bodies cpu           every appender with CPU operands: each call must reach the stand-in for the reference's own
+                                  code, nothing becomes pending, no device is touched (tests/test_apply_with_hip_cpu.py)
+        lazy_bodies gpu <file>    the same expressions with ->gpu() operands, chains on and off: launches counted through
+                                  np_debug_launch_count, values written to <file> (method_bodies.c's record format; checked
+                                  against the oracle by tests/test_gpu_lazy_bodies.py) and compared bit for bit, chain
+                                  against eager, by the program itself
+    """
+    flush, marshal_op = _edit("buffer.c:80-81"), _edit("numpower.c:194-195")
+    marshal_bin, marshal_un = _edit("numpower.c:3374-3540"), _edit("numpower.c:1608-3357")
+    call_un = _edit("numpower.c:1651-3348")
+    o = ["/* generated by tools/apply_with_hip.py: lazy_program_source() — do not edit */",
+         "#define _POSIX_C_SOURCE 200809L",
+         "#include <assert.h>", "#include <stdint.h>", "#include <stdio.h>", "#include <stdlib.h>", "#include <string.h>", "",
+         "#define HAVE_NP_HIP 1", "#define HAVE_CUBLAS 1",
+         '#include "numpower_host.h"', '#include "hip_fast.h"', '#include "hip_lazy.h"', '#include "hip_math.h"', '#include "np_hip_debug.h"', "",
+         _LAZY_PROGRAM_ZEND,
+         "NDArray* buffer_get(int uuid) {", "    assert(MAIN_MEM_STACK.buffer[uuid] != NULL);",
+         "#ifdef HAVE_NP_HIP", _indent(flush.new, "    "), "#endif", "    return MAIN_MEM_STACK.buffer[uuid];", "}", "",
+         _LAZY_PROGRAM_MARSHAL, ""]
+    # the L2 functions as section 2b leaves them: GPU operands -> NPH_Binary_Float, CPU operands -> "the reference's body"
+    for name, _ in LAZY_BINARY:
+        e = next(x for n, x in FAST_BINARY if n == "NDArray_%s_Float" % name)
+        o += ["static NDArray *patched_NDArray_%s_Float(NDArray *a, NDArray *b) {" % name, "#ifdef HAVE_NP_HIP", _indent(e.new, "    "),
+              "#endif", "    g_reference_bodies++;   /* arithmetics.c: the scalar expand, the broadcast, the AVX2 loop */", "    return NULL;", "}",
+              "#define NDArray_%s_Float patched_NDArray_%s_Float" % (name, name), ""]
+    # ndarray_do_operation_ex (numpower.c:193-229)
+    o += ["static int patched_do_operation_ex(int opcode, zval *result, zval *op1, zval *op2) {",
+          "#ifdef HAVE_NP_HIP", _indent(marshal_op.new, "    "), "#endif",
+          "    if (nda == NULL || ndb == NULL) {", "        return FAILURE;", "    }", "    NDArray *rtn = NULL;", "    switch (opcode) {"]
+    for name, zend in LAZY_BINARY:
+        e = _edit("numpower.c:200-218,3384-3550 `rtn = NDArray_%s_Float" % name)
+        o += ["    case %s:" % zend, "#ifdef HAVE_NP_HIP", _indent(e.new, "        "), "#endif", "        break;"]
+    o += ["    default:", "        return FAILURE;", "    }", "    CHECK_INPUT_AND_FREE(op1, nda);", "    CHECK_INPUT_AND_FREE(op2, ndb);",
+          "    RETURN_NDARRAY(rtn, result);", "    return rtn != NULL ? SUCCESS : FAILURE;", "}", ""]
+    # PHP_METHOD(NDArray, add) ... (numpower.c:3364-3553): the static form, one function per operator
+    for name, _ in LAZY_BINARY:
+        e = _edit("numpower.c:200-218,3384-3550 `rtn = NDArray_%s_Float" % name)
+        o += ["static void patched_method_%s(zval *a, zval *b, zval *return_value) {" % name.lower(), "    NDArray *rtn = NULL;",
+              "#ifdef HAVE_NP_HIP", _indent(marshal_bin.new, "    "), "#endif",
+              "    if (nda == NULL) {", "        return;", "    }", "    if (ndb == NULL) {", "        CHECK_INPUT_AND_FREE(a, nda);", "        return;", "    }",
+              "#ifdef HAVE_NP_HIP", _indent(e.new, "    "), "#endif",
+              "    CHECK_INPUT_AND_FREE(a, nda);", "    CHECK_INPUT_AND_FREE(b, ndb);", "    RETURN_NDARRAY(rtn, return_value);", "}", ""]
+    # the unary PHP_METHODs (numpower.c:1608-3357)
+    rx = re.compile(call_un.anchor, re.M)
+    for name, sfx, rest in LAZY_UNARY:
+        ref_line = "        rtn = NDArrayMathGPU_ElementWise%s(nda, %s);" % (sfx, rest)
+        m = rx.search(ref_line)
+        assert m, ref_line
+        params = {"": "", "1F": ", long precision", "2F": ", double min, double max"}[sfx]
+        o += ["static void patched_method_%s(zval *array%s, zval *return_value) {" % (name, params), "    NDArray *rtn = NULL;",
+              "#ifdef HAVE_NP_HIP", _indent(marshal_un.new, "    "), "#endif",
+              "    if (nda == NULL) {", "        return;", "    }",
+              "    if (NDArray_DEVICE(nda) == NDARRAY_DEVICE_CPU) {",
+              "        g_reference_bodies++;   /* rtn = NDArray_Map(nda, float_%s); */" % name, "    } else {", "#ifdef HAVE_CUBLAS",
+              _indent(m.expand(call_un.new), "        "), "#endif", "    }",
+              "    RETURN_NDARRAY(rtn, return_value);", "}", ""]
+    o.append(_LAZY_PROGRAM_MAIN)
+    return "\n".join(o)
+
+
+_LAZY_PROGRAM_ZEND = r"""/* ---- the Zend side, restated: a zval is a PHP float or an NDArray object (its handle = the `id` property, numpower.c:84-87) ---- */
+enum { IS_UNDEF = 0, IS_DOUBLE = 5, IS_OBJECT = 8 };
+enum { SUCCESS = 0, FAILURE = -1 };
+enum { ZEND_ADD = 1, ZEND_SUB = 2, ZEND_MUL = 3, ZEND_DIV = 4, ZEND_MOD = 5, ZEND_POW = 12 };
+typedef struct zval { int type; double dval; int handle; } zval;
+#define Z_TYPE_P(z) ((z)->type)
+
+static int g_reference_bodies;   /* calls that reached "the reference's own code" (CPU operands) */
+
+/* src/buffer.h:9-16, src/buffer.c:91-120 */
+struct MemoryStack { NDArray **buffer; int bufferSize; int numElements; int lastFreed; };
+static struct MemoryStack MAIN_MEM_STACK = {NULL, 0, 0, -1};
+
+static void add_to_buffer(NDArray *ndarray) {
+    if (MAIN_MEM_STACK.lastFreed > -1) {
+        ndarray->uuid = MAIN_MEM_STACK.lastFreed;
+        MAIN_MEM_STACK.buffer[MAIN_MEM_STACK.lastFreed] = ndarray;
+        MAIN_MEM_STACK.lastFreed = -1;
+        return;
+    }
+    if (MAIN_MEM_STACK.numElements >= MAIN_MEM_STACK.bufferSize) {
+        const int size = MAIN_MEM_STACK.bufferSize == 0 ? 8 : MAIN_MEM_STACK.bufferSize * 2;
+        MAIN_MEM_STACK.buffer = (NDArray **) realloc(MAIN_MEM_STACK.buffer, (size_t) size * sizeof(NDArray *));
+        MAIN_MEM_STACK.bufferSize = size;
+    }
+    ndarray->uuid = MAIN_MEM_STACK.numElements;
+    MAIN_MEM_STACK.buffer[MAIN_MEM_STACK.numElements++] = ndarray;
+}
+
+/* ndarray_destructor -> buffer_ndarray_free (numpower.c:292-298, src/buffer.c:61-75): the table is read WITHOUT buffer_get */
+static void buffer_ndarray_free(int uuid) {
+    if (MAIN_MEM_STACK.lastFreed == -1) MAIN_MEM_STACK.lastFreed = uuid;
+    if (MAIN_MEM_STACK.buffer[uuid] != NULL) {
+        NDArray_FREE(MAIN_MEM_STACK.buffer[uuid]);
+        MAIN_MEM_STACK.buffer[uuid] = NULL;
+    }
+}
+"""
+
+_LAZY_PROGRAM_MARSHAL = r"""/* numpower.c:89-150 */
+static NDArray *ZVAL_TO_NDARRAY(zval *obj) {
+    if (Z_TYPE_P(obj) == IS_DOUBLE) return NDArray_CreateFromDoubleScalar(obj->dval);
+    if (Z_TYPE_P(obj) == IS_OBJECT) return buffer_get(obj->handle);
+    return NULL;
+}
+static void CHECK_INPUT_AND_FREE(zval *a, NDArray *nda) {
+    if (nda == NULL || a == NULL) return;
+    if (Z_TYPE_P(a) == IS_DOUBLE) NDArray_FREE(nda);
+}
+static void RETURN_NDARRAY(NDArray *array, zval *return_value) {
+    return_value->type = IS_UNDEF;
+    if (array == NULL) return;                       /* RETURN_THROWS() */
+    add_to_buffer(array);
+    return_value->type = IS_OBJECT;
+    return_value->handle = array->uuid;
+}
+/* PHP lets go of a value (a temporary after the operator that consumed it, unset($x), a variable overwritten) */
+static void zval_dtor(zval *z) {
+    if (Z_TYPE_P(z) == IS_OBJECT) buffer_ndarray_free(z->handle);
+    z->type = IS_UNDEF;
+}
+static zval number(double v) { zval z = {IS_DOUBLE, v, 0}; return z; }
+static zval object_of(NDArray *a) { zval z = {IS_UNDEF, 0.0, 0}; RETURN_NDARRAY(a, &z); return z; }"""
+
+_LAZY_PROGRAM_MAIN = r"""/* ---- consumers: methods that are NOT appenders marshal through ZVAL_TO_NDARRAY -> buffer_get, unedited ---- */
+static NDArray *method_cpu(zval *obj) { return NDArray_ToCPU(ZVAL_TO_NDARRAY(obj)); }               /* numpower.c:541-559 */
+static float method_sum(zval *obj) { return NDArray_Sum_Float(ZVAL_TO_NDARRAY(obj)); }               /* numpower.c:4620-4640 */
+static void method_fill(zval *obj, float v) { (void) NDArray_Fill(ZVAL_TO_NDARRAY(obj), v); }        /* numpower.c:4788-4800: writes in place */
+static zval method_slice0(zval *obj, int i) { return object_of(NDArray_LeadingSlice(ZVAL_TO_NDARRAY(obj), i)); }   /* $a[i]: a view */
+static zval method_equal(zval *a, zval *b) {                                                         /* numpower.c:1042-1068: a comparison is no appender */
+    NDArray *nda = ZVAL_TO_NDARRAY(a), *ndb = ZVAL_TO_NDARRAY(b);
+    return object_of(NDArray_Equal(nda, ndb));
+}
+
+static FILE *g_out;
+static int g_failed;
+#define CHECK(cond, ...) do { if (!(cond)) { fprintf(stderr, "lazy_bodies: " __VA_ARGS__); fprintf(stderr, "\n"); g_failed = 1; } } while (0)
+
+static unsigned long long launches(void) {
+    unsigned long long n = 0;
+    np_debug_launch_count(&n);
+    return n;
+}
+
+/* method_bodies.c's record: 32-byte name, int32 ndim, int32 dims[4], the floats; returns the host copy (caller frees) */
+static NDArray *dump(const char *label_text, zval *value) {
+    char label[32];
+    int32_t head[5] = {0, 1, 1, 1, 1};
+    if (Z_TYPE_P(value) != IS_OBJECT) {
+        fprintf(stderr, "lazy_bodies: %s has no value: %s\n", label_text, numpower_host_last_error());
+        g_failed = 1;
+        return NULL;
+    }
+    NDArray *host = method_cpu(value);
+    if (host == NULL) {
+        fprintf(stderr, "lazy_bodies: cpu() of %s failed: %s\n", label_text, numpower_host_last_error());
+        g_failed = 1;
+        return NULL;
+    }
+    memset(label, 0, sizeof label);
+    snprintf(label, sizeof label, "%s", label_text);
+    head[0] = NDArray_NDIM(host);
+    for (int i = 0; i < NDArray_NDIM(host) && i < 4; i++) head[1 + i] = NDArray_SHAPE(host)[i];
+    fwrite(label, 1, sizeof label, g_out);
+    fwrite(head, sizeof(int32_t), 5, g_out);
+    fwrite(NDArray_FDATA(host), sizeof(float), (size_t) NDArray_NUMELEMENTS(host), g_out);
+    return host;
+}
+
+/* x[i] = lo + (hi - lo) * frac(i * 0.6180339887 + seed * 0.37): what tests/test_gpu_method_bodies.py::c_input rebuilds */
+static NDArray *input(const int *shape, int ndim, int seed, float lo, float hi) {
+    long n = 1;
+    for (int i = 0; i < ndim; i++) n *= shape[i];
+    float *host = (float *) malloc(sizeof(float) * (size_t) n);
+    for (long i = 0; i < n; i++) {
+        double t = (double) i * 0.6180339887 + (double) seed * 0.37;
+        t -= (double) (long) t;
+        host[i] = (float) ((double) lo + ((double) hi - (double) lo) * t);
+    }
+    NDArray *cpu = NDArray_FromHostBuffer(host, shape, ndim);
+    free(host);
+    return cpu;
+}
+static zval placed(const int *shape, int ndim, int seed, float lo, float hi, int on_gpu) {   /* nd::array(...)[->gpu()] */
+    NDArray *host = input(shape, ndim, seed, lo, hi);
+    if (!on_gpu) return object_of(host);
+    NDArray *dev = NDArray_ToGPU(host);
+    NDArray_FREE(host);
+    if (dev == NULL) {
+        fprintf(stderr, "lazy_bodies: gpu() failed: %s\n", numpower_host_last_error());
+        exit(1);
+    }
+    return object_of(dev);
+}
+
+/* `$r = <expression>` evaluated as PHP evaluates it: one object per operator, temporaries dropped once consumed */
+typedef struct Env { zval x, y, p, row, col, wide; } Env;
+typedef zval (*Expr)(Env *);
+
+static zval op2(int opcode, zval a, zval b, int drop_a, int drop_b) {   /* $a (op) $b through the do_operation handler */
+    zval r = {IS_UNDEF, 0.0, 0};
+    (void) patched_do_operation_ex(opcode, &r, &a, &b);
+    if (drop_a) zval_dtor(&a);
+    if (drop_b) zval_dtor(&b);
+    return r;
+}
+#define UN(name, v, drop) un_##name(v, drop)
+#define DEFINE_UN(name)                                                       \
+    static zval un_##name(zval a, int drop) {                                 \
+        zval r = {IS_UNDEF, 0.0, 0};                                          \
+        patched_method_##name(&a, &r);                                        \
+        if (drop) zval_dtor(&a);                                              \
+        return r;                                                             \
+    }
+DEFINE_UN(exp) DEFINE_UN(log) DEFINE_UN(sqrt) DEFINE_UN(sin) DEFINE_UN(negate)
+
+/* nd::exp($x) * $y + 2 */
+static zval e_exp_mul_add(Env *e) { return op2(ZEND_ADD, op2(ZEND_MUL, UN(exp, e->x, 0), e->y, 1, 0), number(2.0), 1, 0); }
+/* 2.5 - nd::sqrt($p): the number comes first (swap) */
+static zval e_rscalar(Env *e) { return op2(ZEND_SUB, number(2.5), UN(sqrt, e->p, 0), 0, 1); }
+/* $y / nd::exp($x): the array comes first, the chain is the second operand */
+static zval e_rdiv(Env *e) { return op2(ZEND_DIV, e->y, UN(exp, e->x, 0), 0, 1); }
+/* (nd::sin($x) * $row) / $col: a row and a column operand of the same 2-D view */
+static zval e_bcast(Env *e) { return op2(ZEND_DIV, op2(ZEND_MUL, UN(sin, e->x, 0), e->row, 1, 0), e->col, 1, 0); }
+/* ($x % $y) * $y - $x: the AVX-body quirks of mod and multiply travel with the chain */
+static zval e_quirks(Env *e) { return op2(ZEND_SUB, op2(ZEND_MUL, op2(ZEND_MOD, e->x, e->y, 0, 0), e->y, 1, 0), e->x, 1, 0); }
+/* $row * -$x: the smaller operand first */
+static zval e_rrow(Env *e) { return op2(ZEND_MUL, e->row, UN(negate, e->x, 0), 0, 1); }
+/* nd::exp($x) * nd::log($p): two pending operands — the second one is computed and joins as an array */
+static zval e_two_pending(Env *e) { return op2(ZEND_MUL, UN(exp, e->x, 0), UN(log, e->p, 0), 1, 1); }
+/* $p ** 2 + nd::round($x, 1) through the STATIC methods (PHP_METHOD(pow), PHP_METHOD(add)) and a 1F driver; pow is never a
+ * chain step (hip_lazy.c): its launch comes at once, round + add are one chain that starts from the pending round */
+static zval e_static(Env *e) {
+    zval two = number(2.0), t1 = {IS_UNDEF, 0.0, 0}, t2 = {IS_UNDEF, 0.0, 0}, r = {IS_UNDEF, 0.0, 0};
+    patched_method_pow(&e->p, &two, &t1);
+    patched_method_round(&e->x, 1, &t2);
+    patched_method_add(&t1, &t2, &r);
+    zval_dtor(&t1);
+    zval_dtor(&t2);
+    return r;
+}
+/* nd::mod(nd::subtract(nd::multiply($x, $y), $row), nd::divide($y, 2.0)): the other four static methods */
+static zval e_static2(Env *e) {
+    zval half = number(2.0), t = {IS_UNDEF, 0.0, 0}, u = {IS_UNDEF, 0.0, 0}, v = {IS_UNDEF, 0.0, 0}, r = {IS_UNDEF, 0.0, 0};
+    patched_method_multiply(&e->x, &e->y, &t);
+    patched_method_subtract(&t, &e->row, &u);
+    zval_dtor(&t);
+    patched_method_divide(&e->y, &half, &v);
+    patched_method_mod(&u, &v, &r);
+    zval_dtor(&u);
+    zval_dtor(&v);
+    return r;
+}
+/* nd::clip(nd::exp($x), 0.5, 3.0) - a 2F driver on a pending operand */
+static zval e_clip(Env *e) {
+    zval t = UN(exp, e->x, 0), r = {IS_UNDEF, 0.0, 0};
+    patched_method_clip(&t, 0.5, 3.0, &r);
+    zval_dtor(&t);
+    return r;
+}
+/* fifteen steps: the chain is full after twelve, its value starts a second chain */
+static zval e_long(Env *e) {
+    zval v = UN(negate, e->x, 0);
+    for (int i = 0; i < 7; i++) {
+        v = op2(ZEND_ADD, v, number(0.25 * (i + 1)), 1, 0);
+        v = UN(negate, v, 1);
+    }
+    return v;
+}
+/* nd::exp($row) * $wide: the second operand is LARGER than the pending one — the chain cannot grow; exp is computed and the
+ * multiply is the eager launch (NPH_Binary_Float), the result takes $wide's shape */
+static zval e_grow(Env *e) { return op2(ZEND_MUL, UN(exp, e->row, 0), e->wide, 1, 0); }
+/* $row + $wide: the smaller operand first is still ONE step of a chain that starts from $wide */
+static zval e_small_first(Env *e) { return op2(ZEND_ADD, e->row, e->wide, 0, 0); }
+/* $x + $y: one step — the flush IS the stand-alone launch */
+static zval e_single(Env *e) { return op2(ZEND_ADD, e->x, e->y, 0, 0); }
+
+static const struct { const char *name; Expr fn; int steps; int lazy_launches; } kExpr[] = {
+    {"exp_mul_add", e_exp_mul_add, 3, 1}, {"rscalar", e_rscalar, 2, 1}, {"rdiv", e_rdiv, 2, 1}, {"bcast", e_bcast, 3, 1},
+    {"quirks", e_quirks, 3, 1}, {"rrow", e_rrow, 2, 1}, {"two_pending", e_two_pending, 3, 2}, {"static", e_static, 3, 2}, {"static2", e_static2, 4, 2},
+    {"clip", e_clip, 2, 1}, {"long", e_long, 15, 2}, {"grow", e_grow, 2, 2}, {"small_first", e_small_first, 1, 1}, {"single", e_single, 1, 1},
+};
+enum { kExprCount = (int) (sizeof kExpr / sizeof kExpr[0]) };
+
+int main(int argc, char **argv) {
+    const int gpu = argc >= 2 && strcmp(argv[1], "gpu") == 0;
+    if (argc < 2 || (!gpu && strcmp(argv[1], "cpu") != 0) || (gpu && argc != 3)) {
+        fprintf(stderr, "usage: %s cpu | gpu <output file>\n", argv[0]);
+        return 2;
+    }
+    if (gpu && (g_out = fopen(argv[2], "wb")) == NULL) {
+        perror(argv[2]);
+        return 2;
+    }
+    const int rows = 257, cols = 255;                        /* AVX2 body + ragged tail */
+    const int s2[2] = {rows, cols}, s1[1] = {cols}, scol[2] = {rows, 1};
+    Env e;
+    e.x = placed(s2, 2, 201, -3, 3, gpu);
+    e.y = placed(s2, 2, 202, 0.5f, 4, gpu);
+    e.p = placed(s2, 2, 203, 0.25f, 4, gpu);
+    e.row = placed(s1, 1, 204, -2, 2, gpu);
+    e.col = placed(scol, 2, 205, 0.5f, 2, gpu);
+    e.wide = placed(s2, 2, 206, -1, 1, gpu);
+    NPH_LazyStats st0, st1;
+
+    if (!gpu) {
+        /* BASELINE config 1: CPU operands.  Every appender must hand the call to the reference's own code; nothing pends. */
+        int calls = 0;
+        for (int k = 0; k < kExprCount; k++) {
+            zval r = kExpr[k].fn(&e);
+            calls += kExpr[k].steps;
+            CHECK(Z_TYPE_P(&r) == IS_UNDEF, "%s computed something for CPU operands", kExpr[k].name);
+            CHECK(NPH_PendingCount() == 0, "%s left a pending chain for CPU operands", kExpr[k].name);
+        }
+        /* (an expression whose first step yields nothing stops there, as PHP would on the exception: count what ran) */
+        printf("lazy_bodies cpu: %d expressions, %d reached the reference's own code, 0 pending\n", kExprCount, g_reference_bodies);
+        CHECK(g_reference_bodies >= kExprCount, "only %d calls reached the reference's code", g_reference_bodies);
+        (void) calls;
+        return g_failed;
+    }
+
+    /* ---- 1. every expression: chains on (launches counted) against chains off, bit for bit ---- */
+    for (int k = 0; k < kExprCount; k++) {
+        char label[32];
+        NPH_SetLazy(1);
+        NPH_GetLazyStats(&st0);
+        const unsigned long long l0 = launches();
+        zval r = kExpr[k].fn(&e);
+        const unsigned long long l_build = launches() - l0;
+        snprintf(label, sizeof label, "lazy.%s", kExpr[k].name);
+        NDArray *lazy = dump(label, &r);
+        const unsigned long long l_lazy = launches() - l0;
+        NPH_GetLazyStats(&st1);
+        zval_dtor(&r);
+        CHECK(NPH_PendingCount() == 0, "%s: %d chains still pending after its value was read", kExpr[k].name, NPH_PendingCount());
+
+        NPH_SetLazy(0);
+        const unsigned long long l1 = launches();
+        zval q = kExpr[k].fn(&e);
+        snprintf(label, sizeof label, "eager.%s", kExpr[k].name);
+        NDArray *eager = dump(label, &q);
+        const unsigned long long l_eager = launches() - l1;
+        zval_dtor(&q);
+        NPH_SetLazy(1);
+
+        printf("%-12s %2d steps: %llu launch(es) with chains (%llu before the value was asked for), %llu without; chains flushed %lu, steps in them %lu, "
+               "discarded %lu, eager steps %lu\n", kExpr[k].name, kExpr[k].steps, l_lazy, l_build, l_eager,
+               st1.flushed_chains - st0.flushed_chains, st1.flushed_steps - st0.flushed_steps,
+               st1.discarded_chains - st0.discarded_chains, st1.eager_steps - st0.eager_steps);
+        CHECK(l_lazy == (unsigned long long) kExpr[k].lazy_launches, "%s took %llu launches with chains, expected %d", kExpr[k].name, l_lazy,
+              kExpr[k].lazy_launches);
+        CHECK(l_eager == (unsigned long long) kExpr[k].steps, "%s took %llu launches without chains, expected %d", kExpr[k].name, l_eager,
+              kExpr[k].steps);
+        if (lazy != NULL && eager != NULL) {
+            CHECK(NDArray_NUMELEMENTS(lazy) == NDArray_NUMELEMENTS(eager) && NDArray_NDIM(lazy) == NDArray_NDIM(eager) &&
+                  memcmp(NDArray_FDATA(lazy), NDArray_FDATA(eager), sizeof(float) * (size_t) NDArray_NUMELEMENTS(lazy)) == 0,
+                  "%s: the chain's values differ from the op-by-op values", kExpr[k].name);
+        }
+        if (lazy) NDArray_FREE(lazy);
+        if (eager) NDArray_FREE(eager);
+    }
+
+    /* ---- 2. a value nobody asks for costs nothing ---- */
+    {
+        NPH_GetLazyStats(&st0);
+        const unsigned long long l0 = launches();
+        zval t = op2(ZEND_MUL, UN(exp, e.x, 0), e.y, 1, 0);
+        CHECK(NPH_PendingCount() == 1, "expected one pending chain, have %d", NPH_PendingCount());
+        zval_dtor(&t);
+        NPH_GetLazyStats(&st1);
+        CHECK(launches() == l0 && NPH_PendingCount() == 0 && st1.discarded_chains - st0.discarded_chains == 2,
+              "an unused expression launched %llu kernel(s), %d chains pending", launches() - l0, NPH_PendingCount());
+        printf("unused value: 0 launches, 2 chains discarded\n");
+    }
+    /* ---- 3. writes to an input: the chains that read it are computed first (fill, and fill through a view) ---- */
+    {
+        const int s[2] = {64, 100};
+        zval a = placed(s, 2, 301, -1, 1, 1), b = placed(s, 2, 301, -1, 1, 1);
+        zval c = op2(ZEND_ADD, a, number(1.0), 0, 0);         /* $c = $a + 1;      pending */
+        method_fill(&a, 0.0f);                                /* $a->fill(0);      $c must have been computed from the OLD $a */
+        zval view = method_slice0(&b, 3);                     /* $v = $b[3];       a view of $b */
+        zval d = op2(ZEND_MUL, b, number(2.0), 0, 0);         /* $d = $b * 2;      pending, reads $b */
+        method_fill(&view, 9.0f);                             /* $v->fill(9);      writes $b's buffer through the view */
+        NDArray *hc = dump("write.c", &c), *hd = dump("write.d", &d), *ha = dump("write.a", &a), *hb = dump("write.b", &b);
+        if (hc) NDArray_FREE(hc);
+        if (hd) NDArray_FREE(hd);
+        if (ha) NDArray_FREE(ha);
+        if (hb) NDArray_FREE(hb);
+        zval_dtor(&view); zval_dtor(&c); zval_dtor(&d); zval_dtor(&a); zval_dtor(&b);
+    }
+    /* ---- 4. an input PHP lets go of before the value is asked for stays alive for the chain ---- */
+    {
+        const int s[1] = {1000};
+        zval t = placed(s, 1, 302, 1, 2, 1);
+        zval c = op2(ZEND_DIV, number(1.0), t, 0, 0);         /* $c = 1 / $t; unset($t); */
+        zval_dtor(&t);
+        NDArray *hc = dump("unset.c", &c);
+        if (hc) NDArray_FREE(hc);
+        zval_dtor(&c);
+    }
+    /* ---- 5. consumers see finished values: a reduction and a comparison of pending operands ---- */
+    {
+        zval c = op2(ZEND_MUL, UN(exp, e.x, 0), e.y, 1, 0);
+        const unsigned long long l0 = launches();
+        const float total = method_sum(&c);
+        CHECK(launches() - l0 >= 2, "sum of a pending value: %llu launch(es)", launches() - l0);   /* the chain, then the reduction */
+        zval one = placed(s1, 1, 303, 7, 8, 1);
+        float sum_host[1] = {total};
+        const int s0[1] = {1};
+        zval total_obj = object_of(NDArray_FromHostBuffer(sum_host, s0, 1));
+        NDArray *ht = dump("consumer.sum", &total_obj);
+        if (ht) NDArray_FREE(ht);
+        zval c2 = op2(ZEND_MUL, UN(exp, e.x, 0), e.y, 1, 0);
+        zval eq = method_equal(&c, &c2);                      /* nd::equal($c, $c2): $c2 pending, $c computed above */
+        NDArray *he = dump("consumer.equal", &eq);
+        if (he) NDArray_FREE(he);
+        zval_dtor(&eq); zval_dtor(&c2); zval_dtor(&c); zval_dtor(&one); zval_dtor(&total_obj);
+    }
+    /* ---- 6. errors are the eager path's: a CPU array next to a GPU array, shapes that do not broadcast ---- */
+    {
+        const int s[2] = {4, 5}, t[1] = {7};
+        zval g = placed(s, 2, 304, 0, 1, 1), h = placed(s, 2, 305, 0, 1, 0), odd = placed(t, 1, 306, 0, 1, 1);
+        numpower_host_clear_error();
+        zval r1 = op2(ZEND_ADD, UN(exp, g, 0), h, 1, 0);
+        CHECK(Z_TYPE_P(&r1) == IS_UNDEF && strstr(numpower_host_last_error(), "Device mismatch") != NULL, "GPU + CPU array: %s", numpower_host_last_error());
+        numpower_host_clear_error();
+        zval r2 = op2(ZEND_ADD, UN(exp, g, 0), odd, 1, 0);
+        CHECK(Z_TYPE_P(&r2) == IS_UNDEF && strstr(numpower_host_last_error(), "broadcast") != NULL, "4x5 + 7: %s", numpower_host_last_error());
+        numpower_host_clear_error();
+        zval_dtor(&g); zval_dtor(&h); zval_dtor(&odd);
+    }
+    CHECK(NPH_PendingCount() == 0, "%d chains pending at the end", NPH_PendingCount());
+    zval_dtor(&e.x); zval_dtor(&e.y); zval_dtor(&e.p); zval_dtor(&e.row); zval_dtor(&e.col); zval_dtor(&e.wide);
+    fclose(g_out);
+    if (NDArray_LiveDeviceAllocations() != 0) {
+        fprintf(stderr, "lazy_bodies: %ld device allocations leaked\n", NDArray_LiveDeviceAllocations());
+        g_failed = 1;
+    }
+    printf("lazy_bodies gpu: %s\n", g_failed ? "FAILED" : "ok");
+    return g_failed;
+}
+"""
+
+
 def _indent(text: str, pad: str) -> str:
     return "\n".join((pad + line) if line else line for line in text.split("\n"))
 
@@ -605,6 +1147,8 @@ def apply_edit(text: str, e: Edit, keep_cuda: bool = False):
         old = m.group("old")
         pad = re.match(r"[ \t]*", old).group(0)
         new = e.new.replace("@HIP_M4_BLOCK@", HIP_M4_BLOCK)
+        if e.template:
+            new = m.expand(new)
         if e.after:
             last_pad = re.match(r"[ \t]*", old.split("\n")[-1]).group(0)
             if old.lstrip().startswith("#"):
