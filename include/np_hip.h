@@ -403,6 +403,9 @@ int np_arange(float *out, double start, double step, size_t n);
  * np_comm_barrier returns once every rank's streams (library and communication) have reached the call. */
 int np_comm_init(int rank, int world, const char *endpoint);
 int np_comm_rank(void);    /* -1 without a communicator */
+/* The collective library behind np_comm_*: ncclGetVersion() of the librccl.so.1 the library loads (e.g. 22707 = 2.27.7);
+ * needs no communicator and no device — what bench.py prints next to a multi-GPU line. */
+int np_comm_rccl_version(int *host_version);
 int np_comm_world(void);   /*  0 without a communicator */
 int np_allgather(const void *dev_send, void *dev_recv, size_t bytes_per_rank);
 int np_comm_max(float value, float *host_max);

@@ -99,6 +99,7 @@ PROTOTYPES = {
     "np_comm_stream": (C.c_void_p, []),
     "np_sgemm_strided_batched_allgather": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]),
+    "np_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int)]),
     "np_comm_debug_sendrecv_self": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "np_comm_debug_loopback_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float)]),
     "np_comm_debug_loopback": (C.c_int, [C.c_void_p, C.c_size_t]),

@@ -90,6 +90,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;   // optional
 };
 
 struct Comm {
@@ -149,6 +150,7 @@ int load_rccl(Rccl &r) {
     NP_SYM(GroupEnd, "ncclGroupEnd");
     NP_SYM(GetErrorString, "ncclGetErrorString");
 #undef NP_SYM
+    r.GetVersion = (decltype(r.GetVersion))dlsym(r.handle, "ncclGetVersion");
     return NP_OK;
 }
 
@@ -943,6 +945,15 @@ int np_comm_destroy(void) {
     }
     if (rc != ncclSuccess) return np::fail(NP_ERR_DEVICE, "ncclCommDestroy failed: %s", g_comm.api.GetErrorString(rc));
     if (aborted) return np::fail(NP_ERR_DEVICE, "np_comm_destroy: a transfer never completed (a peer is gone); the communicator was aborted");
+    return NP_OK;
+}
+
+int np_comm_rccl_version(int *host_version) {
+    if (!host_version) return np::fail(NP_ERR_INVALID, "np_comm_rccl_version: null output");
+    *host_version = 0;
+    if (int rc = load_rccl(g_comm.api)) return rc;
+    if (!g_comm.api.GetVersion) return np::fail(NP_ERR_DEVICE, "np_comm_rccl_version: librccl has no ncclGetVersion");
+    NP_RCCL_CHECK(g_comm.api.GetVersion(host_version));
     return NP_OK;
 }
 

@@ -256,6 +256,11 @@ def test_gemm_planner_choices_on_a_256_cu_device():
     for shape in ((100, 100, 100000), (128, 128, 65536), (64, 64, 100000), (256, 256, 32768), (300, 300, 20000)):
         p = plan(*shape)
         assert p["cfg"] >= 6 and p["tail_rows"] > 0 and p["S"] >= 2 and not p["streamk"], (shape, p)
+    # ... unless an operand reaches 4 GiB: the k-quartered kernel's byte offsets are 32-bit, its launcher declines, so the planner
+    # must not pick it — the same K-chunking on the register-staged tiles, sized for THEM
+    for shape in ((100, 100, 11_000_000), (8192, 64, 200_000)):
+        p = plan(*shape)
+        assert p["cfg"] < 6 and (p["S"] >= 2 or p["streamk"]), (shape, p)
     lib.np_sgemm_set_variant(-22)
     try:
         p = plan(100, 100, 100000)

@@ -31,6 +31,27 @@ def test_self_launch_prints_one_json_line(n):
     j = json.loads(lines[0])
     assert j["dry_run"] is True and j["n_gpus"] == n and j["steps"] == 4 and j["warmup"] == 1
     assert j["ranks_seen"] == n          # every spawned rank took part in the max-over-ranks collective
+    assert "gloo" in j["collective"]     # ... and the line says through what (on a node: the RCCL version)
+    # config 5's N > 1 report — the same function, legs and collectives a node runs, on gloo with torch.bmm for the GEMM
+    c5 = j["extras"]["config5_batched_matmul_allgather"]
+    legs = {"compute_only", "gathered", "overlapped_2", "overlapped_4", "overlapped_8"}          # 8 matrices per rank
+    assert set(c5["ms_per_step"]) == legs == set(c5["ms_per_step_min"])
+    assert all(v > 0 for v in c5["ms_per_step"].values()) and set(c5["parity_max_norm_err_vs_fp64"]) == legs - {"compute_only"}
+    assert c5["parity_ok"] is True and c5["scaling"] == "strong" and "%d slab(s) of 8" % n in c5["workload"]
+
+
+def test_a_leg_that_fails_parity_does_not_cost_the_other_legs_their_numbers():
+    """VERDICT r05 next #6a: `bench.py --gpus N` prints ranks_seen, the collective library and per-leg medians EVEN IF one leg's
+    result is wrong — the line says parity_ok false with that leg's error, and every leg keeps its timing."""
+    p = run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1"], {"NP_BENCH_DRYRUN_BAD_LEG": "overlapped_2"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads(p.stdout.strip())
+    c5 = j["extras"]["config5_batched_matmul_allgather"]
+    assert j["ranks_seen"] == 2 and c5["parity_ok"] is False
+    err = c5["parity_max_norm_err_vs_fp64"]
+    assert err["overlapped_2"] > 1e-3 and all(v <= 1e-6 for k, v in err.items() if k != "overlapped_2")
+    assert set(c5["ms_per_step"]) == {"compute_only", "gathered", "overlapped_2", "overlapped_4", "overlapped_8"}
+    assert all(v > 0 for v in c5["ms_per_step"].values())
 
 
 def test_external_launcher_env_is_respected():

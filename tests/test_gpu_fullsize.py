@@ -285,8 +285,9 @@ def test_elementwise_beyond_2p31_elements(hip):
 
 def test_deep_k_matmul_with_operands_beyond_4gib(hip):
     """100 x 100 x 11 000 000: 4.4 GB per operand (the reference's `unsigned int` byte sizes stop at 4 GiB, gpu_alloc.c:11).  The
-    planner answers with K-chunks on the k-quartered tiles, whose 32-bit byte offsets do not reach that far: the launcher says so
-    and the chunks run on the register-staged tiles (64-bit addressing) under the same fold.  Built on the device from values
+    k-quartered tiles address with 32-bit byte offsets and do not reach that far: since round 6 the PLANNER knows (it
+    used to pick their K-chunked plan, the launcher declined, and the chunks ran on kernels the plan was not sized for) and
+    answers with K-chunks on the register-staged tiles (64-bit addressing) under the same fold.  Built on the device from values
     whose partial sums fp32 holds EXACTLY inside a chunk (eighths, sums below 2^21; constant terms that are not exact lose the same
     half-ulp at every step — 0.3 % with 0.5 + i / 128 — which is fp32 arithmetic, not addressing): A[i, :] = 1 + (i mod 4) / 4,
     B[:, j] = 1 + (j mod 2) / 2, one element of A in the row that crosses byte 2^32 and one row of B beyond it scaled by 1024:
@@ -299,7 +300,9 @@ def test_deep_k_matmul_with_operands_beyond_4gib(hip):
     k = 11_000_000
     out = (C.c_double * 11)()
     check(lib.np_sgemm_debug_plan(m, n, k, 1, 0, out))
-    assert out[0] >= 6 and out[1] > 0 and out[2] >= 2, list(out)
+    assert out[0] < 6 and out[1] > 0 and out[2] >= 2, list(out)          # a K-chunked plan, not on the k-quartered tiles (cfg 6 ...)
+    check(lib.np_sgemm_debug_plan(m, n, 100_000, 1, 0, out))
+    assert out[0] >= 6 and out[1] > 0 and out[2] >= 2, list(out)         # ... which the same product below 4 GiB does get
     a, b, c = D.DeviceArray((m * k,)), D.DeviceArray((k * n,)), D.DeviceArray((m, n))
     ai = 1.0 + (np.arange(m) % 4) / 4.0
     rj = 1.0 + (np.arange(n) % 2) / 2.0

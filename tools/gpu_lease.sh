@@ -51,19 +51,21 @@ r_profile() {
     # the same kernels launched at the BASELINE sizes ONLY (bench.py also runs add / sum at 1000 x 1000 for config 1, which share
     # kernel names with the 1e8 launches and pull their average down): per-kernel averages that reproduce the bench fractions
     # ... each kept running for >= 250 ms, so the averages are those of warm kernels (tools/prof_kernels.py)
-    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/kt2" -o k --output-format csv -- python "$R/tools/prof_kernels.py" 20 250 > "$O/prof_kernels.log" 2>&1)
+    (cd /tmp && export TMPDIR=/tmp && NP_PROF_SECTIONS="$O/prof_sections_kt.json" timeout 900 rocprofv3 --kernel-trace --stats -d "$O/kt2" -o k --output-format csv -- python "$R/tools/prof_kernels.py" 20 250 > "$O/prof_kernels.log" 2>&1)
     cp "$O"/kt2/*kernel_stats.csv "$O/prof_kernels_stats.csv" 2>/dev/null
     head -20 "$O/prof_kernels_stats.csv" | cut -c1-200
 }
 r_counters() {
     (cd /tmp && export TMPDIR=/tmp
-     timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$O/fetch" -o f --output-format csv -- python "$R/tools/prof_kernels.py" 3 > "$O/fetch.log" 2>&1
-     timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$O/write" -o w --output-format csv -- python "$R/tools/prof_kernels.py" 3 > "$O/write.log" 2>&1
+     NP_PROF_SECTIONS="$O/prof_sections.json" timeout 400 rocprofv3 --pmc FETCH_SIZE -d "$O/fetch" -o f --output-format csv -- python "$R/tools/prof_kernels.py" 3 > "$O/fetch.log" 2>&1
+     NP_PROF_SECTIONS="$O/prof_sections_w.json" timeout 400 rocprofv3 --pmc WRITE_SIZE -d "$O/write" -o w --output-format csv -- python "$R/tools/prof_kernels.py" 3 > "$O/write.log" 2>&1
      timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE -d "$O/p1" -o p1 --output-format csv -- python "$R/tools/prof_counters.py" 5 gemm,pow,add,cols,rows > "$O/p1.log" 2>&1
      timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d "$O/p2" -o p2 --output-format csv -- python "$R/tools/prof_counters.py" 5 gemm,pow,add,cols,rows > "$O/p2.log" 2>&1)
     python tools/pmc_summary.py "$O"/p1/*counter_collection.csv "$O"/p2/*counter_collection.csv > "$O/pmc_sq.txt" 2>&1
     python tools/pmc_summary.py "$O"/fetch/*counter_collection.csv "$O"/write/*counter_collection.csv > "$O/pmc_summary.txt" 2>&1
-    python tools/pmc_traffic.py "$O"/fetch/*counter_collection.csv "$O"/write/*counter_collection.csv "$O/pmc_traffic.json"
+    # HBM bytes per CALL of every workload of the bench: the CSVs cut at prof_kernels.py's marker launches (tools/pmc_traffic.py)
+    cmp -s "$O/prof_sections.json" "$O/prof_sections_w.json" || echo "WARNING: the two PMC passes ran different sections"
+    python tools/pmc_traffic.py "$O"/fetch/*counter_collection.csv "$O"/write/*counter_collection.csv "$O/pmc_traffic.json" "$O/prof_sections.json"
     python tools/gemm_pmc_json.py "$O/gemm_pmc.json" "$O"/p1/*counter_collection.csv "$O"/p2/*counter_collection.csv
     # both carry the stamp of the sources they were measured on (tools/source_stamp.py; the same lease's kernel stats sit next to them)
     python - "$O" <<'PY'

@@ -1,51 +1,68 @@
-"""Build profiles/rNN/pmc_traffic.json (HBM bytes per launch of the benchmarked kernels) from the two
-rocprofv3 --pmc passes over tools/prof_kernels.py (FETCH_SIZE and WRITE_SIZE counter_collection CSVs).
+"""Build profiles/rNN/pmc_traffic.json — HBM bytes per CALL of every workload bench.py reports — from the two rocprofv3 --pmc
+passes over tools/prof_kernels.py (FETCH_SIZE and WRITE_SIZE counter_collection CSVs) and the section list that run wrote.
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE reports half of a wide coalesced read stream
 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE calibrates 1:1 (add writes its 0.4 GB).
-Usage: python tools/pmc_traffic.py fetch.csv write.csv out.json"""
+Round 6: the CSV rows are ordered by dispatch and cut at prof_kernels.py's marker launches (`raise_error_kernel`), so a workload's
+figure is the SUM over every kernel one call launched (np_moments' pass + fold, the median's six kernels, a K-chunked product's
+fold) divided by the number of calls — no entry of the bench is left without a counter figure because it is not one kernel.
+The 2x on FETCH_SIZE is calibrated on 16 B/lane streaming reads; kernels that read with narrower accesses (the strided side of
+a skinny transpose) may be over-stated by it, never under-stated.
+Usage: python tools/pmc_traffic.py fetch.csv write.csv out.json [sections.json]"""
 import collections, csv, json, sys
 
-KEYS = [  # bench key, substring(s) identifying the kernel
-    ("sgemm_dma_kernel", ["sgemm_dma_kernel"]),
-    ("add_1e8", ["binary_vec_kernel<0, 0, 0,"]),
-    ("pow_1e8", ["binary_vec_kernel<5, 0, 0,"]),
-    ("exp_1e8", ["unary_vec_kernel<2,"]),
-    ("log_1e8", ["unary_vec_kernel<5,"]),
-    ("add_row_broadcast", ["binary_vec_kernel<0, 0, 2,"]),
-    ("add_col_broadcast", ["binary_vec_kernel<0, 0, 3,"]),
-    ("sum_axis0", ["reduce_axis_cols<0, false"]),
-    ("fused_chain_1e8", [">, -1>", "fused_chain_kernel"]),          # cchain_flat_kernel<CChain<...>, -1> (store)
-    ("fused_chain_sum_1e8", [">, 0>(", ">, 0>"]),                   # cchain_flat_kernel<CChain<...>, 0> (sum)
-    ("sum_exp_axis0_fused", ["cchain_cols_kernel", "fused_chain_cols_kernel"]),
-    ("sum_exp_axis1_fused", ["cchain_rows_kernel", "fused_chain_rows_kernel"]),
-    ("transpose_65536x4096", ["transpose_tile_kernel"]),
-    ("argmax_1e8", ["argreduce_rows_kernel<true"]),
-    ("argmax_axis1_65536x1024", ["argreduce_rows_wave<true"]),
-    ("sgemv_10x1e7", ["sgemv_fewrows_chunks_kernel"]),
-    ("moments_second_pass_1e8", ["reduce_xform_pass1<1"]),
-]
+MARKER = "raise_error_kernel"
 
 
-def means(path, counter):
-    d = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter:
-            d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in d.items()}
+def rows(path, counter):
+    rs = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    if rs and "Dispatch_Id" in rs[0]:
+        rs.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return rs
 
 
-def pick(table, pats):
-    for name, v in table.items():
-        if any(p in name for p in pats):
-            return v
-    return None
+def by_section(path, counter, n_sections):
+    """-> [{"total": sum of the counter, "kernels": {short kernel name: [launches, sum]}}] per section, cut at the markers."""
+    out, cur = [], None
+    for r in rows(path, counter):
+        name = r["Kernel_Name"]
+        if MARKER in name:
+            cur = {"total": 0.0, "kernels": collections.OrderedDict()}
+            out.append(cur)
+            continue
+        if cur is None:
+            continue            # uploads' fill / copy kernels before the first marker
+        v = float(r["Counter_Value"])
+        cur["total"] += v
+        short = name.split("(")[0][-80:]
+        k = cur["kernels"].setdefault(short, [0, 0.0])
+        k[0] += 1
+        k[1] += v
+    if len(out) != n_sections:
+        raise SystemExit("%s: %d marker launches for %d sections (was the CSV written by another prof_kernels.py?)" % (path, len(out), n_sections))
+    return out
 
 
-fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
-out = {"_note": __doc__.split("Usage")[0].strip() + "  (the non-kernel keys: _note, and source_sha16 / kernel_sha16 written by tools/gpu_lease.sh)"}
-for key, pats in KEYS:
-    f, w = pick(fetch, pats), pick(write, pats)
-    if f is not None and w is not None:
-        out[key] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes": (2 * f + w) * 1024}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: round(v["hbm_bytes"] / 1e6) for k, v in out.items() if isinstance(v, dict)}))
+def main(argv):
+    fetch_csv, write_csv, out_json = argv[1], argv[2], argv[3]
+    sections = json.load(open(argv[4])) if len(argv) > 4 else None
+    if sections is None:
+        raise SystemExit(__doc__)
+    f = by_section(fetch_csv, "FETCH_SIZE", len(sections))
+    w = by_section(write_csv, "WRITE_SIZE", len(sections))
+    out = {"_note": __doc__.split("Usage")[0].strip() + "  (the non-workload keys: _note, and source_sha16 / kernel_sha16 written by tools/gpu_lease.sh)"}
+    for (label, calls), fs, ws in zip(sections, f, w):
+        if label == "end" or calls <= 0:
+            continue
+        kernels = {}
+        for name, (launches, total) in fs["kernels"].items():
+            kernels[name] = {"launches_per_call": launches / calls, "FETCH_SIZE_KB_per_call": total / calls}
+        for name, (launches, total) in ws["kernels"].items():
+            kernels.setdefault(name, {"launches_per_call": launches / calls})["WRITE_SIZE_KB_per_call"] = total / calls
+        out[label] = {"calls": calls, "FETCH_SIZE_KB": fs["total"] / calls, "WRITE_SIZE_KB": ws["total"] / calls,
+                      "hbm_bytes": (2 * fs["total"] + ws["total"]) * 1024 / calls, "kernels": kernels}
+    json.dump(out, open(out_json, "w"), indent=1)
+    print(json.dumps({k: round(v["hbm_bytes"] / 1e6, 1) for k, v in out.items() if isinstance(v, dict)}))
+
+
+if __name__ == "__main__":
+    main(sys.argv)
