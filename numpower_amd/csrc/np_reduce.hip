@@ -29,6 +29,7 @@ using namespace np::dev;   // r_identity / r_combine / wave_reduce / block_reduc
 // One partial per workgroup, so more workgroups = more partials for the one-block second pass to fold.
 int g_wg_per_cu = 0;   // 0 = the default below
 int g_arg_flat_wg_per_cu = 0;   // the flat walks for a few columns: workgroups per CU, 0 = by shape (np_reduce_set_variant(4100000 + N): A/B)
+int g_arg_xcd_runs_off = 0;     // argreduce_cols_tile on unaligned rows: 1 = the plain workgroup order (np_reduce_set_variant(4200001): A/B)
 int g_arg_cols_wg_per_cu = 0;   // argreduce_cols_tile: workgroups per CU the axis is cut for; 0 = by alignment (np_reduce_set_variant(4000000 + N): A/B)
 constexpr int kStreamWgPerCu = 8;
 inline size_t stream_cap() {
@@ -881,13 +882,26 @@ template <int OP, bool FINAL, typename I>
 __global__ __launch_bounds__(256) void reduce_axis_cols(const float *__restrict__ in,
                                                         float *__restrict__ out, I axis_len,
                                                         I inner, I splits, float mean_div,
-                                                        int prod_quirk, I body_end) {
+                                                        int prod_quirk, I body_end, unsigned xcd_runs = 0) {
     __shared__ v4f lds[3][64];
     const I inner4 = (inner + 3) / 4;   // column groups per row; the last one may hold fewer than 4 columns
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const I col4 = (I)blockIdx.x * 64 + lane;
-    const I split = blockIdx.y;
-    const I o = blockIdx.z;
+    unsigned tile = blockIdx.x, split_u = blockIdx.y, o_u = blockIdx.z;
+    if (xcd_runs) {
+        // rows that are not whole 128-byte lines: neighbouring tiles share a line at each end of their 1 KiB piece of a row;
+        // dealt to the XCDs in eight contiguous runs they share it in ONE L2 instead of fetching it twice (round 6, first
+        // measured on argreduce_cols_tile: 9973^2 fetched 1.14 x its bytes, 1.08 x this way; np_sgemm.hip's tile_coords bijection)
+        const unsigned T = gridDim.x, S = gridDim.y, W = T * S * gridDim.z;
+        const unsigned L = blockIdx.x + T * (blockIdx.y + S * blockIdx.z);
+        const unsigned q = W / 8, r = W % 8, xcd = L % 8, idx = L / 8;
+        const unsigned unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile = unit % T;
+        split_u = (unit / T) % S;
+        o_u = unit / (T * S);
+    }
+    const I col4 = (I)tile * 64 + lane;
+    const I split = split_u;
+    const I o = o_u;
     const I chunk = (axis_len + splits - 1) / splits;
     const I r0 = split * chunk;
     I r1 = r0 + chunk;
@@ -1403,16 +1417,19 @@ int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t in
         const size_t inner4 = (inner + 3) / 4;
         const size_t splits = choose_splits(outer, axis_len, inner4);
         const dim3 grid((unsigned)((inner4 + 63) / 64), (unsigned)splits, (unsigned)outer);
+        // tiles that straddle 128-byte lines: neighbours on one XCD (np_reduce_set_variant(4200001): the launch order, A/B)
+        const unsigned xcd_runs = ((inner * sizeof(float)) % 128 != 0 || ((uintptr_t)in & 127u) != 0) && grid.x > 1 &&
+                                  (size_t)grid.x * grid.y * grid.z < (size_t(1) << 31) && !g_arg_xcd_runs_off ? 1u : 0u;
         if (splits == 1) {
             reduce_axis_cols<OP, true, I><<<grid, 256, 0, s>>>(in, out, (I)axis_len, (I)inner, (I)1,
-                                                            mean_div, quirk, (I)body_end);
+                                                            mean_div, quirk, (I)body_end, xcd_runs);
             NP_LAUNCH_CHECK("reduce_axis_cols");
             return NP_OK;
         }
         np::Scratch partials;
         if (int rc = partials.alloc(outer * splits * inner * sizeof(float))) return rc;
         reduce_axis_cols<OP, false, I><<<grid, 256, 0, s>>>(in, (float *)partials.ptr, (I)axis_len,
-                                                         (I)inner, (I)splits, mean_div, 0, (I)0);
+                                                         (I)inner, (I)splits, mean_div, 0, (I)0, xcd_runs);
         NP_LAUNCH_CHECK("reduce_axis_cols(pass 1)");
         // pass 2: the partials are an outer x splits x inner array; MEAN must divide by the real
         // axis length, not by `splits`.
@@ -1757,13 +1774,28 @@ __global__ __launch_bounds__(256) void argreduce_small_inner4(const float *__res
 template <bool IS_MAX, bool FINAL>
 __global__ __launch_bounds__(256) void argreduce_cols_tile(const float *__restrict__ in, float *__restrict__ pv,
                                                            unsigned *__restrict__ pi, float *__restrict__ out,
-                                                           unsigned axis_len, unsigned inner, unsigned chunk_len) {
+                                                           unsigned axis_len, unsigned inner, unsigned chunk_len, unsigned xcd_runs) {
     __shared__ float sv[3][64][4];
     __shared__ unsigned si[3][64][4];
     const float id = IS_MAX ? -INFINITY : INFINITY;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned o = blockIdx.z, c = blockIdx.y, chunks = gridDim.y;
-    const unsigned col = (blockIdx.x * 64 + lane) * 4;
+    unsigned o = blockIdx.z, c = blockIdx.y, tile = blockIdx.x;
+    const unsigned chunks = gridDim.y;
+    if (xcd_runs) {
+        // Rows that are not 16-byte multiples: a tile's 1 KiB piece of a row shares its first and its last 128-byte line with
+        // the neighbouring tiles.  Workgroup L runs on XCD L % 8, so with the plain order neighbours sit on different XCDs and
+        // each fetches the shared line for its own L2: 9 lines for 8, +12.4 % of traffic (FETCH_SIZE, 9973^2:
+        // profiles/r06/arg_unaligned_probe.log).  Dealing the (tile, chunk, outer) units to the XCDs in eight contiguous runs
+        // (np_sgemm.hip's tile_coords bijection) makes neighbouring tiles of a chunk share ONE L2.
+        const unsigned T = gridDim.x, W = T * chunks * gridDim.z;
+        const unsigned L = blockIdx.x + T * (blockIdx.y + chunks * blockIdx.z);
+        const unsigned q = W / 8, r = W % 8, xcd = L % 8, idx = L / 8;
+        const unsigned unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile = unit % T;
+        c = (unit / T) % chunks;
+        o = unit / (T * chunks);
+    }
+    const unsigned col = (tile * 64 + lane) * 4;
     const unsigned ncol = col >= inner ? 0u : (inner - col >= 4 ? 4u : inner - col);   // columns this lane owns
     const unsigned a0 = c * chunk_len;
     const unsigned a1 = axis_len - a0 < chunk_len ? axis_len : a0 + chunk_len;   // (a0 + chunk_len may wrap on an axis near 2^32)
@@ -1801,14 +1833,36 @@ __global__ __launch_bounds__(256) void argreduce_cols_tile(const float *__restri
             for (int k = 0; k < 4; ++k) arg_take<IS_MAX>(bv[k], ba[k], x0[k], a);
         }
     } else if (ncol > 0) {
-        for (unsigned a = first; a < a1; a += 4)
-            for (unsigned k = 0; k < ncol; ++k) {
-                const float x = p[(size_t)a * inner + k];
-                // (k is not a compile-time index here: the four accumulators are selected by hand)
-                if (k == 0) arg_take<IS_MAX>(bv[0], ba[0], x, a);
-                else if (k == 1) arg_take<IS_MAX>(bv[1], ba[1], x, a);
-                else arg_take<IS_MAX>(bv[2], ba[2], x, a);
+        // The last 1-3 columns of a row with inner % 4 != 0: ONE lane per chunk.  Until round 6 it walked its rows one scalar load
+        // at a time — load, compare, next load: ~48 dependent memory round trips per column behind which the whole workgroup (and,
+        // with every chunk's last tile doing the same, the launch) waited: 10007^2 ran 3.5 TB/s where 10008^2 runs 5.4
+        // (profiles/r06/arg_unaligned_probe.log).  Eight rows in flight like the full lanes; a column this lane does not own is
+        // read again as its last one (in bounds) and never taken.
+        const unsigned k1 = ncol > 1 ? 1u : 0u, k2 = ncol > 2 ? 2u : k1;
+        unsigned a = first;
+        for (; a + 28 < a1; a += 32) {
+            float x0[8], x1[8], x2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float *q = p + (size_t)(a + 4 * u) * inner;
+                x0[u] = __builtin_nontemporal_load(q);
+                x1[u] = __builtin_nontemporal_load(q + k1);
+                x2[u] = __builtin_nontemporal_load(q + k2);
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                arg_take<IS_MAX>(bv[0], ba[0], x0[u], a + 4 * u);
+                if (ncol > 1) arg_take<IS_MAX>(bv[1], ba[1], x1[u], a + 4 * u);
+                if (ncol > 2) arg_take<IS_MAX>(bv[2], ba[2], x2[u], a + 4 * u);
+            }
+        }
+        for (; a < a1; a += 4) {
+            const float *q = p + (size_t)a * inner;
+            const float y0 = q[0], y1 = q[k1], y2 = q[k2];
+            arg_take<IS_MAX>(bv[0], ba[0], y0, a);
+            if (ncol > 1) arg_take<IS_MAX>(bv[1], ba[1], y1, a);
+            if (ncol > 2) arg_take<IS_MAX>(bv[2], ba[2], y2, a);
+        }
     }
     if (wave > 0) {
 #pragma unroll
@@ -2055,20 +2109,28 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
         const size_t wg_per_cu = g_arg_cols_wg_per_cu > 0 ? (size_t)g_arg_cols_wg_per_cu : (rows_aligned ? 2 : 8);
         const size_t base_wg = tiles * outer, target_wg = (size_t)np::num_cus() * wg_per_cu;
         if (base_wg < target_wg) {
-            chunks = (target_wg + base_wg - 1) / base_wg;
+            // ROUNDED DOWN (round 6): with two fat workgroups per CU the launch must not exceed the machine — 39 tiles in
+            // ceil(512 / 39) = 14 chunks are 546 workgroups, and the 34 beyond the 512 that start together run alone at the end:
+            // 9984^2 5.56 -> 6.0 TB/s, 16384 x 6144 5.3 -> 6.2, 30000 x 3000 5.0 -> 5.6 with the count that fits; every shape whose
+            // tile count divides 512 (1024, 2048, 4096, 8192 ... columns) was exact already (profiles/r06/arg_cols_ab.log)
+            chunks = target_wg / base_wg;
             const size_t max_chunks = axis_len / 64 > 0 ? axis_len / 64 : 1;
             if (chunks > max_chunks) chunks = max_chunks;
+            if (chunks < 1) chunks = 1;
         }
         size_t chunk_len = (axis_len + chunks - 1) / chunks;
         if (chunks > 1 && chunk_len % 2 == 0) ++chunk_len;
         chunks = (axis_len + chunk_len - 1) / chunk_len;
         if (tiles <= 0x7fffffffu && chunks <= 65535) {
             const dim3 grid((unsigned)tiles, (unsigned)chunks, (unsigned)outer);
+            // neighbouring tiles on one XCD when rows straddle lines (argreduce_cols_tile; np_reduce_set_variant(4200001): off, A/B)
+            const bool rows_are_lines = (inner * sizeof(float)) % 128 == 0 && ((uintptr_t)in & 127u) == 0;
+            const unsigned xcd_runs = (!rows_are_lines && tiles > 1 && tiles * chunks * outer < (size_t(1) << 31) && !g_arg_xcd_runs_off) ? 1u : 0u;
             if (chunks == 1) {
                 if (is_max)
-                    argreduce_cols_tile<true, true><<<grid, 256, 0, s>>>(in, nullptr, nullptr, out, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len);
+                    argreduce_cols_tile<true, true><<<grid, 256, 0, s>>>(in, nullptr, nullptr, out, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len, xcd_runs);
                 else
-                    argreduce_cols_tile<false, true><<<grid, 256, 0, s>>>(in, nullptr, nullptr, out, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len);
+                    argreduce_cols_tile<false, true><<<grid, 256, 0, s>>>(in, nullptr, nullptr, out, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len, xcd_runs);
                 NP_LAUNCH_CHECK("argreduce_cols_tile");
                 return NP_OK;
             }
@@ -2076,9 +2138,9 @@ int np_argreduce(int is_max, const float *in, size_t outer, size_t axis_len, siz
             if (int rc = pv.alloc(total * chunks * sizeof(float))) return rc;
             if (int rc = pi.alloc(total * chunks * sizeof(unsigned))) return rc;
             if (is_max)
-                argreduce_cols_tile<true, false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, nullptr, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len);
+                argreduce_cols_tile<true, false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, nullptr, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len, xcd_runs);
             else
-                argreduce_cols_tile<false, false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, nullptr, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len);
+                argreduce_cols_tile<false, false><<<grid, 256, 0, s>>>(in, (float *)pv.ptr, (unsigned *)pi.ptr, nullptr, (unsigned)axis_len, (unsigned)inner, (unsigned)chunk_len, xcd_runs);
             NP_LAUNCH_CHECK("argreduce_cols_tile");
             return launch_arg_fold(is_max, (const float *)pv.ptr, (const unsigned *)pi.ptr, out, total, chunks, inner);
         }
@@ -2221,6 +2283,10 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
 int np_reduce_set_variant(int variant) {
     if (variant >= 2000000 && variant < 2100000) {   // the largest first-pass grid that folds its partials in-kernel
         np::g_fold_in_kernel_max = (size_t)(variant - 2000000);
+        return NP_OK;
+    }
+    if (variant == 4200000 || variant == 4200001) {   // argmax / argmin over wide unaligned rows: tiles dealt to the XCDs in runs (0) or in launch order (1)
+        g_arg_xcd_runs_off = variant - 4200000;
         return NP_OK;
     }
     if (variant >= 4100000 && variant < 4100100) {   // argmax / argmin over a few columns (flat walks): workgroups per CU

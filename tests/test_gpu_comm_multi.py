@@ -133,7 +133,7 @@ def test_sharded_matmul_across_real_ranks(tmp_path, oracle):
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600) for p in procs]
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and so.strip().endswith("OK"), (r, so[-300:], se[-1500:])
+        assert p.returncode == 0 and "OK" in so.splitlines(), (r, so[-300:], se[-1500:])   # (RCCL's banner may follow it: C stdio is flushed at exit)
     batch, m, k, n = 4 * world, 96, 160, 64
     A = np.stack([synth.uniform((m, k), 700 + i, -1.0, 1.0) for i in range(batch)])
     B = np.stack([synth.uniform((k, n), 800 + i, -1.0, 1.0) for i in range(batch)])
@@ -174,7 +174,7 @@ def _run_workers(script, world, tmp_path, tag):
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600) for p in procs]
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and so.strip().endswith("OK"), (r, so[-300:], se[-1500:])
+        assert p.returncode == 0 and "OK" in so.splitlines(), (r, so[-300:], se[-1500:])   # (RCCL's banner may follow it: C stdio is flushed at exit)
 
 
 def _check_torch_worker_results(world, tmp_path, tag):

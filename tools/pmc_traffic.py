@@ -8,7 +8,7 @@ fold) divided by the number of calls — no entry of the bench is left without a
 The 2x on FETCH_SIZE is calibrated on 16 B/lane streaming reads; kernels that read with narrower accesses (the strided side of
 a skinny transpose) may be over-stated by it, never under-stated.
 Usage: python tools/pmc_traffic.py fetch.csv write.csv out.json [sections.json]"""
-import collections, csv, json, sys
+import collections, csv, json, re, sys
 
 MARKER = "raise_error_kernel"
 
@@ -33,7 +33,8 @@ def by_section(path, counter, n_sections):
             continue            # uploads' fill / copy kernels before the first marker
         v = float(r["Counter_Value"])
         cur["total"] += v
-        short = name.split("(")[0][-80:]
+        m = re.search(r"(\w+)(<.*>)?\(", name.replace("(anonymous namespace)::", ""))   # void ns::kernel<...>(args) -> kernel
+        short = m.group(1) if m else name[:60]
         k = cur["kernels"].setdefault(short, [0, 0.0])
         k[0] += 1
         k[1] += v
@@ -51,7 +52,7 @@ def main(argv):
     w = by_section(write_csv, "WRITE_SIZE", len(sections))
     out = {"_note": __doc__.split("Usage")[0].strip() + "  (the non-workload keys: _note, and source_sha16 / kernel_sha16 written by tools/gpu_lease.sh)"}
     for (label, calls), fs, ws in zip(sections, f, w):
-        if label == "end" or calls <= 0:
+        if label == "end" or label.startswith("_") or calls <= 0:
             continue
         kernels = {}
         for name, (launches, total) in fs["kernels"].items():
