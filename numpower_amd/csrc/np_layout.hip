@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
 // cache hits) and files each element under its column's shift.  `out` must be 128-byte aligned (pool blocks are).
 template <int TR, int TC>
 __global__ __launch_bounds__(256) void transpose_walign_kernel(const float *__restrict__ in, float *__restrict__ out, unsigned rows,
-                                                               unsigned cols, unsigned tiles_x, unsigned tiles_y, PlaneBatch pb) {
+                                                               unsigned cols, unsigned tiles_x, unsigned tiles_y, PlaneBatch pb,
+                                                               unsigned order) {
     constexpr int C4 = TC / 4, RPP = 256 / C4, PASSES = (TR + 32) / RPP, HALF = PASSES / 2;
     constexpr int OC4 = TR / 4, ORPP = 256 / OC4, OPASSES = TC / ORPP;
     extern __shared__ __attribute__((aligned(16))) float tile[];
@@ -147,8 +148,17 @@ __global__ __launch_bounds__(256) void transpose_walign_kernel(const float *__re
     const float *src = in + off_in;
     float *dst = out + off_out;
     const size_t ipitch = pb.in_pitch, opitch = pb.out_pitch;
-    const unsigned bx = blockIdx.x % tiles_x;
-    const unsigned by = (blockIdx.x / tiles_x + bx) % tiles_y;
+    // Which tile: order 0 = the diagonal walk of transpose_tile_kernel in launch order.  A tile reads 32 rows of its neighbour
+    // above and shares partial lines with its neighbours left and right; in launch order those run on OTHER XCDs (workgroup b on
+    // XCD b % 8) and every shared line is fetched into two L2s.  order 1 / 2 deal the tiles to the XCDs in eight contiguous runs
+    // (np_sgemm.hip's tile_coords bijection) — 1: of the diagonal walk, 2: column strip by column strip (by fastest).
+    unsigned unit = blockIdx.x;
+    if (order) {
+        const unsigned W = tiles_x * tiles_y, q = W / 8, r = W % 8, xcd = unit % 8, idx = unit / 8;
+        unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const unsigned bx = order == 2 ? unit / tiles_y : unit % tiles_x;
+    const unsigned by = order == 2 ? unit % tiles_y : (unit / tiles_x + bx) % tiles_y;
     const int r0 = (int)(by * TR);
     const unsigned c0 = bx * TC;
     const unsigned tx4 = threadIdx.x % C4, ty = threadIdx.x / C4;
@@ -526,6 +536,15 @@ int g_tile = 0;   // 0 = default, else 64 / 128 (np_layout_set_variant)
 // per CU end more evenly — 4099^2 4.80 -> 5.07 TB/s, 5000 x 4099 (1320 tiles) +1 %; from ~2000 tiles up the small tiles LOSE (8191 x 8193 -2 %,
 // 6001 x 6003 -14 %, 12345 x 6789 -19 %: they read 96 rows for every 64 they write) — profiles/r05/walign_tile_ab.log.
 size_t g_walign64_below_tiles = 1200;
+// transpose_walign_kernel's tile order: -1 = by size (below), 0 / 1 / 2 forced (np_layout_set_variant(17000 + k), 17003 = by size).
+// Dealing the diagonal walk to the XCDs in eight contiguous runs lets a tile find its neighbour's 32 halo rows and the lines it shares
+// left and right in its OWN XCD's L2: 4099^2 5.08 -> 6.00 TB/s, 6001 x 6003 4.88 -> 5.71, 12345 x 6789 5.22 -> 5.75 — but 8191 x 8193
+// 5.74 -> 5.58 and 8193 x 8191 5.75 -> 5.18 (the eight XCDs then work 1024 rows = 2^25 bytes apart; profiles/r06/walign_order_ab.log).
+// Taken below 6 * 10^7 elements per plane (4000 tiles of 128 x 128), where every shape of the sweep gains.
+int g_walign_order = -1;
+static inline unsigned walign_order(size_t rows, size_t cols) {
+    return g_walign_order >= 0 ? (unsigned)g_walign_order : (rows * cols < (size_t)60'000'000 ? 1u : 0u);
+}
 
 template <int TR, int TC>
 int launch_transpose(const float *in, float *out, size_t batch, size_t rows, size_t cols, bool vec, const PlaneBatch &pb) {
@@ -604,7 +623,7 @@ int transpose_planes(const float *in, float *out, size_t batch, size_t rows, siz
         if (tiles_x * tiles_y <= 0x7fffffffu) {
             constexpr size_t lds = (size_t)64 * 66 * sizeof(float);
             transpose_walign_kernel<64, 64><<<dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch), 256, lds, np::stream()>>>(
-                in, out, (unsigned)rows, (unsigned)cols, (unsigned)tiles_x, (unsigned)tiles_y, pb);
+                in, out, (unsigned)rows, (unsigned)cols, (unsigned)tiles_x, (unsigned)tiles_y, pb, walign_order(rows, cols));
             NP_LAUNCH_CHECK("transpose_walign_kernel");
             return NP_OK;
         }
@@ -621,7 +640,7 @@ int transpose_planes(const float *in, float *out, size_t batch, size_t rows, siz
                 if (dev >= 0 && dev < 64) attr_set[dev] = true;
             }
             transpose_walign_kernel<128, 128><<<dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)batch), 256, lds, np::stream()>>>(
-                in, out, (unsigned)rows, (unsigned)cols, (unsigned)tiles_x, (unsigned)tiles_y, pb);
+                in, out, (unsigned)rows, (unsigned)cols, (unsigned)tiles_x, (unsigned)tiles_y, pb, walign_order(rows, cols));
             NP_LAUNCH_CHECK("transpose_walign_kernel");
             return NP_OK;
         }
@@ -637,6 +656,10 @@ extern "C" {
 int np_layout_set_variant(int variant) {
     if (variant >= 7000 && variant < 17000) {
         g_walign64_below_tiles = (size_t)(variant - 7000);
+        return NP_OK;
+    }
+    if (variant >= 17000 && variant <= 17003) {   // write-aligned transposes: 0 = diagonal walk in launch order, 1 / 2 = dealt to the XCDs in runs, 3 = by size
+        g_walign_order = variant == 17003 ? -1 : variant - 17000;
         return NP_OK;
     }
     g_tile = variant;
