@@ -5,6 +5,8 @@
  *                           PHP_METHOD(add / subtract / multiply / divide / mod / pow) (numpower.c:3384-3550)
  *   NPH_LazyElementWise*    the `rtn = NDArrayMathGPU_ElementWise(nda, cuda_float_sin);` ... of the unary PHP_METHODs
  *                           (numpower.c:1651-3348; clip :2487, round :2959)
+ *   NPH_ReduceAll           the `NDArray_Sum_Float(nda)` / Float_Prod / Min / Max of PHP_METHOD(sum, prod, min, max, mean)
+ *                           (numpower.c:4638,4744,4673,4712,2660,2675): a pending operand is reduced inside its chain's kernel
  *   NPH_OnBufferGet         buffer_get (src/buffer.c:80-83): the flush point
  *   NPH_OnFree              NDArray_FREE (src/ndarray.c:587-592): a pending array that dies releases its inputs
  *   NPH_PrepareChain        operand kinds + AVX-body quirk flags of a chain (shared with NDArray_FusedChain of the host
@@ -212,6 +214,25 @@ int NPH_Flush(NDArray *a) {
     }
     release_chain(c);
     return rc;
+}
+
+float NPH_ReduceAll(int reduce_op, NPH_EagerReduce eager, NDArray *a) {
+    if (a == NULL || eager == NULL) return -1.0f;
+    Chain *c = find_chain(a);
+    if (c == NULL) return eager(a);                        /* values are there (or a CPU array): the reference function */
+    if (!g_lazy_on || reduce_op < 0 || reduce_op >= NP_REDUCE_OP_COUNT) {
+        if (NPH_Flush(a) != 0) return -1.0f;
+        return eager(a);
+    }
+    NPH_ChainCall call;
+    float v = -1.0f;
+    if (NPH_PrepareChain(c->inputs, c->scalars, c->n_inputs, c->ops, c->n_ops, &call) != 0) return -1.0f;
+    if (np_fused_chain_reduce(call.ptrs, call.kinds, c->n_inputs, call.prog, c->n_ops, reduce_op, call.rows, call.cols, &v) != NP_OK) {
+        np_ext_throw(np_last_error());
+        return -1.0f;
+    }
+    g_stats.fused_reductions++;
+    return v;                                              /* `a` stays pending: nobody has asked for its values yet */
 }
 
 void NPH_OnBufferGet(NDArray *a) {

@@ -73,6 +73,17 @@ struct NDArray *NPH_LazyElementWise(struct NDArray *a, NPH_UnaryFn op);
 struct NDArray *NPH_LazyElementWise1F(struct NDArray *a, NPH_Unary1FFn op, float val1);
 struct NDArray *NPH_LazyElementWise2F(struct NDArray *a, NPH_Unary2FFn op, float val1, float val2);
 
+/* The full reductions as consumers that know about chains: `double value = NDArray_Sum_Float(nda);` of PHP_METHOD(sum)
+ * (numpower.c:4638; likewise prod :4744, min :4673, max :4712 and the two `NDArray_Sum_Float(nda) / NDArray_NUMELEMENTS(nda)` of
+ * PHP_METHOD(mean) :2660,2675) becomes `NPH_ReduceAll(NP_SUM, NDArray_Sum_Float, nda)`.  A pending operand is reduced INSIDE its
+ * chain's kernel (np_fused_chain_reduce: the expression's values never go to memory — nd::sum(nd::exp($a) * $b) reads 8 B/elem in
+ * one launch instead of writing 4, reading 4 more and launching twice) and STAYS pending; anything else goes to `eager`, the
+ * reference function.  min / max are bit-identical either way; sum / prod are folded in the chain kernel's (deterministic) order,
+ * which is not the order np_reduce_all folds stored values in: equal within the bar every reduction is held to (1e-5 of fp64),
+ * not bit for bit.  Returns what `eager` returns on failure: a raised error and -1. */
+typedef float (*NPH_EagerReduce)(struct NDArray *);
+float NPH_ReduceAll(int reduce_op, NPH_EagerReduce eager, struct NDArray *a);
+
 /* 0 = values are there (or were computed now), -1 = an error was raised */
 int NPH_Flush(struct NDArray *a);
 int NPH_IsPending(const struct NDArray *a);
@@ -80,9 +91,9 @@ int NPH_PendingCount(void);
 /* on (default) / off: off makes every appender take the eager path (one launch per op, as section 2b alone) */
 void NPH_SetLazy(int on);
 /* counters for tests and the demo program: chains flushed as one launch, steps those chains held, chains discarded
- * unevaluated, steps that took the eager path although an operand was on the GPU */
+ * unevaluated, steps that took the eager path although an operand was on the GPU, reductions run inside a chain's kernel */
 typedef struct NPH_LazyStats {
-    unsigned long flushed_chains, flushed_steps, discarded_chains, eager_steps;
+    unsigned long flushed_chains, flushed_steps, discarded_chains, eager_steps, fused_reductions;
 } NPH_LazyStats;
 void NPH_GetLazyStats(NPH_LazyStats *out);
 

@@ -78,7 +78,7 @@ def test_the_default_tree_is_hip_only(patched):
                 assert not tool._CUDA_NAME.search(side)
     assert {"_reduce(0, 0, axis, array, rtn, operation);", "_single_reduce(0, 0, axis, array, rtn, operation);",
             "rtn = NDArray_Map(nda, float_exp2);", "rtn = NDArray_Add_Float(nda, ndb);"} <= set(else_sides)
-    assert len(else_sides) == 3 + 43 + 12
+    assert len(else_sides) == 3 + 43 + 12 + 5 + 6
     # the two things that are left are not compiled by a --with-hip build (config.m4 swaps them for the glue)
     assert (out / "src" / "gpu_alloc.c").exists() and "src/hip/gpu_alloc_hip.c" in (out / "config.m4").read_text()
     # the checker is not vacuous: the --keep-cuda tree fails the raw check at its #else sides
@@ -280,12 +280,19 @@ def test_pending_chains_flush_at_the_one_marshalling_point(patched):
     assert sum(p.read_text(errors="replace").count("MAIN_MEM_STACK.buffer[") for p in other) == 0      # nobody reads the table behind buffer_get's back
     assert ref_np.count("buffer_get(") == 6 == new_np.count("buffer_get(")
     # appender scopes: 1 operator handler + 6 static methods + 36 unary methods, each closed right behind the lookups
-    assert new_np.count("NPH_LAZY_MARSHAL_BEGIN();") == 43 == new_np.count("NPH_LAZY_MARSHAL_END();")
+    # ... + the five full reductions (sum, min, max, prod, mean), consumers that know chains
+    assert new_np.count("NPH_LAZY_MARSHAL_BEGIN();") == 43 + 5 == new_np.count("NPH_LAZY_MARSHAL_END();")
     for m in re.finditer(r"NPH_LAZY_MARSHAL_BEGIN\(\);\n(.*?)NPH_LAZY_MARSHAL_END\(\);", new_np, flags=re.S):
         lines = [ln.strip() for ln in m.group(1).strip().split("\n")]
         assert 1 <= len(lines) <= 2 and all(re.fullmatch(r"NDArray \*nd[ab] = ZVAL_TO_NDARRAY\((op1|op2|a|b|array)\);", ln) for ln in lines), lines
     # every marshalling call of the reference is still there (the appenders' inside a scope + kept on the guard's #else side)
-    assert new_np.count("ZVAL_TO_NDARRAY(") == ref_np.count("ZVAL_TO_NDARRAY(") + 2 + 12 + 36
+    assert new_np.count("ZVAL_TO_NDARRAY(") == ref_np.count("ZVAL_TO_NDARRAY(") + 2 + 12 + 36 + 5
+    assert new_np.count("NPH_ReduceAll(") == 6          # sum, min, max, prod + mean's two branches
+    for fn, op in (("NDArray_Sum_Float", "NP_SUM"), ("NDArray_Min", "NP_MIN"), ("NDArray_Max", "NP_MAX"), ("NDArray_Float_Prod", "NP_PROD")):
+        assert "= NPH_ReduceAll(%s, %s, nda);" % (op, fn) in new_np
+    # the axis forms reach reduce() / single_reduce() with an operand that may still be pending: both compute it first
+    nd_c = (out / "src/ndarray.c").read_text()
+    assert nd_c.count("if (NPH_Flush(array) != 0) {") == 2
     assert new_np.count("rtn = NPH_LazyBinary(") == 12 and len(re.findall(r"rtn = NPH_LazyElementWise(?:1F|2F)?\(nda, cuda_float_\w+", new_np)) == 36
     assert "rtn = NPH_LazyElementWise2F(nda, cuda_float_clip, (float)min, (float)max);" in new_np
     assert "rtn = NPH_LazyElementWise1F(nda, cuda_float_round, (float)precision);" in new_np
@@ -331,7 +338,7 @@ def test_the_pending_chain_text_runs_as_a_program_and_cpu_operands_reach_the_ref
     proc = subprocess.run([str(exe), "cpu"], capture_output=True, text=True, timeout=120)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     m = re.search(r"(\d+) expressions, (\d+) reached the reference's own code, 0 pending", proc.stdout)
-    assert m and int(m.group(1)) >= 14 and int(m.group(2)) >= int(m.group(1))
+    assert m and int(m.group(1)) >= 14 and int(m.group(2)) >= int(m.group(1)) + 5          # + the five reductions of a CPU array
 
 
 @needs_reference

@@ -124,6 +124,8 @@ _LAZY_FLUSH_NOTE = ("/* numpower_amd 2c: every consumer obtains its NDArray* her
                     " * array whose values are still a pending chain gets them now, in ONE fused launch, and so do the chains that read\n"
                     " * this array's buffer (the consumer may write it); appenders switch this off while they look their operands up */\n")
 _LAZY_MARSHAL_NOTE = "/* numpower_amd 2c: an appender — its operands may stay pending chains (hip_lazy.h) */\n"
+_LAZY_REDUCE_NOTE = ("/* numpower_amd 2c: a consumer that knows chains — a pending operand is reduced inside its chain's kernel (NPH_ReduceAll);\n"
+                     " * the axis forms flush it (reduce() / single_reduce()) */\n")
 # unary PHP_METHODs that call NDArrayMathGPU_ElementWise{,1F,2F}(nda, ...): 33 + clip + round in the reference, + exp2's
 # new device branch (section 2a)
 N_UNARY_APPENDERS = 36
@@ -277,7 +279,10 @@ EDITS = [
          "/* numpower_amd: sum / prod over an axis of a GPU array is ONE np_reduce_axis launch into the result allocated\n"
          " * above, instead of one operation() + allocation + copy per slice (_reduce, ndarray.c:394-429); CPU arrays, any\n"
          " * other operation and a negative axis (which reduce() lets through, ndarray.c:534) keep the reference's loop */\n"
-         "if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && *axis >= 0 &&\n"
+         "if (NPH_Flush(array) != 0) {                 /* section 2c: sum / prod / mean look their operand up as consumers that know chains */\n"
+         "    NDArray_FREE(rtn);\n"
+         "    rtn = NULL;\n"
+         "} else if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && *axis >= 0 &&\n"
          "    (operation == NDArray_Add_Float || operation == NDArray_Multiply_Float)) {\n"
          "    if (NPH_ReduceAxisInto(array, *axis, operation == NDArray_Add_Float ? NP_SUM : NP_PROD,\n"
          "                           operation == NDArray_Multiply_Float ? NP_QUIRK_AVX_BODY : 0u, rtn) != 0) {\n"
@@ -293,7 +298,10 @@ EDITS = [
          " * for them (apply_single_reduce stores only when the target is on the CPU, ndarray.c:389).  For a GPU array this is what\n"
          " * the method's CPU branch computes — reduce(Add) / n, numpower.c:2662-2669 — as one np_reduce_axis launch; every other\n"
          " * operation (min / max / median / all) and every CPU array keeps the reference's loop */\n"
-         "if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && *axis >= 0 && operation == NDArray_Mean_Float) {\n"
+         "if (NPH_Flush(array) != 0) {                 /* section 2c */\n"
+         "    NDArray_FREE(rtn);\n"
+         "    rtn = NULL;\n"
+         "} else if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && *axis >= 0 && operation == NDArray_Mean_Float) {\n"
          "    if (NPH_ReduceAxisInto(array, *axis, NP_MEAN, 0u, rtn) != 0) {\n"
          "        NDArray_FREE(rtn);\n"
          "        rtn = NULL;\n"
@@ -350,6 +358,31 @@ EDITS = [
          # (not the CUDA side of a --keep-cuda pair: PHP_METHOD(rsqrt)'s `#else` keeps the reference's statement)
          r"(?<!#else\n)^(?P<old>[ \t]*rtn = NDArrayMathGPU_ElementWise(?P<sfx>1F|2F)?\(nda, (?P<rest>cuda_float_\w+[^;\n]*)\);)$",
          r"rtn = NPH_LazyElementWise\g<sfx>(nda, \g<rest>);", expect=N_UNARY_APPENDERS, template=True),
+    # ... and the full reductions reduce a pending operand inside its chain's kernel
+    Edit("numpower.c", "numpower.c:4630-4738 PHP_METHOD(sum, min, max, prod): operand looked up as a chain-aware consumer",
+         r"^(?P<old>[ \t]*NDArray \*nda = ZVAL_TO_NDARRAY\(a\);)\n"
+         r"(?=(?:(?!PHP_METHOD)[^\n]*\n){1,16}?[^\n]*= NDArray_(?:Sum_Float|Float_Prod|Min|Max)\(nda\);)",
+         _LAZY_REDUCE_NOTE +
+         "NPH_LAZY_MARSHAL_BEGIN();\n"
+         "NDArray *nda = ZVAL_TO_NDARRAY(a);\n"
+         "NPH_LAZY_MARSHAL_END();", expect=4, guard=True),
+    Edit("numpower.c", "numpower.c:2653 PHP_METHOD(mean): operand looked up as a chain-aware consumer",
+         r"^(?P<old>[ \t]*NDArray \*nda = ZVAL_TO_NDARRAY\(array\);)\n"
+         r"(?=(?:(?!PHP_METHOD)[^\n]*\n){1,8}?[ \t]*RETURN_DOUBLE\(\(NDArray_Sum_Float\(nda\) / NDArray_NUMELEMENTS\(nda\)\)\);)",
+         _LAZY_REDUCE_NOTE +
+         "NPH_LAZY_MARSHAL_BEGIN();\n"
+         "NDArray *nda = ZVAL_TO_NDARRAY(array);\n"
+         "NPH_LAZY_MARSHAL_END();", guard=True),
+    Edit("numpower.c", "numpower.c:2660,2675 PHP_METHOD(mean): `NDArray_Sum_Float(nda) / n` inside the chain's kernel",
+         r"^(?P<old>[ \t]*RETURN_DOUBLE\(\(NDArray_Sum_Float\(nda\) / NDArray_NUMELEMENTS\(nda\)\)\);)$",
+         "RETURN_DOUBLE((NPH_ReduceAll(NP_SUM, NDArray_Sum_Float, nda) / NDArray_NUMELEMENTS(nda)));", expect=2, guard=True),
+] + [
+    Edit("numpower.c", "numpower.c:%s `%s = %s(nda)`: reduce inside the chain's kernel" % (_line, _lhs, _fn),
+         r"^(?P<old>[ \t]*%s = %s\(nda\);)$" % (re.escape(_lhs), _fn),
+         "%s = NPH_ReduceAll(%s, %s, nda);" % (_lhs, _op, _fn), guard=True)
+    for _line, _lhs, _fn, _op in (("4638", "double value", "NDArray_Sum_Float", "NP_SUM"), ("4673", "value", "NDArray_Min", "NP_MIN"),
+                                  ("4712", "value", "NDArray_Max", "NP_MAX"), ("4744", "value", "NDArray_Float_Prod", "NP_PROD"))
+] + [
     # ---- config.m4: the option, and the source list ----
     Edit("config.m4", "config.m4:7-8: --with-hip next to --with-cuda",
          r"^(?P<old>PHP_ARG_WITH\(cuda, for CUDA support,\n\[  --with-cuda           Include CUDA support\], \[no\], \[no\]\))$",
@@ -390,6 +423,13 @@ CONTEXTS.update({
     "numpower.c:1651-3348 `rtn = NDArrayMathGPU_ElementWise{,1F,2F}(nda, cuda_float_*)`: append to the pending chain":
         "NDArray *rtn = 0, *nda = 0;",
 })
+CONTEXTS.update({
+    "numpower.c:4630-4738 PHP_METHOD(sum, min, max, prod): operand looked up as a chain-aware consumer": "zval *a = 0;",
+    "numpower.c:2653 PHP_METHOD(mean): operand looked up as a chain-aware consumer": "zval *array = 0;",
+})
+for _e in EDITS:
+    if "reduce inside the chain's kernel" in _e.what:
+        CONTEXTS[_e.what] = "NDArray *nda = 0;" + ("" if _e.what.startswith("numpower.c:4638") else " double value = 0;")
 for _e in EDITS:
     if "`rtn = NDArray_" in _e.what:
         CONTEXTS[_e.what] = "NDArray *rtn = 0, *nda = 0, *ndb = 0;"
@@ -498,7 +538,7 @@ def fast_path_program_source() -> str:
     o = ["/* generated by tools/apply_with_hip.py: fast_path_program_source() — do not edit */",
          "#define _POSIX_C_SOURCE 200809L",
          "#include <stdint.h>", "#include <stdio.h>", "#include <stdlib.h>", "#include <string.h>", "",
-         "#define HAVE_NP_HIP 1", '#include "numpower_host.h"', '#include "hip_fast.h"', "",
+         "#define HAVE_NP_HIP 1", '#include "numpower_host.h"', '#include "hip_fast.h"', '#include "hip_lazy.h"', "",
          "static int g_fell_through;   /* calls that reached the reference's own code (the stand-ins below) */",
          "static NDArray *reference_body(void) { g_fell_through++; return NULL; }",
          "static void _reduce(int current_axis, int rtn_init, int *axis, NDArray *target, NDArray *rtn,",
@@ -744,6 +784,26 @@ def lazy_program_source() -> str:
               "        g_reference_bodies++;   /* rtn = NDArray_Map(nda, float_%s); */" % name, "    } else {", "#ifdef HAVE_CUBLAS",
               _indent(m.expand(call_un.new), "        "), "#endif", "    }",
               "    RETURN_NDARRAY(rtn, return_value);", "}", ""]
+    # the full reductions (numpower.c:4620-4751, 2642-2688): the no-axis branch of each method
+    marshal_red, marshal_mean = _edit("numpower.c:4630-4738"), _edit("numpower.c:2653")
+    mean_call = _edit("numpower.c:2660,2675")
+    for fn in ("NDArray_Sum_Float", "NDArray_Float_Prod", "NDArray_Min", "NDArray_Max"):
+        o += ["static float patched_%s(NDArray *a) {" % fn,
+              "    if (NDArray_DEVICE(a) == NDARRAY_DEVICE_GPU) return %s(a);   /* the device branch of the reference function (section 2a) */" % fn,
+              "    g_reference_bodies++;                                          /* its CPU loop */", "    return 0.0f;", "}",
+              "#define %s patched_%s" % (fn, fn), ""]
+    for name, prefix in (("sum", "numpower.c:4638"), ("min", "numpower.c:4673"), ("max", "numpower.c:4712"), ("prod", "numpower.c:4744")):
+        e = _edit(prefix)
+        o += ["static double patched_method_%s(zval *a) {" % name] + (["    double value;"] if name != "sum" else []) + [
+              "#ifdef HAVE_NP_HIP", _indent(marshal_red.new, "    "), "#endif",
+              "    if (nda == NULL) {", "        return -1.0;", "    }",
+              "#ifdef HAVE_NP_HIP", _indent(e.new, "    "), "#endif",
+              "    CHECK_INPUT_AND_FREE(a, nda);", "    return value;", "}", ""]
+    o += ["#define RETURN_DOUBLE(d) return (d)",
+          "static double patched_method_mean(zval *array) {",
+          "#ifdef HAVE_NP_HIP", _indent(marshal_mean.new, "    "), "#endif",
+          "    if (nda == NULL) {", "        return -1.0;", "    }",
+          "#ifdef HAVE_NP_HIP", _indent(mean_call.new, "    "), "#endif", "}", ""]
     o.append(_LAZY_PROGRAM_MAIN)
     return "\n".join(o)
 
@@ -756,6 +816,7 @@ typedef struct zval { int type; double dval; int handle; } zval;
 #define Z_TYPE_P(z) ((z)->type)
 
 static int g_reference_bodies;   /* calls that reached "the reference's own code" (CPU operands) */
+static NDArray *(*const kHostAddFloat)(NDArray *, NDArray *) = NDArray_Add_Float;   /* (the name is a stand-in further down) */
 
 /* src/buffer.h:9-16, src/buffer.c:91-120 */
 struct MemoryStack { NDArray **buffer; int bufferSize; int numElements; int lastFreed; };
@@ -809,6 +870,7 @@ static void zval_dtor(zval *z) {
     if (Z_TYPE_P(z) == IS_OBJECT) buffer_ndarray_free(z->handle);
     z->type = IS_UNDEF;
 }
+static NDArray *buffer_peek(zval *z) { return Z_TYPE_P(z) == IS_OBJECT ? MAIN_MEM_STACK.buffer[z->handle] : NULL; }   /* tests only: no flush */
 static zval number(double v) { zval z = {IS_DOUBLE, v, 0}; return z; }
 static zval object_of(NDArray *a) { zval z = {IS_UNDEF, 0.0, 0}; RETURN_NDARRAY(a, &z); return z; }"""
 
@@ -884,7 +946,7 @@ static zval placed(const int *shape, int ndim, int seed, float lo, float hi, int
 }
 
 /* `$r = <expression>` evaluated as PHP evaluates it: one object per operator, temporaries dropped once consumed */
-typedef struct Env { zval x, y, p, row, col, wide; } Env;
+typedef struct Env { zval x, y, p, row, col, wide, w; } Env;
 typedef zval (*Expr)(Env *);
 
 static zval op2(int opcode, zval a, zval b, int drop_a, int drop_b) {   /* $a (op) $b through the do_operation handler */
@@ -991,6 +1053,7 @@ int main(int argc, char **argv) {
     e.row = placed(s1, 1, 204, -2, 2, gpu);
     e.col = placed(scol, 2, 205, 0.5f, 2, gpu);
     e.wide = placed(s2, 2, 206, -1, 1, gpu);
+    e.w = placed(s2, 2, 207, 0.9997f, 1.0003f, gpu);       /* factors of a product that stays near 1 */
     NPH_LazyStats st0, st1;
 
     if (!gpu) {
@@ -1002,6 +1065,10 @@ int main(int argc, char **argv) {
             CHECK(Z_TYPE_P(&r) == IS_UNDEF, "%s computed something for CPU operands", kExpr[k].name);
             CHECK(NPH_PendingCount() == 0, "%s left a pending chain for CPU operands", kExpr[k].name);
         }
+        const int before = g_reference_bodies;
+        (void) patched_method_sum(&e.x); (void) patched_method_min(&e.x); (void) patched_method_max(&e.x); (void) patched_method_prod(&e.x);
+        (void) patched_method_mean(&e.x);
+        CHECK(g_reference_bodies - before == 5 && NPH_PendingCount() == 0, "the reductions of a CPU array: %d reached the reference's code", g_reference_bodies - before);
         /* (an expression whose first step yields nothing stops there, as PHP would on the exception: count what ran) */
         printf("lazy_bodies cpu: %d expressions, %d reached the reference's own code, 0 pending\n", kExprCount, g_reference_bodies);
         CHECK(g_reference_bodies >= kExprCount, "only %d calls reached the reference's code", g_reference_bodies);
@@ -1106,6 +1173,61 @@ int main(int argc, char **argv) {
         if (he) NDArray_FREE(he);
         zval_dtor(&eq); zval_dtor(&c2); zval_dtor(&c); zval_dtor(&one); zval_dtor(&total_obj);
     }
+    /* ---- 5b. the full reductions reduce a pending operand INSIDE its chain's kernel: one launch, the values never stored ---- */
+    {
+        static const struct { const char *name; double (*fn)(zval *); int exact; } kRed[] = {
+            {"sum", patched_method_sum, 0}, {"mean", patched_method_mean, 0}, {"max", patched_method_max, 1}, {"min", patched_method_min, 1},
+            {"prod", patched_method_prod, 0}};
+        for (int k = 0; k < 5; k++) {
+            double got[2];
+            unsigned long long cost[2];
+            for (int lazy = 1; lazy >= 0; lazy--) {
+                NPH_SetLazy(lazy);
+                NPH_GetLazyStats(&st0);
+                const unsigned long long l0 = launches();
+                /* nd::sum(nd::exp($x) * $y) ...; a product that stays near 1: nd::prod(nd::clip($w, 0.9998, 1.0002)) */
+                zval c = {IS_UNDEF, 0.0, 0};
+                if (k == 4) patched_method_clip(&e.w, 0.9998, 1.0002, &c);
+                else c = op2(ZEND_MUL, UN(exp, e.x, 0), e.y, 1, 0);
+                got[lazy] = kRed[k].fn(&c);
+                cost[lazy] = launches() - l0;
+                NPH_GetLazyStats(&st1);
+                if (lazy) CHECK(st1.fused_reductions - st0.fused_reductions == 1 && NPH_IsPending(buffer_peek(&c)),
+                                "%s of a pending value: %lu fused reductions, pending afterwards %d", kRed[k].name,
+                                st1.fused_reductions - st0.fused_reductions, NPH_IsPending(buffer_peek(&c)));
+                zval_dtor(&c);
+            }
+            NPH_SetLazy(1);
+            const int steps = k == 4 ? 1 : 2;
+            printf("%-4s of a pending value: %llu launch(es), %llu without chains; %.9g / %.9g\n", kRed[k].name, cost[1], cost[0], got[1], got[0]);
+            CHECK(cost[1] == 1 && cost[0] == (unsigned long long) steps + 1, "%s: %llu launches with chains, %llu without", kRed[k].name, cost[1], cost[0]);
+            const double tol = kRed[k].exact ? 0.0 : 2e-6 * (got[0] < 0 ? -got[0] : got[0]);
+            CHECK((got[1] > got[0] ? got[1] - got[0] : got[0] - got[1]) <= tol, "%s: %.9g inside the chain, %.9g of the stored values", kRed[k].name, got[1], got[0]);
+            float both[2] = {(float) got[1], (float) got[0]};
+            const int s2v[1] = {2};
+            char label[32];
+            snprintf(label, sizeof label, "reduce.%s", kRed[k].name);
+            zval obj = object_of(NDArray_FromHostBuffer(both, s2v, 1));
+            NDArray *h = dump(label, &obj);
+            if (h) NDArray_FREE(h);
+            zval_dtor(&obj);
+        }
+        /* with an axis the operand is computed first (reduce() flushes it: ONE launch for the two steps), then reduced (np_reduce_axis:
+         * one or two launches by shape) */
+        zval c = op2(ZEND_MUL, UN(exp, e.x, 0), e.y, 1, 0);
+        const unsigned long long l0 = launches();
+        int axis = 0;
+        NPH_LAZY_MARSHAL_BEGIN();
+        NDArray *pending = ZVAL_TO_NDARRAY(&c);
+        NPH_LAZY_MARSHAL_END();
+        CHECK(NPH_IsPending(pending), "expected a pending operand");
+        CHECK(NPH_Flush(pending) == 0, "flush failed");   /* what the statement inserted into reduce() does first (fast_path_bodies runs that text) */
+        zval red = object_of(reduce(pending, &axis, kHostAddFloat));
+        CHECK(launches() - l0 >= 2 && launches() - l0 <= 3, "sum(axis 0) of a pending value: %llu launches", launches() - l0);
+        NDArray *hr = dump("reduce.axis0", &red);
+        if (hr) NDArray_FREE(hr);
+        zval_dtor(&red); zval_dtor(&c);
+    }
     /* ---- 6. errors are the eager path's: a CPU array next to a GPU array, shapes that do not broadcast ---- */
     {
         const int s[2] = {4, 5}, t[1] = {7};
@@ -1120,7 +1242,7 @@ int main(int argc, char **argv) {
         zval_dtor(&g); zval_dtor(&h); zval_dtor(&odd);
     }
     CHECK(NPH_PendingCount() == 0, "%d chains pending at the end", NPH_PendingCount());
-    zval_dtor(&e.x); zval_dtor(&e.y); zval_dtor(&e.p); zval_dtor(&e.row); zval_dtor(&e.col); zval_dtor(&e.wide);
+    zval_dtor(&e.x); zval_dtor(&e.y); zval_dtor(&e.p); zval_dtor(&e.row); zval_dtor(&e.col); zval_dtor(&e.wide); zval_dtor(&e.w);
     fclose(g_out);
     if (NDArray_LiveDeviceAllocations() != 0) {
         fprintf(stderr, "lazy_bodies: %ld device allocations leaked\n", NDArray_LiveDeviceAllocations());
