@@ -1,5 +1,5 @@
 #!/bin/bash
-# What runs on a GPU lease, in one place (rounds 2 and 3 kept one script per lease: tools/attic/gpu_r0*.sh).
+# What runs on a GPU lease, in one place (rounds 2 and 3 kept one script per lease; those left the tree in round 6).
 #   gpurun --timeout 1500 -- 'bash tools/gpu_lease.sh <recipe> [tag]'
 # Recipes (outputs under gpurun_out/<tag>/, tag defaults to the recipe name; copy what should be judged to profiles/rNN/):
 #   tests      the -m gpu suite (the gate)
