@@ -1431,6 +1431,12 @@ int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t in
         reduce_axis_cols<OP, false, I><<<grid, 256, 0, s>>>(in, (float *)partials.ptr, (I)axis_len,
                                                          (I)inner, (I)splits, mean_div, 0, (I)0, xcd_runs);
         NP_LAUNCH_CHECK("reduce_axis_cols(pass 1)");
+        // Many chunks over few column tiles (a tall, skinny array: 500000 x 200 is ONE tile in 3072 chunks): the pass below would
+        // fold them with one workgroup per tile, four rows in flight per wave — 192 dependent iterations, as long as the first
+        // pass itself (134 us where the read takes 67).  The partials are again a tall skinny array: reduce THEM in chunks first
+        // (one more 4 us launch).  From 256 chunks up; BASELINE config 4 (192 chunks over 16 tiles, a 5 us fold) is not touched.
+        if (splits >= 256)
+            return launch_reduce_axis<OP, I>((const float *)partials.ptr, outer, splits, inner, out, flags, mean_div);
         // pass 2: the partials are an outer x splits x inner array; MEAN must divide by the real
         // axis length, not by `splits`.
         const dim3 grid2((unsigned)((inner4 + 63) / 64), 1, (unsigned)outer);

@@ -30,7 +30,9 @@ CASES = [((65536, 4096), 0), ((65536, 4096), 1), ((4096, 65536), 0), ((4096, 655
          ((256, 1024, 1024), 1), ((256, 1024, 1024), 0), ((256, 1024, 1024), 2), ((30_000_000, 3), 0), ((30_000_000, 3), 1),
          ((3, 30_000_000), 0), ((3, 30_000_000), 1), ((100_000_000, 1), 0), ((16, 16, 16, 16, 16, 64), 3), ((10007, 10007), 0),
          ((10007, 10007), 1), ((30_000_000, 4), 0), ((12_000_000, 8), 0), ((100_000, 64, 16), 1), ((3, 10_000_000, 2), 1),
-         ((1_000_000, 64), 0), ((400_000, 128), 0)]
+         ((1_000_000, 64), 0), ((400_000, 128), 0),
+         # tall and skinny with a few hundred to a few thousand columns (feature means over samples): few column tiles, many chunks
+         ((500_000, 200), 0), ((400_000, 256), 0), ((200_000, 512), 0), ((100_000, 1000), 0), ((65536, 1000), 0), ((50_000, 2000), 0), ((25_000, 4000), 0)]
 for shape, axis in CASES:
     n = int(np.prod(shape))
     x = D.DeviceArray(shape); D.fill(x, 1.0)
