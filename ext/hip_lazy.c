@@ -7,6 +7,8 @@
  *                           (numpower.c:1651-3348; clip :2487, round :2959)
  *   NPH_ReduceAll           the `NDArray_Sum_Float(nda)` / Float_Prod / Min / Max of PHP_METHOD(sum, prod, min, max, mean)
  *                           (numpower.c:4638,4744,4673,4712,2660,2675): a pending operand is reduced inside its chain's kernel
+ *   NPH_ChainReduceAxisInto reduce() / single_reduce() (src/ndarray.c:570, :509) on a pending operand: sum / mean over the last axis (or
+ *                           the first of a 2-d array) inside the chain's kernel
  *   NPH_OnBufferGet         buffer_get (src/buffer.c:80-83): the flush point
  *   NPH_OnFree              NDArray_FREE (src/ndarray.c:587-592): a pending array that dies releases its inputs
  *   NPH_PrepareChain        operand kinds + AVX-body quirk flags of a chain (shared with NDArray_FusedChain of the host
@@ -233,6 +235,46 @@ float NPH_ReduceAll(int reduce_op, NPH_EagerReduce eager, NDArray *a) {
     }
     g_stats.fused_reductions++;
     return v;                                              /* `a` stays pending: nobody has asked for its values yet */
+}
+
+int NPH_ChainAxisView(const NDArray *first, int axis, const NPH_ChainCall *call, size_t *rows, size_t *cols, int *ax) {
+    const int nd = NDArray_NDIM(first);
+    const size_t n = (size_t) NDArray_NUMELEMENTS(first);
+    if (nd < 1 || n == 0 || axis < 0 || axis >= nd) return 0;
+    if (axis == nd - 1) {
+        *cols = (size_t) NDArray_SHAPE(first)[nd - 1];
+        *rows = *cols ? n / *cols : 0;
+        *ax = 1;
+    } else if (axis == 0 && nd == 2) {
+        *rows = (size_t) NDArray_SHAPE(first)[0];
+        *cols = (size_t) NDArray_SHAPE(first)[1];
+        *ax = 0;
+    } else {
+        return 0;
+    }
+    const int flat_chain = call->rows == 1 && call->cols == n;             /* no broadcast operand: any rows x cols view will do */
+    return flat_chain || (call->rows == *rows && call->cols == *cols);
+}
+
+int NPH_ChainReduceAxisInto(NDArray *array, int axis, int reduce_op, NDArray *rtn) {
+    if (array == NULL || rtn == NULL) return 0;
+    Chain *c = find_chain(array);
+    if (c == NULL || !g_lazy_on) return 0;
+    if (reduce_op != NP_SUM && reduce_op != NP_MEAN && reduce_op != NP_MIN && reduce_op != NP_MAX) return 0;
+    if (NDArray_DEVICE(rtn) != NDARRAY_DEVICE_GPU) return 0;
+    NPH_ChainCall call;
+    if (NPH_PrepareChain(c->inputs, c->scalars, c->n_inputs, c->ops, c->n_ops, &call) != 0) return -1;
+    size_t rows = 0, cols = 0;
+    int ax = -1;
+    if (!NPH_ChainAxisView(array, axis, &call, &rows, &cols, &ax)) return 0;
+    if ((size_t) NDArray_NUMELEMENTS(rtn) != (ax == 1 ? rows : cols)) return 0;
+    if (np_fused_chain_reduce_axis(call.ptrs, call.kinds, c->n_inputs, call.prog, c->n_ops, reduce_op, rows, cols, ax,
+                                   NDArray_FDATA(rtn)) != NP_OK) {
+        np_ext_throw(np_last_error());
+        return -1;
+    }
+    g_stats.fused_reductions++;
+    return 1;
 }
 
 void NPH_OnBufferGet(NDArray *a) {

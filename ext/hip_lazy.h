@@ -84,6 +84,18 @@ struct NDArray *NPH_LazyElementWise2F(struct NDArray *a, NPH_Unary2FFn op, float
 typedef float (*NPH_EagerReduce)(struct NDArray *);
 float NPH_ReduceAll(int reduce_op, NPH_EagerReduce eager, struct NDArray *a);
 
+/* reduce() / single_reduce() (src/ndarray.c:570, :509) met a pending operand: `rtn` (allocated by the caller with the reduced
+ * shape) = reduction of the chain's values over `axis`, INSIDE the chain's kernel (np_fused_chain_reduce_axis: nd::sum(nd::exp($x), 1)
+ * reads 4 B/elem once instead of writing 4 and reading 4 more) — for the last axis of any array and the first axis of a 2-d array,
+ * reduce_op NP_SUM / NP_MEAN / NP_MIN / NP_MAX (a product carries the zero-sign quirks of the reference's slice-by-slice multiply: it
+ * reduces stored values).  1 = done (the operand stays pending), 0 = not this way (values there, another axis, a product: the caller
+ * flushes and reduces the stored values), -1 = an error was raised. */
+int NPH_ChainReduceAxisInto(struct NDArray *array, int axis, int reduce_op, struct NDArray *rtn);
+/* the rows x cols view np_fused_chain_reduce_axis needs for `axis` of an array shaped like `first`, given the chain's own 2-d view
+ * (call->rows x call->cols, fixed by its broadcast operands): 1 + *rows, *cols, *ax (0 = first axis, 1 = last) or 0 = no such view */
+struct NPH_ChainCall;
+int NPH_ChainAxisView(const struct NDArray *first, int axis, const struct NPH_ChainCall *call, size_t *rows, size_t *cols, int *ax);
+
 /* 0 = values are there (or were computed now), -1 = an error was raised */
 int NPH_Flush(struct NDArray *a);
 int NPH_IsPending(const struct NDArray *a);

@@ -1128,20 +1128,10 @@ NDArray *NDArray_FusedChainReduceAxis(NDArray **inputs, int n_inputs, const np_f
         throw_error("axis %d is out of bounds for array of dimension %d", axis, nd);
         return nullptr;
     }
-    const size_t n = (size_t)NDArray_NUMELEMENTS(first);
     size_t rows = 0, cols = 0;
     int ax = -1;
-    if (axis == nd - 1) {
-        cols = (size_t)first->dimensions[nd - 1];
-        rows = cols ? n / cols : 0;
-        ax = 1;
-    } else if (axis == 0 && nd == 2) {
-        rows = (size_t)first->dimensions[0];
-        cols = (size_t)first->dimensions[1];
-        ax = 0;
-    }
-    const bool flat_chain = c.rows == 1 && c.cols == n;             // no broadcast operand: any rows x cols view will do
-    if (ax < 0 || n == 0 || (!flat_chain && (c.rows != rows || c.cols != cols))) {
+    // (which axes reduce inside the chain's kernel: ext/hip_lazy.c, shared with the pending chains of a `--with-hip` tree)
+    if (!NPH_ChainAxisView(first, axis, &c, &rows, &cols, &ax)) {
         NDArray *value = NDArray_FusedChain(inputs, n_inputs, ops, n_ops);
         if (!value) return nullptr;
         NDArray *r = reduce_axis(value, axis, reduce_op, false);

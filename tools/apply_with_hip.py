@@ -279,16 +279,20 @@ EDITS = [
          "/* numpower_amd: sum / prod over an axis of a GPU array is ONE np_reduce_axis launch into the result allocated\n"
          " * above, instead of one operation() + allocation + copy per slice (_reduce, ndarray.c:394-429); CPU arrays, any\n"
          " * other operation and a negative axis (which reduce() lets through, ndarray.c:534) keep the reference's loop */\n"
-         "if (NPH_Flush(array) != 0) {                 /* section 2c: sum / prod / mean look their operand up as consumers that know chains */\n"
-         "    NDArray_FREE(rtn);\n"
-         "    rtn = NULL;\n"
-         "} else if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && *axis >= 0 &&\n"
+         "if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && *axis >= 0 &&\n"
          "    (operation == NDArray_Add_Float || operation == NDArray_Multiply_Float)) {\n"
-         "    if (NPH_ReduceAxisInto(array, *axis, operation == NDArray_Add_Float ? NP_SUM : NP_PROD,\n"
-         "                           operation == NDArray_Multiply_Float ? NP_QUIRK_AVX_BODY : 0u, rtn) != 0) {\n"
+         "    /* section 2c: PHP_METHOD(sum / prod / mean) look their operand up without flushing it — a sum over the last axis (or the\n"
+         "     * first of a 2-d array) of a pending value runs INSIDE its chain's kernel; anything else computes the value first */\n"
+         "    int nph_done = operation == NDArray_Add_Float ? NPH_ChainReduceAxisInto(array, *axis, NP_SUM, rtn) : 0;\n"
+         "    if (nph_done < 0 || (nph_done == 0 && (NPH_Flush(array) != 0 ||\n"
+         "        NPH_ReduceAxisInto(array, *axis, operation == NDArray_Add_Float ? NP_SUM : NP_PROD,\n"
+         "                           operation == NDArray_Multiply_Float ? NP_QUIRK_AVX_BODY : 0u, rtn) != 0))) {\n"
          "        NDArray_FREE(rtn);\n"
          "        rtn = NULL;\n"
          "    }\n"
+         "} else if (NPH_Flush(array) != 0) {\n"
+         "    NDArray_FREE(rtn);\n"
+         "    rtn = NULL;\n"
          "} else {\n"
          "    _reduce(0, 0, axis, array, rtn, operation);\n"
          "}", guard=True),
@@ -298,14 +302,15 @@ EDITS = [
          " * for them (apply_single_reduce stores only when the target is on the CPU, ndarray.c:389).  For a GPU array this is what\n"
          " * the method's CPU branch computes — reduce(Add) / n, numpower.c:2662-2669 — as one np_reduce_axis launch; every other\n"
          " * operation (min / max / median / all) and every CPU array keeps the reference's loop */\n"
-         "if (NPH_Flush(array) != 0) {                 /* section 2c */\n"
-         "    NDArray_FREE(rtn);\n"
-         "    rtn = NULL;\n"
-         "} else if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && *axis >= 0 && operation == NDArray_Mean_Float) {\n"
-         "    if (NPH_ReduceAxisInto(array, *axis, NP_MEAN, 0u, rtn) != 0) {\n"
+         "if (rtn != NULL && NDArray_DEVICE(array) == NDARRAY_DEVICE_GPU && *axis >= 0 && operation == NDArray_Mean_Float) {\n"
+         "    int nph_done = NPH_ChainReduceAxisInto(array, *axis, NP_MEAN, rtn);   /* section 2c: a pending operand, inside its chain's kernel */\n"
+         "    if (nph_done < 0 || (nph_done == 0 && (NPH_Flush(array) != 0 || NPH_ReduceAxisInto(array, *axis, NP_MEAN, 0u, rtn) != 0))) {\n"
          "        NDArray_FREE(rtn);\n"
          "        rtn = NULL;\n"
          "    }\n"
+         "} else if (NPH_Flush(array) != 0) {\n"
+         "    NDArray_FREE(rtn);\n"
+         "    rtn = NULL;\n"
          "} else {\n"
          "    _single_reduce(0, 0, axis, array, rtn, operation);\n"
          "}", guard=True),
@@ -799,6 +804,22 @@ def lazy_program_source() -> str:
               "    if (nda == NULL) {", "        return -1.0;", "    }",
               "#ifdef HAVE_NP_HIP", _indent(e.new, "    "), "#endif",
               "    CHECK_INPUT_AND_FREE(a, nda);", "    return value;", "}", ""]
+    # reduce() (src/ndarray.c:523-578) around its edited statement, and PHP_METHOD(sum)'s axis branch in front of it
+    reduce_edit = _edit("ndarray.c:570 reduce()")
+    o += ["static void _reduce(int current_axis, int rtn_init, int *axis, NDArray *target, NDArray *rtn, NDArray *(*operation)(NDArray *, NDArray *)) {",
+          "    (void) current_axis; (void) rtn_init; (void) axis; (void) target; (void) rtn; (void) operation;",
+          "    g_reference_bodies++;   /* the reference's slice-by-slice loop */", "}",
+          "static NDArray *patched_reduce(NDArray *array, int *axis, NDArray *(*operation)(NDArray *, NDArray *)) {",
+          "    int out_shape[8], j = 0;",
+          "    for (int i = 0; i < NDArray_NDIM(array); i++) if (i != *axis) out_shape[j++] = NDArray_SHAPE(array)[i];",
+          '    NDArray *rtn = NDArray_Zeros(out_shape, j, "float32", NDArray_DEVICE(array));',
+          "#ifdef HAVE_NP_HIP", _indent(reduce_edit.new, "    "), "#endif", "    return rtn;", "}",
+          "static zval patched_method_sum_axis(zval *a, int axis_i) {   /* rtn = reduce(nda, &axis_i, NDArray_Add_Float); numpower.c:4636 */",
+          "    zval return_value = {IS_UNDEF, 0.0, 0};",
+          "#ifdef HAVE_NP_HIP", _indent(marshal_red.new, "    "), "#endif",
+          "    if (nda == NULL) {", "        return return_value;", "    }",
+          "    NDArray *rtn = patched_reduce(nda, &axis_i, NDArray_Add_Float);",
+          "    CHECK_INPUT_AND_FREE(a, nda);", "    RETURN_NDARRAY(rtn, &return_value);", "    return return_value;", "}", ""]
     o += ["#define RETURN_DOUBLE(d) return (d)",
           "static double patched_method_mean(zval *array) {",
           "#ifdef HAVE_NP_HIP", _indent(marshal_mean.new, "    "), "#endif",
@@ -816,7 +837,6 @@ typedef struct zval { int type; double dval; int handle; } zval;
 #define Z_TYPE_P(z) ((z)->type)
 
 static int g_reference_bodies;   /* calls that reached "the reference's own code" (CPU operands) */
-static NDArray *(*const kHostAddFloat)(NDArray *, NDArray *) = NDArray_Add_Float;   /* (the name is a stand-in further down) */
 
 /* src/buffer.h:9-16, src/buffer.c:91-120 */
 struct MemoryStack { NDArray **buffer; int bufferSize; int numElements; int lastFreed; };
@@ -1212,21 +1232,37 @@ int main(int argc, char **argv) {
             if (h) NDArray_FREE(h);
             zval_dtor(&obj);
         }
-        /* with an axis the operand is computed first (reduce() flushes it: ONE launch for the two steps), then reduced (np_reduce_axis:
-         * one or two launches by shape) */
-        zval c = op2(ZEND_MUL, UN(exp, e.x, 0), e.y, 1, 0);
-        const unsigned long long l0 = launches();
-        int axis = 0;
-        NPH_LAZY_MARSHAL_BEGIN();
-        NDArray *pending = ZVAL_TO_NDARRAY(&c);
-        NPH_LAZY_MARSHAL_END();
-        CHECK(NPH_IsPending(pending), "expected a pending operand");
-        CHECK(NPH_Flush(pending) == 0, "flush failed");   /* what the statement inserted into reduce() does first (fast_path_bodies runs that text) */
-        zval red = object_of(reduce(pending, &axis, kHostAddFloat));
-        CHECK(launches() - l0 >= 2 && launches() - l0 <= 3, "sum(axis 0) of a pending value: %llu launches", launches() - l0);
-        NDArray *hr = dump("reduce.axis0", &red);
-        if (hr) NDArray_FREE(hr);
-        zval_dtor(&red); zval_dtor(&c);
+        /* nd::sum(nd::exp($x) * $y, $axis): the last axis, and the first of a 2-d array, run inside the chain's kernel (one launch
+         * or two: a column sum folds its chunks in a second one); the middle axis of a 3-d array computes the value first */
+        for (int axis = 1; axis >= 0; axis--) {
+            char label[32];
+            const unsigned long long l0 = launches();
+            zval c = op2(ZEND_MUL, UN(exp, e.x, 0), e.y, 1, 0);
+            NPH_GetLazyStats(&st0);
+            zval red = patched_method_sum_axis(&c, axis);
+            NPH_GetLazyStats(&st1);
+            const unsigned long long cost = launches() - l0;
+            CHECK(st1.fused_reductions - st0.fused_reductions == 1 && NPH_IsPending(buffer_peek(&c)) && cost <= 2,
+                  "sum(axis %d) of a pending value: %llu launches, %lu fused", axis, cost, st1.fused_reductions - st0.fused_reductions);
+            printf("sum(axis %d) of a pending value: %llu launch(es), nothing stored\n", axis, cost);
+            snprintf(label, sizeof label, "reduce.axis%d", axis);
+            NDArray *hr = dump(label, &red);
+            if (hr) NDArray_FREE(hr);
+            zval_dtor(&red); zval_dtor(&c);
+        }
+        {
+            const int s3[3] = {6, 37, 20};
+            zval a3 = placed(s3, 3, 208, -2, 2, 1);
+            zval c = UN(exp, a3, 0);
+            NPH_GetLazyStats(&st0);
+            zval red = patched_method_sum_axis(&c, 1);
+            NPH_GetLazyStats(&st1);
+            CHECK(st1.fused_reductions == st0.fused_reductions && st1.flushed_chains - st0.flushed_chains == 1 && !NPH_IsPending(buffer_peek(&c)),
+                  "sum over the middle axis of a pending 3-d value must compute the value first");
+            NDArray *hr = dump("reduce.mid3", &red);
+            if (hr) NDArray_FREE(hr);
+            zval_dtor(&red); zval_dtor(&c); zval_dtor(&a3);
+        }
     }
     /* ---- 6. errors are the eager path's: a CPU array next to a GPU array, shapes that do not broadcast ---- */
     {
