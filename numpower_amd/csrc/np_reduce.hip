@@ -29,6 +29,7 @@ using namespace np::dev;   // r_identity / r_combine / wave_reduce / block_reduc
 // One partial per workgroup, so more workgroups = more partials for the one-block second pass to fold.
 int g_wg_per_cu = 0;   // 0 = the default below
 int g_arg_flat_wg_per_cu = 0;   // the flat walks for a few columns: workgroups per CU, 0 = by shape (np_reduce_set_variant(4100000 + N): A/B)
+int g_small_inner_dword = 0;    // reduce_small_inner: 1 = the dword walk of rounds 1-5 (np_reduce_set_variant(4300001): A/B)
 int g_arg_xcd_runs_off = 0;     // argreduce_cols_tile on unaligned rows: 1 = the plain workgroup order (np_reduce_set_variant(4200001): A/B)
 int g_arg_cols_wg_per_cu = 0;   // argreduce_cols_tile: workgroups per CU the axis is cut for; 0 = by alignment (np_reduce_set_variant(4000000 + N): A/B)
 constexpr int kStreamWgPerCu = 8;
@@ -1067,6 +1068,71 @@ __global__ __launch_bounds__(256) void reduce_small_inner(const float *__restric
     }
 }
 
+// The same slab walked with FLOAT4 loads (round 6; the form np_argreduce's small-inner kernels took in round 5: N x 3 argmax 6.1 TB/s
+// where this sum ran 4.8).  A thread's vector v = t + j T starts at flat element 4 t + 4 j T, and 4 j T is a whole number of rows
+// (T is a multiple of inner): component k of thread t stays in column (4 t + k) % inner for the whole walk.  Four loads in flight, four
+// times the bytes of the dword walk above.  Needs the slab to start on a 16-byte boundary: `in` aligned, rows_per_block % 4 == 0 and
+// (outer == 1 or axis_len * inner % 4 == 0) — the host checks; else the dword kernel.  out[outer][blocks][inner].
+template <int OP, typename I>
+__global__ __launch_bounds__(256) void reduce_small_inner_v4(const float *__restrict__ in, float *__restrict__ out, I axis_len,
+                                                             I inner, I rows_per_block) {
+    __shared__ float lds[1024];
+    const unsigned T = (256u / (unsigned)inner) * (unsigned)inner;
+    const I o = blockIdx.y, b = blockIdx.x;
+    const I r0 = b * rows_per_block;
+    const I r1 = axis_len - r0 < rows_per_block ? axis_len : r0 + rows_per_block;
+    const size_t cnt = (size_t)(r1 - r0) * inner, nvec = cnt >> 2;
+    const float *p = in + ((size_t)o * axis_len + r0) * inner;
+    const float id = r_identity<OP>();
+    const unsigned t = threadIdx.x;
+    if (t < T) {
+        v4f a0{id, id, id, id}, a1 = a0, a2 = a0, a3 = a0;
+        size_t v = t;
+        for (; v + 3 * (size_t)T < nvec; v += 4 * (size_t)T) {
+            const v4f x0 = __builtin_nontemporal_load((const v4f *)(p + v * 4));
+            const v4f x1 = __builtin_nontemporal_load((const v4f *)(p + (v + T) * 4));
+            const v4f x2 = __builtin_nontemporal_load((const v4f *)(p + (v + 2 * (size_t)T) * 4));
+            const v4f x3 = __builtin_nontemporal_load((const v4f *)(p + (v + 3 * (size_t)T) * 4));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a0[k] = r_combine<OP>(a0[k], x0[k]);
+                a1[k] = r_combine<OP>(a1[k], x1[k]);
+                a2[k] = r_combine<OP>(a2[k], x2[k]);
+                a3[k] = r_combine<OP>(a3[k], x3[k]);
+            }
+        }
+        if (v < nvec) {   // at most three vectors are left per lane: issued together
+            const bool h1 = v + T < nvec, h2 = v + 2 * (size_t)T < nvec;
+            const v4f x0 = __builtin_nontemporal_load((const v4f *)(p + v * 4));
+            v4f x1{id, id, id, id}, x2 = x1;
+            if (h1) x1 = __builtin_nontemporal_load((const v4f *)(p + (v + T) * 4));
+            if (h2) x2 = __builtin_nontemporal_load((const v4f *)(p + (v + 2 * (size_t)T) * 4));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a0[k] = r_combine<OP>(a0[k], x0[k]);
+                a1[k] = r_combine<OP>(a1[k], x1[k]);
+                a2[k] = r_combine<OP>(a2[k], x2[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds[4 * t + k] = r_combine<OP>(r_combine<OP>(a0[k], a1[k]), r_combine<OP>(a2[k], a3[k]));
+    }
+    __syncthreads();
+    // entry e = m * inner + c (m < 4 T / inner) belongs to column c: halve the m range until one entry per column is left
+    for (unsigned mcur = 4 * T / (unsigned)inner; mcur > 1;) {
+        const unsigned half = (mcur + 1) / 2;
+        for (unsigned idx = t; idx < (mcur - half) * (unsigned)inner; idx += 256) lds[idx] = r_combine<OP>(lds[idx], lds[idx + half * (unsigned)inner]);
+        __syncthreads();
+        mcur = half;
+    }
+    if (t < (unsigned)inner) {
+        float r = lds[t];
+        for (size_t e = 4 * nvec; e < cnt; ++e)                 // the <= 3 leftover elements of the slab
+            if (e % inner == t) r = r_combine<OP>(r, p[e]);
+        out[((size_t)o * gridDim.x + b) * inner + t] = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // axis reduction, inner == 1: "row" reduce.  LPR lanes cooperate on one row (LPR = 64: one wave
 // per row; 256: one workgroup per row), reading the row with coalesced accesses.
@@ -1451,12 +1517,19 @@ int launch_reduce_axis(const float *in, size_t outer, size_t axis_len, size_t in
         const size_t max_blocks = axis_len / 256;
         if (blocks > max_blocks) blocks = max_blocks;
         if (blocks < 1) blocks = 1;
-        const size_t rows_per_block = (axis_len + blocks - 1) / blocks;
+        size_t rows_per_block = (axis_len + blocks - 1) / blocks;
+        // slabs that start on 16-byte boundaries: the float4 walk (np_reduce_set_variant(4300001): the dword walk, A/B)
+        const bool v4 = !g_small_inner_dword && ((uintptr_t)in & 15u) == 0 && (outer == 1 || (axis_len * inner) % 4 == 0);
+        if (v4) rows_per_block = (rows_per_block + 3) / 4 * 4;
         blocks = (axis_len + rows_per_block - 1) / rows_per_block;
         np::Scratch partials;
         if (int rc = partials.alloc(outer * blocks * inner * sizeof(float))) return rc;
-        reduce_small_inner<P1, I><<<dim3((unsigned)blocks, (unsigned)outer), 256, 0, s>>>(
-            in, (float *)partials.ptr, (I)axis_len, (I)inner, (I)rows_per_block);
+        if (v4)
+            reduce_small_inner_v4<P1, I><<<dim3((unsigned)blocks, (unsigned)outer), 256, 0, s>>>(
+                in, (float *)partials.ptr, (I)axis_len, (I)inner, (I)rows_per_block);
+        else
+            reduce_small_inner<P1, I><<<dim3((unsigned)blocks, (unsigned)outer), 256, 0, s>>>(
+                in, (float *)partials.ptr, (I)axis_len, (I)inner, (I)rows_per_block);
         NP_LAUNCH_CHECK("reduce_small_inner");
         return launch_reduce_axis<OP, I>((const float *)partials.ptr, outer, blocks, inner, out, flags, mean_div);
     }
@@ -2289,6 +2362,10 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
 int np_reduce_set_variant(int variant) {
     if (variant >= 2000000 && variant < 2100000) {   // the largest first-pass grid that folds its partials in-kernel
         np::g_fold_in_kernel_max = (size_t)(variant - 2000000);
+        return NP_OK;
+    }
+    if (variant == 4300000 || variant == 4300001) {   // column sums over a few columns: float4 walk (0) or dword walk (1)
+        g_small_inner_dword = variant - 4300000;
         return NP_OK;
     }
     if (variant == 4200000 || variant == 4200001) {   // argmax / argmin over wide unaligned rows: tiles dealt to the XCDs in runs (0) or in launch order (1)
