@@ -60,7 +60,7 @@ template <int TR, int TC, bool VEC>
 __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__restrict__ in,
                                                              float *__restrict__ out, unsigned rows,
                                                              unsigned cols, unsigned tiles_x,
-                                                             unsigned tiles_y, PlaneBatch pb) {
+                                                             unsigned tiles_y, PlaneBatch pb, unsigned order = 0) {
     // a TR x TC tile of the input (TR rows, TC columns) becomes a TC x TR tile of the output
     constexpr int LDT = TR + 1;           // tile[c][r]
     constexpr int C4 = TC / 4;            // float4 columns per input tile row
@@ -80,8 +80,15 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const float *__rest
     // neighbouring column blocks AND write different column offsets of the output, instead of all
     // writing segments a power-of-two stride apart (HBM channel camping on 8192 x 8192 etc.)
     // (the grid is linear in x: a 10^7 x 3 matrix has more tile rows than gridDim.y allows)
-    const unsigned bx = blockIdx.x % tiles_x;
-    const unsigned by = (blockIdx.x / tiles_x + bx) % tiles_y;
+    // order 1 (round 6; rows that are not whole lines share a line with the neighbouring tile at each end of a segment): the same
+    // walk dealt to the XCDs in eight contiguous runs, as in transpose_walign_kernel below
+    unsigned unit = blockIdx.x;
+    if (order) {
+        const unsigned W = tiles_x * tiles_y, q = W / 8, r = W % 8, xcd = unit % 8, idx = unit / 8;
+        unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const unsigned bx = unit % tiles_x;
+    const unsigned by = (unit / tiles_x + bx) % tiles_y;
     const unsigned r0 = by * TR, c0 = bx * TC;
     const unsigned tx4 = threadIdx.x % C4, ty = threadIdx.x / C4;
 
@@ -531,6 +538,7 @@ __global__ __launch_bounds__(256) void arange_kernel(float *__restrict__ out, co
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 int g_tile = 0;   // 0 = default, else 64 / 128 (np_layout_set_variant)
+int g_tile_order = -1;   // transpose_tile_kernel's tile order: -1 = by alignment, 0 = launch order, 1 = XCD runs (np_layout_set_variant(17010 + k), 17013 = by alignment)
 // Write-aligned transposes with fewer 128 x 128 tiles than this take 64 x 64 tiles (0 = never; np_layout_set_variant(7000 + N) sets it): at two
 // workgroups of 67 KB LDS per CU, 1089 tiles (4099^2) are 2.1 resident rounds and a third of the last one idles; 4225 small tiles at eight
 // per CU end more evenly — 4099^2 4.80 -> 5.07 TB/s, 5000 x 4099 (1320 tiles) +1 %; from ~2000 tiles up the small tiles LOSE (8191 x 8193 -2 %,
@@ -564,12 +572,16 @@ int launch_transpose(const float *in, float *out, size_t batch, size_t rows, siz
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
+    // (the XCD runs that help the write-aligned kernel do NOT help here — input rows off the line grid, output rows on it: 8000 x 8001
+    //  4.24 -> 4.35 TB/s, 4096 x 4099 5.12 -> 4.49, 8192 x 10001 / 16000 x 5001 / 3200 x 30001 -1 %, profiles/r06/tile_order_ab.log —
+    //  so the launch order stays; np_layout_set_variant(17011) forces the runs for A/B)
+    const unsigned order = g_tile_order > 0 ? 1u : 0u;
     if (vec)
         transpose_tile_kernel<TR, TC, true><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols,
-                                                                             (unsigned)tiles_x, (unsigned)tiles_y, pb);
+                                                                             (unsigned)tiles_x, (unsigned)tiles_y, pb, order);
     else
         transpose_tile_kernel<TR, TC, false><<<grid, 256, lds, np::stream()>>>(in, out, (unsigned)rows, (unsigned)cols,
-                                                                              (unsigned)tiles_x, (unsigned)tiles_y, pb);
+                                                                              (unsigned)tiles_x, (unsigned)tiles_y, pb, order);
     NP_LAUNCH_CHECK("transpose_tile_kernel");
     return NP_OK;
 }
@@ -656,6 +668,10 @@ extern "C" {
 int np_layout_set_variant(int variant) {
     if (variant >= 7000 && variant < 17000) {
         g_walign64_below_tiles = (size_t)(variant - 7000);
+        return NP_OK;
+    }
+    if (variant >= 17010 && variant <= 17013) {
+        g_tile_order = variant == 17013 ? -1 : variant - 17010;
         return NP_OK;
     }
     if (variant >= 17000 && variant <= 17003) {   // write-aligned transposes: 0 = diagonal walk in launch order, 1 / 2 = dealt to the XCDs in runs, 3 = by size

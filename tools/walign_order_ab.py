@@ -17,11 +17,12 @@ host = src.to_host()
 for _ in range(200):
     check(lib.np_transpose2d(src.ptr, dst.ptr, 1, 8192, 8192))
 D.sync()
-for rows, cols in ((8191, 8193), (8196, 8192), (8190, 8194), (8193, 8191), (8000, 8001), (10001, 9999), (12345, 6789), (6001, 6003), (4099, 4099), (1500, 65536), (65536, 1500), (3000, 30001)):
+for rows, cols in ((8191, 8193), (8196, 8192), (8190, 8194), (8193, 8191), (8000, 8001), (4096, 4099), (8192, 10001), (16000, 5001), (3200, 30001), (10001, 9999), (12345, 6789), (6001, 6003), (4099, 4099), (1500, 65536), (65536, 1500), (3000, 30001)):
     best = {}
     for rnd in range(6):
         for order in (0, 1, 2):
             check(lib.np_layout_set_variant(17000 + order))
+            check(lib.np_layout_set_variant(17010 + min(order, 1)))     # (the plain tile kernel knows orders 0 and 1)
             for _ in range(3):
                 check(lib.np_transpose2d(src.ptr, dst.ptr, 1, rows, cols))
             D.sync()
@@ -34,4 +35,5 @@ for rows, cols in ((8191, 8193), (8196, 8192), (8190, 8194), (8193, 8191), (8000
                 got = dst.to_host()[:rows * cols].reshape(cols, rows)
                 assert (got == host[:rows * cols].reshape(rows, cols).T).all(), (rows, cols, order)
     check(lib.np_layout_set_variant(17003))          # back to the default rule
+    check(lib.np_layout_set_variant(17013))
     print("  %6d x %-6d " % (rows, cols) + "  ".join("order %d %5.0f GB/s" % (o, 8.0 * rows * cols / best[o] / 1e6) for o in (0, 1, 2)), flush=True)
