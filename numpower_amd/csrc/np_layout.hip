@@ -420,6 +420,7 @@ struct PlanePermuteArgs {
     unsigned ta, tb, tiles_a, tiles_b;
     unsigned pitch;                 // LDS floats per a
     unsigned m_tbE, m_taE, m_E;     // floor(2^32 / d) + 1 for d = tb * E, ta * E, E (exact quotients below 2^12 ... 2^13)
+    unsigned xcd_runs;              // 1: tiles dealt to the XCDs in eight contiguous runs
     PlaneBatch pb;
 };
 // floats per tile.  16384-float tiles (a 100 x 100 plane as ONE tile, 67 KB of LDS, two workgroups per CU) were measured in
@@ -437,6 +438,10 @@ __global__ __launch_bounds__(256) void permute_plane_kernel(const float *__restr
     const T *in = (const T *)in_f;
     T *out = (T *)out_f;
     unsigned id = blockIdx.x;
+    if (p.xcd_runs) {   // neighbouring tiles (they share the lines at the ends of their runs) on ONE XCD: np_sgemm.hip's tile_coords bijection
+        const unsigned units = gridDim.x, q = units / 8, r = units % 8, xcd = id % 8, idx = id / 8;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const unsigned tb_i = id % p.tiles_b;
     id /= p.tiles_b;
     const unsigned ta_i = id % p.tiles_a;
@@ -538,6 +543,7 @@ __global__ __launch_bounds__(256) void arange_kernel(float *__restrict__ out, co
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
 int g_tile = 0;   // 0 = default, else 64 / 128 (np_layout_set_variant)
+int g_plane_order = -1;  // permute_plane_kernel: -1 = default, 0 = launch order, 1 = XCD runs (np_layout_set_variant(17020 + k), 17023 = default)
 int g_tile_order = -1;   // transpose_tile_kernel's tile order: -1 = by alignment, 0 = launch order, 1 = XCD runs (np_layout_set_variant(17010 + k), 17013 = by alignment)
 // Write-aligned transposes with fewer 128 x 128 tiles than this take 64 x 64 tiles (0 = never; np_layout_set_variant(7000 + N) sets it): at two
 // workgroups of 67 KB LDS per CU, 1089 tiles (4099^2) are 2.1 resident rounds and a third of the last one idles; 4225 small tiles at eight
@@ -668,6 +674,10 @@ extern "C" {
 int np_layout_set_variant(int variant) {
     if (variant >= 7000 && variant < 17000) {
         g_walign64_below_tiles = (size_t)(variant - 7000);
+        return NP_OK;
+    }
+    if (variant >= 17020 && variant <= 17023) {
+        g_plane_order = variant == 17023 ? -1 : variant - 17020;
         return NP_OK;
     }
     if (variant >= 17010 && variant <= 17013) {
@@ -895,6 +905,11 @@ int np_permute(const float *in, float *out, int ndim, const int *host_shape, con
             const size_t blocks = (size_t)p.tiles_a * p.tiles_b * batch;
             if (blocks <= 0x7fffffffu && (size_t)p.ta * p.pitch <= cap + pad && p.tb * E > 1 && p.ta * E > 1) {
                 const size_t lds = ((size_t)p.ta * p.pitch + 3) / 4 * 4 * sizeof(float) * (w4 ? 4 : 1);
+                // tiles dealt to the XCDs in runs (round 6) where elements are single floats or odd runs of them — neighbouring tiles then
+                // share the lines at the ends of their runs in ONE L2: (200, 33, 77, 41) -> (3, 1, 2, 0) 2.69 -> 3.40 TB/s, (1000, 1000, 5, 20)
+                // reversed 2.79 -> 2.91, 100^4 and (50, 60, 70, 80) unchanged; float4 elements (runs that ARE whole lines) lose 5-20 % that
+                // way and keep the launch order (profiles/r06/plane_order_ab.log)
+                p.xcd_runs = g_plane_order >= 0 ? (unsigned)g_plane_order : (w4 ? 0u : 1u);
                 if (w4)
                     permute_plane_kernel<4><<<(unsigned)blocks, 256, lds, np::stream()>>>(in, out, p);
                 else
