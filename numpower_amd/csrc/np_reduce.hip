@@ -322,10 +322,13 @@ __device__ __forceinline__ Mom mom_block_reduce(Mom a, Mom *lds) {
 template <bool COHERENT>
 __device__ __forceinline__ Mom mom_fold_partials(const float *partials, unsigned np, Mom *lds) {
     Mom f{0.0f, 0.0f, 0.0f, 0.0f};
-    for (unsigned base = 0; base < np; base += 4 * 256u) {
-        Mom v[4];
+    // nine partials per thread in flight: the 2049 of a 10^8-element pass are ONE trip (three dependent trips of four cost the
+    // one-workgroup fold ~3 us of memory round trips, of a 72 us call)
+    constexpr int UNR = 9;
+    for (unsigned base = 0; base < np; base += UNR * 256u) {
+        Mom v[UNR];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             const unsigned i = base + u * 256u + threadIdx.x;
             v[u] = Mom{0.0f, 0.0f, 0.0f, 0.0f};
             if (i < np) {
@@ -337,7 +340,7 @@ __device__ __forceinline__ Mom mom_fold_partials(const float *partials, unsigned
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) f = mom_merge(f, v[u]);
+        for (int u = 0; u < UNR; ++u) f = mom_merge(f, v[u]);
     }
     return mom_block_reduce(f, lds);
 }
