@@ -22,6 +22,10 @@
  * non-appender access to an array (any buffer_get, which is what fill / offsetSet / in-place methods go through) first
  * flushes the chains that read that array's buffer — through views too (the root of the `base` links is compared).
  *
+ * Threads: the table of pending chains and the appender-scope counter are process-wide, like the reference's MAIN_MEM_STACK
+ * (src/buffer.c:13; PHP NTS: one request = one thread) — not for concurrent appenders.  Readers that find nothing pending
+ * (NPH_OnFree / NPH_OnBufferGet with an empty table) touch one counter and return.
+ *
  * Scope (what numpower_amd/lazy.py defines): linear chains acc = f_k(... f_1(x)) of at most NPH_MAX_OPS unary / binary
  * steps over at most NPH_MAX_INPUTS arrays; a binary step takes another GPU array of the chain's shape, a smaller one that
  * broadcasts onto it (row vector, column, 0-d) or a number.  Anything else — an operand that is itself pending (it is
