@@ -89,6 +89,12 @@ section("add_row_broadcast")
 for _ in range(iters): D.binary("add", a, "full", row, "row", 25000, 4000, out=o)
 section("add_col_broadcast")
 for _ in range(iters): D.binary("add", a, "full", col, "col", 25000, 4000, out=o)
+# C3c as BASELINE.json words it: exp(X) + r in ONE pass through the fused chain (bench.py: exp_plus_row_fused / exp_plus_col_fused)
+prog2 = (FusedOp * 2)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0), FusedOp(1, BINARY_OPS["add"], 1, 0, 0, 0, 0, 0))
+for label, dvec, kind in (("row", row, 2), ("col", col, 3)):
+    ptrs2 = (C.c_void_p * 2)(a.ptr, dvec.ptr); kinds2 = (C.c_int * 2)(0, kind)
+    section("exp_plus_%s_fused" % label)
+    for _ in range(iters): check(lib.np_fused_chain(ptrs2, kinds2, 2, prog2, 2, o.ptr, 25000, 4000))
 section("sum_1e8")
 for _ in range(iters): D.reduce_all("sum", a)
 flag = C.c_int(0)
