@@ -26,6 +26,16 @@ from ._lib import BINARY_OPS, UNARY_OPS
 
 CPU, GPU = 0, 1
 
+# NP_LAZY_BINDING=1 (or NDArray.set_lazy_binding(True)): this stand-in then behaves like a `--with-hip` tree with INTEGRATION.md 2c
+# applied — the arithmetic operators / static arithmetic methods / unary methods call the appenders of ext/hip_lazy.c
+# (NPH_LazyBinary, NPH_LazyElementWise*), the full reductions NPH_ReduceAll, and EVERY other use of an array's pointer goes through
+# the marshalling point (`_p` = buffer_get: NPH_OnBufferGet computes pending values first).  Off by default: the mirror is then the
+# 2a + 2b tree (one launch per op) and `$a->lazy()` (numpower_amd/lazy.py) is the explicit form.  Running the whole GPU suite with
+# the switch on is the flush-set test of the mirror: every method that is not an appender must see finished values.
+import os as _os
+_LAZY_BINDING = _os.environ.get("NP_LAZY_BINDING") == "1"
+_LAZY_ARITH = ("add", "subtract", "multiply", "divide", "mod", "pow")
+
 
 class Error(RuntimeError):
     """PHP `Error` thrown by zend_throw_error in the reference."""
@@ -146,6 +156,16 @@ def _load_host():
     for name in ("NDArray_VSTACK", "NDArray_HSTACK", "NDArray_DSTACK", "NDArray_ColumnStack"):
         sig[name] = (_P, [C.POINTER(_P), C.c_int])
     sig["NDArray_Slice"] = (_P, [_P, C.POINTER(_P), C.c_int])
+    # ext/hip_lazy.c
+    sig["NPH_LazyBinary"] = (_P, [C.c_int, C.c_void_p, _P, _P])
+    sig["NPH_LazyElementWise"] = (_P, [_P, C.c_void_p])
+    sig["NPH_LazyElementWise1F"] = (_P, [_P, C.c_void_p, C.c_float])
+    sig["NPH_LazyElementWise2F"] = (_P, [_P, C.c_void_p, C.c_float, C.c_float])
+    sig["NPH_ReduceAll"] = (C.c_float, [C.c_int, C.c_void_p, _P])
+    sig["NPH_OnBufferGet"] = (None, [_P])
+    sig["NPH_Flush"] = (C.c_int, [_P])
+    sig["NPH_IsPending"] = (C.c_int, [_P])
+    sig["NPH_PendingCount"] = (C.c_int, [])
     for name, (res, args) in sig.items():
         fn = getattr(h, name)
         fn.restype = res
@@ -190,19 +210,39 @@ class NDArray:
     MAIN_MEM_STACK instead, buffer.c:91-120; the ownership rules are the same: the object's
     destructor calls NDArray_FREE, views keep their base alive through the refcount)."""
 
-    __slots__ = ("_p", "_h")
+    __slots__ = ("_ptr", "_h")
 
     def __init__(self, ptr):
         self._h = _load_host()
         if not ptr:
             _raise_pending(self._h)
-        self._p = ptr
+        self._ptr = ptr
+
+    @property
+    def _p(self):
+        """The marshalling point (ZVAL_TO_NDARRAY -> buffer_get, numpower.c:105, src/buffer.c:80): with the lazy binding on, a pending
+        value is computed here, and so are the chains that read this array (the consumer may write it).  Appenders use _ptr."""
+        p = self._ptr
+        if _LAZY_BINDING and p:
+            self._h.NPH_OnBufferGet(p)
+            if self._h.numpower_host_last_error():
+                _raise_pending(self._h)
+        return p
+
+    @_p.setter
+    def _p(self, value):
+        self._ptr = value
+
+    @staticmethod
+    def set_lazy_binding(on: bool):
+        global _LAZY_BINDING
+        _LAZY_BINDING = bool(on)
 
     def __del__(self):
         try:
-            if self._p:
-                self._h.NDArray_FREE(self._p)
-                self._p = None
+            if self._ptr:
+                self._h.NDArray_FREE(self._ptr)      # ndarray_destructor -> buffer_ndarray_free: no flush on the way out
+                self._ptr = None
         except Exception:
             pass
 
@@ -323,6 +363,8 @@ class NDArray:
         h = _load_host()
         x, _tx = NDArray._coerce(a)
         y, _ty = NDArray._coerce(b)
+        if _LAZY_BINDING and name in _LAZY_ARITH:     # ndarray_do_operation_ex / PHP_METHOD(add ...) as section 2c edits them
+            return NDArray._wrap(h.NPH_LazyBinary(BINARY_OPS[name], _fn(h, _BINARY_FN[name]), x._ptr, y._ptr))
         return NDArray._wrap(getattr(h, _BINARY_FN[name])(x._p, y._p))
 
     add = staticmethod(lambda a, b: NDArray._binary("add", a, b))
@@ -388,18 +430,24 @@ class NDArray:
             return NDArray._wrap(h.NDArray_Exp2(x._p))
         if name == "abs":     # PHP_METHOD(NDArray, abs) calls NDArray_Abs (numpower.c:1619)
             return NDArray._wrap(h.NDArray_Abs(x._p))
+        if _LAZY_BINDING and x._ptr.contents.device == GPU:      # the method's device branch, as section 2c edits it
+            return NDArray._wrap(h.NPH_LazyElementWise(x._ptr, _fn(h, "cuda_float_" + name)))
         return NDArray._wrap(h.NDArrayMathGPU_ElementWise(x._p, _fn(h, "cuda_float_" + name)))
 
     @staticmethod
     def clip(a, min, max):
         h = _load_host()
         x, _ = NDArray._coerce(a)
+        if _LAZY_BINDING and x._ptr.contents.device == GPU:
+            return NDArray._wrap(h.NPH_LazyElementWise2F(x._ptr, _fn(h, "cuda_float_clip"), float(min), float(max)))
         return NDArray._wrap(h.NDArrayMathGPU_ElementWise2F(x._p, _fn(h, "cuda_float_clip"), float(min), float(max)))
 
     @staticmethod
     def round(a, precision=0):
         h = _load_host()
         x, _ = NDArray._coerce(a)
+        if _LAZY_BINDING and x._ptr.contents.device == GPU:
+            return NDArray._wrap(h.NPH_LazyElementWise1F(x._ptr, _fn(h, "cuda_float_round"), float(precision)))
         return NDArray._wrap(h.NDArrayMathGPU_ElementWise1F(x._p, _fn(h, "cuda_float_round"), float(precision)))
 
     # ---- reductions -----------------------------------------------------------------------------------
@@ -411,7 +459,11 @@ class NDArray:
             fn = {"sum": h.NDArray_Sum_Float, "prod": h.NDArray_Float_Prod, "min": h.NDArray_Min,
                   "max": h.NDArray_Max}[op]
             h.numpower_host_clear_error()
-            v = fn(x._p)
+            if _LAZY_BINDING:     # PHP_METHOD(sum ...) as section 2c edits it: a pending operand is reduced inside its chain's kernel
+                from ._lib import REDUCE_OPS
+                v = h.NPH_ReduceAll(REDUCE_OPS[op], C.cast(fn, C.c_void_p), x._ptr)
+            else:
+                v = fn(x._p)
             if h.numpower_host_last_error():
                 _raise_pending(h)
             return float(v)
