@@ -399,3 +399,30 @@ def test_order_stat_beyond_2p31_elements(hip):
     finally:
         _lib.check(lib.np_select_set_variant(1))
         chunk.free(); big.free()
+
+
+def test_moments_beyond_2p31_elements(hip):
+    """np_moments / np_weighted_sums on more than 2^31 elements (the reference's `int` loop counters stop there, statistics.c:98):
+    a constant array with a thousand outliers across the 2^31 line has its mean and its sum of squared deviations in closed form."""
+    import ctypes as C
+    from numpower_amd._lib import check, load
+    lib = load()
+    D = hip
+    n = (1 << 31) + 4096
+    a = D.DeviceArray((n,))
+    D.fill(a, 1.0)
+    k = 1000
+    D.fill(a.view((1 << 31) - 500, (k,)), 3.0)              # 500 on either side of element 2^31
+    mean, m2 = C.c_float(), C.c_float()
+    check(lib.np_moments(a.ptr, n, C.byref(mean), C.byref(m2)))
+    mu = 1.0 + 2.0 * k / n
+    want_m2 = (n - k) * (mu - 1.0) ** 2 + k * (3.0 - mu) ** 2
+    assert abs(mean.value - mu) <= 1e-6 * mu
+    assert abs(m2.value - want_m2) <= 1e-5 * want_m2, (m2.value, want_m2)
+    w = D.DeviceArray((n,))
+    D.fill(w, 0.5)
+    saw, sw = C.c_float(), C.c_float()
+    check(lib.np_weighted_sums(a.ptr, w.ptr, n, C.byref(saw), C.byref(sw)))
+    assert abs(sw.value - 0.5 * n) <= 1e-5 * 0.5 * n and abs(saw.value - 0.5 * (n + 2.0 * k)) <= 1e-5 * 0.5 * n
+    for d in (a, w):
+        d.free()
