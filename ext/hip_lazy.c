@@ -73,6 +73,12 @@ static void raise(const char *fmt, int i) {
     np_ext_throw(msg);
 }
 
+void NPH_RequestInit(void) {
+    memset(g_chain, 0, sizeof g_chain);      /* (the arrays these named belonged to a request that is over: not touched) */
+    g_pending = 0;
+    nph_marshal_lazy = 0;
+}
+
 int NPH_IsPending(const NDArray *a) { return find_chain(a) != NULL; }
 int NPH_PendingCount(void) { return g_pending; }
 void NPH_SetLazy(int on) { g_lazy_on = on != 0; }

@@ -100,6 +100,11 @@ int NPH_ChainReduceAxisInto(struct NDArray *array, int axis, int reduce_op, stru
 struct NPH_ChainCall;
 int NPH_ChainAxisView(const struct NDArray *first, int axis, const struct NPH_ChainCall *call, size_t *rows, size_t *cols, int *ax);
 
+/* PHP_RINIT (numpower.c:5250, next to buffer_init): a request starts with no pending chain and with the appender scope closed,
+ * whatever the previous request of this process left behind — a fatal error inside ZVAL_TO_NDARRAY (memory limit) bails out with
+ * longjmp past NPH_LAZY_MARSHAL_END, and Zend has by then released every array the table still names.  Nothing is dereferenced. */
+void NPH_RequestInit(void);
+
 /* 0 = values are there (or were computed now), -1 = an error was raised */
 int NPH_Flush(struct NDArray *a);
 int NPH_IsPending(const struct NDArray *a);

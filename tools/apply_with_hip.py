@@ -328,6 +328,10 @@ EDITS = [
          "/* numpower_amd 2c: the last reference to an array whose values were never asked for drops its chain (and the\n"
          " * references the chain holds on its inputs) — no kernel ever ran for it */\n"
          "NPH_OnFree(array);", after=True),
+    Edit("numpower.c", "numpower.c:5250 PHP_RINIT: no pending chain, appender scope closed",
+         r"^(?P<old>[ \t]*buffer_init\(2\);)$",
+         "/* numpower_amd 2c: whatever the previous request of this process left behind (a bailout inside an appender's lookup) */\n"
+         "NPH_RequestInit();", after=True),
     # the appenders look their operands up without flushing them
     Edit("numpower.c", "numpower.c:194-195 ndarray_do_operation_ex: operands looked up as an appender",
          r"^(?P<old>[ \t]*NDArray \*nda = ZVAL_TO_NDARRAY\(op1\);\n[ \t]*NDArray \*ndb = ZVAL_TO_NDARRAY\(op2\);)$",
@@ -423,6 +427,7 @@ CONTEXTS.update({
     "buffer.c:80-81 buffer_get: the flush point of pending chains": "struct { NDArray **buffer; } MAIN_MEM_STACK = {0}; int uuid = 0;",
     "ndarray.c:588-591 NDArray_FREE: a pending array that dies releases its chain": "NDArray *array = 0;",
     "numpower.c:194-195 ndarray_do_operation_ex: operands looked up as an appender": "zval *op1 = 0, *op2 = 0;",
+    "numpower.c:5250 PHP_RINIT: no pending chain, appender scope closed": " ",
     "numpower.c:3374-3540 PHP_METHOD(add ... pow): operands looked up as an appender": "zval *a = 0, *b = 0;",
     "numpower.c:1608-3357 the unary PHP_METHODs: operand looked up as an appender": "zval *array = 0;",
     "numpower.c:1651-3348 `rtn = NDArrayMathGPU_ElementWise{,1F,2F}(nda, cuda_float_*)`: append to the pending chain":
@@ -825,7 +830,9 @@ def lazy_program_source() -> str:
           "#ifdef HAVE_NP_HIP", _indent(marshal_mean.new, "    "), "#endif",
           "    if (nda == NULL) {", "        return -1.0;", "    }",
           "#ifdef HAVE_NP_HIP", _indent(mean_call.new, "    "), "#endif", "}", ""]
-    o.append(_LAZY_PROGRAM_MAIN)
+    rinit = _edit("numpower.c:5250 PHP_RINIT")
+    o.append(_LAZY_PROGRAM_MAIN.replace("    @RINIT@", "    nph_marshal_lazy = 7;   /* as a request that bailed out inside an appender's lookup leaves it */\n" +
+                                        _indent(rinit.new, "    ")))
     return "\n".join(o)
 
 
@@ -1064,6 +1071,7 @@ int main(int argc, char **argv) {
         perror(argv[2]);
         return 2;
     }
+    @RINIT@
     const int rows = 257, cols = 255;                        /* AVX2 body + ragged tail */
     const int s2[2] = {rows, cols}, s1[1] = {cols}, scol[2] = {rows, 1};
     Env e;
