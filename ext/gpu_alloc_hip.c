@@ -34,7 +34,7 @@ void vmalloc(void **target, unsigned int size) {
 /* gpu_alloc.c:30-33 */
 void vfree(void *target) {
     np_ext_count_device_alloc(-1);
-    if (np_free(target) != NP_OK) np_ext_throw(np_last_error());
+    if (np_free(target) != NP_OK) np_ext_throw_last();
 }
 
 /* gpu_alloc.c:36-40 (NDARRAY_VCHECK at request shutdown) */
@@ -45,22 +45,22 @@ void vmemcheck(void) {
 
 /* gpu_alloc.c:20-27.  NOTE the reference's argument order: (source, destination, bytes). */
 void vmemcpyd2d(char *target, char *dst, unsigned int size) {
-    if (np_memcpy_d2d(dst, target, (size_t)size) != NP_OK) np_ext_throw(np_last_error());
+    if (np_memcpy_d2d(dst, target, (size_t)size) != NP_OK) np_ext_throw_last();
 }
 
 void vmemcpyh2d(char *target, char *dst, unsigned int size) {
-    if (np_memcpy_h2d(dst, target, (size_t)size) != NP_OK) np_ext_throw(np_last_error());
+    if (np_memcpy_h2d(dst, target, (size_t)size) != NP_OK) np_ext_throw_last();
 }
 
 /* gpu_alloc.c:43-54: one float back to the host (blocks). */
 float NDArray_VFLOAT(char *target) {
     float value = 0.0f;
-    if (np_read_float((const float *)target, 0, &value) != NP_OK) np_ext_throw(np_last_error());
+    if (np_read_float((const float *)target, 0, &value) != NP_OK) np_ext_throw_last();
     return value;
 }
 
 float NDArray_VFLOATF_I(float *target, int index) {
     float value = 0.0f;
-    if (np_read_float(target, (size_t)index, &value) != NP_OK) np_ext_throw(np_last_error());
+    if (np_read_float(target, (size_t)index, &value) != NP_OK) np_ext_throw_last();
     return value;
 }

@@ -131,7 +131,7 @@ NDArray *NPH_Binary_Float(int op, NDArray *a, NDArray *b) {
     const size_t body_end = quirk_ops ? np_avx_body_end(loop_numel_a) : 0;
     if (np_binary(op, NDArray_FDATA(a), ak, NDArray_FDATA(b), bk, NDArray_FDATA(result), rows, cols, flags,
                   body_end) != NP_OK) {
-        np_ext_throw(np_last_error());
+        np_ext_throw_last();
         NDArray_FREE(result);
         return NULL;
     }
@@ -165,7 +165,7 @@ int NPH_ReduceAxisInto(NDArray *array, int axis, int reduce_op, unsigned flags, 
     if (reduce_op != NP_PROD || nd - axis - 1 < 1) flags &= ~(unsigned) NP_QUIRK_AVX_BODY;
     if (np_reduce_axis(reduce_op, NDArray_FDATA(array), outer, (size_t) NDArray_SHAPE(array)[axis], inner,
                        NDArray_FDATA(rtn), flags) != NP_OK) {
-        np_ext_throw(np_last_error());
+        np_ext_throw_last();
         return -1;
     }
     return 0;

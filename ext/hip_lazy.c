@@ -213,7 +213,7 @@ int NPH_Flush(NDArray *a) {
             st = np_fused_chain(call.ptrs, call.kinds, c->n_inputs, call.prog, c->n_ops, out, call.rows, call.cols);
         }
         if (st != NP_OK) {
-            np_ext_throw(np_last_error());
+            np_ext_throw_last();
             rc = -1;
         } else {
             g_stats.flushed_chains++;
@@ -236,7 +236,7 @@ float NPH_ReduceAll(int reduce_op, NPH_EagerReduce eager, NDArray *a) {
     float v = -1.0f;
     if (NPH_PrepareChain(c->inputs, c->scalars, c->n_inputs, c->ops, c->n_ops, &call) != 0) return -1.0f;
     if (np_fused_chain_reduce(call.ptrs, call.kinds, c->n_inputs, call.prog, c->n_ops, reduce_op, call.rows, call.cols, &v) != NP_OK) {
-        np_ext_throw(np_last_error());
+        np_ext_throw_last();
         return -1.0f;
     }
     g_stats.fused_reductions++;
@@ -276,7 +276,7 @@ int NPH_ChainReduceAxisInto(NDArray *array, int axis, int reduce_op, NDArray *rt
     if ((size_t) NDArray_NUMELEMENTS(rtn) != (ax == 1 ? rows : cols)) return 0;
     if (np_fused_chain_reduce_axis(call.ptrs, call.kinds, c->n_inputs, call.prog, c->n_ops, reduce_op, rows, cols, ax,
                                    NDArray_FDATA(rtn)) != NP_OK) {
-        np_ext_throw(np_last_error());
+        np_ext_throw_last();
         return -1;
     }
     g_stats.fused_reductions++;

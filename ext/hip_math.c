@@ -26,7 +26,7 @@
 #include "np_hip.h"
 
 static void raise_if(int rc) {
-    if (rc != NP_OK) np_ext_throw(np_last_error());
+    if (rc != NP_OK) np_ext_throw_last();
 }
 
 static size_t count(int n) { return n > 0 ? (size_t)n : 0; }

@@ -56,7 +56,7 @@ static NDArray *unary_out_of_place(NDArray *in, int code, float p0, float p1) {
     NDArray *out = NDArray_EmptyLike(in);
     if (out == NULL) return NULL;
     if (np_unary(code, NDArray_FDATA(in), NDArray_FDATA(out), (size_t)NDArray_NUMELEMENTS(in), p0, p1) != NP_OK) {
-        np_ext_throw(np_last_error());
+        np_ext_throw_last();
         NDArray_FREE(out);
         return NULL;
     }
@@ -108,7 +108,7 @@ NDArray *NDArrayMathGPU_ElementWise1N(NDArray *ndarray, ElementWiseFloatGPUOpera
     if (out == NULL) return NULL;
     if (np_binary(code, NDArray_FDATA(ndarray), NP_FULL, NDArray_FDATA(val1), NP_FULL, NDArray_FDATA(out), 1,
                   (size_t)NDArray_NUMELEMENTS(ndarray), 0, 0) != NP_OK) {
-        np_ext_throw(np_last_error());
+        np_ext_throw_last();
         NDArray_FREE(out);
         return NULL;
     }

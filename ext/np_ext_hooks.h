@@ -23,6 +23,17 @@ void np_ext_throw(const char *message);
 /* +1 on vmalloc, -1 on vfree; returns the new count (what vmemcheck reports). */
 int np_ext_count_device_alloc(int delta);
 
+/* Raise the C ABI's last error through the host and ACKNOWLEDGE a device error while doing so (np_hip.h: device errors are sticky
+ * until np_clear_device_error()).  For a binding the raised exception IS the report; an error word nobody acknowledges would fail
+ * every later sync point of the process — a php-fpm worker poisoned by one request.  (np_clear_device_error waits for the device
+ * and costs nothing when no error is up.) */
+const char *np_last_error(void);
+int np_clear_device_error(unsigned *host_bits);
+static inline void np_ext_throw_last(void) {
+    np_ext_throw(np_last_error());
+    (void) np_clear_device_error((unsigned *) 0);
+}
+
 #ifdef __cplusplus
 }
 #endif

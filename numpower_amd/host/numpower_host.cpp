@@ -53,6 +53,7 @@ void throw_error(const char *fmt, ...) {
 bool dev_ok(int rc) {
     if (rc == NP_OK) return true;
     throw_error("%s", np_last_error());
+    (void)np_clear_device_error(nullptr);   // the raised error IS the report: a sticky device error is acknowledged with it (np_ext_hooks.h)
     return false;
 }
 

@@ -91,3 +91,21 @@ def test_device_error_is_sticky_per_device_and_needs_an_acknowledgement():
     assert lib.np_sync() == 0
     assert (back == x).all() and out.value == float(x.sum())
     assert lib.np_free(dev) == 0
+
+
+def test_the_binding_reports_a_device_error_as_its_exception_and_acknowledges_it(hip):
+    """At the C ABI a device error is sticky until np_clear_device_error() (above).  A BINDING reports it the way it reports every
+    failed call — an exception (zend_throw_error; `Error` in the stand-in) — and acknowledges it with that report
+    (ext/np_ext_hooks.h np_ext_throw_last, dev_ok of the host library): one failed call per error, not a poisoned process."""
+    from numpower_amd._lib import load
+    from numpower_amd.ndarray import Error, NDArray
+    lib = load()
+    assert lib.np_clear_device_error(None) == 0
+    x = np.arange(4096, dtype=np.float32)
+    g = NDArray.array(x).gpu()
+    assert NDArray.sum(g) == float(x.sum())
+    assert lib.np_debug_raise_device_error(2) == 0
+    with pytest.raises(Error, match="device-side wait gave up"):
+        NDArray.sum(g)                                        # the report ...
+    assert NDArray.sum(g) == float(x.sum())                   # ... was the acknowledgement: the next call is a normal call
+    assert lib.np_sync() == 0
