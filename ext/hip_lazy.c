@@ -418,10 +418,9 @@ NDArray *NPH_LazyBinary(int op, NPH_EagerBinary eager, NDArray *a, NDArray *b) {
     if (a == NULL || b == NULL || eager == NULL) return NULL;
     if (!NPH_TAKES(a, b)) return eager(a, b);              /* CPU operands: the reference's own code, nothing pending */
     const int pa = find_chain(a) != NULL, pb = find_chain(b) != NULL;
-    /* pow stays a launch of its own: np_binary's pow (log2 table in registers, four elements at a time) and the chain
-     * interpreter's are two <= 1 ulp implementations that differ in the last bit here and there, and an expression must
-     * not change its value with the way it happens to be evaluated */
-    if (g_lazy_on && op != NP_POW) {
+    /* pow is a step like the others: the chain runs np_binary's arithmetic for it, `** 2` with a PHP number included
+     * (x * x in both, np_elementwise.hip) — an expression must not change its value with the way it is evaluated */
+    if (g_lazy_on) {
         NDArray *head = NULL, *other = NULL;
         int swap = 0;
         if (pa || (!pb && is_gpu_array(a) && (NDArray_NDIM(b) == 0 || NDArray_NUMELEMENTS(b) <= NDArray_NUMELEMENTS(a)))) {

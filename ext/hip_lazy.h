@@ -29,9 +29,9 @@
  * Scope (what numpower_amd/lazy.py defines): linear chains acc = f_k(... f_1(x)) of at most NPH_MAX_OPS unary / binary
  * steps over at most NPH_MAX_INPUTS arrays; a binary step takes another GPU array of the chain's shape, a smaller one that
  * broadcasts onto it (row vector, column, 0-d) or a number.  Anything else — an operand that is itself pending (it is
- * flushed first and joins as an array), a chain that is full, an operand that would have to grow the chain's shape, pow
- * (whose stand-alone kernel and chain step are two <= 1 ulp implementations: a value must not depend on how it came to be
- * evaluated), CPU operands — takes the eager path of section 2b unchanged.
+ * flushed first and joins as an array), a chain that is full, an operand that would have to grow the chain's shape,
+ * CPU operands — takes the eager path of section 2b unchanged.  Every step, pow and `** 2` included, runs the arithmetic of
+ * its stand-alone kernel: a value does not depend on how it came to be evaluated.
  */
 #ifndef NUMPOWER_AMD_EXT_HIP_LAZY_H
 #define NUMPOWER_AMD_EXT_HIP_LAZY_H

@@ -207,8 +207,8 @@ int np_unary(int op, const float *in, float *out, size_t n, float p0, float p1);
  *     out[i] = acc
  * e.g. nd::exp($a) * $b + 2 costs 12 B/elem instead of 8 + 12 + 8 = 28 B/elem and two temporaries
  * (one allocation + one full round trip per PHP-level op in the reference, numpower.c:193-229).
- * Every step runs the same arithmetic as np_unary / np_binary, so the result is bit-identical to
- * the unfused sequence; flags/body_end have the meaning they have in np_binary.  The result is
+ * Every step runs the same arithmetic as np_unary / np_binary (`value ** 2.0f` with a host scalar is
+ * the product x * x in both), so the result is bit-identical to the unfused sequence; flags/body_end have the meaning they have in np_binary.  The result is
  * rows x cols; inputs[0] is NP_FULL (rows*cols elements) or NP_HOST_SCALAR, the other inputs have
  * any np_operand_kind: NP_FULL, NP_ROW (cols floats, added to every row), NP_COL (rows floats, one
  * per row), NP_SCALAR (device 0-d) or NP_HOST_SCALAR — the broadcast cases of ndarray.c:1196-1291

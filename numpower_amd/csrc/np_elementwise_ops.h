@@ -358,6 +358,10 @@ __device__ __forceinline__ float fast_atanh(float x) {
     return copysignf(0.5f * fast_log1p<false>((2.0f * a) / (1.0f - a)), x);
 }
 
+// Not an op of the C ABI: what a chain runs for the step `value ** 2.0f` (np_fused_chain maps it), because np_binary computes
+// `$a ** 2` as the correctly rounded x * x and a chain must return the bits of the op-by-op sequence.
+constexpr int NP_UNARY_SQUARE = NP_UNARY_OP_COUNT;
+
 template <int OP>
 __device__ __forceinline__ float unary_apply(float x, float p0, float p1) {
     if constexpr (OP == NP_ABS) return fabsf(x);
@@ -418,6 +422,7 @@ __device__ __forceinline__ float unary_apply(float x, float p0, float p1) {
     }
     if constexpr (OP == NP_POSITIVE) return (x < 0.0f) ? -x : x;   // double_math.c:241-244
     if constexpr (OP == NP_RECIPROCAL) return __fdiv_rn(1.0f, x);
+    if constexpr (OP == NP_UNARY_SQUARE) return x * x;
     return 0.0f;
 }
 

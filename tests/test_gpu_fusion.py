@@ -337,3 +337,44 @@ def test_chains_are_persistent_values(hip):
         ref = ref + b
     assert _same(p.eval().cpu().numpy(), ref * np.float32(3.0)) and _same(q.eval().cpu().numpy(), ref - np.float32(1.0))
     assert len(long.ops) == 12 and len(p.ops) == 1 and len(q.ops) == 1
+
+
+@pytest.mark.parametrize("shape", [(1000, 1000), (257, 1001), (3, 5), (5000, 4000)])
+def test_pow_steps_are_the_stand_alone_pow_bit_for_bit(shape, hip, oracle):
+    """`value ** 2` with a PHP number is x * x in np_binary (the correctly rounded square); a chain runs the same product for that
+    step — and the general pow (array exponent, another number, the number as the BASE, a 0-d device 2.0) runs np_binary's pow.
+    Bit-identical to the op-by-op sequence at every size class of the stand-alone kernel (its log2 table lives in LDS for small
+    arrays, in registers for large ones), incl. as the operand of a full and of an axis reduction."""
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    from numpower_amd.ndarray import NDArray
+    x = synth.uniform(shape, 191, -3.0, 3.0)
+    y = synth.uniform(shape, 192, 0.5, 4.0)
+    p = synth.uniform(shape, 193, 0.25, 4.0)
+    x.reshape(-1)[::11] = y.reshape(-1)[::11]                      # zero differences
+    gx, gy, gp = NDArray.array(x).gpu(), NDArray.array(y).gpu(), NDArray.array(p).gpu()
+    two = NDArray.array(np.float32(2.0)).gpu()
+
+    d = oracle.binary("subtract", x, y)
+    fused = ((gx.lazy() - gy) ** 2).eval().cpu().numpy()
+    assert _same(fused, d * d), "(x - y) ** 2 is the fp32 product"
+    assert _same(fused, ((gx - gy) ** 2).cpu().numpy())
+    fused = (((gx.lazy() - gy) ** 2) * 0.5 + gp).eval().cpu().numpy()
+    assert _same(fused, (((gx - gy) ** 2) * 0.5 + gp).cpu().numpy())
+    fused = ((gx.lazy() ** 2) ** 2).eval().cpu().numpy()            # first step of a chain, and twice
+    assert _same(fused, ((gx ** 2) ** 2).cpu().numpy())
+
+    for name, lz, eager in (("p ** y", gp.lazy().sqrt() ** gy, NDArray.sqrt(gp) ** gy),
+                            ("p ** 1.5", (gp.lazy() * 2.0) ** 1.5, (gp * 2.0) ** 1.5),
+                            ("2 ** x", 2.0 ** (gx.lazy() + 1.0), NDArray._binary("pow", 2.0, gx + 1.0)),
+                            ("p ** 0-d 2.0", (gp.lazy() + 1.0) ** two, (gp + 1.0) ** two)):
+        assert _same(lz.eval().cpu().numpy(), eager.cpu().numpy()), name
+    want = oracle.binary("pow", oracle.unary("sqrt", p), y)
+    assert _close((gp.lazy().sqrt() ** gy).eval().cpu().numpy(), want), "sqrt(p) ** y vs the oracle's composition"
+
+    # a mean squared error in one launch: the squares never go to memory
+    d64 = (x.astype(np.float64) - y.astype(np.float64)) ** 2
+    mse = ((gx.lazy() - gy) ** 2).mean()
+    assert abs(mse - d64.mean()) <= 1e-5 * d64.mean()
+    for axis in (0, 1):
+        got = ((gx.lazy() - gy) ** 2).sum(axis=axis).cpu().numpy().astype(np.float64)
+        assert (np.abs(got - d64.sum(axis=axis)) <= 1e-5 * d64.sum(axis=axis)).all(), axis

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 OUTCOMES = {}          # seed -> "values" | the error both evaluations raised
 
-BINARY = ["add", "subtract", "multiply", "divide", "mod"]          # pow is never a chain step (hip_lazy.c)
+BINARY = ["add", "subtract", "multiply", "divide", "mod", "pow"]   # pow incl. `** 2.0`, which is x * x stand-alone and in a chain
 UNARY = ["exp", "sqrt", "abs", "negate", "sin", "tanh", "floor", "sign", "log1p", "reciprocal"]
 
 
@@ -141,7 +141,7 @@ def _evaluate(env, leaves, steps, write_at=None):
             nxt = _unary(env, op, acc)
         else:
             if operand == "number":
-                other, temp = Val(env[0], number=1.5 + 0.25 * k), None
+                other, temp = Val(env[0], number=2.0 if k % 2 == 0 else 1.5 + 0.25 * k), None
             elif operand == "pending":
                 other = temp = _unary(env, "sqrt", leaves["pos"])          # a second pending value meets the chain
             else:

@@ -1007,8 +1007,9 @@ static zval e_quirks(Env *e) { return op2(ZEND_SUB, op2(ZEND_MUL, op2(ZEND_MOD, 
 static zval e_rrow(Env *e) { return op2(ZEND_MUL, e->row, UN(negate, e->x, 0), 0, 1); }
 /* nd::exp($x) * nd::log($p): two pending operands — the second one is computed and joins as an array */
 static zval e_two_pending(Env *e) { return op2(ZEND_MUL, UN(exp, e->x, 0), UN(log, e->p, 0), 1, 1); }
-/* $p ** 2 + nd::round($x, 1) through the STATIC methods (PHP_METHOD(pow), PHP_METHOD(add)) and a 1F driver; pow is never a
- * chain step (hip_lazy.c): its launch comes at once, round + add are one chain that starts from the pending round */
+/* $p ** 2 + nd::round($x, 1) through the STATIC methods (PHP_METHOD(pow), PHP_METHOD(add)) and a 1F driver: the square and the
+ * add are one chain that starts from $p (`** 2` with a PHP number is x * x stand-alone and inside a chain alike); the pending
+ * round is computed when the add consumes it */
 static zval e_static(Env *e) {
     zval two = number(2.0), t1 = {IS_UNDEF, 0.0, 0}, t2 = {IS_UNDEF, 0.0, 0}, r = {IS_UNDEF, 0.0, 0};
     patched_method_pow(&e->p, &two, &t1);
@@ -1053,11 +1054,19 @@ static zval e_grow(Env *e) { return op2(ZEND_MUL, UN(exp, e->row, 0), e->wide, 1
 static zval e_small_first(Env *e) { return op2(ZEND_ADD, e->row, e->wide, 0, 0); }
 /* $x + $y: one step — the flush IS the stand-alone launch */
 static zval e_single(Env *e) { return op2(ZEND_ADD, e->x, e->y, 0, 0); }
+/* ($x - $y) ** 2: the squared difference of a loss, one launch */
+static zval e_sq_diff(Env *e) { return op2(ZEND_POW, op2(ZEND_SUB, e->x, e->y, 0, 0), number(2.0), 1, 0); }
+/* ($p ** $y) * 0.5 and nd::sqrt($p) ** 1.5: pow with an array and with a number other than 2 are steps like any other */
+static zval e_pow_array(Env *e) { return op2(ZEND_MUL, op2(ZEND_POW, e->p, e->y, 0, 0), number(0.5), 1, 0); }
+static zval e_pow_number(Env *e) { return op2(ZEND_POW, UN(sqrt, e->p, 0), number(1.5), 1, 0); }
+/* 2 ** $x: the number is the BASE (swap) - the general pow, not a square */
+static zval e_pow_base2(Env *e) { return op2(ZEND_ADD, op2(ZEND_POW, number(2.0), e->x, 0, 0), number(1.0), 1, 0); }
 
 static const struct { const char *name; Expr fn; int steps; int lazy_launches; } kExpr[] = {
     {"exp_mul_add", e_exp_mul_add, 3, 1}, {"rscalar", e_rscalar, 2, 1}, {"rdiv", e_rdiv, 2, 1}, {"bcast", e_bcast, 3, 1},
     {"quirks", e_quirks, 3, 1}, {"rrow", e_rrow, 2, 1}, {"two_pending", e_two_pending, 3, 2}, {"static", e_static, 3, 2}, {"static2", e_static2, 4, 2},
     {"clip", e_clip, 2, 1}, {"long", e_long, 15, 2}, {"grow", e_grow, 2, 2}, {"small_first", e_small_first, 1, 1}, {"single", e_single, 1, 1},
+    {"sq_diff", e_sq_diff, 2, 1}, {"pow_array", e_pow_array, 2, 1}, {"pow_number", e_pow_number, 2, 1}, {"pow_base2", e_pow_base2, 2, 1},
 };
 enum { kExprCount = (int) (sizeof kExpr / sizeof kExpr[0]) };
 
@@ -1205,17 +1214,19 @@ int main(int argc, char **argv) {
     {
         static const struct { const char *name; double (*fn)(zval *); int exact; } kRed[] = {
             {"sum", patched_method_sum, 0}, {"mean", patched_method_mean, 0}, {"max", patched_method_max, 1}, {"min", patched_method_min, 1},
-            {"prod", patched_method_prod, 0}};
-        for (int k = 0; k < 5; k++) {
+            {"prod", patched_method_prod, 0}, {"mse", patched_method_mean, 0}};
+        for (int k = 0; k < 6; k++) {
             double got[2];
             unsigned long long cost[2];
             for (int lazy = 1; lazy >= 0; lazy--) {
                 NPH_SetLazy(lazy);
                 NPH_GetLazyStats(&st0);
                 const unsigned long long l0 = launches();
-                /* nd::sum(nd::exp($x) * $y) ...; a product that stays near 1: nd::prod(nd::clip($w, 0.9998, 1.0002)) */
+                /* nd::sum(nd::exp($x) * $y) ...; a product that stays near 1: nd::prod(nd::clip($w, 0.9998, 1.0002)); a mean squared
+                 * error: nd::mean(($x - $y) ** 2) */
                 zval c = {IS_UNDEF, 0.0, 0};
                 if (k == 4) patched_method_clip(&e.w, 0.9998, 1.0002, &c);
+                else if (k == 5) c = op2(ZEND_POW, op2(ZEND_SUB, e.x, e.y, 0, 0), number(2.0), 1, 0);
                 else c = op2(ZEND_MUL, UN(exp, e.x, 0), e.y, 1, 0);
                 got[lazy] = kRed[k].fn(&c);
                 cost[lazy] = launches() - l0;
