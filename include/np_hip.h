@@ -65,7 +65,10 @@ int np_sync(void);
  * for everything the current device was given (all streams), puts the library's device-side bookkeeping back in order,
  * clears the word and hands back the bits that were up (1 = a stream-ordering wait of np_comm, 2 = a GEMM workgroup waiting
  * for its siblings' partial tiles; 0 = there was nothing to acknowledge).  Results produced between the failed launch and
- * the acknowledgement must be discarded.  (The reference ignores device errors altogether: cuda_math.cu never checks a launch.) */
+ * the acknowledgement must be discarded.  While the device's communicator still has a transfer in flight that waits for a peer
+ * (after 10 s of grace) it returns NP_ERR_DEVICE and clears nothing — the collective library's kernel does not end by itself
+ * when a rank has died, and waiting for the whole device would never return: np_comm_destroy() first (it aborts the
+ * communicator), then acknowledge.  (The reference ignores device errors altogether: cuda_math.cu never checks a launch.) */
 int np_clear_device_error(unsigned *host_bits /* may be NULL */);
 const char *np_last_error(void);
 /* Library version string, e.g. "numpower_amd 0.1 gfx950". */

@@ -7,6 +7,8 @@
   numpower_amd/lib/libnp_hipmath.so     the ext/ glue alone (reference's cuda_math.h + gpu_alloc.h
                                         symbols over libnp_hip.so, no host layer)
   oracle/lib/libnp_oracle.so            CPU restatement of the reference (test infrastructure)
+  tests/loopback_rccl/lib/librccl.so.1  a stand-in for RCCL that lets several ranks share ONE GPU (test infrastructure: only
+                                        worker processes of tests/test_gpu_comm_loopback_peers.py get it, via LD_LIBRARY_PATH)
 
 hipcc cross-compiles for gfx950 without a GPU.  Objects are rebuilt only when a source or
 header is newer than the object, translation units compile in parallel.
@@ -229,6 +231,22 @@ def build_oracle(force: bool = False, verbose: bool = False) -> Path:
     return lib
 
 
+def build_loopback_rccl(force: bool = False, verbose: bool = False) -> Path:
+    """Compile tests/loopback_rccl (test infrastructure; the product never names it: np_comm.hip dlopens "librccl.so.1" and a
+    test's worker processes are started with LD_LIBRARY_PATH pointing here)."""
+    tdir = ROOT / "tests" / "loopback_rccl"
+    src, lib = tdir / "loopback_rccl.hip", tdir / "lib" / "librccl.so.1"
+    if not src.exists():
+        return lib
+    (tdir / "lib").mkdir(exist_ok=True)
+    if force or _newer(lib, [src]):
+        if verbose:
+            print("[build] compiling tests/loopback_rccl", flush=True)
+        _run([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror", str(src),
+              "-o", str(lib), "-Wl,-soname,librccl.so.1", "-lrt"])
+    return lib
+
+
 def build_all(force: bool = False, verbose: bool = False):
     hip = build_hip(force, verbose)
     host = build_host(force, verbose)
@@ -237,6 +255,7 @@ def build_all(force: bool = False, verbose: bool = False):
     build_fast_path_bodies(force, verbose)
     build_lazy_bodies(force, verbose)
     oracle = build_oracle(force, verbose)
+    build_loopback_rccl(force, verbose)
     return hip, host, oracle
 
 

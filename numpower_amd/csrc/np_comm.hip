@@ -522,6 +522,20 @@ int need_comm(const char *who) {
 
 }  // namespace
 
+bool np::comm_transfers_stuck(int device, double grace_s) {
+    if (!g_comm.comm || !g_comm.stream || g_comm.device != device) return false;
+    const double give_up = now_s() + grace_s;
+    while (hipStreamQuery(g_comm.stream) == hipErrorNotReady) {
+        if (now_s() > give_up) {
+            (void)hipGetLastError();
+            return true;
+        }
+        usleep(200);
+    }
+    (void)hipGetLastError();
+    return false;
+}
+
 extern "C" {
 
 int np_comm_init(int rank, int world, const char *endpoint) {

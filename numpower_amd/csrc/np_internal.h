@@ -126,6 +126,11 @@ struct Scratch {
     ~Scratch();
 };
 
+// np_comm.hip: true when a communicator lives on `device` and its communication stream still has unfinished work after
+// `grace_s` seconds — a transfer that waits for a peer (late, or gone: the collective library's kernel then never ends and
+// anything that synchronises the whole device would never return).  np_comm_destroy() is what ends such a transfer.
+bool comm_transfers_stuck(int device, double grace_s);
+
 }  // namespace np
 
 // ---- device-side reduction helpers shared by np_reduce.hip and the fused chain kernel ----

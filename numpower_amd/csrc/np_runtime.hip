@@ -414,7 +414,13 @@ int np_clear_device_error(unsigned *host_bits) {
     // Everything this device was given must have retired before its bookkeeping is touched: a GEMM workgroup that gave up
     // waiting for its siblings leaves its ticket / its stream-K flag where it stood — rings that later launches assume are
     // zero — and kernels on a stream the caller swapped out earlier (np_set_stream) may still hold live tickets (ADVICE r05:
-    // a reset that is only ordered behind the CURRENT stream can wipe a healthy fold's count).  So: the whole device.
+    // a reset that is only ordered behind the CURRENT stream can wipe a healthy fold's count).  So: the whole device —
+    // unless the device's communicator has a transfer in flight that waits for a peer (what the error usually IS, after a
+    // rank died): the collective library's kernel does not end by itself and a device-wide wait would never return.  That
+    // one is np_comm_destroy()'s to end (it aborts the communicator); until then the error stays.
+    if (np::comm_transfers_stuck(r.device, 10.0))
+        return np::fail(NP_ERR_DEVICE, "np_clear_device_error: device %d's communicator still has transfers in flight that wait for a "
+                                       "peer (late, or gone); np_comm_destroy() ends them — acknowledge after it", r.device);
     NP_HIP_CHECK(hipDeviceSynchronize());
     const unsigned bits = __atomic_exchange_n(r.error_words + 2 * r.device, 0u, __ATOMIC_ACQ_REL);
     if (host_bits) *host_bits = bits;

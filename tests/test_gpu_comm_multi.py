@@ -30,13 +30,15 @@ WORKER = textwrap.dedent("""
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     batch, m, k, n = 4 * world, 96, 160, 64
     slab = batch // world
-    D.init(rank)
+    D.init(int(sys.argv[5]) if len(sys.argv) > 5 else rank)      # (argv[5]: every rank on ONE device — tests/test_gpu_comm_loopback_peers.py)
     lib = load()
     check(lib.np_comm_init(rank, world, ("tcp://127.0.0.1:%%d" %% port).encode()))
+    version = C.c_int(0)
+    check(lib.np_comm_rccl_version(C.byref(version)))
     A = np.stack([synth.uniform((m, k), 700 + i, -1.0, 1.0) for i in range(rank * slab, (rank + 1) * slab)])
     B = np.stack([synth.uniform((k, n), 800 + i, -1.0, 1.0) for i in range(rank * slab, (rank + 1) * slab)])
     dA, dB = D.DeviceArray.from_host(A), D.DeviceArray.from_host(B)
-    results = {}
+    results = {"rccl_version": np.array([version.value], dtype=np.float32)}
     for variant in (0, 1, 2, 3):
         check(lib.np_comm_set_variant(variant))
         for chunks, mode in ((1, 1), (1, 2), (2, 0), (3, 0), (4, 0)):
@@ -128,12 +130,13 @@ def test_sharded_matmul_across_real_ranks(tmp_path, oracle):
     if devices < 2:
         pytest.skip("needs two GPUs in one box (RCCL refuses two ranks on one device)")
     world = 4 if devices >= 4 else 2
-    port = _free_port()
-    procs = [subprocess.Popen([sys.executable, "-c", WORKER, str(r), str(world), str(port), str(tmp_path / ("rank%d.npz" % r))],
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
-    outs = [p.communicate(timeout=600) for p in procs]
-    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and "OK" in so.splitlines(), (r, so[-300:], se[-1500:])   # (RCCL's banner may follow it: C stdio is flushed at exit)
+    _run_workers(WORKER, world, tmp_path, "rank")
+    check_abi_worker_results(world, tmp_path, oracle)
+
+
+def check_abi_worker_results(world, tmp_path, oracle, rccl_version=None):
+    """What WORKER's ranks saved: every form of the sharded product on every rank — the same bits, within 1e-5 of the oracle's loop
+    of 2-D matmuls (the 1024^3 matrices: sampled elements against fp64)."""
     batch, m, k, n = 4 * world, 96, 160, 64
     A = np.stack([synth.uniform((m, k), 700 + i, -1.0, 1.0) for i in range(batch)])
     B = np.stack([synth.uniform((k, n), 800 + i, -1.0, 1.0) for i in range(batch)])
@@ -146,13 +149,15 @@ def test_sharded_matmul_across_real_ranks(tmp_path, oracle):
     first = big_first = all_picks = None
     for r in range(world):
         got = np.load(tmp_path / ("rank%d.npz" % r))
+        if rccl_version is not None:
+            assert int(got["rccl_version"][0]) == rccl_version, (r, got["rccl_version"])
         picks = {key: float(got[key][0]) for key in got.files if key.startswith("auto_pick_")}
         assert all(p >= 1 for p in picks.values()), picks
         all_picks = picks if r == 0 else all_picks
         assert picks == all_picks, (r, picks, all_picks)                          # every rank models the same piece count
         for key in got.files:
             x = got[key]
-            if key.startswith("auto_pick_"):
+            if key.startswith("auto_pick_") or key == "rccl_version":
                 continue
             if key.startswith("big_") or key == "auto_big":      # sampled elements of every matrix of the replicated 1024^3 result
                 assert not np.isnan(x).any(), (r, key)
@@ -168,11 +173,16 @@ def test_sharded_matmul_across_real_ranks(tmp_path, oracle):
             assert (x.view(np.uint32) == first.view(np.uint32)).all(), (r, key)   # every rank, every form: the same bits
 
 
-def _run_workers(script, world, tmp_path, tag):
+def _run_workers(script, world, tmp_path, tag, extra=(), env=None, timeout=600):
     port = _free_port()
-    procs = [subprocess.Popen([sys.executable, "-c", script, str(r), str(world), str(port), str(tmp_path / ("%s%d.npz" % (tag, r)))],
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
-    outs = [p.communicate(timeout=600) for p in procs]
+    procs = [subprocess.Popen([sys.executable, "-c", script, str(r), str(world), str(port), str(tmp_path / ("%s%d.npz" % (tag, r))), *extra],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    try:
+        outs = [p.communicate(timeout=timeout) for p in procs]
+    finally:
+        for p in procs:                      # (a rank that is still alive after the others failed: these exact processes, nothing else)
+            if p.poll() is None:
+                p.kill()
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "OK" in so.splitlines(), (r, so[-300:], se[-1500:])   # (RCCL's banner may follow it: C stdio is flushed at exit)
 
