@@ -17,7 +17,9 @@ independent matrices — the path shards over independent arrays with no data-pa
 all-gather) is measured separately and reported under "extras", twice: with torch.distributed's
 all_gather_into_tensor and with the library's own np_allgather (RCCL behind the C ABI).  NP_COMM=abi
 runs the whole multi-rank bench without importing torch (rendezvous, barrier, max over ranks and the
-gather through np_comm_*).
+gather through np_comm_*).  NP_BENCH_SHARE_DEVICE=1 puts every spawned rank on device 0 — possible only over
+a collective library that allows ranks to share a device (the tests' stand-in does, RCCL does not): the line then
+says "valid": false; it is how the N > 1 path runs on a one-GPU box, not a measurement.
 
 The JSON line also carries
   roofline      achieved vs peak for the dominant kernel (fp32 MFMA GEMM), from HIP events
@@ -199,6 +201,8 @@ class Dist:
             v = C.c_int(0)
             ok = load().np_comm_rccl_version(C.byref(v)) == 0
             how = ("np_comm_* (RCCL %d.%d.%d behind the C ABI)" % (v.value // 10000, v.value // 100 % 100, v.value % 100)) if ok else "np_comm_* (RCCL version unknown)"
+            if ok and v.value >= 90000:     # no RCCL release: the loader was pointed at something else (LD_LIBRARY_PATH)
+                how = "np_comm_* over a stand-in for librccl.so.1 (ncclGetVersion says %d: not RCCL)" % v.value
             if not self.abi:
                 how = "none (one rank, no communicator); the library would load " + how
         else:
@@ -233,8 +237,9 @@ def spawn_ranks(n: int, argv, timeout_s: float = 1500.0) -> int:
     import subprocess
     port = _free_port()
     procs = []
+    share = os.environ.get("NP_BENCH_SHARE_DEVICE") == "1"     # every rank on device 0 (see main(): a code-path run)
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if share else str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -1325,6 +1330,11 @@ def main():
     if extras:
         result["extras"] = _compact(extras)
         result["summary"] = _summary(result, extras)       # LAST key: the tail of the line shows every BASELINE config
+    if os.environ.get("NP_BENCH_SHARE_DEVICE") == "1" and args.gpus > 1:
+        # N ranks on ONE device (possible only over a collective library that allows it — RCCL does not): every line of the
+        # N > 1 path runs on hardware, the ranks take the GPU from each other, and the figures are not a measurement of anything
+        result = {**result, "valid": False, "shared_device": True,
+                  "note": "NP_BENCH_SHARE_DEVICE=1: %d ranks share device 0 — a code-path run of the N > 1 bench, not a measurement" % args.gpus}
     if rank0:
         print(json.dumps(result), flush=True)
     dist.close()

@@ -341,3 +341,24 @@ def test_comm_entry_points_without_a_communicator_or_device():
     assert lib.np_comm_set_variant(4) != 0 and b"np_comm_set_variant" in lib.np_last_error()
     for ok in (1, 2, 3, 0):
         assert lib.np_comm_set_variant(ok) == 0
+
+
+def test_loopback_stand_in_for_rccl_is_test_infrastructure_and_complete():
+    """tests/loopback_rccl/lib/librccl.so.1 (ranks that share one GPU: tests/test_gpu_comm_loopback_peers.py) exports every entry
+    point np_comm.hip looks up in the collective library, answers ncclGetVersion with its own number without a device — and
+    nothing of the product names it: np_comm.hip asks the loader for "librccl.so.1", a test's workers get this one through
+    LD_LIBRARY_PATH."""
+    import ctypes as C
+    lib_path = ROOT / "tests" / "loopback_rccl" / "lib" / "librccl.so.1"
+    assert lib_path.exists(), "not built: python -m numpower_amd.build"
+    wanted = re.findall(r'NP_SYM\(\w+, "(ncc\w+)"\)', (ROOT / "numpower_amd" / "csrc" / "np_comm.hip").read_text())
+    wanted += ["ncclCommAbort", "ncclGetVersion"]                      # the two np_comm.hip treats as optional
+    assert len(wanted) >= 12
+    lib = C.CDLL(str(lib_path))
+    for name in wanted:
+        assert hasattr(lib, name), name
+    version = C.c_int(0)
+    assert lib.ncclGetVersion(C.byref(version)) == 0 and version.value == 99901
+    for path in list((ROOT / "numpower_amd").rglob("*")) + list((ROOT / "ext").rglob("*")) + [ROOT / "bench.py", ROOT / "__graft_entry__.py"]:
+        if path.suffix in (".py", ".hip", ".cpp", ".h", ".c") and path.name != "build.py":
+            assert "loopback_rccl" not in path.read_text(), "%s names the tests' stand-in for RCCL" % path

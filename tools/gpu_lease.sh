@@ -5,6 +5,7 @@
 #   tests      the -m gpu suite (the gate)
 #   bench      bench.py twice: default flags and the driver's (--steps 20 --warmup 5)
 #   world1     bench.py's N > 1 code paths on one GPU (torch.distributed plumbing, then the C-ABI communicator)
+#   peers      bench.py --gpus 2 with both ranks on this GPU over tests/loopback_rccl (NP_COMM=abi): the N > 1 path with a peer
 #   profile    rocprofv3 --kernel-trace --stats of bench.py -> bench_kernel_stats.csv
 #   counters   the PMC passes (their own runs, as the guide prescribes): HBM traffic (FETCH_SIZE / WRITE_SIZE ->
 #              pmc_traffic.json), MFMA / SQ counters of the headline kernels (-> gemm_pmc.json, pmc_sq.txt)
@@ -43,6 +44,12 @@ PY
 r_world1() {
     NP_BENCH_FORCE_DIST=1 timeout 600 python bench.py --steps 20 --warmup 5 > "$O/bench_world1_torch.json" 2> "$O/w1t.err"; echo "world1 torch rc=$?"
     NP_BENCH_FORCE_DIST=1 NP_COMM=abi timeout 600 python bench.py --steps 20 --warmup 5 > "$O/bench_world1_abi.json" 2> "$O/w1a.err"; echo "world1 abi rc=$?"
+}
+r_peers() {
+    # the N > 1 bench with two ranks that SHARE this GPU, over the tests' stand-in for librccl.so.1 (tests/loopback_rccl): every
+    # leg of config 5 through np_comm_* with a real peer process; "valid": false in the line - a code-path run, not a measurement
+    LD_LIBRARY_PATH="$R/tests/loopback_rccl/lib:$LD_LIBRARY_PATH" NP_COMM=abi NP_BENCH_SHARE_DEVICE=1 timeout 700 python bench.py --gpus 2 --steps 10 --warmup 3 \
+        > "$O/bench_two_ranks_one_gpu_abi.json" 2> "$O/peers.err"; echo "peers (2 ranks, one GPU, loopback) rc=$?"
 }
 r_profile() {
     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/kt" -o bench --output-format csv -- python "$R/bench.py" > "$O/bench_under_rocprof.json" 2> "$O/bench_under_rocprof.err")
@@ -130,11 +137,12 @@ case "$RECIPE" in
     tests) r_tests ;;
     bench) r_bench ;;
     world1) r_world1 ;;
+    peers) r_peers ;;
     profile) r_profile ;;
     counters) r_counters ;;
     sweeps) r_sweeps ;;
-    evidence) r_tests; r_bench; r_world1; r_profile; r_counters; r_sweeps ;;
+    evidence) r_tests; r_bench; r_world1; r_peers; r_profile; r_counters; r_sweeps ;;
     cleanbuild) r_cleanbuild ;;
     fuzz) r_fuzz ;;
-    *) echo "unknown recipe $RECIPE (tests | bench | world1 | profile | counters | sweeps | evidence | cleanbuild | fuzz)"; exit 2 ;;
+    *) echo "unknown recipe $RECIPE (tests | bench | world1 | peers | profile | counters | sweeps | evidence | cleanbuild | fuzz)"; exit 2 ;;
 esac
