@@ -66,7 +66,7 @@ int np_sync(void);
  * clears the word and hands back the bits that were up (1 = a stream-ordering wait of np_comm, 2 = a GEMM workgroup waiting
  * for its siblings' partial tiles; 0 = there was nothing to acknowledge).  Results produced between the failed launch and
  * the acknowledgement must be discarded.  While the device's communicator still has a transfer in flight that waits for a peer
- * (after 10 s of grace) it returns NP_ERR_DEVICE and clears nothing — the collective library's kernel does not end by itself
+ * (after 10 s of grace, or np_comm_set_wait_limit's seconds if fewer) it returns NP_ERR_DEVICE and clears nothing — the collective library's kernel does not end by itself
  * when a rank has died, and waiting for the whole device would never return: np_comm_destroy() first (it aborts the
  * communicator), then acknowledge.  (The reference ignores device errors altogether: cuda_math.cu never checks a launch.) */
 int np_clear_device_error(unsigned *host_bits /* may be NULL */);
@@ -457,7 +457,8 @@ int np_sgemm_strided_batched_allgather(size_t slab, size_t M, size_t N, size_t K
  * device's error word: np_sync / np_memcpy_d2h / host-result calls / np_comm_* calls on that device return NP_ERR_DEVICE until
  * np_clear_device_error() acknowledges it.
  * A wait for TRANSFERS (which depend on other ranks) gives up after np_comm_set_wait_limit seconds (default 600; 0 = never,
- * like the RCCL kernel it waits for) and raises the same error; np_comm_destroy releases whatever still waits.
+ * like the RCCL kernel it waits for) and raises the same error; np_comm_destroy releases whatever still waits
+ * (after a grace period of 30 s, or of the wait limit if that is shorter, for transfers that are merely still travelling).
  * With peers (world > 1) the sharded GEMM is one launch per piece; see np_hip_debug.h (np_comm_set_variant) for the
  * forms kept for A/B measurements. */
 int np_comm_set_wait_limit(double seconds);

@@ -520,11 +520,18 @@ int need_comm(const char *who) {
     return NP_OK;
 }
 
+// the caller's patience with transfers (np_comm_set_wait_limit) also bounds the grace periods of destroy / acknowledge: someone
+// who declared transfers dead after 2 s does not want np_comm_destroy to hope for 30
+double grace_seconds(double most) {
+    const double limit = (double)kWaitForPeers / 1e8;      // 0 = never give up: no opinion
+    return limit > 0.0 && limit < most ? (limit < 1.0 ? 1.0 : limit) : most;
+}
+
 }  // namespace
 
 bool np::comm_transfers_stuck(int device, double grace_s) {
     if (!g_comm.comm || !g_comm.stream || g_comm.device != device) return false;
-    const double give_up = now_s() + grace_s;
+    const double give_up = now_s() + grace_seconds(grace_s);
     while (hipStreamQuery(g_comm.stream) == hipErrorNotReady) {
         if (now_s() > give_up) {
             (void)hipGetLastError();
@@ -920,7 +927,7 @@ int np_comm_destroy(void) {
     // is reported as incomplete by the next np_sync / np_memcpy_d2h
     // — after a grace period: a gather that is merely still travelling is waited for, as before
     unsigned *err = np::device_error_word();
-    const double give_up = now_s() + 30.0;
+    const double give_up = now_s() + grace_seconds(30.0);
     while (err && hipStreamQuery(np::stream()) == hipErrorNotReady) {
         if (now_s() > give_up) {
             __atomic_store_n(err + 1, 1u, __ATOMIC_RELEASE);
