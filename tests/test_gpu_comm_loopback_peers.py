@@ -1,7 +1,7 @@
 """The sharded batched matmul of BASELINE config 5 with PEER PROCESSES on the one GPU of a usual lease.
 
 RCCL refuses two ranks on one device, so tests/test_gpu_comm_multi.py (real peers over RCCL) skips wherever this repository has
-ever run.  Here the same worker script runs as 2 and as 4 ranks that SHARE device 0, over tests/loopback_rccl — a stand-in for
+ever run.  Here the same worker script runs as 2, 3 and 4 ranks that SHARE device 0, over tests/loopback_rccl — a stand-in for
 librccl.so.1 (test infrastructure, header of loopback_rccl.hip) that np_comm.hip picks up through LD_LIBRARY_PATH, no switch in
 the product: rendezvous over TCP, every form of np_sgemm_strided_batched_allgather (one all-gather, grouped send / recv, 2 / 3 / 4
 overlapped pieces, the library's own piece count; device-side flags, HIP events, one launch per piece, ONE progress-reporting
@@ -32,7 +32,7 @@ def _env():
     return env
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_matmul_across_ranks_that_share_one_gpu(world, tmp_path, oracle):
     _run_workers(WORKER, world, tmp_path, "rank", extra=("0",), env=_env(), timeout=300)
     check_abi_worker_results(world, tmp_path, oracle, rccl_version=LOOPBACK_VERSION)
@@ -80,6 +80,17 @@ SKEW_WORKER = textwrap.dedent("""
         check(lib.np_comm_barrier())
         d_mine.free(); d_all.free()
     check(lib.np_comm_destroy())
+    # a second communicator in the same processes, rendezvous through a FILE this time (rank 0 publishes the id, peers poll)
+    import os
+    check(lib.np_comm_init(rank, world, os.path.join(os.path.dirname(out), "rendezvous.id").encode()))
+    assert lib.np_comm_world() == world and lib.np_comm_rank() == rank
+    mine = np.full(1000, float(rank + 1), dtype=np.float32)
+    d_mine, d_all = D.DeviceArray.from_host(mine), D.DeviceArray((world * 1000,))
+    check(lib.np_allgather(d_mine.ptr, d_all.ptr, 4000))
+    assert (d_all.to_host().reshape(world, 1000) == np.arange(1, world + 1, dtype=np.float32)[:, None]).all()
+    check(lib.np_comm_barrier())
+    check(lib.np_comm_destroy())
+    assert lib.np_comm_world() == 0
     np.savez(out, ok=np.ones(1, dtype=np.float32))
     print("OK")
 """) % str(ROOT)
