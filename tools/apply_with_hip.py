@@ -1062,6 +1062,122 @@ static zval e_pow_number(Env *e) { return op2(ZEND_POW, UN(sqrt, e->p, 0), numbe
 /* 2 ** $x: the number is the BASE (swap) - the general pow, not a square */
 static zval e_pow_base2(Env *e) { return op2(ZEND_ADD, op2(ZEND_POW, number(2.0), e->x, 0, 0), number(1.0), 1, 0); }
 
+/* ---- stress: a seeded random PROGRAM over a pool of PHP variables — operators (arrays, numbers, pending values, views), unary
+ * methods, assignments over live variables, unset(), in-place writes (directly and through a view), reductions, reads — evaluated
+ * through the inserted text exactly as the expressions above.  Run twice, chains on and off: every value read on the way and every
+ * variable alive at the end must agree bit for bit (NaNs as NaNs), nothing may stay pending, no device allocation may leak. ---- */
+enum { kPool = 20 };
+typedef struct Rng { unsigned long long s; } Rng;
+static unsigned rnd(Rng *r, unsigned n) {
+    r->s = r->s * 6364136223846793005ULL + 1442695040888963407ULL;
+    return (unsigned) ((r->s >> 33) % n);
+}
+static unsigned long long fnv(unsigned long long h, const void *p, size_t n) {
+    const unsigned char *q = (const unsigned char *) p;
+    for (size_t i = 0; i < n; i++) h = (h ^ q[i]) * 1099511628211ULL;
+    return h;
+}
+static unsigned long long digest_value(unsigned long long h, zval *z) {
+    if (Z_TYPE_P(z) != IS_OBJECT) return fnv(h, "none", 4);
+    NDArray *host = method_cpu(z);
+    if (host == NULL) {
+        numpower_host_clear_error();
+        return fnv(h, "fail", 4);
+    }
+    const int ndim = NDArray_NDIM(host);
+    h = fnv(h, &ndim, sizeof ndim);
+    h = fnv(h, NDArray_SHAPE(host), sizeof(int) * (size_t) ndim);
+    const float *v = NDArray_FDATA(host);
+    for (long i = 0; i < (long) NDArray_NUMELEMENTS(host); i++) {
+        uint32_t bits;
+        memcpy(&bits, v + i, 4);
+        if (v[i] != v[i]) bits = 0x7fc00000u;              /* a NaN is a NaN */
+        h = fnv(h, &bits, 4);
+    }
+    NDArray_FREE(host);
+    return h;
+}
+static zval fresh_leaf(Rng *r, int rows, int cols, int serial) {
+    const int s2[2] = {rows, cols}, s1[1] = {cols}, sc[2] = {rows, 1};
+    switch (rnd(r, 5)) {
+        case 0: return placed(s1, 1, 400 + serial, 0.5f, 2.0f, 1);
+        case 1: return placed(sc, 2, 400 + serial, 0.5f, 2.0f, 1);
+        default: return placed(s2, 2, 400 + serial, -2.0f, 2.0f, 1);
+    }
+}
+static unsigned long long stress(int lazy, unsigned seed, int n_steps, int rows, int cols, unsigned long *evaluated) {
+    static const int kOps[6] = {ZEND_ADD, ZEND_SUB, ZEND_MUL, ZEND_DIV, ZEND_MOD, ZEND_POW};
+    Rng r = {seed * 2654435761ULL + 12345ULL};
+    zval pool[kPool];
+    unsigned long long h = 1469598103934665603ULL;
+    int serial = 0;
+    NPH_SetLazy(lazy);
+    for (int i = 0; i < kPool; i++) {
+        pool[i].type = IS_UNDEF;
+        if (i < 8) pool[i] = fresh_leaf(&r, rows, cols, serial++);
+    }
+    for (int step = 0; step < n_steps; step++) {
+        const unsigned what = rnd(&r, 100);
+        const int a = (int) rnd(&r, kPool), b = (int) rnd(&r, kPool), dst = (int) rnd(&r, kPool);
+        zval result = {IS_UNDEF, 0.0, 0};
+        if (Z_TYPE_P(&pool[a]) != IS_OBJECT) {             /* an unset variable: give it a new array */
+            pool[a] = fresh_leaf(&r, rows, cols, serial++);
+            continue;
+        }
+        if (what < 45) {                                    /* $dst = $a (op) $b | number */
+            const int op = kOps[rnd(&r, 6)];
+            zval rhs = (Z_TYPE_P(&pool[b]) != IS_OBJECT || rnd(&r, 100) < 30) ? number(op == ZEND_POW ? 2.0 : 0.5 + 0.25 * (double) rnd(&r, 8)) : pool[b];
+            if (op == ZEND_POW && Z_TYPE_P(&rhs) == IS_OBJECT) rhs = number(2.0);
+            if (rnd(&r, 100) < 25 && op != ZEND_POW) (void) patched_do_operation_ex(op, &result, &rhs, &pool[a]);
+            else (void) patched_do_operation_ex(op, &result, &pool[a], &rhs);
+        } else if (what < 70) {                             /* $dst = nd::f($a) */
+            switch (rnd(&r, 6)) {
+                case 0: patched_method_sin(&pool[a], &result); break;
+                case 1: patched_method_negate(&pool[a], &result); break;
+                case 2: patched_method_sqrt(&pool[a], &result); break;
+                case 3: patched_method_exp(&pool[a], &result); break;
+                case 4: patched_method_clip(&pool[a], -4.0, 4.0, &result); break;
+                default: patched_method_round(&pool[a], 1, &result); break;
+            }
+        } else if (what < 78) {                             /* unset($a) */
+            zval_dtor(&pool[a]);
+            continue;
+        } else if (what < 85) {                             /* $a->fill(c): whoever reads $a's buffer is computed first */
+            method_fill(&pool[a], 0.25f * (float) rnd(&r, 9));
+            continue;
+        } else if (what < 90) {                             /* $dst = $a[0] (a view), now and then written through */
+            NDArray *peek = buffer_peek(&pool[a]);
+            if (peek == NULL || NDArray_NDIM(peek) != 2) continue;
+            result = method_slice0(&pool[a], 0);
+            if (Z_TYPE_P(&result) == IS_OBJECT && rnd(&r, 100) < 50) method_fill(&result, 1.5f);
+        } else if (what < 95) {                             /* nd::max($a) / nd::min($a): bit-identical inside a chain and over stored values */
+            const double v = rnd(&r, 2) ? patched_method_max(&pool[a]) : patched_method_min(&pool[a]);
+            float f = (float) v;
+            if (f != f) f = 0.0f;
+            h = fnv(h, &f, sizeof f);
+            (*evaluated)++;
+            continue;
+        } else {                                            /* print_r($a) */
+            h = digest_value(h, &pool[a]);
+            (*evaluated)++;
+            continue;
+        }
+        if (Z_TYPE_P(&result) != IS_OBJECT) {               /* the operator threw (shapes that do not broadcast ...): $dst keeps its value */
+            numpower_host_clear_error();
+            h = fnv(h, "threw", 5);
+            continue;
+        }
+        zval_dtor(&pool[dst]);                              /* assignment: the old value of $dst goes once the new one exists */
+        pool[dst] = result;
+    }
+    for (int i = 0; i < kPool; i++) {
+        h = digest_value(h, &pool[i]);
+        zval_dtor(&pool[i]);
+    }
+    NPH_SetLazy(1);
+    return h;
+}
+
 static const struct { const char *name; Expr fn; int steps; int lazy_launches; } kExpr[] = {
     {"exp_mul_add", e_exp_mul_add, 3, 1}, {"rscalar", e_rscalar, 2, 1}, {"rdiv", e_rdiv, 2, 1}, {"bcast", e_bcast, 3, 1},
     {"quirks", e_quirks, 3, 1}, {"rrow", e_rrow, 2, 1}, {"two_pending", e_two_pending, 3, 2}, {"static", e_static, 3, 2}, {"static2", e_static2, 4, 2},
@@ -1295,6 +1411,32 @@ int main(int argc, char **argv) {
         CHECK(Z_TYPE_P(&r2) == IS_UNDEF && strstr(numpower_host_last_error(), "broadcast") != NULL, "4x5 + 7: %s", numpower_host_last_error());
         numpower_host_clear_error();
         zval_dtor(&g); zval_dtor(&h); zval_dtor(&odd);
+    }
+    /* ---- 7. random programs, chains on against chains off ---- */
+    {
+        static const int kShapes[4][2] = {{37, 53}, {64, 64}, {8, 1001}, {129, 255}};
+        unsigned long evaluated = 0;
+        NPH_GetLazyStats(&st0);
+        const unsigned long long l0 = launches();
+        unsigned long long l_lazy = 0, l_eager = 0;
+        for (unsigned seed = 0; seed < 12; seed++) {
+            const int rows = kShapes[seed % 4][0], cols = kShapes[seed % 4][1];
+            const unsigned long long before = launches();
+            const unsigned long long lazy_digest = stress(1, seed, 400, rows, cols, &evaluated);
+            CHECK(NPH_PendingCount() == 0, "stress %u: %d chains pending after every variable was released", seed, NPH_PendingCount());
+            const unsigned long long mid = launches();
+            const unsigned long long eager_digest = stress(0, seed, 400, rows, cols, &evaluated);
+            l_lazy += mid - before;
+            l_eager += launches() - mid;
+            CHECK(lazy_digest == eager_digest, "stress %u (%d x %d): values differ between chains on (%016llx) and off (%016llx)", seed, rows, cols,
+                  lazy_digest, eager_digest);
+        }
+        NPH_GetLazyStats(&st1);
+        printf("stress: 12 random programs of 400 statements, %lu values read on the way: identical with chains on and off; %llu launches with chains, "
+               "%llu without (chains flushed %lu holding %lu steps, discarded %lu, eager steps %lu)\n", evaluated / 2, l_lazy, l_eager,
+               st1.flushed_chains - st0.flushed_chains, st1.flushed_steps - st0.flushed_steps, st1.discarded_chains - st0.discarded_chains,
+               st1.eager_steps - st0.eager_steps);
+        (void) l0;
     }
     CHECK(NPH_PendingCount() == 0, "%d chains pending at the end", NPH_PendingCount());
     zval_dtor(&e.x); zval_dtor(&e.y); zval_dtor(&e.p); zval_dtor(&e.row); zval_dtor(&e.col); zval_dtor(&e.wide); zval_dtor(&e.w);
