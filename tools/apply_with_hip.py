@@ -1062,11 +1062,11 @@ static zval e_pow_number(Env *e) { return op2(ZEND_POW, UN(sqrt, e->p, 0), numbe
 /* 2 ** $x: the number is the BASE (swap) - the general pow, not a square */
 static zval e_pow_base2(Env *e) { return op2(ZEND_ADD, op2(ZEND_POW, number(2.0), e->x, 0, 0), number(1.0), 1, 0); }
 
-/* ---- stress: a seeded random PROGRAM over a pool of PHP variables — operators (arrays, numbers, pending values, views), unary
+/* ---- stress: a seeded random PROGRAM over a pool of 20 (or 96) PHP variables — operators (arrays, numbers, pending values, views), unary
  * methods, assignments over live variables, unset(), in-place writes (directly and through a view), reductions, reads — evaluated
  * through the inserted text exactly as the expressions above.  Run twice, chains on and off: every value read on the way and every
  * variable alive at the end must agree bit for bit (NaNs as NaNs), nothing may stay pending, no device allocation may leak. ---- */
-enum { kPool = 20 };
+enum { kPoolMax = 96 };      /* more variables than the table of pending chains has rows (NPH_MAX_PENDING = 64) */
 typedef struct Rng { unsigned long long s; } Rng;
 static unsigned rnd(Rng *r, unsigned n) {
     r->s = r->s * 6364136223846793005ULL + 1442695040888963407ULL;
@@ -1105,20 +1105,21 @@ static zval fresh_leaf(Rng *r, int rows, int cols, int serial) {
         default: return placed(s2, 2, 400 + serial, -2.0f, 2.0f, 1);
     }
 }
-static unsigned long long stress(int lazy, unsigned seed, int n_steps, int rows, int cols, unsigned long *evaluated) {
+static int g_stress_most_pending;
+static unsigned long long stress(int lazy, unsigned seed, int n_steps, int rows, int cols, int kPool, unsigned long *evaluated) {
     static const int kOps[6] = {ZEND_ADD, ZEND_SUB, ZEND_MUL, ZEND_DIV, ZEND_MOD, ZEND_POW};
     Rng r = {seed * 2654435761ULL + 12345ULL};
-    zval pool[kPool];
+    zval pool[kPoolMax];
     unsigned long long h = 1469598103934665603ULL;
     int serial = 0;
     NPH_SetLazy(lazy);
     for (int i = 0; i < kPool; i++) {
         pool[i].type = IS_UNDEF;
-        if (i < 8) pool[i] = fresh_leaf(&r, rows, cols, serial++);
+        if (i < 8 || i < kPool / 3) pool[i] = fresh_leaf(&r, rows, cols, serial++);
     }
     for (int step = 0; step < n_steps; step++) {
         const unsigned what = rnd(&r, 100);
-        const int a = (int) rnd(&r, kPool), b = (int) rnd(&r, kPool), dst = (int) rnd(&r, kPool);
+        const int a = (int) rnd(&r, (unsigned) kPool), b = (int) rnd(&r, (unsigned) kPool), dst = (int) rnd(&r, (unsigned) kPool);
         zval result = {IS_UNDEF, 0.0, 0};
         if (Z_TYPE_P(&pool[a]) != IS_OBJECT) {             /* an unset variable: give it a new array */
             pool[a] = fresh_leaf(&r, rows, cols, serial++);
@@ -1169,6 +1170,7 @@ static unsigned long long stress(int lazy, unsigned seed, int n_steps, int rows,
         }
         zval_dtor(&pool[dst]);                              /* assignment: the old value of $dst goes once the new one exists */
         pool[dst] = result;
+        if (NPH_PendingCount() > g_stress_most_pending) g_stress_most_pending = NPH_PendingCount();
     }
     for (int i = 0; i < kPool; i++) {
         h = digest_value(h, &pool[i]);
@@ -1421,21 +1423,24 @@ int main(int argc, char **argv) {
         unsigned long long l_lazy = 0, l_eager = 0;
         for (unsigned seed = 0; seed < 12; seed++) {
             const int rows = kShapes[seed % 4][0], cols = kShapes[seed % 4][1];
+            const int vars = seed < 8 ? 20 : kPoolMax;      /* the last four: more live variables than the table of pending chains holds */
             const unsigned long long before = launches();
-            const unsigned long long lazy_digest = stress(1, seed, 400, rows, cols, &evaluated);
+            const int statements = seed < 8 ? 400 : 1200;
+            const unsigned long long lazy_digest = stress(1, seed, statements, rows, cols, vars, &evaluated);
             CHECK(NPH_PendingCount() == 0, "stress %u: %d chains pending after every variable was released", seed, NPH_PendingCount());
             const unsigned long long mid = launches();
-            const unsigned long long eager_digest = stress(0, seed, 400, rows, cols, &evaluated);
+            const unsigned long long eager_digest = stress(0, seed, statements, rows, cols, vars, &evaluated);
             l_lazy += mid - before;
             l_eager += launches() - mid;
             CHECK(lazy_digest == eager_digest, "stress %u (%d x %d): values differ between chains on (%016llx) and off (%016llx)", seed, rows, cols,
                   lazy_digest, eager_digest);
         }
         NPH_GetLazyStats(&st1);
-        printf("stress: 12 random programs of 400 statements, %lu values read on the way: identical with chains on and off; %llu launches with chains, "
-               "%llu without (chains flushed %lu holding %lu steps, discarded %lu, eager steps %lu)\n", evaluated / 2, l_lazy, l_eager,
-               st1.flushed_chains - st0.flushed_chains, st1.flushed_steps - st0.flushed_steps, st1.discarded_chains - st0.discarded_chains,
-               st1.eager_steps - st0.eager_steps);
+        printf("stress: 12 random programs of 400 / 1200 statements, %lu values read on the way: identical with chains on and off; %llu launches with chains, "
+               "%llu without (chains flushed %lu holding %lu steps, discarded %lu, eager steps %lu; at most %d chains pending at once)\n", evaluated / 2,
+               l_lazy, l_eager, st1.flushed_chains - st0.flushed_chains, st1.flushed_steps - st0.flushed_steps,
+               st1.discarded_chains - st0.discarded_chains, st1.eager_steps - st0.eager_steps, g_stress_most_pending);
+        CHECK(g_stress_most_pending == NPH_MAX_PENDING, "the stress never filled the table of pending chains (%d of %d)", g_stress_most_pending, NPH_MAX_PENDING);
         (void) l0;
     }
     CHECK(NPH_PendingCount() == 0, "%d chains pending at the end", NPH_PendingCount());
