@@ -69,7 +69,7 @@ def _binary(env, op, a, b):
     pa, ta = _marshal(h, a)
     pb, tb = _marshal(h, b)
     fn = {"add": "NDArray_Add_Float", "subtract": "NDArray_Subtract_Float", "multiply": "NDArray_Multiply_Float",
-          "divide": "NDArray_Divide_Float", "mod": "NDArray_Mod_Float"}[op]
+          "divide": "NDArray_Divide_Float", "mod": "NDArray_Mod_Float", "pow": "NDArray_Pow_Float"}[op]
     r = h.NPH_LazyBinary(_lib.BINARY_OPS[op], _fn(h, fn), pa, pb)
     if ta:
         h.NDArray_FREE(pa)                    # CHECK_INPUT_AND_FREE

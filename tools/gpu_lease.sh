@@ -12,6 +12,8 @@
 #   sweeps     GEMM shape sweeps, the layout and misc sweeps, the compiled-chain A/B
 #   evidence   all of the above, in that order (the round's evidence run)
 #   fuzz       the long random-shape parity sweeps (tests/test_gpu_fuzz.py x 400, GEMM tiles / splits, compiled chains)
+#   binding    the GPU suite with NP_LAZY_BINDING=1, lazy_bodies, the square-step chains, the peer-process tests (verbose)
+#   after      cleanbuild + fuzz + binding: what follows the evidence lease on the same kernel stamp
 #   cleanbuild a copy of the SOURCES (no prebuilt library, no object files) built from scratch with the box's own hipcc, then
 #              smoke() and a slice of the GPU suite against THAT build (the leases otherwise run the .so files pushed from the
 #              build container: VERDICT r03 #15)
@@ -133,6 +135,16 @@ r_fuzz() {
     timeout 400 python tools/gemm_deep_k_fuzz.py 200 3 2>&1 | tail -4 > "$O/gemm_deep_k_fuzz.log"; cat "$O/gemm_deep_k_fuzz.log"
 }
 
+r_binding() {
+    # what the round built behind the binding and around the communicator, on the final library: the GPU suite with the Python stand-in
+    # appending to pending chains, the inserted text as a program (with its random programs), the chains with a
+    # square step, and the peer-process tests one by one
+    NP_LAZY_BINDING=1 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 > "$O/pytest_lazy_binding.log"; tail -2 "$O/pytest_lazy_binding.log"
+    timeout 300 numpower_amd/lib/lazy_bodies gpu /tmp/lazy_bodies.bin > "$O/lazy_bodies.log" 2>&1; tail -3 "$O/lazy_bodies.log"
+    timeout 300 python tools/sq_chain_probe.py 2 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" > "$O/sq_chain_probe.log"; tail -3 "$O/sq_chain_probe.log"
+    timeout 600 python -m pytest tests/test_gpu_comm_loopback_peers.py tests/test_gpu_comm_multi.py -v --durations=0 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -40 > "$O/pytest_peers.log"; tail -3 "$O/pytest_peers.log"
+}
+
 case "$RECIPE" in
     tests) r_tests ;;
     bench) r_bench ;;
@@ -144,5 +156,7 @@ case "$RECIPE" in
     evidence) r_tests; r_bench; r_world1; r_peers; r_profile; r_counters; r_sweeps ;;
     cleanbuild) r_cleanbuild ;;
     fuzz) r_fuzz ;;
-    *) echo "unknown recipe $RECIPE (tests | bench | world1 | peers | profile | counters | sweeps | evidence | cleanbuild | fuzz)"; exit 2 ;;
+    binding) r_binding ;;
+    after) r_cleanbuild; r_fuzz; r_binding ;;
+    *) echo "unknown recipe $RECIPE (tests | bench | world1 | peers | profile | counters | sweeps | evidence | cleanbuild | fuzz | binding | after)"; exit 2 ;;
 esac
