@@ -3,6 +3,7 @@
   mean   mean((x - y) ** 2)       8 B/elem      next to sum((x - y) * 0.5)
   norm   sum(x ** 2)              4 B/elem      next to sum(exp(x))
   axis   sum((x - y) ** 2, axis)  8 B/elem      next to sum((x - y) * 0.5, axis)
+  twice  x * y + x and (x - y) * y  12 B/elem     an operand named twice: input 0 again, another array again
 np_elementwise_set_variant(7000) forces the interpreter for the right-hand forms (what a chain off the menu runs on).
 Usage: python tools/sq_chain_probe.py [rounds]"""
 import ctypes as C
@@ -51,12 +52,18 @@ half = C.c_float(0.5)
 mul_diff = chain([(B, SUB, 1, 0, 0, 0, 0, 0), (B, MUL, 2, 0, 0, 0, 0, 0)], [dx.ptr, dy.ptr, C.addressof(half)], [0, 0, HOST])
 sq = chain([(B, POW, 1, 0, 0, 0, 0, 0)], [dx.ptr, C.addressof(two)], [0, HOST])
 ex = chain([(U, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0)], [dx.ptr], [0])
+ADD = BINARY_OPS["add"]
+# an operand named twice: input 0 again (re-read where it is used) and another array again (streamed twice)
+x_again = chain([(B, MUL, 1, 0, 0, 0, 0, 0), (B, ADD, 0, 0, 0, 0, 0, 0)], [dx.ptr, dy.ptr], [0, 0])
+y_again = chain([(B, SUB, 1, 0, 0, 0, 0, 0), (B, MUL, 1, 0, 0, 0, 0, 0)], [dx.ptr, dy.ptr], [0, 0])
 res = C.c_float()
 out_r, out_c = D.DeviceArray((R,)), D.DeviceArray((Cc,))
 
 cases = [
     ("store (x-y)**2", 12, lambda: check(lib.np_fused_chain(*sq_diff, do.ptr, 1, N))),
     ("store (x-y)*.5", 12, lambda: check(lib.np_fused_chain(*mul_diff, do.ptr, 1, N))),
+    ("store x*y+x", 12, lambda: check(lib.np_fused_chain(*x_again, do.ptr, 1, N))),
+    ("store (x-y)*y", 12, lambda: check(lib.np_fused_chain(*y_again, do.ptr, 1, N))),
     ("mean((x-y)**2)", 8, lambda: check(lib.np_fused_chain_reduce(*sq_diff, 4, 1, N, C.byref(res)))),
     ("sum((x-y)*.5)", 8, lambda: check(lib.np_fused_chain_reduce(*mul_diff, 0, 1, N, C.byref(res)))),
     ("sum(x**2)", 4, lambda: check(lib.np_fused_chain_reduce(*sq, 0, 1, N, C.byref(res)))),
