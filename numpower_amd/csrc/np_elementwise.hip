@@ -713,7 +713,11 @@ __device__ __forceinline__ void binary_dispatch(int op, float (&acc)[N], const f
 // load of the next array operand is issued as soon as the previous one has been consumed, so it is
 // in flight while the steps in between compute; with input 0 that keeps two loads outstanding per
 // thread without holding every input in registers (which cost occupancy: 6 inputs x 8 values).
-template <int U, int G, typename I, bool RAGGED = false>
+// KEEP: the kernel variant for chains that name a full array MORE THAN ONCE (f(x) * y + x, (x - y) * y): full arrays are read with
+// plain loads, so that the second read of a line finds it in the L2 — non-temporal loads do not leave it there and the array
+// was streamed from HBM twice (10^8 elements: x * y + x 247 us = 16 B/elem -> 192 us; tools/sq_chain_probe.py).  A kernel of its
+// own: the choice as a run-time branch in the common kernel cost the other chains 3-7 % (registers, occupancy 8 -> 7).
+template <int U, int G, typename I, bool RAGGED = false, bool KEEP = false>
 __device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p, int idx, const I (&first)[U],
                                             const I (&row)[U], const I (&col)[U], const bool (&live)[U],
                                             I ragged_cols = 0) {
@@ -722,11 +726,15 @@ __device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p,
         for (int u = 0; u < U; ++u) {
             if constexpr (G == 4) {
                 v4f t = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-                if (live[u]) t = __builtin_nontemporal_load((const v4f_u *)(p + (size_t)first[u]));
+                if constexpr (KEEP) {
+                    if (live[u]) t = *(const v4f_u *)(p + (size_t)first[u]);
+                } else {
+                    if (live[u]) t = __builtin_nontemporal_load((const v4f_u *)(p + (size_t)first[u]));
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dst[u * 4 + e] = t[e];
             } else {
-                dst[u] = live[u] ? __builtin_nontemporal_load(p + (size_t)first[u]) : 0.0f;
+                dst[u] = live[u] ? (KEEP ? p[(size_t)first[u]] : __builtin_nontemporal_load(p + (size_t)first[u])) : 0.0f;
             }
         }
     } else if (idx == FUSED_IDX_ROW) {
@@ -778,7 +786,7 @@ __device__ __forceinline__ void fused_fetch(float (&dst)[U * G], const float *p,
 
 // VACC: the sink accumulates per register element (rv[u * G + e], for column reductions where every
 // element of a slot belongs to a different result) instead of into the one scalar racc.
-template <int U, int G, bool LIGHT, typename I, bool VACC, bool RAGGED = false>
+template <int U, int G, bool LIGHT, typename I, bool VACC, bool RAGGED = false, bool KEEP = false>
 __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict__ out, I elem0, I nslots, I tid,
                                                 I stride, float &racc, float (&rv)[U * G]) {
     constexpr int N = U * G;
@@ -809,17 +817,17 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
             }
         }
         // the chain value starts as input 0 and lives in acc from the first load on: input 0 is not kept in a second
-        // set of registers for the rare step that names it again (x * x ...) — that step re-reads it (an L2 hit), and
-        // every other chain saves N registers and N moves per trip
+        // set of registers for the rare step that names it again (x * x ...) — that step re-reads it (an L2 hit in the KEEP
+        // variant of the kernel, which such chains get), and every other chain saves N registers and N moves per trip
         float acc[N], nxt[N];
         if (in0) {
-            fused_fetch<U, G, I>(acc, in0, FUSED_IDX_FULL, first, row, col, live);
+            fused_fetch<U, G, I, false, KEEP>(acc, in0, FUSED_IDX_FULL, first, row, col, live);
         } else {
 #pragma unroll
             for (int e = 0; e < N; ++e) acc[e] = scalar0;
         }
         if (first_prefetch) {
-            fused_fetch<U, G, I, RAGGED>(nxt, first_prefetch, first_prefetch_idx, first, row, col, live, ragged_cols);
+            fused_fetch<U, G, I, RAGGED, KEEP>(nxt, first_prefetch, first_prefetch_idx, first, row, col, live, ragged_cols);
         } else {
 #pragma unroll
             for (int e = 0; e < N; ++e) nxt[e] = 0.0f;
@@ -846,7 +854,7 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
                 for (int e = 0; e < N; ++e) oth[e] = nxt[e];
             } else if (o.src_kind == FUSED_SRC_INPUT0) {
                 if (in0) {
-                    fused_fetch<U, G, I>(oth, in0, FUSED_IDX_FULL, first, row, col, live);
+                    fused_fetch<U, G, I, false, KEEP>(oth, in0, FUSED_IDX_FULL, first, row, col, live);
                 } else {
 #pragma unroll
                     for (int e = 0; e < N; ++e) oth[e] = scalar0;
@@ -861,7 +869,7 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
                 body[e] = (size_t)first[e / G] < o.body_end;
             }
             if (o.src_kind == FUSED_SRC_STREAM && o.prefetch)
-                fused_fetch<U, G, I, RAGGED>(nxt, o.prefetch, o.prefetch_idx, first, row, col, live, ragged_cols);
+                fused_fetch<U, G, I, RAGGED, KEEP>(nxt, o.prefetch, o.prefetch_idx, first, row, col, live, ragged_cols);
             binary_dispatch<N, LIGHT>(o.op, acc, oth, o.swap != 0, o.quirk != 0, body);
         }
         if constexpr (VACC) {
@@ -914,11 +922,11 @@ __device__ __forceinline__ void fused_span_impl(FusedArgsK f, float *__restrict_
     }
 }
 
-template <int U, int G, bool LIGHT, typename I, bool RAGGED = false>
+template <int U, int G, bool LIGHT, typename I, bool RAGGED = false, bool KEEP = false>
 __device__ __forceinline__ void fused_span(FusedArgsK f, float *__restrict__ out, I elem0, I nslots, I tid,
                                            I stride, float &racc) {
     float unused[U * G];
-    fused_span_impl<U, G, LIGHT, I, false, RAGGED>(f, out, elem0, nslots, tid, stride, racc, unused);
+    fused_span_impl<U, G, LIGHT, I, false, RAGGED, KEEP>(f, out, elem0, nslots, tid, stride, racc, unused);
 }
 
 __device__ __forceinline__ float sink_identity(int sink) {
@@ -1046,7 +1054,7 @@ __global__ __launch_bounds__(256) void fused_chain_cols_kernel(FusedArgs by_valu
     }
 }
 
-template <bool VEC, int U, bool LIGHT, typename I, bool RAGGED = false>
+template <bool VEC, int U, bool LIGHT, typename I, bool RAGGED = false, bool KEEP = false>
 __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, float *__restrict__ out, I n) {
     (void)by_value;   // first kernel argument: lives at offset 0 of the kernarg segment
     FusedArgsK f = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1056,7 +1064,7 @@ __global__ __launch_bounds__(256) void fused_chain_kernel(FusedArgs by_value, fl
     float racc = sink == NP_SUM ? 0.0f : sink == NP_PROD ? 1.0f : sink == NP_MIN ? INFINITY : -INFINITY;
     if constexpr (VEC) {
         const I nvec = n / 4;
-        fused_span<U, 4, LIGHT, I, RAGGED>(f, out, (I)0, nvec, tid, stride, racc);
+        fused_span<U, 4, LIGHT, I, RAGGED, KEEP>(f, out, (I)0, nvec, tid, stride, racc);
         fused_span<1, 1, LIGHT, I>(f, out, nvec * 4, n - nvec * 4, tid, stride, racc);   // ragged tail (< 4 elements)
     } else {
         fused_span<U, 1, LIGHT, I>(f, out, (I)0, n, tid, stride, racc);   // 4-byte aligned views
@@ -1283,6 +1291,20 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     f.scalar0 = input_kinds[0] == NP_FULL ? 0.0f : *inputs[0];
     f.first_prefetch = nullptr;
     f.first_prefetch_idx = FUSED_IDX_FULL;
+    // does the chain name a full array more than once (as the operand of several steps, or input 0 again)?  Such a chain runs
+    // on the interpreter's KEEP variant (see fused_fetch); np_elementwise_set_variant(7002): as every other chain (A/B)
+    bool names_twice = false;
+    if (g_variant != 7002) {
+        for (int i = 0; i < n_inputs && !names_twice; ++i) {
+            if (input_kinds[i] != NP_FULL) continue;
+            int uses = (i == 0) ? 1 : 0;                       // input 0 is the chain's first value
+            for (int k = 0; k < n_ops; ++k)
+                if (ops[k].kind == NP_FUSED_BINARY && ops[k].operand >= 0 && ops[k].operand < n_inputs &&
+                    input_kinds[ops[k].operand] == NP_FULL && inputs[ops[k].operand] == inputs[i])
+                    ++uses;
+            names_twice = uses >= 2;
+        }
+    }
     f.cols = broadcast ? cols : 0;
     f.sink = sink;
     f.ticket = nullptr;
@@ -1322,7 +1344,7 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     // input 0, float4-divisible rows under a broadcast, 32-bit indices, no AVX-body quirk (variant 7000: interpreter only)
     np::FusedStaticDesc sd{};
     bool compiled = n_ops >= 1 && n_ops <= 3 && f.in0 && vec && (!broadcast || cols % 4 == 0) && n < (size_t(1) << 31) &&
-                    g_variant != 7000;
+                    g_variant != 7000 && (!names_twice || g_variant == 7001);   // (the compiled kernels stream every array: 7001 = A/B)
     sd.n_ops = n_ops;
     sd.in0 = f.in0;
     sd.bcast_cols = broadcast ? (unsigned)cols : 0u;
@@ -1594,6 +1616,10 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
         }
     } else if (!vec) {
         if (light) NP_FC(false, 2, true); else NP_FC(false, 2, false);
+    } else if (names_twice && small && fu == 2 && g_variant != 7001) {
+        const unsigned grid = reduce_blocks ? reduce_blocks : grid_for(n / 4 + 1, 2, 0);
+        if (light) fused_chain_kernel<true, 2, true, uint32_t, false, true><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);
+        else fused_chain_kernel<true, 2, false, uint32_t, false, true><<<grid, 256, 0, s>>>(f, out, (uint32_t)n);
     } else if (fu == 1) {
         if (light) NP_FC(true, 1, true); else NP_FC(true, 1, false);
     } else {

@@ -378,3 +378,35 @@ def test_pow_steps_are_the_stand_alone_pow_bit_for_bit(shape, hip, oracle):
     for axis in (0, 1):
         got = ((gx.lazy() - gy) ** 2).sum(axis=axis).cpu().numpy().astype(np.float64)
         assert (np.abs(got - d64.sum(axis=axis)) <= 1e-5 * d64.sum(axis=axis)).all(), axis
+
+
+@pytest.mark.parametrize("shape", [(2000, 3000), (257, 1001), (3, 5)])
+def test_chains_that_name_an_array_twice(shape, hip, oracle):
+    """f(x) * y + x and (x - y) * y name a full array twice: such chains run on the interpreter's KEEP variant (plain loads, so the
+    second read of a line is an L2 hit instead of a second stream from HBM) — the arithmetic is the same code: bit-identical to the
+    op-by-op sequence and to the same chain on the common kernel (np_elementwise_set_variant(7002))."""
+    from numpower_amd._lib import check, load
+    from numpower_amd.lazy import Lazy   # noqa: F401
+    from numpower_amd.ndarray import NDArray
+    lib = load()
+    x = synth.uniform(shape, 291, -2.0, 2.0)
+    y = synth.uniform(shape, 292, 0.5, 2.0)
+    x.reshape(-1)[::9] = 0.0
+    gx, gy = NDArray.array(x).gpu(), NDArray.array(y).gpu()
+    cases = {"tanh(x)*y+x": (lambda: (gx.lazy().tanh() * gy + gx), lambda: NDArray.tanh(gx) * gy + gx),
+             "(x-y)*y": (lambda: (gx.lazy() - gy) * gy, lambda: (gx - gy) * gy),
+             "x*y+x-y": (lambda: gx.lazy() * gy + gx - gy, lambda: gx * gy + gx - gy),
+             "x*x*x": (lambda: gx.lazy() * gx * gx, lambda: gx * gx * gx)}
+    for name, (lz, eager) in cases.items():
+        want = eager().cpu().numpy()
+        got = lz().eval().cpu().numpy()
+        assert _same(got, want), name
+        check(lib.np_elementwise_set_variant(7002))
+        try:
+            assert _same(lz().eval().cpu().numpy(), want), name + " (common kernel)"
+        finally:
+            check(lib.np_elementwise_set_variant(0))
+    want = oracle.binary("multiply", oracle.binary("subtract", x, y), y)      # exact ops, incl. multiply's zero-sign quirk
+    assert _same(((gx.lazy() - gy) * gy).eval().cpu().numpy(), want)
+    s64 = ((x.astype(np.float64) - y) * y).sum()
+    assert abs(((gx.lazy() - gy) * gy).sum() - s64) <= 1e-5 * np.abs((x.astype(np.float64) - y) * y).sum()

@@ -4,7 +4,9 @@
   norm   sum(x ** 2)              4 B/elem      next to sum(exp(x))
   axis   sum((x - y) ** 2, axis)  8 B/elem      next to sum((x - y) * 0.5, axis)
   twice  x * y + x and (x - y) * y  12 B/elem     an operand named twice: input 0 again, another array again
-np_elementwise_set_variant(7000) forces the interpreter for the right-hand forms (what a chain off the menu runs on).
+np_elementwise_set_variant(7000) forces the interpreter for the right-hand forms (what a chain off the menu runs on); 7001 lets the
+compiled kernels take chains with a twice-named array (they stream it twice), 7002 is the interpreter without the plain loads for
+twice-named arrays (round 5's behaviour).
 Usage: python tools/sq_chain_probe.py [rounds]"""
 import ctypes as C
 import sys
@@ -74,7 +76,7 @@ cases = [
     ("sum((x-y)*.5, 1)", 8, lambda: check(lib.np_fused_chain_reduce_axis(*mul_diff, 0, R, Cc, 1, out_r.ptr))),
 ]
 for rnd in range(rounds):
-    for v in (0, 7000):
+    for v in (0, 7000, 7001, 7002):
         check(lib.np_elementwise_set_variant(v))
         for name, bpe, fn in cases:
             us = timed(fn)
