@@ -1341,7 +1341,7 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     FusedStep *last_stream = nullptr;
     bool light = true;
     // the same chain as np_fused_static.hip wants it, while it still may be one of the compiled ones: 1-3 steps on a full
-    // input 0, float4-divisible rows under a broadcast, 32-bit indices, no AVX-body quirk (variant 7000: interpreter only)
+    // input 0, float4-divisible rows under a broadcast, 32-bit indices, no AVX-body quirk other than multiply's (variant 7000: interpreter only)
     np::FusedStaticDesc sd{};
     bool compiled = n_ops >= 1 && n_ops <= 3 && f.in0 && vec && (!broadcast || cols % 4 == 0) && n < (size_t(1) << 31) &&
                     g_variant != 7000 && (!names_twice || g_variant == 7001);   // (the compiled kernels stream every array: 7001 = A/B)
@@ -1409,8 +1409,18 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
             sd.p0[k] = d.p0;
             sd.p1[k] = d.p1;
             sd.scalar[k] = d.scalar;
+            sd.quirk[k] = 0;
+            sd.body_end[k] = 0;
             if (d.kind == NP_FUSED_BINARY) {
-                if (d.quirk) compiled = false;
+                // the AVX-body quirk: the compiled kernels know multiply's (what the binding's chains carry); mod / equal are not on their menu
+                if (d.quirk && binary_has_quirk(d.op)) {
+                    if (d.op == NP_MULTIPLY) {
+                        sd.quirk[k] = 1;
+                        sd.body_end[k] = (unsigned)(d.body_end < n ? d.body_end : n);
+                    } else {
+                        compiled = false;
+                    }
+                }
                 const int kind = input_kinds[o.operand];
                 sd.operand[k] = d.src_kind == FUSED_SRC_SCALAR ? nullptr : d.src_kind == FUSED_SRC_INPUT0 ? f.in0 : inputs[o.operand];
                 sd.idx[k] = d.src_kind != FUSED_SRC_STREAM ? 0 : kind == NP_FULL ? 0 : kind == NP_ROW ? 1 : kind == NP_COL ? 2 : 3;

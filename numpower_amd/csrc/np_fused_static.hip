@@ -15,8 +15,9 @@
 // interpreter and to the op-by-op sequence (tests/test_gpu_fusion.py); a chain that ends in a reduction folds in a
 // different order than the interpreter (more accumulators) and is held to the same 1e-5 bar.
 //
-// Chains that are not on the menu (np_fused_static_covers), that carry the AVX-body quirk flag, whose broadcast rows are
-// not float4-divisible, or that are larger than 2^31 elements go to the interpreter as before.
+// Chains that are not on the menu (np_fused_static_covers), that carry the AVX-body quirk flag on an op other than multiply (or
+// on a multiply under a first-axis sum), whose broadcast rows are not float4-divisible, or that are larger than 2^31 elements go
+// to the interpreter as before.  Multiply's quirk — what every chain of the PHP binding carries — is known here (CArgs::quirk).
 // np_elementwise_set_variant(7000) sends everything there (A/B, tools/fused_static_ab.py).
 #include <type_traits>
 
@@ -48,6 +49,11 @@ struct CArgs {
     const float *operand[3];
     int idx[3];
     float scalar[3], p0[3], p1[3];
+    // a multiply step that carries NP_QUIRK_AVX_BODY (what the PHP binding's chains do: the reference's AVX2 body writes every zero
+    // product as -0.0f, its scalar tail as +0.0f, arithmetics.c:403,410-412): quirk[k] != 0, body = flat index < body_end[k].
+    // Flat kernels only (the axis kernels are not given such chains: fused_static_covers).
+    int quirk[3];
+    unsigned body_end[3];
     unsigned cols, div_m, div_s1, div_s2;   // row length of the result when an operand is broadcast, else 0
     unsigned *ticket;                       // full reduction on a small grid: the last workgroup folds (np_internal.h)
     float *result;
@@ -71,10 +77,25 @@ __device__ __forceinline__ v4f c_fetch(const float *p, int idx, unsigned first, 
 }
 
 // step K of the chain on the N values a lane holds
+// `firsts`: the flat index of the first element of each float4 slot (N == 1: of the element) — only read by a multiply step with
+// the AVX-body quirk; the axis kernels pass nullptr
 template <class CH, int K, int N>
-__device__ __forceinline__ void c_step(const CArgs &a, float (&acc)[N], const float (&oth)[3][N]) {
+__device__ __forceinline__ void c_step(const CArgs &a, float (&acc)[N], const float (&oth)[3][N], const unsigned *firsts = nullptr) {
     if constexpr (K < CH::n) {
         constexpr int s = CH::at(K), OP = cs_op(s);
+        if constexpr (OP == NP_MULTIPLY && cs_kind(s) != CK_UNARY) {
+            if (a.quirk[K]) {   // uniform
+                const unsigned be = a.body_end[K];
+                const float c = a.scalar[K];
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    const bool body = (N == 1 ? firsts[0] : firsts[e / 4] + (unsigned)(e & 3)) < be;
+                    const float o = cs_kind(s) == CK_SCALAR ? c : oth[K][e];
+                    acc[e] = cs_swap(s) ? binary_apply<NP_MULTIPLY, true>(o, acc[e], body) : binary_apply<NP_MULTIPLY, true>(acc[e], o, body);
+                }
+                return;
+            }
+        }
         if constexpr (cs_kind(s) == CK_UNARY) {
             const float p0 = a.p0[K], p1 = a.p1[K];
 #pragma unroll
@@ -116,9 +137,9 @@ __device__ __forceinline__ void c_trip_at(const CArgs &a, const unsigned (&first
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[u * 4 + e] = x[u][e];
-    c_step<CH, 0, U * 4>(a, acc, oth);
-    c_step<CH, 1, U * 4>(a, acc, oth);
-    c_step<CH, 2, U * 4>(a, acc, oth);
+    c_step<CH, 0, U * 4>(a, acc, oth, first);
+    c_step<CH, 1, U * 4>(a, acc, oth, first);
+    c_step<CH, 2, U * 4>(a, acc, oth, first);
 }
 
 // ... with (row, col) derived from the flat index (the flat kernels)
@@ -149,9 +170,9 @@ __device__ __forceinline__ float c_element(const CArgs &a, unsigned e) {
     for (int k = 0; k < 3; ++k)
         if (k < CH::n && cs_kind(CH::at(k)) == CK_ARRAY)
             oth[k][0] = a.operand[k][a.idx[k] == 0 ? (size_t)e : a.idx[k] == 1 ? (size_t)col : a.idx[k] == 2 ? (size_t)row : (size_t)0];
-    c_step<CH, 0, 1>(a, acc, oth);
-    c_step<CH, 1, 1>(a, acc, oth);
-    c_step<CH, 2, 1>(a, acc, oth);
+    c_step<CH, 0, 1>(a, acc, oth, &e);
+    c_step<CH, 1, 1>(a, acc, oth, &e);
+    c_step<CH, 2, 1>(a, acc, oth, &e);
     return acc[0];
 }
 
@@ -359,9 +380,12 @@ __global__ __launch_bounds__(256) void cchain_tile2d_kernel(CArgs a, float *__re
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[u * 4 + e] = x[u][e];
-        c_step<CH, 0, U * 4>(a, acc, oth);
-        c_step<CH, 1, U * 4>(a, acc, oth);
-        c_step<CH, 2, U * 4>(a, acc, oth);
+        unsigned firsts[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) firsts[u] = (r + u) * cols + c0;   // (only a quirk-carrying multiply reads them)
+        c_step<CH, 0, U * 4>(a, acc, oth, firsts);
+        c_step<CH, 1, U * 4>(a, acc, oth, firsts);
+        c_step<CH, 2, U * 4>(a, acc, oth, firsts);
 #pragma unroll
         for (int u = 0; u < U; ++u)
             __builtin_nontemporal_store(v4f{acc[u * 4], acc[u * 4 + 1], acc[u * 4 + 2], acc[u * 4 + 3]}, (v4f_u *)(out + (size_t)(r + u) * cols + c0));
@@ -529,6 +553,8 @@ void fill_args(const np::FusedStaticDesc &d, CArgs &a) {
         a.scalar[k] = k < d.n_ops ? d.scalar[k] : 0.0f;
         a.p0[k] = k < d.n_ops ? d.p0[k] : 0.0f;
         a.p1[k] = k < d.n_ops ? d.p1[k] : 0.0f;
+        a.quirk[k] = k < d.n_ops ? d.quirk[k] : 0;
+        a.body_end[k] = k < d.n_ops ? d.body_end[k] : 0u;
     }
     a.cols = d.bcast_cols;
     a.div_m = d.div_m;
@@ -545,7 +571,9 @@ namespace np {
 bool fused_static_covers(const FusedStaticDesc &d, int sink, int axis_mode) {
     const Launchers *l = find_chain(d);
     if (!l) return false;
-    if (axis_mode == 0 || axis_mode == 1) return sink == NP_SUM;
+    const bool quirk = d.quirk[0] || d.quirk[1] || d.quirk[2];
+    if (axis_mode == 0) return sink == NP_SUM && !quirk;          // the column kernel has no flat index at hand for the AVX-body line
+    if (axis_mode == 1) return sink == NP_SUM;
     return sink < 0 ? l->flat_store != nullptr : sink == NP_SUM;
 }
 

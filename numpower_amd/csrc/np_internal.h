@@ -103,6 +103,8 @@ struct FusedStaticDesc {
     int kind[3], op[3], swap[3], idx[3];
     const float *operand[3];
     float scalar[3], p0[3], p1[3];
+    int quirk[3];            // a multiply step with NP_QUIRK_AVX_BODY (flat kernels only) ...
+    unsigned body_end[3];    // ... whose AVX2 body ends at this flat index
     unsigned bcast_cols, div_m, div_s1, div_s2;
 };
 // sink < 0: the chain value is stored; else NP_SUM ... ; axis_mode -1 flat, 0 first axis, 1 last axis

@@ -99,6 +99,12 @@ for rnd in range(rounds):
     case("exp(a)*b+2", 12.0 * N, lambda: check(lib.np_fused_chain(ptrs3, kinds3, 3, prog3, 3, do.ptr, 1, N)), "store")
     case("sum(exp(a)*b+2)", 8.0 * N, lambda: check(lib.np_fused_chain_reduce(ptrs3, kinds3, 3, prog3, 3, 0, 1, N, C.byref(res))), "sum", sum3)
     case("sum(exp(a))", 4.0 * N, lambda: check(lib.np_fused_chain_reduce(ptrs1, kinds1, 1, prog1, 1, 0, 1, N, C.byref(res))), "sum", float(e64.sum()))
+    # the same chain as the PHP binding builds it: the multiply carries NP_QUIRK_AVX_BODY + the end of the reference's AVX2 body
+    prog3q = (FusedOp * 3)(FusedOp(0, UNARY_OPS["exp"], 0, 0, 0, 0, 0, 0),
+                           FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 1, N - N % 8),
+                           FusedOp(1, BINARY_OPS["add"], 2, 0, 0, 0, 0, 0))
+    case("exp(a)*b+2 (binding: quirk)", 12.0 * N, lambda: check(lib.np_fused_chain(ptrs3, kinds3, 3, prog3q, 3, do.ptr, 1, N)), "store")
+    case("sum(exp(a)*b+2) (quirk)", 8.0 * N, lambda: check(lib.np_fused_chain_reduce(ptrs3, kinds3, 3, prog3q, 3, 0, 1, N, C.byref(res))), "sum", sum3)
     dres = D.DeviceArray((1,))
     case("sum(exp(a)*b+2) dev result", 8.0 * N, lambda: check(lib.np_fused_chain_reduce_dev(ptrs3, kinds3, 3, prog3, 3, 0, 1, N, dres.ptr)), "none")
     case("sum(exp(a)) dev result", 4.0 * N, lambda: check(lib.np_fused_chain_reduce_dev(ptrs1, kinds1, 1, prog1, 1, 0, 1, N, dres.ptr)), "none")
