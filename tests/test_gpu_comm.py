@@ -283,7 +283,7 @@ def test_a_transfer_issued_next_to_a_running_gemm_gets_through(hip):
         transfers()
         alone = float(np.median(transfers()))
         assert (dst.to_host() == np.float32(1.25)).all()
-        assert alone < 0.5, alone
+        assert alone < 1.0, alone                       # measured 0.2 ms (32 MB inside one GPU)
 
         def under(launch, loops):
             for _ in range(3):
@@ -302,15 +302,15 @@ def test_a_transfer_issued_next_to_a_running_gemm_gets_through(hip):
         hip.fill(A, 0.5)
         hip.fill(B, 0.25)
         t, back, done = under(lambda: check(lib.np_sgemm_strided_batched(per, m, m, m, A.ptr, m * m, B.ptr, m * m, Cm.ptr, m * m)), 40)
-        assert back < 0.2 * done, ("the transfers waited for the GEMM queue", back, done)
-        assert t.max() <= alone + 0.8, ("next to the slab GEMM", t, alone)       # measured <= 0.33 ms
+        assert back < 0.5 * done, ("the transfers waited for the GEMM queue", back, done)    # behind the queue: back ~ done
+        assert t.max() <= alone + 1.6, ("next to the slab GEMM", t, alone)       # measured <= 0.33 ms; behind the queue: 40 ms
         n = 4096
         A2, B2, C2 = hip.DeviceArray((n, n)), hip.DeviceArray((n, n)), hip.DeviceArray((n, n))
         hip.fill(A2, 0.5)
         hip.fill(B2, 0.25)
         t, back, done = under(lambda: hip.sgemm(A2, B2, out=C2), 40)
         assert back < 0.5 * done, ("the transfers waited for the GEMM queue", back, done)
-        assert t.max() <= alone + 2.0, ("next to 4096^3 (one resident round): at most ~one product", t, alone)   # measured <= 0.98 ms
+        assert t.max() <= alone + 4.0, ("next to 4096^3 (one resident round): at most ~one product", t, alone)   # measured <= 0.98 ms; behind the queue: 40 ms
     finally:
         check(lib.np_comm_destroy())
 
