@@ -9,7 +9,8 @@ metric is quoted on), one np_sgemm launch per product, 4 distinct operand sets. 
 of round 6 a step was ONE product: W = 5 such steps are 5 ms of matrix work, the device needs ~50 ms
 to raise the matrix cores' clock, and a timed region right behind them reported that ramp —
 0.82-0.85 of the MFMA peak for a kernel that runs at 0.91.  bench_matmul's docstring; the figure of
-the old step definition is still in the line: roofline.frac_launches_5_24.)
+the old step definition is still in the line: roofline.frac_launches_5_24; NP_BENCH_STEP_PRODUCTS=1
+runs the old step.)
 Inputs are resident in HBM before the timed region.  K steps are launched back to back between
 a barrier + device sync on both sides; `value` = all ranks' FLOPs / max-over-ranks wall time.
 With N > 1 every rank (one per GPU) multiplies its own independent matrices.  The ranks come
