@@ -1321,7 +1321,6 @@ static int fused_chain_impl(const float *const *inputs, const int *input_kinds, 
     float *result = out;
     unsigned reduce_blocks = 0;
     if (sink >= 0 && axis_mode < 0) {
-        if (n >= (size_t(1) << 31)) return np::fail(NP_ERR_INVALID, "np_fused_chain_reduce: array too large");
         // grid-stride loop over a capped grid: one workgroup-reduce + partial per block, so few,
         // long-lived blocks (NP_FUSED_RBPC blocks per CU for tools/fused_ab.py)
 #ifdef NP_TUNING   // tools/fused_ab.py; the shipped library reads no environment variable

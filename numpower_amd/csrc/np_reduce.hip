@@ -1650,28 +1650,28 @@ static int launch_weighted_sums(const float *a, const float *w, size_t n, float 
     return NP_OK;
 }
 
-// sum over XFORM(in[, in2]) -> one device float
-template <int XFORM>
-static int xform_sum(const float *in, const float *in2, size_t n, float p0, float p1, float *dev_out) {
-    if (n >= (size_t(1) << 31)) return np::fail(NP_ERR_INVALID, "statistics: array too large");
+// sum over XFORM(in[, in2]) -> one device float (32-bit indices below 2^31 elements, 64-bit beyond: array_equal / allclose of
+// arrays the reference's `int` counts cannot address but 288 GB of HBM can hold)
+template <int XFORM, typename I>
+static int xform_sum_as(const float *in, const float *in2, size_t n, float p0, float p1, float *dev_out) {
     hipStream_t s = np::stream();
-    const bool vec = true;   // dword-aligned float4 loads: views may start anywhere
-    const size_t nvec = n / 4;
-    const size_t blocks = np::capped_grid(((vec ? nvec : n / 4) + 255) / 256, stream_cap());
+    const size_t nvec = n / 4;   // dword-aligned float4 loads: views may start anywhere
+    const size_t blocks = np::capped_grid((nvec + 255) / 256, stream_cap());
     np::Scratch partials;
     if (int rc = partials.alloc(blocks * sizeof(float))) return rc;
     unsigned *ticket = np::fold_ticket(blocks);
-    if (vec)
-        reduce_xform_pass1<XFORM, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, in2, (float *)partials.ptr, (uint32_t)n,
-                                                                         (uint32_t)nvec, p0, p1, ticket, dev_out);
-    else
-        reduce_xform_scalar<XFORM, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, in2, (float *)partials.ptr, (uint32_t)n,
-                                                                          p0, p1, ticket, dev_out);
+    reduce_xform_pass1<XFORM, I><<<(unsigned)blocks, 256, 0, s>>>(in, in2, (float *)partials.ptr, (I)n, (I)nvec, p0, p1, ticket, dev_out);
     NP_LAUNCH_CHECK("reduce_xform");
     if (ticket) return NP_OK;
     reduce_all_pass2<NP_SUM><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, dev_out, 1.0f);
     NP_LAUNCH_CHECK("reduce_all_pass2");
     return NP_OK;
+}
+
+template <int XFORM>
+static int xform_sum(const float *in, const float *in2, size_t n, float p0, float p1, float *dev_out) {
+    if (n < (size_t(1) << 31)) return xform_sum_as<XFORM, uint32_t>(in, in2, n, p0, p1, dev_out);
+    return xform_sum_as<XFORM, uint64_t>(in, in2, n, p0, p1, dev_out);
 }
 
 // argmax / argmin with a handful of columns and many rows (inner <= 64): slabs of rows read as FLAT memory with float4
@@ -2332,7 +2332,6 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
     *host_out = 1;
     if (n == 0) return NP_OK;
     if (!in) return np::fail(NP_ERR_INVALID, "np_all: null input");
-    if (n >= (size_t(1) << 31)) return np::fail(NP_ERR_INVALID, "np_all: array too large");
     if (int rc = np::ensure_init()) return rc;
     hipStream_t s = np::stream();
     size_t head = ((16 - ((uintptr_t)in & 15u)) & 15u) / 4;
@@ -2344,14 +2343,16 @@ int np_all(const float *in, size_t n, unsigned flags, int *host_out) {
     np::ResultCall call;
     float *slot = call.slot;
     if (!slot) return NP_ERR_ALLOC;
-    const uint32_t body_end = (uint32_t)np_avx_body_end(n);
+    const size_t body_end = (flags & NP_QUIRK_AVX_BODY) ? np_avx_body_end(n) : 0;
     unsigned *ticket = np::fold_ticket(blocks);
-    if (flags & NP_QUIRK_AVX_BODY)
-        all_pass1<true, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n, (uint32_t)head,
-                                                                   (uint32_t)nvec, body_end, ticket, slot);
-    else
-        all_pass1<false, uint32_t><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (uint32_t)n, (uint32_t)head,
-                                                                    (uint32_t)nvec, 0u, ticket, slot);
+    const bool wide = n >= (size_t(1) << 31);   // 64-bit indices past 2^31 elements
+#define NP_ALL_PASS1(Q, I) all_pass1<Q, I><<<(unsigned)blocks, 256, 0, s>>>(in, (float *)partials.ptr, (I)n, (I)head, (I)nvec, (I)body_end, ticket, slot)
+    if (flags & NP_QUIRK_AVX_BODY) {
+        if (wide) NP_ALL_PASS1(true, uint64_t); else NP_ALL_PASS1(true, uint32_t);
+    } else {
+        if (wide) NP_ALL_PASS1(false, uint64_t); else NP_ALL_PASS1(false, uint32_t);
+    }
+#undef NP_ALL_PASS1
     NP_LAUNCH_CHECK("all_pass1");
     if (!ticket) {
         reduce_all_pass2<NP_MIN><<<1, 256, 0, s>>>((const float *)partials.ptr, (int)blocks, slot, 1.0f);

@@ -104,6 +104,40 @@ def test_past_2_to_31_elements(hip):
     want = float(np.sqrt(np.float32(3.0)))
     assert [probe(out, i) for i in probes[:-1]] == [want] * 6
     assert probe(out, n - 1) == float(np.sqrt(np.float32(15.0)))
+    # a chain that ends in a full reduction (what nd::sum(nd::sqrt($a * $b)) is behind the binding), array_equal / allclose and
+    # nd::all beyond 2^31 elements: refused as "array too large" until the end of round 6 — while the op-by-op forms worked
+    host = C.c_float()
+    _lib.check(lib.np_fused_chain_reduce(ptrs, kinds, 2, ops, 2, 0, 1, n, C.byref(host)))        # 0 = sum
+    want_sum = want * (n - 1) + float(np.sqrt(np.float32(15.0)))
+    # 2^31 copies of ONE value are the worst case of a per-lane fp32 accumulator: every add inside a binade rounds the same way
+    # (2.7e-5 here; random data averages out, and the reference's single sequential accumulator stops growing at 2^24 * value)
+    assert abs(host.value - want_sum) <= 1e-4 * want_sum, (host.value, want_sum)
+    _lib.check(lib.np_fused_chain_reduce(ptrs, kinds, 2, ops, 2, 3, 1, n, C.byref(host)))        # 3 = max: the far end
+    assert host.value == float(np.sqrt(np.float32(15.0)))
+    any_ = C.c_int(-1)
+    _lib.check(lib.np_count_mismatch(0, out.ptr, out.ptr, n, 0.0, 0.0, C.byref(any_)))
+    assert any_.value == 0
+    _lib.check(lib.np_count_mismatch(0, a.ptr, b.ptr, n, 0.0, 0.0, C.byref(any_)))
+    assert any_.value == 1
+    _lib.check(lib.np_unary(UNARY_OPS["negate"], b.ptr, out.ptr, n, 0.0, 0.0))
+    _lib.check(lib.np_unary(UNARY_OPS["negate"], out.ptr, out.ptr, n, 0.0, 0.0))                  # out = b again
+    _lib.check(lib.np_count_mismatch(0, out.ptr, b.ptr, n, 0.0, 0.0, C.byref(any_)))
+    assert any_.value == 0
+    _lib.check(lib.np_memcpy_h2d(out.ptr + 4 * (n - 1), np.float32([10.5]).ctypes.data, 4))     # only the LAST element differs
+    _lib.check(lib.np_count_mismatch(0, out.ptr, b.ptr, n, 0.0, 0.0, C.byref(any_)))
+    assert any_.value == 1
+    _lib.check(lib.np_count_mismatch(1, out.ptr, b.ptr, n, 0.1, 0.0, C.byref(any_)))             # allclose, rtol 0.1: 10.5 vs 10
+    assert any_.value == 0
+    _lib.check(lib.np_count_mismatch(1, out.ptr, b.ptr, n, 0.01, 0.0, C.byref(any_)))
+    assert any_.value == 1
+    verdict = C.c_int(-1)
+    _lib.check(lib.np_all(b.ptr, n, 0, C.byref(verdict)))
+    assert verdict.value == 1
+    _lib.check(lib.np_memcpy_h2d(out.ptr + 4 * (n - 1), np.float32([0.0]).ctypes.data, 4))      # one zero at the very end
+    _lib.check(lib.np_all(out.ptr, n, 0, C.byref(verdict)))
+    assert verdict.value == 0
+    _lib.check(lib.np_all(out.ptr, n - 1, 0, C.byref(verdict)))
+    assert verdict.value == 1
     # order statistics with 64-bit indices: b is 2.0 everywhere except b[n-1] = 10
     two = (C.c_float * 2)()
     _lib.check(lib.np_order_stat(b.ptr, n, n - 1, two))

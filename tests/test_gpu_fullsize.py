@@ -426,3 +426,82 @@ def test_moments_beyond_2p31_elements(hip):
     assert abs(sw.value - 0.5 * n) <= 1e-5 * 0.5 * n and abs(saw.value - 0.5 * (n + 2.0 * k)) <= 1e-5 * 0.5 * n
     for d in (a, w):
         d.free()
+
+
+def test_layout_beyond_2p31_elements(hip):
+    """Transposes, permutes and strided gathers of a 46342 x 46350 matrix: 2 147 951 700 elements, 8.6 GB per buffer — past the
+    2^31 elements where 32-bit flat indices end (the reference's transposeCoalesced is correct up to 256 x 256,
+    cuda_math.cu:1288-1294, and its `int` counts stop here anyway).  X[r][c] = u[r] + v[c] with 12-bit integers u and 12-bit
+    fractions v, so every sum is exact and the EXPECTED result of each layout op can be built on the device by the broadcast
+    kernels (row / column operands; their own 64-bit form is anchored by probes below) and compared over ALL elements."""
+    import ctypes as C
+    from numpower_amd import _lib
+    lib = _lib.load()
+    D = hip
+    rows, cols = 46342, 46350
+    n = rows * cols
+    assert n > (1 << 31)
+    u = ((np.arange(rows, dtype=np.int64) * 7919) % 4093).astype(np.float32)                 # one per row
+    v = (((np.arange(cols, dtype=np.int64) * 104729) % 4099) / 4096.0).astype(np.float32)    # one per column; u + v exact in fp32
+    du, dv = D.DeviceArray.from_host(u), D.DeviceArray.from_host(v)
+
+    def outer_sum(r, c, per_row, per_col):
+        """(r x c) array with [i][j] = per_row[i] + per_col[j]"""
+        z = D.DeviceArray((r, c))
+        _lib.check(lib.np_memset0(z.ptr, 4 * r * c))
+        t = D.binary("add", z, "full", per_col, "row", r, c)
+        D.binary("add", t, "full", per_row, "col", r, c, out=z)
+        t.free()
+        return z
+
+    def probe(buf, index):
+        f = C.c_float()
+        _lib.check(lib.np_read_float(buf.ptr, index, C.byref(f)))
+        return f.value
+
+    def same(a, b, count):
+        flag = C.c_int(1)
+        _lib.check(lib.np_count_mismatch(0, a.ptr, b.ptr, count, 0.0, 0.0, C.byref(flag)))      # 0 = exact
+        return flag.value == 0
+
+    x = outer_sum(rows, cols, du, dv)
+    for r, c in ((0, 0), (1, 5), (rows - 1, cols - 1), (46333, 17), (rows - 1, 0), (rows // 2, cols // 2)):   # anchors, both sides of 2^31
+        assert probe(x, r * cols + c) == float(u[r] + v[c]), (r, c)
+    assert (rows - 1) * cols > (1 << 31)
+
+    # 2-D transpose: T[c][r] = u[r] + v[c]
+    want_t = outer_sum(cols, rows, dv, du)
+    t = D.DeviceArray((cols, rows))
+    _lib.check(lib.np_transpose2d(x.ptr, t.ptr, 1, rows, cols))
+    assert same(t, want_t, n)
+    for c, r in ((cols - 1, rows - 1), (cols - 1, 0), (46340, 46341), (0, rows - 1)):
+        assert probe(t, c * rows + r) == float(u[r] + v[c]), (c, r)
+    # the same through np_permute, as a batch of one and as two half-height matrices (a batched transpose of 2 x 23171 x 46350)
+    _lib.check(lib.np_memset0(t.ptr, 4 * n))
+    _lib.check(lib.np_permute(x.ptr, t.ptr, 3, (C.c_int * 3)(1, rows, cols), (C.c_int * 3)(0, 2, 1)))
+    assert same(t, want_t, n)
+    want_t.free()
+    half = rows // 2
+    _lib.check(lib.np_memset0(t.ptr, 4 * n))
+    _lib.check(lib.np_permute(x.ptr, t.ptr, 3, (C.c_int * 3)(2, half, cols), (C.c_int * 3)(0, 2, 1)))
+    for b, c, r in ((1, cols - 1, half - 1), (1, 0, 0), (0, 5, 7), (1, 46000, 23000)):
+        assert probe(t, (b * cols + c) * half + r) == float(u[b * half + r] + v[c]), (b, c, r)
+    # axes (1, 0, 2) of (half, 2, cols): whole rows move (the plane / gather kernels): out[j][i][:] = in[i][j][:]
+    _lib.check(lib.np_memset0(t.ptr, 4 * n))
+    _lib.check(lib.np_permute(x.ptr, t.ptr, 3, (C.c_int * 3)(half, 2, cols), (C.c_int * 3)(1, 0, 2)))
+    for j, i, c in ((1, half - 1, cols - 1), (1, 0, 0), (0, 11, 13), (1, 20000, 46349), (0, half - 1, 1)):
+        assert probe(t, (j * half + i) * cols + c) == float(u[2 * i + j] + v[c]), (j, i, c)
+    # strided gather: every second column (n / 2 elements out, input offsets past 2^31) against the expectation built by broadcasts
+    dv2 = D.DeviceArray.from_host(v[::2].copy())
+    want_g = outer_sum(rows, cols // 2, du, dv2)
+    _lib.check(lib.np_strided_copy(x.ptr, t.ptr, 2, (C.c_int * 2)(rows, cols // 2), (C.c_longlong * 2)(cols, 2)))
+    assert same(t, want_g, rows * (cols // 2))
+    # ... and a reversed, transposing gather with negative strides: out[c][r] = x[rows - 1 - r][c]  (n elements, 64-bit everywhere)
+    want_g.free()
+    base = D.DeviceArray((cols,), offset_elems=(rows - 1) * cols, base=x)
+    _lib.check(lib.np_strided_copy(base.ptr, t.ptr, 2, (C.c_int * 2)(cols, rows), (C.c_longlong * 2)(1, -cols)))
+    for c, r in ((cols - 1, rows - 1), (0, 0), (cols - 1, 0), (46340, 46000), (3, rows - 1)):
+        assert probe(t, c * rows + r) == float(u[rows - 1 - r] + v[c]), (c, r)
+    assert lib.np_sync() == 0
+    for d in (x, t, du, dv, dv2):
+        d.free()
