@@ -505,3 +505,122 @@ def test_layout_beyond_2p31_elements(hip):
     assert lib.np_sync() == 0
     for d in (x, t, du, dv, dv2):
         d.free()
+
+
+def test_remaining_entry_points_beyond_2p31_elements(hip):
+    """Every other entry point that takes a size, on operands past 2^31 elements (one MI355X holds 72e9 floats; the reference's
+    `int` counts end at 2^31): axis reductions over each axis form, the weighted sums, matrix . vector, outer, the pitched
+    copy, identity, arange, a chain ending in an axis reduction, and a product whose A has 2.1e9 elements.  Data with closed
+    forms (X[r][c] = u[r] + v[c], 12-bit integers + 12-bit fractions: exact), expectations in fp64 on the host."""
+    import ctypes as C
+    from numpower_amd import _lib
+    from numpower_amd._lib import BINARY_OPS, FusedOp
+    lib = _lib.load()
+    D = hip
+    rows, cols = 46342, 46350
+    n = rows * cols
+    half = rows // 2
+    u = ((np.arange(rows, dtype=np.int64) * 7919) % 4093).astype(np.float32)
+    v = (((np.arange(cols, dtype=np.int64) * 104729) % 4099) / 4096.0).astype(np.float32)
+    u64, v64 = u.astype(np.float64), v.astype(np.float64)
+    du, dv = D.DeviceArray.from_host(u), D.DeviceArray.from_host(v)
+    x = D.DeviceArray((rows, cols))
+    _lib.check(lib.np_memset0(x.ptr, 4 * n))
+    tmp = D.binary("add", x, "full", dv, "row", rows, cols)
+    D.binary("add", tmp, "full", du, "col", rows, cols, out=x)
+
+    def close(got, want, scale, tol=1e-5):
+        return bool((np.abs(got.astype(np.float64) - want) <= tol * scale).all())
+
+    # np_reduce_axis: last axis, first axis, a middle axis
+    o_r, o_c, o_m = D.DeviceArray((rows,)), D.DeviceArray((cols,)), D.DeviceArray((2, cols))
+    _lib.check(lib.np_reduce_axis(0, x.ptr, rows, cols, 1, o_r.ptr, 0))
+    want = cols * u64 + v64.sum()
+    assert close(o_r.to_host(), want, want)
+    _lib.check(lib.np_reduce_axis(2, x.ptr, rows, cols, 1, o_r.ptr, 0))                     # min over a row: exact
+    assert (o_r.to_host() == (u + v.min())).all()
+    _lib.check(lib.np_reduce_axis(0, x.ptr, 1, rows, cols, o_c.ptr, 0))
+    want = u64.sum() + rows * v64
+    assert close(o_c.to_host(), want, want)
+    _lib.check(lib.np_reduce_axis(3, x.ptr, 1, rows, cols, o_c.ptr, 0))                     # max down a column: exact
+    assert (o_c.to_host() == (u.max() + v)).all()
+    _lib.check(lib.np_reduce_axis(0, x.ptr, 2, half, cols, o_m.ptr, 0))
+    want = np.stack([u64[:half].sum() + half * v64, u64[half:2 * half].sum() + half * v64])
+    assert close(o_m.to_host(), want, want)
+    _lib.check(lib.np_reduce_axis(4, x.ptr, 2, half, cols, o_m.ptr, 0))                     # mean
+    assert close(o_m.to_host(), want / half, want / half)
+    # a chain that ends in an axis reduction: sum(X + 1, axis) in one pass
+    ops = (FusedOp * 1)(FusedOp(1, BINARY_OPS["add"], 1, 0, 0, 0, 0, 0))
+    one = np.float32([1.0])
+    ptrs = (C.c_void_p * 2)(x.ptr, one.ctypes.data)
+    kinds = (C.c_int * 2)(0, 4)                                                             # FULL, HOST_SCALAR
+    _lib.check(lib.np_fused_chain_reduce_axis(ptrs, kinds, 2, ops, 1, 0, rows, cols, 1, o_r.ptr))
+    want = cols * (u64 + 1.0) + v64.sum()
+    assert close(o_r.to_host(), want, want)
+    _lib.check(lib.np_fused_chain_reduce_axis(ptrs, kinds, 2, ops, 1, 0, rows, cols, 0, o_c.ptr))
+    want = u64.sum() + rows * (v64 + 1.0)
+    # (down a column every term carries the SAME 12-bit fraction v[c] + 1: once a lane's running sum is past 2^20 each add rounds that
+    # fraction the same way — 2-3e-5 here, where the fused column kernel keeps longer runs of rows in one accumulator; np_reduce_axis above cuts the
+    # axis finer and stays below 1e-5 on the same data; the reference's one accumulator per column is off by 2e-3 from fp64 on it)
+    assert close(o_c.to_host(), want, want, tol=1e-4)
+    # weighted sums over the flat array: sum x * x and sum x
+    s_aw, s_w = C.c_float(), C.c_float()
+    _lib.check(lib.np_weighted_sums(x.ptr, x.ptr, n, C.byref(s_aw), C.byref(s_w)))
+    want_w = cols * u64.sum() + rows * v64.sum()
+    want_aw = cols * (u64 ** 2).sum() + 2.0 * u64.sum() * v64.sum() + rows * (v64 ** 2).sum()
+    assert abs(s_w.value - want_w) <= 1e-5 * want_w and abs(s_aw.value - want_aw) <= 1e-5 * want_aw, (s_w.value, want_w, s_aw.value, want_aw)
+    # matrix . vector with 2.1e9 matrix elements
+    w = (np.arange(cols) % 4).astype(np.float32)
+    dw, y = D.DeviceArray.from_host(w), D.DeviceArray((rows,))
+    _lib.check(lib.np_sgemv(rows, cols, x.ptr, dw.ptr, y.ptr))
+    want = u64 * w.sum(dtype=np.float64) + (v64 * w).sum()
+    assert close(y.to_host(), want, want)
+    # outer: u (x) v, every product exact (12 x 12 bits), against (1 * v[c]) * u[r] built by the broadcast kernels
+    _lib.check(lib.np_outer(du.ptr, rows, dv.ptr, cols, tmp.ptr))
+    D.fill(x, 1.0)
+    e1 = D.binary("multiply", x, "full", dv, "row", rows, cols)
+    D.binary("multiply", e1, "full", du, "col", rows, cols, out=x)
+    flag = C.c_int(1)
+    _lib.check(lib.np_count_mismatch(0, tmp.ptr, x.ptr, n, 0.0, 0.0, C.byref(flag)))
+    assert flag.value == 0
+    # pitched copy: the right half of every row of the outer product into a compact (rows x cols / 2) buffer
+    hw = cols // 2
+    _lib.check(lib.np_copy2d(e1.ptr, hw, x.ptr + 4 * hw, cols, hw, rows))
+    dvh = D.DeviceArray.from_host(v[hw:2 * hw].copy())
+    _lib.check(lib.np_outer(du.ptr, rows, dvh.ptr, hw, tmp.ptr))
+    _lib.check(lib.np_count_mismatch(0, tmp.ptr, e1.ptr, rows * hw, 0.0, 0.0, C.byref(flag)))
+    assert flag.value == 0
+    # identity 46342^2 and arange past 2^31 (NDArray_Arange's float accumulation sticks at 2^24 with step 1: x + 1 rounds back to x)
+    _lib.check(lib.np_identity(x.ptr, rows))
+    got = C.c_float()
+    for i in (0, 1, rows - 1, rows // 2):
+        _lib.check(lib.np_read_float(x.ptr, i * rows + i, C.byref(got)))
+        assert got.value == 1.0
+        _lib.check(lib.np_read_float(x.ptr, i * rows + (i + 1) % rows, C.byref(got)))
+        assert got.value == 0.0
+    assert D.reduce_all("sum", D.DeviceArray((rows * rows,), base=x)) == float(rows)
+    m = (1 << 31) + 100
+    assert m <= n
+    _lib.check(lib.np_arange(x.ptr, 0.0, 1.0, m))
+    for i, want_i in ((0, 0.0), (12345, 12345.0), ((1 << 24) - 1, float((1 << 24) - 1)), (1 << 24, float(1 << 24)), ((1 << 24) + 7, float(1 << 24)),
+                      ((1 << 31) + 99, float(1 << 24))):
+        _lib.check(lib.np_read_float(x.ptr, i, C.byref(got)))
+        assert got.value == want_i, (i, got.value)
+    for d in (tmp, e1, o_r, o_c, o_m, dw, y, dvh):
+        d.free()
+    # a product whose A has 2.1e9 elements: (2^21 + 8) x 1024 . 1024 x 16, A[r][:] = a_r (12-bit integers), B = 0.25: C[r][:] = 256 a_r exactly
+    M, K, N = (1 << 21) + 8, 1024, 16
+    assert M * K > (1 << 31) and M * K <= n
+    a_r = ((np.arange(M, dtype=np.int64) * 7919) % 4093).astype(np.float32)
+    da = D.DeviceArray.from_host(a_r)
+    A = D.DeviceArray((M, K), base=x)
+    _lib.check(lib.np_memset0(A.ptr, 4 * M * K))
+    D.binary("add", A, "full", da, "col", M, K, out=A)
+    B, Cm = D.DeviceArray((K, N)), D.DeviceArray((M, N))
+    D.fill(B, 0.25)
+    _lib.check(lib.np_sgemm(M, N, K, A.ptr, B.ptr, Cm.ptr))
+    got_c = Cm.to_host()
+    assert (got_c == (256.0 * a_r)[:, None]).all()
+    assert lib.np_sync() == 0
+    for d in (x, du, dv, da, B, Cm):
+        d.free()
