@@ -51,6 +51,17 @@ static int on_device(NDArray *a) {
     return 1;
 }
 
+/* the reference's function-pointer interface counts elements in an `int` (cuda_math.h:14-15): an operation that is not one of
+ * this back end's own (those go out of place above, with size_t counts) cannot be handed more than INT_MAX elements */
+static int int_count(NDArray *a, int *n) {
+    if (NDArray_NUMELEMENTS(a) > 2147483647L) {
+        np_ext_throw("array too large for an element-wise operation with an int element count");
+        return 0;
+    }
+    *n = (int)NDArray_NUMELEMENTS(a);
+    return 1;
+}
+
 /* one pass: out[i] = f(in[i]) */
 static NDArray *unary_out_of_place(NDArray *in, int code, float p0, float p1) {
     NDArray *out = NDArray_EmptyLike(in);
@@ -68,7 +79,14 @@ NDArray *NDArrayMathGPU_ElementWise(NDArray *ndarray, ElementWiseFloatGPUOperati
     const int code = np_hip_math_unary_code(op);
     if (code >= 0) return unary_out_of_place(ndarray, code, 0.0f, 0.0f);
     NDArray *rtn = NDArray_Copy(ndarray, NDArray_DEVICE(ndarray));     /* cuda_math.cu:1533-1536 */
-    if (rtn != NULL && op != NULL) op((int)NDArray_NUMELEMENTS(rtn), NDArray_FDATA(rtn));
+    int n = 0;
+    if (rtn != NULL && op != NULL) {
+        if (!int_count(rtn, &n)) {
+            NDArray_FREE(rtn);
+            return NULL;
+        }
+        op(n, NDArray_FDATA(rtn));
+    }
     return rtn;
 }
 
@@ -77,7 +95,14 @@ NDArray *NDArrayMathGPU_ElementWise1F(NDArray *ndarray, ElementWiseFloatGPUOpera
     const int code = np_hip_math_unary1f_code(op);
     if (code >= 0) return unary_out_of_place(ndarray, code, val1, 0.0f);
     NDArray *rtn = NDArray_Copy(ndarray, NDArray_DEVICE(ndarray));     /* cuda_math.cu:1540-1543 */
-    if (rtn != NULL && op != NULL) op((int)NDArray_NUMELEMENTS(rtn), NDArray_FDATA(rtn), val1);
+    int n = 0;
+    if (rtn != NULL && op != NULL) {
+        if (!int_count(rtn, &n)) {
+            NDArray_FREE(rtn);
+            return NULL;
+        }
+        op(n, NDArray_FDATA(rtn), val1);
+    }
     return rtn;
 }
 
@@ -86,7 +111,14 @@ NDArray *NDArrayMathGPU_ElementWise2F(NDArray *ndarray, ElementWiseFloatGPUOpera
     const int code = np_hip_math_unary2f_code(op);
     if (code >= 0) return unary_out_of_place(ndarray, code, val1, val2);
     NDArray *rtn = NDArray_Copy(ndarray, NDArray_DEVICE(ndarray));     /* cuda_math.cu:1554-1557 */
-    if (rtn != NULL && op != NULL) op((int)NDArray_NUMELEMENTS(rtn), NDArray_FDATA(rtn), val1, val2);
+    int n = 0;
+    if (rtn != NULL && op != NULL) {
+        if (!int_count(rtn, &n)) {
+            NDArray_FREE(rtn);
+            return NULL;
+        }
+        op(n, NDArray_FDATA(rtn), val1, val2);
+    }
     return rtn;
 }
 
@@ -101,7 +133,14 @@ NDArray *NDArrayMathGPU_ElementWise1N(NDArray *ndarray, ElementWiseFloatGPUOpera
     const int code = np_hip_math_binary1n_code(op);
     if (code < 0) {
         NDArray *rtn = NDArray_Copy(ndarray, NDArray_DEVICE(ndarray));
-        if (rtn != NULL && op != NULL) op((int)NDArray_NUMELEMENTS(rtn), NDArray_FDATA(rtn), NDArray_FDATA(val1));
+        int n = 0;
+        if (rtn != NULL && op != NULL) {
+            if (!int_count(rtn, &n)) {
+                NDArray_FREE(rtn);
+                return NULL;
+            }
+            op(n, NDArray_FDATA(rtn), NDArray_FDATA(val1));
+        }
         return rtn;
     }
     NDArray *out = NDArray_EmptyLike(ndarray);

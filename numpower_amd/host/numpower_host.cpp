@@ -63,14 +63,28 @@ long shape_numel(const int *shape, int ndim) {
     return n;
 }
 
-// Generate_Strides (initializers.c:115-135): byte strides, C order
+// Generate_Strides (initializers.c:115-135): byte strides, C order.  The struct keeps them as `int` (ndarray.h:52-74): a slab of
+// 2 GiB or more under an axis — (4, 10^9) is 16 GB, a small array on this device — does not fit, and the reference's
+// `shape[i + 1] * strides[i + 1]` wraps there.  Such a stride is stored as kStrideOverflow: the hot path never looks at strides
+// (contiguous-only contract), NDArray_LeadingSlice computes its offset from the extents, and the strided views refuse.
+constexpr int kStrideOverflow = INT_MIN;
 int *make_strides(const int *shape, int ndim) {
     int *st = (int *)malloc(sizeof(int) * (ndim > 0 ? ndim : 1));
     if (ndim > 0) {
-        st[ndim - 1] = (int)sizeof(float);
-        for (int i = ndim - 2; i >= 0; --i) st[i] = shape[i + 1] * st[i + 1];
+        long long s = (long long)sizeof(float);
+        st[ndim - 1] = (int)s;
+        for (int i = ndim - 2; i >= 0; --i) {
+            s = s <= (long long)INT_MAX ? s * (long long)shape[i + 1] : s;
+            st[i] = s <= (long long)INT_MAX ? (int)s : kStrideOverflow;
+        }
     }
     return st;
+}
+
+bool strides_fit(const NDArray *a) {
+    for (int i = 0; i < a->ndim; ++i)
+        if (a->strides[i] == kStrideOverflow) return false;
+    return true;
 }
 
 // Create_NDArray (initializers.c:255-286) without data
@@ -278,7 +292,10 @@ NDArray *NDArray_LeadingSlice(NDArray *a, int index) {   // iterators.c:94-111
         return nullptr;
     }
     NDArray *r = make_header(a->dimensions + 1, a->ndim - 1, a->device);
-    r->data = a->data + (size_t)index * (size_t)a->strides[0];
+    // (a stride that does not fit the struct's int belongs to a freshly laid out, contiguous array: the slab is its other extents)
+    const size_t slab = a->strides[0] != kStrideOverflow ? (size_t)a->strides[0]
+                                                         : (size_t)shape_numel(a->dimensions + 1, a->ndim - 1) * sizeof(float);
+    r->data = a->data + (size_t)index * slab;
     r->base = a;
     a->refcount++;   // NDArray_ADDREF
     return r;
@@ -498,6 +515,7 @@ NDArray *make_view(NDArray *base, char *data, const int *shape, int ndim) {
 }
 
 bool is_c_contiguous(const NDArray *a) {
+    if (!strides_fit(a)) return true;   // only make_strides writes the marker: a fresh C-order layout
     int expect = (int)sizeof(float);
     for (int i = a->ndim - 1; i >= 0; --i) {
         if (a->dimensions[i] != 1 && a->strides[i] != expect) return false;
@@ -559,6 +577,7 @@ NDArray *NDArray_ToContiguous(NDArray *a) {   // manipulation.c:381-421
         throw_error("ToContiguous: more than %d dimensions", NP_MAX_ND_HOST);
         return nullptr;
     }
+    if (!strides_fit(a)) return NDArray_Copy(a, NDArray_DEVICE(a));   // a fresh C-order layout (make_strides): already contiguous
     return gather_to_new(a, a->data, a->dimensions, a->strides, a->ndim);
 }
 
@@ -572,6 +591,10 @@ NDArray *NDArray_Diagonal(NDArray *target, int offset) {   // indexing.c:21-48
         return nullptr;
     }
     if (!require_gpu(target, "diagonal")) return nullptr;
+    if (!strides_fit(target)) {
+        throw_error("diagonal: rows of 2 GiB or more do not fit the int byte strides of an NDArray");
+        return nullptr;
+    }
     const int rows = target->dimensions[0], cols = target->dimensions[1];
     const int shape[1] = {rows < cols ? rows : cols};
     const int stride[1] = {target->strides[0] + target->strides[1]};
@@ -603,8 +626,18 @@ NDArray *NDArray_Reshape(NDArray *target, int *new_shape, int ndim) {   // manip
     return make_view(target, target->data, new_shape, ndim);   // shares data, ADDREFs target
 }
 
+// The reference's struct holds extents as `int` (ndarray.h:52-74): an axis cannot be longer than INT_MAX whatever the device holds.
+static bool fits_extent(long n, const char *what) {
+    if (n > 2147483647L) {
+        throw_error(what);
+        return false;
+    }
+    return true;
+}
+
 NDArray *NDArray_Flatten(NDArray *target) {   // manipulation.c:169-184: always a copy
     if (!target) return nullptr;
+    if (!fits_extent(NDArray_NUMELEMENTS(target), "flatten: more than 2^31 - 1 elements do not fit one axis of an NDArray")) return nullptr;
     NDArray *rtn = NDArray_Copy(target, NDArray_DEVICE(target));
     if (!rtn) return nullptr;
     const int n = (int)NDArray_NUMELEMENTS(target);
@@ -983,6 +1016,7 @@ NDArray *NDArray_Diag(NDArray *a) {   // initializers.c:597-625
     }
     if (NDArray_NDIM(a) == 2) return NDArray_Diagonal(a, 0);
     if (!require_gpu(a, "diag")) return nullptr;
+    if (!fits_extent(NDArray_NUMELEMENTS(a), "diag: operand too long for one axis of an NDArray")) return nullptr;
     const int n = (int)NDArray_NUMELEMENTS(a);
     const int shape[2] = {n, n};
     NDArray *rtn = new_array(shape, 2, NDARRAY_DEVICE_GPU, true);
@@ -1010,6 +1044,10 @@ NDArray *NDArray_Slice(NDArray *array, NDArray **indexes, int num_indices) {
     const int nd = NDArray_NDIM(array);
     if (nd > NP_MAX_ND_HOST) {
         throw_error("slice: more than %d dimensions", NP_MAX_ND_HOST);
+        return nullptr;
+    }
+    if (!strides_fit(array)) {
+        throw_error("slice: rows of 2 GiB or more do not fit the int byte strides of an NDArray");
         return nullptr;
     }
     int new_shape[NP_MAX_ND_HOST], new_strides[NP_MAX_ND_HOST];
@@ -1478,6 +1516,8 @@ NDArray *NDArray_Outer(NDArray *a, NDArray *b) {   // linalg.c:724-751
         return nullptr;
     }
     if (!require_gpu(a, "outer")) return nullptr;
+    if (!fits_extent(NDArray_NUMELEMENTS(a), "outer: operand too long for one axis of an NDArray") ||
+        !fits_extent(NDArray_NUMELEMENTS(b), "outer: operand too long for one axis of an NDArray")) return nullptr;
     const int shape[2] = {(int)NDArray_NUMELEMENTS(a), (int)NDArray_NUMELEMENTS(b)};
     NDArray *rtn = new_array(shape, 2, NDARRAY_DEVICE_GPU, false);   // every element is written: no Zeros pass
     if (!rtn) return nullptr;

@@ -177,3 +177,28 @@ def test_device_copy_and_fill_are_bit_exact(hip):
         _lib.check(lib.np_memcpy_d2h(back.ctypes.data, dst.ptr, 4 * (n + 8)))
         assert (back[off:off + cnt] == 0x80000000).all() and (back[:off] == 0).all() and (back[off + cnt:] == 0).all()
     src.free(); dst.free()
+
+
+def test_rows_of_2_gib_and_more(hip):
+    """(3, 600 000 000): 7.2 GB, rows of 2.4 GB.  The reference's struct keeps byte strides as `int` (ndarray.h:52-74) and
+    Generate_Strides wraps there (initializers.c:115-135: `shape[i + 1] * strides[i + 1]`): $a[1] would point outside the buffer.
+    The hot path never reads strides (contiguous-only contract) and works; the host mirror marks the stride it cannot store,
+    takes $a[i] from the extents, and refuses the strided views (slice, diagonal) out loud instead of reading somewhere else."""
+    from numpower_amd.ndarray import GPU, Error, NDArray as nd
+    rows, cols = 3, 600_000_000
+    a = nd.full([rows, cols], 1.0, GPU)
+    a[1].fill(2.0)                                   # through the view: row 1 only
+    a[2].fill(-3.0)
+    assert [nd.sum(a[i]) / cols for i in range(rows)] == [1.0, 2.0, -3.0]
+    assert nd.max(a) == 2.0 and nd.min(a) == -3.0
+    b = a * 2.0 + 1.0                                # elementwise: strides are never read
+    assert [nd.max(b[i]) for i in range(rows)] == [3.0, 5.0, -5.0] and [nd.min(b[i]) for i in range(rows)] == [3.0, 5.0, -5.0]
+    s0 = nd.sum(a, 0)                                # axis reductions take their extents from the shape
+    assert s0.shape() == [cols] and nd.max(s0) == 0.0 and nd.min(s0) == 0.0
+    s1 = nd.sum(a, 1).cpu().toArray()
+    assert [v / cols for v in s1] == [1.0, 2.0, -3.0]
+    t = nd.transpose(a)                              # (600 000 000, 3): its own strides fit
+    assert t.shape() == [cols, rows] and t[cols - 1].cpu().toArray() == [1.0, 2.0, -3.0]
+    with pytest.raises(Error, match="2 GiB"):
+        a.slice([0, 2], [0, 10, 2])
+    del a, b, s0, t
