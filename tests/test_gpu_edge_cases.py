@@ -202,3 +202,24 @@ def test_rows_of_2_gib_and_more(hip):
     with pytest.raises(Error, match="2 GiB"):
         a.slice([0, 2], [0, 10, 2])
     del a, b, s0, t
+
+
+def test_allocation_failure_is_an_error(hip):
+    """vmalloc's failure text (gpu_alloc.c:15 "device memory allocation failed") for a request no device can hold — as a status of
+    np_malloc and as the exception of the array constructors — and the library usable afterwards.  (Requests a little above the
+    288 GB are no test of this: the driver of this pool backs them with host memory.)"""
+    import ctypes as C
+    from numpower_amd import _lib
+    from numpower_amd.ndarray import GPU, Error, NDArray as nd
+    lib = _lib.load()
+    p = C.c_void_p()
+    rc = lib.np_malloc(C.byref(p), 1 << 44)                                   # 16 TiB
+    assert rc == -2 and p.value is None                                       # NP_ERR_ALLOC
+    assert lib.np_last_error().decode().startswith("device memory allocation failed")
+    with pytest.raises(Error, match="device memory allocation failed"):
+        nd.zeros([1 << 21, 1 << 21], GPU)                                     # 2^42 floats = 16 TiB
+    with pytest.raises(Error, match="device memory allocation failed"):
+        nd.full([1 << 21, 1 << 21], 1.0, GPU)
+    x = nd.full([1000], 2.0, GPU)
+    assert nd.sum(x * x) == 4000.0                                            # still in business
+    assert lib.np_sync() == 0
