@@ -6,9 +6,12 @@
  * Differences a maintainer should know:
  *   - blocks come from np_malloc's caching pool: the result allocation every op makes
  *     (arithmetics.c:211-231) does not reach the driver in steady state;
- *   - the reference's `unsigned int size` caps a buffer at 4 GiB; these entry points keep the
- *     signature (they must, to stay drop-in) and widen to size_t immediately — callers that can
- *     pass more should call np_malloc / np_memcpy_* (size_t) directly;
+ *   - the reference's `unsigned int size` caps a buffer at 4 GiB — and its call sites pass
+ *     `numElements * sizeof(float)`, so a larger array is TRUNCATED, not refused.  Stand-alone
+ *     (libnp_hipmath.so) these entry points keep that signature, which is what objects compiled against
+ *     the reference's gpu_alloc.h call; in a `--with-hip` tree tools/apply_with_hip.py widens the three
+ *     prototypes of src/gpu_alloc.h to size_t and the build defines NP_GPU_ALLOC_WIDE, so the byte
+ *     counts arrive whole (one MI355X holds 288 GB);
  *   - nothing here synchronises the device except the two read-backs, which must.
  */
 #include <stdio.h>
@@ -16,17 +19,28 @@
 #include "np_ext_hooks.h"
 #include "np_hip.h"
 
+#include <stddef.h>
+
+#ifdef NP_GPU_ALLOC_WIDE
+/* a `--with-hip` tree: src/gpu_alloc.h as tools/apply_with_hip.py leaves it (byte counts as size_t) */
+typedef size_t np_alloc_bytes;
+void vmalloc(void **target, np_alloc_bytes size);
+void vmemcpyd2d(char *target, char *dst, np_alloc_bytes size);
+void vmemcpyh2d(char *target, char *dst, np_alloc_bytes size);
+#else
 /* prototypes = src/gpu_alloc.h:8-15 */
+typedef unsigned int np_alloc_bytes;
 void vmalloc(void **target, unsigned int size);
-void vfree(void *target);
-void vmemcheck(void);
 void vmemcpyd2d(char *target, char *dst, unsigned int size);
 void vmemcpyh2d(char *target, char *dst, unsigned int size);
+#endif
+void vfree(void *target);
+void vmemcheck(void);
 float NDArray_VFLOAT(char *target);
 float NDArray_VFLOATF_I(float *target, int index);
 
 /* gpu_alloc.c:11-17 */
-void vmalloc(void **target, unsigned int size) {
+void vmalloc(void **target, np_alloc_bytes size) {
     np_ext_count_device_alloc(+1);
     if (np_malloc(target, (size_t)size) != NP_OK) np_ext_throw("device memory allocation failed");
 }
@@ -44,11 +58,11 @@ void vmemcheck(void) {
 }
 
 /* gpu_alloc.c:20-27.  NOTE the reference's argument order: (source, destination, bytes). */
-void vmemcpyd2d(char *target, char *dst, unsigned int size) {
+void vmemcpyd2d(char *target, char *dst, np_alloc_bytes size) {
     if (np_memcpy_d2d(dst, target, (size_t)size) != NP_OK) np_ext_throw_last();
 }
 
-void vmemcpyh2d(char *target, char *dst, unsigned int size) {
+void vmemcpyh2d(char *target, char *dst, np_alloc_bytes size) {
     if (np_memcpy_h2d(dst, target, (size_t)size) != NP_OK) np_ext_throw_last();
 }
 

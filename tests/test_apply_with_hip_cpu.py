@@ -362,3 +362,31 @@ def test_hip_lazy_uses_only_what_the_reference_headers_declare():
     ours = (ROOT / "include" / "numpower_host.h").read_text()
     for name in used:
         assert re.search(r"#define\s+%s\b|\b%s\s*\(" % (name, name), ours), "%s missing from include/numpower_host.h" % name
+
+
+def test_byte_counts_are_size_t_in_the_emitted_tree(patched, tmp_path):
+    """The reference's vmalloc / vmemcpy* take `unsigned int size` (gpu_alloc.h:8,10-11) and every call site passes
+    `numElements * sizeof(float)`: a result of 4 GiB or more is truncated, not refused.  The emitted tree declares the three with
+    size_t, its m4 block hands NP_GPU_ALLOC_WIDE to the glue, and the glue compiles -Werror in both forms — with the emitted header in
+    front of it (so a mismatch between prototype and definition is a compile error) and stand-alone with the reference's types."""
+    tool, out, _ = patched
+    header = (out / "src" / "gpu_alloc.h").read_text()
+    assert "unsigned int size" not in header
+    assert header.count("size_t size") == 3 and "#include <stddef.h>" in header
+    assert "-DNP_GPU_ALLOC_WIDE=1" in (out / "config.m4").read_text()
+    glue = ROOT / "ext" / "gpu_alloc_hip.c"
+    inc = ["-I", str(ROOT / "include"), "-I", str(ROOT / "ext")]
+    wide = tmp_path / "wide.c"
+    wide.write_text('#include "%s"\n#include "%s"\n' % (out / "src" / "gpu_alloc.h", glue))
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-DNP_GPU_ALLOC_WIDE=1", *inc, "-c", str(wide), "-o", str(tmp_path / "w.o")],
+                ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", *inc, "-c", str(glue), "-o", str(tmp_path / "n.o")]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    # ... and the reference's own header in front of the stand-alone form: the signatures objects built against it expect
+    narrow = tmp_path / "narrow.c"
+    narrow.write_text('#include "%s"\n#include "%s"\n' % (REF / "src" / "gpu_alloc.h", glue))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", *inc, "-c", str(narrow), "-o", str(tmp_path / "r.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # the wrong pairing must NOT compile (the check above is not vacuous)
+    r = subprocess.run(["gcc", "-std=c99", "-Werror", *inc, "-c", str(wide), "-o", str(tmp_path / "x.o")], capture_output=True, text=True)
+    assert r.returncode != 0 and "conflicting types" in r.stderr

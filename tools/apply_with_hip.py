@@ -183,6 +183,17 @@ EDITS = [
          r"^(?P<old>[ \t]*cudaMemcpy\(output_data, NDArray_FDATA\(target_ptr\), sizeof\(float\) \* NDArray_NUMELEMENTS\(target\), cudaMemcpyDeviceToDevice\);\n"
          r"[ \t]*cudaDeviceSynchronize\(\);)$",
          "np_memcpy_d2d(output_data, NDArray_FDATA(target_ptr), sizeof(float) * NDArray_NUMELEMENTS(target));"),
+    # ---- gpu_alloc.h:8,10-11: byte counts as size_t.  Every call site passes `numElements * sizeof(float)` — a size_t
+    #      expression that the reference's `unsigned int size` truncates modulo 4 GiB (a 5 GiB array would get a 1 GiB buffer
+    #      and its kernels would write past it); one MI355X holds 288 GB.  The glue defines the three with size_t when
+    #      NP_GPU_ALLOC_WIDE is set (the m4 block below sets it), and with the reference's types otherwise ----
+    Edit("src/gpu_alloc.h", "gpu_alloc.h:8 vmalloc: size_t bytes",
+         r"^(?P<old>void vmalloc\(void \*\*target, unsigned int size\);)$",
+         "#include <stddef.h>\nvoid vmalloc(void **target, size_t size);"),
+    Edit("src/gpu_alloc.h", "gpu_alloc.h:10-11 vmemcpyd2d / vmemcpyh2d: size_t bytes",
+         r"^(?P<old>void vmemcpyd2d\(char\* target, char\* dst, unsigned int size\);\n"
+         r"void vmemcpyh2d\(char\* target, char\* dst, unsigned int size\);)$",
+         "void vmemcpyd2d(char* target, char* dst, size_t size);\nvoid vmemcpyh2d(char* target, char* dst, size_t size);"),
     # ---- the per-op cudaDeviceSynchronize() after the result allocation: arithmetics.c:218,497,633,758,883 ----
     Edit("src/ndmath/arithmetics.c", "arithmetics.c:218,497,633,758,883: sync after vmalloc (add, subtract, divide, mod, pow)",
          _SYNC, "/* nothing: the back end's stream orders the allocation with the kernels; read-backs block */", expect=5),
@@ -475,7 +486,7 @@ if test "$PHP_HIP" != "no"; then
     [-L$PHP_HIP])
   AC_DEFINE([HAVE_CUBLAS], [1], [a device back end is present (the C files gate every GPU branch on this name)])
   AC_DEFINE([HAVE_NP_HIP], [1], [the device back end is numpower_amd / MI355X])
-  CFLAGS+=" -DNUMPOWER_NDARRAY_HEADER='\\"src/initializers.h\\"' "
+  CFLAGS+=" -DNUMPOWER_NDARRAY_HEADER='\\"src/initializers.h\\"' -DNP_GPU_ALLOC_WIDE=1 "
   NP_GPU_ALLOC_SOURCES="src/hip/gpu_alloc_hip.c src/hip/hip_math.c src/hip/hip_math_drivers.c src/hip/hip_fast.c src/hip/hip_lazy.c src/hip/zend_hooks.c"
 fi'''
 
