@@ -29,7 +29,17 @@ static void raise_if(int rc) {
     if (rc != NP_OK) np_ext_throw_last();
 }
 
-static size_t count(int n) { return n > 0 ? (size_t)n : 0; }
+/* The reference's interface counts elements in an `int` (cuda_math.h:14-79), and its callers pass NDArray_NUMELEMENTS — a long:
+ * an array of 2^31 elements or more arrives here as a NEGATIVE count (or a small wrong one).  Negative is refused out loud instead
+ * of being treated as empty: `nd::sum()` of such an array must not come back as 0.  (The paths a `--with-hip` tree sends GPU
+ * arrays through by default — hip_fast.c, hip_math_drivers.c, hip_lazy.c — count in size_t and do not come here.) */
+static size_t count(int n) {
+    if (n < 0) {
+        np_ext_throw("element count does not fit the int of the reference's cuda_* interface (2^31 - 1 elements)");
+        return 0;
+    }
+    return (size_t)n;
+}
 
 /* ---- unary family --------------------------------------------------------------------------------
  * numpower.c:1651-3348 pass these as `op` to NDArrayMathGPU_ElementWise (table: numpower.c:5136-5174);

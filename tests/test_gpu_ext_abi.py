@@ -286,3 +286,22 @@ def test_driver_refuses_cpu_arrays_with_an_error(hip):
     c = NDArray.array(np.ones((3, 3), dtype=np.float32))          # on the CPU
     with pytest.raises(Error, match="operand is on the CPU"):
         NDArray._wrap(h.NDArrayMathGPU_ElementWise(c._p, _fn(h, "cuda_float_sin")))
+
+
+def test_a_count_past_int_max_is_refused_not_treated_as_empty(glue):
+    """The reference's cuda_* interface counts in `int` and its callers pass NDArray_NUMELEMENTS (a long): 2^31 elements and more
+    arrive as a negative count.  The glue raises instead of filling / summing nothing: nd::sum() of such an array must not be 0."""
+    x = glue.put(np.float32([1.0, 2.0, 3.0, 4.0]))
+    wrapped = C.c_int(-(1 << 31) + 4)                         # what (int)(2^31 + 4) is
+    glue.lib.cuda_fill_float(x, C.c_float(9.0), wrapped)
+    assert b"does not fit the int" in glue.lib.np_ext_last_error()
+    assert glue.get(x, (4,)).tolist() == [1.0, 2.0, 3.0, 4.0]           # untouched
+    glue.lib.np_ext_clear_error()
+    total = C.c_float(0.0)
+    glue.lib.cuda_sum_float(C.c_int(1), x, C.byref(total), wrapped)
+    assert b"does not fit the int" in glue.lib.np_ext_last_error()
+    glue.lib.np_ext_clear_error()
+    glue.lib.cuda_float_exp(wrapped, x)
+    assert b"does not fit the int" in glue.lib.np_ext_last_error()
+    glue.lib.np_ext_clear_error()
+    glue.free(x)
