@@ -227,7 +227,20 @@ int NPH_Flush(NDArray *a) {
 float NPH_ReduceAll(int reduce_op, NPH_EagerReduce eager, NDArray *a) {
     if (a == NULL || eager == NULL) return -1.0f;
     Chain *c = find_chain(a);
-    if (c == NULL) return eager(a);                        /* values are there (or a CPU array): the reference function */
+    if (c == NULL) {
+        /* values are there.  A GPU array goes straight to np_reduce_all with its size_t count: the reference's own function
+         * hands NDArray_NUMELEMENTS to the `int` of cuda_sum_float / cuda_prod_float / cuda_min_float / cuda_max_float
+         * (arithmetics.c:41,63,86, ndarray.c:759,946) — same kernel, same value, no 2^31 limit.  CPU arrays: the reference. */
+        if (NDArray_NDIM(a) != 0 && NDArray_DEVICE(a) == NDARRAY_DEVICE_GPU && reduce_op >= 0 && reduce_op < NP_REDUCE_OP_COUNT) {
+            float r = 0.0f;
+            if (np_reduce_all(reduce_op == NP_MEAN ? NP_SUM : reduce_op, NDArray_FDATA(a), (size_t) NDArray_NUMELEMENTS(a), &r) != NP_OK) {
+                np_ext_throw_last();
+                return -1.0f;
+            }
+            return reduce_op == NP_MEAN ? r / NDArray_NUMELEMENTS(a) : r;   /* (arithmetics.c:87: float / long) */
+        }
+        return eager(a);
+    }
     if (!g_lazy_on || reduce_op < 0 || reduce_op >= NP_REDUCE_OP_COUNT) {
         if (NPH_Flush(a) != 0) return -1.0f;
         return eager(a);
