@@ -194,6 +194,46 @@ EDITS = [
          r"^(?P<old>void vmemcpyd2d\(char\* target, char\* dst, unsigned int size\);\n"
          r"void vmemcpyh2d\(char\* target, char\* dst, unsigned int size\);)$",
          "void vmemcpyd2d(char* target, char* dst, size_t size);\nvoid vmemcpyh2d(char* target, char* dst, size_t size);"),
+    # ---- element counts: the reference hands NDArray_NUMELEMENTS (a long) to the `int` of cuda_fill_float / cuda_equal_float /
+    #      cuda_min|max_float / cuda_prod|sum_float (cuda_math.h:56-66): an array of 2^31 elements or more arrives as a negative
+    #      count.  The seven call sites of the hot path call the C ABI with their size_t count instead (same kernels, same values) ----
+    Edit("src/initializers.c", "initializers.c:639 NDArray_Fill: size_t count",
+         r"^(?P<old>[ \t]*cuda_fill_float\(NDArray_FDATA\(a\), fill_value, NDArray_NUMELEMENTS\(a\)\);)$",
+         "if (np_fill(NDArray_FDATA(a), fill_value, (size_t) NDArray_NUMELEMENTS(a)) != NP_OK) {\n"
+         "    zend_throw_error(NULL, \"%s\", np_last_error());\n"
+         "}"),
+    Edit("src/logic.c", "logic.c:683 compare_ndarrays: size_t count",
+         r"^(?P<old>[ \t]*diff = cuda_equal_float\(NDArray_NUMELEMENTS\(a\), NDArray_FDATA\(a\), NDArray_FDATA\(b\), NDArray_NUMELEMENTS\(a\)\);)$",
+         "int any_mismatch = 1;\n"
+         "if (np_count_mismatch(NP_MISMATCH_EXACT, NDArray_FDATA(a), NDArray_FDATA(b), (size_t) NDArray_NUMELEMENTS(a), 0.0f, 0.0f,\n"
+         "                      &any_mismatch) != NP_OK) {\n"
+         "    zend_throw_error(NULL, \"%s\", np_last_error());\n"
+         "}\n"
+         "diff = any_mismatch ? 0 : 1;"),
+    Edit("src/ndarray.c", "ndarray.c:759 NDArray_Min: size_t count",
+         r"^(?P<old>[ \t]*return cuda_min_float\(array, NDArray_NUMELEMENTS\(target\)\);)$",
+         "min = 0.0f;\n"
+         "if (np_reduce_all(NP_MIN, array, (size_t) NDArray_NUMELEMENTS(target), &min) != NP_OK) {\n"
+         "    zend_throw_error(NULL, \"%s\", np_last_error());\n"
+         "}\n"
+         "return min;"),
+    Edit("src/ndarray.c", "ndarray.c:946 NDArray_Max: size_t count",
+         r"^(?P<old>[ \t]*return cuda_max_float\(array, NDArray_NUMELEMENTS\(target\)\);)$",
+         "max = 0.0f;\n"
+         "if (np_reduce_all(NP_MAX, array, (size_t) NDArray_NUMELEMENTS(target), &max) != NP_OK) {\n"
+         "    zend_throw_error(NULL, \"%s\", np_last_error());\n"
+         "}\n"
+         "return max;"),
+    Edit("src/ndmath/arithmetics.c", "arithmetics.c:41 NDArray_Float_Prod: size_t count",
+         r"^(?P<old>[ \t]*cuda_prod_float\(NDArray_NUMELEMENTS\(a\), NDArray_FDATA\(a\), &value, NDArray_NUMELEMENTS\(a\)\);)$",
+         "if (np_reduce_all(NP_PROD, NDArray_FDATA(a), (size_t) NDArray_NUMELEMENTS(a), &value) != NP_OK) {\n"
+         "    zend_throw_error(NULL, \"%s\", np_last_error());\n"
+         "}"),
+    Edit("src/ndmath/arithmetics.c", "arithmetics.c:63,86 NDArray_Sum_Float / NDArray_Mean_Float: size_t count",
+         r"^(?P<old>[ \t]*cuda_sum_float\(NDArray_NUMELEMENTS\(a\), NDArray_FDATA\(a\), &value, NDArray_NUMELEMENTS\(a\)\);)$",
+         "if (np_reduce_all(NP_SUM, NDArray_FDATA(a), (size_t) NDArray_NUMELEMENTS(a), &value) != NP_OK) {\n"
+         "    zend_throw_error(NULL, \"%s\", np_last_error());\n"
+         "}", expect=2),
     # ---- the per-op cudaDeviceSynchronize() after the result allocation: arithmetics.c:218,497,633,758,883 ----
     Edit("src/ndmath/arithmetics.c", "arithmetics.c:218,497,633,758,883: sync after vmalloc (add, subtract, divide, mod, pow)",
          _SYNC, "/* nothing: the back end's stream orders the allocation with the kernels; read-backs block */", expect=5),
@@ -425,6 +465,12 @@ CONTEXTS = {
     "initializers.c:758 NDArray_Copy: D2D copy": "NDArray *rtn = 0, *a = 0;",
     "linalg.c:145-146 NDArray_SVD: D2D copy + sync": "float *output_data = 0; NDArray *target_ptr = 0, *target = 0;",
     "linalg.c:55-71 NDArray_FMatmul: cuBLAS -> np_sgemm": "NDArray *a = 0, *b = 0, *result = 0;",
+    "initializers.c:639 NDArray_Fill: size_t count": "NDArray *a = 0; float fill_value = 0;",
+    "logic.c:683 compare_ndarrays: size_t count": "NDArray *a = 0, *b = 0; int diff = 1;",
+    "ndarray.c:759 NDArray_Min: size_t count": "NDArray *target = 0; float *array = 0; float min;",
+    "ndarray.c:946 NDArray_Max: size_t count": "NDArray *target = 0; float *array = 0; float max;",
+    "arithmetics.c:41 NDArray_Float_Prod: size_t count": "NDArray *a = 0; float value = 1;",
+    "arithmetics.c:63,86 NDArray_Sum_Float / NDArray_Mean_Float: size_t count": "NDArray *a = 0; float value = 0;",
     "numpower.c:623-633 NDArray::setDevice": "int numDevices = 0; long deviceId = 0;",
     "debug.c:220-254 NDArray_DumpDevices": " ",
     "numpower.c:1791 PHP_METHOD(rsqrt): the right device function": "NDArray *rtn = 0, *nda = 0;",
@@ -522,7 +568,8 @@ def snippet_check_source() -> str:
     for k, e in enumerate(EDITS):
         if not e.context:
             continue
-        ret = "void *" if ("return NULL;" in e.new or "return NPH_" in e.new) else "void "
+        ret = ("void *" if ("return NULL;" in e.new or "return NPH_" in e.new) else
+               "float " if ("return min;" in e.new or "return max;" in e.new) else "void ")   # NDArray_Min / NDArray_Max return a float
         out.append("/* %s */" % e.what)
         out.append("%ssnippet_%d(void) {" % (ret, k))
         out.append("    " + e.context)
