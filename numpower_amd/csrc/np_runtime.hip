@@ -69,6 +69,9 @@ Runtime &rt() {
     return r;
 }
 
+constexpr size_t kAskDriverFrom = size_t(64) << 20;     // np_malloc: requests from 64 MiB on look at the device's free memory first
+constexpr size_t kDriverHeadroom = size_t(256) << 20;   // ... and want this much left next to them
+
 size_t round_size(size_t bytes) {
     if (bytes == 0) bytes = 1;
     if (bytes < (size_t(1) << 20)) {
@@ -621,6 +624,21 @@ int np_malloc(void **dev_ptr, size_t bytes) {
         it->second.pop_back();
     } else {
         const size_t pad = sz >= kStaggerFrom ? kStaggerStep * kStaggerSlots : 0;
+        // The driver of this pool does not refuse a request that no longer fits the device: it backs it with host memory (seen in round 6:
+        // 308 GB on the 288 GB device succeeds).  A cache that goes back only when hipMalloc FAILS would therefore trade a full device for
+        // a slow one — a long-lived process that frees buffers of many sizes would grow into host memory.  So for large requests the driver
+        // is asked first, and when the blocks cached here are what stands between the request and the device's free memory, they go back.
+        if (sz >= kAskDriverFrom) {
+            bool cached = false;
+            for (const DeviceState &o : r.dev)
+                for (const auto &kv : o.free_blocks) cached = cached || !kv.second.empty();
+            size_t free_b = 0, total_b = 0;
+            if (cached && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < sz + pad + kDriverHeadroom) {
+                for (DeviceState &o : r.dev)
+                    if (o.inited) NP_HIP_CHECK(hipStreamSynchronize(o.cur_stream));
+                trim_locked(r);
+            }
+        }
         hipError_t e = hipMalloc(&p, sz + pad);
         if (e != hipSuccess) {
             (void)hipGetLastError();

@@ -223,3 +223,38 @@ def test_allocation_failure_is_an_error(hip):
     x = nd.full([1000], 2.0, GPU)
     assert nd.sum(x * x) == 4000.0                                            # still in business
     assert lib.np_sync() == 0
+
+
+def test_the_cache_goes_back_before_a_request_that_does_not_fit_next_to_it(hip):
+    """The caching pool keeps freed blocks for reuse, and the driver of this pool does not refuse a request that no longer fits the device
+    — it backs it with host memory.  A cache that is given back only when hipMalloc fails would let a long-lived process grow into host
+    memory: np_malloc asks the driver for the device's free memory before a large cache miss and gives its cached blocks back first when
+    they are in the way.  Nothing large is touched here (two 4 MB fills), and with the rule in place the process never holds more than
+    160 GB at once."""
+    import ctypes as C
+    from numpower_amd import _lib
+    lib = _lib.load()
+    GB = 1 << 30
+    trimmed = C.c_size_t()
+    _lib.check(lib.np_pool_trim(C.byref(trimmed)))
+    base = lib.np_pool_reserved_bytes()
+    a = _lib.DeviceBuffer(160 * GB)
+    a.free()                                                                  # cached: still reserved at the driver
+    assert lib.np_pool_reserved_bytes() >= base + 160 * GB
+    b = _lib.DeviceBuffer(150 * GB)                                           # 160 + 150 > 288: the cache must go back FIRST
+    assert lib.np_pool_reserved_bytes() < base + 155 * GB, "the request was placed next to the cache (on this pool: in host memory)"
+    n = 1 << 20
+    _lib.check(lib.np_fill(b.ptr, 7.0, n))
+    _lib.check(lib.np_fill(b.ptr + 150 * GB - 4 * n, 9.0, n))                 # both ends are there
+    v = C.c_float()
+    _lib.check(lib.np_read_float(b.ptr, n - 1, C.byref(v)))
+    assert v.value == 7.0
+    _lib.check(lib.np_read_float(b.ptr + 150 * GB - 4 * n, n - 1, C.byref(v)))
+    assert v.value == 9.0
+    # a request that DOES fit next to the cache leaves the cache alone
+    b.free()
+    c = _lib.DeviceBuffer(40 * GB)
+    assert lib.np_pool_reserved_bytes() >= base + 190 * GB                    # 150 cached + 40 live
+    c.free()
+    _lib.check(lib.np_pool_trim(C.byref(trimmed)))
+    assert trimmed.value >= 190 * GB and lib.np_pool_reserved_bytes() == base
